@@ -1,0 +1,628 @@
+/*
+ * ORACLE -- test infrastructure only.  Never linked into, imported by or executed
+ * from the product path (deseq2_amd/ and its libdeseq2_mi355x.so); only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Plain-C restatement of the three native entry points of thelovelab/DESeq2
+ * (/root/reference/src/DESeq2.cpp):
+ *     fitDisp      DESeq2.cpp:164-277   (+ log_posterior :31-64, dlog_posterior
+ *                                          :68-107, d2log_posterior :111-158)
+ *     fitBeta      DESeq2.cpp:283-465
+ *     fitDispGrid  DESeq2.cpp:469-513
+ * Same control flow, same counters, same break conditions, same clamps.  Each block
+ * cites the reference lines it follows.
+ *
+ * PARITY STATUS: the reference itself cannot be compiled here (needs R, Rcpp,
+ * RcppArmadillo -- none present), so bit parity of iteration counts against a real
+ * R build is UNPINNED.  What pins this oracle: the reference's own known-answer
+ * tests (tests/testthat/test_results.R:9,43-50; test_optim.R:30-39), the
+ * cross-implementation properties its tests assert (test_betaFitting.R,
+ * test_dispersions.R, test_QR.R, test_weights.R) re-run with scipy/mpmath, and the
+ * mpmath accuracy tests of every scalar primitive (tests/test_oracle_*.py).
+ *
+ * ARITHMETIC SPEC (what "the same result" means for the GPU):
+ *   - all arithmetic IEEE binary64, no FMA contraction, fma() only where written;
+ *   - scalar transcendental functions from orc_nmath.c;
+ *   - every sum over the m samples of a gene is taken in WAVE ORDER: 64 partial
+ *     sums, partial l accumulating samples l, l+64, l+128, ... in that order from
+ *     0.0, then a butterfly v[l] += v[l^off] for off = 1,2,4,8,16,32.  The
+ *     reference's own summation order is unspecified (Rcpp sugar / BLAS dgemm /
+ *     LAPACK, all implementation-dependent), so fixing one is within its contract.
+ *     sum_mode = 1 switches to plain serial sums, used only to measure how many
+ *     iteration counts move between two equally valid orders;
+ *   - p x p work: LU with partial pivoting (first maximum wins), reciprocal
+ *     pivots, as LAPACK dgetf2; QR by unblocked Householder reflections as LAPACK
+ *     dgeqr2/dlarfg (what qr_econ reaches for p < 32).
+ */
+#include "orc_nmath.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_PMAX 64
+
+/* ------------------------------------------------------------ wave sums ---- */
+typedef struct { double part[64]; int serial; double sacc; } wsum_t;
+
+static inline void wsum_init(wsum_t *s, int serial) {
+    for (int l = 0; l < 64; l++) s->part[l] = 0.0;
+    s->serial = serial; s->sacc = 0.0;
+}
+static inline void wsum_add(wsum_t *s, long j, double t) {
+    if (s->serial) s->sacc += t; else s->part[j & 63] += t;
+}
+static inline double wsum_total(const wsum_t *s) {
+    if (s->serial) return s->sacc;
+    double v[64], w[64];
+    memcpy(v, s->part, sizeof v);
+    for (int off = 1; off < 64; off <<= 1) {
+        for (int l = 0; l < 64; l++) w[l] = v[l] + v[l ^ off];
+        memcpy(v, w, sizeof v);
+    }
+    return v[0];
+}
+
+/* ---------------------------------------------------------- small p x p ---- */
+/* LU with partial pivoting, in place, row-major a[q*q]; rdiag[i] = 1/U_ii.
+ * Returns the permutation sign (+1/-1).  (arma::det/inv/solve -> LAPACK dgetrf;
+ * DESeq2.cpp:46,85,86,130,133-135,398,439,452)                                 */
+static int lu_decomp(int q, double *a, int *piv, double *rdiag) {
+    int sign = 1;
+    for (int k = 0; k < q; k++) {
+        int pr = k; double best = fabs(a[k * q + k]);
+        for (int i = k + 1; i < q; i++) {
+            double v = fabs(a[i * q + k]);
+            if (v > best) { best = v; pr = i; }
+        }
+        piv[k] = pr;
+        if (pr != k) {
+            for (int j = 0; j < q; j++) { double t = a[k * q + j]; a[k * q + j] = a[pr * q + j]; a[pr * q + j] = t; }
+            sign = -sign;
+        }
+        double rinv = 1.0 / a[k * q + k];
+        rdiag[k] = rinv;
+        for (int i = k + 1; i < q; i++) {
+            double l = a[i * q + k] * rinv;
+            a[i * q + k] = l;
+            for (int j = k + 1; j < q; j++) a[i * q + j] = fma(-l, a[k * q + j], a[i * q + j]);
+        }
+    }
+    return sign;
+}
+static double lu_det(int q, const double *lu, int sign) {
+    double d = lu[0];
+    for (int i = 1; i < q; i++) d = d * lu[i * q + i];
+    return sign < 0 ? -d : d;
+}
+/* solve LU x = P b in place (b -> x) */
+static void lu_solve(int q, const double *lu, const int *piv, const double *rdiag, double *b) {
+    for (int k = 0; k < q; k++) { int pr = piv[k]; if (pr != k) { double t = b[k]; b[k] = b[pr]; b[pr] = t; } }
+    for (int i = 0; i < q; i++) {
+        double t = b[i];
+        for (int j = 0; j < i; j++) t = fma(-lu[i * q + j], b[j], t);
+        b[i] = t;
+    }
+    for (int i = q - 1; i >= 0; i--) {
+        double t = b[i];
+        for (int j = i + 1; j < q; j++) t = fma(-lu[i * q + j], b[j], t);
+        b[i] = t * rdiag[i];
+    }
+}
+/* inverse of a (row-major q x q) into inv; returns det through *det if non-NULL */
+static void mat_inverse(int q, const double *a, double *inv, double *det) {
+    double lu[ORC_PMAX * ORC_PMAX]; int piv[ORC_PMAX]; double rdiag[ORC_PMAX], col[ORC_PMAX];
+    memcpy(lu, a, sizeof(double) * q * q);
+    int sign = lu_decomp(q, lu, piv, rdiag);
+    if (det) *det = lu_det(q, lu, sign);
+    for (int c = 0; c < q; c++) {
+        for (int i = 0; i < q; i++) col[i] = (i == c) ? 1.0 : 0.0;
+        lu_solve(q, lu, piv, rdiag, col);
+        for (int i = 0; i < q; i++) inv[i * q + c] = col[i];
+    }
+}
+static double mat_det(int q, const double *a) {
+    double lu[ORC_PMAX * ORC_PMAX]; int piv[ORC_PMAX]; double rdiag[ORC_PMAX];
+    memcpy(lu, a, sizeof(double) * q * q);
+    int sign = lu_decomp(q, lu, piv, rdiag);
+    return lu_det(q, lu, sign);
+}
+static void mat_mul(int q, const double *a, const double *b, double *c) {
+    for (int i = 0; i < q; i++)
+        for (int j = 0; j < q; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < q; k++) acc = fma(a[i * q + k], b[k * q + j], acc);
+            c[i * q + j] = acc;
+        }
+}
+/* trace(a*b) without forming the product */
+static double trace_prod(int q, const double *a, const double *b) {
+    double acc = 0.0;
+    for (int i = 0; i < q; i++)
+        for (int k = 0; k < q; k++) acc = fma(a[i * q + k], b[k * q + i], acc);
+    return acc;
+}
+
+/* ------------------------------------------------ one gene's row context ---- */
+typedef struct {
+    int m, p;
+    const double *y;      /* m */
+    const double *mu;     /* m */
+    const double *w;      /* m observation weights (ignored unless useWeights) */
+    const double *x;      /* m x p column-major (R layout) */
+    double prior_mean, prior_sigmasq;
+    int usePrior, useWeights, useCR;
+    double weightThreshold;
+    int serial;
+    /* derived once per gene: CR row/column subsets (DESeq2.cpp:41-43) */
+    int q;                /* number of kept columns */
+    int keepcol[ORC_PMAX];
+    const unsigned char *keeprow; /* m, or NULL = all */
+} gene_t;
+
+static void gene_setup_cr(gene_t *g, unsigned char *rowbuf) {
+    g->keeprow = NULL;
+    g->q = g->p;
+    for (int c = 0; c < g->p; c++) g->keepcol[c] = c;
+    if (g->useCR && g->useWeights) {
+        /* x = x.rows(find(wts > weightThreshold)); x = x.cols(find(sum(abs(x)) > 0.0)); */
+        for (int j = 0; j < g->m; j++) rowbuf[j] = (g->w[j] > g->weightThreshold);
+        g->keeprow = rowbuf;
+        int q = 0;
+        for (int c = 0; c < g->p; c++) {
+            /* sum(abs(x)) > 0 over kept rows: any non-zero entry (exact, order-free) */
+            int any = 0;
+            for (int j = 0; j < g->m; j++)
+                if (rowbuf[j] && fabs(g->x[j + (long)g->m * c]) > 0.0) { any = 1; break; }
+            if (any) g->keepcol[q++] = c;
+        }
+        g->q = q;
+    }
+}
+
+/* B = X' diag(wd) X over kept rows / kept columns, wave order by sample index.
+ * term = x_ja * (x_jb * wd_j)   (b = x.t() * (x.each_col() % w_diag), :45,83,129) */
+static void cr_gram(const gene_t *g, const double *wd, double *B) {
+    int q = g->q, m = g->m;
+    for (int a = 0; a < q; a++)
+        for (int b = a; b < q; b++) {
+            const double *xa = g->x + (long)m * g->keepcol[a];
+            const double *xb = g->x + (long)m * g->keepcol[b];
+            wsum_t s; wsum_init(&s, g->serial);
+            for (int j = 0; j < m; j++) {
+                if (g->keeprow && !g->keeprow[j]) continue;
+                wsum_add(&s, j, xa[j] * (xb[j] * wd[j]));
+            }
+            double v = wsum_total(&s);
+            B[a * q + b] = v; B[b * q + a] = v;
+        }
+}
+
+/* DESeq2.cpp:31-64 */
+static double log_posterior(double log_alpha, const gene_t *g, double *scratch) {
+    double prior_part, cr_term;
+    double alpha = orc_exp(log_alpha);
+    int m = g->m;
+    if (g->useCR) {
+        double *wd = scratch;
+        for (int j = 0; j < m; j++) wd[j] = 1.0 / (1.0 / g->mu[j] + alpha);      /* :36 */
+        double B[ORC_PMAX * ORC_PMAX];
+        cr_gram(g, wd, B);                                                       /* :45 */
+        cr_term = -0.5 * orc_log(mat_det(g->q, B));                              /* :46 */
+    } else cr_term = 0.0;
+    double alpha_neg1 = 1.0 / alpha;                                             /* :50 R_pow_di(alpha,-1) */
+    double lg_an1 = orc_lgamma(alpha_neg1);
+    wsum_t s; wsum_init(&s, g->serial);
+    for (int j = 0; j < m; j++) {                                                /* :53,55 */
+        double y = g->y[j], mu = g->mu[j];
+        double t = orc_lgamma(y + alpha_neg1) - lg_an1 - y * orc_log(mu + alpha_neg1)
+                   - alpha_neg1 * orc_log(1.0 + mu * alpha);
+        if (g->useWeights) t = g->w[j] * t;
+        wsum_add(&s, j, t);
+    }
+    double ll_part = wsum_total(&s);
+    if (g->usePrior) {
+        double d = log_alpha - g->prior_mean;
+        prior_part = -0.5 * (d * d) / g->prior_sigmasq;                          /* :58 */
+    } else prior_part = 0.0;
+    return ll_part + prior_part + cr_term;                                       /* :62 */
+}
+
+/* DESeq2.cpp:68-107 */
+static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch) {
+    double prior_part, cr_term;
+    double alpha = orc_exp(log_alpha);
+    int m = g->m;
+    if (g->useCR) {
+        double *wd = scratch, *dwd = scratch + m;
+        for (int j = 0; j < m; j++) {
+            double t = 1.0 / g->mu[j] + alpha;
+            wd[j] = 1.0 / t;                                                     /* :73 */
+            dwd[j] = -1.0 * (1.0 / (t * t));                                     /* :74 */
+        }
+        int q = g->q;
+        double B[ORC_PMAX * ORC_PMAX], dB[ORC_PMAX * ORC_PMAX], Bi[ORC_PMAX * ORC_PMAX], detb;
+        cr_gram(g, wd, B); cr_gram(g, dwd, dB);                                  /* :83,84 */
+        mat_inverse(q, B, Bi, &detb);
+        double ddetb = detb * trace_prod(q, Bi, dB);                             /* :85 */
+        cr_term = -0.5 * ddetb / detb;                                           /* :86 */
+    } else cr_term = 0.0;
+    double alpha_neg1 = 1.0 / alpha;
+    double alpha_neg2 = 1.0 / (alpha * alpha);                                   /* :91 R_pow_di(alpha,-2) */
+    double dg_an1 = orc_digamma(alpha_neg1);
+    wsum_t s; wsum_init(&s, g->serial);
+    for (int j = 0; j < m; j++) {                                                /* :94,96 */
+        double y = g->y[j], mu = g->mu[j];
+        double ma = mu * alpha;
+        double t = dg_an1 + orc_log(1.0 + ma) - ma * (1.0 / (1.0 + ma))
+                   - orc_digamma(y + alpha_neg1) + y * (1.0 / (mu + alpha_neg1));
+        if (g->useWeights) t = g->w[j] * t;
+        wsum_add(&s, j, t);
+    }
+    double ll_part = alpha_neg2 * wsum_total(&s);
+    if (g->usePrior) prior_part = -1.0 * (log_alpha - g->prior_mean) / g->prior_sigmasq; /* :100 */
+    else prior_part = 0.0;
+    return (ll_part + cr_term) * alpha + prior_part;                             /* :105 */
+}
+
+/* DESeq2.cpp:111-158 */
+static double d2log_posterior(double log_alpha, const gene_t *g, double *scratch) {
+    double prior_part, cr_term;
+    double alpha = orc_exp(log_alpha);
+    int m = g->m;
+    if (g->useCR) {
+        double *wd = scratch, *dwd = scratch + m, *d2wd = scratch + 2 * (long)m;
+        for (int j = 0; j < m; j++) {
+            double t = 1.0 / g->mu[j] + alpha;
+            wd[j] = 1.0 / t;                                                     /* :117 */
+            dwd[j] = -1.0 * (1.0 / (t * t));                                     /* :118 */
+            d2wd[j] = 2.0 * (1.0 / (t * t * t));                                 /* :119 */
+        }
+        int q = g->q;
+        double B[ORC_PMAX * ORC_PMAX], dB[ORC_PMAX * ORC_PMAX], d2B[ORC_PMAX * ORC_PMAX];
+        double Bi[ORC_PMAX * ORC_PMAX], M[ORC_PMAX * ORC_PMAX], detb;
+        cr_gram(g, wd, B); cr_gram(g, dwd, dB); cr_gram(g, d2wd, d2B);           /* :129-132 */
+        mat_inverse(q, B, Bi, &detb);
+        double tr1 = trace_prod(q, Bi, dB);
+        double ddetb = detb * tr1;                                               /* :133 */
+        mat_mul(q, Bi, dB, M);
+        double tr2 = trace_prod(q, M, M);                  /* trace(b_i*db*b_i*db) */
+        double tr3 = trace_prod(q, Bi, d2B);
+        double d2detb = detb * (tr1 * tr1 - tr2 + tr3);                          /* :134 */
+        double rr = ddetb / detb;
+        cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;                         /* :135 */
+    } else cr_term = 0.0;
+    double alpha_neg1 = 1.0 / alpha;
+    double alpha_neg2 = 1.0 / (alpha * alpha);
+    double alpha_neg3 = 1.0 / (alpha * (alpha * alpha));   /* R_pow_di(alpha,-3): xn=x; x=x*x; xn*=x */
+    double dg_an1 = orc_digamma(alpha_neg1), tg_an1 = orc_trigamma(alpha_neg1);
+    wsum_t s1, s2; wsum_init(&s1, g->serial); wsum_init(&s2, g->serial);
+    for (int j = 0; j < m; j++) {                                                /* :143,145 */
+        double y = g->y[j], mu = g->mu[j];
+        double ma = mu * alpha, opm = 1.0 + ma, mpa = mu + alpha_neg1;
+        double t1 = dg_an1 + orc_log(opm) - ma * (1.0 / opm)
+                    - orc_digamma(y + alpha_neg1) + y * (1.0 / mpa);
+        double t2 = -1.0 * alpha_neg2 * tg_an1 + (mu * mu) * alpha * (1.0 / (opm * opm))
+                    + alpha_neg2 * orc_trigamma(y + alpha_neg1)
+                    + alpha_neg2 * y * (1.0 / (mpa * mpa));
+        if (g->useWeights) { t1 = g->w[j] * t1; t2 = g->w[j] * t2; }
+        wsum_add(&s1, j, t1); wsum_add(&s2, j, t2);
+    }
+    double ll_part = -2.0 * alpha_neg3 * wsum_total(&s1) + alpha_neg2 * wsum_total(&s2);
+    if (g->usePrior) prior_part = -1.0 / g->prior_sigmasq;                       /* :149 */
+    else prior_part = 0.0;
+    /* :156 -- the inner dlog_posterior call has usePrior = false and the full x */
+    gene_t g0 = *g; g0.usePrior = 0;
+    double dlp0 = dlog_posterior(log_alpha, &g0, scratch);
+    return ((ll_part + cr_term) * (alpha * alpha) + dlp0) + prior_part;
+}
+
+/* ================================================================ fitDisp ==
+ * DESeq2.cpp:164-277.  All matrices in R layout (column-major, gene fastest).  */
+int orc_fit_disp(int n, int m, int p,
+                 const double *y, const double *x, const double *mu_hat,
+                 const double *log_alpha_in, const double *log_alpha_prior_mean,
+                 double log_alpha_prior_sigmasq, double min_log_alpha, double kappa_0,
+                 double tol, int maxit, int usePrior,
+                 const double *weights, int useWeights, double weightThreshold, int useCR,
+                 double *log_alpha_out, int *iter, int *iter_accept, double *last_change,
+                 double *initial_lp, double *initial_dlp, double *last_lp,
+                 double *last_dlp, double *last_d2lp, int sum_mode) {
+    if (p > ORC_PMAX) return -1;
+    const double epsilon = 1.0e-4;                                               /* :175 */
+#pragma omp parallel
+    {
+    double *yrow = malloc(sizeof(double) * m), *murow = malloc(sizeof(double) * m);
+    double *wrow = malloc(sizeof(double) * m), *scratch = malloc(sizeof(double) * 3 * (size_t)m);
+    unsigned char *rowbuf = malloc(m);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {                                                /* :194 */
+        for (int j = 0; j < m; j++) {
+            yrow[j] = y[i + (long)n * j]; murow[j] = mu_hat[i + (long)n * j];
+            wrow[j] = weights ? weights[i + (long)n * j] : 1.0;
+        }
+        gene_t g; memset(&g, 0, sizeof g);
+        g.m = m; g.p = p; g.y = yrow; g.mu = murow; g.w = wrow; g.x = x;
+        g.prior_mean = log_alpha_prior_mean[i]; g.prior_sigmasq = log_alpha_prior_sigmasq;
+        g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
+        g.weightThreshold = weightThreshold; g.serial = sum_mode;
+        gene_setup_cr(&g, rowbuf);
+        double a = log_alpha_in[i];                                              /* :201 */
+        double lp = log_posterior(a, &g, scratch);                               /* :205 */
+        double dlp = dlog_posterior(a, &g, scratch);                             /* :206 */
+        double kappa = kappa_0, lpnew, change = -1.0;                            /* :207-211 */
+        initial_lp[i] = lp; initial_dlp[i] = dlp;
+        int it = 0, it_acc = 0;
+        for (int t = 0; t < maxit; t++) {                                        /* :212 */
+            it++;                                                                /* :214 */
+            double a_propose = a + kappa * dlp;                                  /* :215 */
+            if (a_propose < -30.0) kappa = (-30.0 - a) / dlp;                    /* :218-220 */
+            if (a_propose > 10.0) kappa = (10.0 - a) / dlp;                      /* :222-224 */
+            double theta_kappa = -1.0 * log_posterior(a + kappa * dlp, &g, scratch);   /* :225 */
+            double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);  /* :226 */
+            if (theta_kappa <= theta_hat_kappa) {                                /* :229 */
+                it_acc++;                                                        /* :231 */
+                a = a + kappa * dlp;                                             /* :232 */
+                lpnew = log_posterior(a, &g, scratch);                           /* :233 */
+                change = lpnew - lp;                                             /* :235 */
+                if (change < tol) { lp = lpnew; break; }                         /* :236-239 */
+                if (a < min_log_alpha) break;                                    /* :242-244 */
+                lp = lpnew;                                                      /* :245 */
+                dlp = dlog_posterior(a, &g, scratch);                            /* :246 */
+                kappa = fmin(kappa * 1.1, kappa_0);                              /* :249 */
+                if (it_acc % 5 == 0) kappa = kappa / 2.0;                        /* :253-255 */
+            } else {
+                kappa = kappa / 2.0;                                             /* :257 */
+            }
+        }
+        last_lp[i] = lp; last_dlp[i] = dlp;                                      /* :260-261 */
+        last_d2lp[i] = d2log_posterior(a, &g, scratch);                          /* :262 */
+        log_alpha_out[i] = a;                                                    /* :263 */
+        last_change[i] = change;                                                 /* :265 */
+        iter[i] = it; iter_accept[i] = it_acc;
+    }
+    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf);
+    }
+    return 0;
+}
+
+/* ============================================================ fitDispGrid ==
+ * DESeq2.cpp:469-513 */
+int orc_fit_disp_grid(int n, int m, int p,
+                      const double *y, const double *x, const double *mu_hat,
+                      const double *disp_grid, int ngrid,
+                      const double *log_alpha_prior_mean, double log_alpha_prior_sigmasq,
+                      int usePrior, const double *weights, int useWeights,
+                      double weightThreshold, int useCR, double *log_alpha_out, int sum_mode) {
+    if (p > ORC_PMAX || ngrid < 2 || ngrid > 1024) return -1;
+    double delta = disp_grid[1] - disp_grid[0];                                  /* :480 */
+#pragma omp parallel
+    {
+    double *yrow = malloc(sizeof(double) * m), *murow = malloc(sizeof(double) * m);
+    double *wrow = malloc(sizeof(double) * m), *scratch = malloc(sizeof(double) * 3 * (size_t)m);
+    unsigned char *rowbuf = malloc(m);
+    double *lpv = malloc(sizeof(double) * ngrid), *fine = malloc(sizeof(double) * ngrid);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {                                                /* :492 */
+        for (int j = 0; j < m; j++) {
+            yrow[j] = y[i + (long)n * j]; murow[j] = mu_hat[i + (long)n * j];
+            wrow[j] = weights ? weights[i + (long)n * j] : 1.0;
+        }
+        gene_t g; memset(&g, 0, sizeof g);
+        g.m = m; g.p = p; g.y = yrow; g.mu = murow; g.w = wrow; g.x = x;
+        g.prior_mean = log_alpha_prior_mean[i]; g.prior_sigmasq = log_alpha_prior_sigmasq;
+        g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
+        g.weightThreshold = weightThreshold; g.serial = sum_mode;
+        gene_setup_cr(&g, rowbuf);
+        for (int t = 0; t < ngrid; t++) lpv[t] = log_posterior(disp_grid[t], &g, scratch);  /* :496-500 */
+        int idx = 0; double best = lpv[0];                                       /* :501 .max(idxmax) */
+        for (int t = 1; t < ngrid; t++) if (lpv[t] > best) { best = lpv[t]; idx = t; }
+        double a_hat = disp_grid[idx];                                           /* :502 */
+        /* arma::linspace(a_hat - delta, a_hat + delta, ngrid)                      :503 */
+        double start = a_hat - delta, end = a_hat + delta;
+        double step = (end >= start) ? (end - start) / (double)(ngrid - 1)
+                                     : -(start - end) / (double)(ngrid - 1);
+        for (int t = 0; t < ngrid - 1; t++) fine[t] = start + (double)t * step;
+        fine[ngrid - 1] = end;
+        for (int t = 0; t < ngrid; t++) lpv[t] = log_posterior(fine[t], &g, scratch);       /* :504-507 */
+        idx = 0; best = lpv[0];
+        for (int t = 1; t < ngrid; t++) if (lpv[t] > best) { best = lpv[t]; idx = t; }
+        log_alpha_out[i] = fine[idx];                                            /* :509 */
+    }
+    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(lpv); free(fine);
+    }
+    return 0;
+}
+
+/* ================================================================ fitBeta ==
+ * DESeq2.cpp:283-465 */
+
+/* Least squares  min || [sqrt(w) X; sqrt(ridge)] beta - [sqrt(w) z; 0] ||  by
+ * unblocked Householder QR of the (m+p) x p matrix (DESeq2.cpp:344-356: join_cols,
+ * qr_econ, gamma_hat = q.t() * big_z_sqrt_w, solve(beta_hat, r, gamma_hat)).
+ * A: (m+p) x p row-major work matrix, b: (m+p) rhs.  Reflector k is generated as
+ * LAPACK dlarfg does (beta = -sign(alpha) ||col||, tau = (beta-alpha)/beta,
+ * v = col/(alpha-beta)), with the column dot products S_kj = sum_{i>k} a_ik a_ij
+ * taken in wave order over the row index i.                                    */
+static void householder_ls(int M, int p, double *A, double *b, double *beta, int serial) {
+    for (int k = 0; k < p; k++) {
+        double S[ORC_PMAX + 1];
+        for (int j = k; j <= p; j++) {
+            wsum_t s; wsum_init(&s, serial);
+            for (int i = k + 1; i < M; i++) {
+                double aik = A[(long)i * p + k];
+                double other = (j < p) ? A[(long)i * p + j] : b[i];
+                wsum_add(&s, i, aik * other);
+            }
+            S[j] = wsum_total(&s);
+        }
+        double alpha = A[(long)k * p + k];
+        double tau, scal, bet;
+        if (S[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha; }
+        else {
+            bet = -copysign(sqrt(alpha * alpha + S[k]), alpha);
+            tau = (bet - alpha) / bet;
+            scal = 1.0 / (alpha - bet);
+        }
+        double tvec[ORC_PMAX + 1];
+        for (int j = k + 1; j <= p; j++) {
+            double akj = (j < p) ? A[(long)k * p + j] : b[k];
+            double wj = akj + scal * S[j];
+            tvec[j] = -tau * wj;
+        }
+        for (int i = k + 1; i < M; i++) {
+            double v = A[(long)i * p + k] * scal;
+            for (int j = k + 1; j < p; j++) A[(long)i * p + j] = fma(v, tvec[j], A[(long)i * p + j]);
+            b[i] = fma(v, tvec[p], b[i]);
+        }
+        for (int j = k + 1; j < p; j++) A[(long)k * p + j] = A[(long)k * p + j] + tvec[j];
+        b[k] = b[k] + tvec[p];
+        A[(long)k * p + k] = bet;
+    }
+    for (int i = p - 1; i >= 0; i--) {
+        double t = b[i];
+        for (int j = i + 1; j < p; j++) t = fma(-A[(long)i * p + j], beta[j], t);
+        beta[i] = t / A[(long)i * p + i];
+    }
+}
+
+int orc_fit_beta(int n, int m, int p,
+                 const double *y, const double *x, const double *nf, const double *alpha_hat,
+                 const double *contrast, const double *beta_init, const double *lambda,
+                 const double *weights, int useWeights, double tol, int maxit, int useQR,
+                 double minmu,
+                 double *beta_mat, double *beta_var_mat, double *iter, double *hat_diagonals,
+                 double *contrast_num, double *contrast_denom, double *deviance, int sum_mode) {
+    if (p > ORC_PMAX) return -1;
+    const double large = 30.0;                                                   /* :316 */
+#pragma omp parallel
+    {
+    int M = m + p;
+    double *yrow = malloc(sizeof(double) * m), *nfrow = malloc(sizeof(double) * m);
+    double *wts = malloc(sizeof(double) * m), *mu = malloc(sizeof(double) * m);
+    double *w_vec = malloc(sizeof(double) * m), *w_sqrt = malloc(sizeof(double) * m);
+    double *z = malloc(sizeof(double) * m);
+    double *A = malloc(sizeof(double) * (size_t)M * p), *bb = malloc(sizeof(double) * M);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {                                                /* :319 */
+        double beta_hat[ORC_PMAX];
+        for (int j = 0; j < m; j++) {
+            yrow[j] = y[i + (long)n * j]; nfrow[j] = nf[i + (long)n * j];
+            wts[j] = weights ? weights[i + (long)n * j] : 1.0;
+        }
+        for (int c = 0; c < p; c++) beta_hat[c] = beta_init[i + (long)n * c];    /* :323 */
+        double alpha = alpha_hat[i];
+        /* mu_hat = nfrow % exp(x * beta_hat), clamped                            :324-327 */
+        #define ORC_UPDATE_MU() \
+            for (int j = 0; j < m; j++) { \
+                double eta = x[j] * beta_hat[0]; \
+                for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], beta_hat[c], eta); \
+                mu[j] = fmax(nfrow[j] * orc_exp(eta), minmu); }
+        /* w_vec, w_sqrt_vec                                            :336-342,390-396 */
+        #define ORC_UPDATE_W() \
+            for (int j = 0; j < m; j++) { \
+                double wv = useWeights ? (wts[j] * mu[j]) / (1.0 + alpha * mu[j]) \
+                                       : mu[j] / (1.0 + alpha * mu[j]); \
+                w_vec[j] = wv; w_sqrt[j] = sqrt(wv); }
+        ORC_UPDATE_MU();
+        double dev = 0.0, dev_old = 0.0;                                         /* :329-330 */
+        double it = 0.0;
+        for (int t = 0; t < maxit; t++) {                                        /* :334 / :388 */
+            it += 1.0;                                                           /* :335 / :389 */
+            ORC_UPDATE_W();
+            for (int j = 0; j < m; j++)                                          /* :349 / :397 */
+                z[j] = orc_log(mu[j] / nfrow[j]) + (yrow[j] - mu[j]) / mu[j];
+            if (useQR) {
+                /* weighted_x_ridge = join_cols(x.each_col() % w_sqrt_vec, sqrt(ridge)) :344 */
+                for (int j = 0; j < m; j++) {
+                    for (int c = 0; c < p; c++) A[(long)j * p + c] = x[j + (long)m * c] * w_sqrt[j];
+                    bb[j] = z[j] * w_sqrt[j];                                    /* :351-353 */
+                }
+                for (int r = 0; r < p; r++) {
+                    for (int c = 0; c < p; c++) A[(long)(m + r) * p + c] = (r == c) ? sqrt(lambda[c]) : 0.0;
+                    bb[m + r] = 0.0;
+                }
+                householder_ls(M, p, A, bb, beta_hat, sum_mode);                 /* :345-356 */
+            } else {
+                /* solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec)) :398 */
+                double G[ORC_PMAX * ORC_PMAX], rhs[ORC_PMAX];
+                for (int a = 0; a < p; a++) {
+                    for (int b = a; b < p; b++) {
+                        wsum_t s; wsum_init(&s, sum_mode);
+                        for (int j = 0; j < m; j++)
+                            wsum_add(&s, j, x[j + (long)m * a] * (x[j + (long)m * b] * w_vec[j]));
+                        double v = wsum_total(&s);
+                        G[a * p + b] = v; G[b * p + a] = v;
+                    }
+                    wsum_t s; wsum_init(&s, sum_mode);
+                    for (int j = 0; j < m; j++) wsum_add(&s, j, x[j + (long)m * a] * (z[j] * w_vec[j]));
+                    rhs[a] = wsum_total(&s);
+                }
+                for (int a = 0; a < p; a++) G[a * p + a] = G[a * p + a] + lambda[a];
+                int piv[ORC_PMAX]; double rdiag[ORC_PMAX];
+                lu_decomp(p, G, piv, rdiag);
+                lu_solve(p, G, piv, rdiag, rhs);
+                for (int a = 0; a < p; a++) beta_hat[a] = rhs[a];
+            }
+            int toolarge = 0;                                                    /* :357 / :399 */
+            for (int c = 0; c < p; c++) if (fabs(beta_hat[c]) > large) toolarge++;
+            if (toolarge > 0) { it = (double)maxit; break; }                     /* :358-359 */
+            ORC_UPDATE_MU();                                                     /* :361-364 */
+            wsum_t s; wsum_init(&s, sum_mode);                                   /* :365-373 */
+            for (int j = 0; j < m; j++) {
+                double d = orc_dnbinom_mu_log(yrow[j], 1.0 / alpha, mu[j]);
+                double term = useWeights ? (-2.0 * wts[j]) * d : -2.0 * d;
+                wsum_add(&s, j, term);
+            }
+            dev = wsum_total(&s);
+            double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);          /* :374 */
+            if (isnan(conv_test)) { it = (double)maxit; break; }                 /* :375-378 */
+            if ((t > 0) & (conv_test < tol)) break;                              /* :379-381 */
+            dev_old = dev;                                                       /* :382 */
+        }
+        deviance[i] = dev;                                                       /* :427 */
+        for (int c = 0; c < p; c++) beta_mat[i + (long)n * c] = beta_hat[c];     /* :428 */
+        iter[i] = it;
+        ORC_UPDATE_W();                                                          /* :430-436 */
+        /* xtwxr_inv = (x.t() * (x.each_col() % w_vec) + ridge).i()                :439 */
+        double G[ORC_PMAX * ORC_PMAX], Gr[ORC_PMAX * ORC_PMAX], Gi[ORC_PMAX * ORC_PMAX];
+        for (int a = 0; a < p; a++)
+            for (int b = a; b < p; b++) {
+                wsum_t s; wsum_init(&s, sum_mode);
+                for (int j = 0; j < m; j++)
+                    wsum_add(&s, j, x[j + (long)m * a] * (x[j + (long)m * b] * w_vec[j]));
+                double v = wsum_total(&s);
+                G[a * p + b] = v; G[b * p + a] = v;
+            }
+        memcpy(Gr, G, sizeof(double) * p * p);
+        for (int a = 0; a < p; a++) Gr[a * p + a] = Gr[a * p + a] + lambda[a];
+        mat_inverse(p, Gr, Gi, NULL);
+        /* hat diagonal, loop order of :443-449 */
+        for (int jp = 0; jp < m; jp++) {
+            double h = 0.0;
+            for (int idx1 = 0; idx1 < p; idx1++)
+                for (int idx2 = 0; idx2 < p; idx2++) {
+                    double xw1 = x[jp + (long)m * idx1] * w_sqrt[jp];
+                    double xw2 = x[jp + (long)m * idx2] * w_sqrt[jp];
+                    h += xw1 * (xw2 * Gi[idx2 * p + idx1]);
+                }
+            hat_diagonals[i + (long)n * jp] = h;                                 /* :450 */
+        }
+        /* sigma = Gi * G * Gi                                                     :452 */
+        double T[ORC_PMAX * ORC_PMAX], Sg[ORC_PMAX * ORC_PMAX];
+        mat_mul(p, Gi, G, T); mat_mul(p, T, Gi, Sg);
+        double cn = 0.0;                                                         /* :453 */
+        for (int c = 0; c < p; c++) cn = fma(contrast[c], beta_hat[c], cn);
+        contrast_num[i] = cn;
+        double cd = 0.0;                                                         /* :454 */
+        for (int b = 0; b < p; b++) {
+            double r = 0.0;
+            for (int a = 0; a < p; a++) r = fma(contrast[a], Sg[a * p + b], r);
+            cd = fma(r, contrast[b], cd);
+        }
+        contrast_denom[i] = sqrt(cd);
+        for (int c = 0; c < p; c++) beta_var_mat[i + (long)n * c] = Sg[c * p + c];   /* :455 */
+    }
+    free(yrow); free(nfrow); free(wts); free(mu); free(w_vec); free(w_sqrt); free(z); free(A); free(bb);
+    }
+    return 0;
+}

@@ -1,0 +1,152 @@
+"""ORACLE binding -- test infrastructure only.
+
+ctypes front-end of oracle/_build/libdeseq2_oracle.so (the plain-C restatement of
+/root/reference/src/DESeq2.cpp).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product package
+(deseq2_amd) never does.
+
+Function names, argument names/order and returned dict keys mirror the reference's
+Rcpp exports (R/RcppExports.R:4,8,12; return lists at src/DESeq2.cpp:268-276,
+458-464, 512).  All matrices are numpy arrays in R orientation (genes x samples,
+samples x coefficients); they are passed to C in column-major order like R does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libdeseq2_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("deseq2_oracle.c", "orc_nmath.c", "orc_nmath.h", "Makefile")]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        try:
+            _lib = ctypes.CDLL(_SO)
+        except OSError:
+            build(force=True)
+            _lib = ctypes.CDLL(_SO)
+        _lib.orc_vec_unary.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        _lib.orc_vec_dnbinom_mu_log.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long]
+        _lib.orc_bd0.restype = ctypes.c_double
+        _lib.orc_bd0.argtypes = [ctypes.c_double, ctypes.c_double]
+    return _lib
+
+
+def _f(a):
+    """column-major float64 copy (R layout)"""
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6}
+
+
+def unary(name, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_vec_unary(UNARY_OPS[name], _p(x), _p(out), x.size)
+    return out
+
+
+def dnbinom_mu_log(x, size, mu):
+    x, size, mu = np.broadcast_arrays(np.asarray(x, float), np.asarray(size, float), np.asarray(mu, float))
+    x = np.ascontiguousarray(x); size = np.ascontiguousarray(size); mu = np.ascontiguousarray(mu)
+    out = np.empty_like(x)
+    lib().orc_vec_dnbinom_mu_log(_p(x), _p(size), _p(mu), _p(out), x.size)
+    return out
+
+
+def set_threads(k):
+    os.environ["OMP_NUM_THREADS"] = str(int(k))
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(int(k))
+    except OSError:
+        pass
+
+
+def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP,
+            log_alpha_prior_sigmasqSEXP, min_log_alphaSEXP, kappa_0SEXP, tolSEXP, maxitSEXP,
+            usePriorSEXP, weightsSEXP, useWeightsSEXP, weightThresholdSEXP, useCRSEXP,
+            sum_mode=0):
+    y = _f(ySEXP); x = _f(xSEXP); mu = _f(mu_hatSEXP); w = _f(weightsSEXP)
+    n, m = y.shape; p = x.shape[1]
+    assert x.shape[0] == m and mu.shape == (n, m) and w.shape == (n, m)
+    la = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alphaSEXP, float), (n,)))
+    pm = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alpha_prior_meanSEXP, float), (n,)))
+    out = {k: np.zeros(n) for k in ("log_alpha", "last_change", "initial_lp", "initial_dlp",
+                                     "last_lp", "last_dlp", "last_d2lp")}
+    it = np.zeros(n, dtype=np.int32); ita = np.zeros(n, dtype=np.int32)
+    rc = lib().orc_fit_disp(
+        ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(x), _p(mu), _p(la), _p(pm),
+        ctypes.c_double(float(log_alpha_prior_sigmasqSEXP)), ctypes.c_double(float(min_log_alphaSEXP)),
+        ctypes.c_double(float(kappa_0SEXP)), ctypes.c_double(float(tolSEXP)), ctypes.c_int(int(maxitSEXP)),
+        ctypes.c_int(int(bool(usePriorSEXP))), _p(w), ctypes.c_int(int(bool(useWeightsSEXP))),
+        ctypes.c_double(float(weightThresholdSEXP)), ctypes.c_int(int(bool(useCRSEXP))),
+        _p(out["log_alpha"]), _p(it), _p(ita), _p(out["last_change"]), _p(out["initial_lp"]),
+        _p(out["initial_dlp"]), _p(out["last_lp"]), _p(out["last_dlp"]), _p(out["last_d2lp"]),
+        ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_fit_disp failed: %d" % rc)
+    out["iter"] = it; out["iter_accept"] = ita
+    return out
+
+
+def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lambdaSEXP,
+            weightsSEXP, useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, sum_mode=0):
+    y = _f(ySEXP); x = _f(xSEXP); nf = _f(nfSEXP); w = _f(weightsSEXP); b0 = _f(beta_matSEXP)
+    n, m = y.shape; p = x.shape[1]
+    assert x.shape[0] == m and nf.shape == (n, m) and w.shape == (n, m) and b0.shape == (n, p)
+    alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_hatSEXP, float), (n,)))
+    contrast = np.ascontiguousarray(contrastSEXP, dtype=np.float64)
+    lam = np.ascontiguousarray(lambdaSEXP, dtype=np.float64)
+    assert contrast.shape == (p,) and lam.shape == (p,)
+    beta_mat = np.zeros((n, p), order="F"); beta_var = np.zeros((n, p), order="F")
+    H = np.zeros((n, m), order="F")
+    it = np.zeros(n); cn = np.zeros(n); cd = np.zeros(n); dev = np.zeros(n)
+    rc = lib().orc_fit_beta(
+        ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(x), _p(nf), _p(alpha),
+        _p(contrast), _p(b0), _p(lam), _p(w), ctypes.c_int(int(bool(useWeightsSEXP))),
+        ctypes.c_double(float(tolSEXP)), ctypes.c_int(int(maxitSEXP)), ctypes.c_int(int(bool(useQRSEXP))),
+        ctypes.c_double(float(minmuSEXP)),
+        _p(beta_mat), _p(beta_var), _p(it), _p(H), _p(cn), _p(cd), _p(dev), ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_fit_beta failed: %d" % rc)
+    return {"beta_mat": beta_mat, "beta_var_mat": beta_var, "iter": it, "hat_diagonals": H,
+            "contrast_num": cn.reshape(n, 1), "contrast_denom": cd.reshape(n, 1), "deviance": dev}
+
+
+def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEXP,
+                log_alpha_prior_sigmasqSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP,
+                weightThresholdSEXP, useCRSEXP, sum_mode=0):
+    y = _f(ySEXP); x = _f(xSEXP); mu = _f(mu_hatSEXP); w = _f(weightsSEXP)
+    n, m = y.shape; p = x.shape[1]
+    grid = np.ascontiguousarray(disp_gridSEXP, dtype=np.float64)
+    pm = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alpha_prior_meanSEXP, float), (n,)))
+    la = np.zeros(n)
+    rc = lib().orc_fit_disp_grid(
+        ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(x), _p(mu), _p(grid),
+        ctypes.c_int(grid.size), _p(pm), ctypes.c_double(float(log_alpha_prior_sigmasqSEXP)),
+        ctypes.c_int(int(bool(usePriorSEXP))), _p(w), ctypes.c_int(int(bool(useWeightsSEXP))),
+        ctypes.c_double(float(weightThresholdSEXP)), ctypes.c_int(int(bool(useCRSEXP))), _p(la),
+        ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_fit_disp_grid failed: %d" % rc)
+    return {"log_alpha": la}
