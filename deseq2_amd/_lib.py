@@ -1,0 +1,126 @@
+"""ctypes binding of libdeseq2_mi355x.so (include/deseq2_mi355x.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` (or
+`make -C deseq2_amd/csrc`).  There is no fallback: if the library is missing or no
+gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdeseq2_mi355x.so")
+
+DSQ_OK = 0
+DSQ_LAYOUT_R = 0
+DSQ_LAYOUT_GENE_MAJOR = 1
+DSQ_Y_INT32 = 0
+DSQ_Y_FLOAT64 = 1
+DSQ_MAX_P = 16
+
+ERR_NAMES = {1: "DSQ_ERR_ARG", 2: "DSQ_ERR_UNSUPPORTED", 3: "DSQ_ERR_DEVICE", 4: "DSQ_ERR_NOMEM",
+             5: "DSQ_ERR_VALUE"}
+
+
+class DsqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "DSQ_ERR"), code, msg))
+        self.code = code
+
+
+class DsqFitBetaArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("x", C.c_void_p), ("nf", C.c_void_p),
+        ("nf_is_vector", C.c_int32), ("alpha_hat", C.c_void_p), ("contrast", C.c_void_p),
+        ("beta_mat", C.c_void_p), ("lambda_", C.c_void_p), ("weights", C.c_void_p),
+        ("useWeights", C.c_int32), ("tol", C.c_double), ("maxit", C.c_int32), ("useQR", C.c_int32),
+        ("minmu", C.c_double),
+    ]
+
+
+class DsqFitBetaOut(C.Structure):
+    _fields_ = [
+        ("beta_mat", C.c_void_p), ("beta_var_mat", C.c_void_p), ("iter", C.c_void_p),
+        ("hat_diagonals", C.c_void_p), ("contrast_num", C.c_void_p), ("contrast_denom", C.c_void_p),
+        ("deviance", C.c_void_p), ("mu", C.c_void_p), ("mu_floor", C.c_double),
+    ]
+
+
+class DsqFitDispArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("x", C.c_void_p), ("mu_hat", C.c_void_p),
+        ("log_alpha", C.c_void_p), ("log_alpha_prior_mean", C.c_void_p),
+        ("log_alpha_prior_sigmasq", C.c_double), ("min_log_alpha", C.c_double), ("kappa_0", C.c_double),
+        ("tol", C.c_double), ("maxit", C.c_int32), ("usePrior", C.c_int32), ("weights", C.c_void_p),
+        ("useWeights", C.c_int32), ("weightThreshold", C.c_double), ("useCR", C.c_int32),
+    ]
+
+
+class DsqFitDispOut(C.Structure):
+    _fields_ = [
+        ("log_alpha", C.c_void_p), ("iter", C.c_void_p), ("iter_accept", C.c_void_p),
+        ("last_change", C.c_void_p), ("initial_lp", C.c_void_p), ("initial_dlp", C.c_void_p),
+        ("last_lp", C.c_void_p), ("last_dlp", C.c_void_p), ("last_d2lp", C.c_void_p),
+    ]
+
+
+class DsqFitDispGridArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("x", C.c_void_p), ("mu_hat", C.c_void_p),
+        ("disp_grid", C.c_void_p), ("ngrid", C.c_int32), ("log_alpha_prior_mean", C.c_void_p),
+        ("log_alpha_prior_sigmasq", C.c_double), ("usePrior", C.c_int32), ("weights", C.c_void_p),
+        ("useWeights", C.c_int32), ("weightThreshold", C.c_double), ("useCR", C.c_int32),
+    ]
+
+
+class DsqFitDispGridOut(C.Structure):
+    _fields_ = [("log_alpha", C.c_void_p)]
+
+
+# every symbol include/deseq2_mi355x.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = [
+    "dsq_fit_beta", "dsq_fit_beta_dev", "dsq_fit_disp", "dsq_fit_disp_dev", "dsq_fit_disp_grid",
+    "dsq_fit_disp_grid_dev", "dsq_to_gene_major_f64", "dsq_to_gene_major_i32",
+    "dsq_counts_f64_to_gene_major_i32", "dsq_from_gene_major_f64", "dsq_version", "dsq_last_error",
+    "dsq_device_count", "dsq_set_device", "dsq_release_workspace", "dsq_test_math",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libdeseq2_mi355x.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FileNotFoundError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C deseq2_amd/csrc`.  deseq2_amd has no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    L.dsq_last_error.restype = C.c_char_p
+    L.dsq_version.restype = C.c_int
+    L.dsq_device_count.restype = C.c_int
+    for name, a, o in (("dsq_fit_beta", DsqFitBetaArgs, DsqFitBetaOut),
+                       ("dsq_fit_disp", DsqFitDispArgs, DsqFitDispOut),
+                       ("dsq_fit_disp_grid", DsqFitDispGridArgs, DsqFitDispGridOut)):
+        getattr(L, name).argtypes = [C.POINTER(a), C.POINTER(o)]
+        getattr(L, name).restype = C.c_int
+        getattr(L, name + "_dev").argtypes = [C.POINTER(a), C.POINTER(o), C.c_void_p]
+        getattr(L, name + "_dev").restype = C.c_int
+    L.dsq_to_gene_major_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    L.dsq_to_gene_major_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    L.dsq_counts_f64_to_gene_major_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                                    C.c_void_p, C.c_void_p]
+    L.dsq_from_gene_major_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    L.dsq_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.dsq_set_device.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != DSQ_OK:
+        raise DsqError(rc, lib().dsq_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,578 @@
+// capi.hip -- the C ABI of libdeseq2_mi355x.so (include/deseq2_mi355x.h).
+//
+// Host side of the engine: argument validation, device workspaces, layout conversion
+// (R column-major <-> gene-major), kernel dispatch on the design width p, and the
+// host-pointer convenience entry points the R .Call shim binds.  No CPU fallback: if
+// HIP cannot give us a device, every entry point fails with DSQ_ERR_DEVICE.
+#include "../../include/deseq2_mi355x.h"
+#include "dsq_internal.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace dsq {
+
+static thread_local char g_err[512] = "";
+static std::mutex g_mu;
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define DSQ_HIP(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? DSQ_ERR_NOMEM : DSQ_ERR_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                  \
+    } while (0)
+
+int device_cu_count() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev] = v;
+    }
+    return cached[dev];
+}
+
+// ---- workspace pool: grow-only device buffers, one per (device, slot) -------------
+struct Slot { void *p = nullptr; size_t bytes = 0; };
+static std::vector<Slot> g_pool[64];
+
+static int ws_get(int slot, size_t bytes, void **out) {
+    int dev = 0;
+    DSQ_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(DSQ_ERR_DEVICE, "device index %d out of range", dev);
+    auto &pool = g_pool[dev];
+    if ((int)pool.size() <= slot) pool.resize(slot + 1);
+    Slot &s = pool[slot];
+    if (s.bytes < bytes) {
+        if (s.p) { DSQ_HIP(hipDeviceSynchronize()); DSQ_HIP(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&s.p, want);
+        if (e != hipSuccess) { s.p = nullptr; return fail(DSQ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        s.bytes = want;
+    }
+    *out = s.p;
+    return DSQ_OK;
+}
+
+enum {  // workspace slots
+    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD,
+    // host-entry staging
+    WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
+    WS_COUNT
+};
+
+static inline long round_ld(int m) { return ((long)m + 7) & ~7L; }
+
+static int check_device() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(DSQ_ERR_DEVICE, "no HIP device available (%s); libdeseq2_mi355x has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return DSQ_OK;
+}
+
+// counts -> int32 gene-major.  Returns the pointer to use and its ld.
+static int prep_counts(const void *y, int y_type, int layout, long ld_in, int n, int m, hipStream_t st,
+                       const int32_t **out, long *ld_out, bool *checked_async) {
+    *checked_async = false;
+    if (layout == DSQ_LAYOUT_GENE_MAJOR) {
+        if (y_type != DSQ_Y_INT32)
+            return fail(DSQ_ERR_UNSUPPORTED, "gene-major counts must be int32 (y_type = DSQ_Y_INT32)");
+        *out = (const int32_t *)y;
+        *ld_out = ld_in;
+        return DSQ_OK;
+    }
+    long ld = round_ld(m);
+    void *buf;
+    int rc = ws_get(WS_Y, (size_t)n * ld * sizeof(int32_t), &buf);
+    if (rc) return rc;
+    if (y_type == DSQ_Y_INT32) {
+        DSQ_HIP(launch_transpose_r_to_gm_i32((const int32_t *)y, (int32_t *)buf, n, m, ld, st));
+    } else if (y_type == DSQ_Y_FLOAT64) {
+        void *bad;
+        rc = ws_get(WS_BAD, sizeof(int32_t), &bad);
+        if (rc) return rc;
+        DSQ_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
+        DSQ_HIP(launch_counts_f64_to_gm_i32((const double *)y, (int32_t *)buf, n, m, ld, (int32_t *)bad, st));
+        *checked_async = true;
+    } else {
+        return fail(DSQ_ERR_ARG, "unknown y_type %d", y_type);
+    }
+    *out = (const int32_t *)buf;
+    *ld_out = ld;
+    return DSQ_OK;
+}
+
+static int prep_matrix(const double *src, int layout, long ld_in, int n, int m, int slot, hipStream_t st,
+                       const double **out, long ld_expected) {
+    if (layout == DSQ_LAYOUT_GENE_MAJOR) {
+        (void)ld_in;
+        *out = src;
+        return DSQ_OK;
+    }
+    void *buf;
+    int rc = ws_get(slot, (size_t)n * ld_expected * sizeof(double), &buf);
+    if (rc) return rc;
+    DSQ_HIP(launch_transpose_r_to_gm_f64(src, (double *)buf, n, m, ld_expected, st));
+    *out = (const double *)buf;
+    return DSQ_OK;
+}
+
+template <int P>
+struct DispatchP {
+    static hipError_t beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok) {
+        if (p == P) { *ok = true; return launch_fit_beta_p<P>(kp, st); }
+        return DispatchP<P - 1>::beta(p, kp, st, ok);
+    }
+    static hipError_t disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
+        if (p == P) { *ok = true; return launch_fit_disp_p<P>(kp, st, grid); }
+        return DispatchP<P - 1>::disp(p, kp, st, grid, ok);
+    }
+};
+template <>
+struct DispatchP<0> {
+    static hipError_t beta(int, const BetaKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
+    static hipError_t disp(int, const DispKernelParams &, hipStream_t, bool, bool *ok) { *ok = false; return hipSuccess; }
+};
+
+// =============================================================== fitBeta (device)
+static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
+    if (a->p > DSQ_P_REG)
+        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    if (!a->y || !a->x || !a->nf || !a->alpha_hat || !a->contrast || !a->beta_mat || !a->lambda)
+        return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->beta_mat || !o->beta_var_mat || !o->iter || !o->contrast_num || !o->contrast_denom || !o->deviance)
+        return fail(DSQ_ERR_ARG, "NULL output array");
+    if (a->maxit < 0) return fail(DSQ_ERR_ARG, "maxit < 0");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    if (a->layout != DSQ_LAYOUT_R && a->layout != DSQ_LAYOUT_GENE_MAJOR) return fail(DSQ_ERR_ARG, "bad layout");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+
+    BetaKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m; kp.p = a->p;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    if (a->nf_is_vector) { kp.nf = a->nf; kp.nf_is_vector = 1; }
+    else {
+        rc = prep_matrix(a->nf, a->layout, a->ld, a->n, a->m, WS_NF, st, &kp.nf, ld);
+        if (rc) return rc;
+    }
+    if (a->useWeights) {
+        rc = prep_matrix(a->weights, a->layout, a->ld, a->n, a->m, WS_W, st, &kp.weights, ld);
+        if (rc) return rc;
+    }
+    kp.x = a->x; kp.alpha_hat = a->alpha_hat; kp.contrast = a->contrast; kp.beta_init = a->beta_mat;
+    kp.lambda = a->lambda;
+    kp.tol = a->tol; kp.minmu = a->minmu; kp.mu_floor = o->mu_floor;
+    kp.maxit = a->maxit; kp.useQR = a->useQR ? 1 : 0; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
+    kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
+    // n x m outputs: directly when gene-major, through a workspace when R layout
+    double *hat_ws = nullptr, *mu_ws = nullptr;
+    if (o->hat_diagonals) {
+        if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.hat_diagonals = o->hat_diagonals;
+        else {
+            void *b; rc = ws_get(WS_HAT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc;
+            hat_ws = (double *)b; kp.hat_diagonals = hat_ws;
+        }
+    }
+    if (o->mu) {
+        if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.mu_out = o->mu;
+        else {
+            void *b; rc = ws_get(WS_MUOUT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc;
+            mu_ws = (double *)b; kp.mu_out = mu_ws;
+        }
+    }
+    size_t sb = fit_beta_scratch_bytes(a->m, a->p, a->useWeights);
+    if (sb) {
+        void *b; rc = ws_get(WS_SCRATCH, sb, &b); if (rc) return rc;
+        kp.scratch = (double *)b;
+    }
+    bool ok = false;
+    DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    if (hat_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(hat_ws, o->hat_diagonals, a->n, a->m, ld, st));
+    if (mu_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(mu_ws, o->mu, a->n, a->m, ld, st));
+    if (ycheck) {
+        int32_t bad = 0;
+        void *badp; rc = ws_get(WS_BAD, sizeof(int32_t), &badp); if (rc) return rc;
+        DSQ_HIP(hipMemcpyAsync(&bad, badp, sizeof bad, hipMemcpyDeviceToHost, st));
+        DSQ_HIP(hipStreamSynchronize(st));
+        if (bad) return fail(DSQ_ERR_VALUE, "count matrix holds negative, non-finite or non-integer values");
+    }
+    return DSQ_OK;
+}
+
+// =============================================================== fitDisp (device)
+static int disp_common(int n, int m, int p, int layout, long ld_in, const void *y, int y_type, const double *x,
+                       const double *mu_hat, const double *weights, int useWeights, hipStream_t st,
+                       DispKernelParams *kp, bool *ycheck) {
+    if (n < 0 || m < 1 || p < 1) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", n, m, p);
+    if (p > DSQ_P_REG)
+        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", p, DSQ_P_REG);
+    if (!y || !x || !mu_hat) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (useWeights && !weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (layout == DSQ_LAYOUT_GENE_MAJOR && ld_in < m) return fail(DSQ_ERR_ARG, "ld < m");
+    if (layout != DSQ_LAYOUT_R && layout != DSQ_LAYOUT_GENE_MAJOR) return fail(DSQ_ERR_ARG, "bad layout");
+    int rc = check_device();
+    if (rc) return rc;
+    memset(kp, 0, sizeof *kp);
+    kp->n = n; kp->m = m; kp->p = p;
+    if (n == 0) return DSQ_OK;
+    long ld = 0;
+    rc = prep_counts(y, y_type, layout, ld_in, n, m, st, &kp->y, &ld, ycheck);
+    if (rc) return rc;
+    kp->ld = ld;
+    rc = prep_matrix(mu_hat, layout, ld_in, n, m, WS_MU, st, &kp->mu_hat, ld);
+    if (rc) return rc;
+    if (useWeights) {
+        rc = prep_matrix(weights, layout, ld_in, n, m, WS_W, st, &kp->weights, ld);
+        if (rc) return rc;
+    }
+    kp->x = x;
+    kp->useWeights = useWeights ? 1 : 0;
+    return DSQ_OK;
+}
+
+static int finish_ycheck(bool ycheck, hipStream_t st) {
+    if (!ycheck) return DSQ_OK;
+    int32_t bad = 0;
+    void *badp;
+    int rc = ws_get(WS_BAD, sizeof(int32_t), &badp);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(&bad, badp, sizeof bad, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    if (bad) return fail(DSQ_ERR_VALUE, "count matrix holds negative, non-finite or non-integer values");
+    return DSQ_OK;
+}
+
+static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (!a->log_alpha || !a->log_alpha_prior_mean) return fail(DSQ_ERR_ARG, "NULL input vector");
+    if (!o->log_alpha || !o->iter || !o->iter_accept || !o->last_change || !o->initial_lp || !o->initial_dlp ||
+        !o->last_lp || !o->last_dlp || !o->last_d2lp)
+        return fail(DSQ_ERR_ARG, "NULL output array");
+    if (a->maxit < 0) return fail(DSQ_ERR_ARG, "maxit < 0");
+    DispKernelParams kp;
+    bool ycheck = false;
+    int rc = disp_common(a->n, a->m, a->p, a->layout, a->ld, a->y, a->y_type, a->x, a->mu_hat, a->weights,
+                         a->useWeights, st, &kp, &ycheck);
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    kp.log_alpha_in = a->log_alpha; kp.prior_mean = a->log_alpha_prior_mean;
+    kp.prior_sigmasq = a->log_alpha_prior_sigmasq; kp.min_log_alpha = a->min_log_alpha;
+    kp.kappa_0 = a->kappa_0; kp.tol = a->tol; kp.weightThreshold = a->weightThreshold;
+    kp.maxit = a->maxit; kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
+    kp.log_alpha = o->log_alpha; kp.iter = o->iter; kp.iter_accept = o->iter_accept;
+    kp.last_change = o->last_change; kp.initial_lp = o->initial_lp; kp.initial_dlp = o->initial_dlp;
+    kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
+    bool ok = false;
+    DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    return finish_ycheck(ycheck, st);
+}
+
+static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (!a->disp_grid || !a->log_alpha_prior_mean || !o->log_alpha) return fail(DSQ_ERR_ARG, "NULL array");
+    if (a->ngrid < 2) return fail(DSQ_ERR_ARG, "disp_grid needs at least 2 points");
+    DispKernelParams kp;
+    bool ycheck = false;
+    int rc = disp_common(a->n, a->m, a->p, a->layout, a->ld, a->y, a->y_type, a->x, a->mu_hat, a->weights,
+                         a->useWeights, st, &kp, &ycheck);
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    kp.prior_mean = a->log_alpha_prior_mean; kp.prior_sigmasq = a->log_alpha_prior_sigmasq;
+    kp.weightThreshold = a->weightThreshold;
+    kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
+    kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = o->log_alpha;
+    bool ok = false;
+    DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    return finish_ycheck(ycheck, st);
+}
+
+// ---- host-pointer staging helpers --------------------------------------------------
+static int up(int slot, const void *host, size_t bytes, hipStream_t st, void **dev) {
+    int rc = ws_get(slot, bytes ? bytes : 8, dev);
+    if (rc) return rc;
+    if (bytes) DSQ_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, st));
+    return DSQ_OK;
+}
+
+}  // namespace dsq
+
+using namespace dsq;
+
+extern "C" {
+
+int dsq_version(void) { return DSQ_VERSION; }
+const char *dsq_last_error(void) { return g_err; }
+
+int dsq_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int dsq_set_device(int device) {
+    if (hipSetDevice(device) != hipSuccess) return fail(DSQ_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    return DSQ_OK;
+}
+
+int dsq_release_workspace(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 64; d++) {
+        if (g_pool[d].empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        for (auto &s : g_pool[d]) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+        g_pool[d].clear();
+    }
+    (void)hipSetDevice(cur);
+    return DSQ_OK;
+}
+
+int dsq_fit_beta_dev(const DsqFitBetaArgs *args, const DsqFitBetaOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return fit_beta_dev_locked(args, out, (hipStream_t)stream);
+}
+int dsq_fit_disp_dev(const DsqFitDispArgs *args, const DsqFitDispOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return fit_disp_dev_locked(args, out, (hipStream_t)stream);
+}
+int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return fit_disp_grid_dev_locked(args, out, (hipStream_t)stream);
+}
+
+int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream) {
+    if (!src_r || !dst_gm || n < 0 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    DSQ_HIP(launch_transpose_r_to_gm_f64(src_r, dst_gm, n, m, ld, (hipStream_t)stream));
+    return DSQ_OK;
+}
+int dsq_to_gene_major_i32(const int32_t *src_r, int32_t *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream) {
+    if (!src_r || !dst_gm || n < 0 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    DSQ_HIP(launch_transpose_r_to_gm_i32(src_r, dst_gm, n, m, ld, (hipStream_t)stream));
+    return DSQ_OK;
+}
+int dsq_counts_f64_to_gene_major_i32(const double *src_r, int32_t *dst_gm, int32_t n, int32_t m, int64_t ld,
+                                     int32_t *bad, void *stream) {
+    if (!src_r || !dst_gm || !bad || n < 0 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    DSQ_HIP(launch_counts_f64_to_gm_i32(src_r, dst_gm, n, m, ld, bad, (hipStream_t)stream));
+    return DSQ_OK;
+}
+int dsq_from_gene_major_f64(const double *src_gm, double *dst_r, int32_t n, int32_t m, int64_t ld, void *stream) {
+    if (!src_gm || !dst_r || n < 0 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    DSQ_HIP(launch_transpose_gm_to_r_f64(src_gm, dst_r, n, m, ld, (hipStream_t)stream));
+    return DSQ_OK;
+}
+
+// ------------------------------------------------------------ host-pointer entries
+// (what src/r_shim.c binds: R memory in, R memory out, synchronous)
+int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->x || !a->nf || !a->alpha_hat || !a->contrast || !a->beta_mat || !a->lambda)
+        return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->beta_mat || !o->beta_var_mat || !o->iter || !o->contrast_num || !o->contrast_denom || !o->deviance)
+        return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m, p = a->p;
+    const size_t ybytes = n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8);
+    DsqFitBetaArgs d = *a;
+    DsqFitBetaOut od = *o;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, ybytes, st, &v))) return rc; d.y = v;
+    // x, alpha_hat, contrast, beta_mat, lambda share one staging buffer
+    size_t off_x = 0, off_alpha = off_x + m * p, off_con = off_alpha + n, off_beta = off_con + p,
+           off_lam = off_beta + n * p, tot = off_lam + p;
+    if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec + off_x, a->x, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_alpha, a->alpha_hat, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_con, a->contrast, p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_beta, a->beta_mat, n * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_lam, a->lambda, p * 8, hipMemcpyHostToDevice, st));
+    d.x = vec + off_x; d.alpha_hat = vec + off_alpha; d.contrast = vec + off_con; d.beta_mat = vec + off_beta;
+    d.lambda = vec + off_lam;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
+    else d.weights = nullptr;
+    // outputs
+    size_t o_beta = 0, o_var = o_beta + n * p, o_iter = o_var + n * p, o_cn = o_iter + n, o_cd = o_cn + n,
+           o_dev = o_cd + n, o_tot = o_dev + n;
+    if ((rc = ws_get(WS_H_OUTVEC, o_tot * 8, &v))) return rc;
+    double *ov = (double *)v;
+    od.beta_mat = ov + o_beta; od.beta_var_mat = ov + o_var; od.iter = ov + o_iter; od.contrast_num = ov + o_cn;
+    od.contrast_denom = ov + o_cd; od.deviance = ov + o_dev;
+    double *hat_d = nullptr, *mu_d = nullptr;
+    if (o->hat_diagonals) { if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc; hat_d = (double *)v; }
+    if (o->mu) { if ((rc = ws_get(WS_H_OUTMAT2, n * m * 8, &v))) return rc; mu_d = (double *)v; }
+    od.hat_diagonals = hat_d; od.mu = mu_d;
+    rc = fit_beta_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->beta_mat, od.beta_mat, n * p * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->beta_var_mat, od.beta_var_mat, n * p * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->iter, od.iter, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->contrast_num, od.contrast_num, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->contrast_denom, od.contrast_denom, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->deviance, od.deviance, n * 8, hipMemcpyDeviceToHost, st));
+    if (hat_d) DSQ_HIP(hipMemcpyAsync(o->hat_diagonals, hat_d, n * m * 8, hipMemcpyDeviceToHost, st));
+    if (mu_d) DSQ_HIP(hipMemcpyAsync(o->mu, mu_d, n * m * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+static int disp_host_stage(int n_, int m_, int p_, const void *y, int y_type, const double *x, const double *mu_hat,
+                           const double *weights, int useWeights, hipStream_t st, const void **yd,
+                           const double **xd, const double **mud, const double **wd) {
+    const size_t n = n_, m = m_, p = p_;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, y, n * m * (y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; *yd = v;
+    if ((rc = up(WS_H_X, x, m * p * 8, st, &v))) return rc; *xd = (double *)v;
+    if ((rc = up(WS_H_MU, mu_hat, n * m * 8, st, &v))) return rc; *mud = (double *)v;
+    if (useWeights) { if ((rc = up(WS_H_W, weights, n * m * 8, st, &v))) return rc; *wd = (double *)v; }
+    else *wd = nullptr;
+    return DSQ_OK;
+}
+
+int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->x || !a->mu_hat || !a->log_alpha || !a->log_alpha_prior_mean)
+        return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->log_alpha || !o->iter || !o->iter_accept || !o->last_change || !o->initial_lp || !o->initial_dlp ||
+        !o->last_lp || !o->last_dlp || !o->last_d2lp)
+        return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n;
+    DsqFitDispArgs d = *a;
+    DsqFitDispOut od = *o;
+    int rc = disp_host_stage(a->n, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
+                             &d.y, &d.x, &d.mu_hat, &d.weights);
+    if (rc) return rc;
+    void *v;
+    if ((rc = ws_get(WS_H_VEC, 2 * n * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + n, a->log_alpha_prior_mean, n * 8, hipMemcpyHostToDevice, st));
+    d.log_alpha = vec; d.log_alpha_prior_mean = vec + n;
+    if ((rc = ws_get(WS_H_OUTVEC, 8 * n * 8, &v))) return rc;
+    double *ov = (double *)v;
+    od.log_alpha = ov; od.last_change = ov + n; od.initial_lp = ov + 2 * n; od.initial_dlp = ov + 3 * n;
+    od.last_lp = ov + 4 * n; od.last_dlp = ov + 5 * n; od.last_d2lp = ov + 6 * n;
+    od.iter = (int32_t *)(ov + 7 * n); od.iter_accept = od.iter + n;
+    rc = fit_disp_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->last_change, od.last_change, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->initial_lp, od.initial_lp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->initial_dlp, od.initial_dlp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->last_lp, od.last_lp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->last_dlp, od.last_dlp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->last_d2lp, od.last_d2lp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->iter, od.iter, n * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->iter_accept, od.iter_accept, n * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1 || a->p < 1 || a->ngrid < 2) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->x || !a->mu_hat || !a->disp_grid || !a->log_alpha_prior_mean || !o->log_alpha)
+        return fail(DSQ_ERR_ARG, "NULL array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, ng = a->ngrid;
+    DsqFitDispGridArgs d = *a;
+    DsqFitDispGridOut od = *o;
+    int rc = disp_host_stage(a->n, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
+                             &d.y, &d.x, &d.mu_hat, &d.weights);
+    if (rc) return rc;
+    void *v;
+    if ((rc = ws_get(WS_H_VEC, (n + ng) * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha_prior_mean, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + n, a->disp_grid, ng * 8, hipMemcpyHostToDevice, st));
+    d.log_alpha_prior_mean = vec; d.disp_grid = vec + n;
+    if ((rc = ws_get(WS_H_OUTVEC, n * 8, &v))) return rc;
+    od.log_alpha = (double *)v;
+    rc = fit_disp_grid_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_test_math(int op, const double *a, const double *b, const double *c, double *out, int64_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !out || n < 0 || (op >= 7 && !b) || (op >= 8 && !c)) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    void *v;
+    int rc;
+    if ((rc = ws_get(WS_H_VEC, 4 * (size_t)n * 8, &v))) return rc;
+    double *d = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(d, a, n * 8, hipMemcpyHostToDevice, st));
+    if (b) DSQ_HIP(hipMemcpyAsync(d + n, b, n * 8, hipMemcpyHostToDevice, st));
+    if (c) DSQ_HIP(hipMemcpyAsync(d + 2 * n, c, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(launch_test_math(op, d, d + n, d + 2 * n, d + 3 * n, n, st));
+    DSQ_HIP(hipMemcpyAsync(out, d + 3 * n, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// dsq_internal.hpp -- launch-level parameter blocks shared by the kernels and the C ABI.
+// All pointers are device pointers; n x m matrices are gene-major with leading dim ld.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsq {
+
+struct DispKernelParams {
+    int n, m, p;
+    long ld;
+    const int32_t *y;
+    const double *mu_hat;
+    const double *weights;  // nullptr unless useWeights
+    const double *x;        // m x p column-major
+    const double *log_alpha_in;
+    const double *prior_mean;
+    double prior_sigmasq, min_log_alpha, kappa_0, tol, weightThreshold;
+    int maxit, usePrior, useWeights, useCR;
+    // fitDisp outputs
+    double *log_alpha;
+    int32_t *iter, *iter_accept;
+    double *last_change, *initial_lp, *initial_dlp, *last_lp, *last_dlp, *last_d2lp;
+    // fitDispGrid
+    const double *grid;
+    int ngrid;
+};
+
+struct BetaKernelParams {
+    int n, m, p;
+    long ld;
+    const int32_t *y;
+    const double *nf;       // gene-major matrix, or m-vector when nf_is_vector
+    int nf_is_vector;
+    const double *weights;  // nullptr unless useWeights
+    const double *x;        // m x p column-major
+    const double *alpha_hat;
+    const double *contrast;
+    const double *beta_init;  // n x p column-major
+    const double *lambda;
+    double tol, minmu, mu_floor;
+    int maxit, useQR, useWeights;
+    double *beta_mat, *beta_var_mat, *iter, *hat_diagonals, *contrast_num, *contrast_denom, *deviance;
+    double *mu_out;
+    double *scratch;        // global per-wave-slot scratch when rows are not staged in LDS
+};
+
+// Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
+// explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).
+#define DSQ_P_REG 6
+template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
+template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
+// bytes of global scratch fitBeta needs when the per-wave slabs do not fit in LDS (0 if they do)
+size_t fit_beta_scratch_bytes(int m, int p, int use_weights);
+
+hipError_t launch_transpose_r_to_gm_f64(const double *src, double *dst, int n, int m, long ld, hipStream_t st);
+hipError_t launch_transpose_r_to_gm_i32(const int32_t *src, int32_t *dst, int n, int m, long ld, hipStream_t st);
+hipError_t launch_counts_f64_to_gm_i32(const double *src, int32_t *dst, int n, int m, long ld, int32_t *bad, hipStream_t st);
+hipError_t launch_transpose_gm_to_r_f64(const double *src, double *dst, int n, int m, long ld, hipStream_t st);
+hipError_t launch_test_math(int op, const double *a, const double *b, const double *c, double *out, long n, hipStream_t st);
+
+int device_cu_count();
+
+}  // namespace dsq

@@ -1,0 +1,314 @@
+// dsq_math.hpp -- f64 scalar math for the gfx950 NB-GLM kernels.
+//
+// DESeq2's native code (src/DESeq2.cpp) leans on R's nmath (lgammafn, digamma,
+// trigamma, dnbinom_mu) and libm exp/log.  None of that exists on the device, and
+// the ROCm device libm cannot be reproduced on a CPU, so the engine carries its own
+// f64 routines with a fully pinned operation sequence: Cody-Waite + Taylor exp,
+// atanh-series log/log1p, Stirling + upward-shift lgamma/digamma/trigamma, and the
+// Loader saddle-point NB density (stirlerr / bd0) that R's dnbinom_mu uses.
+// Every rounding is explicit: compile with -ffp-contract=off; fma only where written.
+// tests/test_gpu_math.py compares these bit-for-bit with the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsq {
+
+#define DSQ_DEV __device__ __forceinline__
+
+DSQ_DEV double bits2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+DSQ_DEV uint64_t d2bits(double d) { return __builtin_bit_cast(uint64_t, d); }
+
+constexpr double kLn2Hi = 6.93147180369123816490e-01;
+constexpr double kLn2Lo = 1.90821492927058770002e-10;
+constexpr double kInvLn2 = 1.44269504088896338700e+00;
+constexpr double kLnSqrt2Pi = 0.918938533204672741780329736406;
+constexpr double kLn2Pi = 1.837877066409345483560659472811;
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+constexpr double kDblMin = 2.2250738585072014e-308;
+constexpr double kInf = __builtin_huge_val();
+
+DSQ_DEV double dnan() { return __builtin_nan(""); }
+DSQ_DEV bool dfinite(double x) { return __builtin_fabs(x) < kInf; }
+
+// ---------------------------------------------------------------------- exp
+DSQ_DEV double dexp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return kInf;
+    if (x < -745.1332191019412) return 0.0;
+    double kf = __builtin_rint(x * kInvLn2);
+    double hi = __builtin_fma(-kf, kLn2Hi, x);
+    double lo = kf * kLn2Lo;
+    double r = hi - lo;
+    double rerr = (hi - r) - lo;
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    double r2 = r * r;
+    double t = __builtin_fma(r2, p, r);
+    t = t + rerr;
+    double y = 1.0 + t;
+    int k = (int)kf;
+    int k1 = k >> 1;
+    int k2 = k - k1;
+    double s1 = bits2d((uint64_t)(uint32_t)(k1 + 1023) << 52);
+    double s2 = bits2d((uint64_t)(uint32_t)(k2 + 1023) << 52);
+    return (y * s1) * s2;
+}
+
+// ---------------------------------------------------------------------- log
+constexpr double kLg1 = 6.666666666666735130e-01;
+constexpr double kLg2 = 3.999999999940941908e-01;
+constexpr double kLg3 = 2.857142874366239149e-01;
+constexpr double kLg4 = 2.222219843214978396e-01;
+constexpr double kLg5 = 1.818357216161805012e-01;
+constexpr double kLg6 = 1.531383769920937332e-01;
+constexpr double kLg7 = 1.479819860511658591e-01;
+
+DSQ_DEV double log_core(double f, double dk, double c) {
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (kLg2 + w * (kLg4 + w * kLg6));
+    double t2 = z * (kLg1 + w * (kLg3 + w * (kLg5 + w * kLg7)));
+    double R = t2 + t1;
+    return s * (hfsq + R) + (dk * kLn2Lo + c) - hfsq + f + dk * kLn2Hi;
+}
+
+DSQ_DEV double dlog(double x) {
+    if (x != x) return x;
+    if (x < 0.0) return dnan();
+    if (x == 0.0) return -kInf;
+    if (x == kInf) return x;
+    int k = 0;
+    if (x < kDblMin) { x *= 18014398509481984.0; k = -54; }
+    uint64_t ix = d2bits(x);
+    ix += (uint64_t)(0x3ff00000u - 0x3fe6a09eu) << 32;
+    k += (int)(ix >> 52) - 0x3ff;
+    ix = (ix & 0x000fffffffffffffULL) + ((uint64_t)0x3fe6a09eu << 32);
+    double f = bits2d(ix) - 1.0;
+    return log_core(f, (double)k, 0.0);
+}
+
+DSQ_DEV double dlog1p(double x) {
+    if (x != x) return x;
+    if (x < -1.0) return dnan();
+    if (x == -1.0) return -kInf;
+    if (x == kInf) return x;
+    if (__builtin_fabs(x) < 1.1102230246251565e-16) return x;
+    if (x > -0.2928932188134524 && x < 0.41421356237309503) return log_core(x, 0.0, 0.0);
+    double u = 1.0 + x;
+    uint64_t iu = d2bits(u);
+    iu += (uint64_t)(0x3ff00000u - 0x3fe6a09eu) << 32;
+    int k = (int)(iu >> 52) - 0x3ff;
+    double c = 0.0;
+    if (k < 54) {
+        c = (k >= 2) ? 1.0 - (u - x) : x - (u - 1.0);
+        c = c / u;
+    }
+    iu = (iu & 0x000fffffffffffffULL) + ((uint64_t)0x3fe6a09eu << 32);
+    double f = bits2d(iu) - 1.0;
+    return log_core(f, (double)k, c);
+}
+
+// ------------------------------------------------------------------- lgamma
+// Stirling with the lgammacor sum for x >= 10, upward shift below (domain x > 0).
+DSQ_DEV double dlgamma(double x) {
+    if (x != x) return x;
+    if (x <= 0.0) return (x == 0.0) ? kInf : dnan();
+    if (x == kInf) return x;
+    double prod = 1.0, xs = x;
+    bool shifted = false;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        if (xs < 10.0) { prod = prod * xs; xs = xs + 1.0; shifted = true; }
+    }
+    double lx = dlog(xs);
+    double rx = 1.0 / xs;
+    double r2 = rx * rx;
+    double c = -3617.0 / 122400.0;
+    c = __builtin_fma(c, r2, 1.0 / 156.0);
+    c = __builtin_fma(c, r2, -691.0 / 360360.0);
+    c = __builtin_fma(c, r2, 1.0 / 1188.0);
+    c = __builtin_fma(c, r2, -1.0 / 1680.0);
+    c = __builtin_fma(c, r2, 1.0 / 1260.0);
+    c = __builtin_fma(c, r2, -1.0 / 360.0);
+    c = __builtin_fma(c, r2, 1.0 / 12.0);
+    double cor = c * rx;
+    double res = kLnSqrt2Pi + (xs - 0.5) * lx - xs + cor;
+    if (shifted) res = res - dlog(prod);
+    return res;
+}
+
+DSQ_DEV double ddigamma(double x) {
+    if (x != x) return x;
+    if (x <= 0.0) return dnan();
+    if (x == kInf) return x;
+    double num = 0.0, den = 1.0, xs = x;
+    bool shifted = false;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        if (xs < 10.0) {
+            num = __builtin_fma(num, xs, den); den = den * xs; xs = xs + 1.0; shifted = true;
+        }
+    }
+    double lx = dlog(xs);
+    double rx = 1.0 / xs;
+    double r2 = rx * rx;
+    double c = -3617.0 / 8160.0;
+    c = __builtin_fma(c, r2, 1.0 / 12.0);
+    c = __builtin_fma(c, r2, -691.0 / 32760.0);
+    c = __builtin_fma(c, r2, 1.0 / 132.0);
+    c = __builtin_fma(c, r2, -1.0 / 240.0);
+    c = __builtin_fma(c, r2, 1.0 / 252.0);
+    c = __builtin_fma(c, r2, -1.0 / 120.0);
+    c = __builtin_fma(c, r2, 1.0 / 12.0);
+    double res = (lx - 0.5 * rx) - c * r2;
+    if (shifted) res = res - num / den;
+    return res;
+}
+
+DSQ_DEV double dtrigamma(double x) {
+    if (x != x) return x;
+    if (x <= 0.0) return dnan();
+    if (x == kInf) return 0.0;
+    double num = 0.0, den = 1.0, xs = x;
+    bool shifted = false;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        if (xs < 10.0) {
+            double d2 = xs * xs;
+            num = __builtin_fma(num, d2, den); den = den * d2; xs = xs + 1.0; shifted = true;
+        }
+    }
+    double rx = 1.0 / xs;
+    double r2 = rx * rx;
+    double c = -3617.0 / 510.0;
+    c = __builtin_fma(c, r2, 7.0 / 6.0);
+    c = __builtin_fma(c, r2, -691.0 / 2730.0);
+    c = __builtin_fma(c, r2, 5.0 / 66.0);
+    c = __builtin_fma(c, r2, -1.0 / 30.0);
+    c = __builtin_fma(c, r2, 1.0 / 42.0);
+    c = __builtin_fma(c, r2, -1.0 / 30.0);
+    c = __builtin_fma(c, r2, 1.0 / 6.0);
+    double res = rx + r2 * (0.5 + rx * c);
+    if (shifted) res = res + num / den;
+    return res;
+}
+
+// ----------------------------------------------------------------- stirlerr
+// log(n!) - log(sqrt(2 pi n) (n/e)^n); table at half-integers <= 15.
+__device__ const double kSferrHalves[31] = {
+    0.0,
+    0.1534264097200273452913839393,   0.08106146679532725821967026359,
+    0.05481412105191765389613870235,  0.04134069595540929409382208141,
+    0.03316287351993628748511050974,  0.02767792568499833914878929275,
+    0.02374616365629749597133027909,  0.02079067210376509311152277177,
+    0.01848845053267318523077935748,  0.01664469118982119216319486537,
+    0.01513497322191737887351383688,  0.01387612882307074799874572702,
+    0.01281046524292022692425065528,  0.01189670994589177009505572412,
+    0.0111045597582069173266307552,   0.01041126526197209649747856713,
+    0.009799416126158803298390373402, 0.009255462182712732917728636633,
+    0.008768700134139385462955047269, 0.00833056343336287125646931866,
+    0.007934114564314020547249562491, 0.007573675487951840794972024212,
+    0.007244554301320383179546196602, 0.006942840107209529865664152663,
+    0.006665247032707682442356180895, 0.006408994188004207068439631083,
+    0.006171712263039457647534604798, 0.005951370112758847735624416046,
+    0.005746216513010115682026102477, 0.00555473355196280137103868996};
+
+constexpr double kS0 = 1.0 / 12.0;
+constexpr double kS1 = 1.0 / 360.0;
+constexpr double kS2 = 1.0 / 1260.0;
+constexpr double kS3 = 1.0 / 1680.0;
+constexpr double kS4 = 1.0 / 1188.0;
+
+DSQ_DEV double dstirlerr(double n) {
+    if (n <= 15.0) {
+        double nn = n + n;
+        int inn = (int)nn;
+        if (nn == (double)inn) return kSferrHalves[inn];
+        return dlgamma(n + 1.0) - (n + 0.5) * dlog(n) + n - kLnSqrt2Pi;
+    }
+    double nn = n * n;
+    if (n > 500.0) return (kS0 - kS1 / nn) / n;
+    if (n > 80.0) return (kS0 - (kS1 - kS2 / nn) / nn) / n;
+    if (n > 35.0) return (kS0 - (kS1 - (kS2 - kS3 / nn) / nn) / nn) / n;
+    return (kS0 - (kS1 - (kS2 - (kS3 - kS4 / nn) / nn) / nn) / nn) / n;
+}
+
+// ---------------------------------------------------------------------- bd0
+DSQ_DEV double dbd0(double x, double np) {
+    if (!dfinite(x) || !dfinite(np) || np == 0.0) return dnan();
+    if (__builtin_fabs(x - np) < 0.1 * (x + np)) {
+        double v = (x - np) / (x + np);
+        double s = (x - np) * v;
+        if (__builtin_fabs(s) < kDblMin) return s;
+        double ej = 2.0 * x * v;
+        v = v * v;
+        for (int j = 1; j < 1000; j++) {
+            ej = ej * v;
+            double s1 = s + ej / (double)((j << 1) + 1);
+            if (s1 == s) return s1;
+            s = s1;
+        }
+    }
+    return x * dlog(x / np) + np - x;
+}
+
+DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q) {
+    if (p == 0.0) return (x == 0.0) ? 0.0 : -kInf;
+    if (q == 0.0) return (x == n) ? 0.0 : -kInf;
+    if (x == 0.0) {
+        if (n == 0.0) return 0.0;
+        return (p < 0.1) ? -dbd0(n, n * q) - n * p : n * dlog(q);
+    }
+    if (x == n) {
+        return (q < 0.1) ? -dbd0(n, n * p) - n * q : n * dlog(p);
+    }
+    if (x < 0.0 || x > n) return -kInf;
+    double lc = dstirlerr(n) - dstirlerr(x) - dstirlerr(n - x) - dbd0(x, n * p) - dbd0(n - x, n * q);
+    double lf = kLn2Pi + dlog(x) + dlog1p(-x / n);
+    return lc - 0.5 * lf;
+}
+
+DSQ_DEV double dpois_raw_log(double x, double lambda) {
+    if (lambda == 0.0) return (x == 0.0) ? 0.0 : -kInf;
+    if (!dfinite(lambda)) return -kInf;
+    if (x < 0.0) return -kInf;
+    if (x <= lambda * kDblMin) return -lambda;
+    if (lambda < x * kDblMin) {
+        if (!dfinite(x)) return -kInf;
+        return -lambda + x * dlog(lambda) - dlgamma(x + 1.0);
+    }
+    return -0.5 * dlog(kTwoPi * x) + (-dstirlerr(x) - dbd0(x, lambda));
+}
+
+// log NB(x; size, mu) for a non-negative integer-valued x (saddle-point form).
+DSQ_DEV double dnbinom_mu_log(double x, double size, double mu) {
+    if (x != x || size != size || mu != mu) return x + size + mu;
+    if (mu < 0.0 || size < 0.0) return dnan();
+    if (x < 0.0 || !dfinite(x)) return -kInf;
+    if (x == 0.0 && size == 0.0) return 0.0;
+    if (!dfinite(size)) return dpois_raw_log(x, mu);
+    if (x == 0.0)
+        return size * (size < mu ? dlog(size / (size + mu)) : dlog1p(-mu / (size + mu)));
+    if (x < 1e-10 * size) {
+        double p = (size < mu ? dlog(size / (1.0 + size / mu)) : dlog(mu / (1.0 + mu / size)));
+        return x * p - mu - dlgamma(x + 1.0) + dlog1p(x * (x - 1.0) / (2.0 * size));
+    }
+    double p = size / (size + x);
+    double ans = dbinom_raw_log(size, x + size, size / (size + mu), mu / (size + mu));
+    return dlog(p) + ans;
+}
+
+}  // namespace dsq

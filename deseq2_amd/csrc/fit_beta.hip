@@ -1,0 +1,377 @@
+// fit_beta.hip -- gfx950 kernel replacing fitBeta (src/DESeq2.cpp:283-465): ridge-
+// penalised IRLS for the NB-GLM coefficients, hat diagonals, sandwich covariance and
+// contrast, one wavefront per gene.
+//
+// Per IRLS iteration a wave makes lane-strided passes over its gene's m samples:
+//   A  w = [wts] mu/(1+alpha mu), sqrt(w), z = log(mu/nf) + (y-mu)/mu   -> wave slab
+//   B  weighted least squares for beta
+//        useQR : Householder QR of [sqrt(w) X ; sqrt(ridge)] ((m+p) x p), LAPACK dgeqr2
+//                order.  The reflected matrix is never stored: a row's state after k
+//                reflections depends only on its initial value and the k wave-uniform
+//                reflector parameters, so each of the p stages re-derives its rows on the
+//                fly ("replay") and needs one round of p-k+1 wave reductions.
+//        else  : normal equations X'WX + ridge by one pass + LU (partial pivoting)
+//   C  mu = max(nf exp(X beta), minmu); deviance = -2 sum [wts] log NB(y; 1/alpha, mu)
+// The convergence test and the |beta| > 30 / NaN aborts are wave-uniform scalar flow.
+// Slab (mu, sqrt(w), sqrt(w) z per sample) lives in wave-private LDS, X in a block-shared
+// LDS slab; when m*p is too large for that both fall back to L2-resident global memory.
+#include "dsq_internal.hpp"
+#include "dsq_math.hpp"
+#include "dsq_wave.hpp"
+
+namespace dsq {
+
+template <int P>
+struct SymNB { static constexpr int value = P * (P + 1) / 2; };
+
+static constexpr int kSlabVecs = 3;  // mu, sqrt(w), sqrt(w)*z
+
+template <int P, bool USE_W, bool STAGE>
+__global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    const int M = m + P;
+    constexpr int N = SymNB<P>::value;
+
+    const double *xs;
+    double *slab;
+    if constexpr (STAGE) {
+        double *xl = smem;
+        for (int t = threadIdx.x; t < P * m; t += blockDim.x) xl[t] = kp.x[t];
+        __syncthreads();
+        xs = xl;
+        slab = smem + (size_t)P * m + (size_t)wave * m * kSlabVecs;
+    } else {
+        xs = kp.x;
+        slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
+    }
+    double *mu_s = slab, *sw_s = slab + m, *b_s = slab + 2 * (size_t)m;
+
+    double lambda[P], contrast[P];
+#pragma unroll
+    for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
+    const double large = 30.0;
+
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double alpha = kp.alpha_hat[g];
+        const double size = 1.0 / alpha;
+
+        double beta[P];
+#pragma unroll
+        for (int c = 0; c < P; c++) beta[c] = kp.beta_init[(size_t)g + (size_t)kp.n * c];
+
+        // mu_hat = nfrow % exp(x * beta_hat), clamped at minmu            (:324-327, :361-364)
+        auto update_mu = [&]() {
+            for (int j = lane; j < m; j += 64) {
+                double eta = xs[j] * beta[0];
+#pragma unroll
+                for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta[c], eta);
+                mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
+            }
+        };
+        // w_vec / w_sqrt_vec                                      (:336-342, :390-396, :430-436)
+        auto wvec = [&](int j, double mu) -> double {
+            if constexpr (USE_W) return (wg[j] * mu) / (1.0 + alpha * mu);
+            else return mu / (1.0 + alpha * mu);
+        };
+
+        update_mu();
+        double dev = 0.0, dev_old = 0.0;
+        double it = 0.0;
+        for (int t = 0; t < kp.maxit; t++) {
+            it += 1.0;
+            if (kp.useQR) {
+                // pass A                                                       (:336-353)
+                for (int j = lane; j < m; j += 64) {
+                    double mu = mu_s[j];
+                    double sw = __builtin_sqrt(wvec(j, mu));
+                    double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                    sw_s[j] = sw;
+                    b_s[j] = z * sw;
+                }
+                // pass B: Householder QR by replay                              (:344-356)
+                double scalS[P], tS[P][P + 1], Rm[P][P], gamma[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    double acc[P + 1];
+#pragma unroll
+                    for (int j = 0; j <= P; j++) acc[j] = 0.0;
+                    double prow[P + 1];
+#pragma unroll
+                    for (int j = 0; j <= P; j++) prow[j] = 0.0;
+                    for (int i = lane; i < M; i += 64) {
+                        double a[P], b;
+                        if (i < m) {
+                            double sw = sw_s[i];
+#pragma unroll
+                            for (int c = 0; c < P; c++) a[c] = xs[c * m + i] * sw;
+                            b = b_s[i];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < P; c++) a[c] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
+                            b = 0.0;
+                        }
+#pragma unroll
+                        for (int s = 0; s < k; s++) {
+                            if (i > s) {
+                                double v = a[s] * scalS[s];
+#pragma unroll
+                                for (int j = s + 1; j < P; j++) a[j] = __builtin_fma(v, tS[s][j], a[j]);
+                                b = __builtin_fma(v, tS[s][P], b);
+                            }
+                            // rows i <= s are finished rows of R: never revisited (i >= k > s)
+                        }
+                        if (i > k) {
+#pragma unroll
+                            for (int j = k; j < P; j++) acc[j] += a[k] * a[j];
+                            acc[P] += a[k] * b;
+                        } else if (i == k) {
+#pragma unroll
+                            for (int j = k; j < P; j++) prow[j] = a[j];
+                            prow[P] = b;
+                        }
+                    }
+                    // reductions S_kj, j = k..P, and the pivot row from lane k
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        double tt[P + 1];
+#pragma unroll
+                        for (int j = k; j <= P; j++) tt[j] = __shfl_xor(acc[j], off, 64);
+#pragma unroll
+                        for (int j = k; j <= P; j++) acc[j] = acc[j] + tt[j];
+                    }
+#pragma unroll
+                    for (int j = k; j <= P; j++) prow[j] = __shfl(prow[j], k, 64);
+                    double alpha_k = prow[k];
+                    double tau, scal, bet;
+                    if (acc[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                    else {
+                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acc[k]), alpha_k);
+                        tau = (bet - alpha_k) / bet;
+                        scal = 1.0 / (alpha_k - bet);
+                    }
+                    scalS[k] = scal;
+#pragma unroll
+                    for (int j = k + 1; j <= P; j++) {
+                        double wj = prow[j] + scal * acc[j];
+                        tS[k][j] = -tau * wj;
+                    }
+                    Rm[k][k] = bet;
+#pragma unroll
+                    for (int j = k + 1; j < P; j++) Rm[k][j] = prow[j] + tS[k][j];
+                    gamma[k] = prow[P] + tS[k][P];
+                }
+#pragma unroll
+                for (int i = P - 1; i >= 0; i--) {
+                    double tt = gamma[i];
+#pragma unroll
+                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-Rm[i][j], beta[j], tt);
+                    beta[i] = tt / Rm[i][i];
+                }
+            } else {
+                // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))  (:398)
+                double acc[N + P];
+#pragma unroll
+                for (int i = 0; i < N + P; i++) acc[i] = 0.0;
+                for (int j = lane; j < m; j += 64) {
+                    double mu = mu_s[j];
+                    double wv = wvec(j, mu);
+                    double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                    double xr[P];
+#pragma unroll
+                    for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
+                    int idx = 0;
+#pragma unroll
+                    for (int a = 0; a < P; a++) {
+#pragma unroll
+                        for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
+                        acc[N + a] += xr[a] * (z * wv);
+                    }
+                }
+                wave_allreduce_n(acc);
+                LU<P> lu;
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < P; a++)
+#pragma unroll
+                    for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
+#pragma unroll
+                for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+                lu.factor();
+                double rhs[P];
+#pragma unroll
+                for (int a = 0; a < P; a++) rhs[a] = acc[N + a];
+                lu.solve(rhs);
+#pragma unroll
+                for (int a = 0; a < P; a++) beta[a] = rhs[a];
+            }
+            int toolarge = 0;
+#pragma unroll
+            for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                  // (:357-360)
+            update_mu();
+            double dacc = 0.0;                                                            // (:365-373)
+            for (int j = lane; j < m; j += 64) {
+                double d = dnbinom_mu_log((double)yg[j], size, mu_s[j]);
+                double term;
+                if constexpr (USE_W) term = (-2.0 * wg[j]) * d;
+                else term = -2.0 * d;
+                dacc += term;
+            }
+            dev = wave_allreduce(dacc);
+            double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
+            if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }        // (:375-378)
+            if (uniform((t > 0) && (conv_test < kp.tol))) break;                          // (:379-381)
+            dev_old = dev;
+        }
+
+        // ---- post-loop block (:427-455) ------------------------------------------------
+        double gacc[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) gacc[i] = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double wv = wvec(j, mu_s[j]);
+            sw_s[j] = __builtin_sqrt(wv);
+            double xr[P];
+#pragma unroll
+            for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
+        }
+        wave_allreduce_n(gacc);
+        double G[P][P], Gi[P][P];
+        {
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) { G[a][b] = gacc[idx]; G[b][a] = gacc[idx]; idx++; }
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = G[a][b];
+#pragma unroll
+            for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+            lu.factor();
+            lu.inverse(Gi);
+        }
+        // hat diagonal, loop order of :443-449; fitted means (extension)
+        if (kp.hat_diagonals || kp.mu_out) {
+            for (int j = lane; j < m; j += 64) {
+                if (kp.hat_diagonals) {
+                    double sw = sw_s[j];
+                    double h = 0.0;
+#pragma unroll
+                    for (int i1 = 0; i1 < P; i1++)
+#pragma unroll
+                        for (int i2 = 0; i2 < P; i2++) {
+                            double xw1 = xs[i1 * m + j] * sw;
+                            double xw2 = xs[i2 * m + j] * sw;
+                            h += xw1 * (xw2 * Gi[i2][i1]);
+                        }
+                    kp.hat_diagonals[(size_t)g * kp.ld + j] = h;
+                }
+                if (kp.mu_out) {
+                    double eta = xs[j] * beta[0];
+#pragma unroll
+                    for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta[c], eta);
+                    double v = nfg[j] * dexp(eta);
+                    if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
+                    kp.mu_out[(size_t)g * kp.ld + j] = v;
+                }
+            }
+        }
+        // sigma = Gi * G * Gi                                                            (:452)
+        double T[P][P], Sg[P][P];
+        mat_mul<P>(Gi, G, T);
+        mat_mul<P>(T, Gi, Sg);
+        double cn = 0.0;
+#pragma unroll
+        for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
+        double cd = 0.0;
+#pragma unroll
+        for (int b = 0; b < P; b++) {
+            double rr = 0.0;
+#pragma unroll
+            for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[a][b], rr);
+            cd = __builtin_fma(rr, contrast[b], cd);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < P; c++) {
+                kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
+                kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[c][c];
+            }
+            kp.iter[g] = it;
+            kp.deviance[g] = dev;
+            kp.contrast_num[g] = cn;
+            kp.contrast_denom[g] = __builtin_sqrt(cd);
+        }
+    }
+}
+
+// ---- launch ---------------------------------------------------------------------
+static constexpr size_t kBetaLdsBudget = 64 * 1024;
+
+static inline size_t beta_lds_doubles(int m, int p, int waves) {
+    return (size_t)p * m + (size_t)waves * m * kSlabVecs;
+}
+
+static inline void beta_geometry(int n, int m, int p, int *waves, bool *stage, int *grid) {
+    *waves = 4;
+    *stage = false;
+    for (int w = 4; w >= 1; w >>= 1) {
+        if (beta_lds_doubles(m, p, w) * sizeof(double) <= kBetaLdsBudget) { *waves = w; *stage = true; break; }
+    }
+    const int cus = device_cu_count();
+    int blocks_needed = (n + *waves - 1) / *waves;
+    int cap = *stage ? cus * 16 : cus * 4;
+    *grid = blocks_needed < cap ? blocks_needed : cap;
+    if (*grid < 1) *grid = 1;
+}
+
+#ifndef DSQ_P
+#error "compile with -DDSQ_P=<number of design columns>"
+#endif
+
+#if DSQ_P == 1
+size_t fit_beta_scratch_bytes(int m, int p, int /*use_weights*/) {
+    int waves, grid;
+    bool stage;
+    beta_geometry(1 << 30, m, p, &waves, &stage, &grid);
+    if (stage) return 0;
+    return (size_t)grid * waves * (size_t)m * kSlabVecs * sizeof(double);
+}
+#endif
+
+template <>
+hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp, hipStream_t st) {
+    int waves, grid;
+    bool stage;
+    beta_geometry(kp.n, kp.m, DSQ_P, &waves, &stage, &grid);
+    if (stage) {
+        size_t lds = beta_lds_doubles(kp.m, DSQ_P, waves) * sizeof(double);
+        if (kp.useWeights)
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
+        else
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    } else {
+        if (kp.useWeights)
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false>), dim3(grid), dim3(64 * waves), 0, st, kp);
+        else
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false>), dim3(grid), dim3(64 * waves), 0, st, kp);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dsq

@@ -1,0 +1,389 @@
+// fit_disp.hip -- gfx950 kernels replacing fitDisp (src/DESeq2.cpp:164-277) and
+// fitDispGrid (:469-513): Cox-Reid adjusted profile-likelihood dispersion fit.
+//
+// One wavefront per gene.  Lane l owns samples l, l+64, ...; the gene's row (counts as
+// f64, mu_hat, weights) sits in a wave-private LDS slab and the design matrix X in a
+// block-shared slab, so the ~20 log_posterior / ~7 dlog_posterior evaluations per gene
+// re-read LDS, not HBM.  Each evaluation is one lane-strided pass producing
+// 1 + p(p+1)/2 partial sums that are xor-butterflied across the wave; the p x p
+// determinant / inverse / traces are wave-uniform register math (LU, partial pivoting).
+// The Armijo line search itself is wave-uniform scalar control flow.
+#include "dsq_internal.hpp"
+#include "dsq_math.hpp"
+#include "dsq_rows.hpp"
+#include "dsq_wave.hpp"
+
+namespace dsq {
+
+template <int P>
+struct SymN { static constexpr int value = P * (P + 1) / 2; };
+
+template <int P, bool USE_W, class Rows>
+struct DispGene {
+    Rows r;
+    int m, lane;
+    double prior_mean, prior_sigmasq, thr;
+    bool usePrior, useCR;
+    unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
+
+    DSQ_DEV bool keep_row(int j) const {
+        if constexpr (USE_W) return r.w(j) > thr;
+        return true;
+    }
+
+    // x = x.rows(find(wts > weightThreshold)); x = x.cols(find(sum(abs(x)) > 0.0))
+    DSQ_DEV void setup_cr() {
+        dropmask = 0u;
+        if constexpr (USE_W) {
+            if (useCR) {
+#pragma unroll
+                for (int c = 0; c < P; c++) {
+                    bool any = false;
+                    for (int j = lane; j < m; j += 64)
+                        if (keep_row(j) && __builtin_fabs(r.x(j, c)) > 0.0) any = true;
+                    if (!__any(any)) dropmask |= (1u << c);
+                }
+            }
+        }
+    }
+
+    // K matrices X' diag(wd_k) X over the kept rows; wfun(mu, wd[K]) gives the diagonals.
+    // A dropped column contributes exact zeros; putting 1 on its diagonal in the first
+    // matrix leaves det / inverse / traces equal to those of the compacted matrix.
+    template <int K, class F>
+    DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
+        constexpr int N = SymN<P>::value;
+        double acc[K * N];
+#pragma unroll
+        for (int i = 0; i < K * N; i++) acc[i] = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double wd[K];
+            wfun(r.mu(j), wd);
+            if (keep_row(j)) {
+                double xr[P];
+#pragma unroll
+                for (int c = 0; c < P; c++) xr[c] = r.x(j, c);
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < P; a++)
+#pragma unroll
+                    for (int b = a; b < P; b++) {
+#pragma unroll
+                        for (int k = 0; k < K; k++) acc[k * N + idx] += xr[a] * (xr[b] * wd[k]);
+                        idx++;
+                    }
+            }
+        }
+        wave_allreduce_n(acc);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) {
+                    B[k][a][b] = acc[k * N + idx];
+                    B[k][b][a] = acc[k * N + idx];
+                    idx++;
+                }
+        }
+        if constexpr (USE_W) {
+#pragma unroll
+            for (int c = 0; c < P; c++)
+                if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+        }
+    }
+
+    // log_posterior, src/DESeq2.cpp:31-64
+    DSQ_DEV double lp(double la) const {
+        double alpha = dexp(la);
+        double cr_term = 0.0;
+        if (useCR) {
+            double B[1][P][P];
+            gram<1>([&](double mu, double(&wd)[1]) { wd[0] = 1.0 / (1.0 / mu + alpha); }, B);
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+            lu.factor();
+            cr_term = -0.5 * dlog(lu.det());
+        }
+        double an1 = 1.0 / alpha;
+        double lg_an1 = dlgamma(an1);
+        double acc = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double y = r.y(j), mu = r.mu(j);
+            double t = dlgamma(y + an1) - lg_an1 - y * dlog(mu + an1) - an1 * dlog(1.0 + mu * alpha);
+            if constexpr (USE_W) t = r.w(j) * t;
+            acc += t;
+        }
+        double ll_part = wave_allreduce(acc);
+        double prior_part = 0.0;
+        if (usePrior) {
+            double d = la - prior_mean;
+            prior_part = -0.5 * (d * d) / prior_sigmasq;
+        }
+        return ll_part + prior_part + cr_term;
+    }
+
+    // dlog_posterior, src/DESeq2.cpp:68-107
+    DSQ_DEV double dlp(double la, bool withPrior) const {
+        double alpha = dexp(la);
+        double cr_term = 0.0;
+        if (useCR) {
+            double B[2][P][P];
+            gram<2>(
+                [&](double mu, double(&wd)[2]) {
+                    double t = 1.0 / mu + alpha;
+                    wd[0] = 1.0 / t;
+                    wd[1] = -1.0 * (1.0 / (t * t));
+                },
+                B);
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+            lu.factor();
+            double detb = lu.det();
+            double Bi[P][P];
+            lu.inverse(Bi);
+            double ddetb = detb * trace_prod<P>(Bi, B[1]);
+            cr_term = -0.5 * ddetb / detb;
+        }
+        double an1 = 1.0 / alpha;
+        double an2 = 1.0 / (alpha * alpha);
+        double dg_an1 = ddigamma(an1);
+        double acc = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double y = r.y(j), mu = r.mu(j);
+            double ma = mu * alpha;
+            double t = dg_an1 + dlog(1.0 + ma) - ma * (1.0 / (1.0 + ma)) - ddigamma(y + an1) +
+                       y * (1.0 / (mu + an1));
+            if constexpr (USE_W) t = r.w(j) * t;
+            acc += t;
+        }
+        double ll_part = an2 * wave_allreduce(acc);
+        double prior_part = 0.0;
+        if (withPrior) prior_part = -1.0 * (la - prior_mean) / prior_sigmasq;
+        return (ll_part + cr_term) * alpha + prior_part;
+    }
+
+    // d2log_posterior, src/DESeq2.cpp:111-158
+    DSQ_DEV double d2lp(double la) const {
+        double alpha = dexp(la);
+        double cr_term = 0.0;
+        if (useCR) {
+            double B[3][P][P];
+            gram<3>(
+                [&](double mu, double(&wd)[3]) {
+                    double t = 1.0 / mu + alpha;
+                    wd[0] = 1.0 / t;
+                    wd[1] = -1.0 * (1.0 / (t * t));
+                    wd[2] = 2.0 * (1.0 / (t * t * t));
+                },
+                B);
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+            lu.factor();
+            double detb = lu.det();
+            double Bi[P][P], M[P][P];
+            lu.inverse(Bi);
+            double tr1 = trace_prod<P>(Bi, B[1]);
+            double ddetb = detb * tr1;
+            mat_mul<P>(Bi, B[1], M);
+            double tr2 = trace_prod<P>(M, M);
+            double tr3 = trace_prod<P>(Bi, B[2]);
+            double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
+            double rr = ddetb / detb;
+            cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;
+        }
+        double an1 = 1.0 / alpha;
+        double an2 = 1.0 / (alpha * alpha);
+        double an3 = 1.0 / (alpha * (alpha * alpha));
+        double dg_an1 = ddigamma(an1), tg_an1 = dtrigamma(an1);
+        double acc1 = 0.0, acc2 = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double y = r.y(j), mu = r.mu(j);
+            double ma = mu * alpha, opm = 1.0 + ma, mpa = mu + an1;
+            double t1 = dg_an1 + dlog(opm) - ma * (1.0 / opm) - ddigamma(y + an1) + y * (1.0 / mpa);
+            double t2 = -1.0 * an2 * tg_an1 + (mu * mu) * alpha * (1.0 / (opm * opm)) +
+                        an2 * dtrigamma(y + an1) + an2 * y * (1.0 / (mpa * mpa));
+            if constexpr (USE_W) {
+                double w = r.w(j);
+                t1 = w * t1;
+                t2 = w * t2;
+            }
+            acc1 += t1;
+            acc2 += t2;
+        }
+        double s1 = wave_allreduce(acc1), s2 = wave_allreduce(acc2);
+        double ll_part = -2.0 * an3 * s1 + an2 * s2;
+        double prior_part = usePrior ? -1.0 / prior_sigmasq : 0.0;
+        double dlp0 = dlp(la, false);
+        return ((ll_part + cr_term) * (alpha * alpha) + dlp0) + prior_part;
+    }
+};
+
+// ---- staging --------------------------------------------------------------------
+// LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | (w m) ]
+template <bool USE_W>
+__host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves) {
+    return (size_t)p * m + (size_t)waves * m * (USE_W ? 3 : 2);
+}
+
+template <int P, bool USE_W, bool STAGE, bool GRID>
+__global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+
+    double *xs = smem;
+    double *slab = smem + (size_t)P * m + (size_t)wave * m * (USE_W ? 3 : 2);
+    if constexpr (STAGE) {
+        for (int t = threadIdx.x; t < P * m; t += blockDim.x) xs[t] = kp.x[t];
+        __syncthreads();
+    }
+
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *mug = kp.mu_hat + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+
+        using Rows = typename std::conditional<STAGE, RowsLds, RowsGlobal>::type;
+        DispGene<P, USE_W, Rows> G;
+        if constexpr (STAGE) {
+            double *ys = slab, *ms = slab + m, *ws = slab + 2 * (size_t)m;
+            for (int j = lane; j < m; j += 64) {
+                ys[j] = (double)yg[j];
+                ms[j] = mug[j];
+                if constexpr (USE_W) ws[j] = wg[j];
+            }
+            G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
+        } else {
+            G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
+        }
+        G.m = m; G.lane = lane;
+        G.prior_mean = kp.prior_mean[g];
+        G.prior_sigmasq = kp.prior_sigmasq;
+        G.thr = kp.weightThreshold;
+        G.usePrior = kp.usePrior != 0;
+        G.useCR = kp.useCR != 0;
+        G.setup_cr();
+
+        if constexpr (GRID) {
+            // fitDispGrid, src/DESeq2.cpp:492-510
+            const int ng = kp.ngrid;
+            const double delta = kp.grid[1] - kp.grid[0];
+            int idx = 0;
+            double best = 0.0;
+            for (int t = 0; t < ng; t++) {
+                double v = G.lp(kp.grid[t]);
+                if (t == 0 || v > best) { best = v; idx = t; }
+            }
+            double a_hat = kp.grid[idx];
+            double start = a_hat - delta, end = a_hat + delta;
+            double step = (end >= start) ? (end - start) / (double)(ng - 1)
+                                         : -(start - end) / (double)(ng - 1);
+            double afine = start;
+            for (int t = 0; t < ng; t++) {
+                double a = (t == ng - 1) ? end : start + (double)t * step;
+                double v = G.lp(a);
+                if (t == 0 || v > best) { best = v; afine = a; }
+            }
+            if (lane == 0) kp.log_alpha[g] = afine;
+        } else {
+            // fitDisp, src/DESeq2.cpp:194-266
+            const double epsilon = 1.0e-4;
+            double a = kp.log_alpha_in[g];
+            double lp = G.lp(a);
+            double dlp = G.dlp(a, G.usePrior);
+            double kappa = kp.kappa_0;
+            const double initial_lp = lp, initial_dlp = dlp;
+            double change = -1.0;
+            int it = 0, it_acc = 0;
+            for (int t = 0; t < kp.maxit; t++) {
+                it++;
+                double a_propose = a + kappa * dlp;
+                if (a_propose < -30.0) kappa = (-30.0 - a) / dlp;
+                if (a_propose > 10.0) kappa = (10.0 - a) / dlp;
+                const double a_try = a + kappa * dlp;
+                // the reference evaluates log_posterior(a + kappa*dlp) for the Armijo test and
+                // again after accepting (:225,:233): same argument, same value -> evaluated once
+                const double lp_try = G.lp(a_try);
+                double theta_kappa = -1.0 * lp_try;
+                double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);
+                if (uniform(theta_kappa <= theta_hat_kappa)) {
+                    it_acc++;
+                    a = a_try;
+                    double lpnew = lp_try;
+                    change = lpnew - lp;
+                    if (uniform(change < kp.tol)) { lp = lpnew; break; }
+                    if (uniform(a < kp.min_log_alpha)) break;
+                    lp = lpnew;
+                    dlp = G.dlp(a, G.usePrior);
+                    kappa = __builtin_fmin(kappa * 1.1, kp.kappa_0);
+                    if (it_acc % 5 == 0) kappa = kappa / 2.0;
+                } else {
+                    kappa = kappa / 2.0;
+                }
+            }
+            double d2 = G.d2lp(a);
+            if (lane == 0) {
+                kp.log_alpha[g] = a;
+                kp.iter[g] = it;
+                kp.iter_accept[g] = it_acc;
+                kp.last_change[g] = change;
+                kp.initial_lp[g] = initial_lp;
+                kp.initial_dlp[g] = initial_dlp;
+                kp.last_lp[g] = lp;
+                kp.last_dlp[g] = dlp;
+                kp.last_d2lp[g] = d2;
+            }
+        }
+    }
+}
+
+// ---- launch ---------------------------------------------------------------------
+static constexpr size_t kLdsBudget = 64 * 1024;  // per block: leaves >= 2 blocks per CU
+
+template <int P, bool USE_W, bool GRID>
+static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
+    int waves = 4;
+    bool stage = false;
+    for (int w = 4; w >= 1; w >>= 1) {
+        if (disp_lds_doubles<USE_W>(kp.m, P, w) * sizeof(double) <= kLdsBudget) { waves = w; stage = true; break; }
+    }
+    const int cus = device_cu_count();
+    int blocks_needed = (kp.n + waves - 1) / waves;
+    int grid = blocks_needed < cus * 16 ? blocks_needed : cus * 16;
+    if (grid < 1) grid = 1;
+    if (stage) {
+        size_t lds = disp_lds_doubles<USE_W>(kp.m, P, waves) * sizeof(double);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, GRID>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    } else {
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, GRID>), dim3(grid), dim3(64 * waves), 0, st, kp);
+    }
+    return hipGetLastError();
+}
+
+// One translation unit per design width: compiled with -DDSQ_P=<p> (csrc/Makefile), so the
+// fully unrolled p x p register math of each width builds in parallel.
+#ifndef DSQ_P
+#error "compile with -DDSQ_P=<number of design columns>"
+#endif
+
+template <>
+hipError_t launch_fit_disp_p<DSQ_P>(const DispKernelParams &kp, hipStream_t st, bool grid) {
+    if (grid)
+        return kp.useWeights ? launch_disp_p<DSQ_P, true, true>(kp, st) : launch_disp_p<DSQ_P, false, true>(kp, st);
+    return kp.useWeights ? launch_disp_p<DSQ_P, true, false>(kp, st) : launch_disp_p<DSQ_P, false, false>(kp, st);
+}
+
+}  // namespace dsq

@@ -1,0 +1,288 @@
+"""Python mirror of the reference's R/RcppExports.R:4,8,12 -- the three `.Call` stubs
+`fitDisp`, `fitBeta`, `fitDispGrid` -- bound to the MI355X engine instead of
+src/DESeq2.cpp.  Same argument names, same order, same return-list member names and
+types (`fitBeta$iter` is double, `fitDisp$iter` is integer; `contrast_num/denom` are
+n x 1 matrices; src/DESeq2.cpp:268-276, 458-464, 512).
+
+Two flavours:
+  fitBeta / fitDisp / fitDispGrid             numpy in, numpy out (host pointers through
+                                              dsq_fit_*; what the R shim does)
+  fitBeta_dev / fitDisp_dev / fitDispGrid_dev torch CUDA tensors in/out through
+                                              dsq_fit_*_dev on the current stream; matrices
+                                              may be R-layout or gene-major.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _fcol(a, dtype=np.float64):
+    """numpy array in R memory order (column-major)"""
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _counts(y):
+    y = np.asarray(y)
+    if y.dtype.kind in "iu" or y.dtype == np.bool_:
+        return np.asfortranarray(y.astype(np.int32, copy=False)), L.DSQ_Y_INT32
+    return np.asfortranarray(y.astype(np.float64, copy=False)), L.DSQ_Y_FLOAT64
+
+
+def _scalar_len1(v, name):
+    a = np.asarray(v, dtype=np.float64).reshape(-1)
+    if a.size != 1:
+        raise ValueError("%s must be a single value" % name)
+    return float(a[0])
+
+
+def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lambdaSEXP, weightsSEXP,
+            useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, want_mu=False, mu_floor=0.0,
+            want_hat=True):
+    y, ytype = _counts(ySEXP)
+    x = _fcol(xSEXP); nf = _fcol(nfSEXP); b0 = _fcol(beta_matSEXP)
+    if y.ndim != 2 or x.ndim != 2:
+        raise ValueError("ySEXP and xSEXP must be matrices")
+    n, m = y.shape
+    p = x.shape[1]
+    if x.shape[0] != m or nf.shape != (n, m) or b0.shape != (n, p):
+        raise ValueError("non-conformable arguments")
+    useW = bool(useWeightsSEXP)
+    w = _fcol(weightsSEXP) if (useW or weightsSEXP is not None) else None
+    if w is not None and w.shape != (n, m):
+        raise ValueError("weights must be n x m")
+    alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_hatSEXP, np.float64).reshape(-1), (n,)))
+    contrast = np.ascontiguousarray(np.asarray(contrastSEXP, np.float64).reshape(-1))
+    lam = np.ascontiguousarray(np.asarray(lambdaSEXP, np.float64).reshape(-1))
+    if contrast.size != p or lam.size != p:
+        raise ValueError("contrast and lambda must have length ncol(x)")
+    out = {"beta_mat": np.zeros((n, p), order="F"), "beta_var_mat": np.zeros((n, p), order="F"),
+           "iter": np.zeros(n), "hat_diagonals": np.zeros((n, m), order="F") if want_hat else None,
+           "contrast_num": np.zeros((n, 1)), "contrast_denom": np.zeros((n, 1)), "deviance": np.zeros(n)}
+    mu = np.zeros((n, m), order="F") if want_mu else None
+    a = L.DsqFitBetaArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, x=_ptr(x),
+                         nf=_ptr(nf), nf_is_vector=0, alpha_hat=_ptr(alpha), contrast=_ptr(contrast),
+                         beta_mat=_ptr(b0), lambda_=_ptr(lam), weights=_ptr(w) if useW else None,
+                         useWeights=int(useW), tol=_scalar_len1(tolSEXP, "tol"),
+                         maxit=int(_scalar_len1(maxitSEXP, "maxit")), useQR=int(bool(useQRSEXP)),
+                         minmu=_scalar_len1(minmuSEXP, "minmu"))
+    o = L.DsqFitBetaOut(beta_mat=_ptr(out["beta_mat"]), beta_var_mat=_ptr(out["beta_var_mat"]),
+                        iter=_ptr(out["iter"]), hat_diagonals=_ptr(out["hat_diagonals"]),
+                        contrast_num=_ptr(out["contrast_num"]), contrast_denom=_ptr(out["contrast_denom"]),
+                        deviance=_ptr(out["deviance"]), mu=_ptr(mu), mu_floor=float(mu_floor))
+    L.check(L.lib().dsq_fit_beta(C.byref(a), C.byref(o)))
+    if want_mu:
+        out["mu"] = mu
+    return out
+
+
+def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP, log_alpha_prior_sigmasqSEXP,
+            min_log_alphaSEXP, kappa_0SEXP, tolSEXP, maxitSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP,
+            weightThresholdSEXP, useCRSEXP):
+    y, ytype = _counts(ySEXP)
+    x = _fcol(xSEXP); mu = _fcol(mu_hatSEXP)
+    n, m = y.shape
+    p = x.shape[1]
+    if x.shape[0] != m or mu.shape != (n, m):
+        raise ValueError("non-conformable arguments")
+    useW = bool(useWeightsSEXP)
+    w = _fcol(weightsSEXP) if useW else None
+    if w is not None and w.shape != (n, m):
+        raise ValueError("weights must be n x m")
+    la = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alphaSEXP, np.float64).reshape(-1), (n,)))
+    pm = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alpha_prior_meanSEXP, np.float64).reshape(-1), (n,)))
+    out = {k: np.zeros(n) for k in ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp",
+                                     "last_dlp", "last_d2lp")}
+    out["iter"] = np.zeros(n, dtype=np.int32)
+    out["iter_accept"] = np.zeros(n, dtype=np.int32)
+    a = L.DsqFitDispArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, x=_ptr(x),
+                         mu_hat=_ptr(mu), log_alpha=_ptr(la), log_alpha_prior_mean=_ptr(pm),
+                         log_alpha_prior_sigmasq=_scalar_len1(log_alpha_prior_sigmasqSEXP, "sigmasq"),
+                         min_log_alpha=_scalar_len1(min_log_alphaSEXP, "min_log_alpha"),
+                         kappa_0=_scalar_len1(kappa_0SEXP, "kappa_0"), tol=_scalar_len1(tolSEXP, "tol"),
+                         maxit=int(_scalar_len1(maxitSEXP, "maxit")), usePrior=int(bool(usePriorSEXP)),
+                         weights=_ptr(w), useWeights=int(useW),
+                         weightThreshold=_scalar_len1(weightThresholdSEXP, "weightThreshold"),
+                         useCR=int(bool(useCRSEXP)))
+    o = L.DsqFitDispOut(**{k: _ptr(v) for k, v in out.items()})
+    L.check(L.lib().dsq_fit_disp(C.byref(a), C.byref(o)))
+    return out
+
+
+def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEXP,
+                log_alpha_prior_sigmasqSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP, weightThresholdSEXP,
+                useCRSEXP):
+    y, ytype = _counts(ySEXP)
+    x = _fcol(xSEXP); mu = _fcol(mu_hatSEXP)
+    n, m = y.shape
+    p = x.shape[1]
+    if x.shape[0] != m or mu.shape != (n, m):
+        raise ValueError("non-conformable arguments")
+    useW = bool(useWeightsSEXP)
+    w = _fcol(weightsSEXP) if useW else None
+    grid = np.ascontiguousarray(np.asarray(disp_gridSEXP, np.float64).reshape(-1))
+    pm = np.ascontiguousarray(np.broadcast_to(np.asarray(log_alpha_prior_meanSEXP, np.float64).reshape(-1), (n,)))
+    la = np.zeros(n)
+    a = L.DsqFitDispGridArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, x=_ptr(x),
+                             mu_hat=_ptr(mu), disp_grid=_ptr(grid), ngrid=grid.size,
+                             log_alpha_prior_mean=_ptr(pm),
+                             log_alpha_prior_sigmasq=_scalar_len1(log_alpha_prior_sigmasqSEXP, "sigmasq"),
+                             usePrior=int(bool(usePriorSEXP)), weights=_ptr(w), useWeights=int(useW),
+                             weightThreshold=_scalar_len1(weightThresholdSEXP, "weightThreshold"),
+                             useCR=int(bool(useCRSEXP)))
+    o = L.DsqFitDispGridOut(log_alpha=_ptr(la))
+    L.check(L.lib().dsq_fit_disp_grid(C.byref(a), C.byref(o)))
+    return {"log_alpha": la}
+
+
+def test_math(op, a, b=None, c=None):
+    """Evaluate one device-math primitive on the GPU (parity hook, see dsq_test_math)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, np.float64), a.shape))
+    c = None if c is None else np.ascontiguousarray(np.broadcast_to(np.asarray(c, np.float64), a.shape))
+    out = np.empty_like(a)
+    L.check(L.lib().dsq_test_math(int(op), _ptr(a), _ptr(b), _ptr(c), _ptr(out), a.size))
+    return out
+
+
+# ------------------------------------------------------------------------------------
+# device-resident flavour: torch CUDA tensors, current stream, no host round trip
+# ------------------------------------------------------------------------------------
+def _t_ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class GeneMajor:
+    """n x m device matrix in the engine's native layout (row-major, leading dim ld)."""
+
+    def __init__(self, tensor, m):
+        assert tensor.dim() == 2 and tensor.is_contiguous()
+        self.t = tensor
+        self.n = tensor.shape[0]
+        self.ld = tensor.shape[1]
+        self.m = m
+
+    def view(self):
+        return self.t[:, : self.m]
+
+
+def gene_major_ld(m):
+    return (m + 7) & ~7
+
+
+def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWeights, tol, maxit, useQR,
+                minmu, want_hat=True, want_mu=False, mu_floor=0.0, nf_is_vector=False):
+    """All array arguments are torch CUDA tensors.  y / nf / weights: GeneMajor (y int32) --
+    outputs hat_diagonals / mu are GeneMajor too; x: (m, p) column-major i.e. a (p, m)
+    contiguous tensor is passed as `x` (see `design_to_device`)."""
+    import torch
+    assert isinstance(y, GeneMajor)
+    n, m, ld = y.n, y.m, y.ld
+    p = x.shape[0]
+    dev = y.t.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = {"beta_mat": torch.empty((p, n), **f64), "beta_var_mat": torch.empty((p, n), **f64),
+           "iter": torch.empty(n, **f64), "contrast_num": torch.empty(n, **f64),
+           "contrast_denom": torch.empty(n, **f64), "deviance": torch.empty(n, **f64)}
+    hat = GeneMajor(torch.empty((n, ld), **f64), m) if want_hat else None
+    mu = GeneMajor(torch.empty((n, ld), **f64), m) if want_mu else None
+    if nf_is_vector:
+        nf_ptr = _t_ptr(nf)
+    else:
+        assert isinstance(nf, GeneMajor) and nf.ld == ld
+        nf_ptr = _t_ptr(nf.t)
+    if useWeights:
+        assert isinstance(weights, GeneMajor) and weights.ld == ld
+    a = L.DsqFitBetaArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                         y_type=L.DSQ_Y_INT32, x=_t_ptr(x), nf=nf_ptr, nf_is_vector=int(nf_is_vector),
+                         alpha_hat=_t_ptr(alpha_hat), contrast=_t_ptr(contrast), beta_mat=_t_ptr(beta_mat),
+                         lambda_=_t_ptr(lambda_), weights=_t_ptr(weights.t) if useWeights else None,
+                         useWeights=int(bool(useWeights)), tol=float(tol), maxit=int(maxit),
+                         useQR=int(bool(useQR)), minmu=float(minmu))
+    o = L.DsqFitBetaOut(beta_mat=_t_ptr(out["beta_mat"]), beta_var_mat=_t_ptr(out["beta_var_mat"]),
+                        iter=_t_ptr(out["iter"]), hat_diagonals=_t_ptr(hat.t) if hat else None,
+                        contrast_num=_t_ptr(out["contrast_num"]), contrast_denom=_t_ptr(out["contrast_denom"]),
+                        deviance=_t_ptr(out["deviance"]), mu=_t_ptr(mu.t) if mu else None,
+                        mu_floor=float(mu_floor))
+    L.check(L.lib().dsq_fit_beta_dev(C.byref(a), C.byref(o), _stream()))
+    out["hat_diagonals"] = hat
+    out["mu"] = mu
+    return out
+
+
+def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_sigmasq, min_log_alpha,
+                kappa_0, tol, maxit, usePrior, weights, useWeights, weightThreshold, useCR):
+    import torch
+    assert isinstance(y, GeneMajor) and isinstance(mu_hat, GeneMajor) and mu_hat.ld == y.ld
+    n, m, ld = y.n, y.m, y.ld
+    p = x.shape[0]
+    dev = y.t.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = {k: torch.empty(n, **f64) for k in ("log_alpha", "last_change", "initial_lp", "initial_dlp",
+                                               "last_lp", "last_dlp", "last_d2lp")}
+    out["iter"] = torch.empty(n, dtype=torch.int32, device=dev)
+    out["iter_accept"] = torch.empty(n, dtype=torch.int32, device=dev)
+    a = L.DsqFitDispArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                         y_type=L.DSQ_Y_INT32, x=_t_ptr(x), mu_hat=_t_ptr(mu_hat.t), log_alpha=_t_ptr(log_alpha),
+                         log_alpha_prior_mean=_t_ptr(log_alpha_prior_mean),
+                         log_alpha_prior_sigmasq=float(log_alpha_prior_sigmasq),
+                         min_log_alpha=float(min_log_alpha), kappa_0=float(kappa_0), tol=float(tol),
+                         maxit=int(maxit), usePrior=int(bool(usePrior)),
+                         weights=_t_ptr(weights.t) if useWeights else None, useWeights=int(bool(useWeights)),
+                         weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
+    o = L.DsqFitDispOut(**{k: _t_ptr(v) for k, v in out.items()})
+    L.check(L.lib().dsq_fit_disp_dev(C.byref(a), C.byref(o), _stream()))
+    return out
+
+
+def fitDispGrid_dev(y, x, mu_hat, disp_grid, log_alpha_prior_mean, log_alpha_prior_sigmasq, usePrior, weights,
+                    useWeights, weightThreshold, useCR):
+    import torch
+    assert isinstance(y, GeneMajor) and isinstance(mu_hat, GeneMajor) and mu_hat.ld == y.ld
+    n, m, ld = y.n, y.m, y.ld
+    p = x.shape[0]
+    la = torch.empty(n, dtype=torch.float64, device=y.t.device)
+    a = L.DsqFitDispGridArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                             y_type=L.DSQ_Y_INT32, x=_t_ptr(x), mu_hat=_t_ptr(mu_hat.t),
+                             disp_grid=_t_ptr(disp_grid), ngrid=int(disp_grid.numel()),
+                             log_alpha_prior_mean=_t_ptr(log_alpha_prior_mean),
+                             log_alpha_prior_sigmasq=float(log_alpha_prior_sigmasq), usePrior=int(bool(usePrior)),
+                             weights=_t_ptr(weights.t) if useWeights else None, useWeights=int(bool(useWeights)),
+                             weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
+    o = L.DsqFitDispGridOut(log_alpha=_t_ptr(la))
+    L.check(L.lib().dsq_fit_disp_grid_dev(C.byref(a), C.byref(o), _stream()))
+    return {"log_alpha": la}
+
+
+def to_gene_major(t_r, dtype=None):
+    """(n, m) torch CUDA tensor holding an R-layout matrix, given as its TRANSPOSE storage:
+    pass a contiguous (m, n) tensor (column-major n x m).  Returns GeneMajor."""
+    import torch
+    m, n = t_r.shape
+    ld = gene_major_ld(m)
+    if t_r.dtype == torch.int32:
+        dst = torch.zeros((n, ld), dtype=torch.int32, device=t_r.device)
+        L.check(L.lib().dsq_to_gene_major_i32(_t_ptr(t_r), _t_ptr(dst), n, m, ld, _stream()))
+    else:
+        assert t_r.dtype == torch.float64
+        dst = torch.zeros((n, ld), dtype=torch.float64, device=t_r.device)
+        L.check(L.lib().dsq_to_gene_major_f64(_t_ptr(t_r), _t_ptr(dst), n, m, ld, _stream()))
+    return GeneMajor(dst, m)
+
+
+def from_gene_major(gm):
+    """GeneMajor f64 -> contiguous (m, n) tensor = column-major n x m (R layout)."""
+    import torch
+    dst = torch.empty((gm.m, gm.n), dtype=torch.float64, device=gm.t.device)
+    L.check(L.lib().dsq_from_gene_major_f64(_t_ptr(gm.t), _t_ptr(dst), gm.n, gm.m, gm.ld, _stream()))
+    return dst

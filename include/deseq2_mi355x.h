@@ -1,0 +1,201 @@
+/*
+ * deseq2_mi355x.h -- C ABI of libdeseq2_mi355x.so, the MI355X (gfx950) engine that
+ * replaces the three native entry points of thelovelab/DESeq2:
+ *
+ *   reference routine (src/RcppExports.cpp:84-89)      replaced by
+ *   _DESeq2_fitBeta      (src/DESeq2.cpp:283-465)      dsq_fit_beta      / dsq_fit_beta_dev
+ *   _DESeq2_fitDisp      (src/DESeq2.cpp:164-277)      dsq_fit_disp      / dsq_fit_disp_dev
+ *   _DESeq2_fitDispGrid  (src/DESeq2.cpp:469-513)      dsq_fit_disp_grid / dsq_fit_disp_grid_dev
+ *
+ * Plain pointers and sizes only.  Two families:
+ *   dsq_fit_*      : every array pointer is a HOST pointer in R's layout (what a
+ *                    .Call shim gets from REAL()/INTEGER()); the call uploads, runs
+ *                    the HIP kernels, downloads and returns synchronously.  This is
+ *                    what src/r_shim.c binds.
+ *   dsq_fit_*_dev  : every array pointer is a DEVICE pointer; work is enqueued on
+ *                    `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *                    and the call returns without synchronising.  Used by the
+ *                    Python host mirror and bench.py to keep Y / nf / weights / mu
+ *                    resident in HBM across the four calls of one DESeq() fit.
+ *
+ * Matrix layouts (the `layout` field):
+ *   DSQ_LAYOUT_R           n x m matrices are column-major as in R: (i,j) at i + n*j
+ *   DSQ_LAYOUT_GENE_MAJOR  n x m matrices are row-major with leading dimension `ld`
+ *                          (elements): (i,j) at i*ld + j.  This is the engine's
+ *                          native layout (one wavefront per gene reads a coalesced
+ *                          row); R-layout inputs are transposed on the device first.
+ * n x p matrices (beta_mat, beta_var_mat) and n-vectors are ALWAYS in R layout
+ * (column-major n x p).  x is m x p column-major, contrast/lambda are p-vectors.
+ *
+ * Semantics (argument meaning, iteration counters, break conditions, clamps, output
+ * list members) follow the reference line by line; see DESIGN.md.  Inputs are
+ * borrowed and never written.  No CPU fallback exists: without a usable gfx950
+ * device every call fails with DSQ_ERR_DEVICE.
+ */
+#ifndef DESEQ2_MI355X_H
+#define DESEQ2_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSQ_VERSION 100
+
+enum {
+    DSQ_OK = 0,
+    DSQ_ERR_ARG = 1,         /* bad size / NULL pointer / inconsistent arguments          */
+    DSQ_ERR_UNSUPPORTED = 2, /* p or m outside the compiled kernel range                  */
+    DSQ_ERR_DEVICE = 3,      /* no gfx950 device, HIP runtime error, kernel launch error  */
+    DSQ_ERR_NOMEM = 4,       /* device or host allocation failed                          */
+    DSQ_ERR_VALUE = 5        /* non-integer / negative count in a REALSXP count matrix    */
+};
+
+enum { DSQ_LAYOUT_R = 0, DSQ_LAYOUT_GENE_MAJOR = 1 };
+enum { DSQ_Y_INT32 = 0, DSQ_Y_FLOAT64 = 1 }; /* R INTSXP or REALSXP count matrix */
+
+#define DSQ_MAX_P 16 /* largest number of design columns with a compiled kernel */
+
+/* ---- fitBeta ------------------------------------------------------------------
+ * reference: List fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP,
+ *   beta_matSEXP, lambdaSEXP, weightsSEXP, useWeightsSEXP, tolSEXP, maxitSEXP,
+ *   useQRSEXP, minmuSEXP)                                   src/DESeq2.cpp:283        */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;         /* DSQ_LAYOUT_* for y / nf / weights / hat_diagonals / mu      */
+    int64_t ld;             /* leading dimension for DSQ_LAYOUT_GENE_MAJOR (>= m)          */
+    const void *y;          /* n x m counts                                                */
+    int32_t y_type;         /* DSQ_Y_INT32 or DSQ_Y_FLOAT64                                */
+    const double *x;        /* m x p design, column-major                                  */
+    const double *nf;       /* n x m normalization factors, or (nf_is_vector) m size factors */
+    int32_t nf_is_vector;   /* extension: 1 = nf points at m size factors shared by all genes */
+    const double *alpha_hat;/* n                                                           */
+    const double *contrast; /* p                                                           */
+    const double *beta_mat; /* n x p initial beta (natural-log scale), column-major        */
+    const double *lambda;   /* p ridge values (natural-log scale)                          */
+    const double *weights;  /* n x m observation weights; may be NULL when useWeights == 0 */
+    int32_t useWeights;
+    double tol;
+    int32_t maxit;          /* 0 is valid: only the post-loop block runs (R/results.R:797) */
+    int32_t useQR;
+    double minmu;
+} DsqFitBetaArgs;
+
+typedef struct {
+    /* members of the reference's return list (src/DESeq2.cpp:458-464); caller-allocated */
+    double *beta_mat;       /* n x p column-major                                          */
+    double *beta_var_mat;   /* n x p column-major                                          */
+    double *iter;           /* n (double, as the reference's NumericVector)                */
+    double *hat_diagonals;  /* n x m in `layout`; may be NULL to skip the 8*m bytes/gene   */
+    double *contrast_num;   /* n                                                           */
+    double *contrast_denom; /* n                                                           */
+    double *deviance;       /* n                                                           */
+    /* extension: fitted means, so R/fitNbinomGLMs.R:180 need not redo
+     * nf * exp(x beta) on the host.  mu = max(nf*exp(x beta), mu_floor); NULL = skip.   */
+    double *mu;             /* n x m in `layout`                                           */
+    double mu_floor;        /* 0 = unclamped (fitNbinomGLMs.R:180); minmu = core.R:763     */
+} DsqFitBetaOut;
+
+int dsq_fit_beta(const DsqFitBetaArgs *args, const DsqFitBetaOut *out);
+int dsq_fit_beta_dev(const DsqFitBetaArgs *args, const DsqFitBetaOut *out, void *stream);
+
+/* ---- fitDisp ------------------------------------------------------------------
+ * reference: List fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP,
+ *   log_alpha_prior_meanSEXP, log_alpha_prior_sigmasqSEXP, min_log_alphaSEXP,
+ *   kappa_0SEXP, tolSEXP, maxitSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP,
+ *   weightThresholdSEXP, useCRSEXP)                         src/DESeq2.cpp:164        */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *x;                    /* m x p column-major                              */
+    const double *mu_hat;               /* n x m                                           */
+    const double *log_alpha;            /* n initial values                                */
+    const double *log_alpha_prior_mean; /* n                                               */
+    double log_alpha_prior_sigmasq;
+    double min_log_alpha;
+    double kappa_0;
+    double tol;
+    int32_t maxit;
+    int32_t usePrior;
+    const double *weights;              /* n x m; may be NULL when useWeights == 0         */
+    int32_t useWeights;
+    double weightThreshold;
+    int32_t useCR;
+} DsqFitDispArgs;
+
+typedef struct {
+    /* members of the reference's return list (src/DESeq2.cpp:268-276); each n long */
+    double *log_alpha;
+    int32_t *iter;
+    int32_t *iter_accept;
+    double *last_change;
+    double *initial_lp;
+    double *initial_dlp;
+    double *last_lp;
+    double *last_dlp;
+    double *last_d2lp;
+} DsqFitDispOut;
+
+int dsq_fit_disp(const DsqFitDispArgs *args, const DsqFitDispOut *out);
+int dsq_fit_disp_dev(const DsqFitDispArgs *args, const DsqFitDispOut *out, void *stream);
+
+/* ---- fitDispGrid --------------------------------------------------------------
+ * reference: List fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP,
+ *   log_alpha_prior_meanSEXP, log_alpha_prior_sigmasqSEXP, usePriorSEXP, weightsSEXP,
+ *   useWeightsSEXP, weightThresholdSEXP, useCRSEXP)         src/DESeq2.cpp:469        */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *x;
+    const double *mu_hat;
+    const double *disp_grid;            /* ngrid log-alpha values (R/wrappers.R:70-72)     */
+    int32_t ngrid;
+    const double *log_alpha_prior_mean; /* n                                               */
+    double log_alpha_prior_sigmasq;
+    int32_t usePrior;
+    const double *weights;
+    int32_t useWeights;
+    double weightThreshold;
+    int32_t useCR;
+} DsqFitDispGridArgs;
+
+typedef struct {
+    double *log_alpha;                  /* n (src/DESeq2.cpp:512)                          */
+} DsqFitDispGridOut;
+
+int dsq_fit_disp_grid(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out);
+int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, void *stream);
+
+/* ---- layout helpers (device pointers, async on stream) --------------------------
+ * R layout (column-major n x m) <-> gene-major (row-major, leading dimension ld).   */
+int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);
+int dsq_to_gene_major_i32(const int32_t *src_r, int32_t *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);
+/* REALSXP counts -> int32 gene-major; *bad (device int32) is set non-zero if any value
+ * is negative, non-finite or non-integer                                             */
+int dsq_counts_f64_to_gene_major_i32(const double *src_r, int32_t *dst_gm, int32_t n, int32_t m,
+                                     int64_t ld, int32_t *bad, void *stream);
+int dsq_from_gene_major_f64(const double *src_gm, double *dst_r, int32_t n, int32_t m, int64_t ld, void *stream);
+
+/* ---- misc ---------------------------------------------------------------------- */
+int dsq_version(void);
+const char *dsq_last_error(void);        /* thread-local message of the last failing call  */
+int dsq_device_count(void);              /* number of visible HIP devices (0 if none)      */
+int dsq_set_device(int device);          /* device used by subsequent calls on this thread */
+int dsq_release_workspace(void);         /* free the cached device workspaces              */
+
+/* Parity hook for tests: evaluate one scalar primitive of the device math library on
+ * the GPU (op: 0 exp, 1 log, 2 log1p, 3 lgamma, 4 digamma, 5 trigamma, 6 stirlerr,
+ * 7 bd0(a,b), 8 dnbinom_mu_log(a=x, b=size, c=mu)).  HOST pointers, n elements.       */
+int dsq_test_math(int op, const double *a, const double *b, const double *c, double *out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESEQ2_MI355X_H */

@@ -1,0 +1,133 @@
+"""-m gpu: HIP kernels vs the CPU oracle through the C ABI (host-pointer entry points,
+R layout, exactly what the .Call shim passes).  Bar (BASELINE.json north_star):
+convergence flags and iteration counts bit-exact; beta / SE / dispersions / statistics
+within 1e-6 relative.  Because the kernels implement the oracle's arithmetic operation
+for operation, the tests assert the stronger property: every output identical."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_same, make_case
+
+pytestmark = pytest.mark.gpu
+
+BETA_KEYS = ["iter", "beta_mat", "beta_var_mat", "deviance", "contrast_num", "contrast_denom", "hat_diagonals"]
+DISP_KEYS = ["iter", "iter_accept", "log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp",
+             "last_dlp", "last_d2lp"]
+
+
+def _fit_beta_both(oracle, d, alpha, lam, useW, useQR, maxit=100, tol=1e-8, minmu=0.5, contrast=None):
+    from deseq2_amd import native
+    p = d["x"].shape[1]
+    contrast = np.r_[1.0, np.zeros(p - 1)] if contrast is None else contrast
+    args = (d["counts"], d["x"], d["nf"], alpha, contrast, d["beta_init"], lam, d["weights"], useW, tol, maxit,
+            useQR, minmu)
+    return native.fitBeta(*args), oracle.fitBeta(*args)
+
+
+CASES = [
+    # n, m, design, weights, useQR
+    (600, 6, "two_group", False, True),        # config C1 shape
+    (500, 100, "two_group", False, True),      # config C2 shape
+    (300, 500, "batch_condition", False, True),  # config C3 shape
+    (300, 200, "two_group", True, True),       # config C5 pass 1 (weights)
+    (300, 100, "two_group", False, False),     # useQR = FALSE (tests/testthat/test_QR.R)
+    (200, 37, "batch_condition", True, False),
+    (200, 70, ("factor", 6), False, True),     # p = 6, ragged m (not a multiple of 64)
+]
+
+
+@pytest.mark.parametrize("n,m,design,useW,useQR", CASES)
+def test_fit_beta_matches_oracle(oracle, n, m, design, useW, useQR):
+    d = make_case(n, m, design, seed=3, weights=useW, sf_random=True)
+    p = d["x"].shape[1]
+    lam = np.full(p, 1e-6) / np.log(2) ** 2           # R/fitNbinomGLMs.R:73,162
+    got, want = _fit_beta_both(oracle, d, d["alpha_init"], lam, useW, useQR)
+    for k in BETA_KEYS:
+        assert_same(got[k], want[k], "fitBeta$" + k)
+    assert (want["iter"] < 100).mean() > 0.9
+
+
+@pytest.mark.parametrize("n,m,design,useW", [(500, 100, "two_group", False), (300, 500, "batch_condition", False),
+                                              (300, 200, "two_group", True), (600, 6, "two_group", False),
+                                              (200, 70, ("factor", 6), True)])
+@pytest.mark.parametrize("usePrior", [False, True])
+def test_fit_disp_matches_oracle(oracle, n, m, design, useW, usePrior):
+    from deseq2_amd import native
+    d = make_case(n, m, design, seed=4, weights=useW)
+    p = d["x"].shape[1]
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    fb = oracle.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
+                        lam, d["weights"], useW, 1e-8, 100, True, 0.5)
+    mu = np.maximum(d["nf"] * np.exp(fb["beta_mat"] @ d["x"].T), 0.5)     # R/core.R:763
+    w = np.maximum(d["weights"], 1e-6)                                     # R/core.R:702
+    la0 = np.log(d["alpha_init"])
+    prior_mean = la0 + 0.3 if usePrior else la0
+    args = (d["counts"], d["x"], mu, la0, prior_mean, 0.7 if usePrior else 1.0, np.log(1e-8 / 10), 1.0, 1e-6, 100,
+            usePrior, w, useW, 1e-2, True)
+    got = native.fitDisp(*args)
+    want = oracle.fitDisp(*args)
+    for k in DISP_KEYS:
+        assert_same(got[k], want[k], "fitDisp$" + k)
+
+
+def test_fit_disp_grid_matches_oracle(oracle):
+    from deseq2_amd import native
+    for (n, m, design, useW) in [(200, 100, "two_group", False), (150, 60, "batch_condition", True)]:
+        d = make_case(n, m, design, seed=5, weights=useW)
+        mu = np.maximum(d["nf"] * np.exp(d["beta_init"] @ d["x"].T), 0.5)
+        grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 20)            # R/wrappers.R:70-72
+        nn = d["counts"].shape[0]
+        for usePrior in (False, True):
+            args = (d["counts"], d["x"], mu, grid, np.zeros(nn) - 1.0, 1.0, usePrior, d["weights"], useW, 1e-2, True)
+            assert_same(native.fitDispGrid(*args)["log_alpha"], oracle.fitDispGrid(*args)["log_alpha"],
+                        "fitDispGrid$log_alpha")
+
+
+def test_known_answers_from_reference_tests(oracle):
+    """tests/testthat/test_results.R:9,43-50 and test_optim.R:30-39 through the GPU."""
+    from deseq2_amd import native
+    yk = np.repeat([100, 200, 800], 4).astype(np.int32)[None, :]
+    group = np.tile([1, 2], 6); cond = np.repeat([1, 2, 3], 4)
+    X = np.column_stack([np.ones(12), group == 2, cond == 2, cond == 3]).astype(float)
+    binit = np.linalg.lstsq(X, np.log(yk[0] + .1), rcond=None)[0][None, :]
+    lam = np.full(4, 1e-6) / np.log(2) ** 2
+    r = native.fitBeta(yk, X, np.ones((1, 12)), [0.05], [1, 0, 0, 0], binit, lam, np.ones((1, 12)), False, 1e-8,
+                       100, True, 0.5)
+    np.testing.assert_allclose(r["beta_mat"][0] / np.log(2), [np.log2(100), 0, 1, 3], atol=1e-6)
+    yo = np.array([0, 0, 0, 0, 0, 1000, 1000, 0, 0, 0], np.int32)[None, :]
+    Xo = np.column_stack([np.ones(10), np.repeat([0, 1], 5)]).astype(float)
+    binit = np.linalg.lstsq(Xo, np.log(yo[0] + .1), rcond=None)[0][None, :]
+    r = native.fitBeta(yo, Xo, np.ones((1, 10)), [2.0], [1, 0], binit, lam[:2], np.ones((1, 10)), False, 1e-8, 100,
+                       True, 0.5)
+    assert r["iter"][0] == 100
+
+
+def test_maxit_zero_contrast_mode(oracle):
+    """R/results.R:797-807: getContrast calls fitBeta with maxit = 0, useQR = FALSE"""
+    d = make_case(200, 50, "batch_condition", seed=6)
+    lam = np.full(4, 1e-6) / np.log(2) ** 2
+    got, want = _fit_beta_both(oracle, d, d["alpha_init"], lam, False, False, maxit=0,
+                               contrast=np.array([0.0, 1.0, -1.0, 0.5]))
+    for k in BETA_KEYS:
+        assert_same(got[k], want[k], "fitBeta(maxit=0)$" + k)
+    assert (got["iter"] == 0).all()
+
+
+def test_double_counts_and_bad_counts():
+    from deseq2_amd import native, _lib
+    d = make_case(50, 20, "two_group", seed=7)
+    lam = np.full(2, 1e-6)
+    a = native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], [1, 0], d["beta_init"], lam, d["weights"],
+                       False, 1e-8, 100, True, 0.5)
+    b = native.fitBeta(d["counts"].astype(np.float64), d["x"], d["nf"], d["alpha_init"], [1, 0], d["beta_init"],
+                       lam, d["weights"], False, 1e-8, 100, True, 0.5)
+    assert_same(a["beta_mat"], b["beta_mat"], "REALSXP counts")
+    bad = d["counts"].astype(np.float64); bad[3, 4] = 2.5
+    with pytest.raises(_lib.DsqError):
+        native.fitBeta(bad, d["x"], d["nf"], d["alpha_init"], [1, 0], d["beta_init"], lam, d["weights"], False,
+                       1e-8, 100, True, 0.5)
+    with pytest.raises(_lib.DsqError):   # p beyond compiled kernels must fail loudly, never fall back
+        x9 = np.column_stack([d["x"]] + [np.random.default_rng(i).normal(size=20) for i in range(15)])
+        native.fitBeta(d["counts"], x9, d["nf"], d["alpha_init"], np.r_[1, np.zeros(16)],
+                       np.zeros((d["counts"].shape[0], 17)), np.full(17, 1e-6), d["weights"], False, 1e-8, 100,
+                       True, 0.5)
