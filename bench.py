@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- genes/sec of the full DESeq() dispersion + beta + Wald fit on MI355X.
+
+One "step" = one pass of the hot path over one synthetic count matrix that is already
+resident in HBM in R's layout (column-major int32 counts, f64 normalization-factor matrix):
+layout conversion -> fitBeta (mu-hat) -> fitDisp -> fitDispGrid (stragglers) -> host trend /
+prior variance on n-vectors -> fitDisp (MAP) -> fitDispGrid -> fitBeta (final dispersions) ->
+Wald statistics and p-values.  Workload at every N: BASELINE.json configs[2]
+(50k genes x 500 samples, ~batch+condition, p = 4) PER GPU (weak scaling: genes shard
+across ranks, no data-path collective; the only exchange is the all-gather of two n-vectors
+for the global dispersion trend, as in DESeqParallel).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6    # public MI355X spec (vector f64); reported for context only
+
+
+def algorithmic_bytes_per_gene(kernel, m, nf_matrix=True, weights=False, hat=True, mu=False):
+    """fitBeta reads Y (4m) [+ nf matrix 8m] [+ weights 8m], writes
+    H (8m) [+ mu (8m)]; fitDisp reads Y (4m) + mu-hat (8m) [+ weights 8m]."""
+    if kernel == "fit_beta":
+        return 4 * m + (8 * m if nf_matrix else 0) + (8 * m if weights else 0) + (8 * m if hat else 0) + (8 * m if mu else 0)
+    return 4 * m + 8 * m + (8 * m if weights else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genes", type=int, default=50000)
+    ap.add_argument("--samples", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-genes", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: deseq2_amd has no CPU compute path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from deseq2_amd import core, simulate, parallel
+    from deseq2_amd.engine import DeviceEngine
+
+    n_req, m = args.genes, args.samples
+    x = simulate.design_batch_condition(m)              # ~batch(3) + condition(2): p = 4
+    p = x.shape[1]
+    d = simulate.make_counts(n_req, x, seed=1 + rank)
+    counts = d["counts"]
+    n = counts.shape[0]
+    E = DeviceEngine(dev)
+    # inputs resident in HBM in R layout before the timed region
+    counts_r = torch.as_tensor(np.ascontiguousarray(counts.T), device=dev)                 # (m, n) int32
+    nf_r = torch.ones((m, n), dtype=torch.float64, device=dev) * torch.as_tensor(d["size_factors"], device=dev)[:, None]
+    torch.cuda.synchronize()
+
+    def step():
+        dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x)
+        if world > 1:
+            parallel.DESeqParallel(dds, comm_device=dev)
+        else:
+            core.DESeq(dds)
+        return dds
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    E.record = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dds = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nn = torch.tensor([n], dtype=torch.int64, device=dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_total = int(nn.item())
+    else:
+        n_total = n
+    rec, E.record = E.record, None
+
+    if rank == 0:
+        # ---- per-kernel launch durations (HIP events on the launch stream) -------------
+        per = {}
+        for name, ng, e0, e1 in rec:
+            per.setdefault(name, []).append((ng, e0.elapsed_time(e1)))
+        kern = {k: {"launches": len(v), "avg_ms": float(np.mean([t for _, t in v])),
+                    "genes_per_launch": float(np.mean([g for g, _ in v]))} for k, v in per.items()}
+        # the two full-size kernels; dominant = larger share of the step
+        share = {k: sum(t for _, t in per[k]) for k in per}
+        dom = max(("fit_beta", "fit_disp"), key=lambda k: share.get(k, 0.0))
+        full = [(g, t) for g, t in per[dom] if g == n]
+        avg_ms = float(np.mean([t for _, t in full]))
+        bytes_per_gene = algorithmic_bytes_per_gene(dom, m, nf_matrix=True, weights=False,
+                                                    hat=(dom == "fit_beta"), mu=(dom == "fit_beta"))
+        if dom == "fit_beta":
+            # fitBeta#1 writes mu (no H), fitBeta#2 writes mu and H: average of the two launches
+            bytes_per_gene = (algorithmic_bytes_per_gene("fit_beta", m, hat=False, mu=True) +
+                              algorithmic_bytes_per_gene("fit_beta", m, hat=True, mu=True)) / 2.0
+        achieved = bytes_per_gene * n / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": bytes_per_gene * n, "avg_launch_ms": avg_ms,
+                    "note": "f64-VALU/transcendental bound, not HBM bound (DESIGN.md); see profiles/"}
+
+        it_beta = float(np.mean(dds.mcols["betaIter"]))
+        it_disp = float(np.mean(dds.mcols["dispIter"]))
+        out = {
+            "metric": "genes/sec for DESeq() disp+beta+Wald fit, 50k x 500 x p=4",
+            "value": n_total * args.steps / dt,
+            "unit": "genes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d genes x %d samples per GPU, ~batch+condition (p=%d), "
+                                   "Wald test; inputs resident in HBM in R layout (int32 counts, f64 nf matrix)"
+                                   % (n, m, p),
+                       "genes_per_gpu": n, "samples": m, "p": p, "parallelism": "gene-shard x%d" % world},
+            "roofline": roofline,
+            "kernels": kern,
+            "mean_iterations": {"fitBeta_final": it_beta, "fitDisp_MAP": it_disp,
+                                "fitDisp_geneEst": float(np.mean(dds.mcols["dispGeneIter"]))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(counts, d["size_factors"], x, args.cpu_sample_genes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(counts, sf, x, k):
+    """The CPU oracle (plain-C restatement of src/DESeq2.cpp, 1 thread like the reference) timed
+    on the first k genes of the same workload through the same host code."""
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    from oracle import oracle as O
+    O.set_threads(1)
+    sub = counts[:k]
+    sub = sub[sub.sum(axis=1) > 0]
+    t0 = time.perf_counter()
+    dds = core.DESeqDataSet(sub, x, sizeFactors=sf, engine=HostEngine(O))
+    core.DESeq(dds)
+    dt = time.perf_counter() - t0
+    return {"value": sub.shape[0] / dt, "unit": "genes/s", "cores": 1, "kind": "port",
+            "sample": "first %d genes of the same %d-sample matrix, full DESeq() chain over the C oracle, %.1f s"
+                      % (sub.shape[0], counts.shape[1], dt)}
+
+
+if __name__ == "__main__":
+    main()

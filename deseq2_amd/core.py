@@ -1,0 +1,475 @@
+"""Host-side mirror of the reference's callers of the native boundary (R/core.R,
+R/fitNbinomGLMs.R, R/wrappers.R): same function names, same argument meaning and defaults,
+same decision rules, operating on a minimal DESeqDataSet stand-in.  The three native
+routines go to the MI355X engine (engine.py); the all-gene "global" steps between them
+(dispersion trend, prior variance) stay on the host exactly as in DESeqParallel
+(R/parallel.R:27-28) -- they exchange only n-vectors.
+
+Not mirrored (out of the hot-path scope): size-factor estimation, outlier
+replacement / Cook's distances, local/glmGamPoi dispersion fits, results(), lfcShrink().
+"""
+import numpy as np
+from scipy import special as sps
+
+from .engine import HostEngine
+
+LOG2E = np.log2(np.e)
+
+
+class DESeqDataSet:
+    """counts (n x m int), model matrix x (m x p), size factors (m) or normalization
+    factors (n x m), optional observation weights (n x m).  `mcols` holds per-gene vectors
+    (R: mcols(object)), `assays` the n x m engine handles (mu, H)."""
+
+    def __init__(self, counts, x, sizeFactors=None, normalizationFactors=None, weights=None, engine=None):
+        counts = np.asarray(counts)
+        if counts.ndim != 2 or (counts < 0).any():
+            raise ValueError("counts must be a non-negative integer matrix")          # R/AllClasses.R:9-20
+        self.n, self.m = counts.shape
+        self.x = np.asarray(x, dtype=np.float64)
+        if self.x.shape[0] != self.m:
+            raise ValueError("model matrix rows must match samples")
+        self.engine = engine if engine is not None else HostEngine()
+        if normalizationFactors is not None:
+            nf = np.asarray(normalizationFactors, np.float64)
+        else:
+            sf = np.ones(self.m) if sizeFactors is None else np.asarray(sizeFactors, np.float64)
+            nf = np.broadcast_to(sf[None, :], counts.shape)                          # getSizeOrNormFactors :2221
+        self.counts_host = counts.astype(np.int32)
+        E = self.engine
+        self.y = E.counts(self.counts_host)
+        self.nf = E.matrix(nf)
+        self.has_weights = weights is not None
+        self.weights_raw = None if weights is None else np.asarray(weights, np.float64)
+        self.xh = E.design(self.x)
+        self.mcols = {}
+        self.assays = {}
+        self.attrs = {}
+        self.dispersionFunction = None
+
+    @classmethod
+    def from_device(cls, engine, counts_r, nf_r, x, weights=None):
+        """Build from matrices ALREADY RESIDENT in HBM in R layout: `counts_r` (int32) and
+        `nf_r` (float64) are contiguous (m, n) torch tensors, i.e. column-major n x m exactly as
+        R holds them.  Converts to the engine's gene-major layout on the device (no host copy)."""
+        self = cls.__new__(cls)
+        self.m, self.n = counts_r.shape
+        self.x = np.asarray(x, dtype=np.float64)
+        self.engine = engine
+        self.counts_host = None
+        self.y = engine.native.to_gene_major(counts_r)
+        self.nf = engine.native.to_gene_major(nf_r)
+        self.has_weights = weights is not None
+        self.weights_raw = None if weights is None else np.asarray(weights, np.float64)
+        self.xh = engine.design(self.x)
+        self.mcols, self.assays, self.attrs = {}, {}, {}
+        self.dispersionFunction = None
+        return self
+
+    @property
+    def p(self):
+        return self.x.shape[1]
+
+
+# ------------------------------------------------------------------ R/wrappers.R
+def _na_guard(fname, **args):
+    """R/wrappers.R:31-34,110-113: error naming the arguments that contain NA"""
+    bad = [k for k, v in args.items() if v is not None and isinstance(v, np.ndarray) and np.isnan(v).any()]
+    if bad:
+        raise ValueError("in call to %s, the following arguments contain NA: %s" % (fname, ", ".join(bad)))
+
+
+def fitDispGridWrapper(E, y, x, mu, logAlphaPriorMean, logAlphaPriorSigmaSq, usePrior, weights, useWeights,
+                       weightThreshold, useCR, ncol_y):
+    """R/wrappers.R:63-82"""
+    _na_guard("fitDispGridWrapper", logAlphaPriorMean=np.asarray(logAlphaPriorMean, float))
+    minLogAlpha = np.log(1e-8)
+    maxLogAlpha = np.log(max(10, ncol_y))
+    dispGrid = np.linspace(minLogAlpha, maxLogAlpha, 20)
+    la = E.fit_disp_grid(y, x, mu, dispGrid, logAlphaPriorMean, logAlphaPriorSigmaSq, usePrior, weights,
+                         useWeights, weightThreshold, useCR)["log_alpha"]
+    return np.exp(la)
+
+
+# ------------------------------------------------------------------ weights
+def getAndCheckWeights(dds, weightThreshold=1e-2):
+    """R/core.R:2697-2751 (row-max normalisation; the per-gene rank checks flag rows)"""
+    E = dds.engine
+    if dds.has_weights:
+        w = dds.weights_raw
+        if (w < 0).any():
+            raise ValueError("all(weights >= 0) is not TRUE")
+        w = w / w.max(axis=1, keepdims=True)
+        if "weightsOK" not in dds.attrs:
+            x = dds.x
+            p = x.shape[1]
+            ok = np.ones(dds.n, dtype=bool)
+            if np.linalg.matrix_rank(x) == p:
+                for i in range(dds.n):
+                    t1 = np.linalg.matrix_rank(w[i][:, None] * x) == p
+                    sub = x[w[i] > weightThreshold]
+                    sub = sub[:, np.abs(sub).sum(axis=0) > 0]
+                    t2 = sub.shape[1] > 0 and np.linalg.matrix_rank(sub) == sub.shape[1]
+                    ok[i] = t1 and t2
+            dds.mcols["weightsFail"] = ~ok
+            dds.attrs["weightsOK"] = True
+        return w, True
+    return None, False
+
+
+def getBaseMeansAndVariances(dds):
+    """R/core.R:2138-2157"""
+    E = dds.engine
+    w = None
+    if dds.has_weights:
+        w = E.matrix(dds.weights_raw)
+    bm, bv, az = E.normalized_row_stats(dds.y, dds.nf, w)
+    dds.mcols["baseMean"], dds.mcols["baseVar"], dds.mcols["allZero"] = bm, bv, az
+    return dds
+
+
+def modelMatrixGroups(x):
+    """R/core.R:2450-2452"""
+    _, inv = np.unique(np.asarray(x), axis=0, return_inverse=True)
+    return inv.reshape(-1)
+
+
+# ------------------------------------------------------------------ R/fitNbinomGLMs.R
+def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, betaTol=1e-8, maxit=100,
+                  useOptim=True, useQR=True, minmu=0.5, weights=None, useWeights=False, mu_floor=0.0,
+                  want_hat=True):
+    """R/fitNbinomGLMs.R:29-236 (IRLS branch; the L-BFGS-B fallback rows are reported in
+    `rowsForOptim` instead of being refitted -- fitNbinomGLMsOptim is a per-row R loop
+    outside the native boundary)."""
+    E = dds.engine
+    x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
+    xh = dds.xh if modelMatrix is None else E.design(x)
+    y, nf = dds.y, dds.nf
+    if rows is not None:
+        y, nf = E.take_rows(y, rows), E.take_rows(nf, rows)
+        weights = E.take_rows(weights, rows) if weights is not None else None
+    n = E.nrow(y)
+    p = x.shape[1]
+    if alpha_hat is None:
+        alpha_hat = dds.mcols["dispersion"] if rows is None else dds.mcols["dispersion"][rows]
+    alpha_hat = np.asarray(alpha_hat, np.float64)
+    if alpha_hat.shape[0] != n:
+        raise ValueError("alpha_hat needs to be the same length as nrows(object)")
+    if lam is None:
+        lam = np.full(p, 1e-6)                                                     # :73
+    lam = np.asarray(lam, np.float64)
+    if not (np.abs(x).sum(axis=0) > 0).all():
+        raise ValueError("all(colSums(abs(modelMatrix)) > 0) is not TRUE")          # :45
+    # initial betas by QR least squares when full rank (:139-155)
+    if np.linalg.matrix_rank(x) == p:
+        beta_mat = E.beta_init(y, nf, xh)
+    else:
+        beta0 = np.zeros((n, p))
+        bm, _, _ = E.normalized_row_stats(y, nf)
+        if (x[:, 0] == 1).all():
+            beta0[:, 0] = np.log(bm)
+        else:
+            beta0[:] = 1.0
+        beta_mat = beta0
+    lambdaNatLogScale = lam / np.log(2) ** 2                                       # :162
+    contrast = np.r_[1.0, np.zeros(p - 1)]                                         # R/wrappers.R:105-108
+    _na_guard("fitBeta", alpha_hatSEXP=alpha_hat, lambdaSEXP=lambdaNatLogScale)
+    betaRes = E.fit_beta(y, xh, nf, alpha_hat, contrast, beta_mat, lambdaNatLogScale, weights, useWeights,
+                         betaTol, maxit, useQR, minmu, want_mu=True, mu_floor=mu_floor, want_hat=want_hat)
+    mu = betaRes["mu"]                                                             # :180
+    rowStable = ~np.isnan(betaRes["beta_mat"]).any(axis=1)                         # :185
+    rowVarPositive = ~(betaRes["beta_var_mat"] <= 0).any(axis=1)                   # :188
+    betaConv = betaRes["iter"] < maxit                                             # :191
+    betaMatrix = LOG2E * betaRes["beta_mat"]                                       # :194
+    betaSE = LOG2E * np.sqrt(np.maximum(betaRes["beta_var_mat"], 0))               # :198
+    if useOptim:
+        rowsForOptim = np.where(~betaConv | ~rowStable | ~rowVarPositive)[0]       # :203-207
+    else:
+        rowsForOptim = np.where(~rowStable | ~rowVarPositive)[0]
+    return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu,
+            "betaIter": betaRes["iter"], "modelMatrix": x, "nterms": p,
+            "hat_diagonals": betaRes.get("hat_diagonals"), "deviance_native": betaRes["deviance"],
+            "rowsForOptim": rowsForOptim, "beta_natlog": betaRes["beta_mat"]}
+
+
+# ------------------------------------------------------------------ dispersions
+def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, maxit=100, useCR=True,
+                               weightThreshold=1e-2, modelMatrix=None, niter=1, linearMu=None, minmu=0.5,
+                               alphaInit=None):
+    """R/core.R:657-860"""
+    if np.log(minDisp / 10) <= -30:
+        raise ValueError("for computational stability, log(minDisp/10) should be above -30")
+    E = dds.engine
+    x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
+    if np.linalg.matrix_rank(x) < x.shape[1]:
+        raise ValueError("the model matrix is not full rank")                       # checkFullRank :2624
+    if x.shape[0] == x.shape[1]:
+        raise ValueError("the number of samples and the number of model coefficients are equal")
+    if niter != 1:
+        raise NotImplementedError("niter > 1 is not mirrored (default DESeq() uses niter = 1)")
+    getBaseMeansAndVariances(dds)
+    w_host, useWeights = getAndCheckWeights(dds, weightThreshold)
+    weights_glm = E.matrix(w_host) if useWeights else None          # fitNbinomGLMs re-reads them unfloored (:77)
+    weights = E.matrix(np.maximum(w_host, 1e-6)) if useWeights else None            # :702
+    nz = ~dds.mcols["allZero"]
+    if not nz.all():
+        raise ValueError("all-zero rows must be removed before fitting (the engine fits objectNZ)")
+    m = dds.m
+    if alphaInit is None:
+        roughDisp = E.rough_disp(dds.y, dds.nf, dds.xh)                             # :713
+        bm, bv = dds.mcols["baseMean"], dds.mcols["baseVar"]
+        momentsDisp = (bv - E.xim(dds.nf) * bm) / bm ** 2                           # :2439-2448
+        alpha_hat = np.minimum(roughDisp, momentsDisp)
+    else:
+        alpha_hat = np.broadcast_to(np.asarray(alphaInit, float), (dds.n,)).copy()
+    maxDisp = max(10, m)
+    alpha_hat = alpha_init = np.minimum(np.maximum(minDisp, alpha_hat), maxDisp)    # :727-728
+    if linearMu is None:
+        linearMu = (len(np.unique(modelMatrixGroups(x))) == x.shape[1]) and not useWeights   # :735-742
+    if not linearMu:
+        fit = fitNbinomGLMs(dds, alpha_hat=alpha_hat, modelMatrix=modelMatrix, weights=weights_glm,
+                            useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False)   # :755-757
+        mu = fit["mu"]                                                              # clamped at minmu (:763)
+    else:
+        mu = E.clamp_min(E.linear_mu(dds.y, dds.nf, dds.xh), minmu)                 # :760,763
+    la0 = np.log(alpha_hat)
+    dispRes = E.fit_disp(dds.y, dds.xh if modelMatrix is None else E.design(x), mu, la0, la0, 1.0,
+                         np.log(minDisp / 10), kappa_0, dispTol, maxit, False, weights, useWeights,
+                         weightThreshold, useCR)                                    # :771-782
+    dispIter = dispRes["iter"]
+    alpha_hat_new = np.minimum(np.exp(dispRes["log_alpha"]), maxDisp)               # :785
+    dispGeneEst = alpha_hat_new.copy()
+    noIncrease = dispRes["last_lp"] < dispRes["initial_lp"] + np.abs(dispRes["initial_lp"]) / 1e6   # :828
+    dispGeneEst[noIncrease] = alpha_init[noIncrease]
+    dispGeneEstConv = (dispIter < maxit) & ~(dispIter == 1)                         # :832
+    refitDisp = ~dispGeneEstConv & (dispGeneEst > minDisp * 10)                     # :835
+    if refitDisp.sum() > 0:
+        idx = np.where(refitDisp)[0]
+        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), dds.xh, E.take_rows(mu, idx),
+                                      np.zeros(idx.size), 1.0, False, E.take_rows(weights, idx), useWeights,
+                                      weightThreshold, useCR, m)                    # :837-846
+        dispGeneEst[refitDisp] = dispGrid
+    dispGeneEst = np.minimum(np.maximum(dispGeneEst, minDisp), maxDisp)             # :848
+    dds.mcols["dispGeneEst"] = dispGeneEst
+    dds.mcols["dispGeneIter"] = dispIter
+    dds.assays["mu"] = mu
+    dds.attrs["disp_weights"] = weights
+    dds.attrs["useWeights"] = useWeights
+    return dds
+
+
+def parametricDispersionFit(means, disps):
+    """R/core.R:2166-2190: disp ~ asymptDisp + extraPois/mean by a Gamma GLM with identity link
+    (stats::glm IRLS restated: weights mu^-2, working response = disps)."""
+    coefs = np.array([0.1, 1.0])
+    it = 0
+    while True:
+        residuals = disps / (coefs[0] + coefs[1] / means)
+        good = (residuals > 1e-4) & (residuals < 15)
+        yg, xg = disps[good], 1.0 / means[good]
+        X = np.column_stack([np.ones(xg.size), xg])
+        b = coefs.copy()
+        converged = False
+        dev_old = None
+        for _ in range(25):                                   # glm.control(maxit = 25, epsilon = 1e-8)
+            mu = X @ b
+            if (mu <= 0).any():
+                raise RuntimeError("parametric dispersion fit failed")
+            wgt = 1.0 / mu ** 2
+            XtW = X.T * wgt
+            b = np.linalg.solve(XtW @ X, XtW @ yg)
+            mu = X @ b
+            if (mu <= 0).any():
+                raise RuntimeError("parametric dispersion fit failed")
+            dev = -2.0 * np.sum(np.log(yg / mu) - (yg - mu) / mu)
+            if dev_old is not None and abs(dev - dev_old) / (abs(dev) + 0.1) < 1e-8:
+                converged = True
+                break
+            dev_old = dev
+        oldcoefs = coefs
+        coefs = b
+        if not (coefs > 0).all():
+            raise RuntimeError("parametric dispersion fit failed")
+        if np.sum(np.log(coefs / oldcoefs) ** 2) < 1e-6 and converged:
+            break
+        it += 1
+        if it > 10:
+            raise RuntimeError("dispersion fit did not converge")
+    return coefs
+
+
+def _mad(v):
+    med = np.median(v)
+    return 1.4826 * np.median(np.abs(v - med))
+
+
+def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8):
+    """R/core.R:864-939 + `dispersionFunction<-` (R/methods.R:142-190)"""
+    dge, bm = dds.mcols["dispGeneEst"], dds.mcols["baseMean"]
+    useForFit = dge > 100 * minDisp
+    if useForFit.sum() == 0:
+        raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
+    if fitType == "parametric":
+        try:
+            coefs = parametricDispersionFit(bm[useForFit], dge[useForFit])
+            fn = ("parametric", coefs)
+        except RuntimeError:
+            fitType = "mean"       # the reference falls back to locfit (not available here)
+    if fitType == "mean":
+        useForMean = dge > 10 * minDisp
+        v = np.sort(dge[useForMean])
+        k = int(np.floor(v.size * 0.001))
+        fn = ("mean", float(v[k: v.size - k].mean()))                                  # mean(trim = 0.001)
+    if fn[0] == "parametric":
+        dispFit = fn[1][0] + fn[1][1] / bm
+    else:
+        dispFit = np.full(bm.shape, fn[1])
+    dds.mcols["dispFit"] = dispFit
+    aboveMinDisp = dge >= minDisp * 100
+    varLogDispEsts = None
+    if aboveMinDisp.sum() > 0:
+        res = np.log(dge) - np.log(dispFit)
+        varLogDispEsts = _mad(res[aboveMinDisp]) ** 2                                  # methods.R:180
+    dds.dispersionFunction = {"fitType": fn[0], "coefficients": fn[1], "varLogDispEsts": varLogDispEsts}
+    return dds
+
+
+def estimateDispersionsPriorVar(dds, minDisp=1e-8):
+    """R/core.R:1135-1208 (the (m-p) <= 3 Monte-Carlo branch relies on R's RNG stream and is not
+    mirrored)"""
+    dge = dds.mcols["dispGeneEst"]
+    aboveMinDisp = dge >= minDisp * 100
+    if aboveMinDisp.sum() == 0:
+        raise RuntimeError("no data found which is greater than minDisp")
+    varLogDispEsts = dds.dispersionFunction["varLogDispEsts"]
+    m, p = dds.x.shape
+    if (m - p) <= 3 and m > p:
+        raise NotImplementedError("residual df <= 3: the reference's seeded Monte-Carlo matching is not mirrored")
+    if m > p:
+        expVarLogDisp = sps.polygamma(1, (m - p) / 2.0)
+        return float(max(varLogDispEsts - expVarLogDisp, 0.25))                       # :1200
+    return float(varLogDispEsts)
+
+
+def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6,
+                           maxit=100, useCR=True, weightThreshold=1e-2):
+    """R/core.R:943-1131"""
+    E = dds.engine
+    if dispPriorVar is None:
+        dispPriorVar = estimateDispersionsPriorVar(dds, minDisp)                     # :986
+    dds.dispersionFunction["dispPriorVar"] = dispPriorVar
+    w_host, useWeights = getAndCheckWeights(dds, weightThreshold)                    # :999 (no 1e-6 floor here)
+    weights = E.matrix(w_host) if useWeights else None
+    dge, dfit = dds.mcols["dispGeneEst"], dds.mcols["dispFit"]
+    mu = dds.assays["mu"]
+    dispInit = np.where(dge > 0.1 * dfit, dge, dfit)                                 # :1019-1021
+    dispInit = np.where(np.isnan(dispInit), dfit, dispInit)
+    res = E.fit_disp(dds.y, dds.xh, mu, np.log(dispInit), np.log(dfit), dispPriorVar, np.log(minDisp / 10),
+                     kappa_0, dispTol, maxit, True, weights, useWeights, weightThreshold, useCR)   # :1027-1039
+    dispMAP = np.exp(res["log_alpha"])
+    dispIter = res["iter"]
+    dispConv = dispIter < maxit                                                      # :1048
+    refitDisp = ~dispConv
+    if refitDisp.sum() > 0:
+        idx = np.where(refitDisp)[0]
+        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), dds.xh, E.take_rows(mu, idx),
+                                      np.log(dfit)[idx], dispPriorVar, True, E.take_rows(weights, idx),
+                                      useWeights, weightThreshold, True, dds.m)      # :1051-1061
+        dispMAP[refitDisp] = dispGrid
+    maxDisp = max(10, dds.m)
+    dispMAP = np.minimum(np.maximum(dispMAP, minDisp), maxDisp)                      # :1100-1101
+    dispersionFinal = dispMAP.copy()
+    varLogDispEsts = dds.dispersionFunction["varLogDispEsts"]
+    dispOutlier = np.log(dge) > np.log(dfit) + outlierSD * np.sqrt(varLogDispEsts)   # :1111-1113
+    dispOutlier[np.isnan(dispOutlier)] = False
+    dispersionFinal[dispOutlier] = dge[dispOutlier]
+    dds.mcols.update(dispersion=dispersionFinal, dispIter=dispIter, dispOutlier=dispOutlier, dispMAP=dispMAP)
+    return dds
+
+
+def estimateDispersions(dds, fitType="parametric", **kw):
+    """R/methods.R:500-563"""
+    estimateDispersionsGeneEst(dds, **kw)
+    estimateDispersionsFit(dds, fitType=fitType)
+    estimateDispersionsMAP(dds)
+    return dds
+
+
+# ------------------------------------------------------------------ tests
+def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=None, useQR=True, minmu=0.5,
+                   modelMatrix=None):
+    """R/core.R:1332-1565 with betaPrior = FALSE (Cook's distances not mirrored)"""
+    if "dispersion" not in dds.mcols:
+        raise RuntimeError("testing requires dispersion estimates, first call estimateDispersions()")
+    E = dds.engine
+    w_host, useWeights = getAndCheckWeights(dds)
+    weights = E.matrix(w_host) if useWeights else None
+    fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
+                        modelMatrix=modelMatrix, weights=weights, useWeights=useWeights)     # :1403-1408
+    dds.assays["mu"] = fit["mu"]
+    dds.assays["H"] = fit["hat_diagonals"]
+    dds.attrs.update(betaPrior=False, betaPriorVar=np.full(fit["nterms"], 1e6), test="Wald")
+    betaMatrix, betaSE = fit["betaMatrix"], fit["betaSE"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        WaldStatistic = betaMatrix / betaSE                                         # :1471
+    if useT:
+        from scipy.stats import t as tdist
+        if df is None:
+            num = w_host.sum(axis=1) if useWeights else np.full(dds.n, dds.m)
+            df = num - dds.p
+        df = np.where(np.asarray(df, float) > 0, df, np.nan)
+        WaldPvalue = 2 * tdist.sf(np.abs(WaldStatistic), df=np.asarray(df)[:, None])
+    else:
+        WaldPvalue = 2 * sps.ndtr(-np.abs(WaldStatistic))                           # :1507
+    logLike = E.nbinom_loglike(dds.y, fit["mu"], dds.mcols["dispersion"], weights, useWeights)   # fitNbinomGLMs.R:182
+    dds.mcols.update(beta=betaMatrix, betaSE=betaSE, WaldStatistic=WaldStatistic, WaldPvalue=WaldPvalue,
+                     betaConv=fit["betaConv"], betaIter=fit["betaIter"], deviance=-2 * logLike,
+                     rowsForOptim=fit["rowsForOptim"])
+    return dds
+
+
+def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, minmu=0.5):
+    """R/core.R:1787-2012: full vs reduced model matrices (betaPrior = FALSE).  `reduced` is a
+    model matrix whose column space is nested in dds.x; an intercept-only reduced model takes
+    the closed form of R/fitNbinomGLMs.R:99-137."""
+    from scipy.stats import chi2
+    E = dds.engine
+    reduced = np.asarray(reduced, np.float64)
+    w_host, useWeights = getAndCheckWeights(dds)
+    weights = E.matrix(w_host) if useWeights else None
+    disp = dds.mcols["dispersion"]
+    full = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
+                         weights=weights, useWeights=useWeights)
+    ll_full = E.nbinom_loglike(dds.y, full["mu"], disp, weights, useWeights)
+    if reduced.shape[1] == 1 and (reduced == 1).all():
+        yh, nfh = E.to_numpy(dds.y), E.to_numpy(dds.nf)
+        cn = yh / nfh
+        b = (np.log2((w_host * cn).sum(1) / w_host.sum(1)) if useWeights else np.log2(cn.mean(1)))
+        mu_red = E.matrix(nfh * (2.0 ** b)[:, None])
+        red = {"betaMatrix": b[:, None], "nterms": 1}
+    else:
+        red = fitNbinomGLMs(dds, modelMatrix=reduced, betaTol=betaTol, maxit=maxit, useOptim=useOptim,
+                            useQR=useQR, minmu=minmu, weights=weights, useWeights=useWeights, want_hat=False)
+        mu_red = red["mu"]
+    ll_red = E.nbinom_loglike(dds.y, mu_red, disp, weights, useWeights)
+    LRTStatistic = 2 * (ll_full - ll_red)                                            # :1877
+    LRTPvalue = chi2.sf(LRTStatistic, df=full["nterms"] - red["nterms"])             # :1878
+    dds.assays["mu"] = full["mu"]
+    dds.assays["H"] = full["hat_diagonals"]
+    dds.mcols.update(beta=full["betaMatrix"], betaSE=full["betaSE"], LRTStatistic=LRTStatistic,
+                     LRTPvalue=LRTPvalue, fullBetaConv=full["betaConv"], betaIter=full["betaIter"],
+                     deviance=-2 * ll_full)
+    return dds
+
+
+def DESeq(dds, test="Wald", fitType="parametric", reduced=None, **kw):
+    """R/core.R:280-432, default serial path without outlier replacement (size factors are
+    taken as given: estimateSizeFactors is outside the hot path)."""
+    estimateDispersions(dds, fitType=fitType)
+    if test == "Wald":
+        nbinomWaldTest(dds, **kw)
+    elif test == "LRT":
+        nbinomLRT(dds, reduced, **kw)
+    else:
+        raise ValueError("test should be either 'Wald' or 'LRT'")
+    return dds

@@ -1,0 +1,268 @@
+"""Engines: where the n x m matrices of one analysis live and who runs the three native
+routines on them.
+
+The host-side mirror of the reference's R callers (core.py, fit_nbinom_glms.py) is written
+once against this small interface.  n-vectors and n x p matrices are always host numpy
+arrays (they are what R keeps in mcols()); n x m matrices are opaque handles:
+
+  HostEngine    handles are numpy arrays in R orientation (genes x samples); every call
+                goes through the host-pointer C ABI (dsq_fit_*), i.e. exactly what the
+                .Call shim does -- upload, kernels, download.  Constructed with the module
+                providing fitBeta/fitDisp/fitDispGrid, so the parity tests can run the very
+                same host code over the CPU oracle.
+  DeviceEngine  handles are gene-major torch CUDA tensors resident in HBM; calls go through
+                dsq_fit_*_dev on the current stream.  Y / nf / weights are uploaded and
+                transposed once, mu-hat produced by fitBeta is consumed in place by fitDisp
+                (SURVEY 8f-2).  torch is used for memory, streams and the O(n*m)
+                elementwise glue (row gathers, clamps); the fits are the HIP kernels.
+"""
+import numpy as np
+
+
+class HostEngine:
+    name = "host"
+
+    def __init__(self, fns=None):
+        if fns is None:
+            from . import native as fns
+        self.fns = fns
+
+    # ---- handles
+    def counts(self, K):
+        return np.ascontiguousarray(K, dtype=np.int32)
+
+    def matrix(self, A):
+        return None if A is None else np.ascontiguousarray(A, dtype=np.float64)
+
+    def design(self, x):
+        return np.ascontiguousarray(x, dtype=np.float64)
+
+    def to_numpy(self, h):
+        return h
+
+    def take_rows(self, h, idx):
+        return None if h is None else h[idx]
+
+    def clamp_min(self, h, v):
+        return np.maximum(h, v)
+
+    def nrow(self, h):
+        return h.shape[0]
+
+    # ---- O(n*m) glue the reference does in R around the native calls
+    def beta_init(self, y, nf, x):
+        """R/fitNbinomGLMs.R:139-145"""
+        q, r = np.linalg.qr(x)
+        ylog = np.log(y / nf + 0.1).T
+        return np.linalg.solve(r, q.T @ ylog).T.copy()
+
+    def normalized_row_stats(self, y, nf, weights=None):
+        """baseMean, baseVar, allZero (R/core.R:2138-2146)"""
+        cn = y / nf
+        if weights is not None:
+            cn = weights * cn
+        return cn.mean(axis=1), cn.var(axis=1, ddof=1), (y.sum(axis=1) == 0)
+
+    def rough_disp(self, y, nf, x):
+        """roughDispEstimate, R/core.R:2422-2437 (linearModelMu :2454-2463)"""
+        m, p = x.shape
+        yn = y / nf
+        q, r = np.linalg.qr(x)
+        mu = np.maximum((yn @ q) @ (x @ np.linalg.inv(r)).T, 1.0)
+        est = (((yn - mu) ** 2 - mu) / mu ** 2).sum(axis=1) / (m - p)
+        return np.maximum(est, 0.0)
+
+    def xim(self, nf):
+        """momentsDispEstimate's xim, R/core.R:2440-2444"""
+        return float(np.mean(1.0 / nf.mean(axis=0)))
+
+    def linear_mu(self, y, nf, x):
+        """linearModelMuNormalized, R/core.R:2465-2471"""
+        q, r = np.linalg.qr(x)
+        return ((y / nf) @ q) @ (x @ np.linalg.inv(r)).T * nf
+
+    def nbinom_loglike(self, y, mu, disp, weights, useWeights):
+        """nbinomLogLike, R/core.R:2208-2217"""
+        from scipy.stats import nbinom
+        size = 1.0 / np.asarray(disp)[:, None]
+        ll = nbinom.logpmf(y, size, size / (size + mu))
+        if useWeights:
+            ll = weights * ll
+        return ll.sum(axis=1)
+
+    # ---- the three native routines
+    def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
+                 minmu, want_mu=True, mu_floor=0.0, want_hat=True):
+        n, m = y.shape
+        w = weights if weights is not None else np.ones((n, m))
+        r = self.fns.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu)
+        if want_mu:
+            mu = nf * np.exp(r["beta_mat"] @ x.T)                 # R/fitNbinomGLMs.R:180
+            if mu_floor > 0:
+                mu = np.maximum(mu, mu_floor)
+            r["mu"] = mu
+        return r
+
+    def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
+                 usePrior, weights, useWeights, weightThreshold, useCR):
+        n, m = y.shape
+        w = weights if weights is not None else np.ones((n, m))
+        return self.fns.fitDisp(y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol,
+                                maxit, usePrior, w, useWeights, weightThreshold, useCR)
+
+    def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,
+                      weightThreshold, useCR):
+        n, m = y.shape
+        w = weights if weights is not None else np.ones((n, m))
+        return self.fns.fitDispGrid(y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, w, useWeights,
+                                    weightThreshold, useCR)
+
+
+class DeviceEngine:
+    name = "device"
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        from . import native
+        self.torch = torch
+        self.native = native
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceEngine needs a CUDA/HIP device; deseq2_amd has no CPU compute path")
+        torch.cuda.set_device(self.device)
+        from . import _lib
+        _lib.check(_lib.lib().dsq_set_device(self.device.index or 0))
+        self.record = None          # set to a list to collect (name, n, start_event, end_event)
+
+    def _timed(self, name, n, fn):
+        if self.record is None:
+            return fn()
+        t = self.torch
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record()                 # torch current stream == the stream the kernels are launched on
+        r = fn()
+        e1.record()
+        self.record.append((name, n, e0, e1))
+        return r
+
+    def _vec(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+
+    # ---- handles
+    def counts(self, K):
+        t = self.torch.as_tensor(np.ascontiguousarray(np.asarray(K, dtype=np.int32).T), device=self.device)
+        return self.native.to_gene_major(t)
+
+    def matrix(self, A):
+        if A is None:
+            return None
+        t = self.torch.as_tensor(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T), device=self.device)
+        return self.native.to_gene_major(t)
+
+    def design(self, x):
+        return self.torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.float64).T), device=self.device)
+
+    def to_numpy(self, h):
+        return h.view().cpu().numpy()
+
+    def take_rows(self, h, idx):
+        if h is None:
+            return None
+        ii = self.torch.as_tensor(np.asarray(idx), device=self.device)
+        if ii.dtype == self.torch.bool:
+            ii = ii.nonzero().squeeze(1)
+        return self.native.GeneMajor(h.t.index_select(0, ii).contiguous(), h.m)
+
+    def clamp_min(self, h, v):
+        return self.native.GeneMajor(self.torch.clamp_min(h.t, v), h.m)
+
+    def nrow(self, h):
+        return h.n
+
+    # ---- O(n*m) glue (torch elementwise / small GEMMs on the device; host work in R)
+    def _xmats(self, x_dev):
+        x = x_dev.t()                                   # m x p
+        q, r = self.torch.linalg.qr(x)
+        return x, q, r
+
+    def beta_init(self, y, nf, x_dev):
+        x, q, r = self._xmats(x_dev)
+        ylog = self.torch.log(y.view().to(self.torch.float64) / nf.view() + 0.1)     # n x m
+        b = self.torch.linalg.solve_triangular(r, (ylog @ q).t(), upper=True)       # p x n
+        return b.contiguous()                                                        # (p, n) = col-major n x p
+
+    def normalized_row_stats(self, y, nf, weights=None):
+        yv = y.view().to(self.torch.float64)
+        cn = yv / nf.view()
+        if weights is not None:
+            cn = weights.view() * cn
+        return (cn.mean(dim=1).cpu().numpy(), cn.var(dim=1, unbiased=True).cpu().numpy(),
+                (yv.sum(dim=1) == 0).cpu().numpy())
+
+    def rough_disp(self, y, nf, x_dev):
+        x, q, r = self._xmats(x_dev)
+        m, p = x.shape
+        yn = y.view().to(self.torch.float64) / nf.view()
+        hat_t = self.torch.linalg.solve_triangular(r, q.t(), upper=True)              # R^-1 Q'  (p x m)
+        mu = self.torch.clamp_min((yn @ q) @ (x @ self.torch.linalg.inv(r)).t(), 1.0)
+        del hat_t
+        est = (((yn - mu) ** 2 - mu) / mu ** 2).sum(dim=1) / (m - p)
+        return self.torch.clamp_min(est, 0.0).cpu().numpy()
+
+    def xim(self, nf):
+        return float((1.0 / nf.view().mean(dim=0)).mean())
+
+    def linear_mu(self, y, nf, x_dev):
+        x, q, r = self._xmats(x_dev)
+        yn = y.view().to(self.torch.float64) / nf.view()
+        mu = (yn @ q) @ (x @ self.torch.linalg.inv(r)).t() * nf.view()
+        out = self.torch.zeros((y.n, y.ld), dtype=self.torch.float64, device=self.device)
+        out[:, : y.m] = mu
+        return self.native.GeneMajor(out, y.m)
+
+    def nbinom_loglike(self, y, mu, disp, weights, useWeights):
+        t = self.torch
+        yv = y.view().to(t.float64)
+        size = (1.0 / self._vec(disp))[:, None]
+        muv = mu.view()
+        ll = (t.lgamma(yv + size) - t.lgamma(size) - t.lgamma(yv + 1.0)
+              + size * t.log(size / (size + muv)) + yv * t.log(muv / (size + muv)))
+        ll = t.where((yv == 0) & (muv == 0), t.zeros_like(ll), ll)
+        if useWeights:
+            ll = weights.view() * ll
+        return ll.sum(dim=1).cpu().numpy()
+
+    # ---- the three native routines
+    def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
+                 minmu, want_mu=True, mu_floor=0.0, want_hat=True):
+        t = self.torch
+        b0 = beta_mat if t.is_tensor(beta_mat) else self._vec(np.asarray(beta_mat).T)
+        av, cv, lv = self._vec(alpha_hat), self._vec(contrast), self._vec(lam)
+        r = self._timed("fit_beta", y.n, lambda: self.native.fitBeta_dev(
+            y, x, nf, av, cv, b0, lv, weights, useWeights, tol, maxit, useQR, minmu, want_hat=want_hat,
+            want_mu=want_mu, mu_floor=mu_floor))
+        out = {"beta_mat": r["beta_mat"].t().cpu().numpy(), "beta_var_mat": r["beta_var_mat"].t().cpu().numpy(),
+               "iter": r["iter"].cpu().numpy(), "deviance": r["deviance"].cpu().numpy(),
+               "contrast_num": r["contrast_num"].cpu().numpy().reshape(-1, 1),
+               "contrast_denom": r["contrast_denom"].cpu().numpy().reshape(-1, 1),
+               "hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}
+        return out
+
+    def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
+                 usePrior, weights, useWeights, weightThreshold, useCR):
+        n = y.n
+        la = self._vec(np.broadcast_to(np.asarray(log_alpha, float), (n,)))
+        pm = self._vec(np.broadcast_to(np.asarray(prior_mean, float), (n,)))
+        r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
+            y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
+            weightThreshold, useCR))
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,
+                      weightThreshold, useCR):
+        n = y.n
+        pm = self._vec(np.broadcast_to(np.asarray(prior_mean, float), (n,)))
+        gv = self._vec(disp_grid)
+        r = self._timed("fit_disp_grid", n, lambda: self.native.fitDispGrid_dev(
+            y, x, mu_hat, gv, pm, prior_sigmasq, usePrior, weights, useWeights, weightThreshold, useCR))
+        return {"log_alpha": r["log_alpha"].cpu().numpy()}

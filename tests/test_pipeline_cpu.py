@@ -1,0 +1,62 @@
+"""CPU (no GPU): the host-side mirror of the reference's R callers, driven over the CPU
+oracle instead of the MI355X engine (same function signatures).  This is BASELINE.json
+configs[0]: makeExampleDESeqDataSet(n=1000, m=6) ~condition, full DESeq() -- plumbing."""
+import numpy as np
+import pytest
+
+from deseq2_amd import core, simulate
+from deseq2_amd.engine import HostEngine
+
+
+@pytest.fixture(scope="module")
+def fitted(oracle):
+    x = simulate.design_two_group(6)
+    d = simulate.make_counts(1000, x, seed=1)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle))
+    core.DESeq(dds)
+    return dds, d
+
+
+def test_deseq_c1_plumbing(fitted):
+    dds, d = fitted
+    mc = dds.mcols
+    for k in ("dispGeneEst", "dispFit", "dispMAP", "dispersion", "beta", "betaSE", "WaldStatistic", "WaldPvalue"):
+        assert np.isfinite(mc[k]).all(), k
+    assert dds.dispersionFunction["fitType"] == "parametric"
+    a0, a1 = dds.dispersionFunction["coefficients"]
+    assert 0.02 < a0 < 0.4 and 1.0 < a1 < 10.0          # true trend: 0.1 + 4/mean
+    assert (mc["dispersion"] >= 1e-8).all() and (mc["dispersion"] <= 10).all()
+    assert mc["betaConv"].mean() > 0.95
+    # log2 fold changes recover the simulated ones for well-expressed genes
+    hi = mc["baseMean"] > 50
+    assert np.corrcoef(mc["beta"][hi, 1], d["beta"][hi, 1])[0, 1] > 0.8
+    assert ((mc["WaldPvalue"] >= 0) & (mc["WaldPvalue"] <= 1)).all()
+    np.testing.assert_allclose(mc["WaldStatistic"], mc["beta"] / mc["betaSE"])
+
+
+def test_gene_est_rules(fitted):
+    """accept/reject and clamp rules of R/core.R:826-848"""
+    dds, _ = fitted
+    mc = dds.mcols
+    assert mc["dispGeneIter"].min() >= 1 and mc["dispGeneIter"].max() <= 100
+    assert (mc["dispGeneEst"] >= 1e-8).all() and (mc["dispGeneEst"] <= 10).all()
+    out = mc["dispOutlier"]
+    np.testing.assert_array_equal(mc["dispersion"][out], mc["dispGeneEst"][out])
+    np.testing.assert_array_equal(mc["dispersion"][~out], mc["dispMAP"][~out])
+
+
+def test_lrt_reduced_intercept(oracle):
+    x = simulate.design_batch_condition(12)
+    d = simulate.make_counts(300, x, seed=2)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle))
+    core.DESeq(dds, test="LRT", reduced=x[:, :3])
+    assert (dds.mcols["LRTStatistic"] > -0.05).all()   # minmu clamp in IRLS vs unclamped logLike (as in R)
+    assert ((dds.mcols["LRTPvalue"] >= 0) & (dds.mcols["LRTPvalue"] <= 1)).all()
+    dds2 = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle))
+    core.DESeq(dds2, test="LRT", reduced=np.ones((12, 1)))
+    assert (dds2.mcols["LRTStatistic"] >= dds.mcols["LRTStatistic"] - 0.05).all()   # nested models
+
+
+def test_na_guard():
+    with pytest.raises(ValueError, match="contain NA"):
+        core._na_guard("fitBeta", alpha_hatSEXP=np.array([1.0, np.nan]))
