@@ -99,6 +99,13 @@ def lib():
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C deseq2_amd/csrc`.  deseq2_amd has no CPU fallback." % SO_PATH)
+    # torch bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+    # A process must not end up with two runtimes, so when torch is installed it is imported
+    # first: the engine library then binds to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     L.dsq_last_error.restype = C.c_char_p
     L.dsq_version.restype = C.c_int

@@ -1,0 +1,152 @@
+/*
+ * r_shim.c -- the R-side binding of libdeseq2_mi355x.so: three `.Call` entry points with
+ * the names, arities and return-list shapes of the reference's src/RcppExports.cpp:16-94
+ * (_DESeq2_fitDisp 15 args, _DESeq2_fitBeta 13 args, _DESeq2_fitDispGrid 11 args), so that
+ * R/RcppExports.R:4,8,12 and every R caller (R/wrappers.R:35,73,115, R/results.R:797,
+ * tests/testthat/test_dispersions.R:67) work unchanged.
+ *
+ * Uses only Rinternals.h (no Rcpp, no Armadillo).  R is NOT installed in the build image
+ * of this repository, so this file is compiled only where R exists:
+ *     R CMD SHLIB -o DESeq2.so r_shim.c -I../../include -L.. -ldeseq2_mi355x
+ * (see INTEGRATION.md).  It contains no arithmetic: all computation is in the HIP library.
+ */
+#ifdef DSQ_HAVE_R
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <R_ext/Utils.h>
+#include "deseq2_mi355x.h"
+
+static void chk(int rc) {
+    /* the reference turns C++ exceptions into R errors (BEGIN_RCPP/END_RCPP) */
+    if (rc != DSQ_OK) Rf_error("deseq2_mi355x: %s", dsq_last_error());
+}
+
+/* counts arrive as INTSXP from counts(dds) but Rcpp coerced anything numeric
+ * (src/DESeq2.cpp:165,285): accept both */
+static const void *counts_ptr(SEXP y, int *type) {
+    if (TYPEOF(y) == INTSXP) { *type = DSQ_Y_INT32; return INTEGER(y); }
+    if (TYPEOF(y) == REALSXP) { *type = DSQ_Y_FLOAT64; return REAL(y); }
+    Rf_error("ySEXP must be an integer or numeric matrix");
+    return NULL;
+}
+static double scalar_d(SEXP s) { return Rf_asReal(s); }
+static int scalar_i(SEXP s) { return Rf_asInteger(s); }      /* maxit may arrive as double 100 */
+static int scalar_b(SEXP s) { return Rf_asLogical(s) == TRUE; }
+static SEXP as_real(SEXP s, int *np) { SEXP r = PROTECT(Rf_coerceVector(s, REALSXP)); (*np)++; return r; }
+
+static SEXP named_list(int k, const char **names, SEXP *vals) {
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, k)), nm = PROTECT(Rf_allocVector(STRSXP, k));
+    for (int i = 0; i < k; i++) { SET_VECTOR_ELT(out, i, vals[i]); SET_STRING_ELT(nm, i, Rf_mkChar(names[i])); }
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(2);
+    return out;
+}
+
+SEXP _DESeq2_fitBeta(SEXP ySEXP, SEXP xSEXP, SEXP nfSEXP, SEXP alpha_hatSEXP, SEXP contrastSEXP,
+                     SEXP beta_matSEXP, SEXP lambdaSEXP, SEXP weightsSEXP, SEXP useWeightsSEXP,
+                     SEXP tolSEXP, SEXP maxitSEXP, SEXP useQRSEXP, SEXP minmuSEXP) {
+    int np = 0;
+    R_CheckUserInterrupt();
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    SEXP x = as_real(xSEXP, &np), nf = as_real(nfSEXP, &np), alpha = as_real(alpha_hatSEXP, &np);
+    SEXP con = as_real(contrastSEXP, &np), b0 = as_real(beta_matSEXP, &np), lam = as_real(lambdaSEXP, &np);
+    SEXP w = as_real(weightsSEXP, &np);
+    DsqFitBetaArgs a = {0};
+    a.n = n; a.m = m; a.p = p; a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.x = REAL(x); a.nf = REAL(nf); a.alpha_hat = REAL(alpha); a.contrast = REAL(con);
+    a.beta_mat = REAL(b0); a.lambda = REAL(lam); a.weights = REAL(w);
+    a.useWeights = scalar_b(useWeightsSEXP); a.tol = scalar_d(tolSEXP); a.maxit = scalar_i(maxitSEXP);
+    a.useQR = scalar_b(useQRSEXP); a.minmu = scalar_d(minmuSEXP);
+    SEXP beta = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
+    SEXP var = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
+    SEXP iter = PROTECT(Rf_allocVector(REALSXP, n)); np++;      /* NumericVector in the reference (:317) */
+    SEXP hat = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++;
+    SEXP cn = PROTECT(Rf_allocMatrix(REALSXP, n, 1)); np++;
+    SEXP cd = PROTECT(Rf_allocMatrix(REALSXP, n, 1)); np++;
+    SEXP dev = PROTECT(Rf_allocVector(REALSXP, n)); np++;
+    DsqFitBetaOut o = {0};
+    o.beta_mat = REAL(beta); o.beta_var_mat = REAL(var); o.iter = REAL(iter); o.hat_diagonals = REAL(hat);
+    o.contrast_num = REAL(cn); o.contrast_denom = REAL(cd); o.deviance = REAL(dev);
+    chk(dsq_fit_beta(&a, &o));
+    const char *names[] = {"beta_mat", "beta_var_mat", "iter", "hat_diagonals", "contrast_num",
+                           "contrast_denom", "deviance"};                        /* src/DESeq2.cpp:458-464 */
+    SEXP vals[] = {beta, var, iter, hat, cn, cd, dev};
+    SEXP out = named_list(7, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
+SEXP _DESeq2_fitDisp(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP log_alphaSEXP,
+                     SEXP log_alpha_prior_meanSEXP, SEXP log_alpha_prior_sigmasqSEXP,
+                     SEXP min_log_alphaSEXP, SEXP kappa_0SEXP, SEXP tolSEXP, SEXP maxitSEXP,
+                     SEXP usePriorSEXP, SEXP weightsSEXP, SEXP useWeightsSEXP, SEXP weightThresholdSEXP,
+                     SEXP useCRSEXP) {
+    int np = 0;
+    R_CheckUserInterrupt();
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    SEXP x = as_real(xSEXP, &np), mu = as_real(mu_hatSEXP, &np), la = as_real(log_alphaSEXP, &np);
+    SEXP pm = as_real(log_alpha_prior_meanSEXP, &np), w = as_real(weightsSEXP, &np);
+    DsqFitDispArgs a = {0};
+    a.n = n; a.m = m; a.p = p; a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.x = REAL(x); a.mu_hat = REAL(mu); a.log_alpha = REAL(la); a.log_alpha_prior_mean = REAL(pm);
+    a.log_alpha_prior_sigmasq = scalar_d(log_alpha_prior_sigmasqSEXP);
+    a.min_log_alpha = scalar_d(min_log_alphaSEXP); a.kappa_0 = scalar_d(kappa_0SEXP);
+    a.tol = scalar_d(tolSEXP); a.maxit = scalar_i(maxitSEXP); a.usePrior = scalar_b(usePriorSEXP);
+    a.weights = REAL(w); a.useWeights = scalar_b(useWeightsSEXP);
+    a.weightThreshold = scalar_d(weightThresholdSEXP); a.useCR = scalar_b(useCRSEXP);
+    const char *names[] = {"log_alpha", "iter", "iter_accept", "last_change", "initial_lp", "initial_dlp",
+                           "last_lp", "last_dlp", "last_d2lp"};                  /* src/DESeq2.cpp:268-276 */
+    SEXP vals[9];
+    for (int i = 0; i < 9; i++) {
+        vals[i] = PROTECT(Rf_allocVector((i == 1 || i == 2) ? INTSXP : REALSXP, n)); np++;
+    }
+    DsqFitDispOut o = {0};
+    o.log_alpha = REAL(vals[0]); o.iter = INTEGER(vals[1]); o.iter_accept = INTEGER(vals[2]);
+    o.last_change = REAL(vals[3]); o.initial_lp = REAL(vals[4]); o.initial_dlp = REAL(vals[5]);
+    o.last_lp = REAL(vals[6]); o.last_dlp = REAL(vals[7]); o.last_d2lp = REAL(vals[8]);
+    chk(dsq_fit_disp(&a, &o));
+    SEXP out = named_list(9, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
+SEXP _DESeq2_fitDispGrid(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP disp_gridSEXP,
+                         SEXP log_alpha_prior_meanSEXP, SEXP log_alpha_prior_sigmasqSEXP, SEXP usePriorSEXP,
+                         SEXP weightsSEXP, SEXP useWeightsSEXP, SEXP weightThresholdSEXP, SEXP useCRSEXP) {
+    int np = 0;
+    R_CheckUserInterrupt();
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    SEXP x = as_real(xSEXP, &np), mu = as_real(mu_hatSEXP, &np), grid = as_real(disp_gridSEXP, &np);
+    SEXP pm = as_real(log_alpha_prior_meanSEXP, &np), w = as_real(weightsSEXP, &np);
+    DsqFitDispGridArgs a = {0};
+    a.n = n; a.m = m; a.p = p; a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.x = REAL(x); a.mu_hat = REAL(mu); a.disp_grid = REAL(grid); a.ngrid = Rf_length(grid);
+    a.log_alpha_prior_mean = REAL(pm); a.log_alpha_prior_sigmasq = scalar_d(log_alpha_prior_sigmasqSEXP);
+    a.usePrior = scalar_b(usePriorSEXP); a.weights = REAL(w); a.useWeights = scalar_b(useWeightsSEXP);
+    a.weightThreshold = scalar_d(weightThresholdSEXP); a.useCR = scalar_b(useCRSEXP);
+    SEXP la = PROTECT(Rf_allocVector(REALSXP, n)); np++;
+    DsqFitDispGridOut o = {0};
+    o.log_alpha = REAL(la);
+    chk(dsq_fit_disp_grid(&a, &o));
+    const char *names[] = {"log_alpha"};                                         /* src/DESeq2.cpp:512 */
+    SEXP vals[] = {la};
+    SEXP out = named_list(1, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"_DESeq2_fitDisp", (DL_FUNC)&_DESeq2_fitDisp, 15},
+    {"_DESeq2_fitBeta", (DL_FUNC)&_DESeq2_fitBeta, 13},
+    {"_DESeq2_fitDispGrid", (DL_FUNC)&_DESeq2_fitDispGrid, 11},
+    {NULL, NULL, 0}};
+
+void R_init_DESeq2(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}
+#endif /* DSQ_HAVE_R */

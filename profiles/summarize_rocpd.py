@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd database (the default output of `rocprofv3 --kernel-trace
+--stats` on ROCm 7.2) into the per-kernel table kept under profiles/.
+usage: python profiles/summarize_rocpd.py gpurun_out/prof/x_results.db > profiles/rNN_kernel_stats.md"""
+import sqlite3
+import sys
+
+
+def main(path, top=14):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute(
+        "select name, count(*), sum(end-start)/1e6, avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6, "
+        "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+        "max(grid_x), max(workgroup_x) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print("| kernel | calls | total ms | avg ms | min ms | max ms | % GPU time | vgpr | agpr | sgpr | LDS B | scratch B | grid | wg |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows[:top]:
+        print("| `%s` | %d | %.3f | %.3f | %.3f | %.3f | %.1f | %s | %s | %s | %s | %s | %s | %s |" %
+              ((r[0][:90], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot) + tuple(r[6:13])))
+    rest = rows[top:]
+    print("| (%d other kernels: torch glue, copies) | %d | %.3f | | | | %.1f | | | | | | | |" %
+          (len(rest), sum(r[1] for r in rest), sum(r[2] for r in rest), 100 * sum(r[2] for r in rest) / tot))
+    print("\ntotal GPU kernel time: %.3f ms" % tot)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library loads, exports every symbol include/deseq2_mi355x.h declares, and
+fails loudly (no CPU fallback) when no GPU is present.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    h = open(os.path.join(ROOT, "include", "deseq2_mi355x.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsq_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deseq2_amd import _lib
+    L = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 16
+    assert sorted(_lib.EXPORTED_SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert L.dsq_version() == 100
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of the argument blocks: sizes as the C compiler lays them out"""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "deseq2_mi355x.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(DsqFitBetaArgs), sizeof(DsqFitBetaOut),
+ sizeof(DsqFitDispArgs), sizeof(DsqFitDispOut), sizeof(DsqFitDispGridArgs), sizeof(DsqFitDispGridOut)); return 0; }
+'''
+    from deseq2_amd import _lib
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = list(map(int, subprocess.check_output([exe]).split()))
+    want = [ctypes.sizeof(t) for t in (_lib.DsqFitBetaArgs, _lib.DsqFitBetaOut, _lib.DsqFitDispArgs,
+                                        _lib.DsqFitDispOut, _lib.DsqFitDispGridArgs, _lib.DsqFitDispGridOut)]
+    assert sizes == want
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from deseq2_amd import _lib, native
+    y = np.ones((4, 6), dtype=np.int32)
+    x = np.column_stack([np.ones(6), np.repeat([0, 1], 3)]).astype(float)
+    with pytest.raises(_lib.DsqError) as ei:
+        native.fitBeta(y, x, np.ones((4, 6)), np.full(4, 0.1), [1, 0], np.zeros((4, 2)), [1e-6, 1e-6],
+                       np.ones((4, 6)), False, 1e-8, 100, True, 0.5)
+    assert ei.value.code == 3            # DSQ_ERR_DEVICE
+    with pytest.raises(_lib.DsqError):
+        native.fitDisp(y, x, np.ones((4, 6)), np.zeros(4), np.zeros(4), 1.0, -20.0, 1.0, 1e-6, 100, False,
+                       np.ones((4, 6)), False, 1e-2, True)
+
+
+def test_argument_validation():
+    from deseq2_amd import native
+    y = np.ones((4, 6), dtype=np.int32)
+    x = np.ones((5, 2))
+    with pytest.raises(ValueError):
+        native.fitBeta(y, x, np.ones((4, 6)), np.full(4, 0.1), [1, 0], np.zeros((4, 2)), [1e-6, 1e-6],
+                       np.ones((4, 6)), False, 1e-8, 100, True, 0.5)
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under deseq2_amd/ may reference it"""
+    for dp, _, files in os.walk(os.path.join(ROOT, "deseq2_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "orc_" not in txt, f

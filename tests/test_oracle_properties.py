@@ -1,0 +1,162 @@
+"""CPU: the oracle against the properties the reference's own tests assert for this path
+ -- re-run with numpy/scipy because the seeds in the R tests are
+R-RNG specific -- plus the two literal known-answer vectors those tests hold."""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import optimize, stats
+
+from tests.helpers import make_case
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nmath_golden.json")))
+
+
+def _two_group(m):
+    return np.column_stack([np.ones(m), np.repeat([0, 1], m // 2)]).astype(float)
+
+
+def test_kat_results_contrasts(oracle):
+    """tests/testthat/test_results.R:9,43-50: perfect-fit gene -> beta = log2(100), 0, 1, 3"""
+    k = GOLD["kat"]["test_results_R_9_43_50"]
+    y = np.array(k["counts"], float)[None, :]
+    group = np.tile([1, 2], 6); cond = np.repeat([1, 2, 3], 4)
+    X = np.column_stack([np.ones(12), group == 2, cond == 2, cond == 3]).astype(float)
+    b0 = np.linalg.lstsq(X, np.log(y[0] + .1), rcond=None)[0][None, :]
+    lam = np.full(4, 1e-6) / np.log(2) ** 2
+    for alpha in (0.01, 0.05, 0.3):       # "for any alpha" (perfect fit)
+        r = oracle.fitBeta(y, X, np.ones((1, 12)), [alpha], [1, 0, 0, 0], b0, lam, np.ones((1, 12)), False, 1e-8,
+                           100, True, 0.5)
+        np.testing.assert_allclose(r["beta_mat"][0] / np.log(2), k["beta_log2"], atol=1e-6)
+    # contrasts of the test: condition 1 vs 3 = -3, 1 vs 2 = -1, 2 vs 3 = -2 (maxit = 0 mode, R/results.R:797)
+    for c, want in (([0, 0, 0, -1], -3), ([0, 0, -1, 0], -1), ([0, 0, 1, -1], -2)):
+        rc = oracle.fitBeta(y, X, np.ones((1, 12)), [0.05], c, r["beta_mat"], lam, np.ones((1, 12)), False, 1e-8, 0,
+                            False, 0.5)
+        assert rc["contrast_num"][0, 0] / np.log(2) == pytest.approx(want, abs=1e-6)
+        assert rc["iter"][0] == 0
+
+
+def test_kat_optim_nonconvergence(oracle):
+    """tests/testthat/test_optim.R:30-39: IRLS must report iter == maxit for this row"""
+    k = GOLD["kat"]["test_optim_R_30_39"]
+    y = np.array(k["counts"], float)[None, :]
+    X = _two_group(10)
+    b0 = np.linalg.lstsq(X, np.log(y[0] + .1), rcond=None)[0][None, :]
+    for alpha in (0.5, 2.0, 5.0):
+        for useQR in (True, False):
+            r = oracle.fitBeta(y, X, np.ones((1, 10)), [alpha], [1, 0], b0, np.full(2, 1e-6) / np.log(2) ** 2,
+                               np.ones((1, 10)), False, 1e-8, 100, useQR, 0.5)
+            assert r["iter"][0] == k["betaIter"]
+            assert np.abs(r["beta_mat"]).max() > 30          # the diverged beta is kept (:428)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_beta_irls_vs_textbook_and_optim(oracle, seed):
+    """tests/testthat/test_betaFitting.R:2-47"""
+    rng = np.random.default_rng(seed)
+    m = 10
+    y = rng.poisson(20, m).astype(float); sf = np.ones(m); x = _two_group(m)
+    lam, alpha = 2.0, 0.5
+    r = oracle.fitBeta(y[None, :], x, sf[None, :], [alpha], [1, 0], np.array([[1.0, 1.0]]), [0.0, lam],
+                       np.ones((1, m)), False, 1e-8, 100, True, 0.5)
+    b = np.array([1., 1.])
+    for _ in range(100):
+        mu = sf * np.exp(x @ b)
+        w = np.diag(1 / (1 / mu ** 2 * (mu + alpha * mu ** 2)))
+        z = np.log(mu / sf) + (y - mu) / mu
+        b = np.linalg.solve(x.T @ w @ x + np.diag([0, lam]), x.T @ w @ z)
+    np.testing.assert_allclose(r["beta_mat"][0], b, rtol=1e-6, atol=1e-9)
+
+    def obj(pv):
+        mu = np.exp(x @ pv)
+        return -(stats.nbinom.logpmf(y, 1 / alpha, 1 / (1 + alpha * mu)).sum() + stats.norm.logpdf(pv[1], 0, np.sqrt(1 / lam)))
+    o = optimize.minimize(obj, [.1, .1], method="Nelder-Mead", options={"xatol": 1e-10, "fatol": 1e-14, "maxiter": 5000})
+    np.testing.assert_allclose(r["beta_mat"][0], o.x, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_disp_vs_brent_and_derivatives(oracle, seed):
+    """tests/testthat/test_dispersions.R:35-111"""
+    rng = np.random.default_rng(seed)
+    m = 10
+    y = rng.poisson(20, m).astype(float); x = _two_group(m)
+    fb = oracle.fitBeta(y[None, :], x, np.ones((1, m)), [0.5], [1, 0], np.array([[1.0, 1.0]]), [0.0, 2.0],
+                        np.ones((1, m)), False, 1e-8, 100, True, 0.5)
+    mu_hat = np.exp(x @ fb["beta_mat"][0])
+    pm, ps = 0.5, 1.0
+    d = oracle.fitDisp(y[None, :], x, mu_hat[None, :], [0.0], [pm], ps, np.log(1e-8), 1.0, 1e-16, 100, True,
+                       np.ones((1, m)), False, 1e-2, True)
+
+    def logPost(la):
+        a = np.exp(la)
+        w = np.diag(1 / (1 / mu_hat ** 2 * (mu_hat + a * mu_hat ** 2)))
+        return (stats.nbinom.logpmf(y, 1 / a, 1 / (1 + a * mu_hat)).sum() - .5 * np.log(np.linalg.det(x.T @ w @ x))
+                + stats.norm.logpdf(la, pm, np.sqrt(ps)))
+    o = optimize.minimize_scalar(lambda v: -logPost(v), bounds=(-10, 10), method="bounded", options={"xatol": 1e-12})
+    assert d["log_alpha"][0] == pytest.approx(o.x, abs=2e-6)
+    h = 1e-3
+    assert d["initial_dlp"][0] == pytest.approx((logPost(h / 2) - logPost(-h / 2)) / h, rel=1e-6)
+    la = d["log_alpha"][0]
+    assert d["last_d2lp"][0] == pytest.approx((logPost(la + h) - 2 * logPost(la) + logPost(la - h)) / h ** 2, rel=1e-5)
+
+
+def test_qr_equals_normal_equations(oracle):
+    """tests/testthat/test_QR.R:2-10 (tolerance 1e-6)"""
+    d = make_case(300, 40, "batch_condition", seed=8)
+    lam = np.full(4, 1e-6) / np.log(2) ** 2
+    args = (d["counts"], d["x"], d["nf"], d["alpha_init"], [1, 0, 0, 0], d["beta_init"], lam, d["weights"], False,
+            1e-8, 100)
+    a = oracle.fitBeta(*args, True, 0.5); b = oracle.fitBeta(*args, False, 0.5)
+    conv = (a["iter"] < 100) & (b["iter"] < 100)
+    np.testing.assert_allclose(a["beta_mat"][conv], b["beta_mat"][conv], rtol=1e-6, atol=1e-8)
+
+
+def test_weight_zero_equals_sample_removed(oracle):
+    """tests/testthat/test_weights.R:9-19"""
+    d = make_case(100, 12, "two_group", seed=9)
+    w = np.ones_like(d["nf"]); w[:, 0] = 0.0
+    lam = np.full(2, 1e-6) / np.log(2) ** 2
+    a = oracle.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], [1, 0], d["beta_init"], lam, w, True, 1e-8, 100,
+                       True, 0.5)
+    b = oracle.fitBeta(d["counts"][:, 1:], d["x"][1:], d["nf"][:, 1:], d["alpha_init"], [1, 0], d["beta_init"], lam,
+                       w[:, 1:], False, 1e-8, 100, True, 0.5)
+    conv = (a["iter"] < 100) & (b["iter"] < 100)
+    np.testing.assert_allclose(a["beta_mat"][conv], b["beta_mat"][conv], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(a["beta_var_mat"][conv], b["beta_var_mat"][conv], rtol=1e-6)
+    np.testing.assert_allclose(a["deviance"][conv], b["deviance"][conv], rtol=1e-8)
+
+
+def test_grid_brackets_the_optimum(oracle):
+    d = make_case(60, 30, "two_group", seed=10)
+    mu = np.maximum(d["nf"] * np.exp(d["beta_init"] @ d["x"].T), 0.5)
+    grid = np.linspace(np.log(1e-8), np.log(30.0), 20)
+    n = d["counts"].shape[0]
+    g = oracle.fitDispGrid(d["counts"], d["x"], mu, grid, np.zeros(n), 1.0, False, d["weights"], False, 1e-2, True)
+    f = oracle.fitDisp(d["counts"], d["x"], mu, np.log(d["alpha_init"]), np.zeros(n), 1.0, np.log(1e-9), 1.0, 1e-10,
+                       500, False, d["weights"], False, 1e-2, True)
+    ok = (f["iter"] < 500) & (f["log_alpha"] > grid[0] + 1) & (f["log_alpha"] < grid[-1] - 1)
+    delta = grid[1] - grid[0]
+    assert ok.sum() > 20
+    assert np.max(np.abs(g["log_alpha"][ok] - f["log_alpha"][ok])) <= 2 * delta / 19 + 1e-6
+
+
+def test_summation_order_sensitivity(oracle):
+    """How much the FIXED summation order matters: serial sums (sum_mode = 1) vs wave order.
+    Values agree to ~1e-10; a few iteration counters may move -- which is why parity is
+    defined against one fully specified arithmetic."""
+    d = make_case(400, 100, "batch_condition", seed=12)
+    lam = np.full(4, 1e-6) / np.log(2) ** 2
+    args = (d["counts"], d["x"], d["nf"], d["alpha_init"], [1, 0, 0, 0], d["beta_init"], lam, d["weights"], False,
+            1e-8, 100, True, 0.5)
+    a = oracle.fitBeta(*args, sum_mode=0); b = oracle.fitBeta(*args, sum_mode=1)
+    assert (a["iter"] == b["iter"]).mean() > 0.99
+    conv = (a["iter"] < 100) & (b["iter"] < 100) & (a["iter"] == b["iter"])
+    np.testing.assert_allclose(a["beta_mat"][conv], b["beta_mat"][conv], rtol=1e-9, atol=1e-11)
+    mu = np.maximum(d["nf"] * np.exp(a["beta_mat"] @ d["x"].T), 0.5)
+    la0 = np.log(d["alpha_init"])
+    dargs = (d["counts"], d["x"], mu, la0, la0, 1.0, np.log(1e-9), 1.0, 1e-6, 100, False, d["weights"], False, 1e-2, True)
+    da = oracle.fitDisp(*dargs, sum_mode=0); db = oracle.fitDisp(*dargs, sum_mode=1)
+    same = da["iter"] == db["iter"]
+    assert same.mean() > 0.97
+    np.testing.assert_allclose(da["log_alpha"][same], db["log_alpha"][same], rtol=1e-6, atol=1e-7)
