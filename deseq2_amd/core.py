@@ -260,28 +260,34 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
 
 def parametricDispersionFit(means, disps):
     """R/core.R:2166-2190: disp ~ asymptDisp + extraPois/mean by a Gamma GLM with identity link
-    (stats::glm IRLS restated: weights mu^-2, working response = disps)."""
+    (stats::glm's IRLS restated: working weights mu^-2, working response = disps; the two-column
+    normal equations are formed from five weighted sums)."""
+    means = np.asarray(means, np.float64)
+    disps = np.asarray(disps, np.float64)
     coefs = np.array([0.1, 1.0])
     it = 0
     while True:
         residuals = disps / (coefs[0] + coefs[1] / means)
         good = (residuals > 1e-4) & (residuals < 15)
         yg, xg = disps[good], 1.0 / means[good]
-        X = np.column_stack([np.ones(xg.size), xg])
         b = coefs.copy()
         converged = False
         dev_old = None
         for _ in range(25):                                   # glm.control(maxit = 25, epsilon = 1e-8)
-            mu = X @ b
-            if (mu <= 0).any():
+            mu = b[0] + b[1] * xg
+            if mu.min() <= 0:
                 raise RuntimeError("parametric dispersion fit failed")
-            wgt = 1.0 / mu ** 2
-            XtW = X.T * wgt
-            b = np.linalg.solve(XtW @ X, XtW @ yg)
-            mu = X @ b
-            if (mu <= 0).any():
+            wgt = 1.0 / (mu * mu)
+            wx = wgt * xg
+            s0, s1, s2 = wgt.sum(), wx.sum(), (wx * xg).sum()
+            t0, t1 = (wgt * yg).sum(), (wx * yg).sum()
+            det = s0 * s2 - s1 * s1
+            b = np.array([(s2 * t0 - s1 * t1) / det, (s0 * t1 - s1 * t0) / det])
+            mu = b[0] + b[1] * xg
+            if mu.min() <= 0:
                 raise RuntimeError("parametric dispersion fit failed")
-            dev = -2.0 * np.sum(np.log(yg / mu) - (yg - mu) / mu)
+            r = yg / mu
+            dev = -2.0 * (np.log(r).sum() - (r - 1.0).sum())
             if dev_old is not None and abs(dev - dev_old) / (abs(dev) + 0.1) < 1e-8:
                 converged = True
                 break
@@ -420,7 +426,7 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
         df = np.where(np.asarray(df, float) > 0, df, np.nan)
         WaldPvalue = 2 * tdist.sf(np.abs(WaldStatistic), df=np.asarray(df)[:, None])
     else:
-        WaldPvalue = 2 * sps.ndtr(-np.abs(WaldStatistic))                           # :1507
+        WaldPvalue = E.two_sided_normal_p(WaldStatistic)                            # :1507
     logLike = E.nbinom_loglike(dds.y, fit["mu"], dds.mcols["dispersion"], weights, useWeights)   # fitNbinomGLMs.R:182
     dds.mcols.update(beta=betaMatrix, betaSE=betaSE, WaldStatistic=WaldStatistic, WaldPvalue=WaldPvalue,
                      betaConv=fit["betaConv"], betaIter=fit["betaIter"], deviance=-2 * logLike,

@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -33,6 +34,19 @@ static int fail(int code, const char *fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? DSQ_ERR_NOMEM : DSQ_ERR_DEVICE, "%s: %s", #expr, \
                         hipGetErrorString(e_));                                                  \
     } while (0)
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+const Tuning &tuning() {
+    static Tuning t = {env_int("DSQ_BETA_WAVES", 4), env_int("DSQ_BETA_STAGE", -1), env_int("DSQ_BETA_BPC", 0),
+                       env_int("DSQ_BETA_LDS_KB", 64),
+                       env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
+                       env_int("DSQ_DISP_LDS_KB", 64), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0)};
+    return t;
+}
 
 int device_cu_count() {
     static int cached[64];
@@ -139,6 +153,10 @@ struct DispatchP {
         if (p == P) { *ok = true; return launch_fit_beta_p<P>(kp, st); }
         return DispatchP<P - 1>::beta(p, kp, st, ok);
     }
+    static void beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr) {
+        if (p == P) { fit_beta_scratch_doubles<P>(n, m, useW, slab, cscr); return; }
+        DispatchP<P - 1>::beta_scratch(p, n, m, useW, slab, cscr);
+    }
     static hipError_t disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
         if (p == P) { *ok = true; return launch_fit_disp_p<P>(kp, st, grid); }
         return DispatchP<P - 1>::disp(p, kp, st, grid, ok);
@@ -147,6 +165,7 @@ struct DispatchP {
 template <>
 struct DispatchP<0> {
     static hipError_t beta(int, const BetaKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
+    static void beta_scratch(int, int, int, int, size_t *slab, size_t *cscr) { *slab = 0; *cscr = 0; }
     static hipError_t disp(int, const DispKernelParams &, hipStream_t, bool, bool *ok) { *ok = false; return hipSuccess; }
 };
 
@@ -189,6 +208,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     kp.lambda = a->lambda;
     kp.tol = a->tol; kp.minmu = a->minmu; kp.mu_floor = o->mu_floor;
     kp.maxit = a->maxit; kp.useQR = a->useQR ? 1 : 0; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
     // n x m outputs: directly when gene-major, through a workspace when R layout
@@ -207,10 +227,12 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
             mu_ws = (double *)b; kp.mu_out = mu_ws;
         }
     }
-    size_t sb = fit_beta_scratch_bytes(a->m, a->p, a->useWeights);
-    if (sb) {
-        void *b; rc = ws_get(WS_SCRATCH, sb, &b); if (rc) return rc;
+    size_t slab_d = 0, cscr_d = 0;
+    DispatchP<DSQ_P_REG>::beta_scratch(a->p, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    {
+        void *b; rc = ws_get(WS_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b); if (rc) return rc;
         kp.scratch = (double *)b;
+        kp.cscratch = (double *)b + slab_d;
     }
     bool ok = false;
     DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
@@ -287,6 +309,7 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.prior_sigmasq = a->log_alpha_prior_sigmasq; kp.min_log_alpha = a->min_log_alpha;
     kp.kappa_0 = a->kappa_0; kp.tol = a->tol; kp.weightThreshold = a->weightThreshold;
     kp.maxit = a->maxit; kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
+    kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
     kp.log_alpha = o->log_alpha; kp.iter = o->iter; kp.iter_accept = o->iter_accept;
     kp.last_change = o->last_change; kp.initial_lp = o->initial_lp; kp.initial_dlp = o->initial_dlp;
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;

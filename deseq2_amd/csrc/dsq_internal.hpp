@@ -24,6 +24,7 @@ struct DispKernelParams {
     // fitDispGrid
     const double *grid;
     int ngrid;
+    int ablate, force_iters; // profiling only
 };
 
 struct BetaKernelParams {
@@ -43,6 +44,8 @@ struct BetaKernelParams {
     double *beta_mat, *beta_var_mat, *iter, *hat_diagonals, *contrast_num, *contrast_denom, *deviance;
     double *mu_out;
     double *scratch;        // global per-wave-slot scratch when rows are not staged in LDS
+    double *cscratch;       // per-wave-slot scratch for the hoisted NB-density constants (3 m doubles)
+    int ablate, force_iters; // profiling only (env DSQ_ABLATE / DSQ_FORCE_ITERS): skip phases / fixed trip count
 };
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
@@ -50,8 +53,17 @@ struct BetaKernelParams {
 #define DSQ_P_REG 6
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
-// bytes of global scratch fitBeta needs when the per-wave slabs do not fit in LDS (0 if they do)
-size_t fit_beta_scratch_bytes(int m, int p, int use_weights);
+// doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they
+// do not fit in LDS, else 0) and `cscr` (hoisted NB-density constants)
+template <int P> void fit_beta_scratch_doubles(int n, int m, int use_weights, size_t *slab, size_t *cscr);
+
+// launch-geometry knobs (environment variables DSQ_*; read once) -- used for tuning sweeps
+struct Tuning {
+    int beta_waves, beta_stage, beta_bpc, beta_lds_kb;
+    int disp_waves, disp_stage, disp_bpc, disp_lds_kb;
+    int ablate, force_iters;
+};
+const Tuning &tuning();
 
 hipError_t launch_transpose_r_to_gm_f64(const double *src, double *dst, int n, int m, long ld, hipStream_t st);
 hipError_t launch_transpose_r_to_gm_i32(const int32_t *src, int32_t *dst, int n, int m, long ld, hipStream_t st);

@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
         slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
     }
     double *mu_s = slab, *sw_s = slab + m, *b_s = slab + 2 * (size_t)m;
+    // mu-independent parts of the NB log-density (3 doubles per sample), L2-resident scratch
+    double *cs = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * 3;
 
     double lambda[P], contrast[P];
 #pragma unroll
@@ -82,12 +84,23 @@ __global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
         };
 
         update_mu();
+        const int abl = kp.ablate;   // profiling only: 0 in production
+        if (kp.maxit > 0 && !(abl & 16)) {
+            const double st_size = dstirlerr(size), log_size = dlog(size);   // wave-uniform
+            for (int j = lane; j < m; j += 64) {
+                DnbConst c = dnb_prepare((double)yg[j], size, st_size, log_size);
+                cs[j] = c.c0; cs[m + j] = c.c1; cs[2 * (size_t)m + j] = c.c2;
+            }
+        }
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
-            if (kp.useQR) {
+            if (abl & 2) {
+                // (ablated: no least-squares solve)
+            } else if (kp.useQR) {
                 // pass A                                                       (:336-353)
+                if (!(abl & 1))
                 for (int j = lane; j < m; j += 64) {
                     double mu = mu_s[j];
                     double sw = __builtin_sqrt(wvec(j, mu));
@@ -215,10 +228,13 @@ __global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
 #pragma unroll
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
             if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                  // (:357-360)
-            update_mu();
+            if (!(abl & 4)) update_mu();
             double dacc = 0.0;                                                            // (:365-373)
+            if (!(abl & 8))
             for (int j = lane; j < m; j += 64) {
-                double d = dnbinom_mu_log((double)yg[j], size, mu_s[j]);
+                DnbConst c;
+                c.c0 = cs[j]; c.c1 = cs[m + j]; c.c2 = cs[2 * (size_t)m + j];
+                double d = dnb_eval((double)yg[j], size, mu_s[j], c);
                 double term;
                 if constexpr (USE_W) term = (-2.0 * wg[j]) * d;
                 else term = -2.0 * d;
@@ -227,6 +243,8 @@ __global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
             dev = wave_allreduce(dacc);
             double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
             if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }        // (:375-378)
+            if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
+            else
             if (uniform((t > 0) && (conv_test < kp.tol))) break;                          // (:379-381)
             dev_old = dev;
         }
@@ -321,21 +339,32 @@ __global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
 }
 
 // ---- launch ---------------------------------------------------------------------
-static constexpr size_t kBetaLdsBudget = 64 * 1024;
-
+// Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
+// (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
 static inline size_t beta_lds_doubles(int m, int p, int waves) {
     return (size_t)p * m + (size_t)waves * m * kSlabVecs;
 }
 
-static inline void beta_geometry(int n, int m, int p, int *waves, bool *stage, int *grid) {
-    *waves = 4;
+template <int P>
+static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *grid, size_t *lds) {
+    const Tuning &tu = tuning();
+    size_t budget = (size_t)tu.beta_lds_kb * 1024;
+    *waves = tu.beta_waves > 0 ? tu.beta_waves : 4;
     *stage = false;
-    for (int w = 4; w >= 1; w >>= 1) {
-        if (beta_lds_doubles(m, p, w) * sizeof(double) <= kBetaLdsBudget) { *waves = w; *stage = true; break; }
+    for (int w = *waves; w >= 1; w >>= 1) {
+        if (beta_lds_doubles(m, P, w) * sizeof(double) <= budget) { *waves = w; *stage = true; break; }
     }
+    if (tu.beta_stage == 0) *stage = false;
+    *lds = *stage ? beta_lds_doubles(m, P, *waves) * sizeof(double) : 0;
+    int bpc = 0;
+    const void *fn = *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true> : (const void *)fit_beta_kernel<P, false, true>)
+                            : (useW ? (const void *)fit_beta_kernel<P, true, false> : (const void *)fit_beta_kernel<P, false, false>);
+    if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
+    if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();
     int blocks_needed = (n + *waves - 1) / *waves;
-    int cap = *stage ? cus * 16 : cus * 4;
+    int cap = cus * bpc;
     *grid = blocks_needed < cap ? blocks_needed : cap;
     if (*grid < 1) *grid = 1;
 }
@@ -344,23 +373,23 @@ static inline void beta_geometry(int n, int m, int p, int *waves, bool *stage, i
 #error "compile with -DDSQ_P=<number of design columns>"
 #endif
 
-#if DSQ_P == 1
-size_t fit_beta_scratch_bytes(int m, int p, int /*use_weights*/) {
+template <>
+void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_t *cscr) {
     int waves, grid;
     bool stage;
-    beta_geometry(1 << 30, m, p, &waves, &stage, &grid);
-    if (stage) return 0;
-    return (size_t)grid * waves * (size_t)m * kSlabVecs * sizeof(double);
+    size_t lds;
+    beta_geometry<DSQ_P>(n, m, useW != 0, &waves, &stage, &grid, &lds);
+    *slab = stage ? 0 : (size_t)grid * waves * (size_t)m * kSlabVecs;
+    *cscr = (size_t)grid * waves * (size_t)m * 3;
 }
-#endif
 
 template <>
 hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp, hipStream_t st) {
     int waves, grid;
     bool stage;
-    beta_geometry(kp.n, kp.m, DSQ_P, &waves, &stage, &grid);
+    size_t lds;
+    beta_geometry<DSQ_P>(kp.n, kp.m, kp.useWeights != 0, &waves, &stage, &grid, &lds);
     if (stage) {
-        size_t lds = beta_lds_doubles(kp.m, DSQ_P, waves) * sizeof(double);
         if (kp.useWeights)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else

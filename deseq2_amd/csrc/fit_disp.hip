@@ -47,7 +47,7 @@ struct DispGene {
         }
     }
 
-    // K matrices X' diag(wd_k) X over the kept rows; wfun(mu, wd[K]) gives the diagonals.
+    // K matrices X' diag(wd_k) X over the kept rows; wfun(1/mu, wd[K]) gives the diagonals.
     // A dropped column contributes exact zeros; putting 1 on its diagonal in the first
     // matrix leaves det / inverse / traces equal to those of the compacted matrix.
     template <int K, class F>
@@ -58,7 +58,7 @@ struct DispGene {
         for (int i = 0; i < K * N; i++) acc[i] = 0.0;
         for (int j = lane; j < m; j += 64) {
             double wd[K];
-            wfun(r.mu(j), wd);
+            wfun(r.inv_mu(j), wd);
             if (keep_row(j)) {
                 double xr[P];
 #pragma unroll
@@ -100,7 +100,7 @@ struct DispGene {
         double cr_term = 0.0;
         if (useCR) {
             double B[1][P][P];
-            gram<1>([&](double mu, double(&wd)[1]) { wd[0] = 1.0 / (1.0 / mu + alpha); }, B);
+            gram<1>([&](double imu, double(&wd)[1]) { wd[0] = 1.0 / (imu + alpha); }, B);
             LU<P> lu;
 #pragma unroll
             for (int a = 0; a < P; a++)
@@ -134,8 +134,8 @@ struct DispGene {
         if (useCR) {
             double B[2][P][P];
             gram<2>(
-                [&](double mu, double(&wd)[2]) {
-                    double t = 1.0 / mu + alpha;
+                [&](double imu, double(&wd)[2]) {
+                    double t = imu + alpha;
                     wd[0] = 1.0 / t;
                     wd[1] = -1.0 * (1.0 / (t * t));
                 },
@@ -177,8 +177,8 @@ struct DispGene {
         if (useCR) {
             double B[3][P][P];
             gram<3>(
-                [&](double mu, double(&wd)[3]) {
-                    double t = 1.0 / mu + alpha;
+                [&](double imu, double(&wd)[3]) {
+                    double t = imu + alpha;
                     wd[0] = 1.0 / t;
                     wd[1] = -1.0 * (1.0 / (t * t));
                     wd[2] = 2.0 * (1.0 / (t * t * t));
@@ -230,10 +230,10 @@ struct DispGene {
 };
 
 // ---- staging --------------------------------------------------------------------
-// LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | (w m) ]
+// LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | 1/mu m | (w m) ]
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves) {
-    return (size_t)p * m + (size_t)waves * m * (USE_W ? 3 : 2);
+    return (size_t)p * m + (size_t)waves * m * (USE_W ? 4 : 3);
 }
 
 template <int P, bool USE_W, bool STAGE, bool GRID>
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
     const int m = kp.m;
 
     double *xs = smem;
-    double *slab = smem + (size_t)P * m + (size_t)wave * m * (USE_W ? 3 : 2);
+    double *slab = smem + (size_t)P * m + (size_t)wave * m * (USE_W ? 4 : 3);
     if constexpr (STAGE) {
         for (int t = threadIdx.x; t < P * m; t += blockDim.x) xs[t] = kp.x[t];
         __syncthreads();
@@ -259,13 +259,15 @@ __global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
         using Rows = typename std::conditional<STAGE, RowsLds, RowsGlobal>::type;
         DispGene<P, USE_W, Rows> G;
         if constexpr (STAGE) {
-            double *ys = slab, *ms = slab + m, *ws = slab + 2 * (size_t)m;
+            double *ys = slab, *ms = slab + m, *is = slab + 2 * (size_t)m, *ws = slab + 3 * (size_t)m;
             for (int j = lane; j < m; j += 64) {
+                double mu = mug[j];
                 ys[j] = (double)yg[j];
-                ms[j] = mug[j];
+                ms[j] = mu;
+                is[j] = 1.0 / mu;
                 if constexpr (USE_W) ws[j] = wg[j];
             }
-            G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
+            G.r.y_ = ys; G.r.mu_ = ms; G.r.imu_ = is; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
@@ -319,6 +321,7 @@ __global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
                 const double lp_try = G.lp(a_try);
                 double theta_kappa = -1.0 * lp_try;
                 double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);
+                if (kp.force_iters > 0 && t + 1 >= kp.force_iters) break;   // profiling only
                 if (uniform(theta_kappa <= theta_hat_kappa)) {
                     it_acc++;
                     a = a_try;
@@ -351,25 +354,30 @@ __global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
 }
 
 // ---- launch ---------------------------------------------------------------------
-static constexpr size_t kLdsBudget = 64 * 1024;  // per block: leaves >= 2 blocks per CU
-
 template <int P, bool USE_W, bool GRID>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
-    int waves = 4;
+    const Tuning &tu = tuning();
+    size_t budget = (size_t)tu.disp_lds_kb * 1024;
+    int waves = tu.disp_waves > 0 ? tu.disp_waves : 4;
     bool stage = false;
-    for (int w = 4; w >= 1; w >>= 1) {
-        if (disp_lds_doubles<USE_W>(kp.m, P, w) * sizeof(double) <= kLdsBudget) { waves = w; stage = true; break; }
+    for (int w = waves; w >= 1; w >>= 1) {
+        if (disp_lds_doubles<USE_W>(kp.m, P, w) * sizeof(double) <= budget) { waves = w; stage = true; break; }
     }
+    if (tu.disp_stage == 0) stage = false;
+    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves) * sizeof(double) : 0;
+    const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, GRID> : (const void *)fit_disp_kernel<P, USE_W, false, GRID>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
+    if (tu.disp_bpc > 0) bpc = tu.disp_bpc;
     const int cus = device_cu_count();
     int blocks_needed = (kp.n + waves - 1) / waves;
-    int grid = blocks_needed < cus * 16 ? blocks_needed : cus * 16;
+    int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (grid < 1) grid = 1;
-    if (stage) {
-        size_t lds = disp_lds_doubles<USE_W>(kp.m, P, waves) * sizeof(double);
+    if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, GRID>), dim3(grid), dim3(64 * waves), lds, st, kp);
-    } else {
+    else
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, GRID>), dim3(grid), dim3(64 * waves), 0, st, kp);
-    }
     return hipGetLastError();
 }
 

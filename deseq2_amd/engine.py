@@ -90,6 +90,11 @@ class HostEngine:
             ll = weights * ll
         return ll.sum(axis=1)
 
+    def two_sided_normal_p(self, z):
+        """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507"""
+        from scipy import special as sps
+        return 2 * sps.ndtr(-np.abs(z))
+
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
                  minmu, want_mu=True, mu_floor=0.0, want_hat=True):
@@ -231,6 +236,11 @@ class DeviceEngine:
         if useWeights:
             ll = weights.view() * ll
         return ll.sum(dim=1).cpu().numpy()
+
+    def two_sided_normal_p(self, z):
+        t = self.torch
+        zz = t.as_tensor(np.ascontiguousarray(z), device=self.device)
+        return (2 * t.special.ndtr(-zz.abs())).cpu().numpy()
 
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
