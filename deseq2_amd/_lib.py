@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = [
     "dsq_fit_disp_grid_dev", "dsq_to_gene_major_f64", "dsq_to_gene_major_i32",
     "dsq_counts_f64_to_gene_major_i32", "dsq_from_gene_major_f64", "dsq_version", "dsq_last_error",
     "dsq_device_count", "dsq_set_device", "dsq_release_workspace", "dsq_test_math",
+    "dsq_profile_enable", "dsq_profile_last_ms",
 ]
 
 _lib = None
@@ -124,6 +125,8 @@ def lib():
     L.dsq_from_gene_major_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     L.dsq_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.dsq_set_device.argtypes = [C.c_int]
+    L.dsq_profile_enable.argtypes = [C.c_int]
+    L.dsq_profile_last_ms.restype = C.c_double
     _lib = L
     return L
 

@@ -44,7 +44,8 @@ const Tuning &tuning() {
     static Tuning t = {env_int("DSQ_BETA_WAVES", 4), env_int("DSQ_BETA_STAGE", -1), env_int("DSQ_BETA_BPC", 0),
                        env_int("DSQ_BETA_LDS_KB", 64),
                        env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
-                       env_int("DSQ_DISP_LDS_KB", 64), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0)};
+                       env_int("DSQ_DISP_LDS_KB", 64), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
+                       env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1)};
     return t;
 }
 
@@ -58,6 +59,21 @@ int device_cu_count() {
         cached[dev] = v;
     }
     return cached[dev];
+}
+
+// ---- optional kernel timing (HIP events on the launch stream) ----------------------
+static bool g_prof = false;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static bool g_ev_valid = false;
+static void prof_begin(hipStream_t st) {
+    if (!g_prof) return;
+    if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
+    (void)hipEventRecord(g_ev0, st);
+}
+static void prof_end(hipStream_t st) {
+    if (!g_prof) return;
+    (void)hipEventRecord(g_ev1, st);
+    g_ev_valid = true;
 }
 
 // ---- workspace pool: grow-only device buffers, one per (device, slot) -------------
@@ -235,7 +251,9 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         kp.cscratch = (double *)b + slab_d;
     }
     bool ok = false;
+    prof_begin(st);
     DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
+    prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     if (hat_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(hat_ws, o->hat_diagonals, a->n, a->m, ld, st));
     if (mu_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(mu_ws, o->mu, a->n, a->m, ld, st));
@@ -314,7 +332,9 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.last_change = o->last_change; kp.initial_lp = o->initial_lp; kp.initial_dlp = o->initial_dlp;
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
     bool ok = false;
+    prof_begin(st);
     DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
+    prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);
 }
@@ -334,7 +354,9 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
     kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = o->log_alpha;
     bool ok = false;
+    prof_begin(st);
     DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
+    prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);
 }
@@ -365,6 +387,21 @@ int dsq_device_count(void) {
 int dsq_set_device(int device) {
     if (hipSetDevice(device) != hipSuccess) return fail(DSQ_ERR_DEVICE, "hipSetDevice(%d) failed", device);
     return DSQ_OK;
+}
+
+int dsq_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_prof = on != 0;
+    g_ev_valid = false;
+    return DSQ_OK;
+}
+
+double dsq_profile_last_ms(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ev_valid) return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(g_ev1) != hipSuccess || hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 int dsq_release_workspace(void) {

@@ -25,6 +25,7 @@ struct DispKernelParams {
     const double *grid;
     int ngrid;
     int ablate, force_iters; // profiling only
+    int xlds;                // 1: X staged in LDS, 0: read through L1/L2
 };
 
 struct BetaKernelParams {
@@ -46,6 +47,7 @@ struct BetaKernelParams {
     double *scratch;        // global per-wave-slot scratch when rows are not staged in LDS
     double *cscratch;       // per-wave-slot scratch for the hoisted NB-density constants (3 m doubles)
     int ablate, force_iters; // profiling only (env DSQ_ABLATE / DSQ_FORCE_ITERS): skip phases / fixed trip count
+    int xlds;                // 1: X staged in LDS, 0: read through L1/L2
 };
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
@@ -62,6 +64,7 @@ struct Tuning {
     int beta_waves, beta_stage, beta_bpc, beta_lds_kb;
     int disp_waves, disp_stage, disp_bpc, disp_lds_kb;
     int ablate, force_iters;
+    int disp_xlds, beta_xlds;
 };
 const Tuning &tuning();
 

@@ -356,11 +356,17 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     }
     if (tu.beta_stage == 0) *stage = false;
     *lds = *stage ? beta_lds_doubles(m, P, *waves) * sizeof(double) : 0;
-    int bpc = 0;
+    static int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
+    static size_t lds_cache[2][2][8];
+    if (lds_cache[*stage][useW][*waves] != *lds) { bpc_cache[*stage][useW][*waves] = 0; lds_cache[*stage][useW][*waves] = *lds; }
+    int bpc = bpc_cache[*stage][useW][*waves];
     const void *fn = *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true> : (const void *)fit_beta_kernel<P, false, true>)
                             : (useW ? (const void *)fit_beta_kernel<P, true, false> : (const void *)fit_beta_kernel<P, false, false>);
-    if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
+    if (bpc == 0) {
+        if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
+        bpc_cache[*stage][useW][*waves] = bpc;
+    }
     if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();
     int blocks_needed = (n + *waves - 1) / *waves;

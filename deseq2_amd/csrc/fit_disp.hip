@@ -232,8 +232,8 @@ struct DispGene {
 // ---- staging --------------------------------------------------------------------
 // LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | 1/mu m | (w m) ]
 template <bool USE_W>
-__host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves) {
-    return (size_t)p * m + (size_t)waves * m * (USE_W ? 4 : 3);
+__host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3);
 }
 
 template <int P, bool USE_W, bool STAGE, bool GRID>
@@ -244,11 +244,15 @@ __global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
 
-    double *xs = smem;
-    double *slab = smem + (size_t)P * m + (size_t)wave * m * (USE_W ? 4 : 3);
+    const double *xs = smem;
+    double *slab = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)wave * m * (USE_W ? 4 : 3);
     if constexpr (STAGE) {
-        for (int t = threadIdx.x; t < P * m; t += blockDim.x) xs[t] = kp.x[t];
-        __syncthreads();
+        if (kp.xlds) {
+            for (int t = threadIdx.x; t < P * m; t += blockDim.x) smem[t] = kp.x[t];
+            __syncthreads();
+        } else {
+            xs = kp.x;
+        }
     }
 
     for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
@@ -361,23 +365,31 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     int waves = tu.disp_waves > 0 ? tu.disp_waves : 4;
     bool stage = false;
     for (int w = waves; w >= 1; w >>= 1) {
-        if (disp_lds_doubles<USE_W>(kp.m, P, w) * sizeof(double) <= budget) { waves = w; stage = true; break; }
+        if (disp_lds_doubles<USE_W>(kp.m, P, w, tu.disp_xlds) * sizeof(double) <= budget) { waves = w; stage = true; break; }
     }
     if (tu.disp_stage == 0) stage = false;
-    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves) * sizeof(double) : 0;
+    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, tu.disp_xlds) * sizeof(double) : 0;
+    DispKernelParams kq = kp;
+    kq.xlds = tu.disp_xlds;
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, GRID> : (const void *)fit_disp_kernel<P, USE_W, false, GRID>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
+    static int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
+    static size_t lds_cache[2][8];
+    if (lds_cache[stage][waves] != lds) { bpc_cache[stage][waves] = 0; lds_cache[stage][waves] = lds; }
+    int bpc = bpc_cache[stage][waves];
+    if (bpc == 0) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
+        bpc_cache[stage][waves] = bpc;
+    }
     if (tu.disp_bpc > 0) bpc = tu.disp_bpc;
     const int cus = device_cu_count();
     int blocks_needed = (kp.n + waves - 1) / waves;
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (grid < 1) grid = 1;
     if (stage)
-        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, GRID>), dim3(grid), dim3(64 * waves), lds, st, kp);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, GRID>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else
-        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, GRID>), dim3(grid), dim3(64 * waves), 0, st, kp);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, GRID>), dim3(grid), dim3(64 * waves), 0, st, kq);
     return hipGetLastError();
 }
 

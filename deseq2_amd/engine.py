@@ -140,14 +140,17 @@ class DeviceEngine:
         self.record = None          # set to a list to collect (name, n, start_event, end_event)
 
     def _timed(self, name, n, fn):
+        """profiling pass only: the C library brackets the fit kernel with HIP events on the
+        launch stream (dsq_profile_enable); read the duration back after the call."""
         if self.record is None:
             return fn()
-        t = self.torch
-        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-        e0.record()                 # torch current stream == the stream the kernels are launched on
+        from . import _lib
+        L = _lib.lib()
+        L.dsq_profile_enable(1)
         r = fn()
-        e1.record()
-        self.record.append((name, n, e0, e1))
+        ms = L.dsq_profile_last_ms()
+        L.dsq_profile_enable(0)
+        self.record.append((name, n, ms))
         return r
 
     def _vec(self, a):

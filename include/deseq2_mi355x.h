@@ -190,6 +190,12 @@ int dsq_device_count(void);              /* number of visible HIP devices (0 if 
 int dsq_set_device(int device);          /* device used by subsequent calls on this thread */
 int dsq_release_workspace(void);         /* free the cached device workspaces              */
 
+/* Kernel timing for bench.py's roofline: when enabled, every dsq_fit_*_dev call brackets its
+ * fit kernel launch with HIP events on the launch stream; dsq_profile_last_ms() waits for the
+ * most recent one and returns its duration in milliseconds (negative if none was recorded).  */
+int dsq_profile_enable(int on);
+double dsq_profile_last_ms(void);
+
 /* Parity hook for tests: evaluate one scalar primitive of the device math library on
  * the GPU (op: 0 exp, 1 log, 2 log1p, 3 lgamma, 4 digamma, 5 trigamma, 6 stirlerr,
  * 7 bd0(a,b), 8 dnbinom_mu_log(a=x, b=size, c=mu)).  HOST pointers, n elements.       */
