@@ -52,7 +52,7 @@ struct BetaKernelParams {
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).
-#define DSQ_P_REG 6
+#define DSQ_P_REG 10
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
 // doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they

@@ -364,13 +364,18 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     size_t budget = (size_t)tu.disp_lds_kb * 1024;
     int waves = tu.disp_waves > 0 ? tu.disp_waves : 4;
     bool stage = false;
-    for (int w = waves; w >= 1; w >>= 1) {
-        if (disp_lds_doubles<USE_W>(kp.m, P, w, tu.disp_xlds) * sizeof(double) <= budget) { waves = w; stage = true; break; }
+    int xlds = tu.disp_xlds;
+    // preference: X and the per-wave rows in LDS; else only the rows (X through L1/L2); else nothing
+    for (int pass = 0; pass < 2 && !stage; pass++) {
+        for (int w = waves; w >= 1; w >>= 1) {
+            if (disp_lds_doubles<USE_W>(kp.m, P, w, xlds) * sizeof(double) <= budget) { waves = w; stage = true; break; }
+        }
+        if (!stage) { if (xlds) xlds = 0; else break; }
     }
     if (tu.disp_stage == 0) stage = false;
-    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, tu.disp_xlds) * sizeof(double) : 0;
+    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
     DispKernelParams kq = kp;
-    kq.xlds = tu.disp_xlds;
+    kq.xlds = xlds;
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, GRID> : (const void *)fit_disp_kernel<P, USE_W, false, GRID>;
     static int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
     static size_t lds_cache[2][8];

@@ -33,6 +33,10 @@ CASES = [
     (300, 100, "two_group", False, False),     # useQR = FALSE (tests/testthat/test_QR.R)
     (200, 37, "batch_condition", True, False),
     (200, 70, ("factor", 6), False, True),     # p = 6, ragged m (not a multiple of 64)
+    (100, 90, ("factor", 8), True, False),     # p = 8
+    (120, 130, ("factor", 10), False, True),   # config C4 design width (p = 10)
+    (48, 2000, ("factor", 10), False, True),   # config C4 shape: m = 2000, rows/X no longer fit LDS
+    (64, 1500, "batch_condition", True, True),  # large m with weights: slab falls back to global scratch
 ]
 
 
@@ -49,7 +53,8 @@ def test_fit_beta_matches_oracle(oracle, n, m, design, useW, useQR):
 
 @pytest.mark.parametrize("n,m,design,useW", [(500, 100, "two_group", False), (300, 500, "batch_condition", False),
                                               (300, 200, "two_group", True), (600, 6, "two_group", False),
-                                              (200, 70, ("factor", 6), True)])
+                                              (200, 70, ("factor", 6), True), (100, 130, ("factor", 10), False),
+                                              (48, 2000, ("factor", 10), False), (64, 1500, "batch_condition", True)])
 @pytest.mark.parametrize("usePrior", [False, True])
 def test_fit_disp_matches_oracle(oracle, n, m, design, useW, usePrior):
     from deseq2_amd import native
