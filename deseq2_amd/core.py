@@ -401,20 +401,172 @@ def estimateDispersions(dds, fitType="parametric", **kw):
     return dds
 
 
+# ------------------------------------------------------------------ beta prior (R/core.R:1601-1689, R/expanded.R)
+def standard_model_matrix(factors):
+    """model.matrix(~ f1 + f2 + ...) with treatment contrasts; `factors` is an ordered dict
+    name -> integer level codes (0 = reference level).  Returns (x, column names)."""
+    m = len(next(iter(factors.values())))
+    cols, names = [np.ones(m)], ["Intercept"]
+    for f, codes in factors.items():
+        codes = np.asarray(codes)
+        for lv in range(1, int(codes.max()) + 1):
+            cols.append((codes == lv).astype(np.float64)); names.append("%s%d" % (f, lv))
+    return np.column_stack(cols), names
+
+
+def makeExpandedModelMatrix(factors):
+    """R/expanded.R:1-18: intercept + one indicator per level of every design factor
+    (rank deficient; made solvable by the ridge)."""
+    m = len(next(iter(factors.values())))
+    cols, names = [np.ones(m)], ["Intercept"]
+    for f, codes in factors.items():
+        codes = np.asarray(codes)
+        for lv in range(0, int(codes.max()) + 1):
+            cols.append((codes == lv).astype(np.float64)); names.append("%s%d" % (f, lv))
+    return np.column_stack(cols), names
+
+
+def Hmisc_wtd_quantile(x, weights, prob, normwt=True):
+    """R/core.R:2762-2800 (type = 'quantile'), one probability"""
+    x = np.asarray(x, float); w = np.asarray(weights, float)
+    keep = ~(np.isnan(w) | (w == 0))
+    x, w = x[keep], w[keep]
+    if normwt:
+        w = w * x.size / w.sum()
+    o = np.argsort(x, kind="stable")
+    x, w = x[o], w[o]
+    ux, inv = np.unique(x, return_inverse=True)
+    wts = np.bincount(inv, weights=w)
+    n = wts.sum()
+    order = 1 + (n - 1) * prob
+    low = max(np.floor(order), 1.0)
+    high = min(low + 1, n)
+    frac = order % 1
+    cs = np.cumsum(wts)
+
+    def stepq(q):                      # approx(cumsum(wts), x, method='constant', f=1, rule=2)
+        i = np.searchsorted(cs, q, side="left")
+        return ux[min(i, ux.size - 1)]
+    return (1 - frac) * stepq(low) + frac * stepq(high)
+
+
+def matchWeightedUpperQuantileForVariance(x, weights, upperQuantile=0.05):
+    """R/core.R:2416-2419"""
+    sdEst = Hmisc_wtd_quantile(np.abs(x), weights, 1 - upperQuantile, normwt=True) / sps.ndtri(1 - upperQuantile / 2)
+    return float(sdEst) ** 2
+
+
+def matchUpperQuantileForVariance(x, upperQuantile=0.05):
+    """R/core.R:2411-2414"""
+    return float(np.quantile(np.abs(x), 1 - upperQuantile) / sps.ndtri(1 - upperQuantile / 2)) ** 2
+
+
+def estimateBetaPriorVar(dds, mleBetaMatrix, names, betaPriorMethod="weighted", upperQuantile=0.05,
+                         modelMatrixType="standard", factors=None):
+    """R/core.R:1601-1689.  `mleBetaMatrix` (log2 scale) are the MLE coefficients of the standard
+    design whose column names are `names`."""
+    beta = np.asarray(mleBetaMatrix, float)
+    names = list(names)
+    if modelMatrixType == "expanded":                                  # addAllContrasts, expanded.R:76-98
+        for f, codes in factors.items():
+            idx = [i for i, nm in enumerate(names) if nm.startswith(f) and nm != "Intercept"]
+            k = len(idx)
+            if k > 1:
+                for j in range(k - 1):
+                    for i in range(j + 1, k):
+                        beta = np.column_stack([beta, beta[:, idx[i]] - beta[:, idx[j]]])
+                        names.append(f + "Cntrst")
+    dispFit = dds.mcols.get("dispFit")
+    if dispFit is None:
+        dispFit = np.mean(dds.mcols["dispersion"])
+    weights = 1.0 / (1.0 / dds.mcols["baseMean"] + dispFit)            # :1641-1642
+    pv = np.empty(beta.shape[1])
+    for c in range(beta.shape[1]):
+        xcol = beta[:, c]
+        use = np.abs(xcol) < 10
+        if use.sum() == 0:
+            pv[c] = 1e6
+        elif betaPriorMethod == "quantile":
+            pv[c] = matchUpperQuantileForVariance(xcol[use], upperQuantile)
+        else:
+            pv[c] = matchWeightedUpperQuantileForVariance(xcol[use], weights[use], upperQuantile)
+    for c, nm in enumerate(names):
+        if nm == "Intercept":
+            pv[c] = 1e6                                               # :1669-1671
+    if modelMatrixType == "expanded":                                  # averagePriorsOverLevels, expanded.R:20-73
+        xe, enames = makeExpandedModelMatrix(factors)
+        out = np.zeros(len(enames))
+        for c, nm in enumerate(names):
+            if nm in enames:
+                out[enames.index(nm)] = pv[c]
+        for f in factors:
+            mmset = {nm for nm in enames if nm.startswith(f)} | {f + "Cntrst"}
+            vals = [pv[c] for c, nm in enumerate(names) if nm in mmset]
+            meanvar = float(np.mean(vals))
+            for i, nm in enumerate(enames):
+                if nm.startswith(f) and nm != "Intercept":
+                    out[i] = meanvar
+        if not (out > 0).all():
+            raise RuntimeError("beta prior is not greater than 0")
+        return out, enames
+    return pv, names
+
+
+def fitGLMsWithPrior(dds, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, betaPriorVar=None,
+                     modelMatrixType="standard", factors=None, minmu=0.5, weights=None, useWeights=False):
+    """R/fitNbinomGLMs.R:242-337: (1) MLE fit with the wide prior, (2) the all-gene beta prior
+    variance, (3) refit with lambda = 1/betaPriorVar on the standard or expanded design."""
+    if modelMatrixType == "expanded" and factors is None:
+        raise ValueError("an expanded model matrix needs the design factors")
+    names = standard_model_matrix(factors)[1] if factors is not None else ["Intercept"] + [
+        "V%d" % i for i in range(1, dds.p)]
+    fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
+                        weights=weights, useWeights=useWeights)                       # :256-260
+    H, mu, mle = fit["hat_diagonals"], fit["mu"], fit["betaMatrix"]
+    if betaPriorVar is None:
+        betaPriorVar, pnames = estimateBetaPriorVar(dds, mle, names, modelMatrixType=modelMatrixType,
+                                                    factors=factors)                  # :293
+    if (np.asarray(betaPriorVar) == 0).any():
+        raise ValueError("beta prior variances are equal to zero for some variables")
+    lam = 1.0 / np.asarray(betaPriorVar, float)                                       # :311
+    if modelMatrixType == "expanded":
+        xe, _ = makeExpandedModelMatrix(factors)
+        fit2 = fitNbinomGLMs(dds, lam=lam, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR,
+                             modelMatrix=xe, minmu=minmu, weights=weights, useWeights=useWeights)   # :319-325
+    else:
+        fit2 = fitNbinomGLMs(dds, lam=lam, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR,
+                             minmu=minmu, weights=weights, useWeights=useWeights)      # :314-317
+    return {"fit": fit2, "H": H, "betaPriorVar": np.asarray(betaPriorVar), "mu": mu,
+            "modelMatrix": fit2["modelMatrix"], "mleBetaMatrix": mle}
+
+
 # ------------------------------------------------------------------ tests
 def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=None, useQR=True, minmu=0.5,
-                   modelMatrix=None):
-    """R/core.R:1332-1565 with betaPrior = FALSE (Cook's distances not mirrored)"""
+                   modelMatrix=None, betaPrior=False, betaPriorVar=None, modelMatrixType=None, factors=None):
+    """R/core.R:1332-1565 (Cook's distances not mirrored).  betaPrior = TRUE goes through
+    fitGLMsWithPrior (:1416-1432), by default on the expanded model matrix (:1374-1380)."""
     if "dispersion" not in dds.mcols:
         raise RuntimeError("testing requires dispersion estimates, first call estimateDispersions()")
     E = dds.engine
     w_host, useWeights = getAndCheckWeights(dds)
     weights = E.matrix(w_host) if useWeights else None
-    fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
-                        modelMatrix=modelMatrix, weights=weights, useWeights=useWeights)     # :1403-1408
+    if not betaPrior:
+        fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
+                            modelMatrix=modelMatrix, weights=weights, useWeights=useWeights)     # :1403-1408
+        H, mu_fit = fit["hat_diagonals"], fit["mu"]
+        bpv = np.full(fit["nterms"], 1e6)
+    else:
+        if modelMatrixType is None:
+            modelMatrixType = "expanded" if factors is not None else "standard"
+        pf = fitGLMsWithPrior(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR,
+                              betaPriorVar=betaPriorVar, modelMatrixType=modelMatrixType, factors=factors,
+                              minmu=minmu, weights=weights, useWeights=useWeights)       # :1416-1421
+        fit, H, mu_fit, bpv = pf["fit"], pf["H"], pf["mu"], pf["betaPriorVar"]
+        dds.mcols["MLE_beta"] = pf["mleBetaMatrix"]
+    fit = dict(fit); fit["mu"] = mu_fit; fit["hat_diagonals"] = H
     dds.assays["mu"] = fit["mu"]
     dds.assays["H"] = fit["hat_diagonals"]
-    dds.attrs.update(betaPrior=False, betaPriorVar=np.full(fit["nterms"], 1e6), test="Wald")
+    dds.attrs.update(betaPrior=bool(betaPrior), betaPriorVar=bpv, test="Wald")
     betaMatrix, betaSE = fit["betaMatrix"], fit["betaSE"]
     with np.errstate(divide="ignore", invalid="ignore"):
         WaldStatistic = betaMatrix / betaSE                                         # :1471

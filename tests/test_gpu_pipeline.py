@@ -59,3 +59,37 @@ def test_chain_device_resident_matches_oracle(oracle):
     # iteration counts: equal up to the documented start-value effect
     assert (a.mcols["betaIter"] == b.mcols["betaIter"]).mean() > 0.98
     assert (a.mcols["dispIter"] == b.mcols["dispIter"]).mean() > 0.98
+
+
+def test_chain_beta_prior_weights_identical_to_oracle(oracle):
+    """BASELINE configs[4] shape family: weights + betaPrior on the expanded design (p = 3,
+    rank deficient, lambda = 1/sigma^2) -- every column identical to the oracle chain."""
+    factors = {"condition": np.repeat([0, 1], 20)}
+    x, _ = core.standard_model_matrix(factors)
+    d = simulate.make_counts(300, x, seed=24)
+    w = np.random.default_rng(4).uniform(0.05, 1.0, d["counts"].shape)
+    w[np.random.default_rng(5).uniform(size=w.shape) < 0.02] = 0.0
+    res = []
+    for eng in (HostEngine(), HostEngine(oracle)):
+        dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], weights=w, engine=eng)
+        core.estimateDispersions(dds)
+        core.nbinomWaldTest(dds, betaPrior=True, factors=factors)
+        res.append(dds)
+    for k in ("dispersion", "beta", "betaSE", "WaldStatistic", "betaIter", "betaConv", "MLE_beta"):
+        assert_same(res[0].mcols[k], res[1].mcols[k], "betaPrior DESeq()$" + k)
+    assert_same(res[0].attrs["betaPriorVar"], res[1].attrs["betaPriorVar"], "betaPriorVar")
+
+
+def test_chain_lrt_identical_to_oracle(oracle):
+    """BASELINE configs[3] family: nbinomLRT, full (6-level factor) vs a 2-column reduced model"""
+    m = 36
+    x = simulate.design_factor(m, 6)
+    d = simulate.make_counts(250, x, seed=25)
+    red = np.column_stack([np.ones(m), (np.arange(m) >= m // 2).astype(float)])
+    res = []
+    for eng in (HostEngine(), HostEngine(oracle)):
+        dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=eng)
+        core.DESeq(dds, test="LRT", reduced=red)
+        res.append(dds)
+    for k in ("dispersion", "beta", "betaSE", "LRTStatistic", "LRTPvalue", "betaIter"):
+        assert_same(res[0].mcols[k], res[1].mcols[k], "LRT DESeq()$" + k)

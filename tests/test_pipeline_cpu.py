@@ -60,3 +60,33 @@ def test_lrt_reduced_intercept(oracle):
 def test_na_guard():
     with pytest.raises(ValueError, match="contain NA"):
         core._na_guard("fitBeta", alpha_hatSEXP=np.array([1.0, np.nan]))
+
+
+def test_beta_prior_expanded_with_weights(oracle):
+    """BASELINE configs[4] path: observation weights + betaPrior ridge on the expanded
+    (rank-deficient) model matrix, R/fitNbinomGLMs.R:242-337 + R/expanded.R."""
+    factors = {"condition": np.repeat([0, 1], 8)}
+    x, names = core.standard_model_matrix(factors)
+    d = simulate.make_counts(400, x, seed=5)
+    w = np.random.default_rng(1).uniform(0.05, 1, d["counts"].shape)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], weights=w, engine=HostEngine(oracle))
+    core.estimateDispersions(dds)
+    core.nbinomWaldTest(dds, betaPrior=True, factors=factors)
+    bpv = dds.attrs["betaPriorVar"]
+    assert bpv[0] == 1e6 and bpv[1] == bpv[2] and 0.1 < bpv[1] < 10          # levels share one prior variance
+    b = dds.mcols["beta"]
+    assert b.shape[1] == 3 and np.isfinite(b).all()
+    # symmetric shrinkage: the two level effects are (nearly) opposite, and shrunk w.r.t. the MLE
+    conv = dds.mcols["betaConv"]
+    np.testing.assert_allclose(b[conv, 1], -b[conv, 2], atol=1e-4)   # equal up to the 1e-6 ridge on the intercept
+    lfc = b[:, 2] - b[:, 1]
+    mle = dds.mcols["MLE_beta"][:, 1]
+    assert np.abs(lfc).mean() < np.abs(mle).mean()
+    assert np.corrcoef(lfc[conv], mle[conv])[0, 1] > 0.9
+
+
+def test_weighted_quantile_matches_unweighted():
+    x = np.random.default_rng(2).normal(size=2000)
+    assert core.Hmisc_wtd_quantile(np.abs(x), np.ones(x.size), 0.95) == pytest.approx(np.quantile(np.abs(x), 0.95))
+    v = core.matchWeightedUpperQuantileForVariance(x, np.ones(x.size))
+    assert 0.8 < v < 1.25

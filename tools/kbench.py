@@ -25,7 +25,12 @@ def main():
     from deseq2_amd.engine import DeviceEngine
     from tests.helpers import rough_alpha, beta_init_qr
     m = args.samples
-    x = simulate.design_batch_condition(m) if args.design == "bc" else simulate.design_two_group(m)
+    if args.design == "bc":
+        x = simulate.design_batch_condition(m)
+    elif args.design.startswith("f"):
+        x = simulate.design_factor(m, int(args.design[1:]))
+    else:
+        x = simulate.design_two_group(m)
     key = "%d_%d_%s" % (args.genes, m, args.design)
     if os.path.exists(args.cache) and str(np.load(args.cache)["key"]) == key:
         z = np.load(args.cache)
