@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdeseq2_mi355x.so")
+SO_PATH = os.environ.get("DSQ_LIB") or os.path.join(_HERE, "libdeseq2_mi355x.so")   # DSQ_LIB: tuning builds only
 
 DSQ_OK = 0
 DSQ_LAYOUT_R = 0

@@ -16,6 +16,8 @@
 // Slab (mu, sqrt(w), sqrt(w) z per sample) lives in wave-private LDS, X in a block-shared
 // LDS slab; when m*p is too large for that both fall back to L2-resident global memory.
 #include "dsq_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include "dsq_math.hpp"
 #include "dsq_wave.hpp"
 
@@ -26,8 +28,13 @@ struct SymNB { static constexpr int value = P * (P + 1) / 2; };
 
 static constexpr int kSlabVecs = 3;  // mu, sqrt(w), sqrt(w)*z
 
+// min waves per SIMD the register allocator must leave room for (2 => <= 256 unified registers)
+#ifndef DSQ_BETA_MINW
+#define DSQ_BETA_MINW (DSQ_P <= 6 ? 2 : 1)   /* wide designs already spill at 512 registers */
+#endif
+
 template <int P, bool USE_W, bool STAGE>
-__global__ void __launch_bounds__(256) fit_beta_kernel(BetaKernelParams kp) {
+__global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -366,6 +373,7 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
         if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
         bpc_cache[*stage][useW][*waves] = bpc;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, *lds, bpc);
     }
     if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();

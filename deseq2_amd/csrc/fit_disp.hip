@@ -9,6 +9,8 @@
 // determinant / inverse / traces are wave-uniform register math (LU, partial pivoting).
 // The Armijo line search itself is wave-uniform scalar control flow.
 #include "dsq_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include "dsq_math.hpp"
 #include "dsq_rows.hpp"
 #include "dsq_wave.hpp"
@@ -236,8 +238,12 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
     return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3);
 }
 
+#ifndef DSQ_DISP_MINW
+#define DSQ_DISP_MINW (DSQ_P <= 6 ? 2 : 1)   /* wide designs already spill at 512 registers */
+#endif
+
 template <int P, bool USE_W, bool STAGE, bool GRID>
-__global__ void __launch_bounds__(256) fit_disp_kernel(DispKernelParams kp) {
+__global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -385,6 +391,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
         bpc_cache[stage][waves] = bpc;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_disp<P=%d,grid=%d> waves=%d stage=%d lds=%zu occupancy-api blocks/CU=%d\n", P, (int)GRID, waves, (int)stage, lds, bpc);
     }
     if (tu.disp_bpc > 0) bpc = tu.disp_bpc;
     const int cus = device_cu_count();
