@@ -77,7 +77,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x)
+        dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x, sizeFactors=d["size_factors"])
         if world > 1:
             parallel.DESeqParallel(dds, comm_device=dev)
         else:
@@ -105,8 +105,8 @@ def main():
                    "estimateDispersionsMAP", "nbinomWaldTest", "fitNbinomGLMs", "getBaseMeansAndVariances",
                    "parametricDispersionFit"):
             wrap(core, nm)
-        for nm in ("fit_beta", "fit_disp", "fit_disp_grid", "beta_init", "rough_disp", "normalized_row_stats",
-                   "nbinom_loglike", "two_sided_normal_p", "take_rows"):
+        for nm in ("fit_beta", "fit_disp", "fit_disp_grid", "prefit", "nbinom_loglike", "two_sided_normal_p",
+                   "take_rows"):
             f = getattr(E, nm)
 
             def mk(f, nm):

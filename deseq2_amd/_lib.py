@@ -79,6 +79,28 @@ class DsqFitDispGridOut(C.Structure):
     _fields_ = [("log_alpha", C.c_void_p)]
 
 
+class DsqPrefitArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32),
+        ("weights", C.c_void_p), ("useWeights", C.c_int32), ("q", C.c_void_p), ("a", C.c_void_p),
+        ("r", C.c_void_p),
+    ]
+
+
+class DsqPrefitOut(C.Structure):
+    _fields_ = [("baseMean", C.c_void_p), ("baseVar", C.c_void_p), ("allZero", C.c_void_p),
+                ("roughDisp", C.c_void_p), ("beta_init", C.c_void_p)]
+
+
+class DsqLogLikeArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64), ("y", C.c_void_p),
+        ("y_type", C.c_int32), ("mu", C.c_void_p), ("disp", C.c_void_p), ("weights", C.c_void_p),
+        ("useWeights", C.c_int32),
+    ]
+
+
 # every symbol include/deseq2_mi355x.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "dsq_fit_beta", "dsq_fit_beta_dev", "dsq_fit_disp", "dsq_fit_disp_dev", "dsq_fit_disp_grid",
@@ -86,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "dsq_counts_f64_to_gene_major_i32", "dsq_from_gene_major_f64", "dsq_version", "dsq_last_error",
     "dsq_device_count", "dsq_set_device", "dsq_release_workspace", "dsq_test_math",
     "dsq_profile_enable", "dsq_profile_last_ms",
+    "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
 ]
 
 _lib = None
@@ -124,6 +147,10 @@ def lib():
                                                     C.c_void_p, C.c_void_p]
     L.dsq_from_gene_major_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     L.dsq_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.dsq_prefit_moments.argtypes = [C.POINTER(DsqPrefitArgs), C.POINTER(DsqPrefitOut)]
+    L.dsq_prefit_moments_dev.argtypes = [C.POINTER(DsqPrefitArgs), C.POINTER(DsqPrefitOut), C.c_void_p]
+    L.dsq_nbinom_loglike.argtypes = [C.POINTER(DsqLogLikeArgs), C.c_void_p]
+    L.dsq_nbinom_loglike_dev.argtypes = [C.POINTER(DsqLogLikeArgs), C.c_void_p, C.c_void_p]
     L.dsq_set_device.argtypes = [C.c_int]
     L.dsq_profile_enable.argtypes = [C.c_int]
     L.dsq_profile_last_ms.restype = C.c_double

@@ -32,9 +32,11 @@ class DESeqDataSet:
         self.engine = engine if engine is not None else HostEngine()
         if normalizationFactors is not None:
             nf = np.asarray(normalizationFactors, np.float64)
+            self.sizeFactors = None
         else:
             sf = np.ones(self.m) if sizeFactors is None else np.asarray(sizeFactors, np.float64)
             nf = np.broadcast_to(sf[None, :], counts.shape)                          # getSizeOrNormFactors :2221
+            self.sizeFactors = sf
         self.counts_host = counts.astype(np.int32)
         E = self.engine
         self.y = E.counts(self.counts_host)
@@ -48,7 +50,7 @@ class DESeqDataSet:
         self.dispersionFunction = None
 
     @classmethod
-    def from_device(cls, engine, counts_r, nf_r, x, weights=None):
+    def from_device(cls, engine, counts_r, nf_r, x, weights=None, sizeFactors=None):
         """Build from matrices ALREADY RESIDENT in HBM in R layout: `counts_r` (int32) and
         `nf_r` (float64) are contiguous (m, n) torch tensors, i.e. column-major n x m exactly as
         R holds them.  Converts to the engine's gene-major layout on the device (no host copy)."""
@@ -57,6 +59,7 @@ class DESeqDataSet:
         self.x = np.asarray(x, dtype=np.float64)
         self.engine = engine
         self.counts_host = None
+        self.sizeFactors = None if sizeFactors is None else np.asarray(sizeFactors, np.float64)
         self.y = engine.native.to_gene_major(counts_r)
         self.nf = engine.native.to_gene_major(nf_r)
         self.has_weights = weights is not None
@@ -123,8 +126,11 @@ def getBaseMeansAndVariances(dds):
     w = None
     if dds.has_weights:
         w = E.matrix(dds.weights_raw)
-    bm, bv, az = E.normalized_row_stats(dds.y, dds.nf, w)
-    dds.mcols["baseMean"], dds.mcols["baseVar"], dds.mcols["allZero"] = bm, bv, az
+    # one pass also yields the rough dispersion and the IRLS start values used right after
+    # (roughDispEstimate :2422, fitNbinomGLMs.R:139-145); they are cached on the object
+    pf = E.prefit(dds.y, dds.nf, dds.x, w)
+    dds.attrs["prefit"] = pf
+    dds.mcols["baseMean"], dds.mcols["baseVar"], dds.mcols["allZero"] = pf["baseMean"], pf["baseVar"], pf["allZero"]
     return dds
 
 
@@ -162,10 +168,13 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         raise ValueError("all(colSums(abs(modelMatrix)) > 0) is not TRUE")          # :45
     # initial betas by QR least squares when full rank (:139-155)
     if np.linalg.matrix_rank(x) == p:
-        beta_mat = E.beta_init(y, nf, xh)
+        if rows is None and modelMatrix is None and "prefit" in dds.attrs:
+            beta_mat = dds.attrs["prefit"]["beta_init"]
+        else:
+            beta_mat = E.prefit(y, nf, x)["beta_init"]
     else:
         beta0 = np.zeros((n, p))
-        bm, _, _ = E.normalized_row_stats(y, nf)
+        bm = E.prefit(y, nf, np.ones((x.shape[0], 1)))["baseMean"]
         if (x[:, 0] == 1).all():
             beta0[:, 0] = np.log(bm)
         else:
@@ -216,9 +225,10 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
         raise ValueError("all-zero rows must be removed before fitting (the engine fits objectNZ)")
     m = dds.m
     if alphaInit is None:
-        roughDisp = E.rough_disp(dds.y, dds.nf, dds.xh)                             # :713
+        roughDisp = dds.attrs["prefit"]["roughDisp"]                                # :713
         bm, bv = dds.mcols["baseMean"], dds.mcols["baseVar"]
-        momentsDisp = (bv - E.xim(dds.nf) * bm) / bm ** 2                           # :2439-2448
+        xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
+        momentsDisp = (bv - xim * bm) / bm ** 2                                     # :2439-2448
         alpha_hat = np.minimum(roughDisp, momentsDisp)
     else:
         alpha_hat = np.broadcast_to(np.asarray(alphaInit, float), (dds.n,)).copy()

@@ -1,0 +1,151 @@
+// aux.hip -- the O(n m p) steps the reference does in R around the native fits, as one-wave-
+// per-gene kernels:
+//   prefit_moments   baseMean / baseVar / allZero (R/core.R:2138-2146), roughDispEstimate
+//                    (R/core.R:2422-2437 with linearModelMu :2454-2463) and the QR least-squares
+//                    start values of R/fitNbinomGLMs.R:139-145 -- one launch instead of a dozen
+//                    dense host passes;
+//   nbinom_loglike   nbinomLogLike (R/core.R:2208-2217) for fitNbinomGLMs.R:182 / nbinomLRT.
+// Both are HBM-bound in bytes (12..20 m per gene) but still VALU-heavy per byte (one log resp.
+// one NB density per sample).  Same wave-order sums as the fit kernels.
+#include "dsq_internal.hpp"
+#include "dsq_math.hpp"
+#include "dsq_wave.hpp"
+
+namespace dsq {
+
+template <int P, bool USE_W>
+__global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    double rr[P][P];
+#pragma unroll
+    for (int c = 0; c < P; c++)
+#pragma unroll
+        for (int k = 0; k < P; k++) rr[c][k] = kp.r[c + P * k];
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        double a2[2] = {0.0, 0.0};
+        for (int j = lane; j < m; j += 64) {
+            double yy = (double)yg[j];
+            double cn = yy / nfg[j];
+            if constexpr (USE_W) cn = wg[j] * cn;
+            a2[0] += cn;
+            a2[1] += yy;
+        }
+        wave_allreduce_n(a2);
+        const double mean = a2[0] / (double)m;
+        double av = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double cn = (double)yg[j] / nfg[j];
+            if constexpr (USE_W) cn = wg[j] * cn;
+            double dlt = cn - mean;
+            av += dlt * dlt;
+        }
+        av = wave_allreduce(av);
+        double tu[2 * P];
+#pragma unroll
+        for (int c = 0; c < 2 * P; c++) tu[c] = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double yn = (double)yg[j] / nfg[j];
+            double ly = dlog(yn + 0.1);
+#pragma unroll
+            for (int c = 0; c < P; c++) {
+                double qv = kp.q[(size_t)c * m + j];
+                tu[c] += yn * qv;
+                tu[P + c] += ly * qv;
+            }
+        }
+        wave_allreduce_n(tu);
+        double ae = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double yn = (double)yg[j] / nfg[j];
+            double mu = tu[0] * kp.a[j];
+#pragma unroll
+            for (int c = 1; c < P; c++) mu = __builtin_fma(tu[c], kp.a[(size_t)c * m + j], mu);
+            mu = __builtin_fmax(1.0, mu);
+            double d = yn - mu;
+            ae += (d * d - mu) / (mu * mu);
+        }
+        ae = wave_allreduce(ae);
+        double b[P];
+#pragma unroll
+        for (int c = P - 1; c >= 0; c--) {
+            double v = tu[P + c];
+#pragma unroll
+            for (int k = c + 1; k < P; k++) v = __builtin_fma(-rr[c][k], b[k], v);
+            b[c] = v / rr[c][c];
+        }
+        if (lane == 0) {
+            kp.baseMean[g] = mean;
+            kp.baseVar[g] = av / (double)(m - 1);
+            kp.allZero[g] = (a2[1] == 0.0) ? 1 : 0;
+            kp.roughDisp[g] = __builtin_fmax(ae / (double)(m - P), 0.0);
+#pragma unroll
+            for (int c = 0; c < P; c++) kp.beta_init[(size_t)g + (size_t)kp.n * c] = b[c];
+        }
+    }
+}
+
+template <bool USE_W>
+__global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *mug = kp.mu + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double size = 1.0 / kp.disp[g];
+        double acc = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double d = dnbinom_mu_log((double)yg[j], size, mug[j]);
+            if constexpr (USE_W) d = wg[j] * d;
+            acc += d;
+        }
+        acc = wave_allreduce(acc);
+        if (lane == 0) kp.loglike[g] = acc;
+    }
+}
+
+static inline int aux_grid(int n) {
+    int blocks = (n + 3) / 4;
+    int cap = device_cu_count() * 8;
+    return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
+}
+
+template <int P>
+static hipError_t launch_prefit_p(const PrefitKernelParams &kp, hipStream_t st) {
+    if (kp.useWeights) hipLaunchKernelGGL((prefit_kernel<P, true>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    else hipLaunchKernelGGL((prefit_kernel<P, false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok) {
+    *ok = true;
+    switch (kp.p) {
+    case 1: return launch_prefit_p<1>(kp, st);
+    case 2: return launch_prefit_p<2>(kp, st);
+    case 3: return launch_prefit_p<3>(kp, st);
+    case 4: return launch_prefit_p<4>(kp, st);
+    case 5: return launch_prefit_p<5>(kp, st);
+    case 6: return launch_prefit_p<6>(kp, st);
+    case 7: return launch_prefit_p<7>(kp, st);
+    case 8: return launch_prefit_p<8>(kp, st);
+    case 9: return launch_prefit_p<9>(kp, st);
+    case 10: return launch_prefit_p<10>(kp, st);
+    default: *ok = false; return hipSuccess;
+    }
+}
+
+hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st) {
+    if (kp.useWeights) hipLaunchKernelGGL((loglike_kernel<true>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    else hipLaunchKernelGGL((loglike_kernel<false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    return hipGetLastError();
+}
+
+}  // namespace dsq

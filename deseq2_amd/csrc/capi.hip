@@ -361,6 +361,68 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     return finish_ycheck(ycheck, st);
 }
 
+// =============================================================== extensions (device)
+static int prefit_dev_locked(const DsqPrefitArgs *a, const DsqPrefitOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 2 || a->p < 1 || a->m <= a->p) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
+    if (!a->y || !a->nf || !a->q || !a->a || !a->r) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->baseMean || !o->baseVar || !o->allZero || !o->roughDisp || !o->beta_init) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    PrefitKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m; kp.p = a->p;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    if (a->nf_is_vector) { kp.nf = a->nf; kp.nf_is_vector = 1; }
+    else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, a->m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
+    if (a->useWeights) { rc = prep_matrix(a->weights, a->layout, a->ld, a->n, a->m, WS_W, st, &kp.weights, ld); if (rc) return rc; }
+    kp.useWeights = a->useWeights ? 1 : 0;
+    kp.q = a->q; kp.a = a->a; kp.r = a->r;
+    kp.baseMean = o->baseMean; kp.baseVar = o->baseVar; kp.allZero = o->allZero; kp.roughDisp = o->roughDisp;
+    kp.beta_init = o->beta_init;
+    bool ok = false;
+    prof_begin(st);
+    DSQ_HIP(launch_prefit(kp, st, &ok));
+    prof_end(st);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    return finish_ycheck(ycheck, st);
+}
+
+static int loglike_dev_locked(const DsqLogLikeArgs *a, double *out, hipStream_t st) {
+    if (!a || !out) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->mu || !a->disp) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    LogLikeKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    rc = prep_matrix(a->mu, a->layout, a->ld, a->n, a->m, WS_MU, st, &kp.mu, ld);
+    if (rc) return rc;
+    if (a->useWeights) { rc = prep_matrix(a->weights, a->layout, a->ld, a->n, a->m, WS_W, st, &kp.weights, ld); if (rc) return rc; }
+    kp.useWeights = a->useWeights ? 1 : 0;
+    kp.disp = a->disp; kp.loglike = out;
+    prof_begin(st);
+    DSQ_HIP(launch_loglike(kp, st));
+    prof_end(st);
+    return finish_ycheck(ycheck, st);
+}
+
 // ---- host-pointer staging helpers --------------------------------------------------
 static int up(int slot, const void *host, size_t bytes, hipStream_t st, void **dev) {
     int rc = ws_get(slot, bytes ? bytes : 8, dev);
@@ -612,6 +674,84 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
     rc = fit_disp_grid_dev_locked(&d, &od, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_prefit_moments_dev(const DsqPrefitArgs *args, const DsqPrefitOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return prefit_dev_locked(args, out, (hipStream_t)stream);
+}
+int dsq_nbinom_loglike_dev(const DsqLogLikeArgs *args, double *loglike, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return loglike_dev_locked(args, loglike, (hipStream_t)stream);
+}
+
+int dsq_prefit_moments(const DsqPrefitArgs *a, const DsqPrefitOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 2 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->q || !a->a || !a->r) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->baseMean || !o->baseVar || !o->allZero || !o->roughDisp || !o->beta_init) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m, p = a->p;
+    DsqPrefitArgs d = *a;
+    DsqPrefitOut od = *o;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
+    else d.weights = nullptr;
+    size_t tot = 2 * m * p + p * p;
+    if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->q, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + m * p, a->a, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + 2 * m * p, a->r, p * p * 8, hipMemcpyHostToDevice, st));
+    d.q = vec; d.a = vec + m * p; d.r = vec + 2 * m * p;
+    if ((rc = ws_get(WS_H_OUTVEC, (4 * n + n * p) * 8, &v))) return rc;
+    double *ov = (double *)v;
+    od.baseMean = ov; od.baseVar = ov + n; od.roughDisp = ov + 2 * n; od.allZero = (int32_t *)(ov + 3 * n);
+    od.beta_init = ov + 4 * n;
+    rc = prefit_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->baseMean, od.baseMean, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->baseVar, od.baseVar, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->roughDisp, od.roughDisp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->allZero, od.allZero, n * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->beta_init, od.beta_init, n * p * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !loglike) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->mu || !a->disp) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m;
+    DsqLogLikeArgs d = *a;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_MU, a->mu, n * m * 8, st, &v))) return rc; d.mu = (double *)v;
+    if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
+    else d.weights = nullptr;
+    if ((rc = up(WS_H_VEC, a->disp, n * 8, st, &v))) return rc; d.disp = (double *)v;
+    if ((rc = ws_get(WS_H_OUTVEC, n * 8, &v))) return rc;
+    rc = loglike_dev_locked(&d, (double *)v, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(loglike, v, n * 8, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;
 }

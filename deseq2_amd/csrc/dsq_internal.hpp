@@ -50,6 +50,33 @@ struct BetaKernelParams {
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
 };
 
+struct PrefitKernelParams {
+    int n, m, p;
+    long ld;
+    const int32_t *y;
+    const double *nf;
+    int nf_is_vector;
+    const double *weights;
+    int useWeights;
+    const double *q, *a, *r;   // Q (m x p), X R^-1 (m x p), R (p x p), all column-major
+    double *baseMean, *baseVar, *roughDisp, *beta_init;
+    int32_t *allZero;
+};
+
+struct LogLikeKernelParams {
+    int n, m;
+    long ld;
+    const int32_t *y;
+    const double *mu;
+    const double *disp;
+    const double *weights;
+    int useWeights;
+    double *loglike;
+};
+
+hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok);
+hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st);
+
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).
 #define DSQ_P_REG 10

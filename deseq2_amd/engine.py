@@ -49,28 +49,11 @@ class HostEngine:
     def nrow(self, h):
         return h.shape[0]
 
-    # ---- O(n*m) glue the reference does in R around the native calls
-    def beta_init(self, y, nf, x):
-        """R/fitNbinomGLMs.R:139-145"""
-        q, r = np.linalg.qr(x)
-        ylog = np.log(y / nf + 0.1).T
-        return np.linalg.solve(r, q.T @ ylog).T.copy()
-
-    def normalized_row_stats(self, y, nf, weights=None):
-        """baseMean, baseVar, allZero (R/core.R:2138-2146)"""
-        cn = y / nf
-        if weights is not None:
-            cn = weights * cn
-        return cn.mean(axis=1), cn.var(axis=1, ddof=1), (y.sum(axis=1) == 0)
-
-    def rough_disp(self, y, nf, x):
-        """roughDispEstimate, R/core.R:2422-2437 (linearModelMu :2454-2463)"""
-        m, p = x.shape
-        yn = y / nf
-        q, r = np.linalg.qr(x)
-        mu = np.maximum((yn @ q) @ (x @ np.linalg.inv(r)).T, 1.0)
-        est = (((yn - mu) ** 2 - mu) / mu ** 2).sum(axis=1) / (m - p)
-        return np.maximum(est, 0.0)
+    # ---- O(n*m) steps the reference does in R around the native calls
+    def prefit(self, y, nf, x, weights=None):
+        """baseMean / baseVar / allZero, roughDispEstimate and the QR start values in one pass
+        (R/core.R:2138-2146, 2422-2437; R/fitNbinomGLMs.R:139-145)"""
+        return self.fns.prefitMoments(y, nf, x, weights, weights is not None)
 
     def xim(self, nf):
         """momentsDispEstimate's xim, R/core.R:2440-2444"""
@@ -83,12 +66,7 @@ class HostEngine:
 
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):
         """nbinomLogLike, R/core.R:2208-2217"""
-        from scipy.stats import nbinom
-        size = 1.0 / np.asarray(disp)[:, None]
-        ll = nbinom.logpmf(y, size, size / (size + mu))
-        if useWeights:
-            ll = weights * ll
-        return ll.sum(axis=1)
+        return self.fns.nbinomLogLike(y, mu, disp, weights if useWeights else None, useWeights)
 
     def two_sided_normal_p(self, z):
         """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507"""
@@ -187,35 +165,18 @@ class DeviceEngine:
     def nrow(self, h):
         return h.n
 
-    # ---- O(n*m) glue (torch elementwise / small GEMMs on the device; host work in R)
-    def _xmats(self, x_dev):
-        x = x_dev.t()                                   # m x p
-        q, r = self.torch.linalg.qr(x)
-        return x, q, r
-
-    def beta_init(self, y, nf, x_dev):
-        x, q, r = self._xmats(x_dev)
-        ylog = self.torch.log(y.view().to(self.torch.float64) / nf.view() + 0.1)     # n x m
-        b = self.torch.linalg.solve_triangular(r, (ylog @ q).t(), upper=True)       # p x n
-        return b.contiguous()                                                        # (p, n) = col-major n x p
-
-    def normalized_row_stats(self, y, nf, weights=None):
-        yv = y.view().to(self.torch.float64)
-        cn = yv / nf.view()
-        if weights is not None:
-            cn = weights.view() * cn
-        return (cn.mean(dim=1).cpu().numpy(), cn.var(dim=1, unbiased=True).cpu().numpy(),
-                (yv.sum(dim=1) == 0).cpu().numpy())
-
-    def rough_disp(self, y, nf, x_dev):
-        x, q, r = self._xmats(x_dev)
-        m, p = x.shape
-        yn = y.view().to(self.torch.float64) / nf.view()
-        hat_t = self.torch.linalg.solve_triangular(r, q.t(), upper=True)              # R^-1 Q'  (p x m)
-        mu = self.torch.clamp_min((yn @ q) @ (x @ self.torch.linalg.inv(r)).t(), 1.0)
-        del hat_t
-        est = (((yn - mu) ** 2 - mu) / mu ** 2).sum(dim=1) / (m - p)
-        return self.torch.clamp_min(est, 0.0).cpu().numpy()
+    # ---- O(n*m) steps around the fits: HIP kernels too (csrc/aux.hip)
+    def prefit(self, y, nf, x, weights=None):
+        t = self.torch
+        q, a, r = self.native.design_qr(x)           # m x p design: thin QR on the host, like stats::qr
+        dq = t.as_tensor(np.ascontiguousarray(q.T), device=self.device)
+        da = t.as_tensor(np.ascontiguousarray(a.T), device=self.device)
+        dr = t.as_tensor(np.ascontiguousarray(r.T), device=self.device)
+        o = self._timed("prefit_moments", y.n, lambda: self.native.prefitMoments_dev(
+            y, nf, dq, da, dr, weights, weights is not None))
+        return {"baseMean": o["baseMean"].cpu().numpy(), "baseVar": o["baseVar"].cpu().numpy(),
+                "allZero": o["allZero"].cpu().numpy().astype(bool), "roughDisp": o["roughDisp"].cpu().numpy(),
+                "beta_init": o["beta_init"]}        # (p, n) device tensor, consumed by fit_beta in place
 
     def xim(self, nf):
         return float((1.0 / nf.view().mean(dim=0)).mean())
@@ -229,16 +190,9 @@ class DeviceEngine:
         return self.native.GeneMajor(out, y.m)
 
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):
-        t = self.torch
-        yv = y.view().to(t.float64)
-        size = (1.0 / self._vec(disp))[:, None]
-        muv = mu.view()
-        ll = (t.lgamma(yv + size) - t.lgamma(size) - t.lgamma(yv + 1.0)
-              + size * t.log(size / (size + muv)) + yv * t.log(muv / (size + muv)))
-        ll = t.where((yv == 0) & (muv == 0), t.zeros_like(ll), ll)
-        if useWeights:
-            ll = weights.view() * ll
-        return ll.sum(dim=1).cpu().numpy()
+        dv = self._vec(disp)
+        o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
+        return o.cpu().numpy()
 
     def two_sided_normal_p(self, z):
         t = self.torch

@@ -140,6 +140,49 @@ def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEX
     return {"log_alpha": la}
 
 
+def design_qr(x):
+    """thin QR of the model matrix, taken on the host like the reference does with stats::qr
+    (R/fitNbinomGLMs.R:139-143, R/core.R:2455-2457): Q (m x p), A = X R^-1 (m x p), R (p x p)"""
+    x = np.asarray(x, np.float64)
+    q, r = np.linalg.qr(x)
+    a = x @ np.linalg.inv(r)
+    return np.asfortranarray(q), np.asfortranarray(a), np.asfortranarray(r)
+
+
+def prefitMoments(counts, nf, x, weights=None, useWeights=False):
+    """baseMean / baseVar / allZero (R/core.R:2138-2146), roughDispEstimate (:2422-2437) and the
+    QR least-squares start values (R/fitNbinomGLMs.R:139-145) in one kernel launch (dsq_prefit_moments)."""
+    y, ytype = _counts(counts)
+    nf = _fcol(nf)
+    n, m = y.shape
+    q, a, r = design_qr(x)
+    p = q.shape[1]
+    w = _fcol(weights) if useWeights else None
+    bm = np.zeros(n); bv = np.zeros(n); az = np.zeros(n, dtype=np.int32); rd = np.zeros(n)
+    b0 = np.zeros((n, p), order="F")
+    args = L.DsqPrefitArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, nf=_ptr(nf),
+                           nf_is_vector=0, weights=_ptr(w), useWeights=int(bool(useWeights)), q=_ptr(q), a=_ptr(a),
+                           r=_ptr(r))
+    out = L.DsqPrefitOut(baseMean=_ptr(bm), baseVar=_ptr(bv), allZero=_ptr(az), roughDisp=_ptr(rd),
+                         beta_init=_ptr(b0))
+    L.check(L.lib().dsq_prefit_moments(C.byref(args), C.byref(out)))
+    return {"baseMean": bm, "baseVar": bv, "allZero": az.astype(bool), "roughDisp": rd, "beta_init": b0}
+
+
+def nbinomLogLike(counts, mu, disp, weights, useWeights):
+    """R/core.R:2208-2217 through dsq_nbinom_loglike"""
+    y, ytype = _counts(counts)
+    mu = _fcol(mu)
+    n, m = y.shape
+    w = _fcol(weights) if useWeights else None
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(disp, np.float64).reshape(-1), (n,)))
+    out = np.zeros(n)
+    args = L.DsqLogLikeArgs(n=n, m=m, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, mu=_ptr(mu),
+                            disp=_ptr(d), weights=_ptr(w), useWeights=int(bool(useWeights)))
+    L.check(L.lib().dsq_nbinom_loglike(C.byref(args), _ptr(out)))
+    return out
+
+
 def test_math(op, a, b=None, c=None):
     """Evaluate one device-math primitive on the GPU (parity hook, see dsq_test_math)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
@@ -286,3 +329,34 @@ def from_gene_major(gm):
     dst = torch.empty((gm.m, gm.n), dtype=torch.float64, device=gm.t.device)
     L.check(L.lib().dsq_from_gene_major_f64(_t_ptr(gm.t), _t_ptr(dst), gm.n, gm.m, gm.ld, _stream()))
     return dst
+
+
+def prefitMoments_dev(y, nf, q, a, r, weights=None, useWeights=False, nf_is_vector=False):
+    """device flavour of prefitMoments: y / nf / weights GeneMajor, q / a (p, m) and r (p, p)
+    contiguous CUDA tensors (= column-major m x p / p x p)."""
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    p = q.shape[0]
+    dev = y.t.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = {"baseMean": torch.empty(n, **f64), "baseVar": torch.empty(n, **f64),
+           "allZero": torch.empty(n, dtype=torch.int32, device=dev), "roughDisp": torch.empty(n, **f64),
+           "beta_init": torch.empty((p, n), **f64)}
+    args = L.DsqPrefitArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                           y_type=L.DSQ_Y_INT32, nf=_t_ptr(nf if nf_is_vector else nf.t),
+                           nf_is_vector=int(nf_is_vector), weights=_t_ptr(weights.t) if useWeights else None,
+                           useWeights=int(bool(useWeights)), q=_t_ptr(q), a=_t_ptr(a), r=_t_ptr(r))
+    o = L.DsqPrefitOut(**{k: _t_ptr(v) for k, v in out.items()})
+    L.check(L.lib().dsq_prefit_moments_dev(C.byref(args), C.byref(o), _stream()))
+    return out
+
+
+def nbinomLogLike_dev(y, mu, disp, weights=None, useWeights=False):
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    out = torch.empty(n, dtype=torch.float64, device=y.t.device)
+    args = L.DsqLogLikeArgs(n=n, m=m, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t), y_type=L.DSQ_Y_INT32,
+                            mu=_t_ptr(mu.t), disp=_t_ptr(disp), weights=_t_ptr(weights.t) if useWeights else None,
+                            useWeights=int(bool(useWeights)))
+    L.check(L.lib().dsq_nbinom_loglike_dev(C.byref(args), _t_ptr(out), _stream()))
+    return out

@@ -173,6 +173,52 @@ typedef struct {
 int dsq_fit_disp_grid(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out);
 int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, void *stream);
 
+/* ---- extensions beyond the three .Call routines ----------------------
+ * dsq_prefit_moments: what estimateDispersionsGeneEst / fitNbinomGLMs compute in R before the
+ * first native call -- baseMean, baseVar, allZero (R/core.R:2138-2146), roughDispEstimate
+ * (R/core.R:2422-2437) and the QR least-squares start values (R/fitNbinomGLMs.R:139-145).
+ * q (m x p), a = X R^-1 (m x p) and r (p x p) come from the thin QR of the model matrix
+ * (stats::qr on the host, as in the reference), all column-major.                          */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *nf;
+    int32_t nf_is_vector;
+    const double *weights;   /* only enter baseMean / baseVar; may be NULL */
+    int32_t useWeights;
+    const double *q, *a, *r;
+} DsqPrefitArgs;
+
+typedef struct {
+    double *baseMean;    /* n */
+    double *baseVar;     /* n */
+    int32_t *allZero;    /* n */
+    double *roughDisp;   /* n */
+    double *beta_init;   /* n x p column-major (natural-log scale) */
+} DsqPrefitOut;
+
+int dsq_prefit_moments(const DsqPrefitArgs *args, const DsqPrefitOut *out);
+int dsq_prefit_moments_dev(const DsqPrefitArgs *args, const DsqPrefitOut *out, void *stream);
+
+/* dsq_nbinom_loglike: nbinomLogLike (R/core.R:2208-2217), rowSums([w *] dnbinom(y, mu, 1/disp, log)) */
+typedef struct {
+    int32_t n, m;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *mu;        /* n x m */
+    const double *disp;      /* n */
+    const double *weights;
+    int32_t useWeights;
+} DsqLogLikeArgs;
+
+int dsq_nbinom_loglike(const DsqLogLikeArgs *args, double *loglike);
+int dsq_nbinom_loglike_dev(const DsqLogLikeArgs *args, double *loglike, void *stream);
+
 /* ---- layout helpers (device pointers, async on stream) --------------------------
  * R layout (column-major n x m) <-> gene-major (row-major, leading dimension ld).   */
 int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);

@@ -626,3 +626,91 @@ int orc_fit_beta(int n, int m, int p,
     }
     return 0;
 }
+
+/* ======================================================== nbinomLogLike ==
+ * R/core.R:2208-2217: rowSums([weights *] dnbinom(counts, mu = mu, size = 1/disp, log = TRUE)).
+ * (called from R/fitNbinomGLMs.R:182 and, per model, from nbinomLRT R/core.R:1850-1877)
+ * dnbinom(.., mu=) is nmath's dnbinom_mu, the same function fitBeta's deviance uses. */
+int orc_nbinom_loglike(int n, int m, const double *y, const double *mu, const double *disp,
+                       const double *weights, int useWeights, double *loglike, int sum_mode) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        wsum_t s; wsum_init(&s, sum_mode);
+        double size = 1.0 / disp[i];
+        for (int j = 0; j < m; j++) {
+            double d = orc_dnbinom_mu_log(y[i + (long)n * j], size, mu[i + (long)n * j]);
+            if (useWeights) d = weights[i + (long)n * j] * d;
+            wsum_add(&s, j, d);
+        }
+        loglike[i] = wsum_total(&s);
+    }
+    return 0;
+}
+
+/* ========================================================= pre-fit moments ==
+ * The O(n m p) host steps that feed the native fits, one pass per gene:
+ *   baseMean, baseVar, allZero     getBaseMeansAndVariances   R/core.R:2138-2146
+ *   roughDisp                      roughDispEstimate          R/core.R:2422-2437
+ *                                  (linearModelMu :2454-2463: mu = (y Q)(X R^-1)')
+ *   beta_init                      QR least squares on log(K/s + 0.1), R/fitNbinomGLMs.R:139-145
+ * q  : m x p (column-major) thin-QR Q of the model matrix,  a : m x p = X R^-1,
+ * r  : p x p upper-triangular R (column-major).  All three are computed by the caller from the
+ * m x p design (stats::qr in the reference).  Weights only enter baseMean / baseVar (:2140-2143).
+ * Sums over samples in wave order; rowVars as the two-pass sum((x-mean)^2)/(m-1).           */
+int orc_prefit_moments(int n, int m, int p, const double *y, const double *nf, const double *weights,
+                       int useWeights, const double *q, const double *a, const double *r,
+                       double *baseMean, double *baseVar, int *allZero, double *roughDisp,
+                       double *beta_init, int sum_mode) {
+    if (p > ORC_PMAX) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        double t[ORC_PMAX], u[ORC_PMAX];
+        wsum_t sm, sy; wsum_init(&sm, sum_mode); wsum_init(&sy, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double yy = y[i + (long)n * j];
+            double cn = yy / nf[i + (long)n * j];
+            if (useWeights) cn = weights[i + (long)n * j] * cn;
+            wsum_add(&sm, j, cn); wsum_add(&sy, j, yy);
+        }
+        double mean = wsum_total(&sm) / (double)m;
+        baseMean[i] = mean;
+        allZero[i] = (wsum_total(&sy) == 0.0);
+        wsum_t sv; wsum_init(&sv, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double cn = y[i + (long)n * j] / nf[i + (long)n * j];
+            if (useWeights) cn = weights[i + (long)n * j] * cn;
+            double dlt = cn - mean;
+            wsum_add(&sv, j, dlt * dlt);
+        }
+        baseVar[i] = wsum_total(&sv) / (double)(m - 1);
+        /* t = yn' Q ; u = log(yn + 0.1)' Q */
+        for (int c = 0; c < p; c++) {
+            wsum_t s1, s2; wsum_init(&s1, sum_mode); wsum_init(&s2, sum_mode);
+            for (int j = 0; j < m; j++) {
+                double yn = y[i + (long)n * j] / nf[i + (long)n * j];
+                wsum_add(&s1, j, yn * q[j + (long)m * c]);
+                wsum_add(&s2, j, orc_log(yn + 0.1) * q[j + (long)m * c]);
+            }
+            t[c] = wsum_total(&s1); u[c] = wsum_total(&s2);
+        }
+        wsum_t se; wsum_init(&se, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double yn = y[i + (long)n * j] / nf[i + (long)n * j];
+            double mu = t[0] * a[j];
+            for (int c = 1; c < p; c++) mu = fma(t[c], a[j + (long)m * c], mu);
+            mu = fmax(1.0, mu);                                                  /* :2426 */
+            double d = yn - mu;
+            wsum_add(&se, j, (d * d - mu) / (mu * mu));                          /* :2435 */
+        }
+        roughDisp[i] = fmax(wsum_total(&se) / (double)(m - p), 0.0);             /* :2435-2436 */
+        /* beta_init = solve(R, u): back substitution */
+        double b[ORC_PMAX];
+        for (int c = p - 1; c >= 0; c--) {
+            double v = u[c];
+            for (int k = c + 1; k < p; k++) v = fma(-r[c + (long)p * k], b[k], v);
+            b[c] = v / r[c + (long)p * c];
+        }
+        for (int c = 0; c < p; c++) beta_init[i + (long)n * c] = b[c];
+    }
+    return 0;
+}

@@ -150,3 +150,44 @@ def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEX
     if rc != 0:
         raise RuntimeError("orc_fit_disp_grid failed: %d" % rc)
     return {"log_alpha": la}
+
+
+def nbinomLogLike(counts, mu, disp, weights, useWeights, sum_mode=0):
+    """R/core.R:2208-2217"""
+    y = _f(counts); mu = _f(mu)
+    n, m = y.shape
+    w = _f(weights) if useWeights else None
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(disp, float), (n,)))
+    out = np.zeros(n)
+    rc = lib().orc_nbinom_loglike(ctypes.c_int(n), ctypes.c_int(m), _p(y), _p(mu), _p(d), _p(w),
+                                  ctypes.c_int(int(bool(useWeights))), _p(out), ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_nbinom_loglike failed")
+    return out
+
+
+def design_qr(x):
+    """thin QR of the model matrix as the reference takes it on the host (qr(), qr.Q, qr.R):
+    returns Q (m x p), A = X R^-1 (m x p), R (p x p)"""
+    x = np.asarray(x, np.float64)
+    q, r = np.linalg.qr(x)
+    a = x @ np.linalg.inv(r)
+    return np.asfortranarray(q), np.asfortranarray(a), np.asfortranarray(r)
+
+
+def prefitMoments(counts, nf, x, weights=None, useWeights=False, sum_mode=0):
+    """baseMean / baseVar / allZero (R/core.R:2138-2146), roughDispEstimate (:2422-2437) and the
+    QR least-squares start values of R/fitNbinomGLMs.R:139-145, one pass per gene."""
+    y = _f(counts); nf = _f(nf)
+    n, m = y.shape
+    q, a, r = design_qr(x)
+    p = q.shape[1]
+    w = _f(weights) if useWeights else None
+    bm = np.zeros(n); bv = np.zeros(n); az = np.zeros(n, dtype=np.int32); rd = np.zeros(n)
+    b0 = np.zeros((n, p), order="F")
+    rc = lib().orc_prefit_moments(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(nf), _p(w),
+                                  ctypes.c_int(int(bool(useWeights))), _p(q), _p(a), _p(r), _p(bm), _p(bv),
+                                  _p(az), _p(rd), _p(b0), ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_prefit_moments failed")
+    return {"baseMean": bm, "baseVar": bv, "allZero": az.astype(bool), "roughDisp": rd, "beta_init": b0}

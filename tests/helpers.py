@@ -39,6 +39,8 @@ def make_case(n, m, design, seed=1, weights=False, sf_random=False, **kw):
     rng = np.random.Generator(np.random.PCG64(seed + 1000))
     sf = np.exp(rng.normal(0, 0.25, m)) if sf_random else None
     d = simulate.make_counts(n, x, seed=seed, size_factors=sf, **kw)
+    if not kw.get("drop_all_zero", True):
+        d["counts"][::37] = 0                      # some all-zero genes (allZero flag)
     counts = d["counts"]
     nn = counts.shape[0]
     nf = np.broadcast_to(d["size_factors"][None, :], (nn, m)).copy()
@@ -48,8 +50,9 @@ def make_case(n, m, design, seed=1, weights=False, sf_random=False, **kw):
         w[rng.uniform(size=(nn, m)) < 0.02] = 0.0
         w = w / w.max(axis=1, keepdims=True)      # R/core.R:2702
     d.update(nf=nf, weights=w, x=x)
-    d["beta_init"] = beta_init_qr(counts.astype(float), nf, x)
-    d["alpha_init"] = rough_alpha(counts.astype(float), nf, x)
+    with np.errstate(all="ignore"):
+        d["beta_init"] = beta_init_qr(counts.astype(float), nf, x)
+        d["alpha_init"] = rough_alpha(counts.astype(float), nf, x)
     return d
 
 

@@ -136,3 +136,31 @@ def test_double_counts_and_bad_counts():
         native.fitBeta(d["counts"], x9, d["nf"], d["alpha_init"], np.r_[1, np.zeros(16)],
                        np.zeros((d["counts"].shape[0], 17)), np.full(17, 1e-6), d["weights"], False, 1e-8, 100,
                        True, 0.5)
+
+
+@pytest.mark.parametrize("n,m,design,useW", [(400, 100, "two_group", False), (300, 500, "batch_condition", True),
+                                              (100, 130, ("factor", 10), False), (200, 7, "two_group", False)])
+def test_prefit_moments_matches_oracle(oracle, n, m, design, useW):
+    """extension: baseMean/baseVar/allZero, roughDispEstimate, IRLS start values"""
+    from deseq2_amd import native
+    d = make_case(n, m, design, seed=13, weights=useW, sf_random=True, drop_all_zero=False)
+    got = native.prefitMoments(d["counts"], d["nf"], d["x"], d["weights"], useW)
+    want = oracle.prefitMoments(d["counts"], d["nf"], d["x"], d["weights"], useW)
+    for k in ("baseMean", "baseVar", "allZero", "roughDisp", "beta_init"):
+        assert_same(got[k], want[k], "prefitMoments$" + k)
+
+
+def test_nbinom_loglike_matches_oracle(oracle):
+    """extension: nbinomLogLike, R/core.R:2208-2217"""
+    from deseq2_amd import native
+    for useW in (False, True):
+        d = make_case(300, 90, "batch_condition", seed=14, weights=useW)
+        mu = d["nf"] * np.exp(d["beta_init"] @ d["x"].T)           # unclamped, as R/fitNbinomGLMs.R:180
+        got = native.nbinomLogLike(d["counts"], mu, d["alpha_init"], d["weights"], useW)
+        want = oracle.nbinomLogLike(d["counts"], mu, d["alpha_init"], d["weights"], useW)
+        assert_same(got, want, "nbinomLogLike")
+        from scipy.stats import nbinom
+        size = 1 / d["alpha_init"][:, None]
+        ref = nbinom.logpmf(d["counts"], size, size / (size + mu))
+        ref = (d["weights"] * ref if useW else ref).sum(axis=1)
+        np.testing.assert_allclose(got, ref, rtol=1e-9)

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); E = DeviceEngine(dev)
 counts_r = torch.as_tensor(np.ascontiguousarray(counts.T), device=dev)
 nf_r = torch.ones((m, n), dtype=torch.float64, device=dev)
 def step():
-    dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x); core.DESeq(dds); return dds
+    dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x, sizeFactors=np.ones(m)); core.DESeq(dds); return dds
 for _ in range(2): step()
 for i in range(4):
     torch.cuda.synchronize(); t = time.perf_counter(); step(); torch.cuda.synchronize()
