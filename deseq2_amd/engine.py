@@ -78,13 +78,10 @@ class HostEngine:
                  minmu, want_mu=True, mu_floor=0.0, want_hat=True):
         n, m = y.shape
         w = weights if weights is not None else np.ones((n, m))
-        r = self.fns.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu)
-        if want_mu:
-            mu = nf * np.exp(r["beta_mat"] @ x.T)                 # R/fitNbinomGLMs.R:180
-            if mu_floor > 0:
-                mu = np.maximum(mu, mu_floor)
-            r["mu"] = mu
-        return r
+        # mu = nf * exp(x beta) comes back from the engine (extension of the fitBeta entry point)
+        # instead of being recomputed on the host as R/fitNbinomGLMs.R:180 does
+        return self.fns.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu,
+                                want_mu=want_mu, mu_floor=mu_floor, want_hat=want_hat)
 
     def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
                  usePrior, weights, useWeights, weightThreshold, useCR):
@@ -197,7 +194,8 @@ class DeviceEngine:
     def two_sided_normal_p(self, z):
         t = self.torch
         zz = t.as_tensor(np.ascontiguousarray(z), device=self.device)
-        return (2 * t.special.ndtr(-zz.abs())).cpu().numpy()
+        # 2*pnorm(-|z|) = erfc(|z|/sqrt(2)): keeps the far tail (ndtr flushes it to 0)
+        return t.special.erfc(zz.abs() * 0.7071067811865476).cpu().numpy()
 
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,

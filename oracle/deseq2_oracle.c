@@ -714,3 +714,19 @@ int orc_prefit_moments(int n, int m, int p, const double *y, const double *nf, c
     }
     return 0;
 }
+
+/* fitted means from the final coefficients: mu = nf * exp(x beta) (R/fitNbinomGLMs.R:180), optionally
+ * floored (R/core.R:763).  eta is accumulated as in fitBeta (:324), exp is the restated one.   */
+int orc_fitted_mu(int n, int m, int p, const double *x, const double *nf, const double *beta,
+                  double mu_floor, double *mu) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            double eta = x[j] * beta[i];
+            for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], beta[i + (long)n * c], eta);
+            double v = nf[i + (long)n * j] * orc_exp(eta);
+            if (mu_floor > 0.0) v = fmax(v, mu_floor);
+            mu[i + (long)n * j] = v;
+        }
+    return 0;
+}

@@ -110,7 +110,8 @@ def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP,
 
 
 def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lambdaSEXP,
-            weightsSEXP, useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, sum_mode=0):
+            weightsSEXP, useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, sum_mode=0,
+            want_mu=False, mu_floor=0.0, want_hat=True):
     y = _f(ySEXP); x = _f(xSEXP); nf = _f(nfSEXP); w = _f(weightsSEXP); b0 = _f(beta_matSEXP)
     n, m = y.shape; p = x.shape[1]
     assert x.shape[0] == m and nf.shape == (n, m) and w.shape == (n, m) and b0.shape == (n, p)
@@ -129,8 +130,14 @@ def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lam
         _p(beta_mat), _p(beta_var), _p(it), _p(H), _p(cn), _p(cd), _p(dev), ctypes.c_int(sum_mode))
     if rc != 0:
         raise RuntimeError("orc_fit_beta failed: %d" % rc)
-    return {"beta_mat": beta_mat, "beta_var_mat": beta_var, "iter": it, "hat_diagonals": H,
-            "contrast_num": cn.reshape(n, 1), "contrast_denom": cd.reshape(n, 1), "deviance": dev}
+    out = {"beta_mat": beta_mat, "beta_var_mat": beta_var, "iter": it, "hat_diagonals": H,
+           "contrast_num": cn.reshape(n, 1), "contrast_denom": cd.reshape(n, 1), "deviance": dev}
+    if want_mu:
+        mu = np.zeros((n, m), order="F")
+        lib().orc_fitted_mu(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(x), _p(nf), _p(beta_mat),
+                            ctypes.c_double(float(mu_floor)), _p(mu))
+        out["mu"] = mu
+    return out
 
 
 def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEXP,
