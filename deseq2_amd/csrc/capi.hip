@@ -314,8 +314,8 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (!a->log_alpha || !a->log_alpha_prior_mean) return fail(DSQ_ERR_ARG, "NULL input vector");
     if (!o->log_alpha || !o->iter || !o->iter_accept || !o->last_change || !o->initial_lp || !o->initial_dlp ||
-        !o->last_lp || !o->last_dlp || !o->last_d2lp)
-        return fail(DSQ_ERR_ARG, "NULL output array");
+        !o->last_lp || !o->last_dlp)
+        return fail(DSQ_ERR_ARG, "NULL output array");   // last_d2lp may be NULL: its kernel is then skipped
     if (a->maxit < 0) return fail(DSQ_ERR_ARG, "maxit < 0");
     DispKernelParams kp;
     bool ycheck = false;

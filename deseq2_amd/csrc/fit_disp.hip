@@ -242,7 +242,11 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
 #define DSQ_DISP_MINW (DSQ_P <= 6 ? 2 : 1)   /* wide designs already spill at 512 registers */
 #endif
 
-template <int P, bool USE_W, bool STAGE, bool GRID>
+// MODE 0: fitDisp line search (all outputs but last_d2lp); MODE 1: fitDispGrid; MODE 2: last_d2lp only,
+// evaluated at the log_alpha the MODE-0 launch stored (same stream).  The second derivative needs
+// three p x p matrices at once; keeping it out of the search kernel saves that kernel's registers, and
+// callers that never read last_d2lp (DESeq() itself does not) skip the launch.
+template <int P, bool USE_W, bool STAGE, int MODE>
 __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
@@ -289,7 +293,10 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.useCR = kp.useCR != 0;
         G.setup_cr();
 
-        if constexpr (GRID) {
+        if constexpr (MODE == 2) {
+            double d2 = G.d2lp(kp.log_alpha[g]);
+            if (lane == 0) kp.last_d2lp[g] = d2;
+        } else if constexpr (MODE == 1) {
             // fitDispGrid, src/DESeq2.cpp:492-510
             const int ng = kp.ngrid;
             const double delta = kp.grid[1] - kp.grid[0];
@@ -347,7 +354,6 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                     kappa = kappa / 2.0;
                 }
             }
-            double d2 = G.d2lp(a);
             if (lane == 0) {
                 kp.log_alpha[g] = a;
                 kp.iter[g] = it;
@@ -357,14 +363,13 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                 kp.initial_dlp[g] = initial_dlp;
                 kp.last_lp[g] = lp;
                 kp.last_dlp[g] = dlp;
-                kp.last_d2lp[g] = d2;
             }
         }
     }
 }
 
 // ---- launch ---------------------------------------------------------------------
-template <int P, bool USE_W, bool GRID>
+template <int P, bool USE_W, int MODE>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
     size_t budget = (size_t)tu.disp_lds_kb * 1024;
@@ -382,7 +387,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
     DispKernelParams kq = kp;
     kq.xlds = xlds;
-    const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, GRID> : (const void *)fit_disp_kernel<P, USE_W, false, GRID>;
+    const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
     static int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
     static size_t lds_cache[2][8];
     if (lds_cache[stage][waves] != lds) { bpc_cache[stage][waves] = 0; lds_cache[stage][waves] = lds; }
@@ -391,7 +396,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
         bpc_cache[stage][waves] = bpc;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_disp<P=%d,grid=%d> waves=%d stage=%d lds=%zu occupancy-api blocks/CU=%d\n", P, (int)GRID, waves, (int)stage, lds, bpc);
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_disp<P=%d,mode=%d> waves=%d stage=%d lds=%zu occupancy-api blocks/CU=%d\n", P, MODE, waves, (int)stage, lds, bpc);
     }
     if (tu.disp_bpc > 0) bpc = tu.disp_bpc;
     const int cus = device_cu_count();
@@ -399,9 +404,9 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (grid < 1) grid = 1;
     if (stage)
-        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, GRID>), dim3(grid), dim3(64 * waves), lds, st, kq);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else
-        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, GRID>), dim3(grid), dim3(64 * waves), 0, st, kq);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, MODE>), dim3(grid), dim3(64 * waves), 0, st, kq);
     return hipGetLastError();
 }
 
@@ -414,8 +419,10 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
 template <>
 hipError_t launch_fit_disp_p<DSQ_P>(const DispKernelParams &kp, hipStream_t st, bool grid) {
     if (grid)
-        return kp.useWeights ? launch_disp_p<DSQ_P, true, true>(kp, st) : launch_disp_p<DSQ_P, false, true>(kp, st);
-    return kp.useWeights ? launch_disp_p<DSQ_P, true, false>(kp, st) : launch_disp_p<DSQ_P, false, false>(kp, st);
+        return kp.useWeights ? launch_disp_p<DSQ_P, true, 1>(kp, st) : launch_disp_p<DSQ_P, false, 1>(kp, st);
+    hipError_t e = kp.useWeights ? launch_disp_p<DSQ_P, true, 0>(kp, st) : launch_disp_p<DSQ_P, false, 0>(kp, st);
+    if (e != hipSuccess || !kp.last_d2lp) return e;
+    return kp.useWeights ? launch_disp_p<DSQ_P, true, 2>(kp, st) : launch_disp_p<DSQ_P, false, 2>(kp, st);
 }
 
 }  // namespace dsq

@@ -112,7 +112,8 @@ class DeviceEngine:
         torch.cuda.set_device(self.device)
         from . import _lib
         _lib.check(_lib.lib().dsq_set_device(self.device.index or 0))
-        self.record = None          # set to a list to collect (name, n, start_event, end_event)
+        self.record = None          # set to a list to collect (name, n, ms) per fit kernel
+        self.want_d2lp = False      # estimateDispersions* never read fitDisp$last_d2lp (R/core.R:784-787,1042)
 
     def _timed(self, name, n, fn):
         """profiling pass only: the C library brackets the fit kernel with HIP events on the
@@ -220,7 +221,7 @@ class DeviceEngine:
         pm = self._vec(np.broadcast_to(np.asarray(prior_mean, float), (n,)))
         r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
             y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
-            weightThreshold, useCR))
+            weightThreshold, useCR, want_d2lp=self.want_d2lp))
         return {k: v.cpu().numpy() for k, v in r.items()}
 
     def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,

@@ -264,7 +264,7 @@ def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWe
 
 
 def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_sigmasq, min_log_alpha,
-                kappa_0, tol, maxit, usePrior, weights, useWeights, weightThreshold, useCR):
+                kappa_0, tol, maxit, usePrior, weights, useWeights, weightThreshold, useCR, want_d2lp=True):
     import torch
     assert isinstance(y, GeneMajor) and isinstance(mu_hat, GeneMajor) and mu_hat.ld == y.ld
     n, m, ld = y.n, y.m, y.ld
@@ -272,7 +272,8 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
     dev = y.t.device
     f64 = dict(dtype=torch.float64, device=dev)
     out = {k: torch.empty(n, **f64) for k in ("log_alpha", "last_change", "initial_lp", "initial_dlp",
-                                               "last_lp", "last_dlp", "last_d2lp")}
+                                               "last_lp", "last_dlp")}
+    out["last_d2lp"] = torch.empty(n, **f64) if want_d2lp else None
     out["iter"] = torch.empty(n, dtype=torch.int32, device=dev)
     out["iter_accept"] = torch.empty(n, dtype=torch.int32, device=dev)
     a = L.DsqFitDispArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
@@ -285,7 +286,7 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
                          weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
     o = L.DsqFitDispOut(**{k: _t_ptr(v) for k, v in out.items()})
     L.check(L.lib().dsq_fit_disp_dev(C.byref(a), C.byref(o), _stream()))
-    return out
+    return {k: v for k, v in out.items() if v is not None}
 
 
 def fitDispGrid_dev(y, x, mu_hat, disp_grid, log_alpha_prior_mean, log_alpha_prior_sigmasq, usePrior, weights,

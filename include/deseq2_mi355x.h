@@ -137,7 +137,7 @@ typedef struct {
     double *initial_dlp;
     double *last_lp;
     double *last_dlp;
-    double *last_d2lp;
+    double *last_d2lp;   /* may be NULL (device entry point): the second-derivative launch is skipped */
 } DsqFitDispOut;
 
 int dsq_fit_disp(const DsqFitDispArgs *args, const DsqFitDispOut *out);
