@@ -42,9 +42,9 @@ static int env_int(const char *name, int dflt) {
 
 const Tuning &tuning() {
     static Tuning t = {env_int("DSQ_BETA_WAVES", 4), env_int("DSQ_BETA_STAGE", -1), env_int("DSQ_BETA_BPC", 0),
-                       env_int("DSQ_BETA_LDS_KB", 64),
+                       env_int("DSQ_BETA_LDS_KB", 160),
                        env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
-                       env_int("DSQ_DISP_LDS_KB", 64), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
+                       env_int("DSQ_DISP_LDS_KB", 160), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
                        env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1)};
     return t;
 }

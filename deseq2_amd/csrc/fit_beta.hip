@@ -26,7 +26,11 @@ namespace dsq {
 template <int P>
 struct SymNB { static constexpr int value = P * (P + 1) / 2; };
 
-static constexpr int kSlabVecs = 3;  // mu, sqrt(w), sqrt(w)*z
+// per-sample state a wave keeps across passes: sqrt(w); mu and sqrt(w)*z sharing one slot (mu is
+// dead once pass A has turned it into the working response); two of the three hoisted NB-density
+// constants.  The third (read once per iteration, streaming) lives in an L2-resident scratch row so
+// that X and the slabs of 4 genes still fit twice into a CU's 160 KiB of LDS at m = 500.
+static constexpr int kSlabVecs = 4;
 
 // min waves per SIMD the register allocator must leave room for (2 => <= 256 unified registers)
 #ifndef DSQ_BETA_MINW
@@ -43,21 +47,21 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     const int M = m + P;
     constexpr int N = SymNB<P>::value;
 
-    const double *xs;
+    const double *xs = kp.x;          // X through L1/L2 unless it also fits in LDS
     double *slab;
     if constexpr (STAGE) {
-        double *xl = smem;
-        for (int t = threadIdx.x; t < P * m; t += blockDim.x) xl[t] = kp.x[t];
-        __syncthreads();
-        xs = xl;
-        slab = smem + (size_t)P * m + (size_t)wave * m * kSlabVecs;
+        if (kp.xlds) {
+            for (int t = threadIdx.x; t < P * m; t += blockDim.x) smem[t] = kp.x[t];
+            __syncthreads();
+            xs = smem;
+        }
+        slab = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)wave * m * kSlabVecs;
     } else {
-        xs = kp.x;
         slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
     }
-    double *mu_s = slab, *sw_s = slab + m, *b_s = slab + 2 * (size_t)m;
-    // mu-independent parts of the NB log-density (3 doubles per sample), L2-resident scratch
-    double *cs = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * 3;
+    double *sw_s = slab, *mu_s = slab + m, *b_s = mu_s;   // mu and sqrt(w)*z share a slot
+    double *cs = slab + 2 * (size_t)m;                     // c0 | c2   (LDS)
+    double *cg = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m;   // c1 (L2)
 
     double lambda[P], contrast[P];
 #pragma unroll
@@ -96,13 +100,19 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
             const double st_size = dstirlerr(size), log_size = dlog(size);   // wave-uniform
             for (int j = lane; j < m; j += 64) {
                 DnbConst c = dnb_prepare((double)yg[j], size, st_size, log_size);
-                cs[j] = c.c0; cs[m + j] = c.c1; cs[2 * (size_t)m + j] = c.c2;
+                cs[j] = c.c0; cs[m + j] = c.c2; cg[j] = c.c1;
             }
         }
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
+        double beta_prev[P];          // beta the current mu slot was computed from
+        bool mu_lost = false;         // QR mode overwrote mu with sqrt(w)*z and beta then diverged
+#pragma unroll
+        for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
+#pragma unroll
+            for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
             if (abl & 2) {
                 // (ablated: no least-squares solve)
             } else if (kp.useQR) {
@@ -234,13 +244,13 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
             int toolarge = 0;
 #pragma unroll
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
-            if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                  // (:357-360)
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0); break; }   // (:357-360)
             if (!(abl & 4)) update_mu();
             double dacc = 0.0;                                                            // (:365-373)
             if (!(abl & 8))
             for (int j = lane; j < m; j += 64) {
                 DnbConst c;
-                c.c0 = cs[j]; c.c1 = cs[m + j]; c.c2 = cs[2 * (size_t)m + j];
+                c.c0 = cs[j]; c.c2 = cs[m + j]; c.c1 = cg[j];
                 double d = dnb_eval((double)yg[j], size, mu_s[j], c);
                 double term;
                 if constexpr (USE_W) term = (-2.0 * wg[j]) * d;
@@ -257,6 +267,16 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
         }
 
         // ---- post-loop block (:427-455) ------------------------------------------------
+        if (mu_lost) {
+            // the reference keeps the mu of the last completed update when beta diverges; here that
+            // slot now holds sqrt(w)*z, so rebuild it from the coefficients it was computed from
+            for (int j = lane; j < m; j += 64) {
+                double eta = xs[j] * beta_prev[0];
+#pragma unroll
+                for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta_prev[c], eta);
+                mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
+            }
+        }
         double gacc[N];
 #pragma unroll
         for (int i = 0; i < N; i++) gacc[i] = 0.0;
@@ -348,21 +368,32 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
-static inline size_t beta_lds_doubles(int m, int p, int waves) {
-    return (size_t)p * m + (size_t)waves * m * kSlabVecs;
+static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds) {
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs;
 }
 
 template <int P>
-static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *grid, size_t *lds) {
+static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *xlds, int *grid, size_t *lds) {
     const Tuning &tu = tuning();
-    size_t budget = (size_t)tu.beta_lds_kb * 1024;
-    *waves = tu.beta_waves > 0 ? tu.beta_waves : 4;
-    *stage = false;
-    for (int w = *waves; w >= 1; w >>= 1) {
-        if (beta_lds_doubles(m, P, w) * sizeof(double) <= budget) { *waves = w; *stage = true; break; }
-    }
+    // Pick (waves per block, X in LDS?) maximising resident waves per CU: 160 KiB of LDS per CU, and
+    // the register budget of these kernels admits 2 waves per SIMD = 8 per CU.  Ties: bigger blocks
+    // (X shared by more genes), then X in LDS.
+    const size_t budget = (size_t)tu.beta_lds_kb * 1024, cu_lds = 160 * 1024;
+    const int wmax = tu.beta_waves > 0 ? tu.beta_waves : 4;
+    int best = -1;
+    *stage = false; *waves = wmax; *xlds = 0;
+    for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
+        for (int w = wmax; w >= 1; w >>= 1) {
+            size_t need = beta_lds_doubles(m, P, w, xl) * sizeof(double);
+            if (need > budget) continue;
+            int blocks = (int)(cu_lds / need);
+            int wpc = w * blocks < 8 ? w * blocks : 8;
+            int score = wpc * 100 + w * 2 + xl;
+            if (score > best) { best = score; *stage = true; *waves = w; *xlds = xl; }
+        }
     if (tu.beta_stage == 0) *stage = false;
-    *lds = *stage ? beta_lds_doubles(m, P, *waves) * sizeof(double) : 0;
+    if (!*stage) *xlds = 0;
+    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double) : 0;
     static int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
     static size_t lds_cache[2][2][8];
     if (lds_cache[*stage][useW][*waves] != *lds) { bpc_cache[*stage][useW][*waves] = 0; lds_cache[*stage][useW][*waves] = *lds; }
@@ -373,7 +404,7 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
         if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
         bpc_cache[*stage][useW][*waves] = bpc;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, *lds, bpc);
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d xlds=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, *xlds, *lds, bpc);
     }
     if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();
@@ -389,20 +420,22 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
 
 template <>
 void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_t *cscr) {
-    int waves, grid;
+    int waves, grid, xlds;
     bool stage;
     size_t lds;
-    beta_geometry<DSQ_P>(n, m, useW != 0, &waves, &stage, &grid, &lds);
+    beta_geometry<DSQ_P>(n, m, useW != 0, &waves, &stage, &xlds, &grid, &lds);
     *slab = stage ? 0 : (size_t)grid * waves * (size_t)m * kSlabVecs;
-    *cscr = (size_t)grid * waves * (size_t)m * 3;
+    *cscr = (size_t)grid * waves * (size_t)m;
 }
 
 template <>
-hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp, hipStream_t st) {
-    int waves, grid;
+hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st) {
+    int waves, grid, xlds;
     bool stage;
     size_t lds;
-    beta_geometry<DSQ_P>(kp.n, kp.m, kp.useWeights != 0, &waves, &stage, &grid, &lds);
+    beta_geometry<DSQ_P>(kp0.n, kp0.m, kp0.useWeights != 0, &waves, &stage, &xlds, &grid, &lds);
+    BetaKernelParams kp = kp0;
+    kp.xlds = xlds;
     if (stage) {
         if (kp.useWeights)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true>), dim3(grid), dim3(64 * waves), lds, st, kp);

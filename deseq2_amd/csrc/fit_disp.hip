@@ -372,17 +372,20 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 template <int P, bool USE_W, int MODE>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
-    size_t budget = (size_t)tu.disp_lds_kb * 1024;
-    int waves = tu.disp_waves > 0 ? tu.disp_waves : 4;
+    // same choice as fit_beta: maximise resident waves per CU (LDS 160 KiB, registers allow 8 waves)
+    const size_t budget = (size_t)tu.disp_lds_kb * 1024, cu_lds = 160 * 1024;
+    const int wmax = tu.disp_waves > 0 ? tu.disp_waves : 4;
+    int best = -1, waves = wmax, xlds = 0;
     bool stage = false;
-    int xlds = tu.disp_xlds;
-    // preference: X and the per-wave rows in LDS; else only the rows (X through L1/L2); else nothing
-    for (int pass = 0; pass < 2 && !stage; pass++) {
-        for (int w = waves; w >= 1; w >>= 1) {
-            if (disp_lds_doubles<USE_W>(kp.m, P, w, xlds) * sizeof(double) <= budget) { waves = w; stage = true; break; }
+    for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
+        for (int w = wmax; w >= 1; w >>= 1) {
+            size_t need = disp_lds_doubles<USE_W>(kp.m, P, w, xl) * sizeof(double);
+            if (need > budget) continue;
+            int blocks = (int)(cu_lds / need);
+            int wpc = w * blocks < 8 ? w * blocks : 8;
+            int score = wpc * 100 + w * 2 + xl;
+            if (score > best) { best = score; stage = true; waves = w; xlds = xl; }
         }
-        if (!stage) { if (xlds) xlds = 0; else break; }
-    }
     if (tu.disp_stage == 0) stage = false;
     size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
     DispKernelParams kq = kp;
