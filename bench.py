@@ -175,8 +175,18 @@ def main():
             bytes_per_gene = (algorithmic_bytes_per_gene("fit_beta", m, hat=False, mu=True) +
                               algorithmic_bytes_per_gene("fit_beta", m, hat=True, mu=True)) / 2.0
         achieved = bytes_per_gene * n / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
+        # this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed
+        # under profiles/ -- counters cannot be read from inside the process.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if n_req == 50000 and m == 500:
+                traffic = pmc[dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": bytes_per_gene * n, "avg_launch_ms": avg_ms,
                     "note": "f64-VALU/transcendental bound, not HBM bound (DESIGN.md); see profiles/"}
 
