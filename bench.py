@@ -55,11 +55,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: deseq2_amd has no CPU compute path")
+    # DSQ_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a 1-GPU box (all ranks on cuda:0,
+    # n-vector exchange over gloo); never set by the driver.
+    one_dev = os.environ.get("DSQ_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = None if one_dev else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from deseq2_amd import core, simulate, parallel
     from deseq2_amd.engine import DeviceEngine
@@ -79,7 +88,7 @@ def main():
     def step():
         dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x, sizeFactors=d["size_factors"])
         if world > 1:
-            parallel.DESeqParallel(dds, comm_device=dev)
+            parallel.DESeqParallel(dds, comm_device=comm_dev)
         else:
             core.DESeq(dds)
         return dds
@@ -140,10 +149,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = dev if comm_dev is not None else torch.device("cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        nn = torch.tensor([n], dtype=torch.int64, device=dev)
+        nn = torch.tensor([n], dtype=torch.int64, device=cdev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         n_total = int(nn.item())
     else:
