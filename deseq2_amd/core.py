@@ -141,12 +141,61 @@ def modelMatrixGroups(x):
 
 
 # ------------------------------------------------------------------ R/fitNbinomGLMs.R
+def fitNbinomGLMsOptim(dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_host, useWeights, betaMatrix,
+                       betaSE, betaConv, beta_mat_init, mu, logLike, minmu=0.5):
+    """R/fitNbinomGLMs.R:340-407: per-row L-BFGS-B on the penalised NB log-posterior for rows the
+    IRLS did not fit.  A host loop in the reference too; only the few affected rows come back
+    from the device."""
+    from scipy.optimize import minimize
+    from scipy.stats import nbinom, norm
+    E = dds.engine
+    rows = np.asarray(rowsForOptim)
+    yh = E.to_numpy(E.take_rows(dds.y, rows)).astype(np.float64)
+    nfh = E.to_numpy(E.take_rows(dds.nf, rows))
+    lambdaNatLogScale = lam / np.log(2) ** 2
+    large = 30.0
+    mu_rows = np.empty_like(yh)
+    for r, row in enumerate(rows):
+        if rowStable[row] and (np.abs(betaMatrix[row]) < large).all():
+            betaRow = betaMatrix[row].copy()                                       # :351-352
+        else:
+            betaRow = np.asarray(beta_mat_init[row], float).copy()                 # :354
+        nf, k, alpha = nfh[r], yh[r], alpha_hat[row]
+        w = weights_host[row] if useWeights else None
+
+        def objectiveFn(pv):                                                       # :359-370
+            mu_row = nf * 2.0 ** (x @ pv)
+            size = 1.0 / alpha
+            with np.errstate(all="ignore"):
+                ll = nbinom.logpmf(k, size, size / (size + mu_row))
+                logLike_ = np.sum(w * ll) if useWeights else np.sum(ll)
+                logPrior = np.sum(norm.logpdf(pv, 0.0, np.sqrt(1.0 / lam)))
+            v = -1.0 * (logLike_ + logPrior)
+            return v if np.isfinite(v) else 1e300
+        o = minimize(objectiveFn, betaRow, method="L-BFGS-B", bounds=[(-large, large)] * len(betaRow))   # :371
+        if o.success:
+            betaConv[row] = True                                                   # :378-380
+        betaMatrix[row] = o.x                                                      # :382
+        mu_row = nf * 2.0 ** (x @ o.x)
+        mu_rows[r] = mu_row                                                        # :386
+        mu_c = np.maximum(mu_row, minmu)                                           # :387
+        wdiag = (w if useWeights else 1.0) / (1.0 / mu_c + alpha)                  # :388-392
+        xtwx = x.T @ (x * np.asarray(wdiag)[:, None])
+        xtwxRidgeInv = np.linalg.inv(xtwx + np.diag(lambdaNatLogScale))
+        sigma = xtwxRidgeInv @ xtwx @ xtwxRidgeInv                                 # :395
+        betaSE[row] = LOG2E * np.sqrt(np.maximum(np.diag(sigma), 0))               # :397
+        size = 1.0 / alpha
+        llv = nbinom.logpmf(k, size, size / (size + mu_c))                         # :398 (clamped mu_row)
+        logLike[row] = np.sum(w * llv) if useWeights else np.sum(llv)
+    return betaMatrix, betaSE, betaConv, rows, mu_rows, logLike
+
+
 def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, betaTol=1e-8, maxit=100,
                   useOptim=True, useQR=True, minmu=0.5, weights=None, useWeights=False, mu_floor=0.0,
-                  want_hat=True):
-    """R/fitNbinomGLMs.R:29-236 (IRLS branch; the L-BFGS-B fallback rows are reported in
-    `rowsForOptim` instead of being refitted -- fitNbinomGLMsOptim is a per-row R loop
-    outside the native boundary)."""
+                  want_hat=True, forceOptim=False, refitOptim=False, weights_host=None):
+    """R/fitNbinomGLMs.R:29-236.  Rows the IRLS does not fit are listed in `rowsForOptim`
+    (:203-211); with refitOptim = TRUE (or forceOptim) they go through the reference's L-BFGS-B
+    fallback on the host (fitNbinomGLMsOptim), as in R."""
     E = dds.engine
     x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
     xh = dds.xh if modelMatrix is None else E.design(x)
@@ -166,6 +215,23 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
     lam = np.asarray(lam, np.float64)
     if not (np.abs(x).sum(axis=0) > 0).all():
         raise ValueError("all(colSums(abs(modelMatrix)) > 0) is not TRUE")          # :45
+    # intercept-only model with the wide prior: closed form, no native call (:99-137)
+    if p == 1 and (x == 1).all() and (lam <= 1e-6).all():
+        yh, nfh = E.to_numpy(y).astype(np.float64), E.to_numpy(nf)
+        wh = weights_host if (useWeights and weights_host is not None) else (E.to_numpy(weights) if useWeights else None)
+        if rows is not None and wh is not None and wh.shape[0] != n:
+            wh = wh[rows]
+        cn = yh / nfh
+        with np.errstate(divide="ignore"):
+            b = np.log2((wh * cn).sum(1) / wh.sum(1)) if useWeights else np.log2(cn.mean(1))
+        mu_h = nfh * (2.0 ** b)[:, None]
+        wd = (wh if useWeights else 1.0) / (1.0 / mu_h + alpha_hat[:, None])
+        xtwx = wd.sum(1)
+        return {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
+                "mu": E.matrix(mu_h), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
+                "hat_diagonals": E.matrix(wd / xtwx[:, None]), "deviance_native": None,
+                "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E,
+                "optimRows": None, "optimMu": None, "optimLogLike": None}
     # initial betas by QR least squares when full rank (:139-155)
     if np.linalg.matrix_rank(x) == p:
         if rows is None and modelMatrix is None and "prefit" in dds.attrs:
@@ -195,7 +261,17 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         rowsForOptim = np.where(~betaConv | ~rowStable | ~rowVarPositive)[0]       # :203-207
     else:
         rowsForOptim = np.where(~rowStable | ~rowVarPositive)[0]
+    if forceOptim:
+        rowsForOptim = np.arange(n)                                                # :209-211
+    optimRows, optimMu, optimLogLike = None, None, None
+    if (refitOptim or forceOptim) and len(rowsForOptim) > 0:
+        ll = np.full(n, np.nan)
+        b0 = E.to_numpy_np(beta_mat) if hasattr(E, "to_numpy_np") else beta_mat
+        betaMatrix, betaSE, betaConv, optimRows, optimMu, optimLogLike = fitNbinomGLMsOptim(
+            dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_host, useWeights, betaMatrix.copy(),
+            betaSE.copy(), betaConv.copy(), b0, mu, ll, minmu=minmu)
     return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu,
+            "optimRows": optimRows, "optimMu": optimMu, "optimLogLike": optimLogLike,
             "betaIter": betaRes["iter"], "modelMatrix": x, "nterms": p,
             "hat_diagonals": betaRes.get("hat_diagonals"), "deviance_native": betaRes["deviance"],
             "rowsForOptim": rowsForOptim, "beta_natlog": betaRes["beta_mat"]}
@@ -562,7 +638,8 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     weights = E.matrix(w_host) if useWeights else None
     if not betaPrior:
         fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
-                            modelMatrix=modelMatrix, weights=weights, useWeights=useWeights)     # :1403-1408
+                            modelMatrix=modelMatrix, weights=weights, useWeights=useWeights,
+                            refitOptim=useOptim, weights_host=w_host)                            # :1403-1408
         H, mu_fit = fit["hat_diagonals"], fit["mu"]
         bpv = np.full(fit["nterms"], 1e6)
     else:
@@ -590,6 +667,8 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     else:
         WaldPvalue = E.two_sided_normal_p(WaldStatistic)                            # :1507
     logLike = E.nbinom_loglike(dds.y, fit["mu"], dds.mcols["dispersion"], weights, useWeights)   # fitNbinomGLMs.R:182
+    if fit.get("optimRows") is not None:
+        logLike[fit["optimRows"]] = fit["optimLogLike"][fit["optimRows"]]           # fitNbinomGLMs.R:399
     dds.mcols.update(beta=betaMatrix, betaSE=betaSE, WaldStatistic=WaldStatistic, WaldPvalue=WaldPvalue,
                      betaConv=fit["betaConv"], betaIter=fit["betaIter"], deviance=-2 * logLike,
                      rowsForOptim=fit["rowsForOptim"])
@@ -609,16 +688,10 @@ def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, 
     full = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
                          weights=weights, useWeights=useWeights)
     ll_full = E.nbinom_loglike(dds.y, full["mu"], disp, weights, useWeights)
-    if reduced.shape[1] == 1 and (reduced == 1).all():
-        yh, nfh = E.to_numpy(dds.y), E.to_numpy(dds.nf)
-        cn = yh / nfh
-        b = (np.log2((w_host * cn).sum(1) / w_host.sum(1)) if useWeights else np.log2(cn.mean(1)))
-        mu_red = E.matrix(nfh * (2.0 ** b)[:, None])
-        red = {"betaMatrix": b[:, None], "nterms": 1}
-    else:
-        red = fitNbinomGLMs(dds, modelMatrix=reduced, betaTol=betaTol, maxit=maxit, useOptim=useOptim,
-                            useQR=useQR, minmu=minmu, weights=weights, useWeights=useWeights, want_hat=False)
-        mu_red = red["mu"]
+    red = fitNbinomGLMs(dds, modelMatrix=reduced, betaTol=betaTol, maxit=maxit, useOptim=useOptim,
+                        useQR=useQR, minmu=minmu, weights=weights, useWeights=useWeights, want_hat=False,
+                        weights_host=w_host)                     # closed form when reduced is ~1 (:99-137)
+    mu_red = red["mu"]
     ll_red = E.nbinom_loglike(dds.y, mu_red, disp, weights, useWeights)
     LRTStatistic = 2 * (ll_full - ll_red)                                            # :1877
     LRTPvalue = chi2.sf(LRTStatistic, df=full["nterms"] - red["nterms"])             # :1878

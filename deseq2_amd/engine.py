@@ -149,6 +149,10 @@ class DeviceEngine:
     def to_numpy(self, h):
         return h.view().cpu().numpy()
 
+    def to_numpy_np(self, b):
+        """n x p host matrix from either a host array or the (p, n) device tensor of start values"""
+        return b.t().cpu().numpy() if self.torch.is_tensor(b) else np.asarray(b)
+
     def take_rows(self, h, idx):
         if h is None:
             return None

@@ -90,3 +90,46 @@ def test_weighted_quantile_matches_unweighted():
     assert core.Hmisc_wtd_quantile(np.abs(x), np.ones(x.size), 0.95) == pytest.approx(np.quantile(np.abs(x), 0.95))
     v = core.matchWeightedUpperQuantileForVariance(x, np.ones(x.size))
     assert 0.8 < v < 1.25
+
+
+def test_optim_fallback_rows(oracle):
+    """tests/testthat/test_optim.R:30-39: the IRLS reports iter == 100 for this row and the
+    L-BFGS-B fallback (R/fitNbinomGLMs.R:340-407) then fits it; :2-27: IRLS == forced optim."""
+    x = simulate.design_two_group(10)
+    d = simulate.make_counts(100, x, seed=1)
+    counts = d["counts"].copy()
+    counts[0] = [0, 0, 0, 0, 0, 1000, 1000, 0, 0, 0]
+    dds = core.DESeqDataSet(counts, x, sizeFactors=np.ones(10), engine=HostEngine(oracle))
+    core.DESeq(dds)
+    assert dds.mcols["betaIter"][0] == 100                       # IRLS gave up ...
+    assert 0 in dds.mcols["rowsForOptim"]
+    assert np.isfinite(dds.mcols["beta"][0]).all() and np.abs(dds.mcols["beta"][0]).max() <= 30   # ... optim fitted it
+    assert np.isfinite(dds.mcols["betaSE"][0]).all() and np.isfinite(dds.mcols["deviance"][0])
+    # forced optim agrees with IRLS on well-behaved rows (tolerance of the reference test: 1e-6 on a
+    # scaled problem; L-BFGS-B's default stopping gives ~1e-4 here)
+    dds2 = core.DESeqDataSet(d["counts"], x, sizeFactors=np.ones(10), engine=HostEngine(oracle))
+    core.estimateDispersions(dds2)
+    a = core.fitNbinomGLMs(dds2, lam=np.array([2.0, 2.0]))
+    b = core.fitNbinomGLMs(dds2, lam=np.array([2.0, 2.0]), forceOptim=True)
+    ok = a["betaConv"] & b["betaConv"]
+    assert ok.mean() > 0.9
+    np.testing.assert_allclose(a["betaMatrix"][ok], b["betaMatrix"][ok], atol=2e-3)
+    np.testing.assert_allclose(a["betaSE"][ok], b["betaSE"][ok], rtol=2e-3)
+
+
+def test_edge_cases_single_gene_and_intercept_only(oracle):
+    """tests/testthat/test_edge_case.R: one gene; design ~1 (closed-form intercept fit)"""
+    x = simulate.design_two_group(8)
+    d = simulate.make_counts(50, x, seed=3)
+    one = core.DESeqDataSet(d["counts"][:1], x, sizeFactors=np.ones(8), engine=HostEngine(oracle))
+    core.estimateDispersionsGeneEst(one)
+    one.mcols["dispersion"] = one.mcols["dispGeneEst"]       # the reference's advice when no trend can be fit
+    core.nbinomWaldTest(one)
+    assert one.mcols["beta"].shape == (1, 2) and np.isfinite(one.mcols["WaldStatistic"]).all()
+    x1 = np.ones((8, 1))
+    dds = core.DESeqDataSet(d["counts"], x1, sizeFactors=np.ones(8), engine=HostEngine(oracle))
+    core.DESeq(dds)
+    np.testing.assert_allclose(dds.mcols["beta"][:, 0], np.log2(d["counts"].mean(axis=1)), rtol=1e-12)
+    assert (dds.mcols["betaIter"] == 1).all() and dds.mcols["betaConv"].all()
+    with pytest.raises(ValueError, match="equal"):
+        core.estimateDispersionsGeneEst(core.DESeqDataSet(d["counts"][:, :2], x[[0, 7]], engine=HostEngine(oracle)))
