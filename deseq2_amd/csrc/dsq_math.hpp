@@ -200,6 +200,54 @@ DSQ_DEV double ddigamma(double x) {
     return res;
 }
 
+// lgamma(x) and digamma(x) of the SAME argument in one go.  Both routines shift x up the same
+// way and both need log(xs) and 1/xs; evaluating them together shares that work.  Every value is
+// produced by the same operations as in dlgamma / ddigamma, so the results are bit-identical.
+DSQ_DEV void dlgamma_digamma(double x, double &lg, double &dg) {
+    if (x != x) { lg = x; dg = x; return; }
+    if (x <= 0.0) { lg = (x == 0.0) ? kInf : dnan(); dg = dnan(); return; }
+    if (x == kInf) { lg = x; dg = x; return; }
+    double prod = 1.0, num = 0.0, den = 1.0, xs = x;
+    bool shifted = false;
+    for (int i = 0; i < 10; i++) {
+        if (!__any(xs < 10.0)) break;
+        if (xs < 10.0) {
+            prod = prod * xs;
+            num = __builtin_fma(num, xs, den); den = den * xs;
+            xs = xs + 1.0; shifted = true;
+        }
+    }
+    double lx = dlog(xs);
+    double rx = 1.0 / xs;
+    double r2 = rx * rx;
+    double c = -3617.0 / 122400.0;
+    c = __builtin_fma(c, r2, 1.0 / 156.0);
+    c = __builtin_fma(c, r2, -691.0 / 360360.0);
+    c = __builtin_fma(c, r2, 1.0 / 1188.0);
+    c = __builtin_fma(c, r2, -1.0 / 1680.0);
+    c = __builtin_fma(c, r2, 1.0 / 1260.0);
+    c = __builtin_fma(c, r2, -1.0 / 360.0);
+    c = __builtin_fma(c, r2, 1.0 / 12.0);
+    double cor = c * rx;
+    double res = kLnSqrt2Pi + (xs - 0.5) * lx - xs + cor;
+    double d = -3617.0 / 8160.0;
+    d = __builtin_fma(d, r2, 1.0 / 12.0);
+    d = __builtin_fma(d, r2, -691.0 / 32760.0);
+    d = __builtin_fma(d, r2, 1.0 / 132.0);
+    d = __builtin_fma(d, r2, -1.0 / 240.0);
+    d = __builtin_fma(d, r2, 1.0 / 252.0);
+    d = __builtin_fma(d, r2, -1.0 / 120.0);
+    d = __builtin_fma(d, r2, 1.0 / 12.0);
+    double dres = (lx - 0.5 * rx) - d * r2;
+    if (__any(shifted)) {
+        double lp = dlog(prod);
+        double q = num / den;
+        if (shifted) { res = res - lp; dres = dres - q; }
+    }
+    lg = res;
+    dg = dres;
+}
+
 DSQ_DEV double dtrigamma(double x) {
     if (x != x) return x;
     if (x <= 0.0) return dnan();

@@ -27,6 +27,7 @@ struct DispGene {
     double prior_mean, prior_sigmasq, thr;
     bool usePrior, useCR;
     unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
+    int ablate;         // profiling only (DSQ_ABLATE), 0 in production
 
     DSQ_DEV bool keep_row(int j) const {
         if constexpr (USE_W) return r.w(j) > thr;
@@ -127,6 +128,71 @@ struct DispGene {
             prior_part = -0.5 * (d * d) / prior_sigmasq;
         }
         return ll_part + prior_part + cr_term;
+    }
+
+    // log_posterior AND dlog_posterior at the same point (src/DESeq2.cpp:31-64, 68-107).  The line
+    // search needs both at every accepted point (:233/:246 and :205/:206); they share exp(la), the
+    // Cox-Reid Gram matrix and its LU, log(1 + mu alpha), mu + 1/alpha, and -- inside lgamma and
+    // digamma of the same argument -- the shift, log(xs) and 1/xs.  Each shared value is produced
+    // by the very expression the separate functions use, so lp and dlp keep their bits.
+    DSQ_DEV double lp_dlp(double la, bool withPrior, double &dlp_out) const {
+        double alpha = dexp(la);
+        double cr_lp = 0.0, cr_dlp = 0.0;
+        if (useCR) {
+            double B[2][P][P];
+            gram<2>(
+                [&](double imu, double(&wd)[2]) {
+                    double t = imu + alpha;
+                    wd[0] = 1.0 / t;
+                    wd[1] = -1.0 * (1.0 / (t * t));
+                },
+                B);
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+            lu.factor();
+            double detb = lu.det();
+            cr_lp = -0.5 * dlog(detb);
+            double Bi[P][P];
+            lu.inverse(Bi);
+            double ddetb = detb * trace_prod<P>(Bi, B[1]);
+            cr_dlp = -0.5 * ddetb / detb;
+        }
+        double an1 = 1.0 / alpha;
+        double an2 = 1.0 / (alpha * alpha);
+        double lg_an1, dg_an1;
+        dlgamma_digamma(an1, lg_an1, dg_an1);
+        double acc = 0.0, acc2 = 0.0;
+        if (!(ablate & 1))          // profiling only
+        for (int j = lane; j < m; j += 64) {
+            double y = r.y(j), mu = r.mu(j);
+            double ma = mu * alpha;
+            double l1 = dlog(1.0 + ma);
+            double mpa = mu + an1;
+            double lg, dg;
+            dlgamma_digamma(y + an1, lg, dg);
+            double t = lg - lg_an1 - y * dlog(mpa) - an1 * l1;
+            double t2 = dg_an1 + l1 - ma * (1.0 / (1.0 + ma)) - dg + y * (1.0 / mpa);
+            if constexpr (USE_W) {
+                double w = r.w(j);
+                t = w * t;
+                t2 = w * t2;
+            }
+            acc += t;
+            acc2 += t2;
+        }
+        double ll_part = wave_allreduce(acc);
+        double ll_dpart = an2 * wave_allreduce(acc2);
+        double prior_part = 0.0, prior_dpart = 0.0;
+        if (usePrior) {
+            double d = la - prior_mean;
+            prior_part = -0.5 * (d * d) / prior_sigmasq;
+        }
+        if (withPrior) prior_dpart = -1.0 * (la - prior_mean) / prior_sigmasq;
+        dlp_out = (ll_dpart + cr_dlp) * alpha + prior_dpart;
+        return ll_part + prior_part + cr_lp;
     }
 
     // dlog_posterior, src/DESeq2.cpp:68-107
@@ -291,6 +357,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.thr = kp.weightThreshold;
         G.usePrior = kp.usePrior != 0;
         G.useCR = kp.useCR != 0;
+        G.ablate = kp.ablate;
         G.setup_cr();
 
         if constexpr (MODE == 2) {
@@ -321,8 +388,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             // fitDisp, src/DESeq2.cpp:194-266
             const double epsilon = 1.0e-4;
             double a = kp.log_alpha_in[g];
-            double lp = G.lp(a);
-            double dlp = G.dlp(a, G.usePrior);
+            double dlp;
+            double lp = G.lp_dlp(a, G.usePrior, dlp);
             double kappa = kp.kappa_0;
             const double initial_lp = lp, initial_dlp = dlp;
             double change = -1.0;
@@ -334,8 +401,10 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                 if (a_propose > 10.0) kappa = (10.0 - a) / dlp;
                 const double a_try = a + kappa * dlp;
                 // the reference evaluates log_posterior(a + kappa*dlp) for the Armijo test and
-                // again after accepting (:225,:233): same argument, same value -> evaluated once
-                const double lp_try = G.lp(a_try);
+                // again after accepting (:225,:233): same argument, same value -> evaluated once;
+                // the derivative it asks for after accepting (:246) is at that same point too
+                double dlp_try;
+                const double lp_try = G.lp_dlp(a_try, G.usePrior, dlp_try);
                 double theta_kappa = -1.0 * lp_try;
                 double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);
                 if (kp.force_iters > 0 && t + 1 >= kp.force_iters) break;   // profiling only
@@ -347,7 +416,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                     if (uniform(change < kp.tol)) { lp = lpnew; break; }
                     if (uniform(a < kp.min_log_alpha)) break;
                     lp = lpnew;
-                    dlp = G.dlp(a, G.usePrior);
+                    dlp = dlp_try;
                     kappa = __builtin_fmin(kappa * 1.1, kp.kappa_0);
                     if (it_acc % 5 == 0) kappa = kappa / 2.0;
                 } else {

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--cache", default="/tmp/kbench_data.npz")
     ap.add_argument("--design", default="bc")
+    ap.add_argument("--nocr", action="store_true")
     args = ap.parse_args()
     import torch
     from deseq2_amd import simulate
@@ -55,7 +56,7 @@ def main():
         fb = E.fit_beta(y, xh, nf, alpha, contrast, b0, lam, None, False, 1e-8, 100, True, 0.5, want_mu=True,
                         mu_floor=0.5, want_hat=True)
         fd = E.fit_disp(y, xh, fb["mu"], np.log(alpha), np.log(alpha), 1.0, np.log(1e-9), 1.0, 1e-6, 100, False, None,
-                        False, 1e-2, True)
+                        False, 1e-2, not args.nocr)
     torch.cuda.synchronize()
     tb = [ms for nm, _, ms in E.record if nm == "fit_beta"][1:]
     td = [ms for nm, _, ms in E.record if nm == "fit_disp"][1:]
