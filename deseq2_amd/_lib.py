@@ -109,6 +109,7 @@ EXPORTED_SYMBOLS = [
     "dsq_device_count", "dsq_set_device", "dsq_release_workspace", "dsq_test_math",
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
+    "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
 ]
 
 _lib = None
@@ -151,6 +152,9 @@ def lib():
     L.dsq_prefit_moments_dev.argtypes = [C.POINTER(DsqPrefitArgs), C.POINTER(DsqPrefitOut), C.c_void_p]
     L.dsq_nbinom_loglike.argtypes = [C.POINTER(DsqLogLikeArgs), C.c_void_p]
     L.dsq_nbinom_loglike_dev.argtypes = [C.POINTER(DsqLogLikeArgs), C.c_void_p, C.c_void_p]
+    L.dsq_parametric_dispersion_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.dsq_parametric_dispersion_fit_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]
     L.dsq_set_device.argtypes = [C.c_int]
     L.dsq_profile_enable.argtypes = [C.c_int]
     L.dsq_profile_last_ms.restype = C.c_double

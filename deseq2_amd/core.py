@@ -345,9 +345,10 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
 
 
 def parametricDispersionFit(means, disps):
-    """R/core.R:2166-2190: disp ~ asymptDisp + extraPois/mean by a Gamma GLM with identity link
-    (stats::glm's IRLS restated: working weights mu^-2, working response = disps; the two-column
-    normal equations are formed from five weighted sums)."""
+    """R/core.R:2166-2190 in numpy -- kept as an independent cross-check of the engine's
+    `parametric_fit` (tests); the pipeline itself calls the engine.  disp ~ asymptDisp +
+    extraPois/mean by a Gamma GLM with identity link (stats::glm's IRLS restated: working weights
+    mu^-2, working response = disps)."""
     means = np.asarray(means, np.float64)
     disps = np.asarray(disps, np.float64)
     coefs = np.array([0.1, 1.0])
@@ -358,7 +359,8 @@ def parametricDispersionFit(means, disps):
         yg, xg = disps[good], 1.0 / means[good]
         b = coefs.copy()
         converged = False
-        dev_old = None
+        r0 = yg / (b[0] + b[1] * xg)
+        dev_old = -2.0 * (np.log(r0).sum() - (r0 - 1.0).sum())     # glm.fit: devold from the start values
         for _ in range(25):                                   # glm.control(maxit = 25, epsilon = 1e-8)
             mu = b[0] + b[1] * xg
             if mu.min() <= 0:
@@ -374,7 +376,7 @@ def parametricDispersionFit(means, disps):
                 raise RuntimeError("parametric dispersion fit failed")
             r = yg / mu
             dev = -2.0 * (np.log(r).sum() - (r - 1.0).sum())
-            if dev_old is not None and abs(dev - dev_old) / (abs(dev) + 0.1) < 1e-8:
+            if abs(dev - dev_old) / (abs(dev) + 0.1) < 1e-8:
                 converged = True
                 break
             dev_old = dev
@@ -395,15 +397,16 @@ def _mad(v):
     return 1.4826 * np.median(np.abs(v - med))
 
 
-def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8):
+def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None):
     """R/core.R:864-939 + `dispersionFunction<-` (R/methods.R:142-190)"""
+    E = engine if engine is not None else dds.engine
     dge, bm = dds.mcols["dispGeneEst"], dds.mcols["baseMean"]
     useForFit = dge > 100 * minDisp
     if useForFit.sum() == 0:
         raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
     if fitType == "parametric":
         try:
-            coefs = parametricDispersionFit(bm[useForFit], dge[useForFit])
+            coefs = E.parametric_fit(bm[useForFit], dge[useForFit])
             fn = ("parametric", coefs)
         except RuntimeError:
             fitType = "mean"       # the reference falls back to locfit (not available here)
@@ -421,7 +424,7 @@ def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8):
     varLogDispEsts = None
     if aboveMinDisp.sum() > 0:
         res = np.log(dge) - np.log(dispFit)
-        varLogDispEsts = _mad(res[aboveMinDisp]) ** 2                                  # methods.R:180
+        varLogDispEsts = E.mad(res[aboveMinDisp]) ** 2                                 # methods.R:180
     dds.dispersionFunction = {"fitType": fn[0], "coefficients": fn[1], "varLogDispEsts": varLogDispEsts}
     return dds
 

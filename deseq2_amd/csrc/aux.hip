@@ -112,6 +112,93 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
     }
 }
 
+// ---- parametricDispersionFit (R/core.R:2166-2190) -----------------------------------------
+// The all-gene step between the two dispersion passes: a Gamma-GLM (identity link) IRLS for
+// disp ~ a0 + a1/mean inside the reference's outlier-filter loop.  It touches only two n-vectors,
+// but on the host it costs milliseconds per step and grows with the number of shards gathered, so
+// it runs here as ONE workgroup of 16 wavefronts that keeps the whole nested loop on the device
+// (no host round trip per iteration).  Sums in block order: thread t takes genes t, t+1024, ...;
+// wave butterfly; the 16 wave sums added in order.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double (*red)[8]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_allreduce_n(v);
+    __syncthreads();                      // previous use of `red` is complete
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double tot = red[0][k];
+        for (int g = 1; g < 16; g++) tot = tot + red[g][k];
+        v[k] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, const double *disps, long n,
+                                                         double *coefs_out, int32_t *status_out) {
+    __shared__ double red[16][8];
+    double c0 = 0.1, c1 = 1.0;
+    int iter = 0, status = 0;
+    for (;;) {
+        double b0 = c0, b1 = c1;
+        bool converged = false, invalid = false;
+        double devold = 0.0;
+        for (int pass = -1; pass < 25 && !invalid; pass++) {
+            if (pass >= 0) {
+                double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                for (long i = threadIdx.x; i < n; i += 1024) {
+                    double mean = means[i], y = disps[i];
+                    double res = y / (c0 + c1 / mean);
+                    if (!((res > 1e-4) && (res < 15.0))) continue;
+                    double x = 1.0 / mean;
+                    double mu = b0 + b1 * x;
+                    double wgt = 1.0 / (mu * mu);
+                    double wx = wgt * x;
+                    a[0] += wgt; a[1] += wx; a[2] += wx * x; a[3] += wgt * y; a[4] += wx * y;
+                }
+                block_sum<5>(a, red);
+                double det = a[0] * a[2] - a[1] * a[1];
+                b0 = (a[2] * a[3] - a[1] * a[4]) / det;
+                b1 = (a[0] * a[4] - a[1] * a[3]) / det;
+            }
+            double d[2] = {0.0, 0.0};
+            int bad = 0;
+            for (long i = threadIdx.x; i < n; i += 1024) {
+                double mean = means[i], y = disps[i];
+                double res = y / (c0 + c1 / mean);
+                if (!((res > 1e-4) && (res < 15.0))) continue;
+                double mu = b0 + b1 * (1.0 / mean);
+                if (!(mu > 0.0)) { bad = 1; continue; }
+                double r = y / mu;
+                d[0] += dlog(r); d[1] += r - 1.0;
+            }
+            if (__syncthreads_or(bad)) { invalid = true; break; }
+            block_sum<2>(d, red);
+            double dev = -2.0 * (d[0] - d[1]);
+            if (pass >= 0 && __builtin_fabs(dev - devold) / (__builtin_fabs(dev) + 0.1) < 1e-8) { converged = true; break; }
+            devold = dev;
+        }
+        if (invalid) { status = 1; break; }
+        double o0 = c0, o1 = c1;
+        c0 = b0; c1 = b1;
+        if (!(c0 > 0.0 && c1 > 0.0)) { status = 1; break; }
+        double l0 = dlog(c0 / o0), l1 = dlog(c1 / o1);
+        if ((l0 * l0 + l1 * l1 < 1e-6) && converged) break;
+        iter++;
+        if (iter > 10) { status = 2; break; }
+    }
+    if (threadIdx.x == 0) { coefs_out[0] = c0; coefs_out[1] = c1; *status_out = status; }
+}
+
+hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(trend_fit_kernel, dim3(1), dim3(1024), 0, st, means, disps, n, coefs, status);
+    return hipGetLastError();
+}
+
 static inline int aux_grid(int n) {
     int blocks = (n + 3) / 4;
     int cap = device_cu_count() * 8;

@@ -678,6 +678,35 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
     return DSQ_OK;
 }
 
+int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, int64_t n, double *coefs,
+                                      int32_t *status, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!means || !disps || !coefs || !status || n < 1) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    prof_begin((hipStream_t)stream);
+    DSQ_HIP(launch_trend_fit(means, disps, (long)n, coefs, status, (hipStream_t)stream));
+    prof_end((hipStream_t)stream);
+    return DSQ_OK;
+}
+
+int dsq_parametric_dispersion_fit(const double *means, const double *disps, int64_t n, double *coefs, int32_t *status) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!means || !disps || !coefs || !status || n < 1) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    hipStream_t st = nullptr;
+    void *v;
+    int rc;
+    if ((rc = ws_get(WS_H_VEC, (2 * (size_t)n + 4) * 8, &v))) return rc;
+    double *d = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(d, means, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(d + n, disps, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(launch_trend_fit(d, d + n, (long)n, d + 2 * n, (int32_t *)(d + 2 * n + 2), st));
+    DSQ_HIP(hipMemcpyAsync(coefs, d + 2 * n, 16, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(status, d + 2 * n + 2, 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
 int dsq_prefit_moments_dev(const DsqPrefitArgs *args, const DsqPrefitOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     return prefit_dev_locked(args, out, (hipStream_t)stream);

@@ -68,6 +68,16 @@ class HostEngine:
         """nbinomLogLike, R/core.R:2208-2217"""
         return self.fns.nbinomLogLike(y, mu, disp, weights if useWeights else None, useWeights)
 
+    def parametric_fit(self, means, disps):
+        """parametricDispersionFit, R/core.R:2166-2190"""
+        return self.fns.parametricDispersionFit(means, disps)
+
+    def mad(self, v):
+        """stats::mad (R/methods.R:180)"""
+        v = np.asarray(v, np.float64)
+        med = np.median(v)
+        return 1.4826 * np.median(np.abs(v - med))
+
     def two_sided_normal_p(self, z):
         """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507"""
         from scipy import special as sps
@@ -195,6 +205,22 @@ class DeviceEngine:
         dv = self._vec(disp)
         o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
         return o.cpu().numpy()
+
+    def parametric_fit(self, means, disps):
+        dm, dd = self._vec(means), self._vec(disps)
+        return self._timed("trend_fit", int(dm.numel()), lambda: self.native.parametricDispersionFit_dev(dm, dd))
+
+    def mad(self, v):
+        """stats::mad on the device (a sort; selecting order statistics is exact, so the value equals numpy's)"""
+        t = self.torch
+        x = self._vec(v)
+
+        def med(z):
+            s, _ = t.sort(z)
+            k = s.numel()
+            return s[k // 2] if k % 2 else (s[k // 2 - 1] + s[k // 2]) * 0.5
+        m0 = med(x)
+        return float(1.4826 * med((x - m0).abs()))
 
     def two_sided_normal_p(self, z):
         t = self.torch

@@ -183,6 +183,22 @@ def nbinomLogLike(counts, mu, disp, weights, useWeights):
     return out
 
 
+_FIT_ERRORS = {1: "parametric dispersion fit failed", 2: "dispersion fit did not converge"}
+
+
+def parametricDispersionFit(means, disps):
+    """R/core.R:2166-2190 through dsq_parametric_dispersion_fit; raises RuntimeError with the
+    reference's messages so the caller can fall back like R/core.R:885-893"""
+    means = np.ascontiguousarray(means, dtype=np.float64)
+    disps = np.ascontiguousarray(disps, dtype=np.float64)
+    coefs = np.zeros(2)
+    st = np.zeros(1, dtype=np.int32)
+    L.check(L.lib().dsq_parametric_dispersion_fit(_ptr(means), _ptr(disps), means.size, _ptr(coefs), _ptr(st)))
+    if st[0] != 0:
+        raise RuntimeError(_FIT_ERRORS.get(int(st[0]), "parametric dispersion fit failed"))
+    return coefs
+
+
 def test_math(op, a, b=None, c=None):
     """Evaluate one device-math primitive on the GPU (parity hook, see dsq_test_math)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
@@ -361,3 +377,16 @@ def nbinomLogLike_dev(y, mu, disp, weights=None, useWeights=False):
                             useWeights=int(bool(useWeights)))
     L.check(L.lib().dsq_nbinom_loglike_dev(C.byref(args), _t_ptr(out), _stream()))
     return out
+
+
+def parametricDispersionFit_dev(means, disps):
+    """means / disps: float64 CUDA tensors; returns the two coefficients as a host array"""
+    import torch
+    out = torch.zeros(3, dtype=torch.float64, device=means.device)      # coefs[2] + status word
+    L.check(L.lib().dsq_parametric_dispersion_fit_dev(_t_ptr(means), _t_ptr(disps), means.numel(), _t_ptr(out),
+                                                      C.c_void_p(out.data_ptr() + 16), _stream()))
+    h = out.cpu()
+    st = int(h[2:3].view(torch.int32)[0])
+    if st != 0:
+        raise RuntimeError(_FIT_ERRORS.get(st, "parametric dispersion fit failed"))
+    return h[:2].numpy().copy()

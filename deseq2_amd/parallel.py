@@ -47,7 +47,7 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
     bm_all = _allgather_vec(dds.mcols["baseMean"], comm_device)
     dge_all = _allgather_vec(dds.mcols["dispGeneEst"], comm_device)
     glob = _GlobalView(bm_all, dge_all, dds.x)
-    core.estimateDispersionsFit(glob, fitType=fitType)
+    core.estimateDispersionsFit(glob, fitType=fitType, engine=dds.engine)
     dispPriorVar = core.estimateDispersionsPriorVar(glob)
     # bring the global dispersion function back to the shard
     fn = glob.dispersionFunction

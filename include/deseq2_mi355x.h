@@ -219,6 +219,15 @@ typedef struct {
 int dsq_nbinom_loglike(const DsqLogLikeArgs *args, double *loglike);
 int dsq_nbinom_loglike_dev(const DsqLogLikeArgs *args, double *loglike, void *stream);
 
+/* dsq_parametric_dispersion_fit: parametricDispersionFit (R/core.R:2166-2190), the all-gene Gamma-GLM
+ * trend disp ~ asymptDisp + extraPois/mean between the two dispersion passes.  means / disps: n values
+ * (the genes with dispGeneEst > 100*minDisp, R/core.R:870).  coefs: 2 doubles.  *status: 0 ok,
+ * 1 = "parametric dispersion fit failed", 2 = "dispersion fit did not converge" (the caller then falls
+ * back as R/core.R:885-893 does).  _dev: device pointers (coefs, status on the device too).        */
+int dsq_parametric_dispersion_fit(const double *means, const double *disps, int64_t n, double *coefs, int32_t *status);
+int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, int64_t n, double *coefs,
+                                      int32_t *status, void *stream);
+
 /* ---- layout helpers (device pointers, async on stream) --------------------------
  * R layout (column-major n x m) <-> gene-major (row-major, leading dimension ld).   */
 int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);

@@ -730,3 +730,94 @@ int orc_fitted_mu(int n, int m, int p, const double *x, const double *nf, const 
         }
     return 0;
 }
+
+/* ==================================================== parametricDispersionFit ==
+ * R/core.R:2166-2190: disps ~ asymptDisp + extraPois / means by stats::glm(family =
+ * Gamma(link = "identity"), start = coefs) inside the outlier-filter loop.  glm.fit's IRLS is
+ * restated for this two-column model: working response = y, working weights = 1/mu^2, stop when
+ * |dev - devold| / (|dev| + 0.1) < 1e-8 (glm.control), at most 25 iterations; devold starts at the
+ * deviance of the start values.  Sums over the genes in BLOCK ORDER: 1024 partial sums, partial t
+ * taking elements t, t+1024, ...; the 64 partials of each of the 16 groups are butterflied
+ * (xor 1..32) and the 16 group sums added in order -- the order the one-workgroup kernel uses.
+ * status: 0 ok, 1 "parametric dispersion fit failed" (a coefficient <= 0 or an invalid mean),
+ * 2 "dispersion fit did not converge" (more than 10 outer rounds).                            */
+typedef struct { double part[1024]; } bsum_t;
+static void bsum_init(bsum_t *s) { for (int t = 0; t < 1024; t++) s->part[t] = 0.0; }
+static double bsum_total(const bsum_t *s) {
+    double tot = 0.0;
+    for (int g = 0; g < 16; g++) {
+        double v[64], w[64];
+        memcpy(v, s->part + 64 * g, sizeof v);
+        for (int off = 1; off < 64; off <<= 1) {
+            for (int l = 0; l < 64; l++) w[l] = v[l] + v[l ^ off];
+            memcpy(v, w, sizeof v);
+        }
+        tot = (g == 0) ? v[0] : tot + v[0];
+    }
+    return tot;
+}
+
+int orc_parametric_dispersion_fit(long n, const double *means, const double *disps, double *coefs_out,
+                                  int *status) {
+    double c0 = 0.1, c1 = 1.0;
+    unsigned char *good = malloc(n > 0 ? n : 1);
+    int iter = 0;
+    *status = 0;
+    for (;;) {
+        for (long i = 0; i < n; i++) {
+            double res = disps[i] / (c0 + c1 / means[i]);                          /* :2170 */
+            good[i] = (res > 1e-4) && (res < 15.0);                                /* :2171 */
+        }
+        double b0 = c0, b1 = c1;
+        int converged = 0, invalid = 0;
+        double devold = 0.0;
+        for (int pass = -1; pass < 25 && !invalid; pass++) {
+            if (pass >= 0) {
+                /* weighted least squares step */
+                bsum_t s0, s1, s2, t0, t1;
+                bsum_init(&s0); bsum_init(&s1); bsum_init(&s2); bsum_init(&t0); bsum_init(&t1);
+                for (long i = 0; i < n; i++) {
+                    if (!good[i]) continue;
+                    double x = 1.0 / means[i], y = disps[i];
+                    double mu = b0 + b1 * x;
+                    double wgt = 1.0 / (mu * mu);
+                    double wx = wgt * x;
+                    int t = (int)(i & 1023);
+                    s0.part[t] += wgt; s1.part[t] += wx; s2.part[t] += wx * x;
+                    t0.part[t] += wgt * y; t1.part[t] += wx * y;
+                }
+                double S0 = bsum_total(&s0), S1 = bsum_total(&s1), S2 = bsum_total(&s2);
+                double T0 = bsum_total(&t0), T1 = bsum_total(&t1);
+                double det = S0 * S2 - S1 * S1;
+                b0 = (S2 * T0 - S1 * T1) / det;
+                b1 = (S0 * T1 - S1 * T0) / det;
+            }
+            /* deviance at the current coefficients (pass = -1: at the start values) */
+            bsum_t d1, d2;
+            bsum_init(&d1); bsum_init(&d2);
+            for (long i = 0; i < n; i++) {
+                if (!good[i]) continue;
+                double mu = b0 + b1 * (1.0 / means[i]);
+                if (!(mu > 0.0)) { invalid = 1; break; }
+                double r = disps[i] / mu;
+                int t = (int)(i & 1023);
+                d1.part[t] += orc_log(r); d2.part[t] += r - 1.0;
+            }
+            if (invalid) break;
+            double dev = -2.0 * (bsum_total(&d1) - bsum_total(&d2));
+            if (pass >= 0 && fabs(dev - devold) / (fabs(dev) + 0.1) < 1e-8) { converged = 1; break; }
+            devold = dev;
+        }
+        if (invalid) { *status = 1; break; }
+        double o0 = c0, o1 = c1;
+        c0 = b0; c1 = b1;
+        if (!(c0 > 0.0 && c1 > 0.0)) { *status = 1; break; }                       /* :2177-2178 */
+        double l0 = orc_log(c0 / o0), l1 = orc_log(c1 / o1);
+        if ((l0 * l0 + l1 * l1 < 1e-6) && converged) break;                        /* :2179-2180 */
+        iter++;
+        if (iter > 10) { *status = 2; break; }                                     /* :2182-2183 */
+    }
+    coefs_out[0] = c0; coefs_out[1] = c1;
+    free(good);
+    return 0;
+}

@@ -198,3 +198,15 @@ def prefitMoments(counts, nf, x, weights=None, useWeights=False, sum_mode=0):
     if rc != 0:
         raise RuntimeError("orc_prefit_moments failed")
     return {"baseMean": bm, "baseVar": bv, "allZero": az.astype(bool), "roughDisp": rd, "beta_init": b0}
+
+
+def parametricDispersionFit(means, disps):
+    """R/core.R:2166-2190; raises RuntimeError with the reference's messages on failure"""
+    means = np.ascontiguousarray(means, dtype=np.float64); disps = np.ascontiguousarray(disps, dtype=np.float64)
+    coefs = np.zeros(2); st = ctypes.c_int(0)
+    lib().orc_parametric_dispersion_fit(ctypes.c_long(means.size), _p(means), _p(disps), _p(coefs), ctypes.byref(st))
+    if st.value == 1:
+        raise RuntimeError("parametric dispersion fit failed")
+    if st.value == 2:
+        raise RuntimeError("dispersion fit did not converge")
+    return coefs

@@ -164,3 +164,15 @@ def test_nbinom_loglike_matches_oracle(oracle):
         ref = nbinom.logpmf(d["counts"], size, size / (size + mu))
         ref = (d["weights"] * ref if useW else ref).sum(axis=1)
         np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+def test_parametric_dispersion_fit_matches_oracle(oracle):
+    """extension: the all-gene trend fit (R/core.R:2166-2190) as a one-workgroup kernel"""
+    from deseq2_amd import native
+    rng = np.random.default_rng(8)
+    for n in (300, 5000, 70001):
+        bm = np.exp(rng.normal(3, 1.5, n)); disp = (0.1 + 4 / bm) * np.exp(rng.normal(0, 0.5, n))
+        assert_same(native.parametricDispersionFit(bm, disp), oracle.parametricDispersionFit(bm, disp),
+                    "parametricDispersionFit n=%d" % n)
+    with pytest.raises(RuntimeError):
+        native.parametricDispersionFit(bm, 1e-3 + 0.5 * bm / bm.max())

@@ -160,3 +160,17 @@ def test_summation_order_sensitivity(oracle):
     same = da["iter"] == db["iter"]
     assert same.mean() > 0.97
     np.testing.assert_allclose(da["log_alpha"][same], db["log_alpha"][same], rtol=1e-6, atol=1e-7)
+
+
+def test_parametric_dispersion_fit_restatement(oracle):
+    """oracle's C restatement of parametricDispersionFit (R/core.R:2166-2190) against the
+    independent numpy IRLS and against the generating trend"""
+    from deseq2_amd import core
+    rng = np.random.default_rng(7)
+    bm = np.exp(rng.normal(3, 1.5, 20000)); disp = (0.1 + 4 / bm) * np.exp(rng.normal(0, 0.5, 20000))
+    a = oracle.parametricDispersionFit(bm, disp)
+    b = core.parametricDispersionFit(bm, disp)
+    np.testing.assert_allclose(a, b, rtol=1e-9)
+    assert 0.08 < a[0] < 0.16 and 3.0 < a[1] < 6.0
+    with pytest.raises(RuntimeError, match="failed"):      # decreasing-to-negative trend: a coefficient <= 0
+        oracle.parametricDispersionFit(bm, np.maximum(2.0 - 1.0 / bm, 1e-3) * 0 + 1e-3 + 0.5 * bm / bm.max())
