@@ -101,6 +101,30 @@ class DsqLogLikeArgs(C.Structure):
     ]
 
 
+class DsqCooksArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32),
+        ("mu", C.c_void_p), ("H", C.c_void_p), ("cell_of", C.c_void_p), ("ncell", C.c_int32),
+    ]
+
+
+class DsqCooksOut(C.Structure):
+    _fields_ = [("cooks", C.c_void_p), ("maxCooks", C.c_void_p), ("robustDisp", C.c_void_p)]
+
+
+class DsqReplaceArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64), ("y", C.c_void_p),
+        ("y_type", C.c_int32), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32), ("cooks", C.c_void_p),
+        ("cooksCutoff", C.c_double), ("trim", C.c_double), ("replaceable", C.c_void_p),
+    ]
+
+
+class DsqReplaceOut(C.Structure):
+    _fields_ = [("newCounts", C.c_void_p), ("replace", C.c_void_p)]
+
+
 # every symbol include/deseq2_mi355x.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "dsq_fit_beta", "dsq_fit_beta_dev", "dsq_fit_disp", "dsq_fit_disp_dev", "dsq_fit_disp_grid",
@@ -110,6 +134,7 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
+    "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
 _lib = None
@@ -155,6 +180,10 @@ def lib():
     L.dsq_parametric_dispersion_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.dsq_parametric_dispersion_fit_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p]
+    L.dsq_cooks_distance.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut)]
+    L.dsq_cooks_distance_dev.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut), C.c_void_p]
+    L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]
+    L.dsq_replace_outliers_dev.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut), C.c_void_p]
     L.dsq_set_device.argtypes = [C.c_int]
     L.dsq_profile_enable.argtypes = [C.c_int]
     L.dsq_profile_last_ms.restype = C.c_double

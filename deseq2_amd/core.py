@@ -5,8 +5,11 @@ routines go to the MI355X engine (engine.py); the all-gene "global" steps betwee
 (dispersion trend, prior variance) stay on the host exactly as in DESeqParallel
 (R/parallel.R:27-28) -- they exchange only n-vectors.
 
-Not mirrored (out of the hot-path scope): size-factor estimation, outlier
-replacement / Cook's distances, local/glmGamPoi dispersion fits, results(), lfcShrink().
+Cook's distances, outlier replacement and the refit loop are mirrored too; their
+O(n m) parts run in the engine.
+
+Not mirrored (out of the hot-path scope): size-factor estimation,
+local/glmGamPoi dispersion fits, results(), lfcShrink().
 """
 import numpy as np
 from scipy import special as sps
@@ -68,6 +71,23 @@ class DESeqDataSet:
         self.mcols, self.assays, self.attrs = {}, {}, {}
         self.dispersionFunction = None
         return self
+
+    def subset(self, idx, counts_handle=None):
+        """object[idx, ] (optionally over another count matrix handle with the same rows as self)"""
+        E = self.engine
+        sub = DESeqDataSet.__new__(DESeqDataSet)
+        idx = np.asarray(idx)
+        sub.n, sub.m, sub.x, sub.engine = int(idx.size), self.m, self.x, E
+        sub.sizeFactors = self.sizeFactors
+        sub.counts_host = None
+        sub.y = E.take_rows(self.y if counts_handle is None else counts_handle, idx)
+        sub.nf = E.take_rows(self.nf, idx)
+        sub.has_weights = self.has_weights
+        sub.weights_raw = None if self.weights_raw is None else self.weights_raw[idx]
+        sub.xh = self.xh
+        sub.mcols, sub.assays, sub.attrs = {}, {}, {}
+        sub.dispersionFunction = None if self.dispersionFunction is None else dict(self.dispersionFunction)
+        return sub
 
     @property
     def p(self):
@@ -141,17 +161,26 @@ def modelMatrixGroups(x):
 
 
 # ------------------------------------------------------------------ R/fitNbinomGLMs.R
-def fitNbinomGLMsOptim(dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_host, useWeights, betaMatrix,
-                       betaSE, betaConv, beta_mat_init, mu, logLike, minmu=0.5):
+def _dnbinom_mu_log(k, size, mu):
+    """dnbinom(k, mu = mu, size = size, log = TRUE) for the host-side optim fallback, in a form that
+    stays finite for the extreme mu an L-BFGS-B line search visits (beta up to +-30 on the log2 scale)"""
+    k, mu = np.asarray(k, np.float64), np.asarray(mu, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tail = np.where(k > 0, k * (np.log(mu) - np.log(size + mu)), 0.0)
+    return sps.gammaln(k + size) - sps.gammaln(size) - sps.gammaln(k + 1.0) - size * np.log1p(mu / size) + tail
+
+
+def fitNbinomGLMsOptim(E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, weights, useWeights, betaMatrix,
+                       betaSE, betaConv, beta_mat_init, logLike, minmu=0.5):
     """R/fitNbinomGLMs.R:340-407: per-row L-BFGS-B on the penalised NB log-posterior for rows the
     IRLS did not fit.  A host loop in the reference too; only the few affected rows come back
     from the device."""
     from scipy.optimize import minimize
-    from scipy.stats import nbinom, norm
-    E = dds.engine
+    from scipy.stats import norm
     rows = np.asarray(rowsForOptim)
-    yh = E.to_numpy(E.take_rows(dds.y, rows)).astype(np.float64)
-    nfh = E.to_numpy(E.take_rows(dds.nf, rows))
+    yh = E.to_numpy(E.take_rows(y, rows)).astype(np.float64)
+    nfh = E.to_numpy(E.take_rows(nf, rows))
+    wh = E.to_numpy(E.take_rows(weights, rows)) if useWeights else None
     lambdaNatLogScale = lam / np.log(2) ** 2
     large = 30.0
     mu_rows = np.empty_like(yh)
@@ -161,18 +190,26 @@ def fitNbinomGLMsOptim(dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_
         else:
             betaRow = np.asarray(beta_mat_init[row], float).copy()                 # :354
         nf, k, alpha = nfh[r], yh[r], alpha_hat[row]
-        w = weights_host[row] if useWeights else None
+        w = wh[r] if useWeights else None
 
         def objectiveFn(pv):                                                       # :359-370
             mu_row = nf * 2.0 ** (x @ pv)
-            size = 1.0 / alpha
             with np.errstate(all="ignore"):
-                ll = nbinom.logpmf(k, size, size / (size + mu_row))
+                ll = _dnbinom_mu_log(k, 1.0 / alpha, mu_row)
                 logLike_ = np.sum(w * ll) if useWeights else np.sum(ll)
                 logPrior = np.sum(norm.logpdf(pv, 0.0, np.sqrt(1.0 / lam)))
             v = -1.0 * (logLike_ + logPrior)
             return v if np.isfinite(v) else 1e300
-        o = minimize(objectiveFn, betaRow, method="L-BFGS-B", bounds=[(-large, large)] * len(betaRow))   # :371
+
+        def gradFn(pv):                      # stats::optim's numerical gradient: central, ndeps = 1e-3, clipped
+            g = np.empty_like(pv)
+            for i in range(pv.size):
+                hi, lo = pv.copy(), pv.copy()
+                hi[i], lo[i] = min(pv[i] + 1e-3, large), max(pv[i] - 1e-3, -large)
+                g[i] = (objectiveFn(hi) - objectiveFn(lo)) / (hi[i] - lo[i])
+            return g
+        o = minimize(objectiveFn, betaRow, jac=gradFn, method="L-BFGS-B", bounds=[(-large, large)] * len(betaRow),
+                     options=dict(maxcor=5, ftol=1e7 * np.finfo(float).eps, gtol=0.0, maxiter=100))   # :371
         if o.success:
             betaConv[row] = True                                                   # :378-380
         betaMatrix[row] = o.x                                                      # :382
@@ -184,18 +221,17 @@ def fitNbinomGLMsOptim(dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_
         xtwxRidgeInv = np.linalg.inv(xtwx + np.diag(lambdaNatLogScale))
         sigma = xtwxRidgeInv @ xtwx @ xtwxRidgeInv                                 # :395
         betaSE[row] = LOG2E * np.sqrt(np.maximum(np.diag(sigma), 0))               # :397
-        size = 1.0 / alpha
-        llv = nbinom.logpmf(k, size, size / (size + mu_c))                         # :398 (clamped mu_row)
+        llv = _dnbinom_mu_log(k, 1.0 / alpha, mu_c)                                # :398 (clamped mu_row)
         logLike[row] = np.sum(w * llv) if useWeights else np.sum(llv)
     return betaMatrix, betaSE, betaConv, rows, mu_rows, logLike
 
 
 def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, betaTol=1e-8, maxit=100,
                   useOptim=True, useQR=True, minmu=0.5, weights=None, useWeights=False, mu_floor=0.0,
-                  want_hat=True, forceOptim=False, refitOptim=False, weights_host=None):
-    """R/fitNbinomGLMs.R:29-236.  Rows the IRLS does not fit are listed in `rowsForOptim`
-    (:203-211); with refitOptim = TRUE (or forceOptim) they go through the reference's L-BFGS-B
-    fallback on the host (fitNbinomGLMsOptim), as in R."""
+                  want_hat=True, forceOptim=False, weights_host=None, want_loglike=False):
+    """R/fitNbinomGLMs.R:29-236.  Rows the IRLS does not fit (`rowsForOptim`, :203-211) go through the
+    reference's L-BFGS-B fallback on the host (fitNbinomGLMsOptim, :213-227), as in R.  logLike
+    (:182) is computed only when the caller reads it (want_loglike)."""
     E = dds.engine
     x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
     xh = dds.xh if modelMatrix is None else E.design(x)
@@ -230,8 +266,9 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         return {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
                 "mu": E.matrix(mu_h), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
                 "hat_diagonals": E.matrix(wd / xtwx[:, None]), "deviance_native": None,
-                "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E,
-                "optimRows": None, "optimMu": None, "optimLogLike": None}
+                "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E, "optimRows": None,
+                "logLike": (E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights)
+                            if want_loglike else None)}
     # initial betas by QR least squares when full rank (:139-155)
     if np.linalg.matrix_rank(x) == p:
         if rows is None and modelMatrix is None and "prefit" in dds.attrs:
@@ -263,15 +300,19 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         rowsForOptim = np.where(~rowStable | ~rowVarPositive)[0]
     if forceOptim:
         rowsForOptim = np.arange(n)                                                # :209-211
-    optimRows, optimMu, optimLogLike = None, None, None
-    if (refitOptim or forceOptim) and len(rowsForOptim) > 0:
+    logLike = E.nbinom_loglike(y, mu, alpha_hat, weights, useWeights) if want_loglike else None   # :182
+    optimRows = None
+    if len(rowsForOptim) > 0:                                                      # :213-227
         ll = np.full(n, np.nan)
         b0 = E.to_numpy_np(beta_mat) if hasattr(E, "to_numpy_np") else beta_mat
-        betaMatrix, betaSE, betaConv, optimRows, optimMu, optimLogLike = fitNbinomGLMsOptim(
-            dds, x, lam, rowsForOptim, rowStable, alpha_hat, weights_host, useWeights, betaMatrix.copy(),
-            betaSE.copy(), betaConv.copy(), b0, mu, ll, minmu=minmu)
-    return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu,
-            "optimRows": optimRows, "optimMu": optimMu, "optimLogLike": optimLogLike,
+        betaMatrix, betaSE, betaConv, optimRows, optimMu, ll = fitNbinomGLMsOptim(
+            E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, weights, useWeights, betaMatrix.copy(),
+            betaSE.copy(), betaConv.copy(), b0, ll, minmu=minmu)
+        mu = E.put_rows(mu, optimRows, np.maximum(optimMu, mu_floor))              # mu[row,] <- mu_row  (:386)
+        if logLike is not None:
+            logLike[optimRows] = ll[optimRows]                                     # :399
+    return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu, "logLike": logLike,
+            "optimRows": optimRows,
             "betaIter": betaRes["iter"], "modelMatrix": x, "nterms": p,
             "hat_diagonals": betaRes.get("hat_diagonals"), "deviance_native": betaRes["deviance"],
             "rowsForOptim": rowsForOptim, "beta_natlog": betaRes["beta_mat"]}
@@ -621,10 +662,11 @@ def fitGLMsWithPrior(dds, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, be
     if modelMatrixType == "expanded":
         xe, _ = makeExpandedModelMatrix(factors)
         fit2 = fitNbinomGLMs(dds, lam=lam, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR,
-                             modelMatrix=xe, minmu=minmu, weights=weights, useWeights=useWeights)   # :319-325
+                             modelMatrix=xe, minmu=minmu, weights=weights, useWeights=useWeights,
+                             want_loglike=True)                                        # :319-325
     else:
         fit2 = fitNbinomGLMs(dds, lam=lam, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR,
-                             minmu=minmu, weights=weights, useWeights=useWeights)      # :314-317
+                             minmu=minmu, weights=weights, useWeights=useWeights, want_loglike=True)   # :314-317
     return {"fit": fit2, "H": H, "betaPriorVar": np.asarray(betaPriorVar), "mu": mu,
             "modelMatrix": fit2["modelMatrix"], "mleBetaMatrix": mle}
 
@@ -632,7 +674,7 @@ def fitGLMsWithPrior(dds, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, be
 # ------------------------------------------------------------------ tests
 def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=None, useQR=True, minmu=0.5,
                    modelMatrix=None, betaPrior=False, betaPriorVar=None, modelMatrixType=None, factors=None):
-    """R/core.R:1332-1565 (Cook's distances not mirrored).  betaPrior = TRUE goes through
+    """R/core.R:1332-1565.  betaPrior = TRUE goes through
     fitGLMsWithPrior (:1416-1432), by default on the expanded model matrix (:1374-1380)."""
     if "dispersion" not in dds.mcols:
         raise RuntimeError("testing requires dispersion estimates, first call estimateDispersions()")
@@ -642,7 +684,7 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     if not betaPrior:
         fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
                             modelMatrix=modelMatrix, weights=weights, useWeights=useWeights,
-                            refitOptim=useOptim, weights_host=w_host)                            # :1403-1408
+                            weights_host=w_host, want_loglike=True)                              # :1403-1408
         H, mu_fit = fit["hat_diagonals"], fit["mu"]
         bpv = np.full(fit["nterms"], 1e6)
     else:
@@ -656,7 +698,9 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     fit = dict(fit); fit["mu"] = mu_fit; fit["hat_diagonals"] = H
     dds.assays["mu"] = fit["mu"]
     dds.assays["H"] = fit["hat_diagonals"]
-    dds.attrs.update(betaPrior=bool(betaPrior), betaPriorVar=bpv, test="Wald")
+    dds.attrs.update(betaPrior=bool(betaPrior), betaPriorVar=bpv, test="Wald",
+                     modelMatrixType=modelMatrixType, factors=factors)
+    calculateCooksDistance(dds, H, dds.x if modelMatrix is None else np.asarray(modelMatrix, float))   # :1451-1463
     betaMatrix, betaSE = fit["betaMatrix"], fit["betaSE"]
     with np.errstate(divide="ignore", invalid="ignore"):
         WaldStatistic = betaMatrix / betaSE                                         # :1471
@@ -669,9 +713,7 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
         WaldPvalue = 2 * tdist.sf(np.abs(WaldStatistic), df=np.asarray(df)[:, None])
     else:
         WaldPvalue = E.two_sided_normal_p(WaldStatistic)                            # :1507
-    logLike = E.nbinom_loglike(dds.y, fit["mu"], dds.mcols["dispersion"], weights, useWeights)   # fitNbinomGLMs.R:182
-    if fit.get("optimRows") is not None:
-        logLike[fit["optimRows"]] = fit["optimLogLike"][fit["optimRows"]]           # fitNbinomGLMs.R:399
+    logLike = fit["logLike"]                                                    # fitNbinomGLMs.R:182,399
     dds.mcols.update(beta=betaMatrix, betaSE=betaSE, WaldStatistic=WaldStatistic, WaldPvalue=WaldPvalue,
                      betaConv=fit["betaConv"], betaIter=fit["betaIter"], deviance=-2 * logLike,
                      rowsForOptim=fit["rowsForOptim"])
@@ -689,26 +731,164 @@ def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, 
     weights = E.matrix(w_host) if useWeights else None
     disp = dds.mcols["dispersion"]
     full = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
-                         weights=weights, useWeights=useWeights)
-    ll_full = E.nbinom_loglike(dds.y, full["mu"], disp, weights, useWeights)
+                         weights=weights, useWeights=useWeights, want_loglike=True)
+    ll_full = full["logLike"]
     red = fitNbinomGLMs(dds, modelMatrix=reduced, betaTol=betaTol, maxit=maxit, useOptim=useOptim,
                         useQR=useQR, minmu=minmu, weights=weights, useWeights=useWeights, want_hat=False,
-                        weights_host=w_host)                     # closed form when reduced is ~1 (:99-137)
-    mu_red = red["mu"]
-    ll_red = E.nbinom_loglike(dds.y, mu_red, disp, weights, useWeights)
+                        weights_host=w_host, want_loglike=True)   # closed form when reduced is ~1 (:99-137)
+    ll_red = red["logLike"]
     LRTStatistic = 2 * (ll_full - ll_red)                                            # :1877
     LRTPvalue = chi2.sf(LRTStatistic, df=full["nterms"] - red["nterms"])             # :1878
     dds.assays["mu"] = full["mu"]
     dds.assays["H"] = full["hat_diagonals"]
+    dds.attrs.update(betaPrior=False, test="LRT", reduced=reduced)
+    calculateCooksDistance(dds, full["hat_diagonals"], dds.x)                         # :1886-1891
     dds.mcols.update(beta=full["betaMatrix"], betaSE=full["betaSE"], LRTStatistic=LRTStatistic,
                      LRTPvalue=LRTPvalue, fullBetaConv=full["betaConv"], betaIter=full["betaIter"],
                      deviance=-2 * ll_full)
     return dds
 
 
-def DESeq(dds, test="Wald", fitType="parametric", reduced=None, **kw):
-    """R/core.R:280-432, default serial path without outlier replacement (size factors are
-    taken as given: estimateSizeFactors is outside the hot path)."""
+# ------------------------------------------------------------------ count outliers
+def nOrMoreInCell(modelMatrix, n):
+    """R/core.R:2366-2371: per sample, are there n or more samples with the same model-matrix row"""
+    _, inv, cnt = np.unique(np.asarray(modelMatrix, np.float64), axis=0, return_inverse=True, return_counts=True)
+    return cnt[inv.reshape(-1)] >= n
+
+
+def calculateCooksDistance(dds, H, modelMatrix):
+    """calculateCooksDistance (R/core.R:2333-2340) on the robust method-of-moments dispersion
+    (:2277-2331) + recordMaxCooks (:2349-2359); one engine pass over assays mu / H."""
+    r = dds.engine.cooks_distance(dds.y, dds.nf, dds.assays["mu"], H, modelMatrix)
+    dds.assays["cooks"] = r["cooks"]
+    dds.mcols["maxCooks"] = r["maxCooks"]
+    dds.attrs["dispModelMatrix"] = np.asarray(modelMatrix, np.float64)
+    return dds
+
+
+def replaceOutliers(dds, trim=.2, cooksCutoff=None, minReplicates=7, whichSamples=None):
+    """R/core.R:2069-2115.  The replaced count matrix goes to assays["replaceCounts"] (the handle
+    the refit reads); dds.y keeps the original counts, as counts(dds) does at the end of
+    refitWithoutOutliers (:2553-2557)."""
+    from scipy.stats import f as fdist
+    if "cooks" not in dds.assays:
+        raise RuntimeError("first run DESeq, nbinomWaldTest, or nbinomLRT to identify outliers")
+    if minReplicates < 3:
+        raise ValueError("at least 3 replicates are necessary in order to indentify a sample as a count outlier")
+    x = dds.attrs["dispModelMatrix"]
+    p, m = x.shape[1], dds.m
+    if m <= p:
+        return dds
+    if cooksCutoff is None:
+        cooksCutoff = float(fdist.ppf(.99, p, m - p))                                # :2081
+    if whichSamples is None:
+        whichSamples = nOrMoreInCell(x, minReplicates)                               # :2101
+    whichSamples = np.asarray(whichSamples, bool)
+    dds.attrs["replaceable"] = whichSamples
+    r = dds.engine.replace_outliers(dds.y, dds.nf, dds.assays["cooks"], cooksCutoff, whichSamples, trim)
+    dds.mcols["replace"] = r["replace"]
+    dds.assays["replaceCounts"] = r["counts"] if whichSamples.any() else dds.y       # :2108-2112
+    return dds
+
+
+_RESULT_COLS = ("beta", "betaSE", "WaldStatistic", "WaldPvalue", "LRTStatistic", "LRTPvalue", "betaConv",
+                "fullBetaConv", "betaIter", "deviance", "maxCooks")
+
+
+def _dispersion_function(dds, baseMean):
+    fn = dds.dispersionFunction
+    if fn["fitType"] == "parametric":
+        return fn["coefficients"][0] + fn["coefficients"][1] / baseMean
+    return np.full(baseMean.shape, fn["coefficients"])
+
+
+def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace=7, **kw):
+    """R/core.R:2484-2563: replace count outliers by the trimmed mean, then re-estimate the
+    dispersion and refit the rows that had a replacement (all through the same engine entry
+    points, on the row subset)."""
+    E = dds.engine
+    kw = {k: v for k, v in kw.items() if k not in ("betaPrior", "betaPriorVar", "modelMatrixType", "factors")}
+    replaceOutliers(dds, minReplicates=minReplicatesForReplace)
+    if "replace" not in dds.mcols:
+        return dds
+    replace = dds.mcols["replace"]
+    nrefit = int(replace.sum())
+    if nrefit == 0:
+        dds.assays.pop("replaceCounts", None)
+        return dds
+    idx_rep = np.where(replace)[0]
+    whole = dds.subset(idx_rep, dds.assays["replaceCounts"])
+    getBaseMeansAndVariances(whole)                                                   # :2491
+    for k in ("baseMean", "baseVar", "allZero"):
+        dds.mcols[k] = dds.mcols[k].copy()
+        dds.mcols[k][idx_rep] = whole.mcols[k]
+    newAllZero = idx_rep[whole.mcols["allZero"]]
+    if nrefit > newAllZero.size:                                                      # :2496
+        keep = ~whole.mcols["allZero"]
+        refitReplace = idx_rep[keep]
+        sub = dds.subset(refitReplace, dds.assays["replaceCounts"])
+        estimateDispersionsGeneEst(sub)                                               # :2509
+        sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
+        estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"])   # :2518-2519
+        if test == "Wald":
+            nbinomWaldTest(sub, betaPrior=dds.attrs.get("betaPrior", False), betaPriorVar=(
+                dds.attrs["betaPriorVar"] if dds.attrs.get("betaPrior", False) else None),
+                modelMatrixType=dds.attrs.get("modelMatrixType"), factors=dds.attrs.get("factors"), **kw)
+        else:
+            nbinomLRT(sub, reduced, **kw)
+        for k, v in sub.mcols.items():                                                # :2533-2534
+            if k not in dds.mcols or k == "rowsForOptim" or np.shape(v)[:1] != (sub.n,):
+                continue
+            dst = np.array(dds.mcols[k], copy=True)
+            dst[refitReplace] = v
+            dds.mcols[k] = dst
+        for k in _RESULT_COLS:                                                        # :2535
+            if k in dds.mcols and newAllZero.size:
+                a = dds.mcols[k]
+                if a.dtype.kind != "f":
+                    a = a.astype(np.float64)
+                a[newAllZero] = np.nan
+                dds.mcols[k] = a
+        replaceable = dds.attrs["replaceable"]
+        if replaceable.all():                                                         # :2538-2546
+            dds.mcols["maxCooks"] = np.full(dds.n, np.nan)
+        else:
+            x = dds.attrs["dispModelMatrix"]
+            if x.shape[0] > x.shape[1] and nOrMoreInCell(x, 3).any():
+                dds.mcols["maxCooks"] = E.masked_row_max(dds.assays["cooks"], nOrMoreInCell(x, 3), replaceable)
+            else:
+                dds.mcols["maxCooks"] = np.full(dds.n, np.nan)
+    dds.assays["replaceCooks"] = dds.assays["cooks"]                                   # :2551
+    return dds
+
+
+def cooksOutlier(dds, cooksCutoff=None):
+    """The Cook's-distance filter results() applies to the p-values (R/results.R:520-564): genes whose
+    maxCooks exceeds qf(.99, p, m - p); for a two-group design a gene is kept when three or more
+    counts are larger than the count with the largest Cook's distance (:541-560).  Returns the flags
+    (results() sets pvalue <- NA there)."""
+    from scipy.stats import f as fdist
+    x = dds.attrs["dispModelMatrix"]
+    m, p = x.shape
+    if cooksCutoff is None:
+        cooksCutoff = float(fdist.ppf(.99, p, m - p))
+    mx = dds.mcols["maxCooks"]
+    with np.errstate(invalid="ignore"):
+        out = np.where(np.isnan(mx), False, mx > cooksCutoff)
+    two_group = p == 2 and (x[:, 0] == 1).all() and set(np.unique(x[:, 1])) <= {0.0, 1.0}
+    if out.any() and two_group:
+        E = dds.engine
+        ii = np.where(out)[0]
+        cnt = E.to_numpy(E.take_rows(dds.y, ii))
+        ck = E.to_numpy(E.take_rows(dds.assays["cooks"], ii))
+        outCount = cnt[np.arange(ii.size), np.argmax(ck, axis=1)]
+        out[ii[(cnt > outCount[:, None]).sum(axis=1) >= 3]] = False
+    return out
+
+
+def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, **kw):
+    """R/core.R:280-432, serial path (size factors are taken as given: estimateSizeFactors is
+    outside the hot path).  minReplicatesForReplace = np.inf switches the outlier refit off."""
     estimateDispersions(dds, fitType=fitType)
     if test == "Wald":
         nbinomWaldTest(dds, **kw)
@@ -716,4 +896,6 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, **kw):
         nbinomLRT(dds, reduced, **kw)
     else:
         raise ValueError("test should be either 'Wald' or 'LRT'")
+    if np.isfinite(minReplicatesForReplace) and nOrMoreInCell(dds.x, minReplicatesForReplace).any():   # :419-426
+        refitWithoutOutliers(dds, test=test, reduced=reduced, minReplicatesForReplace=minReplicatesForReplace, **kw)
     return dds

@@ -99,7 +99,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
 }
 
 enum {  // workspace slots
-    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD,
+    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN,
     // host-entry staging
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
@@ -424,6 +424,112 @@ static int loglike_dev_locked(const DsqLogLikeArgs *a, double *out, hipStream_t 
 }
 
 // ---- host-pointer staging helpers --------------------------------------------------
+// =============================================================== Cook's distances / replaceOutliers
+static int next_pow2(int n) { int v = 2; while (v < n) v <<= 1; return v; }
+
+static int cooks_dev_locked(const DsqCooksArgs *a, const DsqCooksOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1 || a->p < 1 || a->ncell < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->mu || !a->H || !a->cell_of) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (!o->cooks || !o->maxCooks) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    const int m = a->m;
+    // design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags
+    static std::vector<int32_t> meta;
+    meta.assign((size_t)2 * m + a->ncell + 1, 0);
+    int32_t *perm = meta.data(), *in3 = perm + m, *start = in3 + m;
+    for (int j = 0; j < m; j++) {
+        if (a->cell_of[j] < 0 || a->cell_of[j] >= a->ncell) return fail(DSQ_ERR_VALUE, "cell_of[%d] out of range", j);
+        start[a->cell_of[j] + 1]++;
+    }
+    int maxcell = 0, any3 = 0;
+    for (int c = 0; c < a->ncell; c++) {
+        int sz = start[c + 1];
+        if (sz > maxcell) maxcell = sz;
+        if (sz >= 3) any3 = 1;
+        start[c + 1] += start[c];
+    }
+    {
+        std::vector<int32_t> fill(start, start + a->ncell);
+        for (int j = 0; j < m; j++) perm[fill[a->cell_of[j]]++] = j;
+    }
+    for (int j = 0; j < m; j++) in3[j] = (start[a->cell_of[j] + 1] - start[a->cell_of[j]]) >= 3;
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    CooksKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = m; kp.p = a->p; kp.ncell = a->ncell; kp.any3 = any3;
+    kp.sortcap = next_pow2(any3 ? maxcell : m);
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    kp.nf_is_vector = a->nf_is_vector ? 1 : 0;
+    if (kp.nf_is_vector) kp.nf = a->nf;
+    else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
+    rc = prep_matrix(a->mu, a->layout, a->ld, a->n, m, WS_MU, st, &kp.mu, ld); if (rc) return rc;
+    rc = prep_matrix(a->H, a->layout, a->ld, a->n, m, WS_W, st, &kp.H, ld); if (rc) return rc;
+    void *v;
+    rc = ws_get(WS_CELLS, meta.size() * sizeof(int32_t) + (size_t)a->n * 8, &v); if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(v, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    kp.perm = (int32_t *)v; kp.in3 = kp.perm + m; kp.cell_start = kp.in3 + m;
+    kp.maxCooks = o->maxCooks;
+    if (o->robustDisp) kp.robustDisp = o->robustDisp;
+    else kp.robustDisp = (double *)((char *)v + ((meta.size() * sizeof(int32_t) + 7) & ~(size_t)7));
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.cooks = o->cooks;
+    else { void *b; rc = ws_get(WS_HAT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc; kp.cooks = (double *)b; }
+    bool ok = true;
+    prof_begin(st);
+    DSQ_HIP(launch_cooks(kp, st, &ok));
+    prof_end(st);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "m=%d samples: a gene row plus its sort buffer exceeds the 160 KiB LDS", m);
+    if (a->layout != DSQ_LAYOUT_GENE_MAJOR) DSQ_HIP(launch_transpose_gm_to_r_f64(kp.cooks, o->cooks, a->n, m, ld, st));
+    return finish_ycheck(ycheck, st);
+}
+
+static int replace_dev_locked(const DsqReplaceArgs *a, const DsqReplaceOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->cooks || !a->replaceable) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (!o->newCounts || !o->replace) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (!(a->trim >= 0.0 && a->trim < 0.5)) return fail(DSQ_ERR_ARG, "trim must be in [0, 0.5)");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    const int m = a->m;
+    ReplaceKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = m; kp.cutoff = a->cooksCutoff; kp.trim = a->trim; kp.sortcap = next_pow2(m);
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    kp.nf_is_vector = a->nf_is_vector ? 1 : 0;
+    if (kp.nf_is_vector) kp.nf = a->nf;
+    else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
+    rc = prep_matrix(a->cooks, a->layout, a->ld, a->n, m, WS_COOKS_IN, st, &kp.cooks, ld); if (rc) return rc;
+    static std::vector<int32_t> flags;
+    flags.assign(a->replaceable, a->replaceable + m);
+    void *v;
+    rc = ws_get(WS_CELLS, (size_t)m * sizeof(int32_t), &v); if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(v, flags.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    kp.replaceable = (int32_t *)v;
+    kp.replace = o->replace;
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.newCounts = o->newCounts;
+    else { void *b; rc = ws_get(WS_HAT, (size_t)a->n * ld * sizeof(int32_t), &b); if (rc) return rc; kp.newCounts = (int32_t *)b; }
+    bool ok = true;
+    prof_begin(st);
+    DSQ_HIP(launch_replace(kp, st, &ok));
+    prof_end(st);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "m=%d samples: the sort buffer exceeds the 160 KiB LDS", m);
+    if (a->layout != DSQ_LAYOUT_GENE_MAJOR) DSQ_HIP(launch_transpose_gm_to_r_i32(kp.newCounts, o->newCounts, a->n, m, ld, st));
+    return finish_ycheck(ycheck, st);
+}
+
 static int up(int slot, const void *host, size_t bytes, hipStream_t st, void **dev) {
     int rc = ws_get(slot, bytes ? bytes : 8, dev);
     if (rc) return rc;
@@ -781,6 +887,74 @@ int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
     rc = loglike_dev_locked(&d, (double *)v, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(loglike, v, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_cooks_distance_dev(const DsqCooksArgs *args, const DsqCooksOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return cooks_dev_locked(args, out, (hipStream_t)stream);
+}
+int dsq_replace_outliers_dev(const DsqReplaceArgs *args, const DsqReplaceOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return replace_dev_locked(args, out, (hipStream_t)stream);
+}
+
+int dsq_cooks_distance(const DsqCooksArgs *a, const DsqCooksOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->mu || !a->H || !a->cell_of) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (!o->cooks || !o->maxCooks) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m;
+    DsqCooksArgs d = *a;
+    DsqCooksOut od = *o;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if ((rc = up(WS_H_MU, a->mu, n * m * 8, st, &v))) return rc; d.mu = (double *)v;
+    if ((rc = up(WS_H_W, a->H, n * m * 8, st, &v))) return rc; d.H = (double *)v;
+    if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc; od.cooks = (double *)v;
+    if ((rc = ws_get(WS_H_OUTVEC, 2 * n * 8, &v))) return rc;
+    od.maxCooks = (double *)v; od.robustDisp = (double *)v + n;
+    rc = cooks_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->cooks, od.cooks, n * m * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->maxCooks, od.maxCooks, n * 8, hipMemcpyDeviceToHost, st));
+    if (o->robustDisp) DSQ_HIP(hipMemcpyAsync(o->robustDisp, od.robustDisp, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->cooks || !a->replaceable) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (!o->newCounts || !o->replace) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m;
+    DsqReplaceArgs d = *a;
+    DsqReplaceOut od = *o;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if ((rc = up(WS_H_MU, a->cooks, n * m * 8, st, &v))) return rc; d.cooks = (double *)v;
+    if ((rc = ws_get(WS_H_OUTMAT, n * m * 4, &v))) return rc; od.newCounts = (int32_t *)v;
+    if ((rc = ws_get(WS_H_OUTVEC, n * 4, &v))) return rc; od.replace = (int32_t *)v;
+    rc = replace_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->newCounts, od.newCounts, n * m * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->replace, od.replace, n * 4, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;
 }

@@ -74,6 +74,36 @@ struct LogLikeKernelParams {
     double *loglike;
 };
 
+struct CooksKernelParams {
+    int n, m, p;
+    long ld;
+    const int32_t *y;
+    const double *nf;
+    int nf_is_vector;
+    const double *mu, *H;        // gene-major
+    const int32_t *perm;         // sample indices grouped by design cell
+    const int32_t *cell_start;   // ncell + 1 offsets into perm
+    const int32_t *in3;          // m flags: sample sits in a cell with >= 3 members
+    int ncell, any3;
+    int sortcap;                 // doubles of sort buffer per wave (power of two)
+    double *cooks, *maxCooks, *robustDisp;
+};
+
+struct ReplaceKernelParams {
+    int n, m;
+    long ld;
+    const int32_t *y;
+    const double *nf;
+    int nf_is_vector;
+    const double *cooks;
+    double cutoff, trim;
+    const int32_t *replaceable;  // m flags
+    int sortcap;
+    int32_t *newCounts, *replace;
+};
+
+hipError_t launch_cooks(const CooksKernelParams &kp, hipStream_t st, bool *ok);
+hipError_t launch_replace(const ReplaceKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st);
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
@@ -101,6 +131,7 @@ hipError_t launch_transpose_r_to_gm_f64(const double *src, double *dst, int n, i
 hipError_t launch_transpose_r_to_gm_i32(const int32_t *src, int32_t *dst, int n, int m, long ld, hipStream_t st);
 hipError_t launch_counts_f64_to_gm_i32(const double *src, int32_t *dst, int n, int m, long ld, int32_t *bad, hipStream_t st);
 hipError_t launch_transpose_gm_to_r_f64(const double *src, double *dst, int n, int m, long ld, hipStream_t st);
+hipError_t launch_transpose_gm_to_r_i32(const int32_t *src, int32_t *dst, int n, int m, long ld, hipStream_t st);
 hipError_t launch_test_math(int op, const double *a, const double *b, const double *c, double *out, long n, hipStream_t st);
 
 int device_cu_count();

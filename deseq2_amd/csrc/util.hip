@@ -48,9 +48,10 @@ __global__ void __launch_bounds__(256) r_to_gm_kernel(const TS *__restrict__ src
 }
 
 // src: row-major ld  ->  dst: column-major n x m
-__global__ void __launch_bounds__(256) gm_to_r_kernel(const double *__restrict__ src, double *__restrict__ dst,
+template <typename T>
+__global__ void __launch_bounds__(256) gm_to_r_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                       int n, int m, long ld) {
-    __shared__ double tile[TILE][TILE + 1];
+    __shared__ T tile[TILE][TILE + 1];
     const int tx = threadIdx.x & 63;
     const int ty = threadIdx.x >> 6;
     const long i0 = (long)blockIdx.x * TILE;
@@ -87,7 +88,11 @@ hipError_t launch_counts_f64_to_gm_i32(const double *src, int32_t *dst, int n, i
     return hipGetLastError();
 }
 hipError_t launch_transpose_gm_to_r_f64(const double *src, double *dst, int n, int m, long ld, hipStream_t st) {
-    hipLaunchKernelGGL(gm_to_r_kernel, tgrid(n, m), dim3(256), 0, st, src, dst, n, m, ld);
+    hipLaunchKernelGGL(gm_to_r_kernel<double>, tgrid(n, m), dim3(256), 0, st, src, dst, n, m, ld);
+    return hipGetLastError();
+}
+hipError_t launch_transpose_gm_to_r_i32(const int32_t *src, int32_t *dst, int n, int m, long ld, hipStream_t st) {
+    hipLaunchKernelGGL(gm_to_r_kernel<int32_t>, tgrid(n, m), dim3(256), 0, st, src, dst, n, m, ld);
     return hipGetLastError();
 }
 

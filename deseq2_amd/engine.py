@@ -46,6 +46,12 @@ class HostEngine:
     def clamp_min(self, h, v):
         return np.maximum(h, v)
 
+    def put_rows(self, h, idx, values):
+        """h[idx, ] <- values (a few rows patched from the host, R/fitNbinomGLMs.R:386)"""
+        h = np.array(h, copy=True)
+        h[np.asarray(idx)] = values
+        return h
+
     def nrow(self, h):
         return h.shape[0]
 
@@ -82,6 +88,21 @@ class HostEngine:
         """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507"""
         from scipy import special as sps
         return 2 * sps.ndtr(-np.abs(z))
+
+    # ---- count outliers (R/core.R:2333-2359, 2069-2115)
+    def cooks_distance(self, y, nf, mu, H, x):
+        """calculateCooksDistance + recordMaxCooks; x = the dispersion model matrix"""
+        return self.fns.cooksDistance(y, nf, mu, H, x)
+
+    def replace_outliers(self, y, nf, cooks, cooksCutoff, replaceable, trim=0.2):
+        """replaceOutliers: new counts handle + per-gene `replace` flag"""
+        r = self.fns.replaceOutliers(y, nf, cooks, cooksCutoff, replaceable, trim)
+        return {"counts": np.ascontiguousarray(r["counts"], dtype=np.int32), "replace": r["replace"]}
+
+    def masked_row_max(self, h, use, zero):
+        """apply(h[, use], 1, max) after h[, zero] <- 0   (refitWithoutOutliers, R/core.R:2542-2545)"""
+        a = np.where(np.asarray(zero, bool)[None, :], 0.0, h)
+        return a[:, np.asarray(use, bool)].max(axis=1)
 
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
@@ -174,6 +195,13 @@ class DeviceEngine:
     def clamp_min(self, h, v):
         return self.native.GeneMajor(self.torch.clamp_min(h.t, v), h.m)
 
+    def put_rows(self, h, idx, values):
+        t = self.torch
+        ii = t.as_tensor(np.asarray(idx), device=self.device)
+        out = h.t.clone()
+        out[ii, : h.m] = t.as_tensor(np.ascontiguousarray(values, dtype=np.float64), device=self.device)
+        return self.native.GeneMajor(out, h.m)
+
     def nrow(self, h):
         return h.n
 
@@ -227,6 +255,26 @@ class DeviceEngine:
         zz = t.as_tensor(np.ascontiguousarray(z), device=self.device)
         # 2*pnorm(-|z|) = erfc(|z|/sqrt(2)): keeps the far tail (ndtr flushes it to 0)
         return t.special.erfc(zz.abs() * 0.7071067811865476).cpu().numpy()
+
+    # ---- count outliers: HIP kernels (csrc/outlier.hip)
+    def cooks_distance(self, y, nf, mu, H, x):
+        cells = self.native.cell_index(x)
+        p = np.asarray(x).shape[1]
+        r = self._timed("cooks_distance", y.n, lambda: self.native.cooksDistance_dev(y, nf, mu, H, cells, p))
+        return {"cooks": r["cooks"], "maxCooks": r["maxCooks"].cpu().numpy(),
+                "robustDisp": r["robustDisp"].cpu().numpy()}
+
+    def replace_outliers(self, y, nf, cooks, cooksCutoff, replaceable, trim=0.2):
+        r = self._timed("replace_outliers", y.n, lambda: self.native.replaceOutliers_dev(
+            y, nf, cooks, cooksCutoff, replaceable, trim))
+        return {"counts": r["counts"], "replace": r["replace"].cpu().numpy().astype(bool)}
+
+    def masked_row_max(self, h, use, zero):
+        t = self.torch
+        z = t.as_tensor(np.asarray(zero, bool), device=self.device)
+        u = t.as_tensor(np.asarray(use, bool), device=self.device)
+        a = t.where(z[None, :], t.zeros((), dtype=t.float64, device=self.device), h.view())
+        return a[:, u].max(dim=1).values.cpu().numpy()      # max is exact: glue, not arithmetic
 
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,

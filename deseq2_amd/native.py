@@ -183,6 +183,45 @@ def nbinomLogLike(counts, mu, disp, weights, useWeights):
     return out
 
 
+def cell_index(x):
+    """design cells (nOrMoreInCell, R/core.R:2366-2371): samples with identical model-matrix rows"""
+    _, inv = np.unique(np.asarray(x, np.float64), axis=0, return_inverse=True)
+    return np.ascontiguousarray(inv.reshape(-1), dtype=np.int32)
+
+
+def cooksDistance(counts, nf, mu, H, x):
+    """calculateCooksDistance + recordMaxCooks (R/core.R:2333-2359) through dsq_cooks_distance;
+    `x` is the dispersion model matrix."""
+    y, ytype = _counts(counts)
+    nf, mu, H = _fcol(nf), _fcol(mu), _fcol(H)
+    n, m = y.shape
+    cells = cell_index(x)
+    ck = np.zeros((n, m), order="F")
+    mx, rd = np.zeros(n), np.zeros(n)
+    args = L.DsqCooksArgs(n=n, m=m, p=np.asarray(x).shape[1], layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype,
+                          nf=_ptr(nf), nf_is_vector=0, mu=_ptr(mu), H=_ptr(H), cell_of=_ptr(cells),
+                          ncell=int(cells.max()) + 1)
+    out = L.DsqCooksOut(cooks=_ptr(ck), maxCooks=_ptr(mx), robustDisp=_ptr(rd))
+    L.check(L.lib().dsq_cooks_distance(C.byref(args), C.byref(out)))
+    return {"cooks": ck, "maxCooks": mx, "robustDisp": rd}
+
+
+def replaceOutliers(counts, nf, cooks, cooksCutoff, replaceable, trim=0.2):
+    """replaceOutliers (R/core.R:2069-2115) through dsq_replace_outliers"""
+    y, ytype = _counts(counts)
+    nf, ck = _fcol(nf), _fcol(cooks)
+    n, m = y.shape
+    rep = np.ascontiguousarray(np.asarray(replaceable).astype(np.int32))
+    newc = np.zeros((n, m), dtype=np.int32, order="F")
+    flag = np.zeros(n, dtype=np.int32)
+    args = L.DsqReplaceArgs(n=n, m=m, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, nf=_ptr(nf),
+                            nf_is_vector=0, cooks=_ptr(ck), cooksCutoff=float(cooksCutoff), trim=float(trim),
+                            replaceable=_ptr(rep))
+    out = L.DsqReplaceOut(newCounts=_ptr(newc), replace=_ptr(flag))
+    L.check(L.lib().dsq_replace_outliers(C.byref(args), C.byref(out)))
+    return {"counts": newc, "replace": flag.astype(bool)}
+
+
 _FIT_ERRORS = {1: "parametric dispersion fit failed", 2: "dispersion fit did not converge"}
 
 
@@ -390,3 +429,38 @@ def parametricDispersionFit_dev(means, disps):
     if st != 0:
         raise RuntimeError(_FIT_ERRORS.get(st, "parametric dispersion fit failed"))
     return h[:2].numpy().copy()
+
+
+def cooksDistance_dev(y, nf, mu, H, cell_of, p, nf_is_vector=False):
+    """y / nf / mu / H GeneMajor; cell_of: host int32 array of design-cell ids.  cooks comes back GeneMajor."""
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    dev = y.t.device
+    cells = np.ascontiguousarray(cell_of, dtype=np.int32)
+    ck = torch.zeros((n, ld), dtype=torch.float64, device=dev)
+    mx = torch.empty(n, dtype=torch.float64, device=dev)
+    rd = torch.empty(n, dtype=torch.float64, device=dev)
+    args = L.DsqCooksArgs(n=n, m=m, p=int(p), layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                          y_type=L.DSQ_Y_INT32, nf=_t_ptr(nf if nf_is_vector else nf.t),
+                          nf_is_vector=int(nf_is_vector), mu=_t_ptr(mu.t), H=_t_ptr(H.t), cell_of=_ptr(cells),
+                          ncell=int(cells.max()) + 1)
+    out = L.DsqCooksOut(cooks=_t_ptr(ck), maxCooks=_t_ptr(mx), robustDisp=_t_ptr(rd))
+    L.check(L.lib().dsq_cooks_distance_dev(C.byref(args), C.byref(out), _stream()))
+    return {"cooks": GeneMajor(ck, m), "maxCooks": mx, "robustDisp": rd}
+
+
+def replaceOutliers_dev(y, nf, cooks, cooksCutoff, replaceable, trim=0.2, nf_is_vector=False):
+    """y / nf / cooks GeneMajor; replaceable: host flags.  The new count matrix comes back GeneMajor int32."""
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    dev = y.t.device
+    rep = np.ascontiguousarray(np.asarray(replaceable).astype(np.int32))
+    newc = torch.zeros((n, ld), dtype=torch.int32, device=dev)
+    flag = torch.empty(n, dtype=torch.int32, device=dev)
+    args = L.DsqReplaceArgs(n=n, m=m, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t), y_type=L.DSQ_Y_INT32,
+                            nf=_t_ptr(nf if nf_is_vector else nf.t), nf_is_vector=int(nf_is_vector),
+                            cooks=_t_ptr(cooks.t), cooksCutoff=float(cooksCutoff), trim=float(trim),
+                            replaceable=_ptr(rep))
+    out = L.DsqReplaceOut(newCounts=_t_ptr(newc), replace=_t_ptr(flag))
+    L.check(L.lib().dsq_replace_outliers_dev(C.byref(args), C.byref(out), _stream()))
+    return {"counts": GeneMajor(newc, m), "replace": flag}

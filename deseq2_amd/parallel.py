@@ -39,7 +39,8 @@ def _allgather_vec(v, device=None):
     return np.concatenate([p[:s].cpu().numpy() for p, s in zip(parts, sizes)])
 
 
-def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_device=None, **kw):
+def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_device=None,
+                  minReplicatesForReplace=7, **kw):
     """`dds` is THIS rank's shard.  R/parallel.R:6-74 (betaPrior = FALSE branch)."""
     # round 1: gene-wise estimates on the shard                                 (:18-20)
     core.estimateDispersionsGeneEst(dds)
@@ -61,6 +62,11 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
         core.nbinomWaldTest(dds, **kw)
     else:
         core.nbinomLRT(dds, reduced, **kw)
+    # outlier replacement + refit (R/core.R:419-426 after the parallel branch): per gene, so per shard;
+    # the refit reads the global dispersion function / prior variance already on the shard
+    if np.isfinite(minReplicatesForReplace) and core.nOrMoreInCell(dds.x, minReplicatesForReplace).any():
+        core.refitWithoutOutliers(dds, test=test, reduced=reduced,
+                                  minReplicatesForReplace=minReplicatesForReplace, **kw)
     return dds
 
 

@@ -228,6 +228,57 @@ int dsq_parametric_dispersion_fit(const double *means, const double *disps, int6
 int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, int64_t n, double *coefs,
                                       int32_t *status, void *stream);
 
+/* dsq_cooks_distance: calculateCooksDistance (R/core.R:2333-2340) with its robust method-of-moments
+ * dispersion (robustMethodOfMomentsDisp :2277-2299, trimmedCellVariance :2301-2324, trimmedVariance
+ * :2326-2331) and recordMaxCooks (:2349-2359), called from nbinomWaldTest (:1457-1460) and nbinomLRT
+ * (:1888-1891).  `cell_of` is ALWAYS a host pointer (m design-cell ids 0..ncell-1: samples with identical
+ * rows of the dispersion model matrix share a cell, nOrMoreInCell :2366-2371); p = ncol of that matrix.
+ * maxCooks is NaN (R: NA) when m <= p or no cell has 3 members.                                      */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *nf;
+    int32_t nf_is_vector;
+    const double *mu;        /* n x m fitted means (assays "mu") */
+    const double *H;         /* n x m hat diagonals (fitBeta's hat_diagonals) */
+    const int32_t *cell_of;  /* m, HOST */
+    int32_t ncell;
+} DsqCooksArgs;
+typedef struct {
+    double *cooks;       /* n x m, layout of the inputs */
+    double *maxCooks;    /* n */
+    double *robustDisp;  /* n (may be NULL) */
+} DsqCooksOut;
+int dsq_cooks_distance(const DsqCooksArgs *args, const DsqCooksOut *out);
+int dsq_cooks_distance_dev(const DsqCooksArgs *args, const DsqCooksOut *out, void *stream);
+
+/* dsq_replace_outliers: replaceOutliers (R/core.R:2069-2115).  newCounts = counts, except where
+ * cooks > cooksCutoff in a `replaceable` sample: there as.integer(trimmed mean (trim) of the normalized
+ * counts * nf).  replace[i] = any(cooks[i,] > cooksCutoff) (:2086).  `replaceable` is a host pointer
+ * (m flags, nOrMoreInCell(modelMatrix, minReplicates)).                                              */
+typedef struct {
+    int32_t n, m;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *nf;
+    int32_t nf_is_vector;
+    const double *cooks;        /* n x m */
+    double cooksCutoff;         /* qf(.99, p, m - p) by default (:2081) */
+    double trim;                /* .2 */
+    const int32_t *replaceable; /* m, HOST */
+} DsqReplaceArgs;
+typedef struct {
+    int32_t *newCounts;  /* n x m int32, layout of the inputs */
+    int32_t *replace;    /* n */
+} DsqReplaceOut;
+int dsq_replace_outliers(const DsqReplaceArgs *args, const DsqReplaceOut *out);
+int dsq_replace_outliers_dev(const DsqReplaceArgs *args, const DsqReplaceOut *out, void *stream);
+
 /* ---- layout helpers (device pointers, async on stream) --------------------------
  * R layout (column-major n x m) <-> gene-major (row-major, leading dimension ld).   */
 int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);

@@ -821,3 +821,118 @@ int orc_parametric_dispersion_fit(long n, const double *means, const double *dis
     free(good);
     return 0;
 }
+
+/* ============================================================ outlier machinery ==
+ * calculateCooksDistance (R/core.R:2333-2340) with robustMethodOfMomentsDisp
+ * (:2277-2299) / trimmedCellVariance (:2301-2324) / trimmedVariance (:2326-2331),
+ * recordMaxCooks (:2349-2359) and replaceOutliers (:2069-2115).
+ *
+ * Cells = groups of identical model-matrix rows; `cell_of[j]` in 0..ncell-1 gives sample j's cell.
+ * R's mean(x, trim): lo = floor(n*trim)+1, hi = n+1-lo, mean of the order statistics lo..hi.
+ * The sum of those order statistics is taken in wave order over the RANK (sorted position),
+ * partial l taking ranks lo-1+l, lo-1+l+64, ...                                               */
+static int cmp_dbl(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+static double trimmed_mean_sorted(const double *sorted, int n, double trim, int sum_mode) {
+    int lo = (int)floor((double)n * trim) + 1, hi = n + 1 - lo;
+    wsum_t s; wsum_init(&s, sum_mode);
+    for (int r = lo; r <= hi; r++) wsum_add(&s, r - lo, sorted[r - 1]);
+    return wsum_total(&s) / (double)(hi - lo + 1);
+}
+static int trimfn(int n) { return n <= 3 ? 0 : (n <= 23 ? 1 : 2); }      /* cut(n, c(0,3.5,23.5,Inf)) */
+
+int orc_cooks_distance(int n, int m, int p, const double *y, const double *nf, const double *mu,
+                       const double *H, const int *cell_of, int ncell,
+                       double *cooks, double *maxCooks, double *robustDisp, int sum_mode) {
+    static const double trimratio[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
+    static const double scale_c[3] = {2.04, 1.86, 1.51};
+    int *csize = calloc(ncell, sizeof(int));
+    for (int j = 0; j < m; j++) csize[cell_of[j]]++;
+    int any3 = 0;
+    for (int c = 0; c < ncell; c++) if (csize[c] >= 3) any3 = 1;
+#pragma omp parallel
+    {
+    double *cn = malloc(sizeof(double) * m), *buf = malloc(sizeof(double) * m);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+        wsum_t sm; wsum_init(&sm, sum_mode);
+        for (int j = 0; j < m; j++) { cn[j] = y[i + (long)n * j] / nf[i + (long)n * j]; wsum_add(&sm, j, cn[j]); }
+        double mean_all = wsum_total(&sm) / (double)m;                        /* rowMeans(cnts) :2293 */
+        double v;
+        if (any3) {                                                          /* trimmedCellVariance */
+            v = -INFINITY;
+            for (int c = 0; c < ncell; c++) {
+                int nc = csize[c];
+                if (nc < 3) continue;
+                int tf = trimfn(nc), k = 0;
+                for (int j = 0; j < m; j++) if (cell_of[j] == c) buf[k++] = cn[j];
+                qsort(buf, nc, sizeof(double), cmp_dbl);
+                double cm = trimmed_mean_sorted(buf, nc, trimratio[tf], sum_mode);       /* :2305-2309 */
+                k = 0;
+                for (int j = 0; j < m; j++) if (cell_of[j] == c) { double d = cn[j] - cm; buf[k++] = d * d; }
+                qsort(buf, nc, sizeof(double), cmp_dbl);
+                double ve = scale_c[tf] * trimmed_mean_sorted(buf, nc, trimratio[tf], sum_mode);   /* :2313-2319 */
+                if (ve > v) v = ve;                                          /* rowMax :2322 */
+            }
+        } else {                                                             /* trimmedVariance :2326 */
+            memcpy(buf, cn, sizeof(double) * m);
+            qsort(buf, m, sizeof(double), cmp_dbl);
+            double rm = trimmed_mean_sorted(buf, m, 1.0 / 8.0, sum_mode);
+            for (int j = 0; j < m; j++) { double d = cn[j] - rm; buf[j] = d * d; }
+            qsort(buf, m, sizeof(double), cmp_dbl);
+            v = 1.51 * trimmed_mean_sorted(buf, m, 1.0 / 8.0, sum_mode);
+        }
+        double alpha = (v - mean_all) / (mean_all * mean_all);               /* :2294 */
+        alpha = fmax(alpha, 0.04);                                           /* :2297-2298 */
+        robustDisp[i] = alpha;
+        double mx = -INFINITY; int anyc = 0;
+        for (int j = 0; j < m; j++) {
+            double mj = mu[i + (long)n * j], hj = H[i + (long)n * j], yj = y[i + (long)n * j];
+            double V = mj + alpha * (mj * mj);                                /* :2336 */
+            double d = yj - mj;
+            double pr = (d * d) / V;                                         /* :2337 */
+            double omh = 1.0 - hj;
+            double ck = pr / (double)p * hj / (omh * omh);                   /* :2338 */
+            cooks[i + (long)n * j] = ck;
+            if (csize[cell_of[j]] >= 3) { anyc = 1; if (ck > mx || ck != ck) mx = (ck != ck) ? ck : (mx != mx ? mx : ck); }
+        }
+        maxCooks[i] = (m > p && anyc) ? mx : NAN;                            /* :2353-2357 */
+    }
+    free(cn); free(buf);
+    }
+    free(csize);
+    return 0;
+}
+
+/* replaceOutliers, R/core.R:2069-2115: counts with a Cook's distance above the cutoff are
+ * replaced by as.integer(trimmed mean (trim = .2) of the normalized counts * nf) in the samples
+ * whose cell has >= minReplicates members; `replace` flags genes with ANY distance above it. */
+int orc_replace_outliers(int n, int m, const double *y, const double *nf, const double *cooks,
+                         double cooksCutoff, const int *replaceable, double trim,
+                         int *newCounts, int *replace, int sum_mode) {
+#pragma omp parallel
+    {
+    double *buf = malloc(sizeof(double) * m);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+        int any = 0;
+        for (int j = 0; j < m; j++) {
+            buf[j] = y[i + (long)n * j] / nf[i + (long)n * j];
+            if (cooks[i + (long)n * j] > cooksCutoff) any = 1;
+        }
+        replace[i] = any;                                                    /* :2086 */
+        qsort(buf, m, sizeof(double), cmp_dbl);
+        double tbm = trimmed_mean_sorted(buf, m, trim, sum_mode);            /* :2088 */
+        for (int j = 0; j < m; j++) {
+            int orig = (int)y[i + (long)n * j];
+            int rep = (int)(tbm * nf[i + (long)n * j]);                      /* as.integer: truncation, :2090-2095 */
+            newCounts[i + (long)n * j] =
+                (cooks[i + (long)n * j] > cooksCutoff && replaceable[j]) ? rep : orig;   /* :2098-2112 */
+        }
+    }
+    free(buf);
+    }
+    return 0;
+}

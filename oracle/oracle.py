@@ -210,3 +210,32 @@ def parametricDispersionFit(means, disps):
     if st.value == 2:
         raise RuntimeError("dispersion fit did not converge")
     return coefs
+
+
+def cell_index(x):
+    """cells of identical model-matrix rows (nOrMoreInCell, R/core.R:2366-2371): cell id per sample"""
+    _, inv = np.unique(np.asarray(x, np.float64), axis=0, return_inverse=True)
+    return np.ascontiguousarray(inv.reshape(-1), dtype=np.int32)
+
+
+def cooksDistance(counts, nf, mu, H, x, sum_mode=0):
+    """calculateCooksDistance + robustMethodOfMomentsDisp + recordMaxCooks (R/core.R:2333-2359, 2277-2331)"""
+    y = _f(counts); nf = _f(nf); mu = _f(mu); H = _f(H)
+    n, m = y.shape
+    p = np.asarray(x).shape[1]
+    cells = cell_index(x)
+    ck = np.zeros((n, m), order="F"); mx = np.zeros(n); rd = np.zeros(n)
+    lib().orc_cooks_distance(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(nf), _p(mu), _p(H),
+                             _p(cells), ctypes.c_int(int(cells.max()) + 1), _p(ck), _p(mx), _p(rd), ctypes.c_int(sum_mode))
+    return {"cooks": ck, "maxCooks": mx, "robustDisp": rd}
+
+
+def replaceOutliers(counts, nf, cooks, cooksCutoff, replaceable, trim=0.2, sum_mode=0):
+    """replaceOutliers (R/core.R:2069-2115): new count matrix and the per-gene `replace` flag"""
+    y = _f(counts); nf = _f(nf); ck = _f(cooks)
+    n, m = y.shape
+    rep = np.ascontiguousarray(np.asarray(replaceable).astype(np.int32))
+    newc = np.zeros((n, m), dtype=np.int32, order="F"); flag = np.zeros(n, dtype=np.int32)
+    lib().orc_replace_outliers(ctypes.c_int(n), ctypes.c_int(m), _p(y), _p(nf), _p(ck), ctypes.c_double(float(cooksCutoff)),
+                               _p(rep), ctypes.c_double(float(trim)), _p(newc), _p(flag), ctypes.c_int(sum_mode))
+    return {"counts": newc, "replace": flag.astype(bool)}
