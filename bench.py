@@ -171,8 +171,16 @@ def main():
         per = {}
         for name, ng, ms in rec:
             per.setdefault(name, []).append((ng, ms))
-        kern = {k: {"launches": len(v), "avg_ms": float(np.mean([t for _, t in v])),
-                    "genes_per_launch": float(np.mean([g for g, _ in v]))} for k, v in per.items()}
+        def summary(sel):
+            out = {}
+            for k, v in per.items():
+                v = [(g, t) for g, t in v if sel(g)]
+                if v:
+                    out[k] = {"launches": len(v), "avg_ms": float(np.mean([t for _, t in v])),
+                              "genes_per_launch": float(np.mean([g for g, _ in v]))}
+            return out
+        kern = summary(lambda g: g >= n // 2)                 # the full-size launches of the chain
+        kern_refit = summary(lambda g: g < n // 2)            # refitWithoutOutliers: the replaced rows only
         # the two full-size kernels; dominant = larger share of the step
         share = {k: sum(t for _, t in per[k]) for k in per}
         dom = max(("fit_beta", "fit_disp"), key=lambda k: share.get(k, 0.0))
@@ -221,6 +229,7 @@ def main():
                        "genes_per_gpu": n, "samples": m, "p": p, "parallelism": "gene-shard x%d" % world},
             "roofline": roofline,
             "kernels": kern,
+            "kernels_outlier_refit": kern_refit,
             "mean_iterations": {"fitBeta_final": it_beta, "fitDisp_MAP": it_disp,
                                 "fitDisp_geneEst": float(np.mean(dds.mcols["dispGeneIter"]))},
         }
