@@ -241,22 +241,57 @@ def main():
         dist.destroy_process_group()
 
 
+class _ReferenceFns:
+    """fns module for HostEngine: the three native routines from the REFERENCE's own src/DESeq2.cpp
+    (oracle/_ref/libdeseq2_ref_fast.so: compiled against the stand-in headers of oracle/shim/, special
+    functions in plain double), everything the reference does in R around them from the C oracle."""
+
+    def __init__(self, R, O):
+        self.R, self.O = R, O
+        for name in ("prefitMoments", "nbinomLogLike", "parametricDispersionFit", "cooksDistance", "replaceOutliers",
+                     "design_qr"):
+            setattr(self, name, getattr(O, name))
+        self.fitDisp, self.fitDispGrid = R.fitDisp, R.fitDispGrid
+
+    def fitBeta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu,
+                want_mu=False, mu_floor=0.0, want_hat=True):
+        r = self.R.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu)
+        if want_mu:
+            r["mu"] = self.O.fittedMu(x, nf, r["beta_mat"], mu_floor)
+        return r
+
+
 def cpu_baseline(counts, sf, x, k):
-    """The CPU oracle (plain-C restatement of src/DESeq2.cpp, 1 thread like the reference) timed
-    on the first k genes of the same workload through the same host code."""
+    """CPU baseline, 1 thread like the reference, on the first k genes of the same workload through the
+    same host code: kind "reference" = the reference's own C++ source for fitBeta/fitDisp/fitDispGrid
+    (when the prebuilt oracle/_ref library is present), else kind "port" = the C oracle."""
     from deseq2_amd import core
     from deseq2_amd.engine import HostEngine
     from oracle import oracle as O
     O.set_threads(1)
     sub = counts[:k]
     sub = sub[sub.sum(axis=1) > 0]
-    t0 = time.perf_counter()
-    dds = core.DESeqDataSet(sub, x, sizeFactors=sf, engine=HostEngine(O))
-    core.DESeq(dds)
-    dt = time.perf_counter() - t0
-    return {"value": sub.shape[0] / dt, "unit": "genes/s", "cores": 1, "kind": "port",
-            "sample": "first %d genes of the same %d-sample matrix, full DESeq() chain over the C oracle, %.1f s"
-                      % (sub.shape[0], counts.shape[1], dt)}
+
+    def run(fns):
+        t0 = time.perf_counter()
+        core.DESeq(core.DESeqDataSet(sub, x, sizeFactors=sf, engine=HostEngine(fns)))
+        return time.perf_counter() - t0
+    dt_port = run(O)
+    out = {"value": sub.shape[0] / dt_port, "unit": "genes/s", "cores": 1, "kind": "port",
+           "sample": "first %d genes of the same %d-sample matrix, full DESeq() chain over the C oracle, %.1f s"
+                     % (sub.shape[0], counts.shape[1], dt_port)}
+    try:
+        from oracle import reference as R
+        R.use_fast(True)
+        dt_ref = run(_ReferenceFns(R, O))
+        out = {"value": sub.shape[0] / dt_ref, "unit": "genes/s", "cores": 1, "kind": "reference",
+               "sample": "first %d genes of the same %d-sample matrix, full DESeq() chain; fitBeta/fitDisp/fitDispGrid "
+                         "= the reference's src/DESeq2.cpp compiled against stand-in Rcpp/Armadillo headers (libm "
+                         "special functions), the R-side steps in C, %.1f s" % (sub.shape[0], counts.shape[1], dt_ref),
+               "port_value": sub.shape[0] / dt_port}
+    except (OSError, ImportError):
+        pass
+    return out
 
 
 if __name__ == "__main__":

@@ -139,10 +139,87 @@ SEXP _DESeq2_fitDispGrid(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP disp_grid
     return out;
 }
 
+/* ---- optional extension entry points: not part of the reference's .Call table; the R-side
+ * one-liners that would call them are in INTEGRATION.md section 3 ------------------------------------ */
+
+/* nbinomLogLike(counts, mu, disp, weights, useWeights)   R/core.R:2208-2217 */
+SEXP _DESeq2_mi355x_nbinomLogLike(SEXP ySEXP, SEXP muSEXP, SEXP dispSEXP, SEXP weightsSEXP, SEXP useWeightsSEXP) {
+    int np = 0;
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP);
+    SEXP mu = as_real(muSEXP, &np), disp = as_real(dispSEXP, &np), w = as_real(weightsSEXP, &np);
+    if (Rf_length(disp) != n) Rf_error("disp must have one value per row");
+    DsqLogLikeArgs a = {0};
+    a.n = n; a.m = m; a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.mu = REAL(mu); a.disp = REAL(disp); a.weights = REAL(w); a.useWeights = scalar_b(useWeightsSEXP);
+    SEXP ll = PROTECT(Rf_allocVector(REALSXP, n)); np++;
+    chk(dsq_nbinom_loglike(&a, REAL(ll)));
+    UNPROTECT(np);
+    return ll;
+}
+
+/* calculateCooksDistance + recordMaxCooks   R/core.R:2333-2359; `cells` = 0-based design-cell id per sample
+ * (match(rows of the dispersion model matrix, unique rows) - 1L), p = ncol(modelMatrix) */
+SEXP _DESeq2_mi355x_cooks(SEXP ySEXP, SEXP nfSEXP, SEXP muSEXP, SEXP hSEXP, SEXP cellsSEXP, SEXP pSEXP) {
+    int np = 0;
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP);
+    SEXP nf = as_real(nfSEXP, &np), mu = as_real(muSEXP, &np), h = as_real(hSEXP, &np);
+    SEXP cells = PROTECT(Rf_coerceVector(cellsSEXP, INTSXP)); np++;
+    if (Rf_length(cells) != m) Rf_error("cells must have one entry per sample");
+    int ncell = 0;
+    for (int j = 0; j < m; j++) if (INTEGER(cells)[j] + 1 > ncell) ncell = INTEGER(cells)[j] + 1;
+    DsqCooksArgs a = {0};
+    a.n = n; a.m = m; a.p = scalar_i(pSEXP); a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.nf = REAL(nf); a.nf_is_vector = (Rf_length(nf) == m && n != 1);
+    a.mu = REAL(mu); a.H = REAL(h); a.cell_of = INTEGER(cells); a.ncell = ncell;
+    SEXP ck = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++;
+    SEXP mx = PROTECT(Rf_allocVector(REALSXP, n)); np++;
+    DsqCooksOut o = {0};
+    o.cooks = REAL(ck); o.maxCooks = REAL(mx);
+    chk(dsq_cooks_distance(&a, &o));
+    for (int i = 0; i < n; i++) if (ISNAN(REAL(mx)[i])) REAL(mx)[i] = NA_REAL;      /* rep(NA, numRow) :2356 */
+    const char *names[] = {"cooks", "maxCooks"};
+    SEXP vals[] = {ck, mx};
+    SEXP out = named_list(2, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
+/* replaceOutliers' count replacement   R/core.R:2083-2112 */
+SEXP _DESeq2_mi355x_replace(SEXP ySEXP, SEXP nfSEXP, SEXP cooksSEXP, SEXP cutoffSEXP, SEXP trimSEXP,
+                            SEXP replaceableSEXP) {
+    int np = 0;
+    int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP);
+    SEXP nf = as_real(nfSEXP, &np), ck = as_real(cooksSEXP, &np);
+    SEXP rep = PROTECT(Rf_coerceVector(replaceableSEXP, LGLSXP)); np++;
+    if (Rf_length(rep) != m) Rf_error("replaceable must have one entry per sample");
+    int *flags = (int *)R_alloc(m, sizeof(int));
+    for (int j = 0; j < m; j++) flags[j] = LOGICAL(rep)[j] == TRUE;
+    DsqReplaceArgs a = {0};
+    a.n = n; a.m = m; a.layout = DSQ_LAYOUT_R;
+    a.y = counts_ptr(ySEXP, &a.y_type);
+    a.nf = REAL(nf); a.nf_is_vector = (Rf_length(nf) == m && n != 1);
+    a.cooks = REAL(ck); a.cooksCutoff = scalar_d(cutoffSEXP); a.trim = scalar_d(trimSEXP); a.replaceable = flags;
+    SEXP newc = PROTECT(Rf_allocMatrix(INTSXP, n, m)); np++;
+    SEXP flag = PROTECT(Rf_allocVector(LGLSXP, n)); np++;
+    DsqReplaceOut o = {0};
+    o.newCounts = INTEGER(newc); o.replace = LOGICAL(flag);
+    chk(dsq_replace_outliers(&a, &o));
+    const char *names[] = {"counts", "replace"};
+    SEXP vals[] = {newc, flag};
+    SEXP out = named_list(2, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_fitDisp", (DL_FUNC)&_DESeq2_fitDisp, 15},
     {"_DESeq2_fitBeta", (DL_FUNC)&_DESeq2_fitBeta, 13},
     {"_DESeq2_fitDispGrid", (DL_FUNC)&_DESeq2_fitDispGrid, 11},
+    {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
+    {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
+    {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

@@ -140,6 +140,16 @@ def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lam
     return out
 
 
+def fittedMu(xSEXP, nfSEXP, beta_mat, mu_floor=0.0):
+    """mu = max(nf * exp(x beta), mu_floor) with the oracle's exp (R/fitNbinomGLMs.R:180, R/core.R:763)"""
+    x = _f(xSEXP); nf = _f(nfSEXP); b = _f(beta_mat)
+    n, m = nf.shape
+    mu = np.zeros((n, m), order="F")
+    lib().orc_fitted_mu(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(x.shape[1]), _p(x), _p(nf), _p(b),
+                        ctypes.c_double(float(mu_floor)), _p(mu))
+    return mu
+
+
 def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEXP,
                 log_alpha_prior_sigmasqSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP,
                 weightThresholdSEXP, useCRSEXP, sum_mode=0):

@@ -15,8 +15,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_ref", "libdeseq2_ref.so")
+_SO_FAST = os.path.join(_HERE, "_ref", "libdeseq2_ref_fast.so")   # special functions in double: timing only
 _REF_SRC = "/root/reference/src/DESeq2.cpp"
 _lib = None
+_fast = False
 
 
 def build():
@@ -30,12 +32,20 @@ def available():
     return os.path.exists(_SO) or (os.path.exists(_REF_SRC) and build() is not None)
 
 
+def use_fast(flag=True):
+    """switch to the timing build (bench.py's cpu_baseline); parity tests use the binary128 build"""
+    global _lib, _fast
+    if flag and not os.path.exists(_SO_FAST):
+        raise FileNotFoundError(_SO_FAST)
+    _fast, _lib = bool(flag), None
+
+
 def lib():
     global _lib
     if _lib is None:
         if not available():
             raise FileNotFoundError(_SO)
-        _lib = ctypes.CDLL(_SO)
+        _lib = ctypes.CDLL(_SO_FAST if _fast else _SO)
     return _lib
 
 

@@ -22,6 +22,28 @@ inline double R_pow_di(double x, int n) {       /* R's arithmetic.c: repeated sq
     return xn;
 }
 
+#ifdef SHIM_DOUBLE_MATH
+/* timing build (oracle/_ref/libdeseq2_ref_fast.so, bench.py's cpu_baseline): the same five entry points in
+ * plain double via libm, so the CPU baseline is not slowed down by binary128 emulation.  Not used for parity. */
+inline double Rf_lgammafn(double x) { return std::lgamma(x); }
+inline double Rf_digamma(double x) {
+    double acc = 0.0;
+    while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
+    double i = 1.0 / x, i2 = i * i;
+    return acc + std::log(x) - 0.5 * i - i2 * (1.0 / 12 - i2 * (1.0 / 120 - i2 * (1.0 / 252 - i2 * (1.0 / 240 - i2 * (1.0 / 132)))));
+}
+inline double Rf_trigamma(double x) {
+    double acc = 0.0;
+    while (x < 10.0) { acc += 1.0 / (x * x); x += 1.0; }
+    double i = 1.0 / x, i2 = i * i;
+    return acc + i + 0.5 * i2 + i * i2 * (1.0 / 6 - i2 * (1.0 / 30 - i2 * (1.0 / 42 - i2 * (1.0 / 30 - i2 * (5.0 / 66)))));
+}
+inline double Rf_dnbinom_mu(double x, double size, double mu, int give_log) {
+    double lp = std::lgamma(x + size) - std::lgamma(size) - std::lgamma(x + 1.0) - size * std::log1p(mu / size);
+    if (x > 0) lp += x * (std::log(mu) - std::log(size + mu));
+    return give_log ? lp : std::exp(lp);
+}
+#else
 inline double Rf_lgammafn(double x) { return (double)lgammaq((__float128)x); }
 
 /* digamma / trigamma for x > 0: shift up to x >= 40, then the asymptotic series */
@@ -57,3 +79,4 @@ inline double Rf_dnbinom_mu(double x, double size, double mu, int give_log) {
     double r = (double)lp;
     return give_log ? r : std::exp(r);
 }
+#endif
