@@ -45,7 +45,7 @@ const Tuning &tuning() {
                        env_int("DSQ_BETA_LDS_KB", 160),
                        env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
                        env_int("DSQ_DISP_LDS_KB", 160), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
-                       env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1)};
+                       env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1), env_int("DSQ_DYNAMIC", 1)};
     return t;
 }
 
@@ -99,7 +99,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
 }
 
 enum {  // workspace slots
-    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN,
+    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER,
     // host-entry staging
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
@@ -160,6 +160,18 @@ static int prep_matrix(const double *src, int layout, long ld_in, int n, int m, 
     if (rc) return rc;
     DSQ_HIP(launch_transpose_r_to_gm_f64(src, (double *)buf, n, m, ld_expected, st));
     *out = (const double *)buf;
+    return DSQ_OK;
+}
+
+// zeroed counters for the dynamic gene scheduling of the persistent fit kernels (dsq_wave.hpp next_gene)
+static int work_counter(hipStream_t st, int **out) {
+    *out = nullptr;
+    if (!tuning().dynamic) return DSQ_OK;
+    void *v;
+    int rc = ws_get(WS_COUNTER, 4 * sizeof(int), &v);
+    if (rc) return rc;
+    DSQ_HIP(hipMemsetAsync(v, 0, 4 * sizeof(int), st));
+    *out = (int *)v;
     return DSQ_OK;
 }
 
@@ -225,6 +237,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     kp.tol = a->tol; kp.minmu = a->minmu; kp.mu_floor = o->mu_floor;
     kp.maxit = a->maxit; kp.useQR = a->useQR ? 1 : 0; kp.useWeights = a->useWeights ? 1 : 0;
     kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
+    rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
     // n x m outputs: directly when gene-major, through a workspace when R layout
@@ -328,6 +341,7 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.kappa_0 = a->kappa_0; kp.tol = a->tol; kp.weightThreshold = a->weightThreshold;
     kp.maxit = a->maxit; kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
     kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
+    rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     kp.log_alpha = o->log_alpha; kp.iter = o->iter; kp.iter_accept = o->iter_accept;
     kp.last_change = o->last_change; kp.initial_lp = o->initial_lp; kp.initial_dlp = o->initial_dlp;
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
@@ -353,6 +367,7 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     kp.weightThreshold = a->weightThreshold;
     kp.usePrior = a->usePrior ? 1 : 0; kp.useCR = a->useCR ? 1 : 0;
     kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = o->log_alpha;
+    rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     bool ok = false;
     prof_begin(st);
     DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));

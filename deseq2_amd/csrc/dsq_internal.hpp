@@ -26,6 +26,7 @@ struct DispKernelParams {
     int ngrid;
     int ablate, force_iters; // profiling only
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
+    int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
 };
 
 struct BetaKernelParams {
@@ -48,6 +49,7 @@ struct BetaKernelParams {
     double *cscratch;       // per-wave-slot scratch for the hoisted NB-density constants (3 m doubles)
     int ablate, force_iters; // profiling only (env DSQ_ABLATE / DSQ_FORCE_ITERS): skip phases / fixed trip count
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
+    int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
 };
 
 struct PrefitKernelParams {
@@ -124,6 +126,7 @@ struct Tuning {
     int disp_waves, disp_stage, disp_bpc, disp_lds_kb;
     int ablate, force_iters;
     int disp_xlds, beta_xlds;
+    int dynamic;             // DSQ_DYNAMIC (default 1): dynamic gene scheduling in the fit kernels
 };
 const Tuning &tuning();
 

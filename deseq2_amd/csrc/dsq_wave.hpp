@@ -31,6 +31,17 @@ DSQ_DEV void wave_allreduce_n(double (&v)[N]) {
 
 DSQ_DEV double wave_bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
+// Gene scheduling of the persistent fit kernels.  Every wave starts on gene (block * waves + wave); the
+// iteration counts of the fits are data dependent (2..100), so instead of a fixed grid stride the wave
+// draws its next gene from a global counter (one relaxed atomic per gene, by lane 0).  Genes are
+// independent, so the order does not touch the results.
+DSQ_DEV int next_gene(int *counter, int g, int stride, int lane) {
+    if (counter == nullptr) return g + stride;
+    int nx = 0;
+    if (lane == 0) nx = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(nx) + stride;
+}
+
 // wave-uniform predicate -> scalar branch
 DSQ_DEV bool uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
 

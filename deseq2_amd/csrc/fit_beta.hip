@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
 
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g = next_gene(kp.work_counter, g, gridDim.x * waves, lane)) {
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         }
     }
 
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g = next_gene(kp.work_counter, g, gridDim.x * waves, lane)) {
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *mug = kp.mu_hat + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -459,6 +459,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
     DispKernelParams kq = kp;
     kq.xlds = xlds;
+    if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
     static int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
     static size_t lds_cache[2][8];

@@ -214,8 +214,10 @@ class DeviceEngine:
         dr = t.as_tensor(np.ascontiguousarray(r.T), device=self.device)
         o = self._timed("prefit_moments", y.n, lambda: self.native.prefitMoments_dev(
             y, nf, dq, da, dr, weights, weights is not None))
-        return {"baseMean": o["baseMean"].cpu().numpy(), "baseVar": o["baseVar"].cpu().numpy(),
-                "allZero": o["allZero"].cpu().numpy().astype(bool), "roughDisp": o["roughDisp"].cpu().numpy(),
+        h = o["_pack"].cpu()                        # one copy for the four n-vectors
+        n = y.n
+        return {"baseMean": h[0].numpy(), "baseVar": h[1].numpy(),
+                "allZero": h[3].view(t.int32)[:n].numpy().astype(bool), "roughDisp": h[2].numpy(),
                 "beta_init": o["beta_init"]}        # (p, n) device tensor, consumed by fit_beta in place
 
     def xim(self, nf):
@@ -261,8 +263,8 @@ class DeviceEngine:
         cells = self.native.cell_index(x)
         p = np.asarray(x).shape[1]
         r = self._timed("cooks_distance", y.n, lambda: self.native.cooksDistance_dev(y, nf, mu, H, cells, p))
-        return {"cooks": r["cooks"], "maxCooks": r["maxCooks"].cpu().numpy(),
-                "robustDisp": r["robustDisp"].cpu().numpy()}
+        h = r["_pack"].cpu().numpy()
+        return {"cooks": r["cooks"], "maxCooks": h[0], "robustDisp": h[1]}
 
     def replace_outliers(self, y, nf, cooks, cooksCutoff, replaceable, trim=0.2):
         r = self._timed("replace_outliers", y.n, lambda: self.native.replaceOutliers_dev(
@@ -281,26 +283,34 @@ class DeviceEngine:
                  minmu, want_mu=True, mu_floor=0.0, want_hat=True):
         t = self.torch
         b0 = beta_mat if t.is_tensor(beta_mat) else self._vec(np.asarray(beta_mat).T)
-        av, cv, lv = self._vec(alpha_hat), self._vec(contrast), self._vec(lam)
+        n, pp = y.n, len(lam)
+        dv = self._vec(np.concatenate([np.broadcast_to(np.asarray(alpha_hat, float), (n,)), contrast, lam]))   # one upload
+        av, cv, lv = dv[:n], dv[n:n + pp], dv[n + pp:]
         r = self._timed("fit_beta", y.n, lambda: self.native.fitBeta_dev(
             y, x, nf, av, cv, b0, lv, weights, useWeights, tol, maxit, useQR, minmu, want_hat=want_hat,
             want_mu=want_mu, mu_floor=mu_floor))
-        out = {"beta_mat": r["beta_mat"].t().cpu().numpy(), "beta_var_mat": r["beta_var_mat"].t().cpu().numpy(),
-               "iter": r["iter"].cpu().numpy(), "deviance": r["deviance"].cpu().numpy(),
-               "contrast_num": r["contrast_num"].cpu().numpy().reshape(-1, 1),
-               "contrast_denom": r["contrast_denom"].cpu().numpy().reshape(-1, 1),
-               "hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}
+        h = r["_pack"].cpu().numpy()               # one device-to-host copy for all per-gene outputs
+        p = (h.shape[0] - 4) // 2
+        out = {"beta_mat": np.ascontiguousarray(h[:p].T), "beta_var_mat": np.ascontiguousarray(h[p:2 * p].T),
+               "iter": h[2 * p], "deviance": h[2 * p + 3], "contrast_num": h[2 * p + 1].reshape(-1, 1),
+               "contrast_denom": h[2 * p + 2].reshape(-1, 1), "hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}
         return out
 
     def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
                  usePrior, weights, useWeights, weightThreshold, useCR):
         n = y.n
-        la = self._vec(np.broadcast_to(np.asarray(log_alpha, float), (n,)))
-        pm = self._vec(np.broadcast_to(np.asarray(prior_mean, float), (n,)))
+        dv = self._vec(np.concatenate([np.broadcast_to(np.asarray(log_alpha, float), (n,)),
+                                       np.broadcast_to(np.asarray(prior_mean, float), (n,))]))    # one upload
+        la, pm = dv[:n], dv[n:]
         r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
             y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
             weightThreshold, useCR, want_d2lp=self.want_d2lp))
-        return {k: v.cpu().numpy() for k, v in r.items()}
+        h = r.pop("_pack").cpu()                   # one copy; the views below index the host buffer
+        keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
+        out = {k: h[i].numpy() for i, k in enumerate(keys) if k in r}
+        ints = h[len(keys)].view(self.torch.int32)
+        out["iter"], out["iter_accept"] = ints[:n].numpy(), ints[n:].numpy()
+        return out
 
     def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,
                       weightThreshold, useCR):

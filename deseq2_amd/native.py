@@ -289,9 +289,10 @@ def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWe
     p = x.shape[0]
     dev = y.t.device
     f64 = dict(dtype=torch.float64, device=dev)
-    out = {"beta_mat": torch.empty((p, n), **f64), "beta_var_mat": torch.empty((p, n), **f64),
-           "iter": torch.empty(n, **f64), "contrast_num": torch.empty(n, **f64),
-           "contrast_denom": torch.empty(n, **f64), "deviance": torch.empty(n, **f64)}
+    # all per-gene outputs live in ONE buffer so the caller brings them to the host with one copy
+    pack = torch.empty((2 * p + 4, n), **f64)
+    out = {"beta_mat": pack[:p], "beta_var_mat": pack[p:2 * p], "iter": pack[2 * p], "contrast_num": pack[2 * p + 1],
+           "contrast_denom": pack[2 * p + 2], "deviance": pack[2 * p + 3]}
     hat = GeneMajor(torch.empty((n, ld), **f64), m) if want_hat else None
     mu = GeneMajor(torch.empty((n, ld), **f64), m) if want_mu else None
     if nf_is_vector:
@@ -315,6 +316,7 @@ def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWe
     L.check(L.lib().dsq_fit_beta_dev(C.byref(a), C.byref(o), _stream()))
     out["hat_diagonals"] = hat
     out["mu"] = mu
+    out["_pack"] = pack
     return out
 
 
@@ -326,11 +328,13 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
     p = x.shape[0]
     dev = y.t.device
     f64 = dict(dtype=torch.float64, device=dev)
-    out = {k: torch.empty(n, **f64) for k in ("log_alpha", "last_change", "initial_lp", "initial_dlp",
-                                               "last_lp", "last_dlp")}
-    out["last_d2lp"] = torch.empty(n, **f64) if want_d2lp else None
-    out["iter"] = torch.empty(n, dtype=torch.int32, device=dev)
-    out["iter_accept"] = torch.empty(n, dtype=torch.int32, device=dev)
+    keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
+    pack = torch.empty((len(keys) + 1, n), **f64)       # one buffer, one device-to-host copy for the caller
+    out = {k: pack[i] for i, k in enumerate(keys)}
+    if not want_d2lp:
+        out["last_d2lp"] = None
+    ints = pack[len(keys)].view(torch.int32)            # the last row holds the two int32 counters
+    out["iter"], out["iter_accept"] = ints[:n], ints[n:]
     a = L.DsqFitDispArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
                          y_type=L.DSQ_Y_INT32, x=_t_ptr(x), mu_hat=_t_ptr(mu_hat.t), log_alpha=_t_ptr(log_alpha),
                          log_alpha_prior_mean=_t_ptr(log_alpha_prior_mean),
@@ -341,7 +345,9 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
                          weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
     o = L.DsqFitDispOut(**{k: _t_ptr(v) for k, v in out.items()})
     L.check(L.lib().dsq_fit_disp_dev(C.byref(a), C.byref(o), _stream()))
-    return {k: v for k, v in out.items() if v is not None}
+    out = {k: v for k, v in out.items() if v is not None}
+    out["_pack"] = pack
+    return out
 
 
 def fitDispGrid_dev(y, x, mu_hat, disp_grid, log_alpha_prior_mean, log_alpha_prior_sigmasq, usePrior, weights,
@@ -395,8 +401,8 @@ def prefitMoments_dev(y, nf, q, a, r, weights=None, useWeights=False, nf_is_vect
     p = q.shape[0]
     dev = y.t.device
     f64 = dict(dtype=torch.float64, device=dev)
-    out = {"baseMean": torch.empty(n, **f64), "baseVar": torch.empty(n, **f64),
-           "allZero": torch.empty(n, dtype=torch.int32, device=dev), "roughDisp": torch.empty(n, **f64),
+    pack = torch.empty((4, n), **f64)
+    out = {"baseMean": pack[0], "baseVar": pack[1], "allZero": pack[3].view(torch.int32)[:n], "roughDisp": pack[2],
            "beta_init": torch.empty((p, n), **f64)}
     args = L.DsqPrefitArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
                            y_type=L.DSQ_Y_INT32, nf=_t_ptr(nf if nf_is_vector else nf.t),
@@ -404,6 +410,7 @@ def prefitMoments_dev(y, nf, q, a, r, weights=None, useWeights=False, nf_is_vect
                            useWeights=int(bool(useWeights)), q=_t_ptr(q), a=_t_ptr(a), r=_t_ptr(r))
     o = L.DsqPrefitOut(**{k: _t_ptr(v) for k, v in out.items()})
     L.check(L.lib().dsq_prefit_moments_dev(C.byref(args), C.byref(o), _stream()))
+    out["_pack"] = pack
     return out
 
 
@@ -438,15 +445,15 @@ def cooksDistance_dev(y, nf, mu, H, cell_of, p, nf_is_vector=False):
     dev = y.t.device
     cells = np.ascontiguousarray(cell_of, dtype=np.int32)
     ck = torch.zeros((n, ld), dtype=torch.float64, device=dev)
-    mx = torch.empty(n, dtype=torch.float64, device=dev)
-    rd = torch.empty(n, dtype=torch.float64, device=dev)
+    pack = torch.empty((2, n), dtype=torch.float64, device=dev)
+    mx, rd = pack[0], pack[1]
     args = L.DsqCooksArgs(n=n, m=m, p=int(p), layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
                           y_type=L.DSQ_Y_INT32, nf=_t_ptr(nf if nf_is_vector else nf.t),
                           nf_is_vector=int(nf_is_vector), mu=_t_ptr(mu.t), H=_t_ptr(H.t), cell_of=_ptr(cells),
                           ncell=int(cells.max()) + 1)
     out = L.DsqCooksOut(cooks=_t_ptr(ck), maxCooks=_t_ptr(mx), robustDisp=_t_ptr(rd))
     L.check(L.lib().dsq_cooks_distance_dev(C.byref(args), C.byref(out), _stream()))
-    return {"cooks": GeneMajor(ck, m), "maxCooks": mx, "robustDisp": rd}
+    return {"cooks": GeneMajor(ck, m), "maxCooks": mx, "robustDisp": rd, "_pack": pack}
 
 
 def replaceOutliers_dev(y, nf, cooks, cooksCutoff, replaceable, trim=0.2, nf_is_vector=False):
