@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genes", type=int, default=50000)
     ap.add_argument("--samples", type=int, default=500)
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("DSQ_BENCH_CHUNKS", "1")),
+                    help="gene chunks per GPU, each on its own HIP stream + host thread (1 = serial DESeq(), the "
+                         "default: measured on MI355X, 2-4 chunk threads are 5-35 %% SLOWER -- the per-call host "
+                         "cost is fixed, not per gene, and the interpreter serialises it; see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-genes", type=int, default=4096)
     ap.add_argument("--profile-host", action="store_true", help="print wall time per pipeline phase (adds syncs)")
@@ -85,13 +89,22 @@ def main():
     nf_r = torch.ones((m, n), dtype=torch.float64, device=dev) * torch.as_tensor(d["size_factors"], device=dev)[:, None]
     torch.cuda.synchronize()
 
+    pipe = parallel.Pipeline(E, n_chunks=args.chunks, comm_device=comm_dev) if args.chunks > 1 else None
+
+    def make_dds(lo, hi):
+        return core.DESeqDataSet.from_device(E, counts_r[:, lo:hi].contiguous(), nf_r[:, lo:hi].contiguous(), x,
+                                             sizeFactors=d["size_factors"])
+
     def step():
+        """one DESeq() over this rank's genes; returns the chunk results (one DESeqDataSet per chunk)"""
+        if pipe is not None:
+            return pipe.run(make_dds, n)
         dds = core.DESeqDataSet.from_device(E, counts_r, nf_r, x, sizeFactors=d["size_factors"])
         if world > 1:
             parallel.DESeqParallel(dds, comm_device=comm_dev)
         else:
             core.DESeq(dds)
-        return dds
+        return [dds]
 
     for _ in range(args.warmup):
         step()
@@ -179,12 +192,14 @@ def main():
                     out[k] = {"launches": len(v), "avg_ms": float(np.mean([t for _, t in v])),
                               "genes_per_launch": float(np.mean([g for g, _ in v]))}
             return out
-        kern = summary(lambda g: g >= n // 2)                 # the full-size launches of the chain
-        kern_refit = summary(lambda g: g < n // 2)            # refitWithoutOutliers: the replaced rows only
+        big = n // (2 * max(1, args.chunks))
+        kern = summary(lambda g: g >= big)                    # the full-size (chunk) launches of the chain
+        kern_refit = summary(lambda g: g < big)               # refitWithoutOutliers: the replaced rows only
         # the two full-size kernels; dominant = larger share of the step
         share = {k: sum(t for _, t in per[k]) for k in per}
         dom = max(("fit_beta", "fit_disp"), key=lambda k: share.get(k, 0.0))
-        full = [(g, t) for g, t in per[dom] if g == n]
+        nfull = max(g for g, _ in per[dom])
+        full = [(g, t) for g, t in per[dom] if g == nfull]
         avg_ms = float(np.mean([t for _, t in full]))
         bytes_per_gene = algorithmic_bytes_per_gene(dom, m, nf_matrix=True, weights=False,
                                                     hat=(dom == "fit_beta"), mu=(dom == "fit_beta"))
@@ -192,24 +207,26 @@ def main():
             # fitBeta#1 writes mu (no H), fitBeta#2 writes mu and H: average of the two launches
             bytes_per_gene = (algorithmic_bytes_per_gene("fit_beta", m, hat=False, mu=True) +
                               algorithmic_bytes_per_gene("fit_beta", m, hat=True, mu=True)) / 2.0
-        achieved = bytes_per_gene * n / (avg_ms * 1e-3) / 1e9
+        achieved = bytes_per_gene * nfull / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
         # this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed
         # under profiles/ -- counters cannot be read from inside the process.
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if n_req == 50000 and m == 500:
-                traffic = pmc[dom]["hbm_bytes_per_launch"]
+            if n_req == 50000 and m == 500:     # PMC passes ran this workload; scale to the genes of one launch
+                traffic = pmc[dom]["hbm_bytes_per_launch"] * nfull / pmc.get("_genes_per_launch", 50000)
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": bytes_per_gene * n, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": bytes_per_gene * nfull, "genes_per_launch": nfull,
+                    "avg_launch_ms": avg_ms,
                     "note": "f64-VALU/transcendental bound, not HBM bound (DESIGN.md); see profiles/"}
 
-        it_beta = float(np.mean(dds.mcols["betaIter"]))
-        it_disp = float(np.mean(dds.mcols["dispIter"]))
+        mc = parallel.concat_mcols(dds, ["betaIter", "dispIter", "dispGeneIter"])
+        it_beta = float(np.mean(mc["betaIter"]))
+        it_disp = float(np.mean(mc["dispIter"]))
         out = {
             "metric": "genes/sec for DESeq() disp+beta+Wald fit, 50k x 500 x p=4",
             "value": n_total * args.steps / dt,
@@ -226,12 +243,13 @@ def main():
             "config": {"workload": "BASELINE configs[2]: %d genes x %d samples per GPU, ~batch+condition (p=%d), "
                                    "Wald test; inputs resident in HBM in R layout (int32 counts, f64 nf matrix)"
                                    % (n, m, p),
-                       "genes_per_gpu": n, "samples": m, "p": p, "parallelism": "gene-shard x%d" % world},
+                       "genes_per_gpu": n, "samples": m, "p": p,
+                       "parallelism": "gene-shard x%d, %d chunk stream(s) per GPU" % (world, max(1, args.chunks))},
             "roofline": roofline,
             "kernels": kern,
             "kernels_outlier_refit": kern_refit,
             "mean_iterations": {"fitBeta_final": it_beta, "fitDisp_MAP": it_disp,
-                                "fitDisp_geneEst": float(np.mean(dds.mcols["dispGeneIter"]))},
+                                "fitDisp_geneEst": float(np.mean(mc["dispGeneIter"]))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(counts, d["size_factors"], x, args.cpu_sample_genes)

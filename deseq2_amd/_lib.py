@@ -134,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
-    "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
+    "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
 _lib = None
@@ -180,6 +180,8 @@ def lib():
     L.dsq_parametric_dispersion_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.dsq_parametric_dispersion_fit_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p]
+    L.dsq_linear_mu.argtypes = [C.POINTER(DsqPrefitArgs), C.c_double, C.c_void_p]
+    L.dsq_linear_mu_dev.argtypes = [C.POINTER(DsqPrefitArgs), C.c_double, C.c_void_p, C.c_void_p]
     L.dsq_cooks_distance.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut)]
     L.dsq_cooks_distance_dev.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut), C.c_void_p]
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]

@@ -90,6 +90,37 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
     }
 }
 
+// linearModelMuNormalized (R/core.R:2454-2471): mu = nf * ((yn Q)(X R^-1)'), optionally floored (:763)
+template <int P>
+__global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, double mu_floor, double *mu_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        double tu[P];
+#pragma unroll
+        for (int c = 0; c < P; c++) tu[c] = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double yn = (double)yg[j] / nfg[j];
+#pragma unroll
+            for (int c = 0; c < P; c++) tu[c] += yn * kp.q[(size_t)c * m + j];
+        }
+        wave_allreduce_n(tu);
+        double *mg = mu_out + (size_t)g * kp.ld;
+        for (int j = lane; j < m; j += 64) {
+            double v = tu[0] * kp.a[j];
+#pragma unroll
+            for (int c = 1; c < P; c++) v = __builtin_fma(tu[c], kp.a[(size_t)c * m + j], v);
+            v = v * nfg[j];
+            if (mu_floor > 0.0) v = __builtin_fmax(v, mu_floor);
+            mg[j] = v;
+        }
+    }
+}
+
 template <bool USE_W>
 __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
     const int lane = threadIdx.x & 63;
@@ -225,6 +256,29 @@ hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok)
     case 8: return launch_prefit_p<8>(kp, st);
     case 9: return launch_prefit_p<9>(kp, st);
     case 10: return launch_prefit_p<10>(kp, st);
+    default: *ok = false; return hipSuccess;
+    }
+}
+
+template <int P>
+static hipError_t launch_linear_mu_p(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st) {
+    hipLaunchKernelGGL((linear_mu_kernel<P>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp, mu_floor, mu);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st, bool *ok) {
+    *ok = true;
+    switch (kp.p) {
+    case 1: return launch_linear_mu_p<1>(kp, mu_floor, mu, st);
+    case 2: return launch_linear_mu_p<2>(kp, mu_floor, mu, st);
+    case 3: return launch_linear_mu_p<3>(kp, mu_floor, mu, st);
+    case 4: return launch_linear_mu_p<4>(kp, mu_floor, mu, st);
+    case 5: return launch_linear_mu_p<5>(kp, mu_floor, mu, st);
+    case 6: return launch_linear_mu_p<6>(kp, mu_floor, mu, st);
+    case 7: return launch_linear_mu_p<7>(kp, mu_floor, mu, st);
+    case 8: return launch_linear_mu_p<8>(kp, mu_floor, mu, st);
+    case 9: return launch_linear_mu_p<9>(kp, mu_floor, mu, st);
+    case 10: return launch_linear_mu_p<10>(kp, mu_floor, mu, st);
     default: *ok = false; return hipSuccess;
     }
 }

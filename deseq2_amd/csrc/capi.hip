@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -77,14 +78,19 @@ static void prof_end(hipStream_t st) {
 }
 
 // ---- workspace pool: grow-only device buffers, one per (device, slot) -------------
+// Keyed by (device, stream): calls issued on different streams (e.g. the chunks of a pipelined DESeq(),
+// deseq2_amd/parallel.py) must not share scratch, counters or staging buffers while both are in flight.
+// The stream of the current API call is latched at entry (WsScope, under g_mu).
 struct Slot { void *p = nullptr; size_t bytes = 0; };
-static std::vector<Slot> g_pool[64];
+static std::map<hipStream_t, std::vector<Slot>> g_pool[64];
+static hipStream_t g_ws_stream = nullptr;
+struct WsScope { explicit WsScope(hipStream_t s) { g_ws_stream = s; } };
 
 static int ws_get(int slot, size_t bytes, void **out) {
     int dev = 0;
     DSQ_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(DSQ_ERR_DEVICE, "device index %d out of range", dev);
-    auto &pool = g_pool[dev];
+    auto &pool = g_pool[dev][g_ws_stream];
     if ((int)pool.size() <= slot) pool.resize(slot + 1);
     Slot &s = pool[slot];
     if (s.bytes < bytes) {
@@ -410,6 +416,39 @@ static int prefit_dev_locked(const DsqPrefitArgs *a, const DsqPrefitOut *o, hipS
     return finish_ycheck(ycheck, st);
 }
 
+static int linear_mu_dev_locked(const DsqPrefitArgs *a, double mu_floor, double *mu, hipStream_t st) {
+    if (!a || !mu) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->q || !a->a) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    PrefitKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m; kp.p = a->p;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    if (a->nf_is_vector) { kp.nf = a->nf; kp.nf_is_vector = 1; }
+    else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, a->m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
+    kp.q = a->q; kp.a = a->a;
+    double *dst = mu;
+    if (a->layout != DSQ_LAYOUT_GENE_MAJOR) {
+        void *b; rc = ws_get(WS_MUOUT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc;
+        dst = (double *)b;
+    }
+    bool ok = false;
+    prof_begin(st);
+    DSQ_HIP(launch_linear_mu(kp, mu_floor, dst, st, &ok));
+    prof_end(st);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    if (a->layout != DSQ_LAYOUT_GENE_MAJOR) DSQ_HIP(launch_transpose_gm_to_r_f64(dst, mu, a->n, a->m, ld, st));
+    return finish_ycheck(ycheck, st);
+}
+
 static int loglike_dev_locked(const DsqLogLikeArgs *a, double *out, hipStream_t st) {
     if (!a || !out) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -574,6 +613,7 @@ int dsq_set_device(int device) {
 
 int dsq_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     g_prof = on != 0;
     g_ev_valid = false;
     return DSQ_OK;
@@ -581,6 +621,7 @@ int dsq_profile_enable(int on) {
 
 double dsq_profile_last_ms(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!g_ev_valid) return -1.0;
     float ms = 0.f;
     if (hipEventSynchronize(g_ev1) != hipSuccess || hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
@@ -589,13 +630,14 @@ double dsq_profile_last_ms(void) {
 
 int dsq_release_workspace(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (int d = 0; d < 64; d++) {
         if (g_pool[d].empty()) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (auto &s : g_pool[d]) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+        for (auto &kv : g_pool[d]) for (auto &s : kv.second) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
         g_pool[d].clear();
     }
     (void)hipSetDevice(cur);
@@ -604,14 +646,17 @@ int dsq_release_workspace(void) {
 
 int dsq_fit_beta_dev(const DsqFitBetaArgs *args, const DsqFitBetaOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return fit_beta_dev_locked(args, out, (hipStream_t)stream);
 }
 int dsq_fit_disp_dev(const DsqFitDispArgs *args, const DsqFitDispOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return fit_disp_dev_locked(args, out, (hipStream_t)stream);
 }
 int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return fit_disp_grid_dev_locked(args, out, (hipStream_t)stream);
 }
 
@@ -649,6 +694,7 @@ int dsq_from_gene_major_f64(const double *src_gm, double *dst_r, int32_t n, int3
 // (what src/r_shim.c binds: R memory in, R memory out, synchronous)
 int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -723,6 +769,7 @@ static int disp_host_stage(int n_, int m_, int p_, const void *y, int y_type, co
 
 int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -769,6 +816,7 @@ int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
 
 int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1 || a->p < 1 || a->ngrid < 2) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -802,6 +850,7 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
 int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, int64_t n, double *coefs,
                                       int32_t *status, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     if (!means || !disps || !coefs || !status || n < 1) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;
     prof_begin((hipStream_t)stream);
@@ -812,6 +861,7 @@ int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, 
 
 int dsq_parametric_dispersion_fit(const double *means, const double *disps, int64_t n, double *coefs, int32_t *status) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!means || !disps || !coefs || !status || n < 1) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;
     hipStream_t st = nullptr;
@@ -830,15 +880,23 @@ int dsq_parametric_dispersion_fit(const double *means, const double *disps, int6
 
 int dsq_prefit_moments_dev(const DsqPrefitArgs *args, const DsqPrefitOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return prefit_dev_locked(args, out, (hipStream_t)stream);
+}
+int dsq_linear_mu_dev(const DsqPrefitArgs *args, double mu_floor, double *mu, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
+    return linear_mu_dev_locked(args, mu_floor, mu, (hipStream_t)stream);
 }
 int dsq_nbinom_loglike_dev(const DsqLogLikeArgs *args, double *loglike, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return loglike_dev_locked(args, loglike, (hipStream_t)stream);
 }
 
 int dsq_prefit_moments(const DsqPrefitArgs *a, const DsqPrefitOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 2 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -879,8 +937,38 @@ int dsq_prefit_moments(const DsqPrefitArgs *a, const DsqPrefitOut *o) {
     return DSQ_OK;
 }
 
+int dsq_linear_mu(const DsqPrefitArgs *a, double mu_floor, double *mu) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
+    if (!a || !mu) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->q || !a->a) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m, p = a->p;
+    DsqPrefitArgs d = *a;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if ((rc = ws_get(WS_H_VEC, 2 * m * p * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->q, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + m * p, a->a, m * p * 8, hipMemcpyHostToDevice, st));
+    d.q = vec; d.a = vec + m * p;
+    if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc;
+    rc = linear_mu_dev_locked(&d, mu_floor, (double *)v, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(mu, v, n * m * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
 int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !loglike) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -908,15 +996,18 @@ int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
 
 int dsq_cooks_distance_dev(const DsqCooksArgs *args, const DsqCooksOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return cooks_dev_locked(args, out, (hipStream_t)stream);
 }
 int dsq_replace_outliers_dev(const DsqReplaceArgs *args, const DsqReplaceOut *out, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
     return replace_dev_locked(args, out, (hipStream_t)stream);
 }
 
 int dsq_cooks_distance(const DsqCooksArgs *a, const DsqCooksOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -948,6 +1039,7 @@ int dsq_cooks_distance(const DsqCooksArgs *a, const DsqCooksOut *o) {
 
 int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
@@ -976,6 +1068,7 @@ int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
 
 int dsq_test_math(int op, const double *a, const double *b, const double *c, double *out, int64_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
     if (!a || !out || n < 0 || (op >= 7 && !b) || (op >= 8 && !c)) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;
     if (n == 0) return DSQ_OK;

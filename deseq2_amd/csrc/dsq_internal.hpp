@@ -107,6 +107,7 @@ struct ReplaceKernelParams {
 hipError_t launch_cooks(const CooksKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_replace(const ReplaceKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok);
+hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st, bool *ok);
 hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st);
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
                             hipStream_t st);

@@ -16,7 +16,11 @@ arrays (they are what R keeps in mcols()); n x m matrices are opaque handles:
                 (SURVEY 8f-2).  torch is used for memory, streams and the O(n*m)
                 elementwise glue (row gathers, clamps); the fits are the HIP kernels.
 """
+import threading
+
 import numpy as np
+
+_PROF_LOCK = threading.Lock()
 
 
 class HostEngine:
@@ -66,9 +70,9 @@ class HostEngine:
         return float(np.mean(1.0 / nf.mean(axis=0)))
 
     def linear_mu(self, y, nf, x):
-        """linearModelMuNormalized, R/core.R:2465-2471"""
-        q, r = np.linalg.qr(x)
-        return ((y / nf) @ q) @ (x @ np.linalg.inv(r)).T * nf
+        """linearModelMuNormalized, R/core.R:2465-2471 (engine kernel: a BLAS product on the host would make
+        a gene's value depend on how many rows are in the call)"""
+        return self.fns.linearMu(y, nf, x)
 
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):
         """nbinomLogLike, R/core.R:2208-2217"""
@@ -153,12 +157,21 @@ class DeviceEngine:
             return fn()
         from . import _lib
         L = _lib.lib()
-        L.dsq_profile_enable(1)
-        r = fn()
-        ms = L.dsq_profile_last_ms()
-        L.dsq_profile_enable(0)
+        with _PROF_LOCK:            # the library keeps ONE pair of events: chunk threads take turns here
+            L.dsq_profile_enable(1)
+            r = fn()
+            ms = L.dsq_profile_last_ms()
+            L.dsq_profile_enable(0)
         self.record.append((name, n, ms))
         return r
+
+    def _host(self, t):
+        """device tensor -> host tensor through PINNED memory (torch's caching host allocator recycles
+        the blocks, so this is an async DMA + one stream sync instead of a staged pageable copy)"""
+        h = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+        return h
 
     def _vec(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
@@ -178,11 +191,11 @@ class DeviceEngine:
         return self.torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.float64).T), device=self.device)
 
     def to_numpy(self, h):
-        return h.view().cpu().numpy()
+        return self._host(h.view()).numpy()
 
     def to_numpy_np(self, b):
         """n x p host matrix from either a host array or the (p, n) device tensor of start values"""
-        return b.t().cpu().numpy() if self.torch.is_tensor(b) else np.asarray(b)
+        return self._host(b.t()).numpy() if self.torch.is_tensor(b) else np.asarray(b)
 
     def take_rows(self, h, idx):
         if h is None:
@@ -214,7 +227,7 @@ class DeviceEngine:
         dr = t.as_tensor(np.ascontiguousarray(r.T), device=self.device)
         o = self._timed("prefit_moments", y.n, lambda: self.native.prefitMoments_dev(
             y, nf, dq, da, dr, weights, weights is not None))
-        h = o["_pack"].cpu()                        # one copy for the four n-vectors
+        h = self._host(o["_pack"])                        # one copy for the four n-vectors
         n = y.n
         return {"baseMean": h[0].numpy(), "baseVar": h[1].numpy(),
                 "allZero": h[3].view(t.int32)[:n].numpy().astype(bool), "roughDisp": h[2].numpy(),
@@ -224,17 +237,16 @@ class DeviceEngine:
         return float((1.0 / nf.view().mean(dim=0)).mean())
 
     def linear_mu(self, y, nf, x_dev):
-        x, q, r = self._xmats(x_dev)
-        yn = y.view().to(self.torch.float64) / nf.view()
-        mu = (yn @ q) @ (x @ self.torch.linalg.inv(r)).t() * nf.view()
-        out = self.torch.zeros((y.n, y.ld), dtype=self.torch.float64, device=self.device)
-        out[:, : y.m] = mu
-        return self.native.GeneMajor(out, y.m)
+        t = self.torch
+        q, a, r = self.native.design_qr(x_dev.t().cpu().numpy())
+        dq = t.as_tensor(np.ascontiguousarray(q.T), device=self.device)
+        da = t.as_tensor(np.ascontiguousarray(a.T), device=self.device)
+        return self._timed("linear_mu", y.n, lambda: self.native.linearMu_dev(y, nf, dq, da))
 
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):
         dv = self._vec(disp)
         o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
-        return o.cpu().numpy()
+        return self._host(o).numpy()
 
     def parametric_fit(self, means, disps):
         dm, dd = self._vec(means), self._vec(disps)
@@ -256,27 +268,27 @@ class DeviceEngine:
         t = self.torch
         zz = t.as_tensor(np.ascontiguousarray(z), device=self.device)
         # 2*pnorm(-|z|) = erfc(|z|/sqrt(2)): keeps the far tail (ndtr flushes it to 0)
-        return t.special.erfc(zz.abs() * 0.7071067811865476).cpu().numpy()
+        return self._host(t.special.erfc(zz.abs() * 0.7071067811865476)).numpy()
 
     # ---- count outliers: HIP kernels (csrc/outlier.hip)
     def cooks_distance(self, y, nf, mu, H, x):
         cells = self.native.cell_index(x)
         p = np.asarray(x).shape[1]
         r = self._timed("cooks_distance", y.n, lambda: self.native.cooksDistance_dev(y, nf, mu, H, cells, p))
-        h = r["_pack"].cpu().numpy()
+        h = self._host(r["_pack"]).numpy()
         return {"cooks": r["cooks"], "maxCooks": h[0], "robustDisp": h[1]}
 
     def replace_outliers(self, y, nf, cooks, cooksCutoff, replaceable, trim=0.2):
         r = self._timed("replace_outliers", y.n, lambda: self.native.replaceOutliers_dev(
             y, nf, cooks, cooksCutoff, replaceable, trim))
-        return {"counts": r["counts"], "replace": r["replace"].cpu().numpy().astype(bool)}
+        return {"counts": r["counts"], "replace": self._host(r["replace"]).numpy().astype(bool)}
 
     def masked_row_max(self, h, use, zero):
         t = self.torch
         z = t.as_tensor(np.asarray(zero, bool), device=self.device)
         u = t.as_tensor(np.asarray(use, bool), device=self.device)
         a = t.where(z[None, :], t.zeros((), dtype=t.float64, device=self.device), h.view())
-        return a[:, u].max(dim=1).values.cpu().numpy()      # max is exact: glue, not arithmetic
+        return self._host(a[:, u].max(dim=1).values).numpy()      # max is exact: glue, not arithmetic
 
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
@@ -289,7 +301,7 @@ class DeviceEngine:
         r = self._timed("fit_beta", y.n, lambda: self.native.fitBeta_dev(
             y, x, nf, av, cv, b0, lv, weights, useWeights, tol, maxit, useQR, minmu, want_hat=want_hat,
             want_mu=want_mu, mu_floor=mu_floor))
-        h = r["_pack"].cpu().numpy()               # one device-to-host copy for all per-gene outputs
+        h = self._host(r["_pack"]).numpy()               # one device-to-host copy for all per-gene outputs
         p = (h.shape[0] - 4) // 2
         out = {"beta_mat": np.ascontiguousarray(h[:p].T), "beta_var_mat": np.ascontiguousarray(h[p:2 * p].T),
                "iter": h[2 * p], "deviance": h[2 * p + 3], "contrast_num": h[2 * p + 1].reshape(-1, 1),
@@ -305,7 +317,7 @@ class DeviceEngine:
         r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
             y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
             weightThreshold, useCR, want_d2lp=self.want_d2lp))
-        h = r.pop("_pack").cpu()                   # one copy; the views below index the host buffer
+        h = self._host(r.pop("_pack"))                   # one copy; the views below index the host buffer
         keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
         out = {k: h[i].numpy() for i, k in enumerate(keys) if k in r}
         ints = h[len(keys)].view(self.torch.int32)
@@ -319,4 +331,4 @@ class DeviceEngine:
         gv = self._vec(disp_grid)
         r = self._timed("fit_disp_grid", n, lambda: self.native.fitDispGrid_dev(
             y, x, mu_hat, gv, pm, prior_sigmasq, usePrior, weights, useWeights, weightThreshold, useCR))
-        return {"log_alpha": r["log_alpha"].cpu().numpy()}
+        return {"log_alpha": self._host(r["log_alpha"]).numpy()}

@@ -169,6 +169,20 @@ def prefitMoments(counts, nf, x, weights=None, useWeights=False):
     return {"baseMean": bm, "baseVar": bv, "allZero": az.astype(bool), "roughDisp": rd, "beta_init": b0}
 
 
+def linearMu(counts, nf, x, mu_floor=0.0):
+    """linearModelMuNormalized (R/core.R:2454-2471) through dsq_linear_mu"""
+    y, ytype = _counts(counts)
+    nf = _fcol(nf)
+    n, m = y.shape
+    q, a, r = design_qr(x)
+    q, a = _fcol(q), _fcol(a)
+    mu = np.zeros((n, m), order="F")
+    args = L.DsqPrefitArgs(n=n, m=m, p=q.shape[1], layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, nf=_ptr(nf),
+                           nf_is_vector=0, weights=None, useWeights=0, q=_ptr(q), a=_ptr(a), r=None)
+    L.check(L.lib().dsq_linear_mu(C.byref(args), float(mu_floor), _ptr(mu)))
+    return mu
+
+
 def nbinomLogLike(counts, mu, disp, weights, useWeights):
     """R/core.R:2208-2217 through dsq_nbinom_loglike"""
     y, ytype = _counts(counts)
@@ -412,6 +426,18 @@ def prefitMoments_dev(y, nf, q, a, r, weights=None, useWeights=False, nf_is_vect
     L.check(L.lib().dsq_prefit_moments_dev(C.byref(args), C.byref(o), _stream()))
     out["_pack"] = pack
     return out
+
+
+def linearMu_dev(y, nf, q, a, mu_floor=0.0, nf_is_vector=False):
+    """y / nf GeneMajor, q / a (p, m) contiguous CUDA tensors; returns GeneMajor mu"""
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    mu = torch.zeros((n, ld), dtype=torch.float64, device=y.t.device)
+    args = L.DsqPrefitArgs(n=n, m=m, p=q.shape[0], layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t),
+                           y_type=L.DSQ_Y_INT32, nf=_t_ptr(nf if nf_is_vector else nf.t),
+                           nf_is_vector=int(nf_is_vector), weights=None, useWeights=0, q=_t_ptr(q), a=_t_ptr(a), r=None)
+    L.check(L.lib().dsq_linear_mu_dev(C.byref(args), float(mu_floor), _t_ptr(mu), _stream()))
+    return GeneMajor(mu, m)
 
 
 def nbinomLogLike_dev(y, mu, disp, weights=None, useWeights=False):

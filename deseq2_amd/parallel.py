@@ -8,6 +8,8 @@ src/DESeq2.cpp:194,319,492).  The only exchange is the pair of n-vectors the glo
 needs (baseMean, dispGeneEst): one small all-gather over torch.distributed (RCCL when the
 backend is "nccl", gloo in the CPU tests); every rank then fits the identical trend.
 """
+import os
+
 import numpy as np
 
 from . import core
@@ -39,14 +41,43 @@ def _allgather_vec(v, device=None):
     return np.concatenate([p[:s].cpu().numpy() for p, s in zip(parts, sizes)])
 
 
+class LocalGroup:
+    """The chunk workers of ONE process: k threads, each driving its own HIP stream over a contiguous
+    gene range of this rank's shard (DESeqPipelined).  allgather() concatenates the chunk vectors in chunk
+    order and, when torch.distributed is initialised, lets chunk 0 extend that over the ranks -- the
+    global gene order is (rank, chunk), i.e. the contiguous ranges of R/parallel.R:10."""
+
+    def __init__(self, k, comm_device=None):
+        import threading
+        self.k, self.comm_device = k, comm_device
+        self.barrier = threading.Barrier(k)
+        self.slots = [None] * k
+        self.result = None
+
+    def allgather(self, idx, vec):
+        self.slots[idx] = np.asarray(vec, np.float64)
+        self.barrier.wait()
+        if idx == 0:
+            self.result = _allgather_vec(np.concatenate(self.slots), self.comm_device)
+        self.barrier.wait()
+        res = self.result
+        self.barrier.wait()          # everybody has read before the slots are reused
+        return res
+
+
 def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_device=None,
-                  minReplicatesForReplace=7, **kw):
-    """`dds` is THIS rank's shard.  R/parallel.R:6-74 (betaPrior = FALSE branch)."""
+                  minReplicatesForReplace=7, group=None, chunk=0, **kw):
+    """`dds` is THIS worker's shard (a rank's, or one chunk of a rank's when `group` is given).
+    R/parallel.R:6-74 (betaPrior = FALSE branch)."""
     # round 1: gene-wise estimates on the shard                                 (:18-20)
     core.estimateDispersionsGeneEst(dds)
     # global steps on the gathered n-vectors                                    (:27-28)
-    bm_all = _allgather_vec(dds.mcols["baseMean"], comm_device)
-    dge_all = _allgather_vec(dds.mcols["dispGeneEst"], comm_device)
+    if group is not None:
+        bm_all = group.allgather(chunk, dds.mcols["baseMean"])
+        dge_all = group.allgather(chunk, dds.mcols["dispGeneEst"])
+    else:
+        bm_all = _allgather_vec(dds.mcols["baseMean"], comm_device)
+        dge_all = _allgather_vec(dds.mcols["dispGeneEst"], comm_device)
     glob = _GlobalView(bm_all, dge_all, dds.x)
     core.estimateDispersionsFit(glob, fitType=fitType, engine=dds.engine)
     dispPriorVar = core.estimateDispersionsPriorVar(glob)
@@ -77,3 +108,63 @@ class _GlobalView:
         self.mcols = {"baseMean": baseMean, "dispGeneEst": dispGeneEst}
         self.x = x
         self.dispersionFunction = None
+
+
+class Pipeline:
+    """DESeq() of one rank's genes as k chunks, each in its own thread on its own HIP stream: while one
+    chunk's host code (the R-side decision rules between the native calls) runs, the other chunks' kernels
+    keep the GPU busy.  Same arithmetic per gene and the same all-gene steps as DESeqParallel, so the
+    results equal the serial ones (tests/test_gpu_pipeline.py).  Streams and their engine workspaces
+    persist across calls."""
+
+    def __init__(self, engine, n_chunks=2, comm_device=None):
+        self.engine, self.k, self.comm_device = engine, int(n_chunks), comm_device
+        t = engine.torch
+        self.streams = [t.cuda.Stream(device=engine.device) for _ in range(self.k)]
+
+    def run(self, make_dds, n, **kw):
+        """make_dds(lo, hi) builds the DESeqDataSet of genes [lo, hi) (called inside the chunk's stream)."""
+        overlap = True
+        import threading
+        t = self.engine.torch
+        bounds = [r[[0, -1]] + np.array([0, 1]) for r in shard_ranges(n, self.k)]
+        out, errs = [None] * self.k, []
+        group = LocalGroup(self.k if overlap else 1, self.comm_device)
+        cur = t.cuda.current_stream(self.engine.device)
+
+        def work(c):
+            try:
+                t.cuda.set_device(self.engine.device)
+                self.streams[c].wait_stream(cur)
+                with t.cuda.stream(self.streams[c]):
+                    dds = make_dds(int(bounds[c][0]), int(bounds[c][1]))
+                    out[c] = DESeqParallel(dds, comm_device=self.comm_device, group=group, chunk=c, **kw)
+                    self.streams[c].synchronize()
+            except BaseException as e:          # noqa: BLE001 -- re-raised in the caller's thread
+                errs.append(e)
+                group.barrier.abort()
+        if overlap and self.k > 1:
+            import sys
+            # a chunk thread coming back from a kernel wait must not sit out the interpreter's default 5 ms
+            # switch interval while another chunk runs host code
+            old = sys.getswitchinterval()
+            sys.setswitchinterval(float(os.environ.get("DSQ_SWITCH_INTERVAL", "1e-4")))
+            try:
+                th = [threading.Thread(target=work, args=(c,)) for c in range(self.k)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+            finally:
+                sys.setswitchinterval(old)
+        else:
+            work(0)
+        if errs:
+            raise errs[0]
+        return out
+
+
+def concat_mcols(shards, keys=None):
+    """per-gene columns of the chunk results, back in gene order"""
+    keys = keys if keys is not None else [k for k in shards[0].mcols if k != "rowsForOptim"]
+    return {k: np.concatenate([np.asarray(d.mcols[k]) for d in shards]) for k in keys}

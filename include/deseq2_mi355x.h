@@ -203,6 +203,12 @@ typedef struct {
 int dsq_prefit_moments(const DsqPrefitArgs *args, const DsqPrefitOut *out);
 int dsq_prefit_moments_dev(const DsqPrefitArgs *args, const DsqPrefitOut *out, void *stream);
 
+/* dsq_linear_mu: linearModelMuNormalized (R/core.R:2454-2471), mu = nf * ((y/nf) Q)(X R^-1)', the closed-form
+ * fitted means estimateDispersionsGeneEst uses when the design is a set of groups (R/core.R:735-760); floored at
+ * mu_floor when > 0 (:763).  Takes the q / a fields of DsqPrefitArgs (r, weights unused).  mu: n x m.      */
+int dsq_linear_mu(const DsqPrefitArgs *args, double mu_floor, double *mu);
+int dsq_linear_mu_dev(const DsqPrefitArgs *args, double mu_floor, double *mu, void *stream);
+
 /* dsq_nbinom_loglike: nbinomLogLike (R/core.R:2208-2217), rowSums([w *] dnbinom(y, mu, 1/disp, log)) */
 typedef struct {
     int32_t n, m;

@@ -726,6 +726,30 @@ int orc_prefit_moments(int n, int m, int p, const double *y, const double *nf, c
     return 0;
 }
 
+/* linearModelMuNormalized (R/core.R:2454-2471): mu = nf * ((yn Q) (X R^-1)'), floored at mu_floor when > 0
+ * (R/core.R:763).  q = Q, a = X R^-1 of the thin QR of the design; same sums as the moments above. */
+int orc_linear_mu(int n, int m, int p, const double *y, const double *nf, const double *q, const double *a,
+                  double mu_floor, double *mu, int sum_mode) {
+    if (p > ORC_PMAX) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        double t[ORC_PMAX];
+        for (int c = 0; c < p; c++) {
+            wsum_t s1; wsum_init(&s1, sum_mode);
+            for (int j = 0; j < m; j++) wsum_add(&s1, j, (y[i + (long)n * j] / nf[i + (long)n * j]) * q[j + (long)m * c]);
+            t[c] = wsum_total(&s1);
+        }
+        for (int j = 0; j < m; j++) {
+            double v = t[0] * a[j];
+            for (int c = 1; c < p; c++) v = fma(t[c], a[j + (long)m * c], v);
+            v = v * nf[i + (long)n * j];
+            if (mu_floor > 0.0) v = fmax(v, mu_floor);
+            mu[i + (long)n * j] = v;
+        }
+    }
+    return 0;
+}
+
 /* fitted means from the final coefficients: mu = nf * exp(x beta) (R/fitNbinomGLMs.R:180), optionally
  * floored (R/core.R:763).  eta is accumulated as in fitBeta (:324), exp is the restated one.   */
 int orc_fitted_mu(int n, int m, int p, const double *x, const double *nf, const double *beta,

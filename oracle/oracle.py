@@ -210,6 +210,20 @@ def prefitMoments(counts, nf, x, weights=None, useWeights=False, sum_mode=0):
     return {"baseMean": bm, "baseVar": bv, "allZero": az.astype(bool), "roughDisp": rd, "beta_init": b0}
 
 
+def linearMu(counts, nf, x, mu_floor=0.0, sum_mode=0):
+    """linearModelMuNormalized (R/core.R:2454-2471), optionally floored (R/core.R:763)"""
+    y = _f(counts); nf = _f(nf)
+    n, m = y.shape
+    q, a, r = design_qr(x)
+    q = _f(q); a = _f(a)
+    mu = np.zeros((n, m), order="F")
+    rc = lib().orc_linear_mu(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(q.shape[1]), _p(y), _p(nf), _p(q), _p(a),
+                             ctypes.c_double(float(mu_floor)), _p(mu), ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_linear_mu failed: %d" % rc)
+    return mu
+
+
 def parametricDispersionFit(means, disps):
     """R/core.R:2166-2190; raises RuntimeError with the reference's messages on failure"""
     means = np.ascontiguousarray(means, dtype=np.float64); disps = np.ascontiguousarray(disps, dtype=np.float64)

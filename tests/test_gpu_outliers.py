@@ -126,3 +126,15 @@ def test_chain_lrt_with_outliers_identical_to_oracle(oracle):
     for k in ("dispersion", "beta", "betaSE", "LRTStatistic", "LRTPvalue", "fullBetaConv", "betaIter", "deviance",
               "maxCooks", "replace"):
         assert_same(a.mcols[k], b.mcols[k], "DESeq(LRT, outliers)$" + k)
+
+
+@pytest.mark.parametrize("n,m,kind", [(300, 6, "two"), (200, 24, "bc"), (100, 500, "bc"), (50, 130, "f10")])
+def test_linear_mu_vs_oracle(oracle, n, m, kind):
+    """linearModelMuNormalized (R/core.R:2454-2471) kernel, host ABI and device ABI, bit for bit"""
+    x = _design(kind, m)
+    c, nf, _, _ = _inputs(n, x, seed=5 * m + n)
+    b = oracle.linearMu(c, nf, x, mu_floor=0.5)
+    assert_same(native.linearMu(c, nf, x, mu_floor=0.5), b, "linearMu (host ABI)")
+    E = DeviceEngine("cuda:0")
+    mu = E.clamp_min(E.linear_mu(E.counts(c), E.matrix(nf), E.design(x)), 0.5)
+    assert_same(E.to_numpy(mu), b, "linearMu (device ABI)")

@@ -174,3 +174,19 @@ def test_parametric_dispersion_fit_restatement(oracle):
     assert 0.08 < a[0] < 0.16 and 3.0 < a[1] < 6.0
     with pytest.raises(RuntimeError, match="failed"):      # decreasing-to-negative trend: a coefficient <= 0
         oracle.parametricDispersionFit(bm, np.maximum(2.0 - 1.0 / bm, 1e-3) * 0 + 1e-3 + 0.5 * bm / bm.max())
+
+
+def test_linear_mu_matches_matrix_formula(oracle):
+    """linearModelMuNormalized (R/core.R:2454-2471) == ((y/nf) Q)(X R^-1)' * nf; rows are independent of
+    how many genes are in the call (what a BLAS product does not guarantee)"""
+    from deseq2_amd import simulate
+    x = simulate.design_batch_condition(24)
+    d = simulate.make_counts(100, x, seed=3)
+    c = d["counts"].astype(float)
+    nf = np.broadcast_to(np.exp(np.random.default_rng(0).normal(0, .2, 24))[None, :], c.shape).copy()
+    mu = oracle.linearMu(c, nf, x)
+    q, r = np.linalg.qr(x)
+    ref = ((c / nf) @ q) @ (x @ np.linalg.inv(r)).T * nf
+    np.testing.assert_allclose(mu, ref, rtol=1e-11, atol=1e-11)
+    np.testing.assert_array_equal(oracle.linearMu(c[37:61], nf[37:61], x), mu[37:61])
+    assert (oracle.linearMu(c, nf, x, mu_floor=0.5) >= 0.5).all()

@@ -58,3 +58,75 @@ def test_two_shards_equal_serial(tmp_path, oracle):
         got = np.concatenate([p[k] for p in parts])
         np.testing.assert_array_equal(got, serial.mcols[k], err_msg=k)
     assert float(parts[0]["prior"]) == float(parts[1]["prior"]) == serial.dispersionFunction["dispPriorVar"]
+
+
+def _run_chunks(dd, x, k, comm_device=None, O=None):
+    """k chunk threads of one process over a LocalGroup (what parallel.Pipeline does on HIP streams)"""
+    import threading
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    counts = dd["counts"]
+    ranges = parallel.shard_ranges(counts.shape[0], k)
+    group = parallel.LocalGroup(k, comm_device)
+    out, errs = [None] * k, []
+
+    def work(c):
+        try:
+            dds = core.DESeqDataSet(counts[ranges[c]], x, sizeFactors=dd["size_factors"], engine=HostEngine(O))
+            out[c] = parallel.DESeqParallel(dds, group=group, chunk=c)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            group.barrier.abort()
+    th = [threading.Thread(target=work, args=(c,)) for c in range(k)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return out
+
+
+def test_chunk_threads_equal_serial(oracle):
+    """in-process chunks (LocalGroup): 3 threads over contiguous gene ranges == serial, with outlier refits"""
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_two_group(16)
+    d = simulate.make_counts(300, x, seed=33)
+    d["counts"][::40, 1] = 90000
+    serial = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle)))
+    shards = _run_chunks(d, x, 3, O=oracle)
+    got = parallel.concat_mcols(shards, COLS + ["maxCooks", "replace"])
+    for k in COLS + ["maxCooks", "replace"]:
+        np.testing.assert_array_equal(got[k], serial.mcols[k], err_msg=k)
+    assert serial.mcols["replace"].sum() >= 5
+
+
+def _worker_chunks(rank, world, port, n, m, seed, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    x = simulate.design_two_group(m)
+    d = simulate.make_counts(n, x, seed=seed)
+    idx = parallel.shard_ranges(d["counts"].shape[0], world)[rank]
+    sub = {"counts": d["counts"][idx], "size_factors": d["size_factors"]}
+    shards = _run_chunks(sub, x, 2, O=O)
+    np.savez(os.path.join(outdir, "cshard%d.npz" % rank), idx=idx, **parallel.concat_mcols(shards, COLS))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_times_two_chunks_equal_serial(tmp_path, oracle):
+    """ranks x chunks: the global gene order of the gathered vectors is (rank, chunk)"""
+    import torch.multiprocessing as mp
+    n, m, seed, world = 400, 12, 35, 2
+    mp.spawn(_worker_chunks, args=(world, _free_port(), n, m, seed, str(tmp_path)), nprocs=world, join=True)
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_two_group(m)
+    d = simulate.make_counts(n, x, seed=seed)
+    serial = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle)))
+    parts = [np.load(os.path.join(str(tmp_path), "cshard%d.npz" % r)) for r in range(world)]
+    for k in COLS:
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), serial.mcols[k], err_msg=k)
