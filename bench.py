@@ -225,6 +225,21 @@ def main():
                     "note": "f64-VALU/transcendental bound, not HBM bound (DESIGN.md); see profiles/"}
 
         mc = parallel.concat_mcols(dds, ["betaIter", "dispIter", "dispGeneIter"])
+        # secondary view: the path is bound by f64 VALU issue, so also report the dominant kernel against the
+        # VALU issue peak: wave-instructions per launch (PMC SQ_INSTS_VALU of the committed passes, scaled to the
+        # genes of one launch) / live launch time, vs CUs x 4 SIMDs x clock / 4 cycles per 64-lane f64 instruction
+        valu = None
+        try:
+            insts = pmc[dom]["SQ_INSTS_VALU"] * nfull / pmc.get("_genes_per_launch", 50000)
+            prop = torch.cuda.get_device_properties(dev)
+            clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+            peak = prop.multi_processor_count * 4 * clock_hz / 4.0
+            ach = insts / (avg_ms * 1e-3)
+            valu = {"kernel": dom, "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+                    "frac": ach / peak, "valu_instructions_per_launch": insts,
+                    "note": "SQ_INSTS_VALU from profiles/r01_pmc.json (same workload), launch time measured live"}
+        except (NameError, KeyError, TypeError, ValueError):
+            pass
         it_beta = float(np.mean(mc["betaIter"]))
         it_disp = float(np.mean(mc["dispIter"]))
         out = {
@@ -246,6 +261,7 @@ def main():
                        "genes_per_gpu": n, "samples": m, "p": p,
                        "parallelism": "gene-shard x%d, %d chunk stream(s) per GPU" % (world, max(1, args.chunks))},
             "roofline": roofline,
+            "valu_roofline": valu,
             "kernels": kern,
             "kernels_outlier_refit": kern_refit,
             "mean_iterations": {"fitBeta_final": it_beta, "fitDisp_MAP": it_disp,
