@@ -146,12 +146,40 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
 // ---- parametricDispersionFit (R/core.R:2166-2190) -----------------------------------------
 // The all-gene step between the two dispersion passes: a Gamma-GLM (identity link) IRLS for
 // disp ~ a0 + a1/mean inside the reference's outlier-filter loop.  It touches only two n-vectors,
-// but on the host it costs milliseconds per step and grows with the number of shards gathered, so
-// it runs here as ONE workgroup of 16 wavefronts that keeps the whole nested loop on the device
-// (no host round trip per iteration).  Sums in block order: thread t takes genes t, t+1024, ...;
-// wave butterfly; the 16 wave sums added in order.
+// but every rank of a multi-GPU run fits it over ALL gathered genes (DESeqParallel, R/parallel.R:27),
+// so it must not grow with the node: kTrendBlocks workgroups of 16 wavefronts keep the whole nested
+// loop on the device (no host round trip per iteration) and meet at a grid barrier per reduction.
+// Sums in BLOCK ORDER (the oracle's bsum): partial q = i mod 16384 -> (block, wave, lane); wave
+// butterfly; the 16 wave sums of a block added in order; the 16 block sums added in order.  Every
+// block reads the same block sums in the same order, so all blocks take identical branches.
+static constexpr int kTrendBlocks = 16;
+
+struct TrendWs {
+    unsigned int count, gen;
+    unsigned int pad[14];
+    unsigned long long sums[2][kTrendBlocks][8];   // bit patterns of doubles, double-buffered by parity
+};
+
+__device__ __forceinline__ void grid_barrier(TrendWs *ws) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned g = __hip_atomic_load(&ws->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        unsigned arrived = atomicAdd(&ws->count, 1u);
+        if (arrived == (unsigned)kTrendBlocks - 1u) {
+            atomicExch(&ws->count, 0u);
+            __threadfence();
+            atomicAdd(&ws->gen, 1u);
+        } else {
+            while (__hip_atomic_load(&ws->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(2);
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+
 template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double (*red)[8]) {
+__device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], TrendWs *ws, int &parity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     wave_allreduce_n(v);
     __syncthreads();                      // previous use of `red` is complete
@@ -160,17 +188,31 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double (*red)[8]) {
         for (int k = 0; k < K; k++) red[wave][k] = v[k];
     }
     __syncthreads();
+    if (threadIdx.x < K) {
+        double tot = red[0][threadIdx.x];
+        for (int g = 1; g < 16; g++) tot = tot + red[g][threadIdx.x];
+        __hip_atomic_store(&ws->sums[parity][blockIdx.x][threadIdx.x], (unsigned long long)__double_as_longlong(tot),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    grid_barrier(ws);
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        double tot = red[0][k];
-        for (int g = 1; g < 16; g++) tot = tot + red[g][k];
+        double tot = 0.0;
+        for (int b = 0; b < kTrendBlocks; b++) {
+            double t = __longlong_as_double((long long)__hip_atomic_load(&ws->sums[parity][b][k], __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT));
+            tot = (b == 0) ? t : tot + t;
+        }
         v[k] = tot;
     }
+    parity ^= 1;
 }
 
 __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, const double *disps, long n,
-                                                         double *coefs_out, int32_t *status_out) {
+                                                         double *coefs_out, int32_t *status_out, TrendWs *ws) {
     __shared__ double red[16][8];
+    const long first = (long)blockIdx.x * 1024 + threadIdx.x, stride = 1024L * kTrendBlocks;
+    int parity = 0;
     double c0 = 0.1, c1 = 1.0;
     int iter = 0, status = 0;
     for (;;) {
@@ -180,7 +222,7 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
         for (int pass = -1; pass < 25 && !invalid; pass++) {
             if (pass >= 0) {
                 double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-                for (long i = threadIdx.x; i < n; i += 1024) {
+                for (long i = first; i < n; i += stride) {
                     double mean = means[i], y = disps[i];
                     double res = y / (c0 + c1 / mean);
                     if (!((res > 1e-4) && (res < 15.0))) continue;
@@ -190,24 +232,23 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
                     double wx = wgt * x;
                     a[0] += wgt; a[1] += wx; a[2] += wx * x; a[3] += wgt * y; a[4] += wx * y;
                 }
-                block_sum<5>(a, red);
+                grid_sum<5>(a, red, ws, parity);
                 double det = a[0] * a[2] - a[1] * a[1];
                 b0 = (a[2] * a[3] - a[1] * a[4]) / det;
                 b1 = (a[0] * a[4] - a[1] * a[3]) / det;
             }
-            double d[2] = {0.0, 0.0};
-            int bad = 0;
-            for (long i = threadIdx.x; i < n; i += 1024) {
+            double d[3] = {0.0, 0.0, 0.0};      // sum log r, sum (r - 1), number of invalid means
+            for (long i = first; i < n; i += stride) {
                 double mean = means[i], y = disps[i];
                 double res = y / (c0 + c1 / mean);
                 if (!((res > 1e-4) && (res < 15.0))) continue;
                 double mu = b0 + b1 * (1.0 / mean);
-                if (!(mu > 0.0)) { bad = 1; continue; }
+                if (!(mu > 0.0)) { d[2] += 1.0; continue; }
                 double r = y / mu;
                 d[0] += dlog(r); d[1] += r - 1.0;
             }
-            if (__syncthreads_or(bad)) { invalid = true; break; }
-            block_sum<2>(d, red);
+            grid_sum<3>(d, red, ws, parity);
+            if (d[2] > 0.0) { invalid = true; break; }
             double dev = -2.0 * (d[0] - d[1]);
             if (pass >= 0 && __builtin_fabs(dev - devold) / (__builtin_fabs(dev) + 0.1) < 1e-8) { converged = true; break; }
             devold = dev;
@@ -221,12 +262,17 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
         iter++;
         if (iter > 10) { status = 2; break; }
     }
-    if (threadIdx.x == 0) { coefs_out[0] = c0; coefs_out[1] = c1; *status_out = status; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { coefs_out[0] = c0; coefs_out[1] = c1; *status_out = status; }
 }
 
+size_t trend_fit_workspace_bytes() { return sizeof(TrendWs); }
+
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(trend_fit_kernel, dim3(1), dim3(1024), 0, st, means, disps, n, coefs, status);
+                            void *workspace, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(TrendWs), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(trend_fit_kernel, dim3(kTrendBlocks), dim3(1024), 0, st, means, disps, n, coefs, status,
+                       (TrendWs *)workspace);
     return hipGetLastError();
 }
 

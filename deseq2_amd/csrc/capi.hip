@@ -105,7 +105,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
 }
 
 enum {  // workspace slots
-    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER,
+    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER, WS_TREND,
     // host-entry staging
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
@@ -854,7 +854,9 @@ int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, 
     if (!means || !disps || !coefs || !status || n < 1) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;
     prof_begin((hipStream_t)stream);
-    DSQ_HIP(launch_trend_fit(means, disps, (long)n, coefs, status, (hipStream_t)stream));
+    void *tws;
+    if (int rc = ws_get(WS_TREND, trend_fit_workspace_bytes(), &tws)) return rc;
+    DSQ_HIP(launch_trend_fit(means, disps, (long)n, coefs, status, tws, (hipStream_t)stream));
     prof_end((hipStream_t)stream);
     return DSQ_OK;
 }
@@ -871,7 +873,9 @@ int dsq_parametric_dispersion_fit(const double *means, const double *disps, int6
     double *d = (double *)v;
     DSQ_HIP(hipMemcpyAsync(d, means, n * 8, hipMemcpyHostToDevice, st));
     DSQ_HIP(hipMemcpyAsync(d + n, disps, n * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(launch_trend_fit(d, d + n, (long)n, d + 2 * n, (int32_t *)(d + 2 * n + 2), st));
+    void *tws;
+    if ((rc = ws_get(WS_TREND, trend_fit_workspace_bytes(), &tws))) return rc;
+    DSQ_HIP(launch_trend_fit(d, d + n, (long)n, d + 2 * n, (int32_t *)(d + 2 * n + 2), tws, st));
     DSQ_HIP(hipMemcpyAsync(coefs, d + 2 * n, 16, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipMemcpyAsync(status, d + 2 * n + 2, 4, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));

@@ -110,7 +110,8 @@ hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok)
 hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st, bool *ok);
 hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st);
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
-                            hipStream_t st);
+                            void *workspace, hipStream_t st);
+size_t trend_fit_workspace_bytes();
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).

@@ -771,25 +771,31 @@ int orc_fitted_mu(int n, int m, int p, const double *x, const double *nf, const 
  * Gamma(link = "identity"), start = coefs) inside the outlier-filter loop.  glm.fit's IRLS is
  * restated for this two-column model: working response = y, working weights = 1/mu^2, stop when
  * |dev - devold| / (|dev| + 0.1) < 1e-8 (glm.control), at most 25 iterations; devold starts at the
- * deviance of the start values.  Sums over the genes in BLOCK ORDER: 1024 partial sums, partial t
- * taking elements t, t+1024, ...; the 64 partials of each of the 16 groups are butterflied
- * (xor 1..32) and the 16 group sums added in order -- the order the one-workgroup kernel uses.
+ * deviance of the start values.  Sums over the genes in BLOCK ORDER: 16384 partial sums, partial q
+ * taking elements q, q+16384, ...; q = (block 0..15, wave 0..15, lane 0..63).  The 64 partials of a wave
+ * are butterflied (xor 1..32), the 16 wave sums of a block added in order, then the 16 block sums added
+ * in order -- the order the 16-workgroup kernel uses, independent of the number of genes.
  * status: 0 ok, 1 "parametric dispersion fit failed" (a coefficient <= 0 or an invalid mean),
  * 2 "dispersion fit did not converge" (more than 10 outer rounds).                            */
-typedef struct { double part[1024]; } bsum_t;
-static void bsum_init(bsum_t *s) { for (int t = 0; t < 1024; t++) s->part[t] = 0.0; }
+#define BSUM_PARTS 16384
+typedef struct { double part[BSUM_PARTS]; } bsum_t;
+static void bsum_init(bsum_t *s) { for (int t = 0; t < BSUM_PARTS; t++) s->part[t] = 0.0; }
 static double bsum_total(const bsum_t *s) {
-    double tot = 0.0;
-    for (int g = 0; g < 16; g++) {
-        double v[64], w[64];
-        memcpy(v, s->part + 64 * g, sizeof v);
-        for (int off = 1; off < 64; off <<= 1) {
-            for (int l = 0; l < 64; l++) w[l] = v[l] + v[l ^ off];
-            memcpy(v, w, sizeof v);
+    double grand = 0.0;
+    for (int b = 0; b < 16; b++) {
+        double tot = 0.0;
+        for (int g = 0; g < 16; g++) {
+            double v[64], w[64];
+            memcpy(v, s->part + 1024 * b + 64 * g, sizeof v);
+            for (int off = 1; off < 64; off <<= 1) {
+                for (int l = 0; l < 64; l++) w[l] = v[l] + v[l ^ off];
+                memcpy(v, w, sizeof v);
+            }
+            tot = (g == 0) ? v[0] : tot + v[0];
         }
-        tot = (g == 0) ? v[0] : tot + v[0];
+        grand = (b == 0) ? tot : grand + tot;
     }
-    return tot;
+    return grand;
 }
 
 int orc_parametric_dispersion_fit(long n, const double *means, const double *disps, double *coefs_out,
@@ -809,7 +815,12 @@ int orc_parametric_dispersion_fit(long n, const double *means, const double *dis
         for (int pass = -1; pass < 25 && !invalid; pass++) {
             if (pass >= 0) {
                 /* weighted least squares step */
-                bsum_t s0, s1, s2, t0, t1;
+                bsum_t *bs = malloc(5 * sizeof(bsum_t));
+#define s0 bs[0]
+#define s1 bs[1]
+#define s2 bs[2]
+#define t0 bs[3]
+#define t1 bs[4]
                 bsum_init(&s0); bsum_init(&s1); bsum_init(&s2); bsum_init(&t0); bsum_init(&t1);
                 for (long i = 0; i < n; i++) {
                     if (!good[i]) continue;
@@ -817,29 +828,41 @@ int orc_parametric_dispersion_fit(long n, const double *means, const double *dis
                     double mu = b0 + b1 * x;
                     double wgt = 1.0 / (mu * mu);
                     double wx = wgt * x;
-                    int t = (int)(i & 1023);
+                    int t = (int)(i & (BSUM_PARTS - 1));
                     s0.part[t] += wgt; s1.part[t] += wx; s2.part[t] += wx * x;
                     t0.part[t] += wgt * y; t1.part[t] += wx * y;
                 }
                 double S0 = bsum_total(&s0), S1 = bsum_total(&s1), S2 = bsum_total(&s2);
                 double T0 = bsum_total(&t0), T1 = bsum_total(&t1);
+#undef s0
+#undef s1
+#undef s2
+#undef t0
+#undef t1
+                free(bs);
                 double det = S0 * S2 - S1 * S1;
                 b0 = (S2 * T0 - S1 * T1) / det;
                 b1 = (S0 * T1 - S1 * T0) / det;
             }
             /* deviance at the current coefficients (pass = -1: at the start values) */
-            bsum_t d1, d2;
+            bsum_t *bd = malloc(2 * sizeof(bsum_t));
+#define d1 bd[0]
+#define d2 bd[1]
             bsum_init(&d1); bsum_init(&d2);
             for (long i = 0; i < n; i++) {
                 if (!good[i]) continue;
                 double mu = b0 + b1 * (1.0 / means[i]);
                 if (!(mu > 0.0)) { invalid = 1; break; }
                 double r = disps[i] / mu;
-                int t = (int)(i & 1023);
+                int t = (int)(i & (BSUM_PARTS - 1));
                 d1.part[t] += orc_log(r); d2.part[t] += r - 1.0;
             }
+            double dsum1 = bsum_total(&d1), dsum2 = bsum_total(&d2);
+#undef d1
+#undef d2
+            free(bd);
             if (invalid) break;
-            double dev = -2.0 * (bsum_total(&d1) - bsum_total(&d2));
+            double dev = -2.0 * (dsum1 - dsum2);
             if (pass >= 0 && fabs(dev - devold) / (fabs(dev) + 0.1) < 1e-8) { converged = 1; break; }
             devold = dev;
         }

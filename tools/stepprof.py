@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deseq2_amd import core, simulate
 from deseq2_amd.engine import DeviceEngine
+NG = int(os.environ.get("STEPPROF_GENES", "50000"))
 m = 500; x = simulate.design_batch_condition(m)
-d = simulate.make_counts(50000, x, seed=1); counts = d["counts"]; n = counts.shape[0]
+d = simulate.make_counts(NG, x, seed=1); counts = d["counts"]; n = counts.shape[0]
 dev = torch.device("cuda", 0); E = DeviceEngine(dev)
 counts_r = torch.as_tensor(np.ascontiguousarray(counts.T), device=dev)
 nf_r = torch.ones((m, n), dtype=torch.float64, device=dev)
@@ -18,4 +19,5 @@ for i in range(4):
     torch.cuda.synchronize(); t = time.perf_counter(); step(); torch.cuda.synchronize()
     print("STEP %d: %.2f ms" % (i, (time.perf_counter() - t) * 1e3))
 pr = cProfile.Profile(); pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get("STEPPROF_TOP", "22")))
+if os.environ.get("STEPPROF_CUM"): pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
