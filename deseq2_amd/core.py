@@ -18,6 +18,34 @@ from .engine import HostEngine
 
 LOG2E = np.log2(np.e)
 
+# facts about a model matrix (rank, design cells) are asked for several times per DESeq(); they depend
+# on the m x p matrix only, so they are memoised on its bytes
+_DESIGN_CACHE = {}
+
+
+def _design_fact(kind, x, fn):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    key = (kind, x.shape, x.tobytes())
+    v = _DESIGN_CACHE.get(key)
+    if v is None:
+        if len(_DESIGN_CACHE) > 256:
+            _DESIGN_CACHE.clear()
+        v = _DESIGN_CACHE[key] = fn(x)
+    return v
+
+
+def _rank(x):
+    return _design_fact("rank", x, lambda a: int(np.linalg.matrix_rank(a)))
+
+
+def _cells(x):
+    """(cell id per sample, size of that sample's cell): samples with identical model-matrix rows"""
+    def f(a):
+        _, inv, cnt = np.unique(a, axis=0, return_inverse=True, return_counts=True)
+        inv = inv.reshape(-1)
+        return inv, cnt[inv]
+    return _design_fact("cells", x, f)
+
 
 class DESeqDataSet:
     """counts (n x m int), model matrix x (m x p), size factors (m) or normalization
@@ -156,8 +184,7 @@ def getBaseMeansAndVariances(dds):
 
 def modelMatrixGroups(x):
     """R/core.R:2450-2452"""
-    _, inv = np.unique(np.asarray(x), axis=0, return_inverse=True)
-    return inv.reshape(-1)
+    return _cells(x)[0]
 
 
 # ------------------------------------------------------------------ R/fitNbinomGLMs.R
@@ -270,7 +297,7 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
                 "logLike": (E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights)
                             if want_loglike else None)}
     # initial betas by QR least squares when full rank (:139-155)
-    if np.linalg.matrix_rank(x) == p:
+    if _rank(x) == p:
         if rows is None and modelMatrix is None and "prefit" in dds.attrs:
             beta_mat = dds.attrs["prefit"]["beta_init"]
         else:
@@ -327,7 +354,7 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
         raise ValueError("for computational stability, log(minDisp/10) should be above -30")
     E = dds.engine
     x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
-    if np.linalg.matrix_rank(x) < x.shape[1]:
+    if _rank(x) < x.shape[1]:
         raise ValueError("the model matrix is not full rank")                       # checkFullRank :2624
     if x.shape[0] == x.shape[1]:
         raise ValueError("the number of samples and the number of model coefficients are equal")
@@ -752,8 +779,7 @@ def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, 
 # ------------------------------------------------------------------ count outliers
 def nOrMoreInCell(modelMatrix, n):
     """R/core.R:2366-2371: per sample, are there n or more samples with the same model-matrix row"""
-    _, inv, cnt = np.unique(np.asarray(modelMatrix, np.float64), axis=0, return_inverse=True, return_counts=True)
-    return cnt[inv.reshape(-1)] >= n
+    return _cells(modelMatrix)[1] >= n
 
 
 def calculateCooksDistance(dds, H, modelMatrix):

@@ -147,6 +147,7 @@ class DeviceEngine:
         torch.cuda.set_device(self.device)
         from . import _lib
         _lib.check(_lib.lib().dsq_set_device(self.device.index or 0))
+        self._cache = {}
         self.record = None          # set to a list to collect (name, n, ms) per fit kernel
         self.want_d2lp = False      # estimateDispersions* never read fitDisp$last_d2lp (R/core.R:784-787,1042)
 
@@ -188,7 +189,24 @@ class DeviceEngine:
         return self.native.to_gene_major(t)
 
     def design(self, x):
-        return self.torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.float64).T), device=self.device)
+        """(p, m) device copy of the model matrix, memoised on its bytes (asked for by every fit of a DESeq())"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        key = ("x", x.shape, x.tobytes())
+        v = self._cache.get(key)
+        if v is None:
+            v = self._cache[key] = self.torch.as_tensor(np.ascontiguousarray(x.T), device=self.device)
+        return v
+
+    def _design_qr_dev(self, x):
+        """device copies of Q, X R^-1, R of the (memoised) thin QR of the model matrix"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        key = ("qr", x.shape, x.tobytes())
+        v = self._cache.get(key)
+        if v is None:
+            t = self.torch
+            q, a, r = self.native.design_qr(x)
+            v = self._cache[key] = tuple(t.as_tensor(np.ascontiguousarray(z.T), device=self.device) for z in (q, a, r))
+        return v
 
     def to_numpy(self, h):
         return self._host(h.view()).numpy()
@@ -221,10 +239,7 @@ class DeviceEngine:
     # ---- O(n*m) steps around the fits: HIP kernels too (csrc/aux.hip)
     def prefit(self, y, nf, x, weights=None):
         t = self.torch
-        q, a, r = self.native.design_qr(x)           # m x p design: thin QR on the host, like stats::qr
-        dq = t.as_tensor(np.ascontiguousarray(q.T), device=self.device)
-        da = t.as_tensor(np.ascontiguousarray(a.T), device=self.device)
-        dr = t.as_tensor(np.ascontiguousarray(r.T), device=self.device)
+        dq, da, dr = self._design_qr_dev(x)          # m x p design: thin QR on the host, like stats::qr
         o = self._timed("prefit_moments", y.n, lambda: self.native.prefitMoments_dev(
             y, nf, dq, da, dr, weights, weights is not None))
         h = self._host(o["_pack"])                        # one copy for the four n-vectors
@@ -237,10 +252,7 @@ class DeviceEngine:
         return float((1.0 / nf.view().mean(dim=0)).mean())
 
     def linear_mu(self, y, nf, x_dev):
-        t = self.torch
-        q, a, r = self.native.design_qr(x_dev.t().cpu().numpy())
-        dq = t.as_tensor(np.ascontiguousarray(q.T), device=self.device)
-        da = t.as_tensor(np.ascontiguousarray(a.T), device=self.device)
+        dq, da, _ = self._design_qr_dev(x_dev.t().cpu().numpy())
         return self._timed("linear_mu", y.n, lambda: self.native.linearMu_dev(y, nf, dq, da))
 
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):

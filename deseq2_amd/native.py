@@ -140,7 +140,22 @@ def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEX
     return {"log_alpha": la}
 
 
+_QR_CACHE = {}
+
+
 def design_qr(x):
+    """memoised thin QR of a model matrix (asked for by every prefit / linear_mu call of a DESeq())"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    key = (x.shape, x.tobytes())
+    v = _QR_CACHE.get(key)
+    if v is None:
+        if len(_QR_CACHE) > 64:
+            _QR_CACHE.clear()
+        v = _QR_CACHE[key] = _design_qr(x)
+    return v
+
+
+def _design_qr(x):
     """thin QR of the model matrix, taken on the host like the reference does with stats::qr
     (R/fitNbinomGLMs.R:139-143, R/core.R:2455-2457): Q (m x p), A = X R^-1 (m x p), R (p x p)"""
     x = np.asarray(x, np.float64)
@@ -197,10 +212,20 @@ def nbinomLogLike(counts, mu, disp, weights, useWeights):
     return out
 
 
+_CELL_CACHE = {}
+
+
 def cell_index(x):
     """design cells (nOrMoreInCell, R/core.R:2366-2371): samples with identical model-matrix rows"""
-    _, inv = np.unique(np.asarray(x, np.float64), axis=0, return_inverse=True)
-    return np.ascontiguousarray(inv.reshape(-1), dtype=np.int32)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    key = (x.shape, x.tobytes())
+    v = _CELL_CACHE.get(key)
+    if v is None:
+        if len(_CELL_CACHE) > 64:
+            _CELL_CACHE.clear()
+        _, inv = np.unique(x, axis=0, return_inverse=True)
+        v = _CELL_CACHE[key] = np.ascontiguousarray(inv.reshape(-1), dtype=np.int32)
+    return v
 
 
 def cooksDistance(counts, nf, mu, H, x):
