@@ -10,26 +10,84 @@ namespace dsq {
 
 #define DSQ_DEV __device__ __forceinline__
 
+// ---- cross-lane exchange without LDS ------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip per 32-bit half).  The butterfly
+// partners lane ^ 1, 2, 4, 8 are reachable with DPP modifiers inside a row of 16 lanes and lane ^ 16, 32
+// with gfx950's v_permlane16_swap / v_permlane32_swap, all plain VALU moves.  Same partners, same
+// additions (a + b is commutative in IEEE), so the sums keep their bits; a dependent chain of
+// all-reduces runs 2.2x faster (tools/dppbench.hip) -- it matters in fitBeta's Householder replay,
+// which serialises ~14 reductions per IRLS iteration.
+template <int CTRL>
+DSQ_DEV double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+DSQ_DEV double lane_xor1(double v) { return dpp_mov<0xB1>(v); }    // quad_perm [1,0,3,2]
+DSQ_DEV double lane_xor2(double v) { return dpp_mov<0x4E>(v); }    // quad_perm [2,3,0,1]
+DSQ_DEV double lane_xor8(double v) { return dpp_mov<0x128>(v); }   // row_ror:8
+DSQ_DEV double lane_xor4(double v) {                               // row_shl:4 into banks 0,2; row_shr:4 into 1,3
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0x5, false);
+    l2 = __builtin_amdgcn_update_dpp(l2, lo, 0x114, 0xF, 0xA, false);
+    int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
+    h2 = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xF, 0xA, false);
+    return __hiloint2double(h2, l2);
+}
+typedef unsigned dsq_u2 __attribute__((ext_vector_type(2)));
+// (self, partner) across rows: swap(v, v) leaves [row0,row0,row2,row2] and [row1,row1,row3,row3]
+DSQ_DEV void lane_pair16(double v, double &a, double &b) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    dsq_u2 pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    dsq_u2 ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)ph[0], (int)pl[0]);
+    b = __hiloint2double((int)ph[1], (int)pl[1]);
+}
+DSQ_DEV void lane_pair32(double v, double &a, double &b) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    dsq_u2 pl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    dsq_u2 ph = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)ph[0], (int)pl[0]);
+    b = __hiloint2double((int)ph[1], (int)pl[1]);
+}
+
 // all-reduce: every lane ends with the same bits (a+b is commutative in IEEE).
 DSQ_DEV double wave_allreduce(double v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    v = v + lane_xor1(v);
+    v = v + lane_xor2(v);
+    v = v + lane_xor4(v);
+    v = v + lane_xor8(v);
+    double a, b;
+    lane_pair16(v, a, b); v = a + b;
+    lane_pair32(v, a, b); v = a + b;
     return v;
 }
 
 template <int N>
 DSQ_DEV void wave_allreduce_n(double (&v)[N]) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double t[N];
+    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor1(v[i]);
 #pragma unroll
-        for (int i = 0; i < N; i++) t[i] = __shfl_xor(v[i], off, 64);
+    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor2(v[i]);
 #pragma unroll
-        for (int i = 0; i < N; i++) v[i] = v[i] + t[i];
-    }
+    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor4(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor8(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) { double a, b; lane_pair16(v[i], a, b); v[i] = a + b; }
+#pragma unroll
+    for (int i = 0; i < N; i++) { double a, b; lane_pair32(v[i], a, b); v[i] = a + b; }
 }
 
 DSQ_DEV double wave_bcast(double v, int lane) { return __shfl(v, lane, 64); }
+
+// value of lane `src` (a compile-time-known or wave-uniform lane) in every lane: v_readlane, no LDS
+DSQ_DEV double lane_read(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 
 // Gene scheduling of the persistent fit kernels.  Every wave starts on gene (block * waves + wave); the
 // iteration counts of the fits are data dependent (2..100), so instead of a fixed grid stride the wave

@@ -169,15 +169,9 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                     }
                     // reductions S_kj, j = k..P, and the pivot row from lane k
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        double tt[P + 1];
+                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);    // independent chains: interleaved
 #pragma unroll
-                        for (int j = k; j <= P; j++) tt[j] = __shfl_xor(acc[j], off, 64);
-#pragma unroll
-                        for (int j = k; j <= P; j++) acc[j] = acc[j] + tt[j];
-                    }
-#pragma unroll
-                    for (int j = k; j <= P; j++) prow[j] = __shfl(prow[j], k, 64);
+                    for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
                     double alpha_k = prow[k];
                     double tau, scal, bet;
                     if (acc[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }

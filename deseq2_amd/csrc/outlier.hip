@@ -56,11 +56,13 @@ DSQ_DEV double trimmed_mean_sorted(const double *sorted, int n, double trim, int
 }
 
 DSQ_DEV double wave_max(double v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = (o > v) ? o : v;
-    }
+    double o, a, b;
+    o = lane_xor1(v); v = (o > v) ? o : v;
+    o = lane_xor2(v); v = (o > v) ? o : v;
+    o = lane_xor4(v); v = (o > v) ? o : v;
+    o = lane_xor8(v); v = (o > v) ? o : v;
+    lane_pair16(v, a, b); v = (b > a) ? b : a;
+    lane_pair32(v, a, b); v = (b > a) ? b : a;
     return v;
 }
 

@@ -315,7 +315,9 @@ class DeviceEngine:
             want_mu=want_mu, mu_floor=mu_floor))
         h = self._host(r["_pack"]).numpy()               # one device-to-host copy for all per-gene outputs
         p = (h.shape[0] - 4) // 2
-        out = {"beta_mat": np.ascontiguousarray(h[:p].T), "beta_var_mat": np.ascontiguousarray(h[p:2 * p].T),
+        # n x p matrices as column-major VIEWS of the host buffer (what R holds): no transpose copy, and the
+        # row scans of fitNbinomGLMs (is.na / <= 0 per row) run along contiguous memory
+        out = {"beta_mat": h[:p].T, "beta_var_mat": h[p:2 * p].T,
                "iter": h[2 * p], "deviance": h[2 * p + 3], "contrast_num": h[2 * p + 1].reshape(-1, 1),
                "contrast_denom": h[2 * p + 2].reshape(-1, 1), "hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}
         return out
