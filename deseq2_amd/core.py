@@ -253,9 +253,22 @@ def fitNbinomGLMsOptim(E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, wei
     return betaMatrix, betaSE, betaConv, rows, mu_rows, logLike
 
 
+def _host_vector(v):
+    """an engine may hand back an n-vector that is still on the device (engine.LaunchedVector)"""
+    return v.host() if hasattr(v, "host") else v
+
+
+class PendingFit:
+    """fitNbinomGLMs(defer = TRUE): the fit has been launched; `mu` (and `hat_diagonals`) are engine handles
+    usable at once, finish() runs the host half of R/fitNbinomGLMs.R:184-235 (row checks, optim fallback)."""
+
+    def __init__(self, mu, hat_diagonals, finish):
+        self.mu, self.hat_diagonals, self.finish = mu, hat_diagonals, finish
+
+
 def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, betaTol=1e-8, maxit=100,
                   useOptim=True, useQR=True, minmu=0.5, weights=None, useWeights=False, mu_floor=0.0,
-                  want_hat=True, forceOptim=False, weights_host=None, want_loglike=False):
+                  want_hat=True, forceOptim=False, weights_host=None, want_loglike=False, defer=False):
     """R/fitNbinomGLMs.R:29-236.  Rows the IRLS does not fit (`rowsForOptim`, :203-211) go through the
     reference's L-BFGS-B fallback on the host (fitNbinomGLMsOptim, :213-227), as in R.  logLike
     (:182) is computed only when the caller reads it (want_loglike)."""
@@ -290,12 +303,13 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         mu_h = nfh * (2.0 ** b)[:, None]
         wd = (wh if useWeights else 1.0) / (1.0 / mu_h + alpha_hat[:, None])
         xtwx = wd.sum(1)
-        return {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
+        res = {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
                 "mu": E.matrix(mu_h), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
                 "hat_diagonals": E.matrix(wd / xtwx[:, None]), "deviance_native": None,
                 "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E, "optimRows": None,
-                "logLike": (E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights)
+                "logLike": (_host_vector(E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights))
                             if want_loglike else None)}
+        return PendingFit(res["mu"], res["hat_diagonals"], lambda: res) if defer else res
     # initial betas by QR least squares when full rank (:139-155)
     if _rank(x) == p:
         if rows is None and modelMatrix is None and "prefit" in dds.attrs:
@@ -315,34 +329,41 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
     _na_guard("fitBeta", alpha_hatSEXP=alpha_hat, lambdaSEXP=lambdaNatLogScale)
     betaRes = E.fit_beta(y, xh, nf, alpha_hat, contrast, beta_mat, lambdaNatLogScale, weights, useWeights,
                          betaTol, maxit, useQR, minmu, want_mu=True, mu_floor=mu_floor, want_hat=want_hat)
-    mu = betaRes["mu"]                                                             # :180
-    rowStable = ~np.isnan(betaRes["beta_mat"]).any(axis=1)                         # :185
-    rowVarPositive = ~(betaRes["beta_var_mat"] <= 0).any(axis=1)                   # :188
-    betaConv = betaRes["iter"] < maxit                                             # :191
-    betaMatrix = LOG2E * betaRes["beta_mat"]                                       # :194
-    betaSE = LOG2E * np.sqrt(np.maximum(betaRes["beta_var_mat"], 0))               # :198
-    if useOptim:
-        rowsForOptim = np.where(~betaConv | ~rowStable | ~rowVarPositive)[0]       # :203-207
-    else:
-        rowsForOptim = np.where(~rowStable | ~rowVarPositive)[0]
-    if forceOptim:
-        rowsForOptim = np.arange(n)                                                # :209-211
-    logLike = E.nbinom_loglike(y, mu, alpha_hat, weights, useWeights) if want_loglike else None   # :182
-    optimRows = None
-    if len(rowsForOptim) > 0:                                                      # :213-227
-        ll = np.full(n, np.nan)
-        b0 = E.to_numpy_np(beta_mat) if hasattr(E, "to_numpy_np") else beta_mat
-        betaMatrix, betaSE, betaConv, optimRows, optimMu, ll = fitNbinomGLMsOptim(
-            E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, weights, useWeights, betaMatrix.copy(),
-            betaSE.copy(), betaConv.copy(), b0, ll, minmu=minmu)
-        mu = E.put_rows(mu, optimRows, np.maximum(optimMu, mu_floor))              # mu[row,] <- mu_row  (:386)
-        if logLike is not None:
-            logLike[optimRows] = ll[optimRows]                                     # :399
-    return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu, "logLike": logLike,
-            "optimRows": optimRows,
-            "betaIter": betaRes["iter"], "modelMatrix": x, "nterms": p,
-            "hat_diagonals": betaRes.get("hat_diagonals"), "deviance_native": betaRes["deviance"],
-            "rowsForOptim": rowsForOptim, "beta_natlog": betaRes["beta_mat"]}
+    mu0 = betaRes["mu"]                                                            # :180
+    # launched before the host reads anything back, so the row checks below overlap it (:182)
+    logLike0 = E.nbinom_loglike(y, mu0, alpha_hat, weights, useWeights) if want_loglike else None
+
+    def finish():
+        mu = mu0
+        rowStable = ~np.isnan(betaRes["beta_mat"]).any(axis=1)                     # :185
+        rowVarPositive = ~(betaRes["beta_var_mat"] <= 0).any(axis=1)               # :188
+        betaConv = betaRes["iter"] < maxit                                         # :191
+        betaMatrix = LOG2E * betaRes["beta_mat"]                                   # :194
+        betaSE = LOG2E * np.sqrt(np.maximum(betaRes["beta_var_mat"], 0))           # :198
+        if useOptim:
+            rowsForOptim = np.where(~betaConv | ~rowStable | ~rowVarPositive)[0]   # :203-207
+        else:
+            rowsForOptim = np.where(~rowStable | ~rowVarPositive)[0]
+        if forceOptim:
+            rowsForOptim = np.arange(n)                                            # :209-211
+        logLike = _host_vector(logLike0)
+        optimRows = None
+        if len(rowsForOptim) > 0:                                                  # :213-227
+            ll = np.full(n, np.nan)
+            b0 = E.to_numpy_np(beta_mat) if hasattr(E, "to_numpy_np") else beta_mat
+            betaMatrix, betaSE, betaConv, optimRows, optimMu, ll = fitNbinomGLMsOptim(
+                E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, weights, useWeights, betaMatrix.copy(),
+                betaSE.copy(), betaConv.copy(), b0, ll, minmu=minmu)
+            mu = E.put_rows(mu, optimRows, np.maximum(optimMu, mu_floor))          # mu[row,] <- mu_row  (:386)
+            if logLike is not None:
+                logLike = np.array(logLike, copy=True)
+                logLike[optimRows] = ll[optimRows]                                 # :399
+        return {"betaConv": betaConv, "betaMatrix": betaMatrix, "betaSE": betaSE, "mu": mu, "logLike": logLike,
+                "optimRows": optimRows,
+                "betaIter": betaRes["iter"], "modelMatrix": x, "nterms": p,
+                "hat_diagonals": betaRes.get("hat_diagonals"), "deviance_native": betaRes["deviance"],
+                "rowsForOptim": rowsForOptim, "beta_natlog": betaRes["beta_mat"]}
+    return PendingFit(mu0, betaRes.get("hat_diagonals") if want_hat else None, finish) if defer else finish()
 
 
 # ------------------------------------------------------------------ dispersions
@@ -380,16 +401,30 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
     alpha_hat = alpha_init = np.minimum(np.maximum(minDisp, alpha_hat), maxDisp)    # :727-728
     if linearMu is None:
         linearMu = (len(np.unique(modelMatrixGroups(x))) == x.shape[1]) and not useWeights   # :735-742
+    la0 = np.log(alpha_hat)
+    xh = dds.xh if modelMatrix is None else E.design(x)
+
+    def fit_disp(y, mu, la, w):
+        return E.fit_disp(y, xh, mu, la, la, 1.0, np.log(minDisp / 10), kappa_0, dispTol, maxit, False, w,
+                          useWeights, weightThreshold, useCR)                       # :771-782
     if not linearMu:
-        fit = fitNbinomGLMs(dds, alpha_hat=alpha_hat, modelMatrix=modelMatrix, weights=weights_glm,
-                            useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False)   # :755-757
+        # The GLM fit is launched, the dispersion search is launched on its mu right behind it, and only then
+        # does the host half of fitNbinomGLMs (row checks, optim fallback) run -- overlapping the search.  Genes
+        # are independent: rows whose mu the optim fallback replaces (:386) get their search redone below.
+        pend = fitNbinomGLMs(dds, alpha_hat=alpha_hat, modelMatrix=modelMatrix, weights=weights_glm,
+                             useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False, defer=True)   # :755-757
+        dispRes = fit_disp(dds.y, pend.mu, la0, weights)
+        fit = pend.finish()
         mu = fit["mu"]                                                              # clamped at minmu (:763)
+        if fit["optimRows"] is not None and len(fit["optimRows"]) > 0:
+            idx = np.asarray(fit["optimRows"])
+            sub = fit_disp(E.take_rows(dds.y, idx), E.take_rows(mu, idx), la0[idx], E.take_rows(weights, idx))
+            dispRes = {k: np.array(dispRes[k], copy=True) for k in sub.keys()}
+            for k in dispRes:
+                dispRes[k][idx] = sub[k]
     else:
         mu = E.clamp_min(E.linear_mu(dds.y, dds.nf, dds.xh), minmu)                 # :760,763
-    la0 = np.log(alpha_hat)
-    dispRes = E.fit_disp(dds.y, dds.xh if modelMatrix is None else E.design(x), mu, la0, la0, 1.0,
-                         np.log(minDisp / 10), kappa_0, dispTol, maxit, False, weights, useWeights,
-                         weightThreshold, useCR)                                    # :771-782
+        dispRes = fit_disp(dds.y, mu, la0, weights)
     dispIter = dispRes["iter"]
     alpha_hat_new = np.minimum(np.exp(dispRes["log_alpha"]), maxDisp)               # :785
     dispGeneEst = alpha_hat_new.copy()

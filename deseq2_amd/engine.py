@@ -23,6 +23,55 @@ import numpy as np
 _PROF_LOCK = threading.Lock()
 
 
+class Launched(dict):
+    """Results of a kernel that has been LAUNCHED: n x m device handles are in the dict at once; the per-gene
+    host arrays arrive (one device-to-host copy + stream sync) the first time one of them is read.  A caller
+    that launches its next kernel before touching the host arrays overlaps its own host code with the GPU."""
+
+    def __init__(self, ready, fetch):
+        super().__init__(ready)
+        self._fetch = fetch
+
+    def _materialize(self):
+        if self._fetch is not None:
+            f, self._fetch = self._fetch, None
+            super().update(f())
+
+    def __getitem__(self, k):
+        if not super().__contains__(k):
+            self._materialize()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        if not super().__contains__(k):
+            self._materialize()
+        return super().get(k, default)
+
+    def __contains__(self, k):
+        self._materialize()
+        return super().__contains__(k)
+
+    def items(self):
+        self._materialize()
+        return super().items()
+
+    def keys(self):
+        self._materialize()
+        return super().keys()
+
+
+class LaunchedVector:
+    """an n-vector still on the device; .host() copies it (once)"""
+
+    def __init__(self, fetch):
+        self._fetch, self._v = fetch, None
+
+    def host(self):
+        if self._fetch is not None:
+            self._v, self._fetch = self._fetch(), None
+        return self._v
+
+
 class HostEngine:
     name = "host"
 
@@ -175,7 +224,13 @@ class DeviceEngine:
         return h
 
     def _vec(self, a):
-        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+        """host vector -> device, through pinned memory and WITHOUT blocking the host: a pageable copy on the
+        (null) stream would wait for every kernel launched before it, i.e. serialise launch and host code"""
+        t = self.torch
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        h = t.empty(a.shape, dtype=t.float64, pin_memory=True)
+        h.numpy()[...] = a
+        return h.to(self.device, non_blocking=True)
 
     # ---- handles
     def counts(self, K):
@@ -258,7 +313,7 @@ class DeviceEngine:
     def nbinom_loglike(self, y, mu, disp, weights, useWeights):
         dv = self._vec(disp)
         o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
-        return self._host(o).numpy()
+        return LaunchedVector(lambda: self._host(o).numpy())
 
     def parametric_fit(self, means, disps):
         dm, dd = self._vec(means), self._vec(disps)
@@ -313,14 +368,14 @@ class DeviceEngine:
         r = self._timed("fit_beta", y.n, lambda: self.native.fitBeta_dev(
             y, x, nf, av, cv, b0, lv, weights, useWeights, tol, maxit, useQR, minmu, want_hat=want_hat,
             want_mu=want_mu, mu_floor=mu_floor))
-        h = self._host(r["_pack"]).numpy()               # one device-to-host copy for all per-gene outputs
-        p = (h.shape[0] - 4) // 2
-        # n x p matrices as column-major VIEWS of the host buffer (what R holds): no transpose copy, and the
-        # row scans of fitNbinomGLMs (is.na / <= 0 per row) run along contiguous memory
-        out = {"beta_mat": h[:p].T, "beta_var_mat": h[p:2 * p].T,
-               "iter": h[2 * p], "deviance": h[2 * p + 3], "contrast_num": h[2 * p + 1].reshape(-1, 1),
-               "contrast_denom": h[2 * p + 2].reshape(-1, 1), "hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}
-        return out
+        def fetch():
+            h = self._host(r["_pack"]).numpy()           # one device-to-host copy for all per-gene outputs
+            p = (h.shape[0] - 4) // 2
+            # n x p matrices as column-major VIEWS of the host buffer (what R holds): no transpose copy, and the
+            # row scans of fitNbinomGLMs (is.na / <= 0 per row) run along contiguous memory
+            return {"beta_mat": h[:p].T, "beta_var_mat": h[p:2 * p].T, "iter": h[2 * p], "deviance": h[2 * p + 3],
+                    "contrast_num": h[2 * p + 1].reshape(-1, 1), "contrast_denom": h[2 * p + 2].reshape(-1, 1)}
+        return Launched({"hat_diagonals": r["hat_diagonals"], "mu": r["mu"]}, fetch)
 
     def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
                  usePrior, weights, useWeights, weightThreshold, useCR):
@@ -331,12 +386,14 @@ class DeviceEngine:
         r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
             y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
             weightThreshold, useCR, want_d2lp=self.want_d2lp))
-        h = self._host(r.pop("_pack"))                   # one copy; the views below index the host buffer
-        keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
-        out = {k: h[i].numpy() for i, k in enumerate(keys) if k in r}
-        ints = h[len(keys)].view(self.torch.int32)
-        out["iter"], out["iter_accept"] = ints[:n].numpy(), ints[n:].numpy()
-        return out
+        def fetch():
+            h = self._host(r.pop("_pack"))               # one copy; the views below index the host buffer
+            keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
+            out = {k: h[i].numpy() for i, k in enumerate(keys) if k in r}
+            ints = h[len(keys)].view(self.torch.int32)
+            out["iter"], out["iter_accept"] = ints[:n].numpy(), ints[n:].numpy()
+            return out
+        return Launched({}, fetch)
 
     def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,
                       weightThreshold, useCR):
