@@ -101,6 +101,7 @@ static int lu_decomp(int q, double *a, int *piv, double *rdiag) {
     return sign;
 }
 static double lu_det(int q, const double *lu, int sign) {
+    if (q == 0) return 1.0;   /* every row below the weight threshold (:41-43): det of the 0 x 0 matrix is 1 */
     double d = lu[0];
     for (int i = 1; i < q; i++) d = d * lu[i * q + i];
     return sign < 0 ? -d : d;

@@ -1,0 +1,111 @@
+"""-m gpu: edge cases and a seeded sweep over shapes for the three native routines (HIP vs oracle, every
+output identical): empty and one-gene inputs, the smallest designs, all-zero and huge counts, the
+dispersion clamps, rows whose weights are all zero, every compiled design width."""
+import numpy as np
+import pytest
+
+from deseq2_amd import native, simulate
+from tests.helpers import assert_same, beta_init_qr, rough_alpha
+
+pytestmark = pytest.mark.gpu
+
+BETA_KEYS = ["iter", "beta_mat", "beta_var_mat", "deviance", "contrast_num", "contrast_denom", "hat_diagonals"]
+DISP_KEYS = ["iter", "iter_accept", "log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp",
+             "last_d2lp"]
+
+
+def _both(oracle, y, x, nf, alpha, w, useW, useQR=True, lam=1e-6, prior=False):
+    n, m = y.shape
+    p = x.shape[1]
+    with np.errstate(all="ignore"):
+        b0 = beta_init_qr(y.astype(float), nf, x) if np.linalg.matrix_rank(x) == p else np.zeros((n, p))
+    b0 = np.nan_to_num(b0)
+    lamv = np.full(p, lam) / np.log(2) ** 2
+    bargs = (y, x, nf, alpha, np.r_[1.0, np.zeros(p - 1)], b0, lamv, w, useW, 1e-8, 100, useQR, 0.5)
+    gb, ob = native.fitBeta(*bargs), oracle.fitBeta(*bargs)
+    for k in BETA_KEYS:
+        assert_same(gb[k], ob[k], "fitBeta$" + k)
+    mu = oracle.fittedMu(x, nf, ob["beta_mat"], 0.5) if n else np.zeros((0, m))
+    mu = np.where(np.isfinite(mu), mu, 0.5)
+    la = np.log(alpha)
+    dargs = (y, x, mu, la, la - 0.1, 0.8, np.log(1e-9), 1.0, 1e-6, 100, prior, np.maximum(w, 1e-6) if useW else w, useW,
+             1e-2, True)
+    gd, od = native.fitDisp(*dargs), oracle.fitDisp(*dargs)
+    for k in DISP_KEYS:
+        assert_same(gd[k], od[k], "fitDisp$" + k)
+    grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 12)
+    gargs = (y, x, mu, grid, la, 1.0, prior, dargs[11], useW, 1e-2, True)
+    assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"], "fitDispGrid")
+    return gb, gd
+
+
+def test_empty_and_single_gene(oracle):
+    x = simulate.design_two_group(8)
+    for n in (0, 1):
+        y = np.full((n, 8), 7, dtype=np.int32)
+        _both(oracle, y, x, np.ones((n, 8)), np.full(n, 0.1), np.ones((n, 8)), False)
+
+
+@pytest.mark.parametrize("m,p", [(2, 1), (3, 1), (3, 2), (4, 3), (11, 10), (64, 1), (65, 2), (128, 4), (129, 5)])
+def test_smallest_and_boundary_shapes(oracle, m, p):
+    rng = np.random.default_rng(m * 16 + p)
+    x = np.column_stack([np.ones(m)] + [rng.normal(size=m) for _ in range(p - 1)]) if p > 1 else np.ones((m, 1))
+    y = rng.negative_binomial(2.0, 0.02, size=(37, m)).astype(np.int32)
+    _both(oracle, y, x, np.exp(rng.normal(0, 0.2, (37, m))), rng.uniform(0.01, 2.0, 37), np.ones((37, m)), False)
+
+
+def test_zero_rows_huge_counts_and_clamps(oracle):
+    m = 12
+    x = simulate.design_two_group(m)
+    rng = np.random.default_rng(5)
+    y = rng.negative_binomial(1.5, 0.01, size=(40, m)).astype(np.int32)
+    y[0] = 0                                           # an all-zero gene: mu pinned at minmu
+    y[1] = 0; y[1, 0] = 1                              # a single count
+    y[2] = 2 ** 31 - 1                                 # the largest INTSXP count
+    y[3] = [2 ** 31 - 1] + [0] * (m - 1)
+    y[4, :6] = 0                                       # a whole group at zero: beta runs away, |beta| > 30 abort
+    alpha = rng.uniform(0.05, 1.0, 40)
+    alpha[5], alpha[6], alpha[7] = 1e-8, 10.0, float(m)   # minDisp clamp, maxDisp clamps of R/core.R:727-728
+    _both(oracle, y, x, np.ones((40, m)), alpha, np.ones((40, m)), False)
+    _both(oracle, y, x, np.ones((40, m)), alpha, np.ones((40, m)), False, useQR=False, prior=True)
+
+
+def test_weight_edge_cases(oracle):
+    m = 16
+    x = simulate.design_batch_condition(m)
+    rng = np.random.default_rng(6)
+    y = rng.negative_binomial(2.0, 0.05, size=(30, m)).astype(np.int32)
+    w = rng.uniform(0.0, 1.0, (30, m))
+    w[0] = 0.0                                         # every observation of a gene weighted out
+    w[1, 1:] = 0.0                                     # one observation left
+    w[2, x[:, 1] == 1] = 0.0                           # a design column loses all its samples (:42 drops it)
+    w[3] = 1.0
+    _both(oracle, y, x, np.ones((30, m)), rng.uniform(0.05, 1.0, 30), w, True)
+    _both(oracle, y, x, np.ones((30, m)), rng.uniform(0.05, 1.0, 30), w, True, useQR=False, lam=0.5, prior=True)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_seeded_shape_sweep(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.integers(1, 11))
+    m = int(rng.integers(p + 1, 260))
+    n = int(rng.integers(1, 70))
+    cols = [np.ones(m)]
+    for c in range(p - 1):
+        cols.append(rng.normal(size=m) if rng.uniform() < 0.5 else (rng.uniform(size=m) < 0.4).astype(float))
+    x = np.column_stack(cols)
+    if np.linalg.matrix_rank(x) < p:
+        x[:, 1:] += rng.normal(0, 0.1, (m, p - 1))
+    mu = np.exp(rng.normal(3, 1.5, (n, 1))) * np.exp(rng.normal(0, 0.3, (n, m)))
+    size = 1.0 / rng.uniform(0.02, 2.0, (n, 1))
+    y = rng.negative_binomial(np.broadcast_to(size, mu.shape), size / (size + mu)).astype(np.int32)
+    nf = np.exp(rng.normal(0, 0.25, (n, m)))
+    useW = bool(rng.uniform() < 0.5)
+    w = rng.uniform(0.05, 1.0, (n, m)) if useW else np.ones((n, m))
+    if useW:
+        w[rng.uniform(size=w.shape) < 0.03] = 0.0
+    with np.errstate(all="ignore"):
+        alpha = rough_alpha(y.astype(float), nf, x) if m > p else np.full(n, 0.1)
+    alpha = np.nan_to_num(alpha, nan=0.1)
+    _both(oracle, y, x, nf, alpha, w, useW, useQR=bool(rng.uniform() < 0.6), lam=float(10 ** rng.uniform(-6, 0)),
+          prior=bool(rng.uniform() < 0.5))

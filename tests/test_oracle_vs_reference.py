@@ -156,3 +156,39 @@ def test_golden_file_is_current():
     for fn, dd in res.items():
         for k, v in dd.items():
             np.testing.assert_array_equal(np.asarray(v), z["%s/%s/%s" % (name, fn, k)])
+
+
+@pytest.mark.skipif(not _have_ref(), reason="oracle/_ref/libdeseq2_ref.so not built (needs /root/reference)")
+def test_weight_subsetting_edge_cases_vs_reference(oracle):
+    """src/DESeq2.cpp:39-43: rows with weight <= threshold are dropped from the Cox-Reid matrix, then the
+    design columns that are left all-zero.  Every observation weighted out (a 0 x 0 matrix, det = 1), a single
+    observation left, a design column that loses all its samples."""
+    from oracle import reference
+    from deseq2_amd import simulate
+    from tests.helpers import beta_init_qr
+    m, n, p = 16, 30, 4
+    x = simulate.design_batch_condition(m)
+    rng = np.random.default_rng(6)
+    y = rng.negative_binomial(2.0, 0.05, size=(n, m)).astype(float)
+    w = rng.uniform(0.0, 1.0, (n, m))
+    w[0] = 0.0
+    w[1, 1:] = 0.0
+    w[2, x[:, 1] == 1] = 0.0
+    w[3] = 1.0
+    alpha = rng.uniform(0.05, 1.0, n)
+    nf = np.ones((n, m))
+    bargs = (y, x, nf, alpha, np.r_[1.0, 0, 0, 0], beta_init_qr(y, nf, x), np.full(p, 1e-6) / np.log(2) ** 2, w, True,
+             1e-8, 100, True, 0.5)
+    ob, rb = oracle.fitBeta(*bargs), reference.fitBeta(*bargs)
+    np.testing.assert_array_equal(ob["iter"], rb["iter"])
+    ok = rb["iter"] < 100
+    np.testing.assert_allclose(ob["beta_mat"][ok], rb["beta_mat"][ok], rtol=1e-7, atol=1e-10)
+    mu = np.where(np.isfinite(oracle.fittedMu(x, nf, ob["beta_mat"], 0.5)), oracle.fittedMu(x, nf, ob["beta_mat"], 0.5), 0.5)
+    la = np.log(alpha)
+    for prior in (False, True):
+        dargs = (y, x, mu, la, la - 0.1, 0.8, np.log(1e-9), 1.0, 1e-6, 100, prior, np.maximum(w, 1e-6), True, 1e-2, True)
+        od, rd = oracle.fitDisp(*dargs), reference.fitDisp(*dargs)
+        for k in FLAGS:
+            np.testing.assert_array_equal(od[k], rd[k], err_msg="fitDisp$" + k)
+        for k in ("log_alpha", "initial_lp", "initial_dlp", "last_lp", "last_d2lp"):
+            np.testing.assert_allclose(od[k], rd[k], rtol=1e-7, atol=1e-9, err_msg="fitDisp$" + k)
