@@ -40,6 +40,21 @@ DSQ_DEV void wave_sort(double *b, int n2, int lane) {
     }
 }
 
+// ascending sort of a BITONIC sequence b[0..n2) (first falling, then rising -- what squared deviations of an
+// ascending array from a value inside its range are): the last merge pass of the network is enough
+DSQ_DEV void wave_merge_bitonic(double *b, int n2, int lane) {
+    wave_lds_sync();
+    for (int j = n2 >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < (n2 >> 1); t += 64) {
+            int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            int hi = lo | j;
+            double a = b[lo], c = b[hi];
+            if (a > c) { b[lo] = c; b[hi] = a; }
+        }
+        wave_lds_sync();
+    }
+}
+
 DSQ_DEV int pow2_at_least(int n) {
     int v = 2;
     while (v < n) v <<= 1;
@@ -100,11 +115,12 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                 wave_sort(buf, n2, lane);
                 const double cm = trimmed_mean_sorted(buf, nc, trim, lane);
                 wave_lds_sync();
-                for (int k = lane; k < n2; k += 64) {
-                    double d = k < nc ? cn[kp.perm[s0 + k]] - cm : 0.0;
-                    buf[k] = k < nc ? d * d : inf;
+                // squared deviations of the SORTED values: falling, then rising (+inf padding keeps rising)
+                for (int k = lane; k < nc; k += 64) {
+                    double d = buf[k] - cm;
+                    buf[k] = d * d;
                 }
-                wave_sort(buf, n2, lane);
+                wave_merge_bitonic(buf, n2, lane);
                 const double ve = scale * trimmed_mean_sorted(buf, nc, trim, lane);
                 if (ve > v) v = ve;
             }
@@ -115,11 +131,11 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
             wave_sort(buf, n2, lane);
             const double rm = trimmed_mean_sorted(buf, m, 1.0 / 8.0, lane);
             wave_lds_sync();
-            for (int k = lane; k < n2; k += 64) {
-                double d = k < m ? cn[k] - rm : 0.0;
-                buf[k] = k < m ? d * d : inf;
+            for (int k = lane; k < m; k += 64) {
+                double d = buf[k] - rm;
+                buf[k] = d * d;
             }
-            wave_sort(buf, n2, lane);
+            wave_merge_bitonic(buf, n2, lane);
             v = 1.51 * trimmed_mean_sorted(buf, m, 1.0 / 8.0, lane);
         }
         double alpha = (v - mean_all) / (mean_all * mean_all);
