@@ -302,6 +302,12 @@ hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok)
     case 8: return launch_prefit_p<8>(kp, st);
     case 9: return launch_prefit_p<9>(kp, st);
     case 10: return launch_prefit_p<10>(kp, st);
+    case 11: return launch_prefit_p<11>(kp, st);
+    case 12: return launch_prefit_p<12>(kp, st);
+    case 13: return launch_prefit_p<13>(kp, st);
+    case 14: return launch_prefit_p<14>(kp, st);
+    case 15: return launch_prefit_p<15>(kp, st);
+    case 16: return launch_prefit_p<16>(kp, st);
     default: *ok = false; return hipSuccess;
     }
 }
@@ -325,6 +331,12 @@ hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, doubl
     case 8: return launch_linear_mu_p<8>(kp, mu_floor, mu, st);
     case 9: return launch_linear_mu_p<9>(kp, mu_floor, mu, st);
     case 10: return launch_linear_mu_p<10>(kp, mu_floor, mu, st);
+    case 11: return launch_linear_mu_p<11>(kp, mu_floor, mu, st);
+    case 12: return launch_linear_mu_p<12>(kp, mu_floor, mu, st);
+    case 13: return launch_linear_mu_p<13>(kp, mu_floor, mu, st);
+    case 14: return launch_linear_mu_p<14>(kp, mu_floor, mu, st);
+    case 15: return launch_linear_mu_p<15>(kp, mu_floor, mu, st);
+    case 16: return launch_linear_mu_p<16>(kp, mu_floor, mu, st);
     default: *ok = false; return hipSuccess;
     }
 }

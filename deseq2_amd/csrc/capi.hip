@@ -105,7 +105,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
 }
 
 enum {  // workspace slots
-    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER, WS_TREND,
+    WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER, WS_TREND, WS_PAD_X, WS_PAD_VEC, WS_PAD_BETA,
     // host-entry staging
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
@@ -203,12 +203,40 @@ struct DispatchP<0> {
     static hipError_t disp(int, const DispKernelParams &, hipStream_t, bool, bool *ok) { *ok = false; return hipSuccess; }
 };
 
+// ---- wide designs (DSQ_P_REG < p <= DSQ_P_WIDE): zero-padded to DSQ_P_WIDE columns --------------------------
+// A padded coefficient has an all-zero design column, ridge 1 and start value 0: its estimate is exactly 0 and the
+// Gram / QR / LU arithmetic of the real coefficients sees only extra exact zeros (x + 0 = x, 0 * y = 0), so their
+// results keep their bits (tests/test_gpu_wide.py compares with the oracle run at the true p).
+static inline bool is_wide(int p) { return p > DSQ_P_REG && p <= DSQ_P_WIDE; }
+
+static int wide_pad_matrix(int slot, const double *src, size_t rows, int p, double fill_ones_from, hipStream_t st,
+                           double **out) {
+    // column-major rows x p  ->  rows x DSQ_P_WIDE (new columns 0, or 1 when fill_ones_from >= 0: vectors only)
+    void *b;
+    int rc = ws_get(slot, rows * DSQ_P_WIDE * sizeof(double), &b);
+    if (rc) return rc;
+    DSQ_HIP(hipMemsetAsync(b, 0, rows * DSQ_P_WIDE * sizeof(double), st));
+    DSQ_HIP(hipMemcpyAsync(b, src, rows * (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, st));
+    (void)fill_ones_from;
+    *out = (double *)b;
+    return DSQ_OK;
+}
+
+static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const double **xout, unsigned *padmask) {
+    double *b;
+    int rc = wide_pad_matrix(WS_PAD_X, x, (size_t)m, p, -1, st, &b);
+    if (rc) return rc;
+    *xout = b;
+    *padmask = ((1u << DSQ_P_WIDE) - 1u) & ~((1u << p) - 1u);
+    return DSQ_OK;
+}
+
 // =============================================================== fitBeta (device)
 static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, hipStream_t st) {
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
-    if (a->p > DSQ_P_REG)
-        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    if (a->p > DSQ_P_WIDE)
+        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_WIDE);
     if (!a->y || !a->x || !a->nf || !a->alpha_hat || !a->contrast || !a->beta_mat || !a->lambda)
         return fail(DSQ_ERR_ARG, "NULL input array");
     if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
@@ -246,6 +274,30 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
+    const bool wide = is_wide(a->p);
+    const int pk = wide ? DSQ_P_WIDE : a->p;       // the kernel's design width
+    double *wide_out = nullptr;
+    if (wide) {
+        unsigned padmask;
+        rc = wide_pad_x(a->m, a->p, a->x, st, &kp.x, &padmask); if (rc) return rc;
+        static const double ones[DSQ_P_WIDE] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        void *v;
+        rc = ws_get(WS_PAD_VEC, 2 * DSQ_P_WIDE * sizeof(double), &v); if (rc) return rc;
+        double *vec = (double *)v;
+        DSQ_HIP(hipMemcpyAsync(vec, ones, sizeof ones, hipMemcpyHostToDevice, st));                 // ridge 1 on padding
+        DSQ_HIP(hipMemcpyAsync(vec, a->lambda, a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
+        DSQ_HIP(hipMemsetAsync(vec + DSQ_P_WIDE, 0, DSQ_P_WIDE * sizeof(double), st));
+        DSQ_HIP(hipMemcpyAsync(vec + DSQ_P_WIDE, a->contrast, a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
+        kp.lambda = vec; kp.contrast = vec + DSQ_P_WIDE;
+        rc = ws_get(WS_PAD_BETA, 3 * (size_t)a->n * DSQ_P_WIDE * sizeof(double), &v); if (rc) return rc;
+        double *bb = (double *)v;
+        const size_t np16 = (size_t)a->n * DSQ_P_WIDE;
+        DSQ_HIP(hipMemsetAsync(bb, 0, np16 * sizeof(double), st));
+        DSQ_HIP(hipMemcpyAsync(bb, a->beta_mat, (size_t)a->n * a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
+        kp.beta_init = bb; kp.beta_mat = bb + np16; kp.beta_var_mat = bb + 2 * np16;
+        wide_out = bb + np16;
+        kp.p = pk;
+    }
     // n x m outputs: directly when gene-major, through a workspace when R layout
     double *hat_ws = nullptr, *mu_ws = nullptr;
     if (o->hat_diagonals) {
@@ -263,7 +315,8 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         }
     }
     size_t slab_d = 0, cscr_d = 0;
-    DispatchP<DSQ_P_REG>::beta_scratch(a->p, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    if (wide) fit_beta_scratch_doubles<DSQ_P_WIDE>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    else DispatchP<DSQ_P_REG>::beta_scratch(a->p, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
     {
         void *b; rc = ws_get(WS_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b); if (rc) return rc;
         kp.scratch = (double *)b;
@@ -271,9 +324,15 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     }
     bool ok = false;
     prof_begin(st);
-    DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
+    if (wide) { ok = true; DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE>(kp, st)); }
+    else DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    if (wide) {     // the real coefficients are the leading columns of the padded n x 16 results
+        const size_t np16 = (size_t)a->n * DSQ_P_WIDE, npp = (size_t)a->n * a->p * sizeof(double);
+        DSQ_HIP(hipMemcpyAsync(o->beta_mat, wide_out, npp, hipMemcpyDeviceToDevice, st));
+        DSQ_HIP(hipMemcpyAsync(o->beta_var_mat, wide_out + np16, npp, hipMemcpyDeviceToDevice, st));
+    }
     if (hat_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(hat_ws, o->hat_diagonals, a->n, a->m, ld, st));
     if (mu_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(mu_ws, o->mu, a->n, a->m, ld, st));
     if (ycheck) {
@@ -291,8 +350,8 @@ static int disp_common(int n, int m, int p, int layout, long ld_in, const void *
                        const double *mu_hat, const double *weights, int useWeights, hipStream_t st,
                        DispKernelParams *kp, bool *ycheck) {
     if (n < 0 || m < 1 || p < 1) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", n, m, p);
-    if (p > DSQ_P_REG)
-        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", p, DSQ_P_REG);
+    if (p > DSQ_P_WIDE)
+        return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", p, DSQ_P_WIDE);
     if (!y || !x || !mu_hat) return fail(DSQ_ERR_ARG, "NULL input array");
     if (useWeights && !weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
     if (layout == DSQ_LAYOUT_GENE_MAJOR && ld_in < m) return fail(DSQ_ERR_ARG, "ld < m");
@@ -314,6 +373,11 @@ static int disp_common(int n, int m, int p, int layout, long ld_in, const void *
     }
     kp->x = x;
     kp->useWeights = useWeights ? 1 : 0;
+    if (is_wide(p)) {           // zero-padded design, unit diagonal on the padding in the Cox-Reid matrix
+        rc = wide_pad_x(m, p, x, st, &kp->x, &kp->padmask);
+        if (rc) return rc;
+        kp->p = DSQ_P_WIDE;
+    }
     return DSQ_OK;
 }
 
@@ -353,7 +417,8 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
     bool ok = false;
     prof_begin(st);
-    DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
+    if (is_wide(a->p)) { ok = true; DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, false)); }
+    else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);
@@ -376,7 +441,8 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     bool ok = false;
     prof_begin(st);
-    DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
+    if (is_wide(a->p)) { ok = true; DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, true)); }
+    else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);
@@ -412,7 +478,7 @@ static int prefit_dev_locked(const DsqPrefitArgs *a, const DsqPrefitOut *o, hipS
     prof_begin(st);
     DSQ_HIP(launch_prefit(kp, st, &ok));
     prof_end(st);
-    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_WIDE);
     return finish_ycheck(ycheck, st);
 }
 
@@ -444,7 +510,7 @@ static int linear_mu_dev_locked(const DsqPrefitArgs *a, double mu_floor, double 
     prof_begin(st);
     DSQ_HIP(launch_linear_mu(kp, mu_floor, dst, st, &ok));
     prof_end(st);
-    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_REG);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", a->p, DSQ_P_WIDE);
     if (a->layout != DSQ_LAYOUT_GENE_MAJOR) DSQ_HIP(launch_transpose_gm_to_r_f64(dst, mu, a->n, a->m, ld, st));
     return finish_ycheck(ycheck, st);
 }

@@ -6,6 +6,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The register-resident kernels (one translation unit per design width, -DDSQ_P=p, p <= 10) want every p-loop
+// fully unrolled so that the p x p state stays in registers.  The WIDE translation unit (-DDSQ_P=16, serving
+// 11 <= p <= 16 on zero-padded designs) keeps them as loops: the state then lives in scratch memory -- slow,
+// but it compiles in seconds instead of tens of minutes and needs no second copy of the algorithms.
+#if defined(DSQ_P) && DSQ_P > 10
+#define DSQ_UNROLL_P _Pragma("nounroll")
+#else
+#define DSQ_UNROLL_P _Pragma("unroll")
+#endif
+
 namespace dsq {
 
 #define DSQ_DEV __device__ __forceinline__
@@ -66,17 +76,17 @@ DSQ_DEV double wave_allreduce(double v) {
 
 template <int N>
 DSQ_DEV void wave_allreduce_n(double (&v)[N]) {
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor1(v[i]);
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor2(v[i]);
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor4(v[i]);
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor8(v[i]);
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) { double a, b; lane_pair16(v[i], a, b); v[i] = a + b; }
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < N; i++) { double a, b; lane_pair32(v[i], a, b); v[i] = a + b; }
 }
 
@@ -113,11 +123,11 @@ struct LU {
 
     DSQ_DEV void factor() {
         sign = 1;
-#pragma unroll
+DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
             int pr = k;
             double best = __builtin_fabs(a[k][k]);
-#pragma unroll
+DSQ_UNROLL_P
             for (int i = k + 1; i < P; i++) {
                 double v = __builtin_fabs(a[i][k]);
                 if (v > best) { best = v; pr = i; }
@@ -125,65 +135,65 @@ struct LU {
             piv[k] = pr;
             if (pr != k) {
                 sign = -sign;
-#pragma unroll
+DSQ_UNROLL_P
                 for (int i = k + 1; i < P; i++) {
                     if (i == pr) {
-#pragma unroll
+DSQ_UNROLL_P
                         for (int j = 0; j < P; j++) { double t = a[k][j]; a[k][j] = a[i][j]; a[i][j] = t; }
                     }
                 }
             }
             double rinv = 1.0 / a[k][k];
             rdiag[k] = rinv;
-#pragma unroll
+DSQ_UNROLL_P
             for (int i = k + 1; i < P; i++) {
                 double l = a[i][k] * rinv;
                 a[i][k] = l;
-#pragma unroll
+DSQ_UNROLL_P
                 for (int j = k + 1; j < P; j++) a[i][j] = __builtin_fma(-l, a[k][j], a[i][j]);
             }
         }
     }
     DSQ_DEV double det() const {
         double d = a[0][0];
-#pragma unroll
+DSQ_UNROLL_P
         for (int i = 1; i < P; i++) d = d * a[i][i];
         return sign < 0 ? -d : d;
     }
     DSQ_DEV void solve(double (&b)[P]) const {
-#pragma unroll
+DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
             int pr = piv[k];
             if (pr != k) {
-#pragma unroll
+DSQ_UNROLL_P
                 for (int i = k + 1; i < P; i++) {
                     if (i == pr) { double t = b[k]; b[k] = b[i]; b[i] = t; }
                 }
             }
         }
-#pragma unroll
+DSQ_UNROLL_P
         for (int i = 0; i < P; i++) {
             double t = b[i];
-#pragma unroll
+DSQ_UNROLL_P
             for (int j = 0; j < i; j++) t = __builtin_fma(-a[i][j], b[j], t);
             b[i] = t;
         }
-#pragma unroll
+DSQ_UNROLL_P
         for (int i = P - 1; i >= 0; i--) {
             double t = b[i];
-#pragma unroll
+DSQ_UNROLL_P
             for (int j = i + 1; j < P; j++) t = __builtin_fma(-a[i][j], b[j], t);
             b[i] = t * rdiag[i];
         }
     }
     DSQ_DEV void inverse(double (&inv)[P][P]) const {
-#pragma unroll
+DSQ_UNROLL_P
         for (int c = 0; c < P; c++) {
             double col[P];
-#pragma unroll
+DSQ_UNROLL_P
             for (int i = 0; i < P; i++) col[i] = (i == c) ? 1.0 : 0.0;
             solve(col);
-#pragma unroll
+DSQ_UNROLL_P
             for (int i = 0; i < P; i++) inv[i][c] = col[i];
         }
     }
@@ -191,12 +201,12 @@ struct LU {
 
 template <int P>
 DSQ_DEV void mat_mul(const double (&a)[P][P], const double (&b)[P][P], double (&c)[P][P]) {
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < P; i++)
-#pragma unroll
+DSQ_UNROLL_P
         for (int j = 0; j < P; j++) {
             double acc = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int k = 0; k < P; k++) acc = __builtin_fma(a[i][k], b[k][j], acc);
             c[i][j] = acc;
         }
@@ -205,9 +215,9 @@ DSQ_DEV void mat_mul(const double (&a)[P][P], const double (&b)[P][P], double (&
 template <int P>
 DSQ_DEV double trace_prod(const double (&a)[P][P], const double (&b)[P][P]) {
     double acc = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
     for (int i = 0; i < P; i++)
-#pragma unroll
+DSQ_UNROLL_P
         for (int k = 0; k < P; k++) acc = __builtin_fma(a[i][k], b[k][i], acc);
     return acc;
 }

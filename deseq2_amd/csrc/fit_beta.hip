@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     double *cg = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m;   // c1 (L2)
 
     double lambda[P], contrast[P];
-#pragma unroll
+DSQ_UNROLL_P
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
 
@@ -76,14 +76,14 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
         const double size = 1.0 / alpha;
 
         double beta[P];
-#pragma unroll
+DSQ_UNROLL_P
         for (int c = 0; c < P; c++) beta[c] = kp.beta_init[(size_t)g + (size_t)kp.n * c];
 
         // mu_hat = nfrow % exp(x * beta_hat), clamped at minmu            (:324-327, :361-364)
         auto update_mu = [&]() {
             for (int j = lane; j < m; j += 64) {
                 double eta = xs[j] * beta[0];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta[c], eta);
                 mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
             }
@@ -107,11 +107,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
         double it = 0.0;
         double beta_prev[P];          // beta the current mu slot was computed from
         bool mu_lost = false;         // QR mode overwrote mu with sqrt(w)*z and beta then diverged
-#pragma unroll
+DSQ_UNROLL_P
         for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
             if (abl & 2) {
                 // (ablated: no least-squares solve)
@@ -127,50 +127,50 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                 }
                 // pass B: Householder QR by replay                              (:344-356)
                 double scalS[P], tS[P][P + 1], Rm[P][P], gamma[P];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int k = 0; k < P; k++) {
                     double acc[P + 1];
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = 0; j <= P; j++) acc[j] = 0.0;
                     double prow[P + 1];
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = 0; j <= P; j++) prow[j] = 0.0;
                     for (int i = lane; i < M; i += 64) {
                         double a[P], b;
                         if (i < m) {
                             double sw = sw_s[i];
-#pragma unroll
+DSQ_UNROLL_P
                             for (int c = 0; c < P; c++) a[c] = xs[c * m + i] * sw;
                             b = b_s[i];
                         } else {
-#pragma unroll
+DSQ_UNROLL_P
                             for (int c = 0; c < P; c++) a[c] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
                             b = 0.0;
                         }
-#pragma unroll
+DSQ_UNROLL_P
                         for (int s = 0; s < k; s++) {
                             if (i > s) {
                                 double v = a[s] * scalS[s];
-#pragma unroll
+DSQ_UNROLL_P
                                 for (int j = s + 1; j < P; j++) a[j] = __builtin_fma(v, tS[s][j], a[j]);
                                 b = __builtin_fma(v, tS[s][P], b);
                             }
                             // rows i <= s are finished rows of R: never revisited (i >= k > s)
                         }
                         if (i > k) {
-#pragma unroll
+DSQ_UNROLL_P
                             for (int j = k; j < P; j++) acc[j] += a[k] * a[j];
                             acc[P] += a[k] * b;
                         } else if (i == k) {
-#pragma unroll
+DSQ_UNROLL_P
                             for (int j = k; j < P; j++) prow[j] = a[j];
                             prow[P] = b;
                         }
                     }
                     // reductions S_kj, j = k..P, and the pivot row from lane k
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);    // independent chains: interleaved
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
                     double alpha_k = prow[k];
                     double tau, scal, bet;
@@ -181,39 +181,39 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                         scal = 1.0 / (alpha_k - bet);
                     }
                     scalS[k] = scal;
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = k + 1; j <= P; j++) {
                         double wj = prow[j] + scal * acc[j];
                         tS[k][j] = -tau * wj;
                     }
                     Rm[k][k] = bet;
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = k + 1; j < P; j++) Rm[k][j] = prow[j] + tS[k][j];
                     gamma[k] = prow[P] + tS[k][P];
                 }
-#pragma unroll
+DSQ_UNROLL_P
                 for (int i = P - 1; i >= 0; i--) {
                     double tt = gamma[i];
-#pragma unroll
+DSQ_UNROLL_P
                     for (int j = i + 1; j < P; j++) tt = __builtin_fma(-Rm[i][j], beta[j], tt);
                     beta[i] = tt / Rm[i][i];
                 }
             } else {
                 // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))  (:398)
                 double acc[N + P];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int i = 0; i < N + P; i++) acc[i] = 0.0;
                 for (int j = lane; j < m; j += 64) {
                     double mu = mu_s[j];
                     double wv = wvec(j, mu);
                     double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
                     double xr[P];
-#pragma unroll
+DSQ_UNROLL_P
                     for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
                     int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
                     for (int a = 0; a < P; a++) {
-#pragma unroll
+DSQ_UNROLL_P
                         for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
                         acc[N + a] += xr[a] * (z * wv);
                     }
@@ -221,22 +221,22 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                 wave_allreduce_n(acc);
                 LU<P> lu;
                 int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
                 for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                     for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
-#pragma unroll
+DSQ_UNROLL_P
                 for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
                 lu.factor();
                 double rhs[P];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int a = 0; a < P; a++) rhs[a] = acc[N + a];
                 lu.solve(rhs);
-#pragma unroll
+DSQ_UNROLL_P
                 for (int a = 0; a < P; a++) beta[a] = rhs[a];
             }
             int toolarge = 0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
             if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0); break; }   // (:357-360)
             if (!(abl & 4)) update_mu();
@@ -266,40 +266,40 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
             // slot now holds sqrt(w)*z, so rebuild it from the coefficients it was computed from
             for (int j = lane; j < m; j += 64) {
                 double eta = xs[j] * beta_prev[0];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta_prev[c], eta);
                 mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
             }
         }
         double gacc[N];
-#pragma unroll
+DSQ_UNROLL_P
         for (int i = 0; i < N; i++) gacc[i] = 0.0;
         for (int j = lane; j < m; j += 64) {
             double wv = wvec(j, mu_s[j]);
             sw_s[j] = __builtin_sqrt(wv);
             double xr[P];
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
             int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
         }
         wave_allreduce_n(gacc);
         double G[P][P], Gi[P][P];
         {
             int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = a; b < P; b++) { G[a][b] = gacc[idx]; G[b][a] = gacc[idx]; idx++; }
             LU<P> lu;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = G[a][b];
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
             lu.factor();
             lu.inverse(Gi);
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                 if (kp.hat_diagonals) {
                     double sw = sw_s[j];
                     double h = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
                     for (int i1 = 0; i1 < P; i1++)
-#pragma unroll
+DSQ_UNROLL_P
                         for (int i2 = 0; i2 < P; i2++) {
                             double xw1 = xs[i1 * m + j] * sw;
                             double xw2 = xs[i2 * m + j] * sw;
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
                 }
                 if (kp.mu_out) {
                     double eta = xs[j] * beta[0];
-#pragma unroll
+DSQ_UNROLL_P
                     for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta[c], eta);
                     double v = nfg[j] * dexp(eta);
                     if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
@@ -335,18 +335,18 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
         mat_mul<P>(Gi, G, T);
         mat_mul<P>(T, Gi, Sg);
         double cn = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
         for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
         double cd = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
         for (int b = 0; b < P; b++) {
             double rr = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[a][b], rr);
             cd = __builtin_fma(rr, contrast[b], cd);
         }
         if (lane == 0) {
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) {
                 kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
                 kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[c][c];

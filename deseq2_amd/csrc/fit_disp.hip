@@ -27,6 +27,7 @@ struct DispGene {
     double prior_mean, prior_sigmasq, thr;
     bool usePrior, useCR;
     unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
+    unsigned padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
 
     DSQ_DEV bool keep_row(int j) const {
@@ -36,10 +37,10 @@ struct DispGene {
 
     // x = x.rows(find(wts > weightThreshold)); x = x.cols(find(sum(abs(x)) > 0.0))
     DSQ_DEV void setup_cr() {
-        dropmask = 0u;
+        dropmask = padmask;
         if constexpr (USE_W) {
             if (useCR) {
-#pragma unroll
+DSQ_UNROLL_P
                 for (int c = 0; c < P; c++) {
                     bool any = false;
                     for (int j = lane; j < m; j += 64)
@@ -57,41 +58,41 @@ struct DispGene {
     DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
         constexpr int N = SymN<P>::value;
         double acc[K * N];
-#pragma unroll
+DSQ_UNROLL_P
         for (int i = 0; i < K * N; i++) acc[i] = 0.0;
         for (int j = lane; j < m; j += 64) {
             double wd[K];
             wfun(r.inv_mu(j), wd);
             if (keep_row(j)) {
                 double xr[P];
-#pragma unroll
+DSQ_UNROLL_P
                 for (int c = 0; c < P; c++) xr[c] = r.x(j, c);
                 int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
                 for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                     for (int b = a; b < P; b++) {
-#pragma unroll
+DSQ_UNROLL_P
                         for (int k = 0; k < K; k++) acc[k * N + idx] += xr[a] * (xr[b] * wd[k]);
                         idx++;
                     }
             }
         }
         wave_allreduce_n(acc);
-#pragma unroll
+DSQ_UNROLL_P
         for (int k = 0; k < K; k++) {
             int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = a; b < P; b++) {
                     B[k][a][b] = acc[k * N + idx];
                     B[k][b][a] = acc[k * N + idx];
                     idx++;
                 }
         }
-        if constexpr (USE_W) {
-#pragma unroll
+        if constexpr (USE_W || (P > 10)) {
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++)
                 if (dropmask & (1u << c)) B[0][c][c] = 1.0;
         }
@@ -105,9 +106,9 @@ struct DispGene {
             double B[1][P][P];
             gram<1>([&](double imu, double(&wd)[1]) { wd[0] = 1.0 / (imu + alpha); }, B);
             LU<P> lu;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             cr_term = -0.5 * dlog(lu.det());
@@ -148,9 +149,9 @@ struct DispGene {
                 },
                 B);
             LU<P> lu;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             double detb = lu.det();
@@ -209,9 +210,9 @@ struct DispGene {
                 },
                 B);
             LU<P> lu;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             double detb = lu.det();
@@ -253,9 +254,9 @@ struct DispGene {
                 },
                 B);
             LU<P> lu;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             double detb = lu.det();
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.usePrior = kp.usePrior != 0;
         G.useCR = kp.useCR != 0;
         G.ablate = kp.ablate;
+        G.padmask = kp.padmask;
         G.setup_cr();
 
         if constexpr (MODE == 2) {

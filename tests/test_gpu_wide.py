@@ -1,0 +1,66 @@
+"""-m gpu: wide designs, 11 <= p <= 16: one generic kernel pair (loops not unrolled, p x p state in scratch memory)
+over the design zero-padded to 16 columns (csrc/capi.hip, "wide designs").  Padding must be invisible: every
+output identical to the oracle run at the TRUE p."""
+import numpy as np
+import pytest
+
+from deseq2_amd import core, native, simulate
+from deseq2_amd.engine import DeviceEngine, HostEngine
+from tests.helpers import assert_same, make_case
+
+pytestmark = pytest.mark.gpu
+
+BETA_KEYS = ["iter", "beta_mat", "beta_var_mat", "deviance", "contrast_num", "contrast_denom", "hat_diagonals"]
+DISP_KEYS = ["iter", "iter_accept", "log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp",
+             "last_d2lp"]
+
+
+@pytest.mark.parametrize("levels,m,useW,useQR", [(11, 66, False, True), (12, 60, True, True), (13, 91, False, False),
+                                                 (16, 96, True, False), (16, 160, False, True), (14, 500, False, True)])
+def test_wide_native_routines_match_oracle(oracle, levels, m, useW, useQR):
+    d = make_case(120, m, ("factor", levels), seed=levels + m, weights=useW, sf_random=True)
+    p = d["x"].shape[1]
+    assert p == levels
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    lam[3] = 0.7                                           # one real ridge penalty among the wide priors
+    contrast = np.zeros(p); contrast[0] = 1.0; contrast[p - 1] = -1.0
+    bargs = (d["counts"], d["x"], d["nf"], d["alpha_init"], contrast, d["beta_init"], lam, d["weights"], useW, 1e-8,
+             100, useQR, 0.5)
+    gb, ob = native.fitBeta(*bargs), oracle.fitBeta(*bargs)
+    for k in BETA_KEYS:
+        assert_same(gb[k], ob[k], "fitBeta$" + k)
+    assert (ob["iter"] < 100).mean() > 0.8
+    mu = oracle.fittedMu(d["x"], d["nf"], ob["beta_mat"], 0.5)
+    mu = np.where(np.isfinite(mu), mu, 0.5)
+    la = np.log(d["alpha_init"])
+    w = np.maximum(d["weights"], 1e-6) if useW else d["weights"]
+    for prior in (False, True):
+        dargs = (d["counts"], d["x"], mu, la, la - 0.1, 0.8, np.log(1e-9), 1.0, 1e-6, 100, prior, w, useW, 1e-2, True)
+        gd, od = native.fitDisp(*dargs), oracle.fitDisp(*dargs)
+        for k in DISP_KEYS:
+            assert_same(gd[k], od[k], "fitDisp$" + k)
+    grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 15)
+    gargs = (d["counts"][:40], d["x"], mu[:40], grid, la[:40], 1.0, True, w[:40], useW, 1e-2, True)
+    assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"], "fitDispGrid")
+
+
+def test_wide_chain_lrt_matches_oracle(oracle):
+    """12-level factor, nbinomLRT against the intercept: the whole DESeq() chain on the HBM-resident engine"""
+    m = 96
+    x = simulate.design_factor(m, 12)
+    d = simulate.make_counts(200, x, seed=61)
+    a = core.DESeq(core.DESeqDataSet(d["counts"], x, engine=DeviceEngine("cuda:0")), test="LRT",
+                   reduced=np.ones((m, 1)))
+    b = core.DESeq(core.DESeqDataSet(d["counts"], x, engine=HostEngine(oracle)), test="LRT", reduced=np.ones((m, 1)))
+    for k in ("dispGeneEst", "dispGeneIter", "dispersion", "dispIter", "beta", "betaSE", "LRTStatistic", "LRTPvalue",
+              "fullBetaConv", "betaIter", "deviance", "maxCooks"):
+        assert_same(a.mcols[k], b.mcols[k], "wide LRT DESeq()$" + k)
+
+
+def test_too_wide_is_refused():
+    from deseq2_amd import _lib
+    d = make_case(10, 40, ("factor", 17), seed=1)
+    p = 17
+    with pytest.raises(_lib.DsqError):
+        native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
+                       np.full(p, 1e-6), d["weights"], False, 1e-8, 100, True, 0.5)
