@@ -308,6 +308,14 @@ hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok)
     case 14: return launch_prefit_p<14>(kp, st);
     case 15: return launch_prefit_p<15>(kp, st);
     case 16: return launch_prefit_p<16>(kp, st);
+    case 17: return launch_prefit_p<17>(kp, st);
+    case 18: return launch_prefit_p<18>(kp, st);
+    case 19: return launch_prefit_p<19>(kp, st);
+    case 20: return launch_prefit_p<20>(kp, st);
+    case 21: return launch_prefit_p<21>(kp, st);
+    case 22: return launch_prefit_p<22>(kp, st);
+    case 23: return launch_prefit_p<23>(kp, st);
+    case 24: return launch_prefit_p<24>(kp, st);
     default: *ok = false; return hipSuccess;
     }
 }
@@ -337,6 +345,14 @@ hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, doubl
     case 14: return launch_linear_mu_p<14>(kp, mu_floor, mu, st);
     case 15: return launch_linear_mu_p<15>(kp, mu_floor, mu, st);
     case 16: return launch_linear_mu_p<16>(kp, mu_floor, mu, st);
+    case 17: return launch_linear_mu_p<17>(kp, mu_floor, mu, st);
+    case 18: return launch_linear_mu_p<18>(kp, mu_floor, mu, st);
+    case 19: return launch_linear_mu_p<19>(kp, mu_floor, mu, st);
+    case 20: return launch_linear_mu_p<20>(kp, mu_floor, mu, st);
+    case 21: return launch_linear_mu_p<21>(kp, mu_floor, mu, st);
+    case 22: return launch_linear_mu_p<22>(kp, mu_floor, mu, st);
+    case 23: return launch_linear_mu_p<23>(kp, mu_floor, mu, st);
+    case 24: return launch_linear_mu_p<24>(kp, mu_floor, mu, st);
     default: *ok = false; return hipSuccess;
     }
 }

@@ -208,26 +208,26 @@ struct DispatchP<0> {
 // Gram / QR / LU arithmetic of the real coefficients sees only extra exact zeros (x + 0 = x, 0 * y = 0), so their
 // results keep their bits (tests/test_gpu_wide.py compares with the oracle run at the true p).
 static inline bool is_wide(int p) { return p > DSQ_P_REG && p <= DSQ_P_WIDE; }
+static inline int wide_width(int p) { return p <= DSQ_P_WIDE0 ? DSQ_P_WIDE0 : DSQ_P_WIDE; }   // padded width for a wide p
 
-static int wide_pad_matrix(int slot, const double *src, size_t rows, int p, double fill_ones_from, hipStream_t st,
-                           double **out) {
-    // column-major rows x p  ->  rows x DSQ_P_WIDE (new columns 0, or 1 when fill_ones_from >= 0: vectors only)
+static int wide_pad_matrix(int slot, const double *src, size_t rows, int p, hipStream_t st, double **out) {
+    // column-major rows x p  ->  rows x wide_width(p), new columns zero
+    const size_t pw = wide_width(p);
     void *b;
-    int rc = ws_get(slot, rows * DSQ_P_WIDE * sizeof(double), &b);
+    int rc = ws_get(slot, rows * pw * sizeof(double), &b);
     if (rc) return rc;
-    DSQ_HIP(hipMemsetAsync(b, 0, rows * DSQ_P_WIDE * sizeof(double), st));
+    DSQ_HIP(hipMemsetAsync(b, 0, rows * pw * sizeof(double), st));
     DSQ_HIP(hipMemcpyAsync(b, src, rows * (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, st));
-    (void)fill_ones_from;
     *out = (double *)b;
     return DSQ_OK;
 }
 
 static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const double **xout, unsigned *padmask) {
     double *b;
-    int rc = wide_pad_matrix(WS_PAD_X, x, (size_t)m, p, -1, st, &b);
+    int rc = wide_pad_matrix(WS_PAD_X, x, (size_t)m, p, st, &b);
     if (rc) return rc;
     *xout = b;
-    *padmask = ((1u << DSQ_P_WIDE) - 1u) & ~((1u << p) - 1u);
+    *padmask = ((1u << wide_width(p)) - 1u) & ~((1u << p) - 1u);
     return DSQ_OK;
 }
 
@@ -275,12 +275,13 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
     const bool wide = is_wide(a->p);
-    const int pk = wide ? DSQ_P_WIDE : a->p;       // the kernel's design width
+    const int pk = wide ? wide_width(a->p) : a->p;       // the kernel's design width
     double *wide_out = nullptr;
     if (wide) {
         unsigned padmask;
         rc = wide_pad_x(a->m, a->p, a->x, st, &kp.x, &padmask); if (rc) return rc;
-        static const double ones[DSQ_P_WIDE] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        static double ones[DSQ_P_WIDE];
+        for (int c = 0; c < DSQ_P_WIDE; c++) ones[c] = 1.0;
         void *v;
         rc = ws_get(WS_PAD_VEC, 2 * DSQ_P_WIDE * sizeof(double), &v); if (rc) return rc;
         double *vec = (double *)v;
@@ -289,13 +290,13 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         DSQ_HIP(hipMemsetAsync(vec + DSQ_P_WIDE, 0, DSQ_P_WIDE * sizeof(double), st));
         DSQ_HIP(hipMemcpyAsync(vec + DSQ_P_WIDE, a->contrast, a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
         kp.lambda = vec; kp.contrast = vec + DSQ_P_WIDE;
-        rc = ws_get(WS_PAD_BETA, 3 * (size_t)a->n * DSQ_P_WIDE * sizeof(double), &v); if (rc) return rc;
+        const size_t npw = (size_t)a->n * pk;
+        rc = ws_get(WS_PAD_BETA, 3 * npw * sizeof(double), &v); if (rc) return rc;
         double *bb = (double *)v;
-        const size_t np16 = (size_t)a->n * DSQ_P_WIDE;
-        DSQ_HIP(hipMemsetAsync(bb, 0, np16 * sizeof(double), st));
+        DSQ_HIP(hipMemsetAsync(bb, 0, npw * sizeof(double), st));
         DSQ_HIP(hipMemcpyAsync(bb, a->beta_mat, (size_t)a->n * a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
-        kp.beta_init = bb; kp.beta_mat = bb + np16; kp.beta_var_mat = bb + 2 * np16;
-        wide_out = bb + np16;
+        kp.beta_init = bb; kp.beta_mat = bb + npw; kp.beta_var_mat = bb + 2 * npw;
+        wide_out = bb + npw;
         kp.p = pk;
     }
     // n x m outputs: directly when gene-major, through a workspace when R layout
@@ -315,7 +316,8 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         }
     }
     size_t slab_d = 0, cscr_d = 0;
-    if (wide) fit_beta_scratch_doubles<DSQ_P_WIDE>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    if (wide && pk == DSQ_P_WIDE0) fit_beta_scratch_doubles<DSQ_P_WIDE0>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    else if (wide) fit_beta_scratch_doubles<DSQ_P_WIDE>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
     else DispatchP<DSQ_P_REG>::beta_scratch(a->p, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
     {
         void *b; rc = ws_get(WS_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b); if (rc) return rc;
@@ -324,14 +326,18 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     }
     bool ok = false;
     prof_begin(st);
-    if (wide) { ok = true; DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE>(kp, st)); }
+    if (wide) {
+        ok = true;
+        if (pk == DSQ_P_WIDE0) DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE0>(kp, st));
+        else DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE>(kp, st));
+    }
     else DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     if (wide) {     // the real coefficients are the leading columns of the padded n x 16 results
-        const size_t np16 = (size_t)a->n * DSQ_P_WIDE, npp = (size_t)a->n * a->p * sizeof(double);
+        const size_t npw = (size_t)a->n * pk, npp = (size_t)a->n * a->p * sizeof(double);
         DSQ_HIP(hipMemcpyAsync(o->beta_mat, wide_out, npp, hipMemcpyDeviceToDevice, st));
-        DSQ_HIP(hipMemcpyAsync(o->beta_var_mat, wide_out + np16, npp, hipMemcpyDeviceToDevice, st));
+        DSQ_HIP(hipMemcpyAsync(o->beta_var_mat, wide_out + npw, npp, hipMemcpyDeviceToDevice, st));
     }
     if (hat_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(hat_ws, o->hat_diagonals, a->n, a->m, ld, st));
     if (mu_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(mu_ws, o->mu, a->n, a->m, ld, st));
@@ -376,7 +382,7 @@ static int disp_common(int n, int m, int p, int layout, long ld_in, const void *
     if (is_wide(p)) {           // zero-padded design, unit diagonal on the padding in the Cox-Reid matrix
         rc = wide_pad_x(m, p, x, st, &kp->x, &kp->padmask);
         if (rc) return rc;
-        kp->p = DSQ_P_WIDE;
+        kp->p = wide_width(p);
     }
     return DSQ_OK;
 }
@@ -417,7 +423,11 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
     bool ok = false;
     prof_begin(st);
-    if (is_wide(a->p)) { ok = true; DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, false)); }
+    if (is_wide(a->p)) {
+        ok = true;
+        if (kp.p == DSQ_P_WIDE0) DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, false));
+        else DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, false));
+    }
     else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
@@ -441,7 +451,11 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     bool ok = false;
     prof_begin(st);
-    if (is_wide(a->p)) { ok = true; DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, true)); }
+    if (is_wide(a->p)) {
+        ok = true;
+        if (kp.p == DSQ_P_WIDE0) DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, true));
+        else DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, true));
+    }
     else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);

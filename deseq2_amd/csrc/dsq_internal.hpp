@@ -117,10 +117,11 @@ size_t trend_fit_workspace_bytes();
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).
 #define DSQ_P_REG 10
-// 11 <= p <= DSQ_P_WIDE run on ONE more translation unit (-DDSQ_P=16, loops not unrolled, p x p state in scratch
-// memory) over designs zero-padded to 16 columns: a padded column gets ridge 1 and a unit diagonal in the Cox-Reid
-// matrix, which leaves every quantity of the real coefficients unchanged (capi.hip: WidePad).
-#define DSQ_P_WIDE 16
+// 11 <= p <= DSQ_P_WIDE run on two more translation units (-DDSQ_P=16 and 24: loops not unrolled, p x p state in
+// scratch memory) over designs zero-padded to 16 or 24 columns: a padded column gets ridge 1 and a unit diagonal in
+// the Cox-Reid matrix, which leaves every quantity of the real coefficients unchanged (capi.hip, "wide designs").
+#define DSQ_P_WIDE0 16
+#define DSQ_P_WIDE 24
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
 // doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they

@@ -55,8 +55,8 @@ enum {
 enum { DSQ_LAYOUT_R = 0, DSQ_LAYOUT_GENE_MAJOR = 1 };
 enum { DSQ_Y_INT32 = 0, DSQ_Y_FLOAT64 = 1 }; /* R INTSXP or REALSXP count matrix */
 
-#define DSQ_MAX_P 16 /* largest number of design columns served: 1..10 by register-resident kernels (one per
-                       width), 11..16 by one generic kernel pair over the zero-padded design (slower) */
+#define DSQ_MAX_P 24 /* largest number of design columns served: 1..10 by register-resident kernels (one per
+                       width), 11..24 by generic kernels over the design zero-padded to 16 or 24 (slower) */
 
 /* ---- fitBeta ------------------------------------------------------------------
  * reference: List fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP,

@@ -1,5 +1,5 @@
-"""-m gpu: wide designs, 11 <= p <= 16: one generic kernel pair (loops not unrolled, p x p state in scratch memory)
-over the design zero-padded to 16 columns (csrc/capi.hip, "wide designs").  Padding must be invisible: every
+"""-m gpu: wide designs, 11 <= p <= 24: generic kernel pairs (loops not unrolled, p x p state in scratch memory)
+over the design zero-padded to 16 or 24 columns (csrc/capi.hip, "wide designs").  Padding must be invisible: every
 output identical to the oracle run at the TRUE p."""
 import numpy as np
 import pytest
@@ -16,7 +16,8 @@ DISP_KEYS = ["iter", "iter_accept", "log_alpha", "last_change", "initial_lp", "i
 
 
 @pytest.mark.parametrize("levels,m,useW,useQR", [(11, 66, False, True), (12, 60, True, True), (13, 91, False, False),
-                                                 (16, 96, True, False), (16, 160, False, True), (14, 500, False, True)])
+                                                 (16, 96, True, False), (16, 160, False, True), (14, 500, False, True),
+                                                 (17, 85, False, True), (20, 100, True, False), (24, 120, False, True)])
 def test_wide_native_routines_match_oracle(oracle, levels, m, useW, useQR):
     d = make_case(120, m, ("factor", levels), seed=levels + m, weights=useW, sf_random=True)
     p = d["x"].shape[1]
@@ -59,8 +60,8 @@ def test_wide_chain_lrt_matches_oracle(oracle):
 
 def test_too_wide_is_refused():
     from deseq2_amd import _lib
-    d = make_case(10, 40, ("factor", 17), seed=1)
-    p = 17
+    d = make_case(10, 75, ("factor", 25), seed=1)
+    p = 25
     with pytest.raises(_lib.DsqError):
         native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
                        np.full(p, 1e-6), d["weights"], False, 1e-8, 100, True, 0.5)
