@@ -157,11 +157,17 @@ class HostEngine:
         a = np.where(np.asarray(zero, bool)[None, :], 0.0, h)
         return a[:, np.asarray(use, bool)].max(axis=1)
 
+    def _ones(self, n, m):
+        """the all-ones weight matrix R passes when there are no weights (R/fitNbinomGLMs.R:85): one per shape"""
+        if getattr(self, "_ones_cache", None) is None or self._ones_cache.shape != (n, m):
+            self._ones_cache = np.ones((n, m), order="F")
+        return self._ones_cache
+
     # ---- the three native routines
     def fit_beta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, weights, useWeights, tol, maxit, useQR,
                  minmu, want_mu=True, mu_floor=0.0, want_hat=True):
         n, m = y.shape
-        w = weights if weights is not None else np.ones((n, m))
+        w = weights if weights is not None else self._ones(n, m)
         # mu = nf * exp(x beta) comes back from the engine (extension of the fitBeta entry point)
         # instead of being recomputed on the host as R/fitNbinomGLMs.R:180 does
         return self.fns.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu,
@@ -170,14 +176,14 @@ class HostEngine:
     def fit_disp(self, y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit,
                  usePrior, weights, useWeights, weightThreshold, useCR):
         n, m = y.shape
-        w = weights if weights is not None else np.ones((n, m))
+        w = weights if weights is not None else self._ones(n, m)
         return self.fns.fitDisp(y, x, mu_hat, log_alpha, prior_mean, prior_sigmasq, min_log_alpha, kappa_0, tol,
                                 maxit, usePrior, w, useWeights, weightThreshold, useCR)
 
     def fit_disp_grid(self, y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, weights, useWeights,
                       weightThreshold, useCR):
         n, m = y.shape
-        w = weights if weights is not None else np.ones((n, m))
+        w = weights if weights is not None else self._ones(n, m)
         return self.fns.fitDispGrid(y, x, mu_hat, disp_grid, prior_mean, prior_sigmasq, usePrior, w, useWeights,
                                     weightThreshold, useCR)
 

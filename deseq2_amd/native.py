@@ -53,7 +53,7 @@ def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lam
     if x.shape[0] != m or nf.shape != (n, m) or b0.shape != (n, p):
         raise ValueError("non-conformable arguments")
     useW = bool(useWeightsSEXP)
-    w = _fcol(weightsSEXP) if (useW or weightsSEXP is not None) else None
+    w = _fcol(weightsSEXP) if useW else None          # unused weights are neither converted nor uploaded
     if w is not None and w.shape != (n, m):
         raise ValueError("weights must be n x m")
     alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_hatSEXP, np.float64).reshape(-1), (n,)))
