@@ -81,11 +81,12 @@ class HostEngine:
         self.fns = fns
 
     # ---- handles
+    # n x m handles are held column-major, as R holds them: the C ABI then takes them without a layout copy
     def counts(self, K):
-        return np.ascontiguousarray(K, dtype=np.int32)
+        return np.asfortranarray(K, dtype=np.int32)
 
     def matrix(self, A):
-        return None if A is None else np.ascontiguousarray(A, dtype=np.float64)
+        return None if A is None else np.asfortranarray(A, dtype=np.float64)
 
     def design(self, x):
         return np.ascontiguousarray(x, dtype=np.float64)
