@@ -109,3 +109,44 @@ def test_seeded_shape_sweep(oracle, seed):
     alpha = np.nan_to_num(alpha, nan=0.1)
     _both(oracle, y, x, nf, alpha, w, useW, useQR=bool(rng.uniform() < 0.6), lam=float(10 ** rng.uniform(-6, 0)),
           prior=bool(rng.uniform() < 0.5))
+
+
+def test_device_pointers_in_r_layout(oracle):
+    """dsq_fit_*_dev also accepts DEVICE pointers in R's column-major layout (an R session holding external
+    pointers): same answers as the host-pointer entry."""
+    import ctypes as C
+    import torch
+    from deseq2_amd import _lib as L
+    from tests.helpers import make_case
+    d = make_case(150, 44, "batch_condition", seed=17, sf_random=True)
+    n, m = d["counts"].shape
+    p = d["x"].shape[1]
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    contrast = np.r_[1.0, np.zeros(p - 1)]
+    want = oracle.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], contrast, d["beta_init"], lam, d["weights"],
+                          False, 1e-8, 100, True, 0.5)
+    dev = torch.device("cuda:0")
+
+    def col(a, dt=torch.float64):          # column-major n x m == contiguous (m, n) tensor
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(a).T), dtype=dt, device=dev)
+
+    def ptr(t):
+        return C.c_void_p(t.data_ptr())
+    y, x, nf, b0 = col(d["counts"], torch.int32), col(d["x"]), col(d["nf"]), col(d["beta_init"])
+    al, ct, lm = (torch.as_tensor(v, dtype=torch.float64, device=dev) for v in (d["alpha_init"], contrast, lam))
+    out = {k: torch.zeros(s, dtype=torch.float64, device=dev) for k, s in
+           (("beta_mat", (p, n)), ("beta_var_mat", (p, n)), ("iter", (n,)), ("hat", (m, n)), ("cn", (n,)), ("cd", (n,)),
+            ("dev", (n,)), ("mu", (m, n)))}
+    a = L.DsqFitBetaArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=ptr(y), y_type=L.DSQ_Y_INT32, x=ptr(x),
+                         nf=ptr(nf), nf_is_vector=0, alpha_hat=ptr(al), contrast=ptr(ct), beta_mat=ptr(b0),
+                         lambda_=ptr(lm), weights=None, useWeights=0, tol=1e-8, maxit=100, useQR=1, minmu=0.5)
+    o = L.DsqFitBetaOut(beta_mat=ptr(out["beta_mat"]), beta_var_mat=ptr(out["beta_var_mat"]), iter=ptr(out["iter"]),
+                        hat_diagonals=ptr(out["hat"]), contrast_num=ptr(out["cn"]), contrast_denom=ptr(out["cd"]),
+                        deviance=ptr(out["dev"]), mu=ptr(out["mu"]), mu_floor=0.5)
+    L.check(L.lib().dsq_fit_beta_dev(C.byref(a), C.byref(o), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert_same(out["beta_mat"].cpu().numpy().T, want["beta_mat"], "beta_mat (R layout, device pointers)")
+    assert_same(out["iter"].cpu().numpy(), want["iter"], "iter")
+    assert_same(out["hat"].cpu().numpy().T, want["hat_diagonals"], "hat_diagonals")
+    assert_same(out["mu"].cpu().numpy().T, oracle.fittedMu(d["x"], d["nf"], want["beta_mat"], 0.5), "mu")
+    assert_same(out["dev"].cpu().numpy(), want["deviance"], "deviance")
