@@ -374,7 +374,7 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     // (X shared by more genes), then X in LDS.
     const size_t budget = (size_t)tu.beta_lds_kb * 1024, cu_lds = 160 * 1024;
     const int wmax = tu.beta_waves > 0 ? tu.beta_waves : 4;
-    int best = -1;
+    int best = -1, best_wpc = 0;
     *stage = false; *waves = wmax; *xlds = 0;
     for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
@@ -383,8 +383,11 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
             int blocks = (int)(cu_lds / need);
             int wpc = w * blocks < 8 ? w * blocks : 8;
             int score = wpc * 100 + w * 2 + xl;
-            if (score > best) { best = score; *stage = true; *waves = w; *xlds = xl; }
+            if (score > best) { best = score; best_wpc = wpc; *stage = true; *waves = w; *xlds = xl; }
         }
+    // Long rows (m >~ 1000): the LDS slabs leave fewer than 6 waves per CU and staging loses to plain L2-resident
+    // rows at full occupancy (measured, p = 4: m = 1250 10.6 vs 9.1 ms, m = 2000 18.5 vs 9.1 ms; m = 800 5.1 vs 5.6).
+    if (*stage && best_wpc < 6 && tu.beta_stage < 0) { *stage = false; *waves = wmax; }
     if (tu.beta_stage == 0) *stage = false;
     if (!*stage) *xlds = 0;
     *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double) : 0;

@@ -446,7 +446,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     // same choice as fit_beta: maximise resident waves per CU (LDS 160 KiB, registers allow 8 waves)
     const size_t budget = (size_t)tu.disp_lds_kb * 1024, cu_lds = 160 * 1024;
     const int wmax = tu.disp_waves > 0 ? tu.disp_waves : 4;
-    int best = -1, waves = wmax, xlds = 0;
+    int best = -1, best_wpc = 0, waves = wmax, xlds = 0;
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
@@ -455,8 +455,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
             int blocks = (int)(cu_lds / need);
             int wpc = w * blocks < 8 ? w * blocks : 8;
             int score = wpc * 100 + w * 2 + xl;
-            if (score > best) { best = score; stage = true; waves = w; xlds = xl; }
+            if (score > best) { best = score; best_wpc = wpc; stage = true; waves = w; xlds = xl; }
         }
+    // long rows: below 6 resident waves per CU the staged kernel loses to L2-resident rows at full occupancy
+    // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
+    if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
     size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
     DispKernelParams kq = kp;
