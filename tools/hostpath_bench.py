@@ -2,9 +2,9 @@
 """PCIe-inclusive rate: the same DESeq() chain through the HOST-pointer C ABI (what an unmodified R session
 pays: every call uploads its n x m inputs from pageable host memory and downloads its outputs)."""
 import os, sys, time
-import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import torch  # noqa: F401  (loads the HIP runtime torch bundles before the engine library)
 from deseq2_amd import core, simulate
 from deseq2_amd.engine import HostEngine
 n, m = int(os.environ.get("GENES", "50000")), 500

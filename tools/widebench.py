@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """times the wide-design (generic, scratch-resident) kernels next to a register-resident width"""
-import os, sys, time
+import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import torch  # noqa: F401  (loads the HIP runtime torch bundles before the engine library)
 from deseq2_amd import core, simulate
 from deseq2_amd.engine import DeviceEngine
 E = DeviceEngine("cuda:0")
