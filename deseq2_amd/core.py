@@ -947,9 +947,7 @@ def cooksOutlier(dds, cooksCutoff=None):
     return out
 
 
-def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, **kw):
-    """R/core.R:280-432, serial path (size factors are taken as given: estimateSizeFactors is
-    outside the hot path).  minReplicatesForReplace = np.inf switches the outlier refit off."""
+def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, **kw):
     estimateDispersions(dds, fitType=fitType)
     if test == "Wald":
         nbinomWaldTest(dds, **kw)
@@ -959,4 +957,34 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         raise ValueError("test should be either 'Wald' or 'LRT'")
     if np.isfinite(minReplicatesForReplace) and nOrMoreInCell(dds.x, minReplicatesForReplace).any():   # :419-426
         refitWithoutOutliers(dds, test=test, reduced=reduced, minReplicatesForReplace=minReplicatesForReplace, **kw)
+    return dds
+
+
+def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, **kw):
+    """R/core.R:280-432, serial path (size factors are taken as given: estimateSizeFactors is
+    outside the hot path).  minReplicatesForReplace = np.inf switches the outlier refit off.
+    Rows whose counts are all zero are set aside as every step of the reference does (objectNZ,
+    e.g. R/core.R:705,1351) and come back as NA (NaN) rows of mcols (buildDataFrameWithNARows);
+    the n x m assays then cover the non-zero rows, listed in attrs["nz_rows"]."""
+    getBaseMeansAndVariances(dds)
+    allZero = dds.mcols["allZero"]
+    if not allZero.any():
+        return _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, **kw)
+    nz = np.where(~allZero)[0]
+    if nz.size == 0:
+        raise ValueError("all genes have zero counts in every sample")
+    keep = {k: dds.mcols[k] for k in ("baseMean", "baseVar", "allZero")}
+    sub = _DESeqNZ(dds.subset(nz), test, fitType, reduced, minReplicatesForReplace, **kw)
+    out = {}
+    for k, v in sub.mcols.items():
+        v = np.asarray(v)
+        if v.shape[:1] != (nz.size,) or k == "rowsForOptim":
+            continue
+        full = np.full((dds.n,) + v.shape[1:], np.nan)
+        full[nz] = v
+        out[k] = full
+    out.update(keep)
+    dds.mcols = out
+    dds.assays, dds.attrs = sub.assays, dict(sub.attrs, nz_rows=nz)
+    dds.dispersionFunction = sub.dispersionFunction
     return dds

@@ -133,3 +133,21 @@ def test_edge_cases_single_gene_and_intercept_only(oracle):
     assert (dds.mcols["betaIter"] == 1).all() and dds.mcols["betaConv"].all()
     with pytest.raises(ValueError, match="equal"):
         core.estimateDispersionsGeneEst(core.DESeqDataSet(d["counts"][:, :2], x[[0, 7]], engine=HostEngine(oracle)))
+
+
+def test_all_zero_rows_are_set_aside(oracle):
+    """objectNZ: genes without a single count get NA results, the others are what they are without them"""
+    x = simulate.design_two_group(8)
+    d = simulate.make_counts(120, x, seed=14)
+    counts = d["counts"].copy()
+    zero = np.array([0, 17, 63, counts.shape[0] - 1])
+    counts[zero] = 0
+    E = HostEngine(oracle)
+    full = core.DESeq(core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], engine=E))
+    nz = np.setdiff1d(np.arange(counts.shape[0]), zero)
+    ref = core.DESeq(core.DESeqDataSet(counts[nz], x, sizeFactors=d["size_factors"], engine=E))
+    for k in ("dispGeneEst", "dispersion", "beta", "betaSE", "WaldStatistic", "WaldPvalue", "deviance"):
+        assert np.isnan(full.mcols[k][zero]).all(), k
+        np.testing.assert_array_equal(full.mcols[k][nz], ref.mcols[k], err_msg=k)
+    assert full.mcols["allZero"][zero].all() and (full.mcols["baseMean"][zero] == 0).all()
+    np.testing.assert_array_equal(full.attrs["nz_rows"], nz)
