@@ -171,13 +171,14 @@ def getAndCheckWeights(dds, weightThreshold=1e-2):
 def getBaseMeansAndVariances(dds):
     """R/core.R:2138-2157"""
     E = dds.engine
-    w = None
-    if dds.has_weights:
-        w = E.matrix(dds.weights_raw)
     # one pass also yields the rough dispersion and the IRLS start values used right after
     # (roughDispEstimate :2422, fitNbinomGLMs.R:139-145); they are cached on the object
-    pf = E.prefit(dds.y, dds.nf, dds.x, w)
-    dds.attrs["prefit"] = pf
+    if dds.attrs.get("prefit_for") is dds.y and "prefit" in dds.attrs:   # same count handle: nothing changed
+        pf = dds.attrs["prefit"]
+    else:
+        w = E.matrix(dds.weights_raw) if dds.has_weights else None
+        pf = E.prefit(dds.y, dds.nf, dds.x, w)
+        dds.attrs["prefit"], dds.attrs["prefit_for"] = pf, dds.y
     dds.mcols["baseMean"], dds.mcols["baseVar"], dds.mcols["allZero"] = pf["baseMean"], pf["baseVar"], pf["allZero"]
     return dds
 
@@ -887,7 +888,7 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
     if nrefit > newAllZero.size:                                                      # :2496
         keep = ~whole.mcols["allZero"]
         refitReplace = idx_rep[keep]
-        sub = dds.subset(refitReplace, dds.assays["replaceCounts"])
+        sub = whole if keep.all() else dds.subset(refitReplace, dds.assays["replaceCounts"])
         estimateDispersionsGeneEst(sub)                                               # :2509
         sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
         estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"])   # :2518-2519
