@@ -204,6 +204,7 @@ class DeviceEngine:
         from . import _lib
         _lib.check(_lib.lib().dsq_set_device(self.device.index or 0))
         self._cache = {}
+        self._tls = threading.local()
         self.record = None          # set to a list to collect (name, n, ms) per fit kernel
         self.want_d2lp = False      # estimateDispersions* never read fitDisp$last_d2lp (R/core.R:784-787,1042)
 
@@ -227,6 +228,11 @@ class DeviceEngine:
         the blocks, so this is an async DMA + one stream sync instead of a staged pageable copy)"""
         h = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         h.copy_(t, non_blocking=True)
+        # cooperative chunk pipeline (parallel.Pipeline): this is the point where the host would block on the
+        # GPU, so the chunk hands the interpreter to the next chunk first and synchronises when it is back
+        wait = getattr(self._tls, "before_sync", None)
+        if wait is not None:
+            wait()
         self.torch.cuda.current_stream().synchronize()
         return h
 

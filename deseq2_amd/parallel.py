@@ -41,27 +41,75 @@ def _allgather_vec(v, device=None):
     return np.concatenate([p[:s].cpu().numpy() for p, s in zip(parts, sizes)])
 
 
+class Baton:
+    """Round-robin token for the cooperative chunk pipeline: exactly one chunk thread runs host code at a time
+    (no interpreter-lock contention); a chunk passes the token on wherever it would block on the GPU or on the
+    other chunks, and continues when the token comes round again."""
+
+    def __init__(self, k):
+        import threading
+        self.k, self.turn = k, 0
+        self.cv = threading.Condition()
+        self.alive = [True] * k
+
+    def _advance(self, i):
+        for step in range(1, self.k + 1):
+            j = (i + step) % self.k
+            if self.alive[j]:
+                self.turn = j
+                return
+        self.turn = -1
+
+    def acquire(self, i):
+        with self.cv:
+            while self.turn != i:
+                self.cv.wait()
+
+    def release(self, i):
+        with self.cv:
+            self._advance(i)
+            self.cv.notify_all()
+
+    def handoff(self, i):
+        self.release(i)
+        self.acquire(i)
+
+    def retire(self, i):
+        with self.cv:
+            self.alive[i] = False
+            if self.turn == i:
+                self._advance(i)
+            self.cv.notify_all()
+
+
 class LocalGroup:
     """The chunk workers of ONE process: k threads, each driving its own HIP stream over a contiguous
     gene range of this rank's shard (DESeqPipelined).  allgather() concatenates the chunk vectors in chunk
     order and, when torch.distributed is initialised, lets chunk 0 extend that over the ranks -- the
     global gene order is (rank, chunk), i.e. the contiguous ranges of R/parallel.R:10."""
 
-    def __init__(self, k, comm_device=None):
+    def __init__(self, k, comm_device=None, baton=None):
         import threading
-        self.k, self.comm_device = k, comm_device
+        self.k, self.comm_device, self.baton = k, comm_device, baton
         self.barrier = threading.Barrier(k)
         self.slots = [None] * k
         self.result = None
 
+    def _wait(self, idx):
+        if self.baton is not None:          # never hold the token while waiting for the other chunks
+            self.baton.release(idx)
+        self.barrier.wait()
+        if self.baton is not None:
+            self.baton.acquire(idx)
+
     def allgather(self, idx, vec):
         self.slots[idx] = np.asarray(vec, np.float64)
-        self.barrier.wait()
+        self._wait(idx)
         if idx == 0:
             self.result = _allgather_vec(np.concatenate(self.slots), self.comm_device)
-        self.barrier.wait()
+        self._wait(idx)
         res = self.result
-        self.barrier.wait()          # everybody has read before the slots are reused
+        self._wait(idx)              # everybody has read before the slots are reused
         return res
 
 
@@ -117,8 +165,9 @@ class Pipeline:
     results equal the serial ones (tests/test_gpu_pipeline.py).  Streams and their engine workspaces
     persist across calls."""
 
-    def __init__(self, engine, n_chunks=2, comm_device=None):
+    def __init__(self, engine, n_chunks=2, comm_device=None, cooperative=True):
         self.engine, self.k, self.comm_device = engine, int(n_chunks), comm_device
+        self.cooperative = bool(cooperative)      # chunks take turns on the host (Baton) instead of free-running
         t = engine.torch
         self.streams = [t.cuda.Stream(device=engine.device) for _ in range(self.k)]
 
@@ -129,19 +178,28 @@ class Pipeline:
         t = self.engine.torch
         bounds = [r[[0, -1]] + np.array([0, 1]) for r in shard_ranges(n, self.k)]
         out, errs = [None] * self.k, []
-        group = LocalGroup(self.k if overlap else 1, self.comm_device)
+        baton = Baton(self.k) if (self.cooperative and self.k > 1) else None
+        group = LocalGroup(self.k if overlap else 1, self.comm_device, baton)
         cur = t.cuda.current_stream(self.engine.device)
 
         def work(c):
             try:
                 t.cuda.set_device(self.engine.device)
+                if baton is not None:
+                    baton.acquire(c)
+                    self.engine._tls.before_sync = lambda: baton.handoff(c)
                 self.streams[c].wait_stream(cur)
                 with t.cuda.stream(self.streams[c]):
                     dds = make_dds(int(bounds[c][0]), int(bounds[c][1]))
                     out[c] = DESeqParallel(dds, comm_device=self.comm_device, group=group, chunk=c, **kw)
+                    self.engine._tls.before_sync = None
+                    if baton is not None:
+                        baton.retire(c)
                     self.streams[c].synchronize()
             except BaseException as e:          # noqa: BLE001 -- re-raised in the caller's thread
                 errs.append(e)
+                if baton is not None:
+                    baton.retire(c)
                 group.barrier.abort()
         if overlap and self.k > 1:
             import sys
