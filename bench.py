@@ -3,9 +3,10 @@
 
 One "step" = one pass of the hot path over one synthetic count matrix that is already
 resident in HBM in R's layout (column-major int32 counts, f64 normalization-factor matrix):
-layout conversion -> fitBeta (mu-hat) -> fitDisp -> fitDispGrid (stragglers) -> host trend /
-prior variance on n-vectors -> fitDisp (MAP) -> fitDispGrid -> fitBeta (final dispersions) ->
-Wald statistics and p-values.  Workload at every N: BASELINE.json configs[2]
+layout conversion -> prefit moments -> fitBeta (mu-hat) -> fitDisp -> fitDispGrid (stragglers) -> dispersion
+trend (device kernel) / prior variance on n-vectors -> fitDisp (MAP) -> fitDispGrid -> fitBeta (final
+dispersions) -> logLik, Wald statistics and p-values -> Cook's distances -> replaceOutliers -> refit of the
+replaced rows: everything DESeq() does by default.  Workload at every N: BASELINE.json configs[2]
 (50k genes x 500 samples, ~batch+condition, p = 4) PER GPU (weak scaling: genes shard
 across ranks, no data-path collective; the only exchange is the all-gather of two n-vectors
 for the global dispersion trend, as in DESeqParallel).
@@ -18,7 +19,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# one host thread per rank: the host code is a launcher; BLAS / OpenMP pools spun up by a tiny QR of the design
+# would oversubscribe the node when 8 ranks share it (the CPU baseline sets its own thread count)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
