@@ -17,6 +17,21 @@
 
 namespace dsq {
 
+// a wave-uniform work matrix of DispGene: registers in the per-width builds, the wave's LDS arena in the WIDE build
+#if DSQ_P > 10
+#define DSQ_WORK(T, name) T &name = this->template arena_take<T>()
+#define DSQ_WORK_SCOPE const int dsq_arena_mark_ = arena_off
+#define DSQ_WORK_END arena_off = dsq_arena_mark_
+#else
+#define DSQ_WORK(T, name) T name
+#define DSQ_WORK_SCOPE
+#define DSQ_WORK_END
+#endif
+typedef double DsqMat1[1][DSQ_P][DSQ_P];
+typedef double DsqMat2[2][DSQ_P][DSQ_P];
+typedef double DsqMat3[3][DSQ_P][DSQ_P];
+typedef double DsqMat[DSQ_P][DSQ_P];
+
 template <int P>
 struct SymN { static constexpr int value = P * (P + 1) / 2; };
 
@@ -29,6 +44,17 @@ struct DispGene {
     unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
     unsigned padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
+    // WIDE build only: the wave-uniform p x p work matrices live ONCE per wave in LDS (every lane reads and writes
+    // the same addresses with the same values) instead of once per lane in scratch memory, which is what a rolled
+    // loop over a local array would give -- 64 copies per wave, gigabytes for the resident waves.
+    double *arena;
+    mutable int arena_off;
+    template <class T>
+    DSQ_DEV T &arena_take() const {
+        T *q = reinterpret_cast<T *>(arena + arena_off);
+        arena_off += (int)((sizeof(T) + 7) / 8);
+        return *q;
+    }
 
     DSQ_DEV bool keep_row(int j) const {
         if constexpr (USE_W) return r.w(j) > thr;
@@ -56,40 +82,83 @@ DSQ_UNROLL_P
     // matrix leaves det / inverse / traces equal to those of the compacted matrix.
     template <int K, class F>
     DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
-        constexpr int N = SymN<P>::value;
-        double acc[K * N];
+        if constexpr (P > 10) {
+            // WIDE build: K * P(P+1)/2 per-lane running sums do not fit in registers, and as a dynamically indexed
+            // array they would live in scratch memory.  Two matrix rows per pass over the samples instead, the pass loop
+            // and the column loops fully unrolled so that the sums of a pass ARE registers; the diagonals are
+            // recomputed per pass (a division per sample).  Same terms, same order per entry, same wave reduction.
+            constexpr int RB = 2;
+            _Pragma("unroll")
+            for (int a0 = 0; a0 < P; a0 += RB) {
+                double acc[K][RB][P];
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++)
+                    _Pragma("unroll")
+                    for (int i = 0; i < RB; i++)
+                        _Pragma("unroll")
+                        for (int b = 0; b < P; b++) acc[k][i][b] = 0.0;
+                for (int j = lane; j < m; j += 64) {
+                    double wd[K];
+                    wfun(r.inv_mu(j), wd);
+                    if (keep_row(j)) {
+                        double xr[P];
+                        _Pragma("unroll")
+                        for (int c = a0; c < P; c++) xr[c] = r.x(j, c);
+                        _Pragma("unroll")
+                        for (int i = 0; i < RB; i++)
+                            _Pragma("unroll")
+                            for (int b = a0 + i; b < P; b++)
+                                _Pragma("unroll")
+                                for (int k = 0; k < K; k++) acc[k][i][b] += xr[a0 + i] * (xr[b] * wd[k]);
+                    }
+                }
+                _Pragma("unroll")
+                for (int i = 0; i < RB; i++)
+                    _Pragma("unroll")
+                    for (int b = a0 + i; b < P; b++)
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) {
+                            double v = wave_allreduce(acc[k][i][b]);
+                            B[k][a0 + i][b] = v;
+                            B[k][b][a0 + i] = v;
+                        }
+            }
+        } else {
+            constexpr int N = SymN<P>::value;
+            double acc[K * N];
 DSQ_UNROLL_P
-        for (int i = 0; i < K * N; i++) acc[i] = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double wd[K];
-            wfun(r.inv_mu(j), wd);
-            if (keep_row(j)) {
-                double xr[P];
+            for (int i = 0; i < K * N; i++) acc[i] = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                double wd[K];
+                wfun(r.inv_mu(j), wd);
+                if (keep_row(j)) {
+                    double xr[P];
 DSQ_UNROLL_P
-                for (int c = 0; c < P; c++) xr[c] = r.x(j, c);
+                    for (int c = 0; c < P; c++) xr[c] = r.x(j, c);
+                    int idx = 0;
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                        for (int b = a; b < P; b++) {
+DSQ_UNROLL_P
+                            for (int k = 0; k < K; k++) acc[k * N + idx] += xr[a] * (xr[b] * wd[k]);
+                            idx++;
+                        }
+                }
+            }
+            wave_allreduce_n(acc);
+DSQ_UNROLL_P
+            for (int k = 0; k < K; k++) {
                 int idx = 0;
 DSQ_UNROLL_P
                 for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
                     for (int b = a; b < P; b++) {
-DSQ_UNROLL_P
-                        for (int k = 0; k < K; k++) acc[k * N + idx] += xr[a] * (xr[b] * wd[k]);
+                        B[k][a][b] = acc[k * N + idx];
+                        B[k][b][a] = acc[k * N + idx];
                         idx++;
                     }
             }
-        }
-        wave_allreduce_n(acc);
-DSQ_UNROLL_P
-        for (int k = 0; k < K; k++) {
-            int idx = 0;
-DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                for (int b = a; b < P; b++) {
-                    B[k][a][b] = acc[k * N + idx];
-                    B[k][b][a] = acc[k * N + idx];
-                    idx++;
-                }
         }
         if constexpr (USE_W || (P > 10)) {
 DSQ_UNROLL_P
@@ -103,15 +172,17 @@ DSQ_UNROLL_P
         double alpha = dexp(la);
         double cr_term = 0.0;
         if (useCR) {
-            double B[1][P][P];
+            DSQ_WORK_SCOPE;
+            DSQ_WORK(DsqMat1, B);
             gram<1>([&](double imu, double(&wd)[1]) { wd[0] = 1.0 / (imu + alpha); }, B);
-            LU<P> lu;
+            DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             cr_term = -0.5 * dlog(lu.det());
+            DSQ_WORK_END;
         }
         double an1 = 1.0 / alpha;
         double lg_an1 = dlgamma(an1);
@@ -140,7 +211,8 @@ DSQ_UNROLL_P
         double alpha = dexp(la);
         double cr_lp = 0.0, cr_dlp = 0.0;
         if (useCR) {
-            double B[2][P][P];
+            DSQ_WORK_SCOPE;
+            DSQ_WORK(DsqMat2, B);
             gram<2>(
                 [&](double imu, double(&wd)[2]) {
                     double t = imu + alpha;
@@ -148,7 +220,7 @@ DSQ_UNROLL_P
                     wd[1] = -1.0 * (1.0 / (t * t));
                 },
                 B);
-            LU<P> lu;
+            DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
@@ -156,10 +228,11 @@ DSQ_UNROLL_P
             lu.factor();
             double detb = lu.det();
             cr_lp = -0.5 * dlog(detb);
-            double Bi[P][P];
+            DSQ_WORK(DsqMat, Bi);
             lu.inverse(Bi);
             double ddetb = detb * trace_prod<P>(Bi, B[1]);
             cr_dlp = -0.5 * ddetb / detb;
+            DSQ_WORK_END;
         }
         double an1 = 1.0 / alpha;
         double an2 = 1.0 / (alpha * alpha);
@@ -201,7 +274,8 @@ DSQ_UNROLL_P
         double alpha = dexp(la);
         double cr_term = 0.0;
         if (useCR) {
-            double B[2][P][P];
+            DSQ_WORK_SCOPE;
+            DSQ_WORK(DsqMat2, B);
             gram<2>(
                 [&](double imu, double(&wd)[2]) {
                     double t = imu + alpha;
@@ -209,17 +283,18 @@ DSQ_UNROLL_P
                     wd[1] = -1.0 * (1.0 / (t * t));
                 },
                 B);
-            LU<P> lu;
+            DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             double detb = lu.det();
-            double Bi[P][P];
+            DSQ_WORK(DsqMat, Bi);
             lu.inverse(Bi);
             double ddetb = detb * trace_prod<P>(Bi, B[1]);
             cr_term = -0.5 * ddetb / detb;
+            DSQ_WORK_END;
         }
         double an1 = 1.0 / alpha;
         double an2 = 1.0 / (alpha * alpha);
@@ -244,7 +319,8 @@ DSQ_UNROLL_P
         double alpha = dexp(la);
         double cr_term = 0.0;
         if (useCR) {
-            double B[3][P][P];
+            DSQ_WORK_SCOPE;
+            DSQ_WORK(DsqMat3, B);
             gram<3>(
                 [&](double imu, double(&wd)[3]) {
                     double t = imu + alpha;
@@ -253,14 +329,15 @@ DSQ_UNROLL_P
                     wd[2] = 2.0 * (1.0 / (t * t * t));
                 },
                 B);
-            LU<P> lu;
+            DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
             lu.factor();
             double detb = lu.det();
-            double Bi[P][P], M[P][P];
+            DSQ_WORK(DsqMat, Bi);
+            DSQ_WORK(DsqMat, M);
             lu.inverse(Bi);
             double tr1 = trace_prod<P>(Bi, B[1]);
             double ddetb = detb * tr1;
@@ -270,6 +347,7 @@ DSQ_UNROLL_P
             double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
             double rr = ddetb / detb;
             cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;
+            DSQ_WORK_END;
         }
         double an1 = 1.0 / alpha;
         double an2 = 1.0 / (alpha * alpha);
@@ -300,9 +378,12 @@ DSQ_UNROLL_P
 
 // ---- staging --------------------------------------------------------------------
 // LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | 1/mu m | (w m) ]
+// WIDE build: doubles of per-wave LDS arena for the work matrices (the largest user, d2lp: B[3], LU, Bi, M)
+__host__ __device__ inline size_t disp_arena_doubles(int p) { return p > 10 ? (size_t)6 * p * p + 4 * p + 16 : 0; }
+
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3);
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3) + (size_t)waves * disp_arena_doubles(p);
 }
 
 #ifndef DSQ_DISP_MINW
@@ -323,6 +404,10 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 
     const double *xs = smem;
     double *slab = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)wave * m * (USE_W ? 4 : 3);
+    // WIDE build: the work-matrix arena sits behind the row slabs (staged) or alone in LDS (unstaged)
+    double *arena = STAGE ? smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3) +
+                                (size_t)wave * disp_arena_doubles(P)
+                          : smem + (size_t)wave * disp_arena_doubles(P);
     if constexpr (STAGE) {
         if (kp.xlds) {
             for (int t = threadIdx.x; t < P * m; t += blockDim.x) smem[t] = kp.x[t];
@@ -360,6 +445,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.useCR = kp.useCR != 0;
         G.ablate = kp.ablate;
         G.padmask = kp.padmask;
+        G.arena = arena;
+        G.arena_off = 0;
         G.setup_cr();
 
         if constexpr (MODE == 2) {
@@ -461,7 +548,10 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
-    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double) : 0;
+    if (!stage)
+        while (waves > 1 && (size_t)waves * disp_arena_doubles(P) * sizeof(double) > budget) waves >>= 1;
+    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
+                       : (size_t)waves * disp_arena_doubles(P) * sizeof(double);   // unstaged: only the WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
@@ -484,7 +574,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else
-        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, MODE>), dim3(grid), dim3(64 * waves), 0, st, kq);
+        hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     return hipGetLastError();
 }
 
