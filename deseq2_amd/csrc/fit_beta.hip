@@ -26,6 +26,69 @@ namespace dsq {
 template <int P>
 struct SymNB { static constexpr int value = P * (P + 1) / 2; };
 
+// WIDE build (DSQ_P > 10, see fit_disp.hip): the wave-uniform work arrays live ONCE per wave in an LDS arena instead
+// of once per lane in scratch memory, and the Householder-stage loops stay fully unrolled so that a lane's row and
+// its partial sums are registers.  In the per-width builds the macros expand to the plain local declarations.
+#if DSQ_P > 10
+#define DSQ_BWORK(T, name) T &name = *reinterpret_cast<T *>(arena + arena_off); arena_off += (int)((sizeof(T) + 7) / 8)
+#define DSQ_BMARK(name) const int name = arena_off
+#define DSQ_BRESET(name) arena_off = name
+#define DSQ_UNROLL_Q _Pragma("unroll")
+#else
+#define DSQ_BWORK(T, name) T name
+#define DSQ_BMARK(name)
+#define DSQ_BRESET(name)
+#define DSQ_UNROLL_Q DSQ_UNROLL_P
+#endif
+typedef double DsqVecP[DSQ_P];
+typedef double DsqMatP[DSQ_P][DSQ_P];
+typedef double DsqMatP1[DSQ_P][DSQ_P + 1];
+
+// doubles of per-wave LDS arena the WIDE build needs: lambda, contrast, beta, beta_prev, then the larger of the
+// QR stage state (scalS, tS, Rm, gamma) and the post-loop block (G, Gi, T, Sg, LU)
+__host__ __device__ inline size_t beta_arena_doubles(int p) { return p > 10 ? (size_t)5 * p * p + 12 * p + 32 : 0; }
+
+// WIDE build: G[a][b] = sum_j x_ja (x_jb w_j) (b >= a, mirrored) and, optionally, rhs[a] = sum_j x_ja zw_j, two
+// matrix rows per pass over the samples with the pass and column loops unrolled (register sums); per-sample weights
+// are recomputed per pass.  Same terms, same order, same wave reduction as the one-pass form.
+template <int P, bool WITH_RHS, class FW>
+DSQ_DEV void beta_gram_wide(const double *xs, int m, int lane, FW &&wz, double (&G)[P][P], double *rhs) {
+    constexpr int RB = 2;
+    _Pragma("unroll")
+    for (int a0 = 0; a0 < P; a0 += RB) {
+        double acc[RB][P], racc[RB];
+        _Pragma("unroll")
+        for (int i = 0; i < RB; i++) {
+            racc[i] = 0.0;
+            _Pragma("unroll")
+            for (int b = 0; b < P; b++) acc[i][b] = 0.0;
+        }
+        for (int j = lane; j < m; j += 64) {
+            double wv, zw;
+            wz(j, wv, zw);
+            double xr[P];
+            _Pragma("unroll")
+            for (int c = a0; c < P; c++) xr[c] = xs[c * m + j];
+            _Pragma("unroll")
+            for (int i = 0; i < RB; i++) {
+                _Pragma("unroll")
+                for (int b = a0 + i; b < P; b++) acc[i][b] += xr[a0 + i] * (xr[b] * wv);
+                if constexpr (WITH_RHS) racc[i] += xr[a0 + i] * zw;
+            }
+        }
+        _Pragma("unroll")
+        for (int i = 0; i < RB; i++) {
+            _Pragma("unroll")
+            for (int b = a0 + i; b < P; b++) {
+                double v = wave_allreduce(acc[i][b]);
+                G[a0 + i][b] = v;
+                G[b][a0 + i] = v;
+            }
+            if constexpr (WITH_RHS) rhs[a0 + i] = wave_allreduce(racc[i]);
+        }
+    }
+}
+
 // per-sample state a wave keeps across passes: sqrt(w); mu and sqrt(w)*z sharing one slot (mu is
 // dead once pass A has turned it into the working response); two of the three hoisted NB-density
 // constants.  The third (read once per iteration, streaming) lives in an L2-resident scratch row so
@@ -59,11 +122,19 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     } else {
         slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
     }
+#if DSQ_P > 10
+    double *arena = STAGE ? smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs +
+                                (size_t)wave * beta_arena_doubles(P)
+                          : smem + (size_t)wave * beta_arena_doubles(P);
+    int arena_off = 0;
+#endif
     double *sw_s = slab, *mu_s = slab + m, *b_s = mu_s;   // mu and sqrt(w)*z share a slot
     double *cs = slab + 2 * (size_t)m;                     // c0 | c2   (LDS)
     double *cg = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m;   // c1 (L2)
 
-    double lambda[P], contrast[P];
+    DSQ_BWORK(DsqVecP, lambda);
+    DSQ_BWORK(DsqVecP, contrast);
+    DSQ_BMARK(gene_mark);
 DSQ_UNROLL_P
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
@@ -75,7 +146,8 @@ DSQ_UNROLL_P
         const double alpha = kp.alpha_hat[g];
         const double size = 1.0 / alpha;
 
-        double beta[P];
+        DSQ_BRESET(gene_mark);
+        DSQ_BWORK(DsqVecP, beta);
 DSQ_UNROLL_P
         for (int c = 0; c < P; c++) beta[c] = kp.beta_init[(size_t)g + (size_t)kp.n * c];
 
@@ -105,11 +177,13 @@ DSQ_UNROLL_P
         }
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
-        double beta_prev[P];          // beta the current mu slot was computed from
+        DSQ_BWORK(DsqVecP, beta_prev);   // beta the current mu slot was computed from
         bool mu_lost = false;         // QR mode overwrote mu with sqrt(w)*z and beta then diverged
 DSQ_UNROLL_P
         for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
+        DSQ_BMARK(iter_mark);
         for (int t = 0; t < kp.maxit; t++) {
+            DSQ_BRESET(iter_mark);
             it += 1.0;
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
@@ -126,51 +200,54 @@ DSQ_UNROLL_P
                     b_s[j] = z * sw;
                 }
                 // pass B: Householder QR by replay                              (:344-356)
-                double scalS[P], tS[P][P + 1], Rm[P][P], gamma[P];
-DSQ_UNROLL_P
+                DSQ_BWORK(DsqVecP, scalS);
+                DSQ_BWORK(DsqMatP1, tS);
+                DSQ_BWORK(DsqMatP, Rm);
+                DSQ_BWORK(DsqVecP, gamma);
+DSQ_UNROLL_Q
                 for (int k = 0; k < P; k++) {
                     double acc[P + 1];
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = 0; j <= P; j++) acc[j] = 0.0;
                     double prow[P + 1];
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = 0; j <= P; j++) prow[j] = 0.0;
                     for (int i = lane; i < M; i += 64) {
                         double a[P], b;
                         if (i < m) {
                             double sw = sw_s[i];
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                             for (int c = 0; c < P; c++) a[c] = xs[c * m + i] * sw;
                             b = b_s[i];
                         } else {
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                             for (int c = 0; c < P; c++) a[c] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
                             b = 0.0;
                         }
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                         for (int s = 0; s < k; s++) {
                             if (i > s) {
                                 double v = a[s] * scalS[s];
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                                 for (int j = s + 1; j < P; j++) a[j] = __builtin_fma(v, tS[s][j], a[j]);
                                 b = __builtin_fma(v, tS[s][P], b);
                             }
                             // rows i <= s are finished rows of R: never revisited (i >= k > s)
                         }
                         if (i > k) {
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                             for (int j = k; j < P; j++) acc[j] += a[k] * a[j];
                             acc[P] += a[k] * b;
                         } else if (i == k) {
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                             for (int j = k; j < P; j++) prow[j] = a[j];
                             prow[P] = b;
                         }
                     }
                     // reductions S_kj, j = k..P, and the pivot row from lane k
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);    // independent chains: interleaved
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
                     double alpha_k = prow[k];
                     double tau, scal, bet;
@@ -181,59 +258,76 @@ DSQ_UNROLL_P
                         scal = 1.0 / (alpha_k - bet);
                     }
                     scalS[k] = scal;
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = k + 1; j <= P; j++) {
                         double wj = prow[j] + scal * acc[j];
                         tS[k][j] = -tau * wj;
                     }
                     Rm[k][k] = bet;
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = k + 1; j < P; j++) Rm[k][j] = prow[j] + tS[k][j];
                     gamma[k] = prow[P] + tS[k][P];
                 }
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                 for (int i = P - 1; i >= 0; i--) {
                     double tt = gamma[i];
-DSQ_UNROLL_P
+DSQ_UNROLL_Q
                     for (int j = i + 1; j < P; j++) tt = __builtin_fma(-Rm[i][j], beta[j], tt);
                     beta[i] = tt / Rm[i][i];
                 }
             } else {
                 // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))  (:398)
-                double acc[N + P];
+                if constexpr (P > 10) {
+                    DSQ_BWORK(LU<P>, lu);
+                    DSQ_BWORK(DsqVecP, rhs);
+                    beta_gram_wide<P, true>(xs, m, lane, [&](int j, double &wv, double &zw) {
+                        double mu = mu_s[j];
+                        wv = wvec(j, mu);
+                        double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                        zw = z * wv;
+                    }, lu.a, rhs);
 DSQ_UNROLL_P
-                for (int i = 0; i < N + P; i++) acc[i] = 0.0;
-                for (int j = lane; j < m; j += 64) {
-                    double mu = mu_s[j];
-                    double wv = wvec(j, mu);
-                    double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
-                    double xr[P];
+                    for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+                    lu.factor();
+                    lu.solve(rhs);
 DSQ_UNROLL_P
-                    for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
+                    for (int a = 0; a < P; a++) beta[a] = rhs[a];
+                } else {
+                    double acc[N + P];
+DSQ_UNROLL_P
+                    for (int i = 0; i < N + P; i++) acc[i] = 0.0;
+                    for (int j = lane; j < m; j += 64) {
+                        double mu = mu_s[j];
+                        double wv = wvec(j, mu);
+                        double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                        double xr[P];
+DSQ_UNROLL_P
+                        for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
+                        int idx = 0;
+DSQ_UNROLL_P
+                        for (int a = 0; a < P; a++) {
+DSQ_UNROLL_P
+                            for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
+                            acc[N + a] += xr[a] * (z * wv);
+                        }
+                    }
+                    wave_allreduce_n(acc);
+                    LU<P> lu;
                     int idx = 0;
 DSQ_UNROLL_P
-                    for (int a = 0; a < P; a++) {
+                    for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                        for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
-                        acc[N + a] += xr[a] * (z * wv);
-                    }
+                        for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+                    lu.factor();
+                    double rhs[P];
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++) rhs[a] = acc[N + a];
+                    lu.solve(rhs);
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++) beta[a] = rhs[a];
                 }
-                wave_allreduce_n(acc);
-                LU<P> lu;
-                int idx = 0;
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                    for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
-                lu.factor();
-                double rhs[P];
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++) rhs[a] = acc[N + a];
-                lu.solve(rhs);
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++) beta[a] = rhs[a];
             }
             int toolarge = 0;
 DSQ_UNROLL_P
@@ -271,30 +365,38 @@ DSQ_UNROLL_P
                 mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
             }
         }
-        double gacc[N];
+        DSQ_BRESET(iter_mark);
+        DSQ_BWORK(DsqMatP, G);
+        DSQ_BWORK(DsqMatP, Gi);
+        if constexpr (P > 10) {
+            for (int j = lane; j < m; j += 64) sw_s[j] = __builtin_sqrt(wvec(j, mu_s[j]));
+            beta_gram_wide<P, false>(xs, m, lane, [&](int j, double &wv, double &zw) { wv = wvec(j, mu_s[j]); zw = 0.0; },
+                                     G, nullptr);
+        } else {
+            double gacc[N];
 DSQ_UNROLL_P
-        for (int i = 0; i < N; i++) gacc[i] = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double wv = wvec(j, mu_s[j]);
-            sw_s[j] = __builtin_sqrt(wv);
-            double xr[P];
+            for (int i = 0; i < N; i++) gacc[i] = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                double wv = wvec(j, mu_s[j]);
+                sw_s[j] = __builtin_sqrt(wv);
+                double xr[P];
 DSQ_UNROLL_P
-            for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
-            int idx = 0;
+                for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
+                int idx = 0;
 DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
+                for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
-        }
-        wave_allreduce_n(gacc);
-        double G[P][P], Gi[P][P];
-        {
+                    for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
+            }
+            wave_allreduce_n(gacc);
             int idx = 0;
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
                 for (int b = a; b < P; b++) { G[a][b] = gacc[idx]; G[b][a] = gacc[idx]; idx++; }
-            LU<P> lu;
+        }
+        {
+            DSQ_BWORK(LU<P>, lu);
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
@@ -331,7 +433,8 @@ DSQ_UNROLL_P
             }
         }
         // sigma = Gi * G * Gi                                                            (:452)
-        double T[P][P], Sg[P][P];
+        DSQ_BWORK(DsqMatP, T);
+        DSQ_BWORK(DsqMatP, Sg);
         mat_mul<P>(Gi, G, T);
         mat_mul<P>(T, Gi, Sg);
         double cn = 0.0;
@@ -363,7 +466,7 @@ DSQ_UNROLL_P
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
 static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs;
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(p);
 }
 
 template <int P>
@@ -390,7 +493,10 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     if (*stage && best_wpc < 6 && tu.beta_stage < 0) { *stage = false; *waves = wmax; }
     if (tu.beta_stage == 0) *stage = false;
     if (!*stage) *xlds = 0;
-    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double) : 0;
+    if (!*stage)
+        while (*waves > 1 && (size_t)*waves * beta_arena_doubles(P) * sizeof(double) > budget) *waves >>= 1;
+    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double)
+                  : (size_t)*waves * beta_arena_doubles(P) * sizeof(double);     // unstaged: only the WIDE arena
     static int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
     static size_t lds_cache[2][2][8];
     if (lds_cache[*stage][useW][*waves] != *lds) { bpc_cache[*stage][useW][*waves] = 0; lds_cache[*stage][useW][*waves] = *lds; }
@@ -440,9 +546,9 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
     } else {
         if (kp.useWeights)
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false>), dim3(grid), dim3(64 * waves), 0, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false>), dim3(grid), dim3(64 * waves), 0, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
     }
     return hipGetLastError();
 }
