@@ -10,7 +10,11 @@
 // fully unrolled so that the p x p state stays in registers.  The WIDE translation unit (-DDSQ_P=16, serving
 // 11 <= p <= 16 on zero-padded designs) keeps them as loops: the state then lives in scratch memory -- slow,
 // but it compiles in seconds instead of tens of minutes and needs no second copy of the algorithms.
-#if defined(DSQ_P) && DSQ_P > 10
+// design widths from DSQ_WIDE_MIN up are built in the WIDE form (rolled p^3 loops, work arrays in the LDS arena)
+#ifndef DSQ_WIDE_MIN
+#define DSQ_WIDE_MIN 11
+#endif
+#if defined(DSQ_P) && DSQ_P >= DSQ_WIDE_MIN
 #define DSQ_UNROLL_P _Pragma("nounroll")
 #else
 #define DSQ_UNROLL_P _Pragma("unroll")

@@ -29,7 +29,7 @@ struct SymNB { static constexpr int value = P * (P + 1) / 2; };
 // WIDE build (DSQ_P > 10, see fit_disp.hip): the wave-uniform work arrays live ONCE per wave in an LDS arena instead
 // of once per lane in scratch memory, and the Householder-stage loops stay fully unrolled so that a lane's row and
 // its partial sums are registers.  In the per-width builds the macros expand to the plain local declarations.
-#if DSQ_P > 10
+#if DSQ_P >= DSQ_WIDE_MIN
 #define DSQ_BWORK(T, name) T &name = *reinterpret_cast<T *>(arena + arena_off); arena_off += (int)((sizeof(T) + 7) / 8)
 #define DSQ_BMARK(name) const int name = arena_off
 #define DSQ_BRESET(name) arena_off = name
@@ -46,7 +46,7 @@ typedef double DsqMatP1[DSQ_P][DSQ_P + 1];
 
 // doubles of per-wave LDS arena the WIDE build needs: lambda, contrast, beta, beta_prev, then the larger of the
 // QR stage state (scalS, tS, Rm, gamma) and the post-loop block (G, Gi, T, Sg, LU)
-__host__ __device__ inline size_t beta_arena_doubles(int p) { return p > 10 ? (size_t)5 * p * p + 12 * p + 32 : 0; }
+__host__ __device__ inline size_t beta_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)5 * p * p + 12 * p + 32 : 0; }
 
 // WIDE build: G[a][b] = sum_j x_ja (x_jb w_j) (b >= a, mirrored) and, optionally, rhs[a] = sum_j x_ja zw_j, two
 // matrix rows per pass over the samples with the pass and column loops unrolled (register sums); per-sample weights
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     } else {
         slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
     }
-#if DSQ_P > 10
+#if DSQ_P >= DSQ_WIDE_MIN
     double *arena = STAGE ? smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs +
                                 (size_t)wave * beta_arena_doubles(P)
                           : smem + (size_t)wave * beta_arena_doubles(P);
@@ -277,7 +277,7 @@ DSQ_UNROLL_Q
                 }
             } else {
                 // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))  (:398)
-                if constexpr (P > 10) {
+                if constexpr (P >= DSQ_WIDE_MIN) {
                     DSQ_BWORK(LU<P>, lu);
                     DSQ_BWORK(DsqVecP, rhs);
                     beta_gram_wide<P, true>(xs, m, lane, [&](int j, double &wv, double &zw) {
@@ -368,7 +368,7 @@ DSQ_UNROLL_P
         DSQ_BRESET(iter_mark);
         DSQ_BWORK(DsqMatP, G);
         DSQ_BWORK(DsqMatP, Gi);
-        if constexpr (P > 10) {
+        if constexpr (P >= DSQ_WIDE_MIN) {
             for (int j = lane; j < m; j += 64) sw_s[j] = __builtin_sqrt(wvec(j, mu_s[j]));
             beta_gram_wide<P, false>(xs, m, lane, [&](int j, double &wv, double &zw) { wv = wvec(j, mu_s[j]); zw = 0.0; },
                                      G, nullptr);

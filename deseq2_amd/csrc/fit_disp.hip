@@ -18,7 +18,7 @@
 namespace dsq {
 
 // a wave-uniform work matrix of DispGene: registers in the per-width builds, the wave's LDS arena in the WIDE build
-#if DSQ_P > 10
+#if DSQ_P >= DSQ_WIDE_MIN
 #define DSQ_WORK(T, name) T &name = this->template arena_take<T>()
 #define DSQ_WORK_SCOPE const int dsq_arena_mark_ = arena_off
 #define DSQ_WORK_END arena_off = dsq_arena_mark_
@@ -82,7 +82,7 @@ DSQ_UNROLL_P
     // matrix leaves det / inverse / traces equal to those of the compacted matrix.
     template <int K, class F>
     DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
-        if constexpr (P > 10) {
+        if constexpr (P >= DSQ_WIDE_MIN) {
             // WIDE build: K * P(P+1)/2 per-lane running sums do not fit in registers, and as a dynamically indexed
             // array they would live in scratch memory.  Two matrix rows per pass over the samples instead, the pass loop
             // and the column loops fully unrolled so that the sums of a pass ARE registers; the diagonals are
@@ -160,7 +160,7 @@ DSQ_UNROLL_P
                     }
             }
         }
-        if constexpr (USE_W || (P > 10)) {
+        if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++)
                 if (dropmask & (1u << c)) B[0][c][c] = 1.0;
@@ -379,7 +379,7 @@ DSQ_UNROLL_P
 // ---- staging --------------------------------------------------------------------
 // LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | 1/mu m | (w m) ]
 // WIDE build: doubles of per-wave LDS arena for the work matrices (the largest user, d2lp: B[3], LU, Bi, M)
-__host__ __device__ inline size_t disp_arena_doubles(int p) { return p > 10 ? (size_t)6 * p * p + 4 * p + 16 : 0; }
+__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 4 * p + 16 : 0; }
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
