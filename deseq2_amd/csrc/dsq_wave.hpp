@@ -169,9 +169,25 @@ DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
             int pr = piv[k];
             if (pr != k) {
+                if constexpr (P <= 6) {
+                    // b[k] <-> b[pr] as select chains: written as a conditional swap the compiler turns it into a
+                    // dynamically indexed access, which moves b[] (a register array otherwise) into scratch memory
+                    // (fit_disp<4>: 48 B/lane of scratch and ~90 scratch accesses per evaluation, 209 -> 177 VGPRs
+                    // without it).  Only for the narrow widths: at P = 10 the select form of the second-derivative
+                    // kernel came out WRONG on the device (last_d2lp off by orders of magnitude, everything else
+                    // unchanged), so the wider builds keep the conditional swap they have always been tested with.
+                    const double bk = b[k];
+                    double picked = bk;
 DSQ_UNROLL_P
-                for (int i = k + 1; i < P; i++) {
-                    if (i == pr) { double t = b[k]; b[k] = b[i]; b[i] = t; }
+                    for (int i = k + 1; i < P; i++) picked = (i == pr) ? b[i] : picked;
+DSQ_UNROLL_P
+                    for (int i = k + 1; i < P; i++) b[i] = (i == pr) ? bk : b[i];
+                    b[k] = picked;
+                } else {
+DSQ_UNROLL_P
+                    for (int i = k + 1; i < P; i++) {
+                        if (i == pr) { double t = b[k]; b[k] = b[i]; b[i] = t; }
+                    }
                 }
             }
         }
