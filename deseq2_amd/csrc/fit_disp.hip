@@ -387,7 +387,9 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
 }
 
 #ifndef DSQ_DISP_MINW
-#define DSQ_DISP_MINW (DSQ_P <= 6 ? 2 : 1)   /* wide designs already spill at 512 registers */
+/* p <= 4: the search kernel needs 177 registers, so 3 waves per SIMD cost ten spills and pay (6.42 -> 6.15 ms
+ * at C3); p = 5, 6: 2 waves; wider designs already spill at 512 registers */
+#define DSQ_DISP_MINW (DSQ_P <= 4 ? 3 : DSQ_P <= 6 ? 2 : 1)
 #endif
 
 // MODE 0: fitDisp line search (all outputs but last_d2lp); MODE 1: fitDispGrid; MODE 2: last_d2lp only,
@@ -540,7 +542,8 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
             size_t need = disp_lds_doubles<USE_W>(kp.m, P, w, xl) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
-            int wpc = w * blocks < 8 ? w * blocks : 8;
+            const int wcap = 4 * (DSQ_DISP_MINW);     // waves per CU the register budget of this build admits
+            int wpc = w * blocks < wcap ? w * blocks : wcap;
             int score = wpc * 100 + w * 2 + xl;
             if (score > best) { best = score; best_wpc = wpc; stage = true; waves = w; xlds = xl; }
         }
