@@ -130,3 +130,40 @@ def test_two_ranks_times_two_chunks_equal_serial(tmp_path, oracle):
     parts = [np.load(os.path.join(str(tmp_path), "cshard%d.npz" % r)) for r in range(world)]
     for k in COLS:
         np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), serial.mcols[k], err_msg=k)
+
+
+def test_cooperative_chunks_with_baton(oracle):
+    """the token-passing form (parallel.Baton): chunks take turns, release the token while waiting for each
+    other at the all-gene step, and a finished chunk retires -- same results, no deadlock"""
+    import threading
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_two_group(10)
+    d = simulate.make_counts(240, x, seed=36)
+    k = 3
+    ranges = parallel.shard_ranges(d["counts"].shape[0], k)
+    baton = parallel.Baton(k)
+    group = parallel.LocalGroup(k, None, baton)
+    out, errs = [None] * k, []
+
+    def work(c):
+        try:
+            baton.acquire(c)
+            dds = core.DESeqDataSet(d["counts"][ranges[c]], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle))
+            baton.handoff(c)                       # a point where a device chunk would wait for its kernels
+            out[c] = parallel.DESeqParallel(dds, group=group, chunk=c)
+            baton.retire(c)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            baton.retire(c)
+            group.barrier.abort()
+    th = [threading.Thread(target=work, args=(c,)) for c in range(k)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "deadlock"
+    if errs:
+        raise errs[0]
+    serial = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle)))
+    got = parallel.concat_mcols(out, COLS)
+    for kk in COLS:
+        np.testing.assert_array_equal(got[kk], serial.mcols[kk], err_msg=kk)
