@@ -181,18 +181,23 @@ __global__ void __launch_bounds__(256) replace_kernel(ReplaceKernelParams kp) {
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *ckg = kp.cooks + (size_t)g * kp.ld;
         int any = 0;
-        wave_lds_sync();
-        for (int k = lane; k < n2; k += 64) {
-            buf[k] = k < m ? (double)yg[k] / nfg[k] : inf;
-            if (k < m && ckg[k] > kp.cutoff) any = 1;
-        }
+        for (int k = lane; k < m; k += 64)
+            if (ckg[k] > kp.cutoff) any = 1;
         any = __any(any);
-        wave_sort(buf, n2, lane);
-        const double tbm = trimmed_mean_sorted(buf, m, kp.trim, lane);
         int32_t *og = kp.newCounts + (size_t)g * kp.ld;
-        for (int j = lane; j < m; j += 64) {
-            int rep = (int)(tbm * nfg[j]);
-            og[j] = (ckg[j] > kp.cutoff && kp.replaceable[j]) ? rep : yg[j];
+        if (!any) {
+            // no distance above the cutoff (almost every gene): the counts pass through, and the trimmed base mean
+            // -- the sort -- is never needed
+            for (int j = lane; j < m; j += 64) og[j] = yg[j];
+        } else {
+            wave_lds_sync();
+            for (int k = lane; k < n2; k += 64) buf[k] = k < m ? (double)yg[k] / nfg[k] : inf;
+            wave_sort(buf, n2, lane);
+            const double tbm = trimmed_mean_sorted(buf, m, kp.trim, lane);
+            for (int j = lane; j < m; j += 64) {
+                int rep = (int)(tbm * nfg[j]);
+                og[j] = (ckg[j] > kp.cutoff && kp.replaceable[j]) ? rep : yg[j];
+            }
         }
         if (lane == 0) kp.replace[g] = any ? 1 : 0;
     }
