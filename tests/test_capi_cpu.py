@@ -80,3 +80,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "orc_" not in txt, f
+
+
+def test_r_shim_is_valid_c_against_stub_r_headers():
+    """R is not installed here: the .Call shim is at least syntax- and type-checked (gcc -fsyntax-only -Wall -Werror)
+    against declarations of the Rinternals.h entry points it uses (tests/r_stub/)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-DDSQ_HAVE_R", "-I", os.path.join(root, "tests", "r_stub"),
+                        "-I", os.path.join(root, "include"), os.path.join(root, "deseq2_amd", "csrc", "r_shim.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
