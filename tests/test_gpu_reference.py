@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from deseq2_amd import native
-from tests.test_oracle_vs_reference import GOLDEN, _case, _have_ref, compare, golden_cases, run_all
+from tests.test_oracle_vs_reference import (GOLDEN, HEAD, SHAPES, SHAPE_NAMES, _case, _close, _have_ref, compare,
+                                             golden_cases, load_golden, run_all, shape_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -34,3 +35,17 @@ def test_hip_vs_compiled_reference_live(n, m, design, kw):
     from oracle import reference
     d = _case(n, m, design, seed=n + m, **kw)
     compare(run_all(native, d), run_all(reference, d), d, "live %dx%d" % (n, m))
+
+
+@pytest.mark.parametrize("name", SHAPE_NAMES)
+def test_hip_reproduces_reference_at_baseline_shapes(name):
+    """BASELINE.json configs C2..C5 at full shape (C3: 1000 x 500 p=4; C4: 200 x 2000, 10-level factor, QR; C5:
+    1000 x 200, weights with zeros + the betaPrior pass on the expanded p=3 design; C2: 1000 x 100): the HIP path
+    through the host-pointer C ABI against the outputs of the reference's own src/DESeq2.cpp
+    (tests/golden/reference_shapes.npz, generator tests/golden/make_reference_shapes.py) -- iteration counts equal
+    (ties <= 1 %), well-conditioned share >= 0.95, grid agreement >= 0.95, values within 1e-7 / 1e-8."""
+    d = shape_case(name)
+    got = run_all(native, d)
+    ref = load_golden(SHAPES, name)
+    _close(got["aux"]["mu"][:HEAD], ref["aux"]["mu"], name + " mu", rtol=1e-9)
+    compare(got, ref, d, name, min_well=0.95)
