@@ -114,9 +114,6 @@ def main():
     ap.add_argument("--no-hostpath", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) pass")
     ap.add_argument("--cpu-sample-genes", type=int, default=0, help="genes of the CPU baseline sample (0 = by config)")
     ap.add_argument("--profile-host", action="store_true", help="print wall time per pipeline phase (adds syncs)")
-    ap.add_argument("--legacy-host-chain", action="store_true",
-                    help="time core.DESeq() (Python decision rules between the native calls) instead of the fused "
-                         "device pipeline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -240,6 +237,7 @@ def main():
         step()
     rec, E.record = E.record, None
     mc = parallel.concat_mcols(dds, [k for k in ("betaIter", "dispIter", "dispGeneIter") if k in dds[0].mcols])
+    digest = result_digest(dds[0], world, comm_dev, parallel)
 
     weak = None
     if world > 1 and not args.no_weak:
@@ -334,6 +332,7 @@ def main():
             "kernels": kern,
             "kernels_outlier_refit": kern_refit,
             "mean_iterations": {k: float(np.nanmean(v)) for k, v in mc.items()},
+            "result_digest": digest,
         }
         if weak is not None:
             out["weak"] = weak
@@ -347,6 +346,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def result_digest(dds, world, comm_dev, parallel):
+    """sha1 over the per-gene result columns of ALL ranks in gene order: equal digests at different N mean the
+    sharded run reproduced the serial one bit for bit (tests/testthat/test_parallel.R:27-37)"""
+    import hashlib
+    h = hashlib.sha1()
+    for k in ("dispGeneEst", "dispFit", "dispMAP", "dispersion", "beta", "betaSE", "WaldStatistic", "WaldPvalue",
+              "LRTStatistic", "LRTPvalue", "betaIter", "dispIter", "maxCooks", "replace"):
+        if k not in dds.mcols:
+            continue
+        v = np.asarray(dds.mcols[k], dtype=np.float64)
+        v = v.reshape(v.shape[0], -1)
+        cols = [parallel._allgather_vec(np.ascontiguousarray(v[:, j]), comm_dev) for j in range(v.shape[1])]
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(np.column_stack(cols)).tobytes())
+    return h.hexdigest()
 
 
 def hostpath_ms(core, W, x, cfg, factors, reduced):
@@ -418,7 +434,7 @@ class _ReferenceFns:
     def __init__(self, R, O, pool=None, workers=1):
         self.R, self.O, self.pool, self.workers = R, O, pool, workers
         for name in ("prefitMoments", "nbinomLogLike", "parametricDispersionFit", "cooksDistance", "replaceOutliers",
-                     "design_qr", "linearMu"):
+                     "design_qr", "linearMu", "unary"):
             if hasattr(O, name):
                 setattr(self, name, getattr(O, name))
 

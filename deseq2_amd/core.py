@@ -73,7 +73,8 @@ class DESeqDataSet:
         self.y = E.counts(self.counts_host)
         self.nf = E.matrix(nf)
         self.has_weights = weights is not None
-        self.weights_raw = None if weights is None else np.asarray(weights, np.float64)
+        # assays(object)[["weights"]] as given (an engine handle); normalised by getAndCheckWeights
+        self.weights_h = None if weights is None else E.matrix(np.asarray(weights, np.float64))
         self.xh = E.design(self.x)
         self.mcols = {}
         self.assays = {}
@@ -81,10 +82,11 @@ class DESeqDataSet:
         self.dispersionFunction = None
 
     @classmethod
-    def from_device(cls, engine, counts_r, nf_r, x, weights=None, sizeFactors=None):
-        """Build from matrices ALREADY RESIDENT in HBM in R layout: `counts_r` (int32) and
-        `nf_r` (float64) are contiguous (m, n) torch tensors, i.e. column-major n x m exactly as
-        R holds them.  Converts to the engine's gene-major layout on the device (no host copy)."""
+    def from_device(cls, engine, counts_r, nf_r, x, weights=None, sizeFactors=None, weights_r=None):
+        """Build from matrices ALREADY RESIDENT in HBM in R layout: `counts_r` (int32), `nf_r` and the optional
+        `weights_r` (float64) are contiguous (m, n) torch tensors, i.e. column-major n x m exactly as
+        R holds them.  Converts to the engine's gene-major layout on the device (no host copy).  (`weights`, a
+        host array, is uploaded when no `weights_r` is given.)"""
         self = cls.__new__(cls)
         self.m, self.n = counts_r.shape
         self.x = np.asarray(x, dtype=np.float64)
@@ -93,8 +95,11 @@ class DESeqDataSet:
         self.sizeFactors = None if sizeFactors is None else np.asarray(sizeFactors, np.float64)
         self.y = engine.native.to_gene_major(counts_r)
         self.nf = engine.native.to_gene_major(nf_r)
-        self.has_weights = weights is not None
-        self.weights_raw = None if weights is None else np.asarray(weights, np.float64)
+        self.has_weights = weights is not None or weights_r is not None
+        if weights_r is not None:
+            self.weights_h = engine.native.to_gene_major(weights_r)
+        else:
+            self.weights_h = None if weights is None else engine.matrix(np.asarray(weights, np.float64))
         self.xh = engine.design(self.x)
         self.mcols, self.assays, self.attrs = {}, {}, {}
         self.dispersionFunction = None
@@ -111,9 +116,11 @@ class DESeqDataSet:
         sub.y = E.take_rows(self.y if counts_handle is None else counts_handle, idx)
         sub.nf = E.take_rows(self.nf, idx)
         sub.has_weights = self.has_weights
-        sub.weights_raw = None if self.weights_raw is None else self.weights_raw[idx]
+        sub.weights_h = E.take_rows(self.weights_h, idx)
         sub.xh = self.xh
         sub.mcols, sub.assays, sub.attrs = {}, {}, {}
+        if "weightsOK" in self.attrs:          # attr(object, "weightsOK"): the rank checks ran on the parent
+            sub.attrs["weightsOK"] = True
         sub.dispersionFunction = None if self.dispersionFunction is None else dict(self.dispersionFunction)
         return sub
 
@@ -139,33 +146,41 @@ def fitDispGridWrapper(E, y, x, mu, logAlphaPriorMean, logAlphaPriorSigmaSq, use
     dispGrid = np.linspace(minLogAlpha, maxLogAlpha, 20)
     la = E.fit_disp_grid(y, x, mu, dispGrid, logAlphaPriorMean, logAlphaPriorSigmaSq, usePrior, weights,
                          useWeights, weightThreshold, useCR)["log_alpha"]
-    return np.exp(la)
+    return E.vexp(la)
 
 
 # ------------------------------------------------------------------ weights
-def getAndCheckWeights(dds, weightThreshold=1e-2):
-    """R/core.R:2697-2751 (row-max normalisation; the per-gene rank checks flag rows)"""
+def getAndCheckWeights(dds, weightThreshold=1e-2, modelMatrix=None):
+    """R/core.R:2697-2751: row-max normalisation; once per analysis the per-gene rank checks, whose failures are
+    flagged in mcols weightsFail and treated as all-zero rows (:2736-2747).  Returns (engine handle of the
+    normalised weights, useWeights); the handle is cached on the object."""
     E = dds.engine
-    if dds.has_weights:
-        w = dds.weights_raw
-        if (w < 0).any():
+    if not dds.has_weights:
+        return None, False
+    w = dds.attrs.get("weights_norm")
+    if w is None or dds.attrs.get("weights_norm_of") is not dds.weights_h:
+        if E.any_negative(dds.weights_h):
             raise ValueError("all(weights >= 0) is not TRUE")
-        w = w / w.max(axis=1, keepdims=True)
-        if "weightsOK" not in dds.attrs:
-            x = dds.x
-            p = x.shape[1]
-            ok = np.ones(dds.n, dtype=bool)
-            if np.linalg.matrix_rank(x) == p:
-                for i in range(dds.n):
-                    t1 = np.linalg.matrix_rank(w[i][:, None] * x) == p
-                    sub = x[w[i] > weightThreshold]
-                    sub = sub[:, np.abs(sub).sum(axis=0) > 0]
-                    t2 = sub.shape[1] > 0 and np.linalg.matrix_rank(sub) == sub.shape[1]
-                    ok[i] = t1 and t2
+        w = E.row_max_normalize(dds.weights_h)                                        # :2702
+        dds.attrs["weights_norm"], dds.attrs["weights_norm_of"] = w, dds.weights_h
+        dds.attrs.pop("weights_floor", None)
+    if "weightsOK" not in dds.attrs:
+        x = dds.x if modelMatrix is None else np.asarray(modelMatrix, np.float64)
+        ok = E.weights_ok(w, x, weightThreshold, _rank(x) == x.shape[1])              # :2706-2734
+        if not ok.all():
             dds.mcols["weightsFail"] = ~ok
-            dds.attrs["weightsOK"] = True
-        return w, True
-    return None, False
+            if "allZero" in dds.mcols:
+                dds.mcols["allZero"] = dds.mcols["allZero"] | ~ok                     # :2737
+        dds.attrs["weightsOK"] = True
+    return w, True
+
+
+def _floored_weights(dds, w):
+    """weights <- pmax(weights, 1e-6)   (R/core.R:702), cached next to the normalised handle"""
+    f = dds.attrs.get("weights_floor")
+    if f is None:
+        f = dds.attrs["weights_floor"] = dds.engine.clamp_min(w, 1e-6)
+    return f
 
 
 def getBaseMeansAndVariances(dds):
@@ -176,7 +191,7 @@ def getBaseMeansAndVariances(dds):
     if dds.attrs.get("prefit_for") is dds.y and "prefit" in dds.attrs:   # same count handle: nothing changed
         pf = dds.attrs["prefit"]
     else:
-        w = E.matrix(dds.weights_raw) if dds.has_weights else None
+        w = dds.weights_h if dds.has_weights else None
         pf = E.prefit(dds.y, dds.nf, dds.x, w)
         dds.attrs["prefit"], dds.attrs["prefit_for"] = pf, dds.y
     dds.mcols["baseMean"], dds.mcols["baseVar"], dds.mcols["allZero"] = pf["baseMean"], pf["baseVar"], pf["allZero"]
@@ -269,7 +284,7 @@ class PendingFit:
 
 def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, betaTol=1e-8, maxit=100,
                   useOptim=True, useQR=True, minmu=0.5, weights=None, useWeights=False, mu_floor=0.0,
-                  want_hat=True, forceOptim=False, weights_host=None, want_loglike=False, defer=False):
+                  want_hat=True, forceOptim=False, want_loglike=False, defer=False):
     """R/fitNbinomGLMs.R:29-236.  Rows the IRLS does not fit (`rowsForOptim`, :203-211) go through the
     reference's L-BFGS-B fallback on the host (fitNbinomGLMsOptim, :213-227), as in R.  logLike
     (:182) is computed only when the caller reads it (want_loglike)."""
@@ -295,17 +310,18 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
     # intercept-only model with the wide prior: closed form, no native call (:99-137)
     if p == 1 and (x == 1).all() and (lam <= 1e-6).all():
         yh, nfh = E.to_numpy(y).astype(np.float64), E.to_numpy(nf)
-        wh = weights_host if (useWeights and weights_host is not None) else (E.to_numpy(weights) if useWeights else None)
-        if rows is not None and wh is not None and wh.shape[0] != n:
-            wh = wh[rows]
+        wh = E.to_numpy(weights) if useWeights else None
         cn = yh / nfh
         with np.errstate(divide="ignore"):
             b = np.log2((wh * cn).sum(1) / wh.sum(1)) if useWeights else np.log2(cn.mean(1))
         mu_h = nfh * (2.0 ** b)[:, None]
         wd = (wh if useWeights else 1.0) / (1.0 / mu_h + alpha_hat[:, None])
         xtwx = wd.sum(1)
+        # the caller of the gene-wise dispersion fit reads mu clamped at minmu (fitMu[fitMu < minmu] <- minmu,
+        # R/core.R:763); betaSE, hat and logLike above/below are of the unclamped fit, as in R
+        mu_out = np.maximum(mu_h, mu_floor) if mu_floor > 0 else mu_h
         res = {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
-                "mu": E.matrix(mu_h), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
+                "mu": E.matrix(mu_out), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
                 "hat_diagonals": E.matrix(wd / xtwx[:, None]), "deviance_native": None,
                 "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E, "optimRows": None,
                 "logLike": (_host_vector(E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights))
@@ -321,7 +337,7 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         beta0 = np.zeros((n, p))
         bm = E.prefit(y, nf, np.ones((x.shape[0], 1)))["baseMean"]
         if (x[:, 0] == 1).all():
-            beta0[:, 0] = np.log(bm)
+            beta0[:, 0] = E.vlog(bm)
         else:
             beta0[:] = 1.0
         beta_mat = beta0
@@ -380,62 +396,95 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
         raise ValueError("the model matrix is not full rank")                       # checkFullRank :2624
     if x.shape[0] == x.shape[1]:
         raise ValueError("the number of samples and the number of model coefficients are equal")
-    if niter != 1:
-        raise NotImplementedError("niter > 1 is not mirrored (default DESeq() uses niter = 1)")
+    if not (int(niter) == niter and niter > 0):
+        raise ValueError("length(niter) == 1 & niter > 0 is not TRUE")              # :730
     getBaseMeansAndVariances(dds)
-    w_host, useWeights = getAndCheckWeights(dds, weightThreshold)
-    weights_glm = E.matrix(w_host) if useWeights else None          # fitNbinomGLMs re-reads them unfloored (:77)
-    weights = E.matrix(np.maximum(w_host, 1e-6)) if useWeights else None            # :702
+    w_norm, useWeights = getAndCheckWeights(dds, weightThreshold, modelMatrix=modelMatrix)   # :698
+    weights_glm = w_norm                                            # fitNbinomGLMs re-reads them unfloored (:77)
+    weights = _floored_weights(dds, w_norm) if useWeights else None                 # :702
     nz = ~dds.mcols["allZero"]
     if not nz.all():
         raise ValueError("all-zero rows must be removed before fitting (the engine fits objectNZ)")
-    m = dds.m
+    m, n = dds.m, dds.n
+    xh = dds.xh if modelMatrix is None else E.design(x)
     if alphaInit is None:
-        roughDisp = dds.attrs["prefit"]["roughDisp"]                                # :713
+        if modelMatrix is None:
+            roughDisp = dds.attrs["prefit"]["roughDisp"]                            # :713
+        else:
+            roughDisp = E.prefit(dds.y, dds.nf, x, dds.weights_h if dds.has_weights else None)["roughDisp"]
         bm, bv = dds.mcols["baseMean"], dds.mcols["baseVar"]
         xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
-        momentsDisp = (bv - xim * bm) / bm ** 2                                     # :2439-2448
+        momentsDisp = (bv - xim * bm) / (bm * bm)                                   # :2439-2448
         alpha_hat = np.minimum(roughDisp, momentsDisp)
     else:
-        alpha_hat = np.broadcast_to(np.asarray(alphaInit, float), (dds.n,)).copy()
+        alpha_hat = np.broadcast_to(np.asarray(alphaInit, float), (n,)).copy()
     maxDisp = max(10, m)
     alpha_hat = alpha_init = np.minimum(np.maximum(minDisp, alpha_hat), maxDisp)    # :727-728
+    alpha_hat_new = alpha_hat.copy()
     if linearMu is None:
         linearMu = (len(np.unique(modelMatrixGroups(x))) == x.shape[1]) and not useWeights   # :735-742
-    la0 = np.log(alpha_hat)
-    xh = dds.xh if modelMatrix is None else E.design(x)
 
     def fit_disp(y, mu, la, w):
-        return E.fit_disp(y, xh, mu, la, la, 1.0, np.log(minDisp / 10), kappa_0, dispTol, maxit, False, w,
-                          useWeights, weightThreshold, useCR)                       # :771-782
-    if not linearMu:
-        # The GLM fit is launched, the dispersion search is launched on its mu right behind it, and only then
-        # does the host half of fitNbinomGLMs (row checks, optim fallback) run -- overlapping the search.  Genes
-        # are independent: rows whose mu the optim fallback replaces (:386) get their search redone below.
-        pend = fitNbinomGLMs(dds, alpha_hat=alpha_hat, modelMatrix=modelMatrix, weights=weights_glm,
-                             useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False, defer=True)   # :755-757
-        dispRes = fit_disp(dds.y, pend.mu, la0, weights)
-        fit = pend.finish()
-        mu = fit["mu"]                                                              # clamped at minmu (:763)
-        if fit["optimRows"] is not None and len(fit["optimRows"]) > 0:
-            idx = np.asarray(fit["optimRows"])
-            sub = fit_disp(E.take_rows(dds.y, idx), E.take_rows(mu, idx), la0[idx], E.take_rows(weights, idx))
-            dispRes = {k: np.array(dispRes[k], copy=True) for k in sub.keys()}
-            for k in dispRes:
-                dispRes[k][idx] = sub[k]
-    else:
-        mu = E.clamp_min(E.linear_mu(dds.y, dds.nf, dds.xh), minmu)                 # :760,763
-        dispRes = fit_disp(dds.y, mu, la0, weights)
-    dispIter = dispRes["iter"]
-    alpha_hat_new = np.minimum(np.exp(dispRes["log_alpha"]), maxDisp)               # :785
-    dispGeneEst = alpha_hat_new.copy()
-    noIncrease = dispRes["last_lp"] < dispRes["initial_lp"] + np.abs(dispRes["initial_lp"]) / 1e6   # :828
-    dispGeneEst[noIncrease] = alpha_init[noIncrease]
+        return E.fit_disp(y, xh, mu, la, la, 1.0, np.log(minDisp / 10), kappa_0, dispTol, maxit, False,
+                          w, useWeights, weightThreshold, useCR)                    # :771-782
+
+    fitidx = np.ones(n, bool)
+    mu = None
+    dispIter = np.zeros(n, dtype=np.int32)
+    last_lp = initial_lp = None
+    for it in range(int(niter)):                                                    # :751
+        every = bool(fitidx.all())
+        idx = None if every else np.where(fitidx)[0]
+        y_f = dds.y if every else E.take_rows(dds.y, idx)
+        la_f = E.vlog(alpha_hat if every else alpha_hat[idx])
+        # `weightsSEXP = weights` (:778) is NOT subset by fitidx: from the second pass on fitDisp pairs the rows
+        # of y[fitidx, ] with the FIRST sum(fitidx) rows of the weight matrix.  Mirrored as written.
+        w_f = weights if (every or weights is None) else E.take_rows(weights, np.arange(idx.size))
+        if not linearMu:
+            # The GLM fit is launched, the dispersion search is launched on its mu right behind it, and only then
+            # does the host half of fitNbinomGLMs (row checks, optim fallback) run -- overlapping the search.  Genes
+            # are independent: rows whose mu the optim fallback replaces (:386) get their search redone below.
+            pend = fitNbinomGLMs(dds, rows=idx, alpha_hat=alpha_hat if every else alpha_hat[idx], modelMatrix=modelMatrix,
+                                 weights=weights_glm, useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False,
+                                 defer=True)                                        # :755-757
+            dispRes = fit_disp(y_f, pend.mu, la_f, w_f)
+            fit = pend.finish()
+            fitMu = fit["mu"]                                                       # clamped at minmu (:763)
+            if fit["optimRows"] is not None and len(fit["optimRows"]) > 0:
+                oi = np.asarray(fit["optimRows"])
+                sub = fit_disp(E.take_rows(y_f, oi), E.take_rows(fitMu, oi), la_f[oi], E.take_rows(w_f, oi))
+                dispRes = {k: np.array(dispRes[k], copy=True) for k in sub.keys()}
+                for k in dispRes:
+                    dispRes[k][oi] = sub[k]
+        else:
+            nf_f = dds.nf if every else E.take_rows(dds.nf, idx)
+            fitMu = E.clamp_min(E.linear_mu(y_f, nf_f, xh), minmu)                  # :760,763
+            dispRes = fit_disp(y_f, fitMu, la_f, w_f)
+        mu = fitMu if every else E.set_rows(mu, idx, fitMu)                         # :764
+        new = np.minimum(E.vexp(dispRes["log_alpha"]), maxDisp)                     # :785
+        if every:
+            dispIter = np.asarray(dispRes["iter"]).copy()
+            alpha_hat_new = new
+        else:
+            dispIter[idx] = dispRes["iter"]
+            alpha_hat_new = alpha_hat_new.copy()
+            alpha_hat_new[idx] = new
+        last_lp, initial_lp = dispRes["last_lp"], dispRes["initial_lp"]
+        with np.errstate(invalid="ignore"):
+            fitidx = np.abs(E.vlog(alpha_hat_new) - E.vlog(alpha_hat)) > .05        # :822
+        fitidx[np.isnan(fitidx)] = False
+        alpha_hat = alpha_hat_new
+        if fitidx.sum() == 0:
+            break
+    dispGeneEst = alpha_hat.copy()
+    if niter == 1:
+        noIncrease = last_lp < initial_lp + np.abs(initial_lp) / 1e6               # :828
+        dispGeneEst[noIncrease] = alpha_init[noIncrease]
     dispGeneEstConv = (dispIter < maxit) & ~(dispIter == 1)                         # :832
     refitDisp = ~dispGeneEstConv & (dispGeneEst > minDisp * 10)                     # :835
     if refitDisp.sum() > 0:
         idx = np.where(refitDisp)[0]
-        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), dds.xh, E.take_rows(mu, idx),
+        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), xh, E.take_rows(mu, idx),
                                       np.zeros(idx.size), 1.0, False, E.take_rows(weights, idx), useWeights,
                                       weightThreshold, useCR, m)                    # :837-846
         dispGeneEst[refitDisp] = dispGrid
@@ -527,7 +576,7 @@ def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None)
     aboveMinDisp = dge >= minDisp * 100
     varLogDispEsts = None
     if aboveMinDisp.sum() > 0:
-        res = np.log(dge) - np.log(dispFit)
+        res = E.vlog(dge) - E.vlog(dispFit)
         varLogDispEsts = E.mad(res[aboveMinDisp]) ** 2                                 # methods.R:180
     dds.dispersionFunction = {"fitType": fn[0], "coefficients": fn[1], "varLogDispEsts": varLogDispEsts}
     return dds
@@ -557,29 +606,29 @@ def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, ka
     if dispPriorVar is None:
         dispPriorVar = estimateDispersionsPriorVar(dds, minDisp)                     # :986
     dds.dispersionFunction["dispPriorVar"] = dispPriorVar
-    w_host, useWeights = getAndCheckWeights(dds, weightThreshold)                    # :999 (no 1e-6 floor here)
-    weights = E.matrix(w_host) if useWeights else None
+    weights, useWeights = getAndCheckWeights(dds, weightThreshold)                   # :999 (no 1e-6 floor here)
     dge, dfit = dds.mcols["dispGeneEst"], dds.mcols["dispFit"]
     mu = dds.assays["mu"]
     dispInit = np.where(dge > 0.1 * dfit, dge, dfit)                                 # :1019-1021
     dispInit = np.where(np.isnan(dispInit), dfit, dispInit)
-    res = E.fit_disp(dds.y, dds.xh, mu, np.log(dispInit), np.log(dfit), dispPriorVar, np.log(minDisp / 10),
+    log_dfit = E.vlog(dfit)
+    res = E.fit_disp(dds.y, dds.xh, mu, E.vlog(dispInit), log_dfit, dispPriorVar, np.log(minDisp / 10),
                      kappa_0, dispTol, maxit, True, weights, useWeights, weightThreshold, useCR)   # :1027-1039
-    dispMAP = np.exp(res["log_alpha"])
+    dispMAP = E.vexp(res["log_alpha"])
     dispIter = res["iter"]
     dispConv = dispIter < maxit                                                      # :1048
     refitDisp = ~dispConv
     if refitDisp.sum() > 0:
         idx = np.where(refitDisp)[0]
         dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), dds.xh, E.take_rows(mu, idx),
-                                      np.log(dfit)[idx], dispPriorVar, True, E.take_rows(weights, idx),
+                                      log_dfit[idx], dispPriorVar, True, E.take_rows(weights, idx),
                                       useWeights, weightThreshold, True, dds.m)      # :1051-1061
         dispMAP[refitDisp] = dispGrid
     maxDisp = max(10, dds.m)
     dispMAP = np.minimum(np.maximum(dispMAP, minDisp), maxDisp)                      # :1100-1101
     dispersionFinal = dispMAP.copy()
     varLogDispEsts = dds.dispersionFunction["varLogDispEsts"]
-    dispOutlier = np.log(dge) > np.log(dfit) + outlierSD * np.sqrt(varLogDispEsts)   # :1111-1113
+    dispOutlier = E.vlog(dge) > log_dfit + outlierSD * np.sqrt(varLogDispEsts)      # :1111-1113
     dispOutlier[np.isnan(dispOutlier)] = False
     dispersionFinal[dispOutlier] = dge[dispOutlier]
     dds.mcols.update(dispersion=dispersionFinal, dispIter=dispIter, dispOutlier=dispOutlier, dispMAP=dispMAP)
@@ -742,12 +791,11 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     if "dispersion" not in dds.mcols:
         raise RuntimeError("testing requires dispersion estimates, first call estimateDispersions()")
     E = dds.engine
-    w_host, useWeights = getAndCheckWeights(dds)
-    weights = E.matrix(w_host) if useWeights else None
+    weights, useWeights = getAndCheckWeights(dds)
     if not betaPrior:
         fit = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
                             modelMatrix=modelMatrix, weights=weights, useWeights=useWeights,
-                            weights_host=w_host, want_loglike=True)                              # :1403-1408
+                            want_loglike=True)                                                   # :1403-1408
         H, mu_fit = fit["hat_diagonals"], fit["mu"]
         bpv = np.full(fit["nterms"], 1e6)
     else:
@@ -770,7 +818,7 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     if useT:
         from scipy.stats import t as tdist
         if df is None:
-            num = w_host.sum(axis=1) if useWeights else np.full(dds.n, dds.m)
+            num = E.to_numpy(weights).sum(axis=1) if useWeights else np.full(dds.n, dds.m)
             df = num - dds.p
         df = np.where(np.asarray(df, float) > 0, df, np.nan)
         WaldPvalue = 2 * tdist.sf(np.abs(WaldStatistic), df=np.asarray(df)[:, None])
@@ -790,15 +838,14 @@ def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, 
     from scipy.stats import chi2
     E = dds.engine
     reduced = np.asarray(reduced, np.float64)
-    w_host, useWeights = getAndCheckWeights(dds)
-    weights = E.matrix(w_host) if useWeights else None
+    weights, useWeights = getAndCheckWeights(dds)
     disp = dds.mcols["dispersion"]
     full = fitNbinomGLMs(dds, betaTol=betaTol, maxit=maxit, useOptim=useOptim, useQR=useQR, minmu=minmu,
                          weights=weights, useWeights=useWeights, want_loglike=True)
     ll_full = full["logLike"]
     red = fitNbinomGLMs(dds, modelMatrix=reduced, betaTol=betaTol, maxit=maxit, useOptim=useOptim,
                         useQR=useQR, minmu=minmu, weights=weights, useWeights=useWeights, want_hat=False,
-                        weights_host=w_host, want_loglike=True)   # closed form when reduced is ~1 (:99-137)
+                        want_loglike=True)                        # closed form when reduced is ~1 (:99-137)
     ll_red = red["logLike"]
     LRTStatistic = 2 * (ll_full - ll_red)                                            # :1877
     LRTPvalue = chi2.sf(LRTStatistic, df=full["nterms"] - red["nterms"])             # :1878
@@ -968,13 +1015,15 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     e.g. R/core.R:705,1351) and come back as NA (NaN) rows of mcols (buildDataFrameWithNARows);
     the n x m assays then cover the non-zero rows, listed in attrs["nz_rows"]."""
     getBaseMeansAndVariances(dds)
+    if dds.has_weights:
+        getAndCheckWeights(dds)       # rows whose weights leave a degenerate design count as all-zero (R/core.R:2737)
     allZero = dds.mcols["allZero"]
     if not allZero.any():
         return _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, **kw)
     nz = np.where(~allZero)[0]
     if nz.size == 0:
         raise ValueError("all genes have zero counts in every sample")
-    keep = {k: dds.mcols[k] for k in ("baseMean", "baseVar", "allZero")}
+    keep = {k: dds.mcols[k] for k in ("baseMean", "baseVar", "allZero", "weightsFail") if k in dds.mcols}
     sub = _DESeqNZ(dds.subset(nz), test, fitType, reduced, minReplicatesForReplace, **kw)
     out = {}
     for k, v in sub.mcols.items():

@@ -72,6 +72,37 @@ class LaunchedVector:
         return self._v
 
 
+def _gram_rank(G, tol=1e-10):
+    """rank of stacked symmetric p x p Gram matrices X'X (n, p, p): the number of eigenvalues above tol x the
+    largest -- the rank of X for the 0/1-and-weights design matrices these checks see (qr()$rank in R)"""
+    ev = np.linalg.eigvalsh(G)
+    top = np.maximum(ev[:, -1:], 1e-300)
+    return (ev > tol * top).sum(axis=1)
+
+
+def _weights_ok_host(w, x, thr, full_rank):
+    """the per-gene checks of getAndCheckWeights (R/core.R:2711-2734), all genes at once: test1 = rank(w_i * X) == p;
+    test2 = the rows with w_i > thr, minus their all-zero columns, have full column rank.  Not full rank (expanded
+    designs): no design column may be weighted out entirely."""
+    n, m = w.shape
+    p = x.shape[1]
+    ok = np.ones(n, bool)
+    if full_rank:
+        w2 = w * w
+        G1 = np.einsum("nm,ma,mb->nab", w2, x, x)
+        t1 = _gram_rank(G1) == p
+        keep = (w > thr).astype(np.float64)
+        G2 = np.einsum("nm,ma,mb->nab", keep, x, x)
+        ncol = (np.einsum("nm,ma->na", keep, np.abs(x)) > 0).sum(axis=1)
+        t2 = _gram_rank(G2) == ncol
+        ok = t1 & t2
+    else:
+        for j in range(p):
+            allzero = ((w * x[None, :, j]) == 0).all(axis=1)
+            ok &= ~allzero
+    return ok
+
+
 class HostEngine:
     name = "host"
 
@@ -106,8 +137,34 @@ class HostEngine:
         h[np.asarray(idx)] = values
         return h
 
+    def set_rows(self, h, idx, sub):
+        """h[idx, ] <- sub, both handles (mu[fitidx, ] <- fitMu, R/core.R:764)"""
+        h = np.array(h, copy=True, order="F")
+        h[np.asarray(idx)] = sub
+        return h
+
     def nrow(self, h):
         return h.shape[0]
+
+    # ---- n-vector log / exp in the engine's pinned arithmetic (csrc/dsq_math.hpp; the test suite's CPU checker restates it), so that
+    # the host-side decision rules give the same bits whichever engine runs them and whether they run here or in
+    # the fused device pipeline (R: log(), exp())
+    def vlog(self, v):
+        return self.fns.unary("log", np.asarray(v, np.float64))
+
+    def vexp(self, v):
+        return self.fns.unary("exp", np.asarray(v, np.float64))
+
+    # ---- observation weights (getAndCheckWeights, R/core.R:2697-2751)
+    def any_negative(self, h):
+        return bool((h < 0).any())
+
+    def row_max_normalize(self, h):
+        """weights / apply(weights, 1, max)"""
+        return np.asfortranarray(h / h.max(axis=1, keepdims=True))
+
+    def weights_ok(self, w, x, thr, full_rank):
+        return _weights_ok_host(np.asarray(w), x, thr, full_rank)
 
     # ---- O(n*m) steps the reference does in R around the native calls
     def prefit(self, y, nf, x, weights=None):
@@ -301,8 +358,54 @@ class DeviceEngine:
         out[ii, : h.m] = t.as_tensor(np.ascontiguousarray(values, dtype=np.float64), device=self.device)
         return self.native.GeneMajor(out, h.m)
 
+    def set_rows(self, h, idx, sub):
+        t = self.torch
+        ii = t.as_tensor(np.asarray(idx), device=self.device)
+        out = h.t.clone()
+        out[ii] = sub.t
+        return self.native.GeneMajor(out, h.m)
+
     def nrow(self, h):
         return h.n
+
+    def vlog(self, v):
+        return self.native.unary("log", np.asarray(v, np.float64))
+
+    def vexp(self, v):
+        return self.native.unary("exp", np.asarray(v, np.float64))
+
+    # ---- observation weights: elementwise / flag work on the resident handle
+    def any_negative(self, h):
+        return bool((h.view() < 0).any())
+
+    def row_max_normalize(self, h):
+        t = self.torch
+        out = t.zeros_like(h.t)
+        out[:, : h.m] = h.view() / h.view().max(dim=1, keepdim=True).values
+        return self.native.GeneMajor(out, h.m)
+
+    def weights_ok(self, w, x, thr, full_rank):
+        t = self.torch
+        xd = t.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=self.device)
+        wv = w.view()
+        p = xd.shape[1]
+        if not full_rank:
+            ok = t.ones(w.n, dtype=t.bool, device=self.device)
+            for j in range(p):
+                ok &= ~((wv * xd[None, :, j]) == 0).all(dim=1)
+            return self._host(ok).numpy()
+
+        def rank(G):
+            ev = t.linalg.eigvalsh(G)
+            top = ev[:, -1:].clamp_min(1e-300)
+            return (ev > 1e-10 * top).sum(dim=1)
+        xx = (xd[:, :, None] * xd[:, None, :]).reshape(xd.shape[0], p * p)          # m x p^2
+        G1 = ((wv * wv) @ xx).reshape(-1, p, p)
+        keep = (wv > thr).to(t.float64)
+        G2 = (keep @ xx).reshape(-1, p, p)
+        ncol = ((keep @ xd.abs()) > 0).sum(dim=1)
+        ok = (rank(G1) == p) & (rank(G2) == ncol)
+        return self._host(ok).numpy()
 
     # ---- O(n*m) steps around the fits: HIP kernels too (csrc/aux.hip)
     def prefit(self, y, nf, x, weights=None):

@@ -287,6 +287,15 @@ def test_math(op, a, b=None, c=None):
     return out
 
 
+UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6}
+
+
+def unary(name, x):
+    """n-vector log / exp / ... in the engine's pinned f64 arithmetic (csrc/dsq_math.hpp)"""
+    x = np.asarray(x, np.float64)
+    return test_math(UNARY_OPS[name], x.reshape(-1)).reshape(x.shape)
+
+
 # ------------------------------------------------------------------------------------
 # device-resident flavour: torch CUDA tensors, current stream, no host round trip
 # ------------------------------------------------------------------------------------

@@ -201,3 +201,26 @@ def test_full_size_properties(oracle):
         assert_same(o.mcols[k], a.mcols[k][rows], "sample vs oracle " + k)
     del a, b
     torch.cuda.empty_cache()
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (both on cuda:0 here, n-vector exchange
+    over gloo), reports n_gpus = 2, strong scaling over the config's genes in total plus the weak-scaling figure,
+    and the sharded result equals the serial one (tests/testthat/test_parallel.R:27-37)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSQ_BENCH_ONE_DEVICE="1")
+    common = ["--steps", "1", "--warmup", "0", "--genes", "1500", "--no-cpu-baseline", "--no-hostpath"]
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    j2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert j2["scaling"] == "strong" and j2["config"]["genes_total"] == j1["config"]["genes_total"]
+    assert j2["weak"]["genes_total"] > j2["config"]["genes_total"]
+    assert j2["config"]["genes_this_gpu"] * 2 - j2["config"]["genes_total"] in (0, 1)
+    assert j2["result_digest"] == j1["result_digest"]          # sharded == serial, every per-gene result column
