@@ -434,7 +434,7 @@ class _ReferenceFns:
     def __init__(self, R, O, pool=None, workers=1):
         self.R, self.O, self.pool, self.workers = R, O, pool, workers
         for name in ("prefitMoments", "nbinomLogLike", "parametricDispersionFit", "cooksDistance", "replaceOutliers",
-                     "design_qr", "linearMu", "unary"):
+                     "design_qr", "linearMu", "unary", "interceptFit"):
             if hasattr(O, name):
                 setattr(self, name, getattr(O, name))
 

@@ -101,6 +101,18 @@ class DsqLogLikeArgs(C.Structure):
     ]
 
 
+class DsqInterceptArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64), ("y", C.c_void_p),
+        ("y_type", C.c_int32), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32), ("weights", C.c_void_p),
+        ("useWeights", C.c_int32), ("alpha", C.c_void_p), ("mu_floor", C.c_double),
+    ]
+
+
+class DsqInterceptOut(C.Structure):
+    _fields_ = [("beta_log2", C.c_void_p), ("betaSE", C.c_void_p), ("mu", C.c_void_p), ("hat", C.c_void_p)]
+
+
 class DsqCooksArgs(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
@@ -134,6 +146,7 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
+    "dsq_intercept_fit", "dsq_intercept_fit_dev",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
@@ -182,6 +195,8 @@ def lib():
                                                      C.c_void_p]
     L.dsq_linear_mu.argtypes = [C.POINTER(DsqPrefitArgs), C.c_double, C.c_void_p]
     L.dsq_linear_mu_dev.argtypes = [C.POINTER(DsqPrefitArgs), C.c_double, C.c_void_p, C.c_void_p]
+    L.dsq_intercept_fit.argtypes = [C.POINTER(DsqInterceptArgs), C.POINTER(DsqInterceptOut)]
+    L.dsq_intercept_fit_dev.argtypes = [C.POINTER(DsqInterceptArgs), C.POINTER(DsqInterceptOut), C.c_void_p]
     L.dsq_cooks_distance.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut)]
     L.dsq_cooks_distance_dev.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut), C.c_void_p]
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]

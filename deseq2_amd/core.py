@@ -309,22 +309,17 @@ def fitNbinomGLMs(dds, rows=None, modelMatrix=None, alpha_hat=None, lam=None, be
         raise ValueError("all(colSums(abs(modelMatrix)) > 0) is not TRUE")          # :45
     # intercept-only model with the wide prior: closed form, no native call (:99-137)
     if p == 1 and (x == 1).all() and (lam <= 1e-6).all():
-        yh, nfh = E.to_numpy(y).astype(np.float64), E.to_numpy(nf)
-        wh = E.to_numpy(weights) if useWeights else None
-        cn = yh / nfh
-        with np.errstate(divide="ignore"):
-            b = np.log2((wh * cn).sum(1) / wh.sum(1)) if useWeights else np.log2(cn.mean(1))
-        mu_h = nfh * (2.0 ** b)[:, None]
-        wd = (wh if useWeights else 1.0) / (1.0 / mu_h + alpha_hat[:, None])
-        xtwx = wd.sum(1)
-        # the caller of the gene-wise dispersion fit reads mu clamped at minmu (fitMu[fitMu < minmu] <- minmu,
-        # R/core.R:763); betaSE, hat and logLike above/below are of the unclamped fit, as in R
-        mu_out = np.maximum(mu_h, mu_floor) if mu_floor > 0 else mu_h
-        res = {"betaConv": np.ones(n, bool), "betaMatrix": b[:, None], "betaSE": (LOG2E * np.sqrt(1.0 / xtwx))[:, None],
-                "mu": E.matrix(mu_out), "betaIter": np.ones(n), "modelMatrix": x, "nterms": 1,
-                "hat_diagonals": E.matrix(wd / xtwx[:, None]), "deviance_native": None,
-                "rowsForOptim": np.array([], int), "beta_natlog": b[:, None] / LOG2E, "optimRows": None,
-                "logLike": (_host_vector(E.nbinom_loglike(y, E.matrix(mu_h), alpha_hat, weights, useWeights))
+        # one engine pass (the reference does this in vectorised R): beta = log2 of the [weighted] mean normalized
+        # count, mu = nf 2^beta, betaSE / hat from w = [weights] / (1/mu + alpha).  The mu handed back is floored at
+        # mu_floor (the gene-wise dispersion fit reads fitMu[fitMu < minmu] <- minmu, R/core.R:763); betaSE, hat and
+        # logLike are of the unfloored fit, as in R.
+        r = E.intercept_fit(y, nf, alpha_hat, weights, useWeights, mu_floor=0.0, want_hat=want_hat)
+        mu_h = r["mu"]
+        res = {"betaConv": np.ones(n, bool), "betaMatrix": r["beta"][:, None], "betaSE": r["betaSE"][:, None],
+                "mu": E.clamp_min(mu_h, mu_floor) if mu_floor > 0 else mu_h, "betaIter": np.ones(n), "modelMatrix": x,
+                "nterms": 1, "hat_diagonals": r["hat_diagonals"], "deviance_native": None,
+                "rowsForOptim": np.array([], int), "beta_natlog": r["beta"][:, None] / LOG2E, "optimRows": None,
+                "logLike": (_host_vector(E.nbinom_loglike(y, mu_h, alpha_hat, weights, useWeights))
                             if want_loglike else None)}
         return PendingFit(res["mu"], res["hat_diagonals"], lambda: res) if defer else res
     # initial betas by QR least squares when full rank (:139-155)

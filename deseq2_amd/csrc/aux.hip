@@ -143,6 +143,57 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
     }
 }
 
+// closed form of the intercept-only model (R/fitNbinomGLMs.R:99-137): b = log(mean of normalized counts)
+// [weighted: sum(w K/s) / sum(w)], mu = nf exp(b), w = [weights] / (1/mu + alpha), betaSE = log2(e) sqrt(1/sum w),
+// hat = w / sum w.  mu_out is floored at mu_floor when > 0 (R/core.R:763); betaSE / hat use the unfloored mu.
+template <bool USE_W>
+__global__ void __launch_bounds__(256) intercept_fit_kernel(InterceptKernelParams kp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    const double log2e = 1.4426950408889634;
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double alpha = kp.alpha[g];
+        double s[2] = {0.0, 0.0};
+        for (int j = lane; j < m; j += 64) {
+            double cn = (double)yg[j] / nfg[j];
+            if constexpr (USE_W) { double w = wg[j]; cn = w * cn; s[1] += w; }
+            s[0] += cn;
+        }
+        wave_allreduce_n(s);
+        const double mean = s[0] / (USE_W ? s[1] : (double)m);
+        const double b = dlog(mean);
+        const double eb = dexp(b);
+        double sw = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            double mu = nfg[j] * eb;
+            double wd = 1.0 / (1.0 / mu + alpha);
+            if constexpr (USE_W) wd = wg[j] * wd;
+            sw += wd;
+        }
+        const double xtwx = wave_allreduce(sw);
+        if (kp.hat || kp.mu_out) {
+            for (int j = lane; j < m; j += 64) {
+                double mu = nfg[j] * eb;
+                if (kp.hat) {
+                    double wd = 1.0 / (1.0 / mu + alpha);
+                    if constexpr (USE_W) wd = wg[j] * wd;
+                    kp.hat[(size_t)g * kp.ld + j] = wd / xtwx;
+                }
+                if (kp.mu_out) kp.mu_out[(size_t)g * kp.ld + j] = (kp.mu_floor > 0.0) ? __builtin_fmax(mu, kp.mu_floor) : mu;
+            }
+        }
+        if (lane == 0) {
+            kp.beta_log2[g] = log2e * b;
+            kp.betaSE[g] = log2e * __builtin_sqrt(1.0 / xtwx);
+        }
+    }
+}
+
 // ---- parametricDispersionFit (R/core.R:2166-2190) -----------------------------------------
 // The all-gene step between the two dispersion passes: a Gamma-GLM (identity link) IRLS for
 // disp ~ a0 + a1/mean inside the reference's outlier-filter loop.  It touches only two n-vectors,
@@ -355,6 +406,12 @@ hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, doubl
     case 24: return launch_linear_mu_p<24>(kp, mu_floor, mu, st);
     default: *ok = false; return hipSuccess;
     }
+}
+
+hipError_t launch_intercept_fit(const InterceptKernelParams &kp, hipStream_t st) {
+    if (kp.useWeights) hipLaunchKernelGGL((intercept_fit_kernel<true>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    else hipLaunchKernelGGL((intercept_fit_kernel<false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    return hipGetLastError();
 }
 
 hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st) {

@@ -557,6 +557,47 @@ static int loglike_dev_locked(const DsqLogLikeArgs *a, double *out, hipStream_t 
     return finish_ycheck(ycheck, st);
 }
 
+static int intercept_dev_locked(const DsqInterceptArgs *a, const DsqInterceptOut *o, hipStream_t st) {
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->alpha) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->beta_log2 || !o->betaSE) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
+    int rc = check_device();
+    if (rc) return rc;
+    if (a->n == 0) return DSQ_OK;
+    InterceptKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(a->y, a->y_type, a->layout, a->ld, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    if (a->nf_is_vector) { kp.nf = a->nf; kp.nf_is_vector = 1; }
+    else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, a->m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
+    if (a->useWeights) { rc = prep_matrix(a->weights, a->layout, a->ld, a->n, a->m, WS_W, st, &kp.weights, ld); if (rc) return rc; }
+    kp.useWeights = a->useWeights ? 1 : 0;
+    kp.alpha = a->alpha; kp.mu_floor = a->mu_floor;
+    kp.beta_log2 = o->beta_log2; kp.betaSE = o->betaSE;
+    double *mu_ws = nullptr, *hat_ws = nullptr;
+    if (o->mu) {
+        if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.mu_out = o->mu;
+        else { void *b; rc = ws_get(WS_MUOUT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc; mu_ws = (double *)b; kp.mu_out = mu_ws; }
+    }
+    if (o->hat) {
+        if (a->layout == DSQ_LAYOUT_GENE_MAJOR) kp.hat = o->hat;
+        else { void *b; rc = ws_get(WS_HAT, (size_t)a->n * ld * sizeof(double), &b); if (rc) return rc; hat_ws = (double *)b; kp.hat = hat_ws; }
+    }
+    prof_begin(st);
+    DSQ_HIP(launch_intercept_fit(kp, st));
+    prof_end(st);
+    if (mu_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(mu_ws, o->mu, a->n, a->m, ld, st));
+    if (hat_ws) DSQ_HIP(launch_transpose_gm_to_r_f64(hat_ws, o->hat, a->n, a->m, ld, st));
+    return finish_ycheck(ycheck, st);
+}
+
 // ---- host-pointer staging helpers --------------------------------------------------
 // =============================================================== Cook's distances / replaceOutliers
 static int next_pow2(int n) { int v = 2; while (v < n) v <<= 1; return v; }
@@ -1074,6 +1115,49 @@ int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
     rc = loglike_dev_locked(&d, (double *)v, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(loglike, v, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+int dsq_intercept_fit_dev(const DsqInterceptArgs *args, const DsqInterceptOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws((hipStream_t)stream);
+    return intercept_dev_locked(args, out, (hipStream_t)stream);
+}
+
+int dsq_intercept_fit(const DsqInterceptArgs *a, const DsqInterceptOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (!a->y || !a->nf || !a->alpha) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->beta_log2 || !o->betaSE) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m;
+    DsqInterceptArgs d = *a;
+    DsqInterceptOut od = *o;
+    void *v;
+    int rc;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
+    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
+    if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
+    else d.weights = nullptr;
+    if ((rc = up(WS_H_VEC, a->alpha, n * 8, st, &v))) return rc; d.alpha = (double *)v;
+    if ((rc = ws_get(WS_H_OUTVEC, 2 * n * 8, &v))) return rc;
+    od.beta_log2 = (double *)v; od.betaSE = (double *)v + n;
+    od.mu = od.hat = nullptr;
+    if (o->mu) { if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc; od.mu = (double *)v; }
+    if (o->hat) { if ((rc = ws_get(WS_H_OUTMAT2, n * m * 8, &v))) return rc; od.hat = (double *)v; }
+    rc = intercept_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->beta_log2, od.beta_log2, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->betaSE, od.betaSE, n * 8, hipMemcpyDeviceToHost, st));
+    if (o->mu) DSQ_HIP(hipMemcpyAsync(o->mu, od.mu, n * m * 8, hipMemcpyDeviceToHost, st));
+    if (o->hat) DSQ_HIP(hipMemcpyAsync(o->hat, od.hat, n * m * 8, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;
 }

@@ -77,6 +77,19 @@ struct LogLikeKernelParams {
     double *loglike;
 };
 
+struct InterceptKernelParams {
+    int n, m;
+    long ld;
+    const int32_t *y;
+    const double *nf;
+    int nf_is_vector;
+    const double *weights;
+    int useWeights;
+    const double *alpha;
+    double mu_floor;
+    double *beta_log2, *betaSE, *mu_out, *hat;
+};
+
 struct CooksKernelParams {
     int n, m, p;
     long ld;
@@ -110,6 +123,7 @@ hipError_t launch_replace(const ReplaceKernelParams &kp, hipStream_t st, bool *o
 hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st, bool *ok);
 hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st);
+hipError_t launch_intercept_fit(const InterceptKernelParams &kp, hipStream_t st);
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
                             void *workspace, hipStream_t st);
 size_t trend_fit_workspace_bytes();

@@ -185,6 +185,10 @@ class HostEngine:
         """nbinomLogLike, R/core.R:2208-2217"""
         return self.fns.nbinomLogLike(y, mu, disp, weights if useWeights else None, useWeights)
 
+    def intercept_fit(self, y, nf, alpha, weights, useWeights, mu_floor=0.0, want_hat=True):
+        """closed form of the intercept-only model, R/fitNbinomGLMs.R:99-137"""
+        return self.fns.interceptFit(y, nf, alpha, weights if useWeights else None, useWeights, mu_floor, want_hat)
+
     def parametric_fit(self, means, disps):
         """parametricDispersionFit, R/core.R:2166-2190"""
         return self.fns.parametricDispersionFit(means, disps)
@@ -430,6 +434,13 @@ class DeviceEngine:
         dv = self._vec(disp)
         o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
         return LaunchedVector(lambda: self._host(o).numpy())
+
+    def intercept_fit(self, y, nf, alpha, weights, useWeights, mu_floor=0.0, want_hat=True):
+        av = self._vec(np.broadcast_to(np.asarray(alpha, float), (y.n,)))
+        o = self._timed("intercept_fit", y.n, lambda: self.native.interceptFit_dev(
+            y, nf, av, weights, useWeights, mu_floor, want_hat))
+        h = self._host(o["_pack"]).numpy()
+        return {"beta": h[0], "betaSE": h[1], "mu": o["mu"], "hat_diagonals": o["hat_diagonals"]}
 
     def parametric_fit(self, means, disps):
         dm, dd = self._vec(means), self._vec(disps)

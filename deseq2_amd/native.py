@@ -212,6 +212,24 @@ def nbinomLogLike(counts, mu, disp, weights, useWeights):
     return out
 
 
+def interceptFit(counts, nf, alpha, weights=None, useWeights=False, mu_floor=0.0, want_hat=True):
+    """closed form of R/fitNbinomGLMs.R:99-137 (design ~ 1) through dsq_intercept_fit"""
+    y, ytype = _counts(counts)
+    nf = _fcol(nf)
+    n, m = y.shape
+    w = _fcol(weights) if useWeights else None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, np.float64).reshape(-1), (n,)))
+    b, se = np.zeros(n), np.zeros(n)
+    mu = np.zeros((n, m), order="F")
+    hat = np.zeros((n, m), order="F") if want_hat else None
+    args = L.DsqInterceptArgs(n=n, m=m, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, nf=_ptr(nf),
+                              nf_is_vector=0, weights=_ptr(w), useWeights=int(bool(useWeights)), alpha=_ptr(a),
+                              mu_floor=float(mu_floor))
+    out = L.DsqInterceptOut(beta_log2=_ptr(b), betaSE=_ptr(se), mu=_ptr(mu), hat=_ptr(hat))
+    L.check(L.lib().dsq_intercept_fit(C.byref(args), C.byref(out)))
+    return {"beta": b, "betaSE": se, "mu": mu, "hat_diagonals": hat}
+
+
 _CELL_CACHE = {}
 
 
@@ -483,6 +501,23 @@ def nbinomLogLike_dev(y, mu, disp, weights=None, useWeights=False):
                             useWeights=int(bool(useWeights)))
     L.check(L.lib().dsq_nbinom_loglike_dev(C.byref(args), _t_ptr(out), _stream()))
     return out
+
+
+def interceptFit_dev(y, nf, alpha, weights=None, useWeights=False, mu_floor=0.0, want_hat=True, nf_is_vector=False):
+    """y / nf / weights GeneMajor, alpha a CUDA vector; mu / hat come back GeneMajor, beta / betaSE in `_pack`"""
+    import torch
+    n, m, ld = y.n, y.m, y.ld
+    dev = y.t.device
+    pack = torch.empty((2, n), dtype=torch.float64, device=dev)
+    mu = torch.zeros((n, ld), dtype=torch.float64, device=dev)
+    hat = torch.zeros((n, ld), dtype=torch.float64, device=dev) if want_hat else None
+    args = L.DsqInterceptArgs(n=n, m=m, layout=L.DSQ_LAYOUT_GENE_MAJOR, ld=ld, y=_t_ptr(y.t), y_type=L.DSQ_Y_INT32,
+                              nf=_t_ptr(nf if nf_is_vector else nf.t), nf_is_vector=int(nf_is_vector),
+                              weights=_t_ptr(weights.t) if useWeights else None, useWeights=int(bool(useWeights)),
+                              alpha=_t_ptr(alpha), mu_floor=float(mu_floor))
+    out = L.DsqInterceptOut(beta_log2=_t_ptr(pack[0]), betaSE=_t_ptr(pack[1]), mu=_t_ptr(mu), hat=_t_ptr(hat))
+    L.check(L.lib().dsq_intercept_fit_dev(C.byref(args), C.byref(out), _stream()))
+    return {"_pack": pack, "mu": GeneMajor(mu, m), "hat_diagonals": GeneMajor(hat, m) if want_hat else None}
 
 
 def parametricDispersionFit_dev(means, disps):

@@ -226,6 +226,32 @@ typedef struct {
 int dsq_nbinom_loglike(const DsqLogLikeArgs *args, double *loglike);
 int dsq_nbinom_loglike_dev(const DsqLogLikeArgs *args, double *loglike, void *stream);
 
+/* dsq_intercept_fit: the closed form fitNbinomGLMs takes for an intercept-only design with the wide prior
+ * (R/fitNbinomGLMs.R:99-137; nbinomLRT's reduced = ~1 reaches it for every gene): betaMatrix = log2 of the
+ * [weighted] mean normalized count, mu = nf 2^beta, betaSE and hat from w = [weights] / (1/mu + alpha).
+ * Outputs: beta_log2, betaSE (n); mu, hat (n x m, either may be NULL).  mu is floored at mu_floor when > 0.   */
+typedef struct {
+    int32_t n, m;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *nf;
+    int32_t nf_is_vector;
+    const double *weights;
+    int32_t useWeights;
+    const double *alpha;     /* n */
+    double mu_floor;
+} DsqInterceptArgs;
+
+typedef struct {
+    double *beta_log2, *betaSE;   /* n */
+    double *mu, *hat;             /* n x m or NULL */
+} DsqInterceptOut;
+
+int dsq_intercept_fit(const DsqInterceptArgs *args, const DsqInterceptOut *out);
+int dsq_intercept_fit_dev(const DsqInterceptArgs *args, const DsqInterceptOut *out, void *stream);
+
 /* dsq_parametric_dispersion_fit: parametricDispersionFit (R/core.R:2166-2190), the all-gene Gamma-GLM
  * trend disp ~ asymptDisp + extraPois/mean between the two dispersion passes.  means / disps: n values
  * (the genes with dispGeneEst > 100*minDisp, R/core.R:870).  coefs: 2 doubles.  *status: 0 ok,

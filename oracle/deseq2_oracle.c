@@ -767,6 +767,53 @@ int orc_fitted_mu(int n, int m, int p, const double *x, const double *nf, const 
     return 0;
 }
 
+/* ================================================ intercept-only closed form ==
+ * R/fitNbinomGLMs.R:99-137: design ~ 1 with the wide prior needs no IRLS.
+ *   betaMatrix = log2(mean of normalized counts)   [weighted: sum(w K/s) / sum(w)]     (:104-111)
+ *   mu = nf * 2^beta                                                                      (:112)
+ *   w = [weights] (mu^-1 + alpha)^-1 ; xtwx = rowSums(w) ; sigma = xtwx^-1               (:118-124)
+ *   betaSE = log2(e) sqrt(sigma) ; hat = w * xtwx^-1                                      (:125-126)
+ * Restated on the natural-log scale with the engine's log / exp: b = log(mean), betaMatrix = log2(e) b,
+ * mu = nf exp(b).  mu_out (optional) is floored at mu_floor when > 0 (the caller's fitMu[fitMu < minmu] <- minmu,
+ * R/core.R:763); betaSE / hat use the unfloored mu, as in R.  Sums over samples in wave order.   */
+int orc_intercept_fit(int n, int m, const double *y, const double *nf, const double *weights, int useWeights,
+                      const double *alpha, double mu_floor, double *beta_log2, double *betaSE, double *mu_out,
+                      double *hat, int sum_mode) {
+    const double log2e = 1.4426950408889634;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        wsum_t s1, s0; wsum_init(&s1, sum_mode); wsum_init(&s0, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double cn = y[i + (long)n * j] / nf[i + (long)n * j];
+            if (useWeights) { double w = weights[i + (long)n * j]; cn = w * cn; wsum_add(&s0, j, w); }
+            wsum_add(&s1, j, cn);
+        }
+        double mean = wsum_total(&s1) / (useWeights ? wsum_total(&s0) : (double)m);
+        double b = orc_log(mean);
+        double eb = orc_exp(b);
+        wsum_t sw; wsum_init(&sw, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double mu = nf[i + (long)n * j] * eb;
+            double wd = 1.0 / (1.0 / mu + alpha[i]);
+            if (useWeights) wd = weights[i + (long)n * j] * wd;
+            wsum_add(&sw, j, wd);
+        }
+        double xtwx = wsum_total(&sw);
+        beta_log2[i] = log2e * b;
+        betaSE[i] = log2e * sqrt(1.0 / xtwx);
+        for (int j = 0; j < m; j++) {
+            double mu = nf[i + (long)n * j] * eb;
+            if (hat) {
+                double wd = 1.0 / (1.0 / mu + alpha[i]);
+                if (useWeights) wd = weights[i + (long)n * j] * wd;
+                hat[i + (long)n * j] = wd / xtwx;
+            }
+            if (mu_out) mu_out[i + (long)n * j] = (mu_floor > 0.0) ? fmax(mu, mu_floor) : mu;
+        }
+    }
+    return 0;
+}
+
 /* ==================================================== parametricDispersionFit ==
  * R/core.R:2166-2190: disps ~ asymptDisp + extraPois / means by stats::glm(family =
  * Gamma(link = "identity"), start = coefs) inside the outlier-filter loop.  glm.fit's IRLS is

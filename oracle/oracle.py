@@ -263,3 +263,18 @@ def replaceOutliers(counts, nf, cooks, cooksCutoff, replaceable, trim=0.2, sum_m
     lib().orc_replace_outliers(ctypes.c_int(n), ctypes.c_int(m), _p(y), _p(nf), _p(ck), ctypes.c_double(float(cooksCutoff)),
                                _p(rep), ctypes.c_double(float(trim)), _p(newc), _p(flag), ctypes.c_int(sum_mode))
     return {"counts": newc, "replace": flag.astype(bool)}
+
+
+def interceptFit(counts, nf, alpha, weights=None, useWeights=False, mu_floor=0.0, want_hat=True, sum_mode=0):
+    """closed form of R/fitNbinomGLMs.R:99-137 (design ~ 1): betaMatrix (log2), betaSE, mu, hat_diagonals"""
+    y = _f(counts); nf = _f(nf)
+    n, m = y.shape
+    w = _f(weights) if useWeights else None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, float), (n,)))
+    b, se = np.zeros(n), np.zeros(n)
+    mu = np.zeros((n, m), order="F")
+    hat = np.zeros((n, m), order="F") if want_hat else None
+    lib().orc_intercept_fit(ctypes.c_int(n), ctypes.c_int(m), _p(y), _p(nf), _p(w), ctypes.c_int(int(bool(useWeights))),
+                            _p(a), ctypes.c_double(float(mu_floor)), _p(b), _p(se), _p(mu), _p(hat),
+                            ctypes.c_int(sum_mode))
+    return {"beta": b, "betaSE": se, "mu": mu, "hat_diagonals": hat}

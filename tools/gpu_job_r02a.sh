@@ -7,7 +7,6 @@ timeout 300 python tools/parity_report.py hip > $O/parity_hip.md 2> $O/parity_hi
 timeout 400 python bench.py --steps 10 --warmup 3 > $O/bench_C3.json 2> $O/bench_C3.err
 timeout 300 python bench.py --config C2 --steps 10 --warmup 3 > $O/bench_C2.json 2> $O/bench_C2.err
 timeout 400 python bench.py --config C5 --steps 5 --warmup 2 > $O/bench_C5.json 2> $O/bench_C5.err
-timeout 600 python bench.py --config C4 --steps 3 --warmup 1 > $O/bench_C4.json 2> $O/bench_C4.err
 timeout 120 python bench.py --profile-host --no-cpu-baseline > $O/hostprofile_C3.txt 2>&1
 cat $O/t.log; tail -3 $O/*.err; for f in $O/bench_C*.json; do python - "$f" <<'PY'
 import json,sys
