@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--no-hostpath", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) pass")
     ap.add_argument("--cpu-sample-genes", type=int, default=0, help="genes of the CPU baseline sample (0 = by config)")
     ap.add_argument("--profile-host", action="store_true", help="print wall time per pipeline phase (adds syncs)")
+    ap.add_argument("--call-by-call", action="store_true",
+                    help="time core.DESeq() (the R-side decision rules as host code between the native calls) instead "
+                         "of the fused device-driven chain")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -142,7 +145,7 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    from deseq2_amd import core, simulate, parallel
+    from deseq2_amd import core, fused, simulate, parallel
     from deseq2_amd.engine import DeviceEngine
 
     cfg = dict(CONFIGS[args.config])
@@ -184,10 +187,15 @@ def main():
             kw = dict(test=cfg["test"], reduced=reduced)
             if cfg.get("betaPrior"):
                 kw.update(betaPrior=True, factors=factors)
-            if world > 1:
-                parallel.DESeqParallel(dds, comm_device=comm_dev, **kw)
+            if args.call_by_call:
+                if world > 1:
+                    parallel.DESeqParallel(dds, comm_device=comm_dev, **kw)
+                else:
+                    core.DESeq(dds, **kw)
             else:
-                core.DESeq(dds, **kw)
+                # the fused device-driven chain (deseq2_amd/fused.py); settings it does not cover (betaPrior: C5) run
+                # the call-by-call chain of core.py
+                fused.DESeq(dds, comm_device=comm_dev, **kw)
             return [dds]
         return step
 
@@ -229,6 +237,7 @@ def main():
         return profile_host(core, E, step, torch)
 
     dt, n_total, dds = timed(step, n)
+    fused_used = bool(dds[0].attrs.get("fused"))
 
     # per-kernel launch durations: two extra UNTIMED passes with HIP events around each kernel (recorded inside
     # the C library on the launch stream; reading them back synchronises, so they stay out of the throughput)
@@ -257,22 +266,20 @@ def main():
         for name, ng, ms in rec:
             per.setdefault(name, []).append((ng, ms))
 
-        def summary(sel):
-            out = {}
-            for k, v in per.items():
-                v = [(g, t) for g, t in v if sel(g)]
-                if v:
-                    out[k] = {"launches": len(v), "avg_ms": float(np.mean([t for _, t in v])),
-                              "genes_per_launch": float(np.mean([g for g, _ in v]))}
-            return out
         big = n // 2
-        kern = summary(lambda g: g >= big)                    # the full-size launches of the chain
-        kern_refit = summary(lambda g: g < big)               # refitWithoutOutliers: the replaced rows only
-        share = {k: sum(t for g, t in per[k] if g >= big) for k in per}
+        # full-size launches of the chain vs the row-listed ones (fitDispGrid stragglers, refitWithoutOutliers)
+        small = lambda k, g: k.endswith(":refit") or k.endswith("_grid") or g < big     # noqa: E731
+        kern, kern_refit = {}, {}
+        for k, v in per.items():
+            for dst, sel in ((kern, False), (kern_refit, True)):
+                vv = [(g, t) for g, t in v if small(k, g) == sel]
+                if vv:
+                    dst[k] = {"launches": len(vv), "avg_ms": float(np.mean([t for _, t in vv])),
+                              "genes_per_launch": float(np.mean([g for g, _ in vv]))}
+        share = {k: kern[k]["avg_ms"] * kern[k]["launches"] for k in kern}
         dom = max(("fit_beta", "fit_disp"), key=lambda k: share.get(k, 0.0))
-        nfull = max(g for g, _ in per[dom])
-        full = [(g, t) for g, t in per[dom] if g == nfull]
-        avg_ms = float(np.mean([t for _, t in full]))
+        nfull = n
+        avg_ms = kern[dom]["avg_ms"]
         if dom == "fit_beta":
             # fitBeta#1 writes mu (no H), the final fit writes mu and H: average over the full-size launches
             bytes_per_gene = (algorithmic_bytes_per_gene("fit_beta", m, weights=use_w, hat=False, mu=True) +
@@ -326,7 +333,8 @@ def main():
                                    "of R/parallel.R:10; inputs resident in HBM in R layout (int32 counts, f64 nf "
                                    "matrix%s)" % (cfg["label"], n_total, world, ", f64 weights" if use_w else ""),
                        "name": args.config, "genes_total": n_total, "genes_this_gpu": n, "samples": m, "p": p,
-                       "test": cfg["test"], "parallelism": "gene-shard x%d" % world},
+                       "test": cfg["test"], "parallelism": "gene-shard x%d" % world,
+                       "chain": "fused device-driven (dsq_deseq_dev)" if fused_used else "call-by-call (core.py)"},
             "roofline": roofline,
             "valu_roofline": valu,
             "kernels": kern,

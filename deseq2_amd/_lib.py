@@ -137,6 +137,40 @@ class DsqReplaceOut(C.Structure):
     _fields_ = [("newCounts", C.c_void_p), ("replace", C.c_void_p)]
 
 
+class DsqDeseqArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("ld", C.c_int64), ("phases", C.c_int32),
+        ("y", C.c_void_p), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32), ("useWeights", C.c_int32),
+        ("weights_raw", C.c_void_p), ("weights_norm", C.c_void_p), ("weights_floor", C.c_void_p),
+        ("force_zero", C.c_void_p), ("x", C.c_void_p), ("q", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p),
+        ("xim", C.c_double), ("linearMu", C.c_int32),
+        ("minDisp", C.c_double), ("kappa_0", C.c_double), ("dispTol", C.c_double), ("weightThreshold", C.c_double),
+        ("outlierSD", C.c_double), ("betaTol", C.c_double), ("minmu", C.c_double),
+        ("maxit", C.c_int32), ("useCR", C.c_int32), ("useQR", C.c_int32), ("betaMaxit", C.c_int32),
+        ("disp_grid", C.c_void_p), ("ngrid", C.c_int32), ("expVarLogDisp", C.c_double),
+        ("trend_mean", C.c_void_p), ("trend_disp", C.c_void_p), ("n_trend", C.c_int32),
+        ("lambda_", C.c_void_p), ("min_log_alpha", C.c_double), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64), ("test", C.c_int32),
+        ("cell_of", C.c_void_p), ("ncell", C.c_int32), ("replaceable", C.c_void_p),
+        ("cooksCutoff", C.c_double), ("trim", C.c_double), ("do_replace", C.c_int32),
+    ]
+
+
+class DsqDeseqOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
+        "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
+        "logLikeReduced", "maxCooks", "replace", "optim_geneest", "optim_test", "mu_hat", "mu", "H", "cooks",
+        "replaceCounts", "status", "scalars")]
+
+
+DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS = 1, 2, 4, 8
+DSQ_ST = {k: i for i, k in enumerate((
+    "N_NONZERO", "N_GRID_GENEEST", "N_TREND", "TREND_STATUS", "N_ABOVE_MIN", "N_GRID_MAP", "N_OPTIM_GENEEST",
+    "N_OPTIM_TEST", "N_REPLACE", "N_REFIT", "N_GRID_GENEEST_REFIT", "N_GRID_MAP_REFIT", "N_OPTIM_GENEEST_REFIT",
+    "N_OPTIM_TEST_REFIT"))}
+DSQ_ST_COUNT, DSQ_SC_COUNT = 16, 8
+
 # every symbol include/deseq2_mi355x.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "dsq_fit_beta", "dsq_fit_beta_dev", "dsq_fit_disp", "dsq_fit_disp_dev", "dsq_fit_disp_grid",
@@ -146,7 +180,8 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
-    "dsq_intercept_fit", "dsq_intercept_fit_dev",
+    "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
+    "dsq_profile_count", "dsq_profile_get",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
@@ -201,6 +236,10 @@ def lib():
     L.dsq_cooks_distance_dev.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut), C.c_void_p]
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]
     L.dsq_replace_outliers_dev.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut), C.c_void_p]
+    L.dsq_deseq_dev.argtypes = [C.POINTER(DsqDeseqArgs), C.POINTER(DsqDeseqOut), C.c_void_p]
+    L.dsq_deseq_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.dsq_deseq_workspace_bytes.restype = C.c_int64
+    L.dsq_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.dsq_set_device.argtypes = [C.c_int]
     L.dsq_profile_enable.argtypes = [C.c_int]
     L.dsq_profile_last_ms.restype = C.c_double

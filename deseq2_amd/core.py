@@ -572,7 +572,8 @@ def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None)
     varLogDispEsts = None
     if aboveMinDisp.sum() > 0:
         res = E.vlog(dge) - E.vlog(dispFit)
-        varLogDispEsts = E.mad(res[aboveMinDisp]) ** 2                                 # methods.R:180
+        md = E.mad(res[aboveMinDisp])
+        varLogDispEsts = md * md                                                       # mad(...)^2, methods.R:180
     dds.dispersionFunction = {"fitType": fn[0], "coefficients": fn[1], "varLogDispEsts": varLogDispEsts}
     return dds
 
@@ -630,11 +631,11 @@ def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, ka
     return dds
 
 
-def estimateDispersions(dds, fitType="parametric", **kw):
-    """R/methods.R:500-563"""
-    estimateDispersionsGeneEst(dds, **kw)
+def estimateDispersions(dds, fitType="parametric", maxit=100, **kw):
+    """R/methods.R:500-563 (maxit is handed to both dispersion searches, :520,:546)"""
+    estimateDispersionsGeneEst(dds, maxit=maxit, **kw)
     estimateDispersionsFit(dds, fitType=fitType)
-    estimateDispersionsMAP(dds)
+    estimateDispersionsMAP(dds, maxit=maxit)
     return dds
 
 
@@ -906,7 +907,7 @@ def _dispersion_function(dds, baseMean):
     return np.full(baseMean.shape, fn["coefficients"])
 
 
-def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace=7, **kw):
+def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace=7, disp_maxit=100, **kw):
     """R/core.R:2484-2563: replace count outliers by the trimmed mean, then re-estimate the
     dispersion and refit the rows that had a replacement (all through the same engine entry
     points, on the row subset)."""
@@ -931,9 +932,9 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
         keep = ~whole.mcols["allZero"]
         refitReplace = idx_rep[keep]
         sub = whole if keep.all() else dds.subset(refitReplace, dds.assays["replaceCounts"])
-        estimateDispersionsGeneEst(sub)                                               # :2509
+        estimateDispersionsGeneEst(sub, maxit=disp_maxit)                             # :2509
         sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
-        estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"])   # :2518-2519
+        estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"], maxit=disp_maxit)   # :2518-2519
         if test == "Wald":
             nbinomWaldTest(sub, betaPrior=dds.attrs.get("betaPrior", False), betaPriorVar=(
                 dds.attrs["betaPriorVar"] if dds.attrs.get("betaPrior", False) else None),
@@ -990,8 +991,8 @@ def cooksOutlier(dds, cooksCutoff=None):
     return out
 
 
-def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, **kw):
-    estimateDispersions(dds, fitType=fitType)
+def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, disp_maxit=100, **kw):
+    estimateDispersions(dds, fitType=fitType, maxit=disp_maxit)
     if test == "Wald":
         nbinomWaldTest(dds, **kw)
     elif test == "LRT":
@@ -999,7 +1000,8 @@ def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, **kw):
     else:
         raise ValueError("test should be either 'Wald' or 'LRT'")
     if np.isfinite(minReplicatesForReplace) and nOrMoreInCell(dds.x, minReplicatesForReplace).any():   # :419-426
-        refitWithoutOutliers(dds, test=test, reduced=reduced, minReplicatesForReplace=minReplicatesForReplace, **kw)
+        refitWithoutOutliers(dds, test=test, reduced=reduced, minReplicatesForReplace=minReplicatesForReplace,
+                             disp_maxit=disp_maxit, **kw)
     return dds
 
 
@@ -1028,7 +1030,13 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         full = np.full((dds.n,) + v.shape[1:], np.nan)
         full[nz] = v
         out[k] = full
-    out.update(keep)
+    for k, v in keep.items():
+        # the refit may have updated baseMean / baseVar / allZero of its rows (R/core.R:2491-2494): take the
+        # non-zero rows from the sub-analysis, the all-zero rows as first computed
+        full = np.array(v, copy=True)
+        if k in sub.mcols and np.shape(sub.mcols[k])[:1] == (nz.size,):
+            full[nz] = sub.mcols[k]
+        out[k] = full
     dds.mcols = out
     dds.assays, dds.attrs = sub.assays, dict(sub.attrs, nz_rows=nz)
     dds.dispersionFunction = sub.dispersionFunction

@@ -24,7 +24,9 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
     for (int c = 0; c < P; c++)
 #pragma unroll
         for (int k = 0; k < P; k++) rr[c][k] = kp.r[c + P * k];
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -97,7 +99,9 @@ __global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, d
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         double tu[P];
@@ -127,7 +131,9 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *mug = kp.mu + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -153,7 +159,9 @@ __global__ void __launch_bounds__(256) intercept_fit_kernel(InterceptKernelParam
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
     const double log2e = 1.4426950408889634;
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -176,6 +184,17 @@ __global__ void __launch_bounds__(256) intercept_fit_kernel(InterceptKernelParam
             sw += wd;
         }
         const double xtwx = wave_allreduce(sw);
+        if (kp.loglike) {
+            const double size = 1.0 / alpha;
+            double acc = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                double d = dnbinom_mu_log((double)yg[j], size, nfg[j] * eb);
+                if constexpr (USE_W) d = wg[j] * d;
+                acc += d;
+            }
+            acc = wave_allreduce(acc);
+            if (lane == 0) kp.loglike[g] = acc;
+        }
         if (kp.hat || kp.mu_out) {
             for (int j = lane; j < m; j += 64) {
                 double mu = nfg[j] * eb;
@@ -260,8 +279,10 @@ __device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], Trend
 }
 
 __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, const double *disps, long n,
-                                                         double *coefs_out, int32_t *status_out, TrendWs *ws) {
+                                                         const int32_t *n_dev, double *coefs_out, int32_t *status_out,
+                                                         TrendWs *ws) {
     __shared__ double red[16][8];
+    if (n_dev) n = (long)*n_dev;            // fused pipeline: the number of genes in the fit lives on the device
     const long first = (long)blockIdx.x * 1024 + threadIdx.x, stride = 1024L * kTrendBlocks;
     int parity = 0;
     double c0 = 0.1, c1 = 1.0;
@@ -322,7 +343,16 @@ hipError_t launch_trend_fit(const double *means, const double *disps, long n, do
                             void *workspace, hipStream_t st) {
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(TrendWs), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(trend_fit_kernel, dim3(kTrendBlocks), dim3(1024), 0, st, means, disps, n, coefs, status,
+    hipLaunchKernelGGL(trend_fit_kernel, dim3(kTrendBlocks), dim3(1024), 0, st, means, disps, n, (const int32_t *)nullptr,
+                       coefs, status, (TrendWs *)workspace);
+    return hipGetLastError();
+}
+
+hipError_t launch_trend_fit_dev(const double *means, const double *disps, const int32_t *n_dev, double *coefs,
+                                int32_t *status, void *workspace, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(TrendWs), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(trend_fit_kernel, dim3(kTrendBlocks), dim3(1024), 0, st, means, disps, 0L, n_dev, coefs, status,
                        (TrendWs *)workspace);
     return hipGetLastError();
 }

@@ -27,6 +27,13 @@ static int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+int capi_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 #define DSQ_HIP(expr)                                                                            \
     do {                                                                                         \
@@ -63,19 +70,36 @@ int device_cu_count() {
 }
 
 // ---- optional kernel timing (HIP events on the launch stream) ----------------------
+// dsq_profile_enable(1) starts a list of (name, genes, event pair) -- one entry per bracketed launch (a fit call has
+// one, the fused pipeline one per kernel); dsq_profile_count / dsq_profile_get read the durations back.
+struct ProfEntry { char name[32]; int n; hipEvent_t e0, e1; };
 static bool g_prof = false;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static bool g_ev_valid = false;
-static void prof_begin(hipStream_t st) {
-    if (!g_prof) return;
-    if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
-    (void)hipEventRecord(g_ev0, st);
+static std::vector<ProfEntry> g_prof_list;
+static std::vector<hipEvent_t> g_prof_free;
+static hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
 }
-static void prof_end(hipStream_t st) {
-    if (!g_prof) return;
-    (void)hipEventRecord(g_ev1, st);
-    g_ev_valid = true;
+static void prof_clear() {
+    for (auto &p : g_prof_list) { g_prof_free.push_back(p.e0); g_prof_free.push_back(p.e1); }
+    g_prof_list.clear();
 }
+void capi_prof_begin(const char *name, int n, hipStream_t st) {
+    if (!g_prof) return;
+    ProfEntry p;
+    snprintf(p.name, sizeof p.name, "%s", name);
+    p.n = n; p.e0 = prof_event(); p.e1 = prof_event();
+    (void)hipEventRecord(p.e0, st);
+    g_prof_list.push_back(p);
+}
+void capi_prof_end(hipStream_t st) {
+    if (!g_prof || g_prof_list.empty()) return;
+    (void)hipEventRecord(g_prof_list.back().e1, st);
+}
+static void prof_begin(hipStream_t st) { capi_prof_begin("call", 0, st); }
+static void prof_end(hipStream_t st) { capi_prof_end(st); }
 
 // ---- workspace pool: grow-only device buffers, one per (device, slot) -------------
 // Keyed by (device, stream): calls issued on different streams (e.g. the chunks of a pipelined DESeq(),
@@ -85,6 +109,8 @@ struct Slot { void *p = nullptr; size_t bytes = 0; };
 static std::map<hipStream_t, std::vector<Slot>> g_pool[64];
 static hipStream_t g_ws_stream = nullptr;
 struct WsScope { explicit WsScope(hipStream_t s) { g_ws_stream = s; } };
+std::mutex &capi_mutex() { return g_mu; }
+void capi_latch_stream(hipStream_t s) { g_ws_stream = s; }
 
 static int ws_get(int slot, size_t bytes, void **out) {
     int dev = 0;
@@ -110,6 +136,8 @@ enum {  // workspace slots
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
 };
+static_assert(WS_COUNT <= DSQ_WS_PIPE, "pipeline workspace slots follow the call slots");
+int capi_ws_get(int slot, size_t bytes, void **out) { return ws_get(slot, bytes, out); }
 
 static inline long round_ld(int m) { return ((long)m + 7) & ~7L; }
 
@@ -121,6 +149,8 @@ static int check_device() {
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     return DSQ_OK;
 }
+
+int capi_check_device() { return check_device(); }
 
 // counts -> int32 gene-major.  Returns the pointer to use and its ld.
 static int prep_counts(const void *y, int y_type, int layout, long ld_in, int n, int m, hipStream_t st,
@@ -202,6 +232,16 @@ struct DispatchP<0> {
     static void beta_scratch(int, int, int, int, size_t *slab, size_t *cscr) { *slab = 0; *cscr = 0; }
     static hipError_t disp(int, const DispKernelParams &, hipStream_t, bool, bool *ok) { *ok = false; return hipSuccess; }
 };
+
+hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok) {
+    return DispatchP<DSQ_P_REG>::beta(p, kp, st, ok);
+}
+void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr) {
+    DispatchP<DSQ_P_REG>::beta_scratch(p, n, m, useW, slab, cscr);
+}
+hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
+    return DispatchP<DSQ_P_REG>::disp(p, kp, st, grid, ok);
+}
 
 // ---- wide designs (DSQ_P_REG < p <= DSQ_P_WIDE): zero-padded to DSQ_P_WIDE columns --------------------------
 // A padded coefficient has an all-zero design column, ridge 1 and start value 0: its estimate is exactly 0 and the
@@ -736,17 +776,36 @@ int dsq_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
     g_prof = on != 0;
-    g_ev_valid = false;
+    prof_clear();
     return DSQ_OK;
+}
+
+static double prof_ms(const ProfEntry &p) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.e1) != hipSuccess || hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 double dsq_profile_last_ms(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
-    if (!g_ev_valid) return -1.0;
-    float ms = 0.f;
-    if (hipEventSynchronize(g_ev1) != hipSuccess || hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
-    return (double)ms;
+    if (g_prof_list.empty()) return -1.0;
+    return prof_ms(g_prof_list.back());
+}
+
+int dsq_profile_count(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (int)g_prof_list.size();
+}
+
+int dsq_profile_get(int i, char *name, int cap, int32_t *genes, double *ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (i < 0 || i >= (int)g_prof_list.size()) return fail(DSQ_ERR_ARG, "profile entry %d out of range", i);
+    const ProfEntry &p = g_prof_list[i];
+    if (name && cap > 0) snprintf(name, (size_t)cap, "%s", p.name);
+    if (genes) *genes = p.n;
+    if (ms) *ms = prof_ms(p);
+    return DSQ_OK;
 }
 
 int dsq_release_workspace(void) {
@@ -1237,7 +1296,7 @@ int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
 int dsq_test_math(int op, const double *a, const double *b, const double *c, double *out, int64_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
-    if (!a || !out || n < 0 || (op >= 7 && !b) || (op >= 8 && !c)) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (!a || !out || n < 0 || ((op == 7 || op == 8) && !b) || (op == 8 && !c)) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;
     if (n == 0) return DSQ_OK;
     hipStream_t st = nullptr;

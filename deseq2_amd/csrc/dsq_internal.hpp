@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace dsq {
 
@@ -28,6 +29,12 @@ struct DispKernelParams {
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
     int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
     unsigned padmask;        // WIDE kernels: bit c set = design column c is zero padding
+    const double *prior_sigmasq_dev;   // non-null: the prior variance is read from the device (fused pipeline)
+    // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
+    // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
+    const int32_t *rows;
+    const int32_t *n_dev;
+    int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
 };
 
 struct BetaKernelParams {
@@ -51,6 +58,11 @@ struct BetaKernelParams {
     int ablate, force_iters; // profiling only (env DSQ_ABLATE / DSQ_FORCE_ITERS): skip phases / fixed trip count
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
     int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
+    // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
+    // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
+    const int32_t *rows;
+    const int32_t *n_dev;
+    int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
 };
 
 struct PrefitKernelParams {
@@ -64,6 +76,10 @@ struct PrefitKernelParams {
     const double *q, *a, *r;   // Q (m x p), X R^-1 (m x p), R (p x p), all column-major
     double *baseMean, *baseVar, *roughDisp, *beta_init;
     int32_t *allZero;
+    // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
+    // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
+    const int32_t *rows;
+    const int32_t *n_dev;
 };
 
 struct LogLikeKernelParams {
@@ -75,6 +91,10 @@ struct LogLikeKernelParams {
     const double *weights;
     int useWeights;
     double *loglike;
+    // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
+    // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
+    const int32_t *rows;
+    const int32_t *n_dev;
 };
 
 struct InterceptKernelParams {
@@ -88,6 +108,11 @@ struct InterceptKernelParams {
     const double *alpha;
     double mu_floor;
     double *beta_log2, *betaSE, *mu_out, *hat;
+    double *loglike;         // optional: nbinomLogLike at the (unfloored) fitted means, as loglike_kernel computes it
+    // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
+    // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
+    const int32_t *rows;
+    const int32_t *n_dev;
 };
 
 struct CooksKernelParams {
@@ -103,6 +128,8 @@ struct CooksKernelParams {
     int ncell, any3;
     int sortcap;                 // doubles of sort buffer per wave (power of two)
     double *cooks, *maxCooks, *robustDisp;
+    const int32_t *rows;         // fused pipeline: see DispKernelParams
+    const int32_t *n_dev;
 };
 
 struct ReplaceKernelParams {
@@ -116,7 +143,13 @@ struct ReplaceKernelParams {
     const int32_t *replaceable;  // m flags
     int sortcap;
     int32_t *newCounts, *replace;
+    const int32_t *rows;
+    const int32_t *n_dev;
 };
+
+// gene index of work item i, and the number of work items, of a (possibly row-listed) launch
+#define DSQ_NWORK(kp) ((kp).n_dev ? *(kp).n_dev : (kp).n)
+#define DSQ_GENE(kp, i) ((kp).rows ? (kp).rows[i] : (i))
 
 hipError_t launch_cooks(const CooksKernelParams &kp, hipStream_t st, bool *ok);
 hipError_t launch_replace(const ReplaceKernelParams &kp, hipStream_t st, bool *ok);
@@ -160,5 +193,18 @@ hipError_t launch_transpose_gm_to_r_i32(const int32_t *src, int32_t *dst, int n,
 hipError_t launch_test_math(int op, const double *a, const double *b, const double *c, double *out, long n, hipStream_t st);
 
 int device_cu_count();
+
+// ---- shared by capi.hip and pipeline.hip (the fused DESeq() chain) ------------------------------------------
+int capi_fail(int code, const char *fmt, ...);
+int capi_ws_get(int slot, size_t bytes, void **out);             // grow-only workspace of the current (device, stream)
+int capi_check_device();
+std::mutex &capi_mutex();                                        // the library's call lock
+void capi_latch_stream(hipStream_t s);                           // workspace key of the current call (under the lock)
+hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok);
+void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr);
+hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok);
+void capi_prof_begin(const char *name, int n, hipStream_t st);   // no-ops unless dsq_profile_enable(1)
+void capi_prof_end(hipStream_t st);
+enum { DSQ_WS_PIPE = 40, DSQ_WS_PIPE_SCRATCH = 41, DSQ_WS_PIPE_META = 42, DSQ_WS_COUNT = 48 };
 
 }  // namespace dsq

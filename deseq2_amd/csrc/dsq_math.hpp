@@ -276,6 +276,57 @@ DSQ_DEV double dtrigamma(double x) {
     return res;
 }
 
+// -------------------------------------------------------------------- pnorm
+// 2 * pnorm(|z|, lower.tail = FALSE), the Wald p-value of R/core.R:1507.  R's pnorm (nmath/pnorm.c, not in the
+// reference tree) is W. J. Cody's rational Chebyshev approximation (Math. Comp. 1969, Algorithm 715): three
+// ranges, split exp(-y^2/2) for the tails.  Restated for the upper tail of y = |z| with the engine's exp.
+DSQ_DEV double dpnorm_upper2(double z) {
+    if (z != z) return z;
+    const double y = __builtin_fabs(z);
+    double upper;
+    if (y <= 0.67448975) {
+        double xnum = 0.0, xden = 0.0;
+        if (y > 5.5511151231257827e-17) {
+            const double xsq = y * y;
+            xnum = 0.065682337918207449113 * xsq;
+            xden = xsq;
+            xnum = (xnum + 2.2352520354606839287) * xsq;  xden = (xden + 47.20258190468824187) * xsq;
+            xnum = (xnum + 161.02823106855587881) * xsq;  xden = (xden + 976.09855173777669322) * xsq;
+            xnum = (xnum + 1067.6894854603709582) * xsq;  xden = (xden + 10260.932208618978205) * xsq;
+        }
+        const double temp = y * (xnum + 18154.981253343561249) / (xden + 45507.789335026729956);
+        upper = 0.5 - temp;
+    } else if (y <= 5.656854249492380195206754896838) {
+        double xnum = 1.0765576773720192317e-8 * y, xden = y;
+        xnum = (xnum + 0.39894151208813466764) * y;  xden = (xden + 22.266688044328115691) * y;
+        xnum = (xnum + 8.8831497943883759412) * y;   xden = (xden + 235.38790178262499861) * y;
+        xnum = (xnum + 93.506656132177855979) * y;   xden = (xden + 1519.377599407554805) * y;
+        xnum = (xnum + 597.27027639480026226) * y;   xden = (xden + 6485.558298266760755) * y;
+        xnum = (xnum + 2494.5375852903726711) * y;   xden = (xden + 18615.571640885098091) * y;
+        xnum = (xnum + 6848.1904505362823326) * y;   xden = (xden + 34900.952721145977266) * y;
+        xnum = (xnum + 11602.651437647350124) * y;   xden = (xden + 38912.003286093271411) * y;
+        const double temp = (xnum + 9842.7148383839780218) / (xden + 19685.429676859990727);
+        const double xsq = __builtin_trunc(y * 16.0) / 16.0;
+        const double del = (y - xsq) * (y + xsq);
+        upper = dexp(-xsq * xsq * 0.5) * dexp(-del * 0.5) * temp;
+    } else if (y < 38.5) {
+        const double xsq = 1.0 / (y * y);
+        double xnum = 0.02307344176494017303 * xsq, xden = xsq;
+        xnum = (xnum + 0.21589853405795699) * xsq;       xden = (xden + 1.28426009614491121) * xsq;
+        xnum = (xnum + 0.1274011611602473639) * xsq;     xden = (xden + 0.468238212480865118) * xsq;
+        xnum = (xnum + 0.022235277870649807) * xsq;      xden = (xden + 0.0659881378689285515) * xsq;
+        xnum = (xnum + 0.001421619193227893466) * xsq;   xden = (xden + 0.00378239633202758244) * xsq;
+        double temp = xsq * (xnum + 2.9112874951168792e-5) / (xden + 7.29751555083966205e-5);
+        temp = (0.398942280401432677939946059934 - temp) / y;
+        const double ysq = __builtin_trunc(y * 16.0) / 16.0;
+        const double del = (y - ysq) * (y + ysq);
+        upper = dexp(-ysq * ysq * 0.5) * dexp(-del * 0.5) * temp;
+    } else {
+        upper = 0.0;
+    }
+    return 2.0 * upper;
+}
+
 // ----------------------------------------------------------------- stirlerr
 // log(n!) - log(sqrt(2 pi n) (n/e)^n); table at half-integers <= 15.
 __device__ const double kSferrHalves[31] = {

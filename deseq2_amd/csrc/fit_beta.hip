@@ -109,6 +109,8 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     const int m = kp.m;
     const int M = m + P;
     constexpr int N = SymNB<P>::value;
+    const int nwork = DSQ_NWORK(kp);
+    if (blockIdx.x * waves >= nwork) return;     // (row-listed launches size the grid without knowing the count)
 
     const double *xs = kp.x;          // X through L1/L2 unless it also fits in LDS
     double *slab;
@@ -139,7 +141,8 @@ DSQ_UNROLL_P
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
 
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g = next_gene(kp.work_counter, g, gridDim.x * waves, lane)) {
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -539,6 +542,7 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
     beta_geometry<DSQ_P>(kp0.n, kp0.m, kp0.useWeights != 0, &waves, &stage, &xlds, &grid, &lds);
     BetaKernelParams kp = kp0;
     kp.xlds = xlds;
+    if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();   // a row list: its length lives on the device
     if (stage) {
         if (kp.useWeights)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true>), dim3(grid), dim3(64 * waves), lds, st, kp);

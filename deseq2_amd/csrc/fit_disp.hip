@@ -403,6 +403,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
+    const int nwork = DSQ_NWORK(kp);
+    if (blockIdx.x * waves >= nwork) return;     // (row-listed launches size the grid without knowing the count)
 
     const double *xs = smem;
     double *slab = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)wave * m * (USE_W ? 4 : 3);
@@ -419,7 +421,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         }
     }
 
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g = next_gene(kp.work_counter, g, gridDim.x * waves, lane)) {
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *mug = kp.mu_hat + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         }
         G.m = m; G.lane = lane;
         G.prior_mean = kp.prior_mean[g];
-        G.prior_sigmasq = kp.prior_sigmasq;
+        G.prior_sigmasq = kp.prior_sigmasq_dev ? *kp.prior_sigmasq_dev : kp.prior_sigmasq;
         G.thr = kp.weightThreshold;
         G.usePrior = kp.usePrior != 0;
         G.useCR = kp.useCR != 0;
@@ -573,6 +576,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const int cus = device_cu_count();
     int blocks_needed = (kp.n + waves - 1) / waves;
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
+    if (kp.rows_few && grid > cus) grid = cus;        // a row list (stragglers, refits): its length lives on the device
     if (grid < 1) grid = 1;
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);

@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
     double *cn = smem + (size_t)wave * (m + kp.sortcap);
     double *buf = cn + m;
     const double inf = __builtin_inf();
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         double acc = 0.0;
@@ -176,7 +178,9 @@ __global__ void __launch_bounds__(256) replace_kernel(ReplaceKernelParams kp) {
     double *buf = smem + (size_t)wave * kp.sortcap;
     const double inf = __builtin_inf();
     const int n2 = pow2_at_least(m);
-    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *ckg = kp.cooks + (size_t)g * kp.ld;

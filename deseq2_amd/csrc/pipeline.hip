@@ -1,0 +1,886 @@
+// pipeline.hip -- dsq_deseq_dev: the whole DESeq() chain driven from the device (include/deseq2_mi355x.h).
+//
+// The reference's R code between the native calls is per-gene arithmetic on n-vectors (clamps, accept /
+// convergence / refit rules: R/core.R:727-728, 785, 826-848, 1019-1024, 1048-1063, 1099-1115; betaConv, log2
+// rescaling, Wald statistic: R/fitNbinomGLMs.R:185-198, R/core.R:1471,1507) plus two all-gene steps
+// (parametricDispersionFit R/core.R:2166-2190, mad of the log residuals R/methods.R:180).  Here each rule is a
+// small elementwise kernel, the rows a rule sends on (fitDispGrid stragglers, replaced-outlier rows) are
+// compacted on the device and fitted by ROW-LISTED launches of the same fit kernels (DispKernelParams::rows /
+// n_dev), and the all-gene steps are single-workgroup kernels, so a phase is one uninterrupted stream of
+// launches: no host decision, no device-to-host copy.  Every formula is evaluated with the operations of the
+// host mirror (deseq2_amd/core.py: IEEE + - * / sqrt, the engine's dlog / dexp, numpy's NaN-propagating
+// minimum / maximum), so the results equal the call-by-call chain bit for bit (tests/test_gpu_fused.py).
+#include "../../include/deseq2_mi355x.h"
+#include "dsq_internal.hpp"
+#include "dsq_math.hpp"
+#include "dsq_wave.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace dsq {
+
+hipError_t launch_trend_fit_dev(const double *means, const double *disps, const int32_t *n_dev, double *coefs,
+                                int32_t *status, void *workspace, hipStream_t st);
+
+// numpy.minimum / numpy.maximum: NaN if either operand is NaN
+DSQ_DEV double np_min(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? a : b); }
+DSQ_DEV double np_max(double a, double b) { return (a != a || b != b) ? a + b : (a > b ? a : b); }
+
+struct Rows {                 // the genes a rule kernel covers: rows[0 .. *n_dev) or 0 .. n-1
+    const int32_t *rows;
+    const int32_t *n_dev;
+    int n;
+};
+DSQ_DEV int rows_count(const Rows &r) { return r.n_dev ? *r.n_dev : r.n; }
+DSQ_DEV int rows_gene(const Rows &r, int i) { return r.rows ? r.rows[i] : i; }
+
+// ---- ordered compaction by one workgroup (the trend fit sums its input in index order) -------------------------
+// mode 0: keep = !(allZero | force_zero) -> rows; also folds force_zero into allZero
+// mode 1: keep = disp > thresh -> (means, disps) pairs (useForFit, R/core.R:870)
+__global__ void __launch_bounds__(1024) compact_kernel(int mode, int n, int32_t *allZero, const int32_t *force_zero,
+                                                       const double *mean_in, const double *disp_in, double thresh,
+                                                       int32_t *rows_out, double *mean_out, double *disp_out,
+                                                       int32_t *count_out) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    int c = 0;
+    for (int i = lo; i < hi; i++) {
+        bool keep;
+        if (mode == 0) {
+            int z = allZero[i] | (force_zero ? force_zero[i] : 0);
+            if (force_zero) allZero[i] = z ? 1 : 0;
+            keep = !z;
+        } else {
+            keep = disp_in[i] > thresh;
+        }
+        c += keep ? 1 : 0;
+    }
+    cnt[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 1024; k++) { int v = cnt[k]; cnt[k] = run; run += v; }
+        *count_out = run;
+    }
+    __syncthreads();
+    int o = cnt[t];
+    for (int i = lo; i < hi; i++) {
+        if (mode == 0) {
+            if (!allZero[i]) rows_out[o++] = i;
+        } else if (disp_in[i] > thresh) {
+            mean_out[o] = mean_in[i];
+            disp_out[o] = disp_in[i];
+            o++;
+        }
+    }
+}
+
+// ---- stats::mad of the log dispersion residuals + the prior variance (R/methods.R:172-181, R/core.R:1135-1208) ----
+// Order statistics by radix selection on the order-preserving 64-bit image of the doubles: 8 passes of 8 bits per
+// rank, one workgroup.  A selected order statistic is exact, so the medians equal numpy's.
+DSQ_DEV uint64_t key_of(double d) {
+    uint64_t u = d2bits(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+DSQ_DEV double double_of(uint64_t k) {
+    uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return bits2d(u);
+}
+
+template <class F>
+DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc) {
+    // the rank-th smallest (0-based) of value(i), i < n; every thread returns it
+    uint64_t prefix = 0, mask = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            uint64_t k = key_of(value(i));
+            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long r = rank;
+            int d = 0;
+            for (; d < 255; d++) {
+                if (r < (long)hist[d]) break;
+                r -= (long)hist[d];
+            }
+            bc[0] = (unsigned long long)d;
+            bc[1] = (unsigned long long)r;
+        }
+        __syncthreads();
+        prefix |= (uint64_t)bc[0] << shift;
+        mask |= (uint64_t)255 << shift;
+        rank = (long)bc[1];
+        __syncthreads();
+    }
+    return double_of(prefix);
+}
+
+template <class F>
+DSQ_DEV double block_median(int n, long k, F &&value, unsigned *hist, unsigned long long *bc) {
+    // numpy.median of the k smallest-ranked (finite) values: invalid entries are +inf and sort last
+    if (k & 1) return block_select(n, k / 2, value, hist, bc);
+    double a = block_select(n, k / 2 - 1, value, hist, bc);
+    double b = block_select(n, k / 2, value, hist, bc);
+    return (a + b) * 0.5;
+}
+
+__global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, const double *disp, int n, double minDisp,
+                                                         double expVarLogDisp, int m_gt_p, double *resbuf,
+                                                         double *scalars, int32_t *status) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long bc[2];
+    __shared__ int kshared;
+    const double inf = __builtin_inf();
+    const double c0 = scalars[DSQ_SC_COEF0], c1 = scalars[DSQ_SC_COEF1];
+    if (threadIdx.x == 0) kshared = 0;
+    __syncthreads();
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double d = disp[i];
+        bool above = d >= minDisp * 100.0;                       // aboveMinDisp, R/core.R:897 / :1137
+        double r = inf;
+        if (above) {
+            double fit = c0 + c1 / mean[i];
+            r = dlog(d) - dlog(fit);
+            c++;
+        }
+        resbuf[i] = r;
+    }
+    atomicAdd(&kshared, c);
+    __syncthreads();
+    const long k = kshared;
+    if (threadIdx.x == 0) status[DSQ_ST_N_ABOVE_MIN] = (int32_t)k;
+    if (k == 0) {
+        if (threadIdx.x == 0) { scalars[DSQ_SC_VAR_LOG_DISP] = dnan(); scalars[DSQ_SC_DISP_PRIOR_VAR] = dnan(); }
+        return;
+    }
+    __threadfence_block();
+    const double med = block_median(n, k, [&](int i) { return resbuf[i]; }, hist, bc);
+    const double med2 = block_median(n, k, [&](int i) {
+        double r = resbuf[i];
+        return (r == inf) ? inf : __builtin_fabs(r - med);
+    }, hist, bc);
+    if (threadIdx.x == 0) {
+        const double mad = 1.4826 * med2;
+        const double v = mad * mad;
+        scalars[DSQ_SC_VAR_LOG_DISP] = v;
+        double pv = v;
+        if (m_gt_p) {
+            const double t = v - expVarLogDisp;
+            pv = (0.25 > t) ? 0.25 : t;                           // max(varLogDispEsts - expVarLogDisp, 0.25), :1200
+        }
+        scalars[DSQ_SC_DISP_PRIOR_VAR] = pv;
+    }
+}
+
+// ---- per-gene rules ----------------------------------------------------------------------------------------------
+struct RuleParams {
+    Rows rw;
+    int n;                       // capacity / leading dimension of the n x p matrices
+    int p;
+    double minDisp, maxDisp, xim, outlierSD;
+    int maxit, betaMaxit;
+    const double *baseMean, *baseVar, *roughDisp;
+    double *alpha_init, *la0;
+    // fitDisp outputs
+    const double *la_out, *initial_lp, *last_lp;
+    const int32_t *iter;
+    const double *la_grid;
+    double *dge;
+    int32_t *dispGeneIter;
+    int32_t *grid_flag, *grid_rows, *grid_count;
+    const double *scalars;
+    double *dispFit, *log_dfit, *la_init, *dispMAP, *dispersion;
+    int32_t *dispIter, *dispOutlier;
+    // GLM fit
+    const double *beta_nat, *beta_var, *beta_iter, *logLike;
+    double *beta, *betaSE, *stat, *pvalue, *betaIter_out;
+    int32_t *betaConv, *optim_flag, *optim_count;
+    int wald;
+};
+
+// alpha_hat <- pmin(roughDisp, momentsDisp), bounded to [minDisp, maxDisp] (R/core.R:713-728, :2439-2448)
+__global__ void alpha_init_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    const double bm = q.baseMean[g], bv = q.baseVar[g];
+    const double mom = (bv - q.xim * bm) / (bm * bm);
+    double a = np_min(q.roughDisp[g], mom);
+    a = np_min(np_max(q.minDisp, a), q.maxDisp);
+    q.alpha_init[g] = a;
+    q.la0[g] = dlog(a);
+}
+
+// after the gene-wise fitDisp: accept / convergence / refit rules (R/core.R:785, 826-835)
+__global__ void gene_est_post_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    double d = np_min(dexp(q.la_out[g]), q.maxDisp);
+    const double ilp = q.initial_lp[g];
+    if (q.last_lp[g] < ilp + __builtin_fabs(ilp) / 1e6) d = q.alpha_init[g];      // noIncrease
+    const int it = q.iter[g];
+    q.dispGeneIter[g] = it;
+    const bool conv = (it < q.maxit) && !(it == 1);
+    const bool refit = !conv && (d > q.minDisp * 10.0);
+    q.dge[g] = d;
+    q.grid_flag[g] = refit ? 1 : 0;
+    if (refit) q.grid_rows[atomicAdd(q.grid_count, 1)] = g;
+}
+
+// dispGeneEst[refitDisp] <- exp(grid); final clamp (R/core.R:846-848)
+__global__ void gene_est_final_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    double d = q.dge[g];
+    if (q.grid_flag[g]) d = dexp(q.la_grid[g]);
+    q.dge[g] = np_min(np_max(d, q.minDisp), q.maxDisp);
+}
+
+// dispFit from the trend; start value and prior mean of the MAP search (R/core.R:1019-1024)
+__global__ void map_init_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    const double fit = q.scalars[DSQ_SC_COEF0] + q.scalars[DSQ_SC_COEF1] / q.baseMean[g];
+    const double d = q.dge[g];
+    double init = (d > 0.1 * fit) ? d : fit;
+    if (init != init) init = fit;
+    q.dispFit[g] = fit;
+    q.log_dfit[g] = dlog(fit);
+    q.la_init[g] = dlog(init);
+}
+
+// after the MAP fitDisp: dispMAP, convergence, stragglers to the grid (R/core.R:1042-1050)
+__global__ void map_post_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    const int it = q.iter[g];
+    q.dispMAP[g] = dexp(q.la_out[g]);
+    q.dispIter[g] = it;
+    const bool refit = !(it < q.maxit);
+    q.grid_flag[g] = refit ? 1 : 0;
+    if (refit) q.grid_rows[atomicAdd(q.grid_count, 1)] = g;
+}
+
+// dispMAP[refit] <- exp(grid); clamp; dispOutlier; final dispersion (R/core.R:1061-1063, 1099-1115)
+__global__ void map_final_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    double dm = q.dispMAP[g];
+    if (q.grid_flag[g]) dm = dexp(q.la_grid[g]);
+    dm = np_min(np_max(dm, q.minDisp), q.maxDisp);
+    q.dispMAP[g] = dm;
+    const double d = q.dge[g];
+    const double sd = __builtin_sqrt(q.scalars[DSQ_SC_VAR_LOG_DISP]);
+    const bool outlier = dlog(d) > q.log_dfit[g] + q.outlierSD * sd;       // NaN compares false, as the mirror's mask
+    q.dispOutlier[g] = outlier ? 1 : 0;
+    q.dispersion[g] = outlier ? d : dm;
+}
+
+// the host half of fitNbinomGLMs (R/fitNbinomGLMs.R:185-211) + Wald statistic and p-value (R/core.R:1471,1507)
+__global__ void beta_post_kernel(RuleParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw)) return;
+    const int g = rows_gene(q.rw, i);
+    const double log2e = 1.4426950408889634;
+    bool stable = true, varpos = true;
+    for (int c = 0; c < q.p; c++) {
+        const double b = q.beta_nat[(size_t)g + (size_t)q.n * c], v = q.beta_var[(size_t)g + (size_t)q.n * c];
+        if (b != b) stable = false;
+        if (v <= 0.0) varpos = false;
+        if (q.beta) {
+            const double bl = log2e * b;
+            const double se = log2e * __builtin_sqrt(np_max(v, 0.0));
+            q.beta[(size_t)g + (size_t)q.n * c] = bl;
+            q.betaSE[(size_t)g + (size_t)q.n * c] = se;
+            if (q.wald) {
+                const double z = bl / se;
+                q.stat[(size_t)g + (size_t)q.n * c] = z;
+                q.pvalue[(size_t)g + (size_t)q.n * c] = dpnorm_upper2(z);
+            }
+        }
+    }
+    const double it = q.beta_iter[g];
+    const bool conv = it < (double)q.betaMaxit;
+    if (q.betaConv) q.betaConv[g] = conv ? 1 : 0;
+    if (q.betaIter_out) q.betaIter_out[g] = it;
+    const bool optim = !conv || !stable || !varpos;
+    q.optim_flag[g] = optim ? 1 : 0;
+    if (optim) atomicAdd(q.optim_count, 1);
+}
+
+// rows flagged -> list (order irrelevant: the listed launches write results at the gene's own position)
+__global__ void list_kernel(Rows rw, const int32_t *flag, int want, int32_t *rows_out, int32_t *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(rw)) return;
+    const int g = rows_gene(rw, i);
+    if ((flag[g] != 0) == (want != 0)) rows_out[atomicAdd(count, 1)] = g;
+}
+
+// refitWithoutOutliers: result columns of rows that became all-zero are NA (R/core.R:2535), only when some row
+// is actually refitted (:2496)
+struct NaRowsParams {
+    Rows rw;
+    int n, p;
+    const int32_t *allZero, *n_refit;
+    double *beta, *betaSE, *stat, *pvalue, *betaIter, *logLike, *logLikeReduced, *maxCooks;
+    int32_t *betaConv;
+};
+__global__ void na_rows_kernel(NaRowsParams q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(q.rw) || *q.n_refit <= 0) return;
+    const int g = rows_gene(q.rw, i);
+    if (!q.allZero[g]) return;
+    const double nan = dnan();
+    for (int c = 0; c < q.p; c++) {
+        q.beta[(size_t)g + (size_t)q.n * c] = nan;
+        q.betaSE[(size_t)g + (size_t)q.n * c] = nan;
+        if (q.stat) { q.stat[(size_t)g + (size_t)q.n * c] = nan; q.pvalue[(size_t)g + (size_t)q.n * c] = nan; }
+    }
+    q.betaIter[g] = nan; q.logLike[g] = nan; q.maxCooks[g] = nan;
+    if (q.logLikeReduced) q.logLikeReduced[g] = nan;
+    q.betaConv[g] = -1;
+}
+
+// maxCooks after the refit (R/core.R:2538-2546): NA everywhere when every sample is replaceable, else the row
+// maximum of the ORIGINAL Cook's distances over the samples in cells of >= 3, replaceable samples zeroed
+__global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld, const double *cooks, const int32_t *use,
+                                                         const int32_t *zero, int all_replaceable, int valid,
+                                                         const int32_t *n_refit, double *maxCooks) {
+    if (*n_refit <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int nw = rows_count(rw);
+    for (int wi = blockIdx.x * waves + wave; wi < nw; wi += gridDim.x * waves) {
+        const int g = rows_gene(rw, wi);
+        if (all_replaceable || !valid) {
+            if (lane == 0) maxCooks[g] = dnan();
+            continue;
+        }
+        const double *ck = cooks + (size_t)g * ld;
+        double mx = -__builtin_inf();
+        int isnan_ = 0;
+        for (int j = lane; j < m; j += 64) {
+            if (!use[j]) continue;
+            double v = zero[j] ? 0.0 : ck[j];
+            if (v != v) isnan_ = 1;
+            if (v > mx) mx = v;
+        }
+        double o, a, b;
+        o = lane_xor1(mx); mx = (o > mx) ? o : mx;
+        o = lane_xor2(mx); mx = (o > mx) ? o : mx;
+        o = lane_xor4(mx); mx = (o > mx) ? o : mx;
+        o = lane_xor8(mx); mx = (o > mx) ? o : mx;
+        lane_pair16(mx, a, b); mx = (b > a) ? b : a;
+        lane_pair32(mx, a, b); mx = (b > a) ? b : a;
+        if (lane == 0) maxCooks[g] = __any(isnan_) ? dnan() : mx;
+    }
+}
+
+// ---- orchestration -----------------------------------------------------------------------------------------------
+#define PIPE_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return capi_fail(e_ == hipErrorOutOfMemory ? DSQ_ERR_NOMEM : DSQ_ERR_DEVICE, "%s: %s", #expr, \
+                             hipGetErrorString(e_));                                                     \
+    } while (0)
+
+struct Pipe {
+    const DsqDeseqArgs *a;
+    const DsqDeseqOut *o;
+    hipStream_t st;
+    int n, m, p;
+    long ld;
+    double maxDisp, min_log_alpha;
+    // workspace (device)
+    double *roughDisp, *beta_init, *alpha_init, *la0, *la_out, *last_change, *initial_lp, *initial_dlp, *last_lp, *last_dlp;
+    double *la_grid, *log_dfit, *la_init, *beta_nat, *beta_var, *beta_iter, *cnum, *cden, *dev, *lam, *contrast, *resbuf;
+    double *trend_mean_c, *trend_disp_c, *robustDisp, *scratch, *cscratch;
+    int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
+    int32_t *cells_dev;            // perm | in3 | cell_start | use3 | replaceable
+    void *trend_ws;
+    int next_counter;
+    const char *tag;               // appended to the profile names of the refit chain's launches
+    // host-side facts of the design cells
+    int any3, maxcell, all_replaceable;
+};
+
+enum { CNT_NZ = 0, CNT_GRID1, CNT_TREND, CNT_GRID2, CNT_OPT1, CNT_OPT2, CNT_REP, CNT_REFIT, CNT_GRID1R, CNT_GRID2R,
+       CNT_OPT1R, CNT_OPT2R, CNT_N = 16 };
+
+static int *next_work_counter(Pipe &P) {
+    int *c = P.work_counters + (P.next_counter % 60);
+    P.next_counter++;
+    return c;
+}
+
+static inline dim3 ew_grid(int n) { return dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)); }
+
+static RuleParams rule_params(const Pipe &P, const Rows &rw) {
+    RuleParams q;
+    memset(&q, 0, sizeof q);
+    const DsqDeseqArgs *a = P.a;
+    const DsqDeseqOut *o = P.o;
+    q.rw = rw; q.n = P.n; q.p = P.p;
+    q.minDisp = a->minDisp; q.maxDisp = P.maxDisp; q.xim = a->xim; q.outlierSD = a->outlierSD;
+    q.maxit = a->maxit; q.betaMaxit = a->betaMaxit;
+    q.baseMean = o->baseMean; q.baseVar = o->baseVar; q.roughDisp = P.roughDisp;
+    q.alpha_init = P.alpha_init; q.la0 = P.la0;
+    q.la_out = P.la_out; q.initial_lp = P.initial_lp; q.last_lp = P.last_lp; q.iter = P.iter; q.la_grid = P.la_grid;
+    q.dge = o->dispGeneEst; q.dispGeneIter = o->dispGeneIter;
+    q.grid_flag = P.grid_flag; q.grid_rows = P.rows_grid;
+    q.scalars = o->scalars;
+    q.dispFit = o->dispFit; q.log_dfit = P.log_dfit; q.la_init = P.la_init; q.dispMAP = o->dispMAP;
+    q.dispersion = o->dispersion; q.dispIter = o->dispIter; q.dispOutlier = o->dispOutlier;
+    q.beta_nat = P.beta_nat; q.beta_var = P.beta_var; q.beta_iter = P.beta_iter;
+    return q;
+}
+
+static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const double *alpha, const double *weights,
+                           double *mu_out, double mu_floor, double *hat, double tol, int maxit, int useQR, double minmu,
+                           const char *name) {
+    const DsqDeseqArgs *a = P.a;
+    BetaKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld;
+    kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
+    kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.x = a->x; kp.alpha_hat = alpha; kp.contrast = P.contrast; kp.beta_init = P.beta_init; kp.lambda = P.lam;
+    kp.tol = tol; kp.minmu = minmu; kp.mu_floor = mu_floor; kp.maxit = maxit; kp.useQR = useQR ? 1 : 0;
+    kp.beta_mat = P.beta_nat; kp.beta_var_mat = P.beta_var; kp.iter = P.beta_iter;
+    kp.contrast_num = P.cnum; kp.contrast_denom = P.cden; kp.deviance = P.dev;
+    kp.hat_diagonals = hat; kp.mu_out = mu_out;
+    kp.scratch = P.scratch; kp.cscratch = P.cscratch;
+    kp.work_counter = next_work_counter(P);
+    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
+    bool ok = false;
+    char nm[32];
+    snprintf(nm, sizeof nm, "%s%s", name, P.tag);
+    capi_prof_begin(nm, P.n, P.st);
+    PIPE_HIP(dispatch_fit_beta(P.p, kp, P.st, &ok));
+    capi_prof_end(P.st);
+    if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no register kernel for p=%d", P.p);
+    return DSQ_OK;
+}
+
+static int launch_fit_disp(Pipe &P, const Rows &rw, const int32_t *y, const double *mu, const double *la_in,
+                           const double *prior_mean, bool usePrior, const double *weights, bool useCR, bool grid,
+                           const char *name) {
+    const DsqDeseqArgs *a = P.a;
+    DispKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld;
+    kp.y = y; kp.mu_hat = mu; kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.x = a->x;
+    kp.log_alpha_in = la_in; kp.prior_mean = prior_mean;
+    kp.prior_sigmasq = 1.0;
+    kp.prior_sigmasq_dev = usePrior ? P.o->scalars + DSQ_SC_DISP_PRIOR_VAR : nullptr;
+    kp.min_log_alpha = P.min_log_alpha; kp.kappa_0 = a->kappa_0; kp.tol = a->dispTol;
+    kp.weightThreshold = a->weightThreshold; kp.maxit = a->maxit;
+    kp.usePrior = usePrior ? 1 : 0; kp.useCR = useCR ? 1 : 0;
+    kp.work_counter = next_work_counter(P);
+    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
+    if (grid) {
+        kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = P.la_grid;
+    } else {
+        kp.log_alpha = P.la_out; kp.iter = P.iter; kp.iter_accept = P.iter_accept; kp.last_change = P.last_change;
+        kp.initial_lp = P.initial_lp; kp.initial_dlp = P.initial_dlp; kp.last_lp = P.last_lp; kp.last_dlp = P.last_dlp;
+        kp.last_d2lp = nullptr;          // never read by estimateDispersions* (R/core.R:784-787, 1042)
+    }
+    bool ok = false;
+    char nm[32];
+    snprintf(nm, sizeof nm, "%s%s", name, P.tag);
+    capi_prof_begin(nm, P.n, P.st);
+    PIPE_HIP(dispatch_fit_disp(P.p, kp, P.st, grid, &ok));
+    capi_prof_end(P.st);
+    if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no register kernel for p=%d", P.p);
+    return DSQ_OK;
+}
+
+static int launch_prefit_rows(Pipe &P, const Rows &rw, const int32_t *y) {
+    const DsqDeseqArgs *a = P.a;
+    PrefitKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld;
+    kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
+    kp.weights = a->useWeights ? a->weights_raw : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.q = a->q; kp.a = a->a; kp.r = a->r;
+    kp.baseMean = P.o->baseMean; kp.baseVar = P.o->baseVar; kp.roughDisp = P.roughDisp; kp.beta_init = P.beta_init;
+    kp.allZero = P.o->allZero;
+    kp.rows = rw.rows; kp.n_dev = rw.n_dev;
+    bool ok = false;
+    capi_prof_begin(rw.rows ? "prefit_moments:refit" : "prefit_moments", P.n, P.st);
+    PIPE_HIP(launch_prefit(kp, P.st, &ok));
+    capi_prof_end(P.st);
+    if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d", P.p);
+    return DSQ_OK;
+}
+
+// estimateDispersionsGeneEst on the rows `rw` of the count matrix y (R/core.R:657-860, niter = 1); mu-hat -> mu_hat
+static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, int cnt_grid, int cnt_optim,
+                    int32_t *optim_flag) {
+    const DsqDeseqArgs *a = P.a;
+    RuleParams q = rule_params(P, rw);
+    hipLaunchKernelGGL(alpha_init_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    int rc;
+    if (a->linearMu) {
+        PrefitKernelParams kp;
+        memset(&kp, 0, sizeof kp);
+        kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld; kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
+        kp.q = a->q; kp.a = a->a;
+        kp.rows = rw.rows; kp.n_dev = rw.n_dev;
+        bool ok = false;
+        capi_prof_begin("linear_mu", P.n, P.st);
+        PIPE_HIP(launch_linear_mu(kp, 0.5, mu_hat, P.st, &ok));            // minmu of estimateDispersionsGeneEst
+        capi_prof_end(P.st);
+        if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d", P.p);
+    } else {
+        // fitNbinomGLMs(alpha_hat = alpha_hat) with mu floored at minmu (R/core.R:755-763); rows the IRLS leaves
+        // to the optim fallback are flagged for the caller
+        // (the arguments of THIS fitNbinomGLMs call are its defaults: DESeq()'s betaTol / maxit / useQR / minmu reach
+        // only the test's fit, R/core.R:401-411)
+        rc = launch_fit_beta(P, rw, y, P.alpha_init, a->weights_norm, mu_hat, 0.5, nullptr, 1e-8, 100, 1, 0.5, "fit_beta");
+        if (rc) return rc;
+        RuleParams b = rule_params(P, rw);
+        b.betaMaxit = 100;
+        b.optim_flag = optim_flag; b.optim_count = P.counters + cnt_optim;
+        hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    }
+    rc = launch_fit_disp(P, rw, y, mu_hat, P.la0, P.la0, false, a->weights_floor, a->useCR != 0, false, "fit_disp");
+    if (rc) return rc;
+    q.grid_count = P.counters + cnt_grid;
+    hipLaunchKernelGGL(gene_est_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    Rows gr = {P.rows_grid, P.counters + cnt_grid, P.n};
+    rc = launch_fit_disp(P, gr, y, mu_hat, P.la0, P.la0, false, a->weights_floor, a->useCR != 0, true, "fit_disp_grid");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gene_est_final_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
+// estimateDispersionsMAP (R/core.R:943-1131) on the rows `rw`
+static int map_est(Pipe &P, const Rows &rw, const int32_t *y, const double *mu_hat, int cnt_grid) {
+    const DsqDeseqArgs *a = P.a;
+    RuleParams q = rule_params(P, rw);
+    hipLaunchKernelGGL(map_init_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    int rc = launch_fit_disp(P, rw, y, mu_hat, P.la_init, P.log_dfit, true, a->weights_norm, a->useCR != 0, false, "fit_disp");
+    if (rc) return rc;
+    q.grid_count = P.counters + cnt_grid;
+    hipLaunchKernelGGL(map_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    Rows gr = {P.rows_grid, P.counters + cnt_grid, P.n};
+    rc = launch_fit_disp(P, gr, y, mu_hat, P.la_init, P.log_dfit, true, a->weights_norm, true, true, "fit_disp_grid");   // useCR = TRUE, :1061
+    if (rc) return rc;
+    hipLaunchKernelGGL(map_final_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
+// nbinomWaldTest / nbinomLRT(reduced = ~1) on the rows `rw` (R/core.R:1403-1408, 1471, 1507; 1850-1878)
+static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat, int cnt_optim) {
+    const DsqDeseqArgs *a = P.a;
+    const DsqDeseqOut *o = P.o;
+    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, a->betaTol, a->betaMaxit, a->useQR,
+                             a->minmu, "fit_beta");
+    if (rc) return rc;
+    LogLikeKernelParams lk;
+    memset(&lk, 0, sizeof lk);
+    lk.n = P.n; lk.m = P.m; lk.ld = P.ld; lk.y = y; lk.mu = mu_out; lk.disp = o->dispersion;
+    lk.weights = a->useWeights ? a->weights_norm : nullptr; lk.useWeights = a->useWeights ? 1 : 0;
+    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev;
+    capi_prof_begin(P.tag[0] ? "nbinom_loglike:refit" : "nbinom_loglike", P.n, P.st);
+    PIPE_HIP(launch_loglike(lk, P.st));
+    capi_prof_end(P.st);
+    RuleParams b = rule_params(P, rw);
+    b.beta = o->beta; b.betaSE = o->betaSE; b.stat = o->stat; b.pvalue = o->pvalue; b.wald = (a->test == 0) ? 1 : 0;
+    b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
+    b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
+    hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    if (a->test == 1) {
+        InterceptKernelParams ik;
+        memset(&ik, 0, sizeof ik);
+        ik.n = P.n; ik.m = P.m; ik.ld = P.ld; ik.y = y; ik.nf = a->nf; ik.nf_is_vector = a->nf_is_vector;
+        ik.weights = a->useWeights ? a->weights_norm : nullptr; ik.useWeights = a->useWeights ? 1 : 0;
+        ik.alpha = o->dispersion; ik.beta_log2 = P.cnum; ik.betaSE = P.cden;      // not read by nbinomLRT
+        ik.loglike = o->logLikeReduced; ik.rows = rw.rows; ik.n_dev = rw.n_dev;
+        capi_prof_begin("intercept_fit", P.n, P.st);
+        PIPE_HIP(launch_intercept_fit(ik, P.st));
+        capi_prof_end(P.st);
+    }
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
+static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+
+struct Carve {
+    size_t o_rough, o_binit, o_ainit, o_la0, o_laout, o_lchg, o_ilp, o_idlp, o_llp, o_ldlp, o_lagrid, o_ldfit, o_lainit,
+        o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, dbl;
+    size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, ints;
+    size_t bytes;
+};
+
+static Carve carve(int n, int p, int nt) {
+    Carve c;
+    const size_t nd = align8((size_t)n), np_ = align8((size_t)n * p), ntd = align8((size_t)nt);
+    size_t d = 0;
+    auto takeD = [&](size_t k) { size_t off = d; d += align8(k); return off; };
+    c.o_rough = takeD(nd); c.o_binit = takeD(np_); c.o_ainit = takeD(nd); c.o_la0 = takeD(nd); c.o_laout = takeD(nd);
+    c.o_lchg = takeD(nd); c.o_ilp = takeD(nd); c.o_idlp = takeD(nd); c.o_llp = takeD(nd); c.o_ldlp = takeD(nd);
+    c.o_lagrid = takeD(nd); c.o_ldfit = takeD(nd); c.o_lainit = takeD(nd); c.o_bnat = takeD(np_); c.o_bvar = takeD(np_);
+    c.o_biter = takeD(nd); c.o_cnum = takeD(nd); c.o_cden = takeD(nd); c.o_dev = takeD(nd); c.o_lam = takeD(2 * (size_t)p + 8);
+    c.o_res = takeD(ntd); c.o_tm = takeD(ntd); c.o_td = takeD(ntd); c.o_robust = takeD(nd);
+    c.dbl = d;
+    size_t i = 0;
+    auto takeI = [&](size_t k) { size_t off = i; i += align8(k); return off; };
+    c.i_iter = takeI(nd); c.i_itacc = takeI(nd); c.i_gflag = takeI(nd); c.i_nz = takeI(nd); c.i_grid = takeI(nd);
+    c.i_rep = takeI(nd); c.i_refit = takeI(nd); c.i_cnt = takeI(16); c.i_wc = takeI(64);
+    c.ints = i;
+    c.bytes = d * sizeof(double) + i * sizeof(int32_t) + 256;
+    return c;
+}
+
+static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
+    if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
+    if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (a->ld < a->m) return capi_fail(DSQ_ERR_ARG, "ld < m");
+    if (!a->y || !a->nf || !a->x || !a->q || !a->a || !a->r || !a->disp_grid || a->ngrid < 2 || !a->lambda) return capi_fail(DSQ_ERR_ARG, "NULL input");
+    if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
+    if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
+    if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT vs ~1)");
+    if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
+        !o->dispersion || !o->dispIter || !o->dispOutlier || !o->beta || !o->betaSE || !o->betaConv || !o->betaIter ||
+        !o->logLike || !o->maxCooks || !o->replace || !o->optim_geneest || !o->optim_test || !o->mu_hat || !o->mu || !o->H ||
+        !o->cooks || !o->replaceCounts || !o->status || !o->scalars)
+        return capi_fail(DSQ_ERR_ARG, "NULL output");
+    if (a->test == 0 && (!o->stat || !o->pvalue)) return capi_fail(DSQ_ERR_ARG, "Wald test needs stat / pvalue outputs");
+    if (a->test == 1 && !o->logLikeReduced) return capi_fail(DSQ_ERR_ARG, "LRT needs logLikeReduced");
+    if ((a->phases & DSQ_PH_OUTLIERS) && (!a->cell_of || !a->replaceable || a->ncell < 1)) return capi_fail(DSQ_ERR_ARG, "outlier phase needs cell_of / replaceable");
+    int rc = capi_check_device();
+    if (rc) return rc;
+
+    Pipe P;
+    memset(&P, 0, sizeof P);
+    P.a = a; P.o = o; P.st = st; P.tag = "";
+    const int n = P.n = a->n, m = P.m = a->m, p = P.p = a->p;
+    P.ld = a->ld;
+    P.maxDisp = m > 10 ? (double)m : 10.0;
+    P.min_log_alpha = a->min_log_alpha;
+    // ---- workspace carve (caller-owned: the row lists and counters persist between the phases of an analysis)
+    const int nt_cap = a->n_trend > n ? a->n_trend : n;      // (n_trend is the capacity even in the phases without a trend)
+    Carve cv = carve(n, p, nt_cap);
+    if (!a->workspace || a->workspace_bytes < (int64_t)cv.bytes)
+        return capi_fail(DSQ_ERR_ARG, "workspace of %lld bytes, dsq_deseq_workspace_bytes() asks for %zu",
+                         (long long)a->workspace_bytes, cv.bytes);
+    double *D = (double *)a->workspace;
+    int32_t *I = (int32_t *)(D + cv.dbl);
+    P.roughDisp = D + cv.o_rough; P.beta_init = D + cv.o_binit; P.alpha_init = D + cv.o_ainit; P.la0 = D + cv.o_la0;
+    P.la_out = D + cv.o_laout; P.last_change = D + cv.o_lchg; P.initial_lp = D + cv.o_ilp; P.initial_dlp = D + cv.o_idlp;
+    P.last_lp = D + cv.o_llp; P.last_dlp = D + cv.o_ldlp; P.la_grid = D + cv.o_lagrid; P.log_dfit = D + cv.o_ldfit;
+    P.la_init = D + cv.o_lainit; P.beta_nat = D + cv.o_bnat; P.beta_var = D + cv.o_bvar; P.beta_iter = D + cv.o_biter;
+    P.cnum = D + cv.o_cnum; P.cden = D + cv.o_cden; P.dev = D + cv.o_dev; P.lam = D + cv.o_lam; P.contrast = P.lam + p;
+    P.resbuf = D + cv.o_res; P.trend_mean_c = D + cv.o_tm; P.trend_disp_c = D + cv.o_td; P.robustDisp = D + cv.o_robust;
+    P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
+    P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = I + cv.i_cnt;
+    P.work_counters = I + cv.i_wc;
+    {
+        size_t slab_d = 0, cscr_d = 0;
+        dispatch_beta_scratch(p, n, m, a->useWeights, &slab_d, &cscr_d);
+        void *b;
+        rc = capi_ws_get(DSQ_WS_PIPE_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b);
+        if (rc) return rc;
+        P.scratch = (double *)b; P.cscratch = (double *)b + slab_d;
+    }
+    // dynamic-scheduling counters of the fit launches of THIS call; the row-list counters of the phases it runs
+    PIPE_HIP(hipMemsetAsync(P.work_counters, 0, 64 * sizeof(int32_t), st));
+    {   // the ridge (R/fitNbinomGLMs.R:73,162) and the default contrast (R/wrappers.R:105-108)
+        static double host[2 * DSQ_P_REG + 8];      // (under the library lock; pageable copies are staged at once)
+        for (int c = 0; c < p; c++) { host[c] = a->lambda[c]; host[p + c] = (c == 0) ? 1.0 : 0.0; }
+        PIPE_HIP(hipMemcpyAsync(P.lam, host, 2 * (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
+
+    // ================================================================ gene-wise estimates
+    if (a->phases & DSQ_PH_GENE_EST) {
+        PIPE_HIP(hipMemsetAsync(P.counters, 0, CNT_N * sizeof(int32_t), st));
+        PIPE_HIP(hipMemsetAsync(o->status, 0, DSQ_ST_COUNT * sizeof(int32_t), st));
+        // results of rows that turn out all-zero stay NA: 0xFF bytes are a NaN / -1
+        for (double *v : {o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter, o->logLike, o->maxCooks})
+            PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(double), st));
+        if (o->logLikeReduced) PIPE_HIP(hipMemsetAsync(o->logLikeReduced, 0xFF, (size_t)n * sizeof(double), st));
+        for (double *v : {o->beta, o->betaSE, o->stat, o->pvalue})
+            if (v) PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * p * sizeof(double), st));
+        for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv})
+            PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(int32_t), st));
+        for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag})
+            PIPE_HIP(hipMemsetAsync(v, 0, (size_t)n * sizeof(int32_t), st));
+        const Rows all = {nullptr, nullptr, n};
+        rc = launch_prefit_rows(P, all, a->y);                                   // getBaseMeansAndVariances + moments
+        if (rc) return rc;
+        hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, 0, n, o->allZero, a->force_zero,
+                           (const double *)nullptr, (const double *)nullptr, 0.0, P.rows_nz, (double *)nullptr,
+                           (double *)nullptr, P.counters + CNT_NZ);
+        rc = gene_est(P, nz, a->y, o->mu_hat, CNT_GRID1, CNT_OPT1, o->optim_geneest);
+        if (rc) return rc;
+    }
+    // ================================================================ dispersion trend + prior variance
+    if (a->phases & DSQ_PH_TREND) {
+        const double *tm = a->trend_mean ? a->trend_mean : o->baseMean;
+        const double *td = a->trend_mean ? a->trend_disp : o->dispGeneEst;
+        const int nt = a->trend_mean ? a->n_trend : n;
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_TREND, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, 1, nt, (int32_t *)nullptr, (const int32_t *)nullptr,
+                           tm, td, 100.0 * a->minDisp, (int32_t *)nullptr, P.trend_mean_c, P.trend_disp_c,
+                           P.counters + CNT_TREND);
+        void *tws;
+        rc = capi_ws_get(DSQ_WS_PIPE_META, trend_fit_workspace_bytes() + 64, &tws);
+        if (rc) return rc;
+        capi_prof_begin("trend_fit", nt, st);
+        PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
+                                      o->status + DSQ_ST_TREND_STATUS, tws, st));
+        capi_prof_end(st);
+        capi_prof_begin("prior_var", nt, st);
+        hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
+                           (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status);
+        capi_prof_end(st);
+        PIPE_HIP(hipGetLastError());
+    }
+    // ================================================================ MAP dispersions + test
+    if (a->phases & DSQ_PH_MAP_TEST) {
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_GRID2, 0, sizeof(int32_t), st));
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT2, 0, sizeof(int32_t), st));
+        rc = map_est(P, nz, a->y, o->mu_hat, CNT_GRID2);
+        if (rc) return rc;
+        rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
+        if (rc) return rc;
+    }
+    // ================================================================ count outliers
+    if (a->phases & DSQ_PH_OUTLIERS) {
+        // design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags (nOrMoreInCell, :2366)
+        static std::vector<int32_t> meta;             // (under the library lock; staged by the copy below)
+        meta.assign((size_t)4 * m + a->ncell + 1, 0);
+        int32_t *perm = meta.data(), *in3 = perm + m, *repl = in3 + m, *use3 = repl + m, *start = use3 + m;
+        for (int j = 0; j < m; j++) {
+            if (a->cell_of[j] < 0 || a->cell_of[j] >= a->ncell) return capi_fail(DSQ_ERR_VALUE, "cell_of[%d] out of range", j);
+            start[a->cell_of[j] + 1]++;
+        }
+        int maxcell = 0, any3 = 0;
+        for (int c = 0; c < a->ncell; c++) {
+            int sz = start[c + 1];
+            if (sz > maxcell) maxcell = sz;
+            if (sz >= 3) any3 = 1;
+            start[c + 1] += start[c];
+        }
+        {
+            std::vector<int32_t> fill(start, start + a->ncell);
+            for (int j = 0; j < m; j++) perm[fill[a->cell_of[j]]++] = j;
+        }
+        int all_rep = 1;
+        for (int j = 0; j < m; j++) {
+            in3[j] = (start[a->cell_of[j] + 1] - start[a->cell_of[j]]) >= 3;
+            use3[j] = in3[j];
+            repl[j] = a->replaceable[j] ? 1 : 0;
+            if (!repl[j]) all_rep = 0;
+        }
+        void *mv;
+        rc = capi_ws_get(DSQ_WS_PIPE_META + 1, meta.size() * sizeof(int32_t) + 64, &mv);
+        if (rc) return rc;
+        PIPE_HIP(hipMemcpyAsync(mv, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        int32_t *dperm = (int32_t *)mv, *din3 = dperm + m, *drepl = din3 + m, *duse3 = drepl + m, *dstart = duse3 + m;
+        for (int k = CNT_REP; k < CNT_N; k++) PIPE_HIP(hipMemsetAsync(P.counters + k, 0, sizeof(int32_t), st));
+
+        CooksKernelParams ck;
+        memset(&ck, 0, sizeof ck);
+        ck.n = n; ck.m = m; ck.p = p; ck.ld = P.ld; ck.y = a->y; ck.nf = a->nf; ck.nf_is_vector = a->nf_is_vector;
+        ck.mu = o->mu; ck.H = o->H; ck.perm = dperm; ck.cell_start = dstart; ck.in3 = din3; ck.ncell = a->ncell; ck.any3 = any3;
+        int cap = 2; while (cap < (any3 ? maxcell : m)) cap <<= 1;
+        ck.sortcap = cap;
+        ck.cooks = o->cooks; ck.maxCooks = o->maxCooks; ck.robustDisp = P.robustDisp;
+        ck.rows = nz.rows; ck.n_dev = nz.n_dev;
+        bool ok = true;
+        capi_prof_begin("cooks_distance", n, st);
+        PIPE_HIP(launch_cooks(ck, st, &ok));
+        capi_prof_end(st);
+        if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "m=%d samples: a gene row plus its sort buffer exceeds the 160 KiB LDS", m);
+        if (a->do_replace) {
+            ReplaceKernelParams rk;
+            memset(&rk, 0, sizeof rk);
+            rk.n = n; rk.m = m; rk.ld = P.ld; rk.y = a->y; rk.nf = a->nf; rk.nf_is_vector = a->nf_is_vector;
+            rk.cooks = o->cooks; rk.cutoff = a->cooksCutoff; rk.trim = a->trim; rk.replaceable = drepl;
+            int cap2 = 2; while (cap2 < m) cap2 <<= 1;
+            rk.sortcap = cap2;
+            rk.newCounts = o->replaceCounts; rk.replace = o->replace;
+            rk.rows = nz.rows; rk.n_dev = nz.n_dev;
+            capi_prof_begin("replace_outliers", n, st);
+            PIPE_HIP(launch_replace(rk, st, &ok));
+            capi_prof_end(st);
+            if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "m=%d samples: the sort buffer exceeds the 160 KiB LDS", m);
+            // rows with a replacement (R/core.R:2488-2490) -> their moments on the new counts (:2491) -> the ones
+            // that are still non-zero are refitted (:2496-2500)
+            hipLaunchKernelGGL(list_kernel, ew_grid(n), dim3(256), 0, st, nz, (const int32_t *)o->replace, 1, P.rows_rep,
+                               P.counters + CNT_REP);
+            const Rows rep = {P.rows_rep, P.counters + CNT_REP, n};
+            rc = launch_prefit_rows(P, rep, o->replaceCounts);
+            if (rc) return rc;
+            hipLaunchKernelGGL(list_kernel, ew_grid(n), dim3(256), 0, st, rep, (const int32_t *)o->allZero, 0, P.rows_refit,
+                               P.counters + CNT_REFIT);
+            const Rows rf = {P.rows_refit, P.counters + CNT_REFIT, n};
+            // the same chain on the replaced rows; their mu-hat and fitted means go to the (now dead) mu_hat matrix,
+            // assays mu / H keep the original fit as in R (the refit runs on a subset object, :2500-2531)
+            P.tag = ":refit";
+            rc = gene_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID1R, CNT_OPT1R, o->optim_geneest);
+            if (rc) return rc;
+            rc = map_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID2R);
+            if (rc) return rc;
+            rc = test_fit(P, rf, o->replaceCounts, o->mu_hat, nullptr, CNT_OPT2R);
+            if (rc) return rc;
+            NaRowsParams nr;
+            memset(&nr, 0, sizeof nr);
+            nr.rw = rep; nr.n = n; nr.p = p; nr.allZero = o->allZero; nr.n_refit = P.counters + CNT_REFIT;
+            nr.beta = o->beta; nr.betaSE = o->betaSE; nr.stat = o->stat; nr.pvalue = o->pvalue; nr.betaIter = o->betaIter;
+            nr.logLike = o->logLike; nr.logLikeReduced = o->logLikeReduced; nr.maxCooks = o->maxCooks; nr.betaConv = o->betaConv;
+            hipLaunchKernelGGL(na_rows_kernel, ew_grid(n), dim3(256), 0, st, nr);
+            int grid = (n + 3) / 4, capg = device_cu_count() * 8;
+            if (grid > capg) grid = capg;
+            hipLaunchKernelGGL(masked_max_kernel, dim3(grid), dim3(256), 0, st, nz, m, P.ld, (const double *)o->cooks,
+                               (const int32_t *)duse3, (const int32_t *)drepl, all_rep, (m > p && any3) ? 1 : 0,
+                               (const int32_t *)(P.counters + CNT_REFIT), o->maxCooks);
+            PIPE_HIP(hipGetLastError());
+        }
+    }
+    // counters -> status block (one small device-to-device copy per phase set)
+    static const int map_[][2] = {{CNT_NZ, DSQ_ST_N_NONZERO}, {CNT_GRID1, DSQ_ST_N_GRID_GENEEST}, {CNT_TREND, DSQ_ST_N_TREND},
+                                  {CNT_GRID2, DSQ_ST_N_GRID_MAP}, {CNT_OPT1, DSQ_ST_N_OPTIM_GENEEST}, {CNT_OPT2, DSQ_ST_N_OPTIM_TEST},
+                                  {CNT_REP, DSQ_ST_N_REPLACE}, {CNT_REFIT, DSQ_ST_N_REFIT}, {CNT_GRID1R, DSQ_ST_N_GRID_GENEEST_REFIT},
+                                  {CNT_GRID2R, DSQ_ST_N_GRID_MAP_REFIT}, {CNT_OPT1R, DSQ_ST_N_OPTIM_GENEEST_REFIT},
+                                  {CNT_OPT2R, DSQ_ST_N_OPTIM_TEST_REFIT}};
+    for (auto &kv : map_)
+        PIPE_HIP(hipMemcpyAsync(o->status + kv[1], P.counters + kv[0], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return DSQ_OK;
+}
+
+}  // namespace dsq
+
+extern "C" int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_trend) {
+    (void)m;
+    if (n < 1 || p < 1) return 0;
+    return (int64_t)dsq::carve(n, p, n_trend > n ? n_trend : n).bytes;
+}
+
+extern "C" int dsq_deseq_dev(const DsqDeseqArgs *args, const DsqDeseqOut *out, void *stream) {
+    std::lock_guard<std::mutex> lk(dsq::capi_mutex());
+    dsq::capi_latch_stream((hipStream_t)stream);
+    return dsq::run(args, out, (hipStream_t)stream);
+}

@@ -111,6 +111,7 @@ __global__ void test_math_kernel(int op, const double *a, const double *b, const
     case 6: r = dstirlerr(x); break;
     case 7: r = dbd0(x, b[i]); break;
     case 8: r = dnbinom_mu_log(x, b[i], c[i]); break;
+    case 9: r = dpnorm_upper2(x); break;
     default: r = dnan();
     }
     out[i] = r;

@@ -200,9 +200,8 @@ class HostEngine:
         return 1.4826 * np.median(np.abs(v - med))
 
     def two_sided_normal_p(self, z):
-        """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507"""
-        from scipy import special as sps
-        return 2 * sps.ndtr(-np.abs(z))
+        """2 * pnorm(abs(z), lower.tail = FALSE), R/core.R:1507 (Cody's algorithm as in R's pnorm, engine arithmetic)"""
+        return self.fns.unary("pnorm_upper2", np.asarray(z, np.float64))
 
     # ---- count outliers (R/core.R:2333-2359, 2069-2115)
     def cooks_distance(self, y, nf, mu, H, x):
@@ -388,7 +387,14 @@ class DeviceEngine:
         out[:, : h.m] = h.view() / h.view().max(dim=1, keepdim=True).values
         return self.native.GeneMajor(out, h.m)
 
+    def _prof_lock(self):
+        return _PROF_LOCK
+
     def weights_ok(self, w, x, thr, full_rank):
+        return self._host(self.weights_ok_dev(w, x, thr, full_rank)).numpy()
+
+    def weights_ok_dev(self, w, x, thr, full_rank):
+        """the flags of weights_ok as a device tensor (no host round trip)"""
         t = self.torch
         xd = t.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=self.device)
         wv = w.view()
@@ -397,7 +403,7 @@ class DeviceEngine:
             ok = t.ones(w.n, dtype=t.bool, device=self.device)
             for j in range(p):
                 ok &= ~((wv * xd[None, :, j]) == 0).all(dim=1)
-            return self._host(ok).numpy()
+            return ok
 
         def rank(G):
             ev = t.linalg.eigvalsh(G)
@@ -408,8 +414,7 @@ class DeviceEngine:
         keep = (wv > thr).to(t.float64)
         G2 = (keep @ xx).reshape(-1, p, p)
         ncol = ((keep @ xd.abs()) > 0).sum(dim=1)
-        ok = (rank(G1) == p) & (rank(G2) == ncol)
-        return self._host(ok).numpy()
+        return (rank(G1) == p) & (rank(G2) == ncol)
 
     # ---- O(n*m) steps around the fits: HIP kernels too (csrc/aux.hip)
     def prefit(self, y, nf, x, weights=None):
@@ -459,10 +464,7 @@ class DeviceEngine:
         return float(1.4826 * med((x - m0).abs()))
 
     def two_sided_normal_p(self, z):
-        t = self.torch
-        zz = t.as_tensor(np.ascontiguousarray(z), device=self.device)
-        # 2*pnorm(-|z|) = erfc(|z|/sqrt(2)): keeps the far tail (ndtr flushes it to 0)
-        return self._host(t.special.erfc(zz.abs() * 0.7071067811865476)).numpy()
+        return self.native.unary("pnorm_upper2", np.asarray(z, np.float64))
 
     # ---- count outliers: HIP kernels (csrc/outlier.hip)
     def cooks_distance(self, y, nf, mu, H, x):

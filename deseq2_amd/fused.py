@@ -1,0 +1,365 @@
+"""DESeq() as ONE device-driven chain (dsq_deseq_dev, csrc/pipeline.hip).
+
+core.DESeq() mirrors the reference's R callers one call at a time: every decision rule between two native calls
+is host code on n-vectors, i.e. a device round trip.  Here the same rules run as kernels and the rows a rule sends
+on (fitDispGrid stragglers, replaced-outlier rows) are compacted on the device, so a whole phase is enqueued
+without a host decision.  The host looks at the device TWICE per analysis (after the test statistics, after the
+outlier refit): a few counters tell it whether any row needs the reference's host-side fallback (the L-BFGS-B
+rows of fitNbinomGLMsOptim, R/fitNbinomGLMs.R:340-407) -- those rows, and only those, are re-done through the
+call-by-call code of core.py on a row subset.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
+
+Supported: DeviceEngine, p <= 10, fitType = "parametric", betaPrior = FALSE, test = "Wald" or "LRT" against ~1,
+niter = 1.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import core
+
+
+def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
+    E = dds.engine
+    if getattr(E, "name", "") != "device" or fitType != "parametric":
+        return False
+    if dds.p > 10 or dds.m <= dds.p:
+        return False
+    if kw.get("betaPrior") or kw.get("modelMatrix") is not None or kw.get("useT") or not kw.get("useOptim", True):
+        return False
+    if set(kw) - {"betaPrior", "modelMatrix", "useT", "useOptim", "betaTol", "maxit", "useQR", "minmu", "disp_maxit"}:
+        return False
+    if test == "LRT":
+        r = None if reduced is None else np.asarray(reduced)
+        if r is None or r.shape[1] != 1 or not (r == 1).all():
+            return False
+    elif test != "Wald":
+        return False
+    return True
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _Run:
+    """buffers + argument block of one analysis"""
+
+    def __init__(self, dds, test, minReplicatesForReplace, n_trend, kw):
+        E = dds.engine
+        t = self.t = E.torch
+        self.dds, self.E = dds, E
+        dev = E.device
+        n, m, p, ld = dds.n, dds.m, dds.p, dds.y.ld
+        self.n, self.m, self.p, self.ld = n, m, p, ld
+        self.test = test
+        f64 = dict(dtype=t.float64, device=dev)
+        i32 = dict(dtype=t.int32, device=dev)
+        # ---- weights (getAndCheckWeights, R/core.R:2697-2751), all on the device
+        self.useWeights = bool(dds.has_weights)
+        self.neg = None
+        self.force_zero = None
+        if self.useWeights:
+            self.neg = (dds.weights_h.view() < 0).any()
+            self.w_norm = E.row_max_normalize(dds.weights_h)
+            self.w_floor = E.clamp_min(self.w_norm, 1e-6)
+            ok = E.weights_ok_dev(self.w_norm, dds.x, 1e-2, core._rank(dds.x) == p)
+            self.force_zero = (~ok).to(t.int32)
+        # ---- outputs
+        self.vec = t.empty((10, n), **f64)
+        (self.baseMean, self.baseVar, self.dispGeneEst, self.dispFit, self.dispMAP, self.dispersion, self.betaIter,
+         self.logLike, self.logLikeReduced, self.maxCooks) = self.vec
+        self.mat = t.empty((4, p, n), **f64)                      # beta, betaSE, stat, pvalue: (p, n) = column-major n x p
+        self.ivec = t.empty((9, n), **i32)
+        (self.allZero, self.dispGeneIter, self.dispIter, self.dispOutlier, self.betaConv, self.replace,
+         self.optim_geneest, self.optim_test, _) = self.ivec
+        self.mu_hat = t.empty((n, ld), **f64)
+        self.mu = t.empty((n, ld), **f64)
+        self.H = t.empty((n, ld), **f64)
+        self.cooks = t.empty((n, ld), **f64)
+        self.replaceCounts = t.empty((n, ld), **i32)
+        self.status = t.zeros(L.DSQ_ST_COUNT, **i32)
+        self.scalars = t.zeros(L.DSQ_SC_COUNT, **f64)
+        lib = L.lib()
+        wsb = int(lib.dsq_deseq_workspace_bytes(n, m, p, int(n_trend)))
+        self.workspace = t.empty(wsb, dtype=t.uint8, device=dev)
+        # ---- design facts (host, memoised per design)
+        x = dds.x
+        dq, da, dr = E._design_qr_dev(x)
+        self.keep = [dq, da, dr]
+        minDisp = 1e-8
+        self.minDisp = minDisp
+        grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 20)                    # R/wrappers.R:70-72
+        self.grid = E._vec(grid)
+        self.lam = np.ascontiguousarray(np.full(p, 1e-6) / np.log(2) ** 2)          # R/fitNbinomGLMs.R:73,162
+        xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
+        cells = E.native.cell_index(x)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        do_replace = bool(np.isfinite(minReplicatesForReplace) and core.nOrMoreInCell(x, minReplicatesForReplace).any())
+        self.do_replace = do_replace
+        rep = core.nOrMoreInCell(x, minReplicatesForReplace) if np.isfinite(minReplicatesForReplace) else np.zeros(m, bool)
+        self.replaceable = np.ascontiguousarray(rep.astype(np.int32))
+        from scipy.stats import f as fdist
+        from scipy import special as sps
+        cutoff = float(fdist.ppf(.99, p, m - p))                                     # R/core.R:2081
+        linearMu = (len(np.unique(core.modelMatrixGroups(x))) == p) and not self.useWeights   # :735-742
+        self.args = L.DsqDeseqArgs(
+            n=n, m=m, p=p, ld=ld, phases=0, y=_ptr(dds.y.t), nf=_ptr(dds.nf.t), nf_is_vector=0,
+            useWeights=int(self.useWeights),
+            weights_raw=_ptr(dds.weights_h.t) if self.useWeights else None,
+            weights_norm=_ptr(self.w_norm.t) if self.useWeights else None,
+            weights_floor=_ptr(self.w_floor.t) if self.useWeights else None,
+            force_zero=_ptr(self.force_zero), x=_ptr(dds.xh), q=_ptr(dq), a=_ptr(da), r=_ptr(dr), xim=xim,
+            linearMu=int(bool(linearMu)), minDisp=minDisp, kappa_0=1.0, dispTol=1e-6, weightThreshold=1e-2, outlierSD=2.0,
+            betaTol=kw.get("betaTol", 1e-8), minmu=kw.get("minmu", 0.5), maxit=int(kw.get("disp_maxit", 100)),
+            useCR=int(kw.get("useCR", True)), useQR=int(kw.get("useQR", True)), betaMaxit=int(kw.get("maxit", 100)),
+            disp_grid=_ptr(self.grid), ngrid=20,
+            expVarLogDisp=float(sps.polygamma(1, (m - p) / 2.0)) if m > p else 0.0,
+            trend_mean=None, trend_disp=None, n_trend=int(n_trend), lambda_=self.lam.ctypes.data_as(C.c_void_p),
+            min_log_alpha=float(np.log(minDisp / 10)), workspace=_ptr(self.workspace), workspace_bytes=wsb,
+            test=0 if test == "Wald" else 1, cell_of=self.cells.ctypes.data_as(C.c_void_p),
+            ncell=int(cells.max()) + 1, replaceable=self.replaceable.ctypes.data_as(C.c_void_p), cooksCutoff=cutoff,
+            trim=0.2, do_replace=int(do_replace))
+        self.cooksCutoff = cutoff
+        self.out = L.DsqDeseqOut(
+            baseMean=_ptr(self.baseMean), baseVar=_ptr(self.baseVar), allZero=_ptr(self.allZero),
+            dispGeneEst=_ptr(self.dispGeneEst), dispGeneIter=_ptr(self.dispGeneIter), dispFit=_ptr(self.dispFit),
+            dispMAP=_ptr(self.dispMAP), dispersion=_ptr(self.dispersion), dispIter=_ptr(self.dispIter),
+            dispOutlier=_ptr(self.dispOutlier), beta=_ptr(self.mat[0]), betaSE=_ptr(self.mat[1]),
+            stat=_ptr(self.mat[2]) if test == "Wald" else None, pvalue=_ptr(self.mat[3]) if test == "Wald" else None,
+            betaConv=_ptr(self.betaConv), betaIter=_ptr(self.betaIter), logLike=_ptr(self.logLike),
+            logLikeReduced=_ptr(self.logLikeReduced), maxCooks=_ptr(self.maxCooks), replace=_ptr(self.replace),
+            optim_geneest=_ptr(self.optim_geneest), optim_test=_ptr(self.optim_test), mu_hat=_ptr(self.mu_hat),
+            mu=_ptr(self.mu), H=_ptr(self.H), cooks=_ptr(self.cooks), replaceCounts=_ptr(self.replaceCounts),
+            status=_ptr(self.status), scalars=_ptr(self.scalars))
+
+    def launch(self, phases, trend=None):
+        self.args.phases = int(phases)
+        if trend is not None:
+            assert int(trend[0].numel()) == int(self.args.n_trend)
+            self.args.trend_mean, self.args.trend_disp = _ptr(trend[0]), _ptr(trend[1])
+            self._trend = trend
+        stream = C.c_void_p(self.t.cuda.current_stream().cuda_stream)
+        E = self.E
+        if E.record is not None:
+            lib = L.lib()
+            with E._prof_lock():
+                lib.dsq_profile_enable(1)
+                L.check(lib.dsq_deseq_dev(C.byref(self.args), C.byref(self.out), stream))
+                nm = C.create_string_buffer(40)
+                g, ms = C.c_int32(0), C.c_double(0.0)
+                for i in range(lib.dsq_profile_count()):
+                    lib.dsq_profile_get(i, nm, 40, C.byref(g), C.byref(ms))
+                    E.record.append((nm.value.decode(), int(g.value), ms.value))
+                lib.dsq_profile_enable(0)
+            return
+        L.check(L.lib().dsq_deseq_dev(C.byref(self.args), C.byref(self.out), stream))
+
+    def read_status(self):
+        """ONE small device-to-host copy + stream sync: counters and scalars of the phases run so far"""
+        t = self.t
+        parts = [self.status.to(t.float64), self.scalars]
+        if self.neg is not None:
+            parts.append(self.neg.to(t.float64).reshape(1))
+        h = self.E._host(t.cat(parts)).numpy()
+        st = {k: int(h[i]) for k, i in L.DSQ_ST.items()}
+        sc = h[L.DSQ_ST_COUNT: L.DSQ_ST_COUNT + L.DSQ_SC_COUNT]
+        if self.neg is not None and h[-1] != 0:
+            raise ValueError("all(weights >= 0) is not TRUE")
+        return st, sc
+
+
+def _rows_where(run, flag_tensor, extra=None):
+    t = run.t
+    f = flag_tensor != 0
+    if extra is not None:
+        f = f & extra
+    return run.E._host(f.nonzero().squeeze(1)).numpy()
+
+
+def _patch_gene_est(run, rows, kw):
+    """rows the gene-wise GLM fit left to the optim fallback: estimateDispersionsGeneEst of core.py on that subset
+    (genes are independent), written over the pipeline's dispGeneEst / dispGeneIter / mu-hat rows"""
+    dds, E, t = run.dds, run.E, run.t
+    sub = dds.subset(rows)
+    core.estimateDispersionsGeneEst(sub, maxit=kw.get("disp_maxit", 100))
+    ii = t.as_tensor(rows, device=E.device)
+    run.dispGeneEst[ii] = t.as_tensor(sub.mcols["dispGeneEst"], device=E.device)
+    run.dispGeneIter[ii] = t.as_tensor(np.asarray(sub.mcols["dispGeneIter"], np.int32), device=E.device)
+    run.mu_hat[ii] = sub.assays["mu"].t
+
+
+def _test_subset(run, sub, reduced, kw):
+    """nbinomWaldTest / nbinomLRT fits of core.py on a subset whose mcols dispersion is set; returns the columns the
+    pipeline keeps"""
+    tk = {k: v for k, v in kw.items() if k in ("betaTol", "maxit", "useQR", "minmu")}
+    E = sub.engine
+    weights, useWeights = core.getAndCheckWeights(sub)
+    fit = core.fitNbinomGLMs(sub, weights=weights, useWeights=useWeights, want_loglike=True, **tk)
+    out = {"beta": fit["betaMatrix"], "betaSE": fit["betaSE"], "betaConv": fit["betaConv"], "betaIter": fit["betaIter"],
+           "logLike": fit["logLike"], "mu": fit["mu"]}
+    if run.test == "Wald":
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out["stat"] = fit["betaMatrix"] / fit["betaSE"]
+        out["pvalue"] = E.two_sided_normal_p(out["stat"])
+    else:
+        red = core.fitNbinomGLMs(sub, modelMatrix=reduced, weights=weights, useWeights=useWeights, want_hat=False,
+                                 want_loglike=True, **tk)
+        out["logLikeReduced"] = red["logLike"]
+    return out
+
+
+def _write_test_rows(run, rows, o, write_mu=True):
+    E, t = run.E, run.t
+    ii = t.as_tensor(rows, device=E.device)
+    dv = lambda a: t.as_tensor(np.ascontiguousarray(a), device=E.device)     # noqa: E731
+    run.mat[0][:, ii] = dv(np.asarray(o["beta"]).T)
+    run.mat[1][:, ii] = dv(np.asarray(o["betaSE"]).T)
+    if run.test == "Wald":
+        run.mat[2][:, ii] = dv(np.asarray(o["stat"]).T)
+        run.mat[3][:, ii] = dv(np.asarray(o["pvalue"]).T)
+    else:
+        run.logLikeReduced[ii] = dv(o["logLikeReduced"])
+    run.betaConv[ii] = dv(np.asarray(o["betaConv"]).astype(np.int32))
+    run.betaIter[ii] = dv(np.asarray(o["betaIter"], np.float64))
+    run.logLike[ii] = dv(o["logLike"])
+    if write_mu:
+        run.mu[ii] = o["mu"].t
+
+
+def _patch_test(run, rows, reduced, kw):
+    """rows of the final GLM fit that go to the optim fallback (R/fitNbinomGLMs.R:203-227)"""
+    sub = run.dds.subset(rows)
+    sub.mcols["dispersion"] = run.E._host(run.dispersion[run.t.as_tensor(rows, device=run.E.device)]).numpy()
+    _write_test_rows(run, rows, _test_subset(run, sub, reduced, kw))
+
+
+def _patch_refit(run, rows, reduced, kw, fn):
+    """replaced-outlier rows whose refit needs the optim fallback: the refit of core.refitWithoutOutliers on them"""
+    E, t = run.E, run.t
+    dds = run.dds
+    sub = dds.subset(rows, run.E.native.GeneMajor(run.replaceCounts, dds.m))
+    core.estimateDispersionsGeneEst(sub, maxit=kw.get("disp_maxit", 100))
+    sub.dispersionFunction = dict(fn)
+    sub.mcols["dispFit"] = fn["coefficients"][0] + fn["coefficients"][1] / sub.mcols["baseMean"]
+    core.estimateDispersionsMAP(sub, dispPriorVar=fn["dispPriorVar"], maxit=kw.get("disp_maxit", 100))
+    ii = t.as_tensor(rows, device=E.device)
+    dv = lambda a: t.as_tensor(np.ascontiguousarray(a), device=E.device)     # noqa: E731
+    for k, dst in (("dispGeneEst", run.dispGeneEst), ("dispFit", run.dispFit), ("dispMAP", run.dispMAP),
+                   ("dispersion", run.dispersion)):
+        dst[ii] = dv(sub.mcols[k])
+    for k, dst in (("dispGeneIter", run.dispGeneIter), ("dispIter", run.dispIter), ("dispOutlier", run.dispOutlier)):
+        dst[ii] = dv(np.asarray(sub.mcols[k]).astype(np.int32))
+    _write_test_rows(run, rows, _test_subset(run, sub, reduced, kw), write_mu=False)
+
+
+def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None, **kw):
+    """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
+    chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
+    over the gathered (baseMean, dispGeneEst) of all ranks."""
+    if not supported(dds, test=test, reduced=reduced, fitType=fitType, **kw):
+        from . import parallel
+        if parallel.world_size() > 1:
+            return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                          minReplicatesForReplace=minReplicatesForReplace, **kw)
+        return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
+                          minReplicatesForReplace=minReplicatesForReplace, **kw)
+    from . import parallel
+    E = dds.engine
+    t = E.torch
+    world = parallel.world_size()
+    n = dds.n
+    n_all = n
+    if world > 1:
+        sizes = parallel.allgather_sizes(n, comm_device)
+        n_all = int(max(sizes)) * world
+    run = _Run(dds, test, minReplicatesForReplace, n_all if world > 1 else 0, kw)
+
+    def fallback(why):
+        raise RuntimeError(why)
+
+    trend = None
+    if world == 1:
+        run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
+        st, sc = run.read_status()
+        if st["N_OPTIM_GENEEST"] > 0:
+            _patch_gene_est(run, _rows_where(run, run.optim_geneest), kw)
+            run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
+            st, sc = run.read_status()
+    else:
+        run.launch(L.DSQ_PH_GENE_EST)
+        st, sc = run.read_status()
+        if st["N_OPTIM_GENEEST"] > 0:
+            _patch_gene_est(run, _rows_where(run, run.optim_geneest), kw)
+        trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
+        run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST, trend=trend)
+        st, sc = run.read_status()
+    if st["N_NONZERO"] == 0:
+        raise ValueError("all genes have zero counts in every sample")
+    if st["N_TREND"] == 0:
+        raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
+    if st["TREND_STATUS"] != 0 or st["N_ABOVE_MIN"] == 0:
+        # the reference falls back to a local / mean fit here (R/core.R:885-893): not on the fused path
+        if world > 1:
+            return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                          minReplicatesForReplace=minReplicatesForReplace, **kw)
+        return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
+                          minReplicatesForReplace=minReplicatesForReplace, **kw)
+    fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
+          "dispPriorVar": float(sc[3])}
+    if st["N_OPTIM_TEST"] > 0:
+        _patch_test(run, _rows_where(run, run.optim_test), reduced, kw)
+    run.launch(L.DSQ_PH_OUTLIERS)
+    # ---- results: one packed copy
+    st2, _ = run.read_status()
+    if run.do_replace and (st2["N_OPTIM_GENEEST_REFIT"] > 0 or st2["N_OPTIM_TEST_REFIT"] > 0):
+        refit = (run.replace != 0) & (run.allZero == 0)
+        rows = _rows_where(run, (run.optim_geneest != 0) | (run.optim_test != 0), refit)
+        if rows.size:
+            _patch_refit(run, rows, reduced, kw, fn)
+    hv = E._host(run.vec).numpy()
+    hm = E._host(run.mat).numpy()
+    hi = E._host(run.ivec).numpy()
+    allZero = hi[0].astype(bool)
+    anyz = bool(allZero.any())
+
+    def icol(v, as_bool=False):
+        if anyz:
+            out = v.astype(np.float64)
+            out[allZero] = np.nan
+            return out
+        return v.astype(bool) if as_bool else v.copy()
+    mc = {"baseMean": hv[0], "baseVar": hv[1], "allZero": allZero, "dispGeneEst": hv[2], "dispGeneIter": icol(hi[1]),
+          "dispFit": hv[3], "dispMAP": hv[4], "dispersion": hv[5], "dispIter": icol(hi[2]),
+          "dispOutlier": icol(hi[3], True), "beta": hm[0].T, "betaSE": hm[1].T, "betaIter": hv[6],
+          "deviance": -2 * hv[7], "maxCooks": hv[9]}
+    if run.force_zero is not None:
+        wf = E._host(run.force_zero).numpy().astype(bool)
+        if wf.any():
+            mc["weightsFail"] = wf
+    conv = hi[4].astype(np.float64)
+    conv[hi[4] < 0] = np.nan
+    if test == "Wald":
+        mc.update(WaldStatistic=hm[2].T, WaldPvalue=hm[3].T, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
+    else:
+        from scipy.stats import chi2
+        stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878
+        mc.update(LRTStatistic=stat, LRTPvalue=chi2.sf(stat, df=dds.p - 1),
+                  fullBetaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
+    if run.do_replace:
+        mc["replace"] = icol(hi[5], True)
+    dds.mcols = mc
+    GM = E.native.GeneMajor
+    dds.assays = {"mu": GM(run.mu, dds.m), "H": GM(run.H, dds.m), "cooks": GM(run.cooks, dds.m)}
+    dds.attrs.update(betaPrior=False, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
+                     status={**st, **{k: v for k, v in st2.items() if k.startswith(("N_REPLACE", "N_REFIT")) or k.endswith("_REFIT")}})
+    if run.do_replace:
+        dds.attrs["replaceable"] = run.replaceable.astype(bool)
+        if st2["N_REPLACE"] > 0:
+            dds.assays["replaceCounts"] = GM(run.replaceCounts, dds.m)
+            dds.assays["replaceCooks"] = dds.assays["cooks"]
+    if anyz:
+        dds.attrs["nz_rows"] = np.where(~allZero)[0]
+    dds.dispersionFunction = fn
+    dds._fused_run = run           # keeps the device buffers of the assays alive
+    return dds

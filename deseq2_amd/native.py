@@ -305,7 +305,7 @@ def test_math(op, a, b=None, c=None):
     return out
 
 
-UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6}
+UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6, "pnorm_upper2": 9}
 
 
 def unary(name, x):

@@ -41,6 +41,45 @@ def _allgather_vec(v, device=None):
     return np.concatenate([p[:s].cpu().numpy() for p, s in zip(parts, sizes)])
 
 
+def world_size():
+    try:
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    except ImportError:
+        return 1
+
+
+def allgather_sizes(n, device=None):
+    """the shard sizes of all ranks, in rank order"""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+    out = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(v.item()) for v in out]
+
+
+def allgather_device_pairs(a, b, nmax, comm_device, torch):
+    """(baseMean, dispGeneEst) of all ranks as two device vectors of world * nmax values in rank order, each shard
+    padded with NaN to nmax: the trend fit skips NaN rows, so the padded sequence fits like the concatenation"""
+    import torch.distributed as dist
+    ws = dist.get_world_size()
+    dev = a.device
+    buf = torch.full((2, nmax), float("nan"), dtype=torch.float64, device=dev)
+    buf[0, : a.numel()] = a
+    buf[1, : b.numel()] = b
+    if comm_device is None:                       # ranks sharing one device (tests): exchange through the host
+        hb = buf.cpu()
+        parts = [torch.empty_like(hb) for _ in range(ws)]
+        dist.all_gather(parts, hb)
+        g = torch.stack(parts).to(dev)            # (ws, 2, nmax)
+    else:
+        g = torch.empty((ws, 2, nmax), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(g.view(-1), buf.view(-1))
+    return g[:, 0, :].contiguous().view(-1), g[:, 1, :].contiguous().view(-1)
+
+
 class Baton:
     """Round-robin token for the cooperative chunk pipeline: exactly one chunk thread runs host code at a time
     (no interpreter-lock contention); a chunk passes the token on wherever it would block on the GPU or on the
@@ -117,6 +156,9 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
                   minReplicatesForReplace=7, group=None, chunk=0, **kw):
     """`dds` is THIS worker's shard (a rank's, or one chunk of a rank's when `group` is given).
     R/parallel.R:6-74 (betaPrior = FALSE branch)."""
+    if kw.get("betaPrior"):
+        raise NotImplementedError("DESeqParallel mirrors the betaPrior = FALSE branch of R/parallel.R (the global "
+                                  "beta prior variance of :30-52 is not exchanged)")
     # round 1: gene-wise estimates on the shard                                 (:18-20)
     core.estimateDispersionsGeneEst(dds)
     # global steps on the gathered n-vectors                                    (:27-28)

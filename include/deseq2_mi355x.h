@@ -340,6 +340,98 @@ double dsq_profile_last_ms(void);
  * 7 bd0(a,b), 8 dnbinom_mu_log(a=x, b=size, c=mu)).  HOST pointers, n elements.       */
 int dsq_test_math(int op, const double *a, const double *b, const double *c, double *out, int64_t n);
 
+/* ---- dsq_deseq_dev: the whole DESeq() chain, device-driven ---------------------------
+ * estimateDispersionsGeneEst (R/core.R:657-860) -> estimateDispersionsFit (:864-939, parametric) +
+ * estimateDispersionsPriorVar (:1135-1208) -> estimateDispersionsMAP (:943-1131) -> nbinomWaldTest (:1332-1565)
+ * or nbinomLRT against ~1 (:1787-2012) -> replaceOutliers / refitWithoutOutliers (:2069-2115, :2484-2563) on
+ * matrices resident in HBM in the gene-major layout.  The per-gene decision rules R applies between the native
+ * calls (clamps, accept / convergence / refit rules, dispOutlier, betaConv ...) run as small kernels, the rows a
+ * rule sends to fitDispGrid or to the outlier refit are compacted on the device and fitted by row-listed launches
+ * of the same kernels, so a phase needs no host round trip.  Rows that need R's host-side fallback (the
+ * L-BFGS-B rows of fitNbinomGLMsOptim) are only FLAGGED (optim_* outputs): the caller re-does them through the
+ * per-call entry points.  Phases (bit mask), each asynchronous on `stream`:
+ *   DSQ_PH_GENE_EST   counts -> baseMean .. dispGeneEst, mu-hat
+ *   DSQ_PH_TREND      parametric trend + prior variance over (trend_mean, trend_disp) [n_trend on the device] or,
+ *                     when those are NULL, over this call's own genes (multi-GPU: the gathered vectors)
+ *   DSQ_PH_MAP_TEST   dispFit, MAP dispersions, final GLM fit, Wald / LRT statistics
+ *   DSQ_PH_OUTLIERS   Cook's distances, replaceOutliers, refit of the replaced rows, maxCooks
+ * status[] (int32, device): see DSQ_ST_*; scalars[] (double, device): see DSQ_SC_*.                            */
+#define DSQ_PH_GENE_EST 1
+#define DSQ_PH_TREND    2
+#define DSQ_PH_MAP_TEST 4
+#define DSQ_PH_OUTLIERS 8
+
+enum { DSQ_ST_N_NONZERO = 0, DSQ_ST_N_GRID_GENEEST, DSQ_ST_N_TREND, DSQ_ST_TREND_STATUS, DSQ_ST_N_ABOVE_MIN,
+       DSQ_ST_N_GRID_MAP, DSQ_ST_N_OPTIM_GENEEST, DSQ_ST_N_OPTIM_TEST, DSQ_ST_N_REPLACE, DSQ_ST_N_REFIT,
+       DSQ_ST_N_GRID_GENEEST_REFIT, DSQ_ST_N_GRID_MAP_REFIT, DSQ_ST_N_OPTIM_GENEEST_REFIT, DSQ_ST_N_OPTIM_TEST_REFIT,
+       DSQ_ST_COUNT = 16 };
+enum { DSQ_SC_COEF0 = 0, DSQ_SC_COEF1, DSQ_SC_VAR_LOG_DISP, DSQ_SC_DISP_PRIOR_VAR, DSQ_SC_COUNT = 8 };
+
+typedef struct {
+    int32_t n, m, p;
+    int64_t ld;
+    int32_t phases;
+    const int32_t *y;              /* n x ld gene-major counts                                                  */
+    const double *nf;              /* n x ld normalization factors, or m size factors (nf_is_vector)            */
+    int32_t nf_is_vector;
+    int32_t useWeights;
+    const double *weights_raw;     /* assays[["weights"]] as given: enters baseMean / baseVar (R/core.R:2140)   */
+    const double *weights_norm;    /* / row max (R/core.R:2702): GLM fits, MAP, logLik                           */
+    const double *weights_floor;   /* pmax(weights_norm, 1e-6) (R/core.R:702): gene-wise dispersion search       */
+    const int32_t *force_zero;     /* n flags or NULL: rows treated as all-zero (weightsFail, R/core.R:2737)     */
+    const double *x;               /* m x p design, column-major                                                 */
+    const double *q, *a, *r;       /* thin QR of the design: Q, X R^-1 (m x p), R (p x p), column-major          */
+    double xim;                    /* momentsDispEstimate's mean(1 / sizeFactors) (R/core.R:2440-2444)           */
+    int32_t linearMu;              /* R/core.R:735-742                                                           */
+    double minDisp, kappa_0, dispTol, weightThreshold, outlierSD, betaTol, minmu;
+    int32_t maxit, useCR, useQR, betaMaxit;
+    const double *disp_grid;       /* ngrid log-alpha grid points of fitDispGridWrapper (R/wrappers.R:70-72)     */
+    int32_t ngrid;
+    double expVarLogDisp;          /* trigamma((m - p) / 2) (R/core.R:1196); ignored when m <= p                  */
+    const double *trend_mean, *trend_disp;   /* device vectors of n_trend values, or NULL                        */
+    int32_t n_trend;
+    const double *lambda;          /* HOST: p ridge values on the natural-log scale (R/fitNbinomGLMs.R:162)      */
+    double min_log_alpha;          /* log(minDisp / 10) (R/core.R:775)                                           */
+    void *workspace;               /* device, dsq_deseq_workspace_bytes(...): holds the row lists and counters of
+                                      the analysis between phases -- the same buffer for all its phases           */
+    int64_t workspace_bytes;
+    int32_t test;                  /* 0 Wald, 1 LRT with reduced = ~1                                            */
+    /* outlier phase (all host arrays; R/core.R:2081,2101,2366-2371) */
+    const int32_t *cell_of;        /* HOST: design cell of each sample                                           */
+    int32_t ncell;
+    const int32_t *replaceable;    /* HOST: m flags nOrMoreInCell(x, minReplicatesForReplace)                    */
+    double cooksCutoff, trim;
+    int32_t do_replace;            /* 0: Cook's distances only                                                   */
+} DsqDeseqArgs;
+
+typedef struct {
+    /* per-gene results, device, caller-allocated; rows that are all-zero come back NaN / -1 */
+    double *baseMean, *baseVar;
+    int32_t *allZero;
+    double *dispGeneEst;
+    int32_t *dispGeneIter;
+    double *dispFit, *dispMAP, *dispersion;
+    int32_t *dispIter, *dispOutlier;
+    double *beta, *betaSE, *stat, *pvalue;      /* n x p column-major, log2 scale; stat / pvalue Wald only        */
+    int32_t *betaConv;
+    double *betaIter, *logLike, *logLikeReduced, *maxCooks;
+    int32_t *replace;
+    int32_t *optim_geneest, *optim_test;        /* n flags: rows R hands to the L-BFGS-B fallback                 */
+    /* n x ld gene-major */
+    double *mu_hat;                             /* clamped fitted means of the gene-wise fit (assays mu of GeneEst) */
+    double *mu, *H, *cooks;
+    int32_t *replaceCounts;
+    int32_t *status;                            /* DSQ_ST_COUNT */
+    double *scalars;                            /* DSQ_SC_COUNT */
+} DsqDeseqOut;
+
+int dsq_deseq_dev(const DsqDeseqArgs *args, const DsqDeseqOut *out, void *stream);
+int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_trend);
+
+/* kernel timings of the calls since dsq_profile_enable(1): one entry per bracketed launch */
+int dsq_profile_count(void);
+int dsq_profile_get(int i, char *name, int cap, int32_t *genes, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,7 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6}
+UNARY_OPS = {"exp": 0, "log": 1, "log1p": 2, "lgamma": 3, "digamma": 4, "trigamma": 5, "stirlerr": 6, "pnorm_upper2": 9}
 
 
 def unary(name, x):

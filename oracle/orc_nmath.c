@@ -327,6 +327,58 @@ double orc_dnbinom_mu_log(double x, double size, double mu) {
     }
 }
 
+/* 2 * pnorm(|z|, lower.tail = FALSE): the Wald p-value (R/core.R:1507).  R's pnorm (nmath/pnorm.c) is Cody's
+ * rational Chebyshev approximation of the normal distribution function (W. J. Cody, Math. Comp. 23 (1969); ACM
+ * Algorithm 715): |z| <= 0.67448975 by a (4,4) rational in z^2, <= sqrt(32) by an (8,8) rational times
+ * exp(-z^2/2) with the argument split at 1/16, beyond by an asymptotic (5,5) rational in 1/z^2.  Upper tail
+ * only, restated with orc_exp.                                                                                 */
+double orc_pnorm_upper2(double z) {
+    if (z != z) return z;
+    const double y = fabs(z);
+    double upper;
+    if (y <= 0.67448975) {
+        double xnum = 0.0, xden = 0.0;
+        if (y > 5.5511151231257827e-17) {
+            const double xsq = y * y;
+            xnum = 0.065682337918207449113 * xsq;
+            xden = xsq;
+            xnum = (xnum + 2.2352520354606839287) * xsq;  xden = (xden + 47.20258190468824187) * xsq;
+            xnum = (xnum + 161.02823106855587881) * xsq;  xden = (xden + 976.09855173777669322) * xsq;
+            xnum = (xnum + 1067.6894854603709582) * xsq;  xden = (xden + 10260.932208618978205) * xsq;
+        }
+        const double temp = y * (xnum + 18154.981253343561249) / (xden + 45507.789335026729956);
+        upper = 0.5 - temp;
+    } else if (y <= 5.656854249492380195206754896838) {
+        double xnum = 1.0765576773720192317e-8 * y, xden = y;
+        xnum = (xnum + 0.39894151208813466764) * y;  xden = (xden + 22.266688044328115691) * y;
+        xnum = (xnum + 8.8831497943883759412) * y;   xden = (xden + 235.38790178262499861) * y;
+        xnum = (xnum + 93.506656132177855979) * y;   xden = (xden + 1519.377599407554805) * y;
+        xnum = (xnum + 597.27027639480026226) * y;   xden = (xden + 6485.558298266760755) * y;
+        xnum = (xnum + 2494.5375852903726711) * y;   xden = (xden + 18615.571640885098091) * y;
+        xnum = (xnum + 6848.1904505362823326) * y;   xden = (xden + 34900.952721145977266) * y;
+        xnum = (xnum + 11602.651437647350124) * y;   xden = (xden + 38912.003286093271411) * y;
+        const double temp = (xnum + 9842.7148383839780218) / (xden + 19685.429676859990727);
+        const double xsq = trunc(y * 16.0) / 16.0;
+        const double del = (y - xsq) * (y + xsq);
+        upper = orc_exp(-xsq * xsq * 0.5) * orc_exp(-del * 0.5) * temp;
+    } else if (y < 38.5) {
+        const double xsq = 1.0 / (y * y);
+        double xnum = 0.02307344176494017303 * xsq, xden = xsq;
+        xnum = (xnum + 0.21589853405795699) * xsq;       xden = (xden + 1.28426009614491121) * xsq;
+        xnum = (xnum + 0.1274011611602473639) * xsq;     xden = (xden + 0.468238212480865118) * xsq;
+        xnum = (xnum + 0.022235277870649807) * xsq;      xden = (xden + 0.0659881378689285515) * xsq;
+        xnum = (xnum + 0.001421619193227893466) * xsq;   xden = (xden + 0.00378239633202758244) * xsq;
+        double temp = xsq * (xnum + 2.9112874951168792e-5) / (xden + 7.29751555083966205e-5);
+        temp = (0.398942280401432677939946059934 - temp) / y;
+        const double ysq = trunc(y * 16.0) / 16.0;
+        const double del = (y - ysq) * (y + ysq);
+        upper = orc_exp(-ysq * ysq * 0.5) * orc_exp(-del * 0.5) * temp;
+    } else {
+        upper = 0.0;
+    }
+    return 2.0 * upper;
+}
+
 void orc_vec_unary(int op, const double *in, double *out, long n) {
     for (long i = 0; i < n; i++) {
         double x = in[i], r;
@@ -338,6 +390,7 @@ void orc_vec_unary(int op, const double *in, double *out, long n) {
         case 4: r = orc_digamma(x); break;
         case 5: r = orc_trigamma(x); break;
         case 6: r = orc_stirlerr(x); break;
+        case 9: r = orc_pnorm_upper2(x); break;
         default: r = NAN;
         }
         out[i] = r;

@@ -32,6 +32,7 @@ double orc_trigamma(double x); /* domain x > 0 */
 double orc_stirlerr(double n);
 double orc_bd0(double x, double np);
 double orc_dnbinom_mu_log(double x, double size, double mu);
+double orc_pnorm_upper2(double z);  /* 2 * pnorm(|z|, lower.tail = FALSE) */
 
 /* vector helpers for the ctypes tests: op selects the function */
 void orc_vec_unary(int op, const double *in, double *out, long n);

@@ -28,24 +28,32 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    """ctypes mirrors of the argument blocks: sizes as the C compiler lays them out"""
+    """ctypes mirrors of the argument blocks: sizes and the offset of every field as the C compiler lays them out"""
     import subprocess
     import tempfile
-    src = r'''
-#include <stdio.h>
-#include "deseq2_mi355x.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(DsqFitBetaArgs), sizeof(DsqFitBetaOut),
- sizeof(DsqFitDispArgs), sizeof(DsqFitDispOut), sizeof(DsqFitDispGridArgs), sizeof(DsqFitDispGridOut)); return 0; }
-'''
     from deseq2_amd import _lib
+    names = ["DsqFitBetaArgs", "DsqFitBetaOut", "DsqFitDispArgs", "DsqFitDispOut", "DsqFitDispGridArgs",
+             "DsqFitDispGridOut", "DsqPrefitArgs", "DsqPrefitOut", "DsqLogLikeArgs", "DsqInterceptArgs",
+             "DsqInterceptOut", "DsqCooksArgs", "DsqCooksOut", "DsqReplaceArgs", "DsqReplaceOut", "DsqDeseqArgs",
+             "DsqDeseqOut"]
+    lines = []
+    for nm in names:
+        t = getattr(_lib, nm)
+        lines.append('printf("%%zu", sizeof(%s));' % nm)
+        for f, _ in t._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (nm, "lambda" if f == "lambda_" else f))
+        lines.append('printf("\\n");')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "deseq2_mi355x.h"\nint main(void){\n%s\nreturn 0; }\n' % "\n".join(lines)
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        sizes = list(map(int, subprocess.check_output([exe]).split()))
-    want = [ctypes.sizeof(t) for t in (_lib.DsqFitBetaArgs, _lib.DsqFitBetaOut, _lib.DsqFitDispArgs,
-                                        _lib.DsqFitDispOut, _lib.DsqFitDispGridArgs, _lib.DsqFitDispGridOut)]
-    assert sizes == want
+        out = subprocess.check_output([exe]).decode().strip().splitlines()
+    for nm, line in zip(names, out):
+        t = getattr(_lib, nm)
+        got = list(map(int, line.split()))
+        want = [ctypes.sizeof(t)] + [getattr(t, f).offset for f, _ in t._fields_]
+        assert got == want, nm
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1,0 +1,133 @@
+"""-m gpu: the fused device-driven DESeq() chain (dsq_deseq_dev, deseq2_amd/fused.py) against the call-by-call chain
+of core.py on the same engine -- every per-gene column, the assays and the dispersion function BIT FOR BIT -- over
+the branches the reference's callers take: linear mu / GLM mu, fitDispGrid stragglers, optim-fallback rows,
+all-zero rows, observation weights incl. rows whose weights fail, count outliers + refit, LRT against ~1."""
+import numpy as np
+import pytest
+
+from deseq2_amd import core, fused, simulate
+from deseq2_amd.engine import DeviceEngine
+from tests.helpers import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    return DeviceEngine("cuda:0")
+
+
+def _both(E, counts, x, sf, weights=None, **kw):
+    a = core.DESeqDataSet(counts, x, sizeFactors=sf, weights=weights, engine=E)
+    core.DESeq(a, **kw)
+    b = core.DESeqDataSet(counts, x, sizeFactors=sf, weights=weights, engine=E)
+    assert fused.supported(b, **{k: v for k, v in kw.items() if k != "minReplicatesForReplace"})
+    fused.DESeq(b, **kw)
+    assert b.attrs.get("fused")
+    return a, b
+
+
+def _compare(a, b, what):
+    E = a.engine
+    keys = [k for k in a.mcols if k != "rowsForOptim"]
+    assert set(keys) <= set(b.mcols) | {"rowsForOptim"}, (sorted(keys), sorted(b.mcols))
+    for k in keys:
+        va, vb = np.asarray(a.mcols[k]), np.asarray(b.mcols[k])
+        assert_same(va.astype(np.float64), vb.astype(np.float64), "%s: mcols$%s" % (what, k))
+    fa, fb = a.dispersionFunction, b.dispersionFunction
+    assert_same(np.asarray(fa["coefficients"]), np.asarray(fb["coefficients"]), what + ": trend coefficients")
+    assert fa["varLogDispEsts"] == fb["varLogDispEsts"] and fa["dispPriorVar"] == fb["dispPriorVar"], what
+    nz = a.attrs.get("nz_rows")
+    for k in ("mu", "H", "cooks"):
+        ha, hb = E.to_numpy(a.assays[k]), E.to_numpy(b.assays[k])
+        if nz is not None:
+            hb = hb[nz]                      # the call-by-call chain keeps the assays of the non-zero rows
+        assert_same(ha, hb, "%s: assays$%s" % (what, k))
+
+
+def _spike_outliers(counts, rng, k=6):
+    counts = counts.copy()
+    rows = rng.choice(counts.shape[0], k, replace=False)
+    for r in rows:
+        counts[r, rng.integers(counts.shape[1])] = int(counts[r].max() * 40 + 1000)
+    return counts
+
+
+def test_wald_batch_condition_with_outlier_refit(E):
+    x = simulate.design_batch_condition(48)                 # cells of 8 >= 7: replaceOutliers + refit
+    d = simulate.make_counts(900, x, seed=3, size_factors=np.exp(np.random.default_rng(1).normal(0, .2, 48)))
+    counts = _spike_outliers(d["counts"], np.random.default_rng(5))
+    a, b = _both(E, counts, x, d["size_factors"])
+    assert b.attrs["status"]["N_REPLACE"] >= 3 and b.attrs["status"]["N_REFIT"] >= 3
+    assert a.mcols["replace"].sum() == b.attrs["status"]["N_REPLACE"]
+    _compare(a, b, "batch+condition, outliers")
+    rep = np.asarray(a.mcols["replace"], bool)
+    assert_same(E.to_numpy(a.assays["replaceCounts"])[rep], E.to_numpy(b.assays["replaceCounts"])[rep], "replaceCounts")
+
+
+def test_wald_two_group_linear_mu_no_replace(E):
+    x = simulate.design_two_group(10)                       # groups == columns: linearModelMu; cells of 5: no refit
+    d = simulate.make_counts(700, x, seed=4)
+    a, b = _both(E, d["counts"], x, d["size_factors"])
+    _compare(a, b, "two-group")
+    assert "replace" not in b.mcols
+
+
+def test_all_zero_rows_and_stragglers(E):
+    x = simulate.design_batch_condition(24)
+    d = simulate.make_counts(500, x, seed=6, drop_all_zero=False)
+    counts = d["counts"].copy()
+    counts[::41] = 0
+    a, b = _both(E, counts, x, d["size_factors"], disp_maxit=4)       # 4 line-search steps: many grid refits
+    assert b.attrs["status"]["N_GRID_GENEEST"] > 10 and b.attrs["status"]["N_GRID_MAP"] > 10
+    assert b.mcols["allZero"].sum() >= 12
+    _compare(a, b, "all-zero rows + stragglers")
+
+
+def test_optim_fallback_rows(E):
+    x = simulate.design_two_group(16)
+    xb = np.column_stack([x, (np.arange(16) % 2).astype(float)])      # p = 3, groups != columns: GLM mu
+    d = simulate.make_counts(400, xb, seed=8)
+    counts = d["counts"].copy()
+    # the reference's own non-convergence example (tests/testthat/test_optim.R:30-39), several times
+    for r in (3, 77, 200):
+        counts[r] = np.array([0, 0, 0, 0, 0, 1000, 1000, 0, 0, 0, 0, 0, 0, 0, 0, 2])
+    a, b = _both(E, counts, xb, d["size_factors"], minReplicatesForReplace=np.inf)
+    st = b.attrs["status"]
+    assert st["N_OPTIM_GENEEST"] + st["N_OPTIM_TEST"] >= 1
+    assert (~np.asarray(a.mcols["betaConv"], bool)).sum() == (~np.asarray(b.mcols["betaConv"], bool)).sum()
+    _compare(a, b, "optim rows")
+
+
+def test_weights_with_failing_rows(E):
+    x = simulate.design_batch_condition(42)                 # cells of 7
+    d = simulate.make_counts(500, x, seed=9)
+    n = d["counts"].shape[0]
+    rng = np.random.default_rng(2)
+    w = rng.uniform(0.05, 1.0, (n, 42))
+    w[rng.uniform(size=w.shape) < 0.02] = 0.0
+    w[7, x[:, 3] == 1] = 0.0                                # gene 7 loses a whole condition: weightsFail
+    counts = _spike_outliers(d["counts"], np.random.default_rng(6), k=4)
+    a, b = _both(E, counts, x, d["size_factors"], weights=w)
+    assert b.mcols["weightsFail"][7] and np.isnan(b.mcols["dispersion"][7])
+    _compare(a, b, "weights")
+
+
+def test_lrt_against_intercept(E):
+    x = simulate.design_factor(60, 5)                       # cells of 12
+    d = simulate.make_counts(600, x, seed=10, intercept_mean=2.0)
+    counts = _spike_outliers(d["counts"], np.random.default_rng(7), k=5)
+    red = np.ones((60, 1))
+    a, b = _both(E, counts, x, d["size_factors"], test="LRT", reduced=red)
+    _compare(a, b, "LRT")
+    assert np.isfinite(b.mcols["LRTPvalue"]).all()
+
+
+def test_unsupported_settings_fall_back(E):
+    x = simulate.design_two_group(12)
+    d = simulate.make_counts(200, x, seed=11)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E)
+    assert not fused.supported(dds, betaPrior=True)
+    assert not fused.supported(dds, test="LRT", reduced=x[:, :1] * 2)
+    fused.DESeq(dds, betaPrior=True, factors={"condition": x[:, 1].astype(int)})
+    assert "WaldPvalue" in dds.mcols and not dds.attrs.get("fused")
