@@ -19,13 +19,13 @@ namespace dsq {
 #define DSQ_DEV __device__ __forceinline__
 
 struct RowsLds {
-    const double *y_;    // m
+    const int32_t *y_;   // m (counts stay int32 in LDS: 4 B/sample)
     const double *mu_;   // m
     const double *imu_;  // m: 1/mu, computed once per gene (it does not depend on alpha)
     const double *w_;    // m or nullptr
     const double *x_;    // p x m (column c at x_ + c*m)
     int m;
-    DSQ_DEV double y(int j) const { return y_[j]; }
+    DSQ_DEV double y(int j) const { return (double)y_[j]; }
     DSQ_DEV double mu(int j) const { return mu_[j]; }
     DSQ_DEV double inv_mu(int j) const { return imu_[j]; }
     DSQ_DEV double w(int j) const { return w_[j]; }

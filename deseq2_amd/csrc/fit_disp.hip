@@ -49,11 +49,68 @@ struct DispGene {
     // loop over a local array would give -- 64 copies per wave, gigabytes for the resident waves.
     double *arena;
     mutable int arena_off;
+    // unweighted genes: the distinct count values (ascending) and their multiplicities, in wave-private LDS -- the
+    // lgamma / digamma terms of the likelihood depend on a sample only through its count, so they are evaluated once
+    // per DISTINCT count (often a handful) instead of once per sample
+    const int32_t *dv, *dc;
+    int nv;
     template <class T>
     DSQ_DEV T &arena_take() const {
         T *q = reinterpret_cast<T *>(arena + arena_off);
         arena_off += (int)((sizeof(T) + 7) / 8);
         return *q;
+    }
+
+    // sort the gene's counts (bitonic network in the wave's LDS slice), keep the first of every run and its length.
+    // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
+    DSQ_DEV void build_distinct(int32_t *buf) {
+        if constexpr (USE_W) { dv = dc = nullptr; nv = 0; return; }
+        int n2 = 2;
+        while (n2 < m) n2 <<= 1;
+        lds_sync();
+        for (int k = lane; k < n2; k += 64) buf[k] = k < m ? (int32_t)r.y(k) : 0x7fffffff;
+        lds_sync();
+        for (int kk = 2; kk <= n2; kk <<= 1)
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int t = lane; t < (n2 >> 1); t += 64) {
+                    int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                    int hi = lo | jj;
+                    bool asc = (lo & kk) == 0;
+                    int32_t a = buf[lo], c = buf[hi];
+                    if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
+                }
+                lds_sync();
+            }
+        int base = 0;
+        for (int k0 = 0; k0 < m; k0 += 64) {
+            const int k = k0 + lane;
+            const bool valid = k < m;
+            const int32_t v = valid ? buf[k] : 0;
+            const int32_t prev = (valid && k > 0) ? buf[k - 1] : -1;
+            const bool head = valid && (k == 0 || v != prev);
+            const unsigned long long mask = __ballot(head);
+            const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
+            lds_sync();                                  // every lane has read before any lane writes
+            if (head) { buf[rank] = v; buf[m + rank] = k; }
+            base += __popcll(mask);
+            lds_sync();
+        }
+        nv = base;
+        for (int i0 = 0; i0 < nv; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < nv;
+            const int s0 = valid ? buf[m + i] : 0;
+            const int s1 = valid ? ((i + 1 < nv) ? buf[m + i + 1] : m) : 0;
+            lds_sync();
+            if (valid) buf[m + i] = s1 - s0;
+            lds_sync();
+        }
+        dv = buf; dc = buf + m;
+    }
+    DSQ_DEV static void lds_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
     DSQ_DEV bool keep_row(int j) const {
@@ -186,14 +243,29 @@ DSQ_UNROLL_P
         }
         double an1 = 1.0 / alpha;
         double lg_an1 = dlgamma(an1);
+        // log(mu + 1/alpha) = log(1 + mu alpha) - log alpha: one logarithm per sample; without weights the lgamma terms
+        // run over the distinct counts (src/DESeq2.cpp:53,55 regrouped; the CPU checker states the same grouping)
         double acc = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double y = r.y(j), mu = r.mu(j);
-            double t = dlgamma(y + an1) - lg_an1 - y * dlog(mu + an1) - an1 * dlog(1.0 + mu * alpha);
-            if constexpr (USE_W) t = r.w(j) * t;
-            acc += t;
+        double ll_part;
+        if constexpr (USE_W) {
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double l1 = dlog(1.0 + mu * alpha);
+                double t = dlgamma(y + an1) - lg_an1 - y * (l1 - la) - an1 * l1;
+                acc += r.w(j) * t;
+            }
+            ll_part = wave_allreduce(acc);
+        } else {
+            double accv = 0.0;
+            for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dlgamma((double)dv[i] + an1) - lg_an1);
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double l1 = dlog(1.0 + mu * alpha);
+                acc += -(y * (l1 - la)) - an1 * l1;
+            }
+            double sv = wave_allreduce(accv);
+            ll_part = sv + wave_allreduce(acc);
         }
-        double ll_part = wave_allreduce(acc);
         double prior_part = 0.0;
         if (usePrior) {
             double d = la - prior_mean;
@@ -239,26 +311,48 @@ DSQ_UNROLL_P
         double lg_an1, dg_an1;
         dlgamma_digamma(an1, lg_an1, dg_an1);
         double acc = 0.0, acc2 = 0.0;
-        if (!(ablate & 1))          // profiling only
-        for (int j = lane; j < m; j += 64) {
-            double y = r.y(j), mu = r.mu(j);
-            double ma = mu * alpha;
-            double l1 = dlog(1.0 + ma);
-            double mpa = mu + an1;
-            double lg, dg;
-            dlgamma_digamma(y + an1, lg, dg);
-            double t = lg - lg_an1 - y * dlog(mpa) - an1 * l1;
-            double t2 = dg_an1 + l1 - ma * (1.0 / (1.0 + ma)) - dg + y * (1.0 / mpa);
-            if constexpr (USE_W) {
+        double ll_part, ll_dpart;
+        if constexpr (USE_W) {
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double ma = mu * alpha;
+                double opm = 1.0 + ma;
+                double l1 = dlog(opm);
+                double rr = 1.0 / opm;
+                double lg, dg;
+                dlgamma_digamma(y + an1, lg, dg);
+                double t = lg - lg_an1 - y * (l1 - la) - an1 * l1;
+                double t2 = dg_an1 + l1 - ma * rr - dg + y * (alpha * rr);
                 double w = r.w(j);
-                t = w * t;
-                t2 = w * t2;
+                acc += w * t;
+                acc2 += w * t2;
             }
-            acc += t;
-            acc2 += t2;
+            ll_part = wave_allreduce(acc);
+            ll_dpart = an2 * wave_allreduce(acc2);
+        } else {
+            double accv = 0.0, accv2 = 0.0;
+            if (!(ablate & 2))          // profiling only
+            for (int i = lane; i < nv; i += 64) {
+                double lg, dg;
+                dlgamma_digamma((double)dv[i] + an1, lg, dg);
+                const double c = (double)dc[i];
+                accv += c * (lg - lg_an1);
+                accv2 += c * (dg_an1 - dg);
+            }
+            if (!(ablate & 1))          // profiling only
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double ma = mu * alpha;
+                double opm = 1.0 + ma;
+                double l1 = dlog(opm);
+                double rr = 1.0 / opm;
+                acc += -(y * (l1 - la)) - an1 * l1;
+                acc2 += l1 - ma * rr + y * (alpha * rr);
+            }
+            double sv = wave_allreduce(accv), sv2 = wave_allreduce(accv2);
+            ll_part = sv + wave_allreduce(acc);
+            ll_dpart = an2 * (sv2 + wave_allreduce(acc2));
         }
-        double ll_part = wave_allreduce(acc);
-        double ll_dpart = an2 * wave_allreduce(acc2);
         double prior_part = 0.0, prior_dpart = 0.0;
         if (usePrior) {
             double d = la - prior_mean;
@@ -300,15 +394,29 @@ DSQ_UNROLL_P
         double an2 = 1.0 / (alpha * alpha);
         double dg_an1 = ddigamma(an1);
         double acc = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double y = r.y(j), mu = r.mu(j);
-            double ma = mu * alpha;
-            double t = dg_an1 + dlog(1.0 + ma) - ma * (1.0 / (1.0 + ma)) - ddigamma(y + an1) +
-                       y * (1.0 / (mu + an1));
-            if constexpr (USE_W) t = r.w(j) * t;
-            acc += t;
+        double ll_sum;
+        if constexpr (USE_W) {
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double ma = mu * alpha;
+                double rr = 1.0 / (1.0 + ma);
+                double t = dg_an1 + dlog(1.0 + ma) - ma * rr - ddigamma(y + an1) + y * (alpha * rr);
+                acc += r.w(j) * t;
+            }
+            ll_sum = wave_allreduce(acc);
+        } else {
+            double accv = 0.0;
+            for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dg_an1 - ddigamma((double)dv[i] + an1));
+            for (int j = lane; j < m; j += 64) {
+                double y = r.y(j), mu = r.mu(j);
+                double ma = mu * alpha;
+                double rr = 1.0 / (1.0 + ma);
+                acc += dlog(1.0 + ma) - ma * rr + y * (alpha * rr);
+            }
+            double sv = wave_allreduce(accv);
+            ll_sum = sv + wave_allreduce(acc);
         }
-        double ll_part = an2 * wave_allreduce(acc);
+        double ll_part = an2 * ll_sum;
         double prior_part = 0.0;
         if (withPrior) prior_part = -1.0 * (la - prior_mean) / prior_sigmasq;
         return (ll_part + cr_term) * alpha + prior_part;
@@ -377,13 +485,22 @@ DSQ_UNROLL_P
 };
 
 // ---- staging --------------------------------------------------------------------
-// LDS carve (doubles): [ X: p*m ][ per wave: y m | mu m | 1/mu m | (w m) ]
+// LDS carve (doubles): [ X: p*m ][ per wave slab ][ per wave WIDE arena ]
+//   staged slab    : mu m | 1/mu m | (w m) | y int32 m | (distinct counts: 2 m int32, unweighted only)
+//   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
 // WIDE build: doubles of per-wave LDS arena for the work matrices (the largest user, d2lp: B[3], LU, Bi, M)
 __host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 4 * p + 16 : 0; }
 
 template <bool USE_W>
+__host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
+    const size_t half = ((size_t)m + 1) / 2;                 // m int32
+    const size_t dist = USE_W ? 0 : (size_t)m;               // 2 m int32
+    return stage ? (size_t)m * (USE_W ? 3 : 2) + half + dist : dist;
+}
+
+template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3) + (size_t)waves * disp_arena_doubles(p);
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true) + (size_t)waves * disp_arena_doubles(p);
 }
 
 #ifndef DSQ_DISP_MINW
@@ -407,11 +524,11 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     if (blockIdx.x * waves >= nwork) return;     // (row-listed launches size the grid without knowing the count)
 
     const double *xs = smem;
-    double *slab = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)wave * m * (USE_W ? 4 : 3);
-    // WIDE build: the work-matrix arena sits behind the row slabs (staged) or alone in LDS (unstaged)
-    double *arena = STAGE ? smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * (USE_W ? 4 : 3) +
-                                (size_t)wave * disp_arena_doubles(P)
-                          : smem + (size_t)wave * disp_arena_doubles(P);
+    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE);
+    const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
+    double *slab = smem + xoff + (size_t)wave * slab_d;
+    // WIDE build: the work-matrix arena sits behind the slabs
+    double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P);
     if constexpr (STAGE) {
         if (kp.xlds) {
             for (int t = threadIdx.x; t < P * m; t += blockDim.x) smem[t] = kp.x[t];
@@ -429,17 +546,21 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 
         using Rows = typename std::conditional<STAGE, RowsLds, RowsGlobal>::type;
         DispGene<P, USE_W, Rows> G;
+        int32_t *dist;
         if constexpr (STAGE) {
-            double *ys = slab, *ms = slab + m, *is = slab + 2 * (size_t)m, *ws = slab + 3 * (size_t)m;
+            double *ms = slab, *is = slab + m, *ws = slab + 2 * (size_t)m;
+            int32_t *ys = reinterpret_cast<int32_t *>(slab + (size_t)m * (USE_W ? 3 : 2));
+            dist = ys + 2 * (((size_t)m + 1) / 2);
             for (int j = lane; j < m; j += 64) {
                 double mu = mug[j];
-                ys[j] = (double)yg[j];
+                ys[j] = yg[j];
                 ms[j] = mu;
                 is[j] = 1.0 / mu;
                 if constexpr (USE_W) ws[j] = wg[j];
             }
             G.r.y_ = ys; G.r.mu_ = ms; G.r.imu_ = is; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
+            dist = reinterpret_cast<int32_t *>(slab);
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
@@ -452,6 +573,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.padmask = kp.padmask;
         G.arena = arena;
         G.arena_off = 0;
+        G.build_distinct(dist);
         G.setup_cr();
 
         if constexpr (MODE == 2) {
@@ -554,10 +676,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
+    const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P)) * sizeof(double);
     if (!stage)
-        while (waves > 1 && (size_t)waves * disp_arena_doubles(P) * sizeof(double) > budget) waves >>= 1;
+        while (waves > 1 && (size_t)waves * unstaged_wave > budget) waves >>= 1;
     size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
-                       : (size_t)waves * disp_arena_doubles(P) * sizeof(double);   // unstaged: only the WIDE arena
+                       : (size_t)waves * unstaged_wave;   // unstaged: the distinct-count buffer + the WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter

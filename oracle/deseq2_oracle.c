@@ -169,7 +169,31 @@ typedef struct {
     int q;                /* number of kept columns */
     int keepcol[ORC_PMAX];
     const unsigned char *keeprow; /* m, or NULL = all */
+    /* unweighted genes: the DISTINCT count values (ascending) and their multiplicities -- the lgamma / digamma
+     * terms of the likelihood depend on the sample only through its count, so they are evaluated once per distinct
+     * value (see log_posterior).  NULL with observation weights. */
+    int nv;
+    const double *dv, *dc;
 } gene_t;
+
+static int cmp_count(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* vbuf, cbuf: m doubles each */
+static void gene_setup_distinct(gene_t *g, double *vbuf, double *cbuf) {
+    g->nv = 0; g->dv = NULL; g->dc = NULL;
+    if (g->useWeights) return;
+    memcpy(vbuf, g->y, sizeof(double) * g->m);
+    qsort(vbuf, g->m, sizeof(double), cmp_count);
+    int nv = 0;
+    for (int j = 0; j < g->m; j++) {
+        if (nv > 0 && vbuf[j] == vbuf[nv - 1]) cbuf[nv - 1] += 1.0;
+        else { vbuf[nv] = vbuf[j]; cbuf[nv] = 1.0; nv++; }
+    }
+    g->nv = nv; g->dv = vbuf; g->dc = cbuf;
+}
 
 static void gene_setup_cr(gene_t *g, unsigned char *rowbuf) {
     g->keeprow = NULL;
@@ -223,15 +247,31 @@ static double log_posterior(double log_alpha, const gene_t *g, double *scratch) 
     } else cr_term = 0.0;
     double alpha_neg1 = 1.0 / alpha;                                             /* :50 R_pow_di(alpha,-1) */
     double lg_an1 = orc_lgamma(alpha_neg1);
+    /* :53,55  sum_j [w_j] ( lgamma(y_j + 1/a) - lgamma(1/a) - y_j log(mu_j + 1/a) - (1/a) log(1 + mu_j a) ), with
+     *   log(mu + 1/a) = log(1 + mu a) - log a      (one logarithm per sample instead of two), and, without weights,
+     *   sum_j (lgamma(y_j + 1/a) - lgamma(1/a)) = sum_v c_v (lgamma(v + 1/a) - lgamma(1/a))  over the distinct
+     *   counts v with multiplicity c_v (one lgamma per distinct count instead of one per sample).               */
     wsum_t s; wsum_init(&s, g->serial);
-    for (int j = 0; j < m; j++) {                                                /* :53,55 */
-        double y = g->y[j], mu = g->mu[j];
-        double t = orc_lgamma(y + alpha_neg1) - lg_an1 - y * orc_log(mu + alpha_neg1)
-                   - alpha_neg1 * orc_log(1.0 + mu * alpha);
-        if (g->useWeights) t = g->w[j] * t;
-        wsum_add(&s, j, t);
+    double ll_part;
+    if (g->dv) {
+        wsum_t sv; wsum_init(&sv, g->serial);
+        for (int i = 0; i < g->nv; i++)
+            wsum_add(&sv, i, g->dc[i] * (orc_lgamma(g->dv[i] + alpha_neg1) - lg_an1));
+        for (int j = 0; j < m; j++) {
+            double y = g->y[j], mu = g->mu[j];
+            double l1 = orc_log(1.0 + mu * alpha);
+            wsum_add(&s, j, -(y * (l1 - log_alpha)) - alpha_neg1 * l1);
+        }
+        ll_part = wsum_total(&sv) + wsum_total(&s);
+    } else {
+        for (int j = 0; j < m; j++) {
+            double y = g->y[j], mu = g->mu[j];
+            double l1 = orc_log(1.0 + mu * alpha);
+            double t = orc_lgamma(y + alpha_neg1) - lg_an1 - y * (l1 - log_alpha) - alpha_neg1 * l1;
+            wsum_add(&s, j, g->w[j] * t);
+        }
+        ll_part = wsum_total(&s);
     }
-    double ll_part = wsum_total(&s);
     if (g->usePrior) {
         double d = log_alpha - g->prior_mean;
         prior_part = -0.5 * (d * d) / g->prior_sigmasq;                          /* :58 */
@@ -261,16 +301,33 @@ static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch)
     double alpha_neg1 = 1.0 / alpha;
     double alpha_neg2 = 1.0 / (alpha * alpha);                                   /* :91 R_pow_di(alpha,-2) */
     double dg_an1 = orc_digamma(alpha_neg1);
+    /* :94,96  sum_j [w_j] ( digamma(1/a) + log(1 + mu a) - mu a / (1 + mu a) - digamma(y + 1/a) + y / (mu + 1/a) ),
+     * with r = 1 / (1 + mu a):  mu a / (1 + mu a) = (mu a) r,  1 / (mu + 1/a) = a r  (one division per sample), and
+     * the digamma terms over the distinct counts when there are no weights (see log_posterior).                */
     wsum_t s; wsum_init(&s, g->serial);
-    for (int j = 0; j < m; j++) {                                                /* :94,96 */
-        double y = g->y[j], mu = g->mu[j];
-        double ma = mu * alpha;
-        double t = dg_an1 + orc_log(1.0 + ma) - ma * (1.0 / (1.0 + ma))
-                   - orc_digamma(y + alpha_neg1) + y * (1.0 / (mu + alpha_neg1));
-        if (g->useWeights) t = g->w[j] * t;
-        wsum_add(&s, j, t);
+    double ll_sum;
+    if (g->dv) {
+        wsum_t sv; wsum_init(&sv, g->serial);
+        for (int i = 0; i < g->nv; i++)
+            wsum_add(&sv, i, g->dc[i] * (dg_an1 - orc_digamma(g->dv[i] + alpha_neg1)));
+        for (int j = 0; j < m; j++) {
+            double y = g->y[j], mu = g->mu[j];
+            double ma = mu * alpha;
+            double r = 1.0 / (1.0 + ma);
+            wsum_add(&s, j, orc_log(1.0 + ma) - ma * r + y * (alpha * r));
+        }
+        ll_sum = wsum_total(&sv) + wsum_total(&s);
+    } else {
+        for (int j = 0; j < m; j++) {
+            double y = g->y[j], mu = g->mu[j];
+            double ma = mu * alpha;
+            double r = 1.0 / (1.0 + ma);
+            double t = dg_an1 + orc_log(1.0 + ma) - ma * r - orc_digamma(y + alpha_neg1) + y * (alpha * r);
+            wsum_add(&s, j, g->w[j] * t);
+        }
+        ll_sum = wsum_total(&s);
     }
-    double ll_part = alpha_neg2 * wsum_total(&s);
+    double ll_part = alpha_neg2 * ll_sum;
     if (g->usePrior) prior_part = -1.0 * (log_alpha - g->prior_mean) / g->prior_sigmasq; /* :100 */
     else prior_part = 0.0;
     return (ll_part + cr_term) * alpha + prior_part;                             /* :105 */
@@ -346,6 +403,7 @@ int orc_fit_disp(int n, int m, int p,
     double *yrow = malloc(sizeof(double) * m), *murow = malloc(sizeof(double) * m);
     double *wrow = malloc(sizeof(double) * m), *scratch = malloc(sizeof(double) * 3 * (size_t)m);
     unsigned char *rowbuf = malloc(m);
+    double *vbuf = malloc(sizeof(double) * m), *cbuf = malloc(sizeof(double) * m);
 #pragma omp for schedule(static)
     for (int i = 0; i < n; i++) {                                                /* :194 */
         for (int j = 0; j < m; j++) {
@@ -358,6 +416,7 @@ int orc_fit_disp(int n, int m, int p,
         g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
         g.weightThreshold = weightThreshold; g.serial = sum_mode;
         gene_setup_cr(&g, rowbuf);
+        gene_setup_distinct(&g, vbuf, cbuf);
         double a = log_alpha_in[i];                                              /* :201 */
         double lp = log_posterior(a, &g, scratch);                               /* :205 */
         double dlp = dlog_posterior(a, &g, scratch);                             /* :206 */
@@ -392,7 +451,7 @@ int orc_fit_disp(int n, int m, int p,
         last_change[i] = change;                                                 /* :265 */
         iter[i] = it; iter_accept[i] = it_acc;
     }
-    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf);
+    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(vbuf); free(cbuf);
     }
     return 0;
 }
@@ -413,6 +472,7 @@ int orc_fit_disp_grid(int n, int m, int p,
     double *wrow = malloc(sizeof(double) * m), *scratch = malloc(sizeof(double) * 3 * (size_t)m);
     unsigned char *rowbuf = malloc(m);
     double *lpv = malloc(sizeof(double) * ngrid), *fine = malloc(sizeof(double) * ngrid);
+    double *vbuf = malloc(sizeof(double) * m), *cbuf = malloc(sizeof(double) * m);
 #pragma omp for schedule(static)
     for (int i = 0; i < n; i++) {                                                /* :492 */
         for (int j = 0; j < m; j++) {
@@ -425,6 +485,7 @@ int orc_fit_disp_grid(int n, int m, int p,
         g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
         g.weightThreshold = weightThreshold; g.serial = sum_mode;
         gene_setup_cr(&g, rowbuf);
+        gene_setup_distinct(&g, vbuf, cbuf);
         for (int t = 0; t < ngrid; t++) lpv[t] = log_posterior(disp_grid[t], &g, scratch);  /* :496-500 */
         int idx = 0; double best = lpv[0];                                       /* :501 .max(idxmax) */
         for (int t = 1; t < ngrid; t++) if (lpv[t] > best) { best = lpv[t]; idx = t; }
@@ -440,7 +501,7 @@ int orc_fit_disp_grid(int n, int m, int p,
         for (int t = 1; t < ngrid; t++) if (lpv[t] > best) { best = lpv[t]; idx = t; }
         log_alpha_out[i] = fine[idx];                                            /* :509 */
     }
-    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(lpv); free(fine);
+    free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(lpv); free(fine); free(vbuf); free(cbuf);
     }
     return 0;
 }

@@ -168,11 +168,14 @@ def compare(got, ref, d, name, min_well=None, min_grid=None):
         for k in FLAGS:
             np.testing.assert_array_equal(g[k][well_strict], r[k][well_strict], err_msg="%s %s$%s" % (name, fn, k))
         for k in ("log_alpha", "initial_lp", "last_lp"):
-            _close(g[k][well], r[k][well], "%s %s$%s" % (name, fn, k), rtol=1e-7 if k == "log_alpha" else 1e-8,
-                   atol=1e-9)
-        for k in ("initial_dlp", "last_dlp", "last_d2lp"):
+            _close(g[k][well_strict], r[k][well_strict], "%s %s$%s" % (name, fn, k),
+                   rtol=1e-7 if k == "log_alpha" else 1e-8, atol=1e-9)
+            # a tie gene stops one (tiny) step earlier or later: its optimum agrees to the search's own tolerance
+            _close(g[k][tie], r[k][tie], "%s %s$%s (ties)" % (name, fn, k), rtol=1e-6, atol=1e-9)
+        _close(g["initial_dlp"][well], r["initial_dlp"][well], "%s %s$initial_dlp" % (name, fn), rtol=1e-6, atol=1e-5)
+        for k in ("last_dlp", "last_d2lp"):
             if k in g and g[k] is not None:
-                _close(g[k][well], r[k][well], "%s %s$%s" % (name, fn, k), rtol=1e-6, atol=1e-5)
+                _close(g[k][well_strict], r[k][well_strict], "%s %s$%s" % (name, fn, k), rtol=1e-6, atol=1e-5)
         floor = ~well
         if floor.any():        # both end (far) below any dispersion the callers keep (minDisp clamp 1e-8 .. 1e-6)
             assert (np.exp(g["log_alpha"][floor]) < 1e-5).all() and (np.exp(r["log_alpha"][floor]) < 1e-5).all()
