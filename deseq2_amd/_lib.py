@@ -34,7 +34,7 @@ class DsqFitBetaArgs(C.Structure):
         ("nf_is_vector", C.c_int32), ("alpha_hat", C.c_void_p), ("contrast", C.c_void_p),
         ("beta_mat", C.c_void_p), ("lambda_", C.c_void_p), ("weights", C.c_void_p),
         ("useWeights", C.c_int32), ("tol", C.c_double), ("maxit", C.c_int32), ("useQR", C.c_int32),
-        ("minmu", C.c_double),
+        ("minmu", C.c_double), ("cell_of", C.c_void_p), ("ncell", C.c_int32),
     ]
 
 

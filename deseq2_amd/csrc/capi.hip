@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -53,7 +54,8 @@ const Tuning &tuning() {
                        env_int("DSQ_BETA_LDS_KB", 160),
                        env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
                        env_int("DSQ_DISP_LDS_KB", 160), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
-                       env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1), env_int("DSQ_DYNAMIC", 1)};
+                       env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1), env_int("DSQ_DYNAMIC", 1),
+                       env_int("DSQ_BETA_CELLS", 1)};
     return t;
 }
 
@@ -132,6 +134,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
 
 enum {  // workspace slots
     WS_Y = 0, WS_NF, WS_W, WS_MU, WS_HAT, WS_MUOUT, WS_SCRATCH, WS_BAD, WS_CELLS, WS_COOKS_IN, WS_COUNTER, WS_TREND, WS_PAD_X, WS_PAD_VEC, WS_PAD_BETA,
+    WS_CELLS_BETA,
     // host-entry staging
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
@@ -271,6 +274,56 @@ static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const doubl
     return DSQ_OK;
 }
 
+// design cells -> device arrays for the cell-collapsed fitBeta kernel: cells renumbered in order of first appearance,
+// samples grouped by cell (ascending inside a cell).  labels: m host ints (any numbering).  Returns the number of
+// cells (0: more than DSQ_CMAX, or cells switched off) and the device pointers.
+int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, const int32_t **perm_dev,
+                      const int32_t **start_dev) {
+    *perm_dev = *start_dev = nullptr;
+    if (!labels || !tuning().beta_cells) return 0;
+    static std::vector<int32_t> buf;                     // (under the library lock)
+    std::map<int32_t, int> id;
+    std::vector<int> cell(m);
+    int C = 0;
+    for (int j = 0; j < m; j++) {
+        auto it = id.find(labels[j]);
+        if (it == id.end()) {
+            if (C == DSQ_CMAX) return 0;
+            it = id.emplace(labels[j], C++).first;
+        }
+        cell[j] = it->second;
+    }
+    buf.assign((size_t)m + C + 1, 0);
+    int32_t *start = buf.data(), *perm = buf.data() + C + 1;
+    for (int j = 0; j < m; j++) start[cell[j] + 1]++;
+    for (int c = 0; c < C; c++) start[c + 1] += start[c];
+    std::vector<int> fill(start, start + C);
+    for (int j = 0; j < m; j++) perm[fill[cell[j]]++] = j;
+    void *v;
+    if (ws_get(slot, buf.size() * sizeof(int32_t), &v)) return 0;
+    if (hipMemcpyAsync(v, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    *start_dev = (const int32_t *)v;
+    *perm_dev = (const int32_t *)v + C + 1;
+    return C;
+}
+
+// cell labels of a HOST design matrix (m x p column-major): rows compared exactly
+static void cells_of_host_design(const double *x, int m, int p, std::vector<int32_t> *labels) {
+    labels->assign(m, 0);
+    std::vector<int> reps;
+    for (int j = 0; j < m; j++) {
+        int found = -1;
+        for (size_t c = 0; c < reps.size() && found < 0; c++) {
+            bool same = true;
+            for (int k = 0; k < p && same; k++) same = x[j + (size_t)m * k] == x[reps[c] + (size_t)m * k];
+            if (same) found = (int)c;
+        }
+        if (found < 0) { found = (int)reps.size(); reps.push_back(j); }
+        (*labels)[j] = found;
+        if ((int)reps.size() > DSQ_CMAX) { labels->clear(); return; }
+    }
+}
+
 // =============================================================== fitBeta (device)
 static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, hipStream_t st) {
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
@@ -312,6 +365,8 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     kp.maxit = a->maxit; kp.useQR = a->useQR ? 1 : 0; kp.useWeights = a->useWeights ? 1 : 0;
     kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
+    if (a->cell_of && a->ncell > 0 && a->p <= DSQ_P_REG)
+        kp.ncell = capi_upload_cells(a->cell_of, a->m, WS_CELLS_BETA, st, &kp.cell_perm, &kp.cell_start);
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;
     const bool wide = is_wide(a->p);
@@ -919,6 +974,11 @@ int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
     if (o->hat_diagonals) { if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc; hat_d = (double *)v; }
     if (o->mu) { if ((rc = ws_get(WS_H_OUTMAT2, n * m * 8, &v))) return rc; mu_d = (double *)v; }
     od.hat_diagonals = hat_d; od.mu = mu_d;
+    std::vector<int32_t> labels;
+    if (!a->cell_of) {                       // R hands over the design matrix itself: find its cells here
+        cells_of_host_design(a->x, a->m, a->p, &labels);
+        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
+    }
     rc = fit_beta_dev_locked(&d, &od, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(o->beta_mat, od.beta_mat, n * p * 8, hipMemcpyDeviceToHost, st));

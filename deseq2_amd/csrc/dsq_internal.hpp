@@ -63,6 +63,10 @@ struct BetaKernelParams {
     const int32_t *rows;
     const int32_t *n_dev;
     int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
+    // design cells (samples with identical design rows, numbered by first appearance): ncell > 0 selects the
+    // cell-collapsed kernel; cell_perm = samples grouped by cell (ascending inside a cell), cell_start = ncell + 1 offsets
+    const int32_t *cell_perm, *cell_start;
+    int ncell;
 };
 
 struct PrefitKernelParams {
@@ -169,6 +173,7 @@ size_t trend_fit_workspace_bytes();
 // the Cox-Reid matrix, which leaves every quantity of the real coefficients unchanged (capi.hip, "wide designs").
 #define DSQ_P_WIDE0 16
 #define DSQ_P_WIDE 24
+#define DSQ_CMAX 32       // most design cells the cell-collapsed fitBeta kernel takes
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
 // doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they
@@ -182,6 +187,7 @@ struct Tuning {
     int ablate, force_iters;
     int disp_xlds, beta_xlds;
     int dynamic;             // DSQ_DYNAMIC (default 1): dynamic gene scheduling in the fit kernels
+    int beta_cells;          // DSQ_BETA_CELLS (default 1): cell-collapsed fitBeta for designs with <= DSQ_CMAX cells
 };
 const Tuning &tuning();
 
@@ -198,6 +204,8 @@ int device_cu_count();
 int capi_fail(int code, const char *fmt, ...);
 int capi_ws_get(int slot, size_t bytes, void **out);             // grow-only workspace of the current (device, stream)
 int capi_check_device();
+int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, const int32_t **perm_dev,
+                      const int32_t **start_dev);
 std::mutex &capi_mutex();                                        // the library's call lock
 void capi_latch_stream(hipStream_t s);                           // workspace key of the current call (under the lock)
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok);

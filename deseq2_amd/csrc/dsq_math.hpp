@@ -484,6 +484,29 @@ DSQ_DEV DnbConst dnb_prepare(double x, double size, double st_size, double log_s
     return c;
 }
 
+// the same split with the constants folded into one value (cell-collapsed fitBeta: they are summed once per gene):
+// dnb_general = (x, size) is on the general branch; dnb_const = c2 + (c0 - c1); dnb_iter = -bd0(size, n p) - bd0(x, n q)
+DSQ_DEV bool dnb_general(double x, double size) {
+    const double n = x + size;
+    return (x > 0.0) && dfinite(x) && (size > 0.0) && dfinite(size) && !(x < 1e-10 * size) && (n != size) && dfinite(n);
+}
+DSQ_DEV double dnb_const(double x, double size, double st_size, double log_size) {
+    const double n = x + size;
+    const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
+    const double lf = kLn2Pi + log_size + dlog1p(-size / n);
+    const double c1 = 0.5 * lf;
+    const double c2 = dlog(size / (size + x));
+    return c2 + (c0 - c1);
+}
+DSQ_DEV bool dnb_iter(double x, double size, double mu, double &it) {
+    const double p = size / (size + mu), q = mu / (size + mu);
+    it = 0.0;
+    if (!(mu > 0.0 && p != 0.0 && q != 0.0)) return false;
+    const double n = x + size;
+    it = -dbd0(size, n * p) - dbd0(n - size, n * q);
+    return true;
+}
+
 DSQ_DEV double dnb_eval(double x, double size, double mu, const DnbConst &c) {
     double p = size / (size + mu), q = mu / (size + mu);
     if (c.c0 == c.c0 && mu > 0.0 && p != 0.0 && q != 0.0) {

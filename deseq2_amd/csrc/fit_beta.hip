@@ -465,6 +465,333 @@ DSQ_UNROLL_P
     }
 }
 
+// ---- cell-collapsed fitBeta -------------------------------------------------------------------------------------
+// Designs with few distinct rows (every factor design: a handful of CELLS of samples sharing a design row x_c).
+//   * the linear predictor is one value per cell (lane c owns cell c): mu_j = max(nf_j exp(eta_c), minmu);
+//   * an IRLS step needs the samples only through S_c = sum w_j, T_c = sum w_j z_j: the weighted least squares is the
+//     Householder QR of the COLLAPSED (C + p) x p matrix [sqrt(S_c) x_c ; sqrt(ridge)] -- one row per LANE, no pass
+//     over the samples, no replay (the general kernel re-derives every sample row in every one of the p stages);
+//   * one sweep over the samples per iteration computes mu, the two bd0 terms of the deviance, w, z and the cell sums
+//     for the NEXT step (the mu-independent part of the NB density is summed once per gene): mu is never stored, so
+//     the kernel has no per-wave LDS slab at all and occupancy is set by registers alone;
+//   * post-loop: X'WX = sum_c S_c x_c x_c', hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c.
+// Sums over samples run cell by cell in wave order over the rank inside the cell.  Arithmetic spec = the CPU checker's
+// fit_beta_gene_cells; results are bit-identical to it.
+#ifndef DSQ_BETA_CELL_MINW
+#define DSQ_BETA_CELL_MINW (DSQ_P <= 6 ? 3 : DSQ_P <= 10 ? 2 : 1)
+#endif
+
+// the rarely taken branch of the deviance sweep (a sample off the general branch of the NB density, e.g. a zero
+// count): kept out of line so that its registers do not count against the sweep's
+__device__ __noinline__ static double nb_offbranch(double y, double size, double mu, double st_size, double log_size,
+                                                   int gen_need_const) {
+    double cst = 0.0;
+    if (gen_need_const) cst = dnb_const(y, size, st_size, log_size);
+    return dnbinom_mu_log(y, size, mu) - cst;
+}
+
+template <int P, bool USE_W>
+__global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(BetaKernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m;
+    const int C = kp.ncell;
+    const int Mrows = C + P;
+    const int nwork = DSQ_NWORK(kp);
+    if (blockIdx.x * waves >= nwork) return;
+    // block-shared: x_c (C x P doubles) | cell_start (C + 1) | cell_perm (m)
+    double *xcs = smem;
+    int32_t *starts = reinterpret_cast<int32_t *>(smem + (size_t)DSQ_CMAX * P);
+    int32_t *perm = starts + DSQ_CMAX + 2;
+    for (int t = threadIdx.x; t <= C; t += blockDim.x) starts[t] = kp.cell_start[t];
+    for (int t = threadIdx.x; t < m; t += blockDim.x) perm[t] = kp.cell_perm[t];
+    for (int t = threadIdx.x; t < C * P; t += blockDim.x) {
+        const int c = t / P, k = t - c * P;
+        xcs[t] = kp.x[(size_t)k * m + kp.cell_perm[kp.cell_start[c]]];
+    }
+    __syncthreads();
+    double lambda[P], contrast[P];
+#pragma unroll
+    for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
+    const double large = 30.0;
+    const double minmu = kp.minmu;
+
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+        const int g = DSQ_GENE(kp, wi);
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double alpha = kp.alpha_hat[g];
+        const double size = 1.0 / alpha;
+        double beta[P];
+#pragma unroll
+        for (int c = 0; c < P; c++) beta[c] = kp.beta_init[(size_t)g + (size_t)kp.n * c];
+
+        double etal = 0.0, expl = 0.0, exp_prev = 0.0;     // lane c: eta_c, exp(eta_c) of cell c
+        double Sl = 0.0, Tl = 0.0;                         // lane c: S_c, T_c
+        auto cell_eta = [&]() {
+            if (lane < C) {
+                double eta = xcs[lane * P] * beta[0];
+#pragma unroll
+                for (int k = 1; k < P; k++) eta = __builtin_fma(xcs[lane * P + k], beta[k], eta);
+                etal = eta;
+                expl = dexp(eta);
+            }
+        };
+        const bool with_dev_ever = kp.maxit > 0;
+        const double st_size = with_dev_ever ? dstirlerr(size) : 0.0, log_size = with_dev_ever ? dlog(size) : 0.0;
+        double K = 0.0, dev = 0.0;
+        // one sweep over the samples at the current beta
+        auto sweep = [&](bool with_dev, bool with_k) {
+            double dacc = 0.0, kacc = 0.0;
+            for (int c = 0; c < C; c++) {
+                const double e = lane_read(expl, c), eta = lane_read(etal, c);
+                const int s0 = starts[c], s1 = starts[c + 1];
+                double a1 = 0.0, a2 = 0.0;
+                for (int k = s0 + lane; k < s1; k += 64) {
+                    const int j = perm[k];
+                    const double nf = nfg[j], y = (double)yg[j];
+                    const double raw = nf * e;
+                    const double mu = __builtin_fmax(raw, minmu);
+                    double wv;
+                    if constexpr (USE_W) wv = (wg[j] * mu) / (1.0 + alpha * mu);
+                    else wv = mu / (1.0 + alpha * mu);
+                    const double lg = (raw >= minmu) ? eta : dlog(mu / nf);
+                    const double zj = lg + (y - mu) / mu;
+                    a1 += wv;
+                    a2 += wv * zj;
+                    if (with_dev || with_k) {
+                        const bool gen = dnb_general(y, size);
+                        double cst = 0.0;
+                        if (with_k) {
+                            if (gen) cst = dnb_const(y, size, st_size, log_size);
+                            if constexpr (USE_W) kacc += wg[j] * cst;
+                            else kacc += cst;
+                        }
+                        if (with_dev) {
+                            double t, itv;
+                            if (gen && dnb_iter(y, size, mu, itv)) t = itv;
+                            else if (gen && with_k) t = dnbinom_mu_log(y, size, mu) - cst;     // (the start sweep has no deviance)
+                            else t = nb_offbranch(y, size, mu, st_size, log_size, gen ? 1 : 0);
+                            if constexpr (USE_W) dacc += wg[j] * t;
+                            else dacc += t;
+                        }
+                    }
+                }
+                const double s = wave_allreduce(a1), tt = wave_allreduce(a2);
+                if (lane == c) { Sl = s; Tl = tt; }
+            }
+            if (with_k) K = wave_allreduce(kacc);
+            if (with_dev) dev = -2.0 * (K + wave_allreduce(dacc));
+        };
+
+        cell_eta();
+        sweep(false, with_dev_ever);
+        double dev_old = 0.0, it = 0.0;
+        for (int t = 0; t < kp.maxit; t++) {
+            it += 1.0;
+            exp_prev = expl;
+            if (kp.useQR) {
+                // rows: lane c < C the cell rows, lanes C .. C+P-1 the ridge rows, the rest zero
+                double a[P], b = 0.0;
+                const double sS = __builtin_sqrt(Sl);
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    double v = 0.0;
+                    if (lane < C) v = xcs[lane * P + k] * sS;
+                    else if (lane - C == k) v = __builtin_sqrt(lambda[k]);
+                    a[k] = v;
+                }
+                if (lane < C) b = (sS > 0.0) ? Tl / sS : 0.0;
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    double acc[P + 1];
+                    const bool below = (lane > k) && (lane < Mrows);
+#pragma unroll
+                    for (int j = k; j < P; j++) acc[j] = below ? a[k] * a[j] : 0.0;
+                    acc[P] = below ? a[k] * b : 0.0;
+#pragma unroll
+                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);
+                    double prow[P + 1];
+#pragma unroll
+                    for (int j = k; j < P; j++) prow[j] = lane_read(a[j], k);
+                    prow[P] = lane_read(b, k);
+                    const double alpha_k = prow[k];
+                    double tau, scal, bet;
+                    if (acc[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                    else {
+                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acc[k]), alpha_k);
+                        tau = (bet - alpha_k) / bet;
+                        scal = 1.0 / (alpha_k - bet);
+                    }
+                    double tvec[P + 1];
+#pragma unroll
+                    for (int j = k + 1; j <= P; j++) tvec[j] = -tau * (prow[j] + scal * acc[j]);
+                    if (below) {
+                        const double v = a[k] * scal;
+#pragma unroll
+                        for (int j = k + 1; j < P; j++) a[j] = __builtin_fma(v, tvec[j], a[j]);
+                        b = __builtin_fma(v, tvec[P], b);
+                    } else if (lane == k) {
+#pragma unroll
+                        for (int j = k + 1; j < P; j++) a[j] = a[j] + tvec[j];
+                        b = b + tvec[P];
+                        a[k] = bet;
+                    }
+                }
+#pragma unroll
+                for (int i = P - 1; i >= 0; i--) {
+                    double tt = lane_read(b, i);
+#pragma unroll
+                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-lane_read(a[j], i), beta[j], tt);
+                    beta[i] = tt / lane_read(a[i], i);
+                }
+            } else {
+                LU<P> lu;
+                double rhs[P];
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+#pragma unroll
+                    for (int b = a; b < P; b++) {
+                        double v = 0.0;
+                        for (int c = 0; c < C; c++) v += xcs[c * P + a] * (xcs[c * P + b] * lane_read(Sl, c));
+                        lu.a[a][b] = v; lu.a[b][a] = v;
+                    }
+                    double v = 0.0;
+                    for (int c = 0; c < C; c++) v += xcs[c * P + a] * lane_read(Tl, c);
+                    rhs[a] = v;
+                }
+#pragma unroll
+                for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+                lu.factor();
+                lu.solve(rhs);
+#pragma unroll
+                for (int a = 0; a < P; a++) beta[a] = rhs[a];
+            }
+            int toolarge = 0;
+#pragma unroll
+            for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; expl = exp_prev; break; }          // (:357-360)
+            cell_eta();
+            sweep(true, false);
+            const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
+            if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }                  // (:375-378)
+            if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
+            else if (uniform((t > 0) && (conv_test < kp.tol))) break;                               // (:379-381)
+            dev_old = dev;
+        }
+
+        // ---- post-loop block (:427-455) from the cell sums of the final mu ----------------------------------------
+        double G[P][P], Gi[P][P];
+#pragma unroll
+        for (int a = 0; a < P; a++)
+#pragma unroll
+            for (int b = a; b < P; b++) {
+                double v = 0.0;
+                for (int c = 0; c < C; c++) v += xcs[c * P + a] * (xcs[c * P + b] * lane_read(Sl, c));
+                G[a][b] = v; G[b][a] = v;
+            }
+        {
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = G[a][b];
+#pragma unroll
+            for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lambda[a];
+            lu.factor();
+            lu.inverse(Gi);
+        }
+        if (kp.hat_diagonals || kp.mu_out) {
+            // fitted means from the FINAL coefficients (also when they diverged), as the general kernel reports them
+            double eo = 0.0;
+            if (lane < C) {
+                double eta = xcs[lane * P] * beta[0];
+#pragma unroll
+                for (int k = 1; k < P; k++) eta = __builtin_fma(xcs[lane * P + k], beta[k], eta);
+                eo = dexp(eta);
+            }
+            for (int c = 0; c < C; c++) {
+                double h = 0.0;
+#pragma unroll
+                for (int i1 = 0; i1 < P; i1++)
+#pragma unroll
+                    for (int i2 = 0; i2 < P; i2++) h += xcs[c * P + i1] * (xcs[c * P + i2] * Gi[i2][i1]);
+                const double e = lane_read(expl, c), eout = lane_read(eo, c);
+                const int s0 = starts[c], s1 = starts[c + 1];
+                for (int k = s0 + lane; k < s1; k += 64) {
+                    const int j = perm[k];
+                    const double nf = nfg[j];
+                    if (kp.hat_diagonals) {
+                        const double mu = __builtin_fmax(nf * e, minmu);
+                        double wv;
+                        if constexpr (USE_W) wv = (wg[j] * mu) / (1.0 + alpha * mu);
+                        else wv = mu / (1.0 + alpha * mu);
+                        kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * h;
+                    }
+                    if (kp.mu_out) {
+                        double v = nf * eout;
+                        if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
+                        kp.mu_out[(size_t)g * kp.ld + j] = v;
+                    }
+                }
+            }
+        }
+        double T[P][P], Sg[P][P];
+        mat_mul<P>(Gi, G, T);
+        mat_mul<P>(T, Gi, Sg);
+        double cn = 0.0;
+#pragma unroll
+        for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
+        double cd = 0.0;
+#pragma unroll
+        for (int b = 0; b < P; b++) {
+            double rr = 0.0;
+#pragma unroll
+            for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[a][b], rr);
+            cd = __builtin_fma(rr, contrast[b], cd);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < P; c++) {
+                kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
+                kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[c][c];
+            }
+            kp.iter[g] = it;
+            kp.deviance[g] = dev;
+            kp.contrast_num[g] = cn;
+            kp.contrast_denom[g] = __builtin_sqrt(cd);
+        }
+    }
+}
+
+template <int P>
+static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) {
+    const size_t lds = (size_t)DSQ_CMAX * P * sizeof(double) + ((size_t)DSQ_CMAX + 2 + kp.m) * sizeof(int32_t);
+    const int waves = 4;
+    const void *fn = kp.useWeights ? (const void *)fit_beta_cell_kernel<P, true> : (const void *)fit_beta_cell_kernel<P, false>;
+    static int bpc_cache[2];
+    static size_t lds_cache[2];
+    const int wi = kp.useWeights ? 1 : 0;
+    if (lds_cache[wi] != lds || bpc_cache[wi] == 0) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int bpc = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * waves, lds) != hipSuccess || bpc < 1) bpc = 1;
+        bpc_cache[wi] = bpc; lds_cache[wi] = lds;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_cells<P=%d> lds=%zu occupancy-api blocks/CU=%d\n", P, lds, bpc);
+    }
+    const int cus = device_cu_count();
+    int blocks_needed = (kp.n + waves - 1) / waves;
+    int grid = blocks_needed < cus * bpc_cache[wi] ? blocks_needed : cus * bpc_cache[wi];
+    if (kp.rows_few && grid > cus) grid = cus;
+    if (grid < 1) grid = 1;
+    if (kp.useWeights) hipLaunchKernelGGL((fit_beta_cell_kernel<P, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    else hipLaunchKernelGGL((fit_beta_cell_kernel<P, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    return hipGetLastError();
+}
+
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
@@ -536,6 +863,7 @@ void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_
 
 template <>
 hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st) {
+    if (kp0.ncell > 0 && kp0.ncell <= DSQ_CMAX && kp0.ncell + DSQ_P <= 64) return launch_beta_cells<DSQ_P>(kp0, st);
     int waves, grid, xlds;
     bool stage;
     size_t lds;

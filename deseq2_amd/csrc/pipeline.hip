@@ -412,6 +412,8 @@ struct Pipe {
     int32_t *cells_dev;            // perm | in3 | cell_start | use3 | replaceable
     void *trend_ws;
     int next_counter;
+    const int32_t *cell_perm, *cell_start;   // design cells for the cell-collapsed fitBeta kernel (ncell = 0: general)
+    int ncell;
     const char *tag;               // appended to the profile names of the refit chain's launches
     // host-side facts of the design cells
     int any3, maxcell, all_replaceable;
@@ -465,6 +467,7 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.scratch = P.scratch; kp.cscratch = P.cscratch;
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
+    kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell;
     bool ok = false;
     char nm[32];
     snprintf(nm, sizeof nm, "%s%s", name, P.tag);
@@ -711,6 +714,8 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         PIPE_HIP(hipMemcpyAsync(P.lam, host, 2 * (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
     }
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
+    if (a->cell_of && a->ncell > 0)
+        P.ncell = capi_upload_cells(a->cell_of, m, DSQ_WS_PIPE_META + 2, st, &P.cell_perm, &P.cell_start);
 
     // ================================================================ gene-wise estimates
     if (a->phases & DSQ_PH_GENE_EST) {

@@ -264,6 +264,7 @@ class DeviceEngine:
         from . import _lib
         _lib.check(_lib.lib().dsq_set_device(self.device.index or 0))
         self._cache = {}
+        self._cells = {}
         self._tls = threading.local()
         self.record = None          # set to a list to collect (name, n, ms) per fit kernel
         self.want_d2lp = False      # estimateDispersions* never read fitDisp$last_d2lp (R/core.R:784-787,1042)
@@ -323,6 +324,7 @@ class DeviceEngine:
         v = self._cache.get(key)
         if v is None:
             v = self._cache[key] = self.torch.as_tensor(np.ascontiguousarray(x.T), device=self.device)
+            self._cells[v.data_ptr()] = self.native.cell_index(x)       # design cells, for the cell-collapsed fitBeta
         return v
 
     def _design_qr_dev(self, x):
@@ -496,7 +498,7 @@ class DeviceEngine:
         av, cv, lv = dv[:n], dv[n:n + pp], dv[n + pp:]
         r = self._timed("fit_beta", y.n, lambda: self.native.fitBeta_dev(
             y, x, nf, av, cv, b0, lv, weights, useWeights, tol, maxit, useQR, minmu, want_hat=want_hat,
-            want_mu=want_mu, mu_floor=mu_floor))
+            want_mu=want_mu, mu_floor=mu_floor, cells=self._cells.get(x.data_ptr())))
         def fetch():
             h = self._host(r["_pack"]).numpy()           # one device-to-host copy for all per-gene outputs
             p = (h.shape[0] - 4) // 2

@@ -345,7 +345,7 @@ def gene_major_ld(m):
 
 
 def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWeights, tol, maxit, useQR,
-                minmu, want_hat=True, want_mu=False, mu_floor=0.0, nf_is_vector=False):
+                minmu, want_hat=True, want_mu=False, mu_floor=0.0, nf_is_vector=False, cells=None):
     """All array arguments are torch CUDA tensors.  y / nf / weights: GeneMajor (y int32) --
     outputs hat_diagonals / mu are GeneMajor too; x: (m, p) column-major i.e. a (p, m)
     contiguous tensor is passed as `x` (see `design_to_device`)."""
@@ -373,7 +373,9 @@ def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWe
                          alpha_hat=_t_ptr(alpha_hat), contrast=_t_ptr(contrast), beta_mat=_t_ptr(beta_mat),
                          lambda_=_t_ptr(lambda_), weights=_t_ptr(weights.t) if useWeights else None,
                          useWeights=int(bool(useWeights)), tol=float(tol), maxit=int(maxit),
-                         useQR=int(bool(useQR)), minmu=float(minmu))
+                         useQR=int(bool(useQR)), minmu=float(minmu),
+                         cell_of=_ptr(cells) if cells is not None else None,
+                         ncell=(int(cells.max()) + 1) if cells is not None else 0)
     o = L.DsqFitBetaOut(beta_mat=_t_ptr(out["beta_mat"]), beta_var_mat=_t_ptr(out["beta_var_mat"]),
                         iter=_t_ptr(out["iter"]), hat_diagonals=_t_ptr(hat.t) if hat else None,
                         contrast_num=_t_ptr(out["contrast_num"]), contrast_denom=_t_ptr(out["contrast_denom"]),

@@ -81,6 +81,11 @@ typedef struct {
     int32_t maxit;          /* 0 is valid: only the post-loop block runs (R/results.R:797) */
     int32_t useQR;
     double minmu;
+    /* extension: design cells.  HOST array of m labels, samples with identical rows of x carrying the same label
+     * (any numbering), ncell = number of labels; NULL / 0 = not known.  With at most 32 cells the cell-collapsed
+     * kernel runs.  The host-pointer entry point derives the cells from x itself when this is NULL.  */
+    const int32_t *cell_of;
+    int32_t ncell;
 } DsqFitBetaArgs;
 
 typedef struct {

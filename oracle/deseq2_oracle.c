@@ -506,6 +506,191 @@ int orc_fit_disp_grid(int n, int m, int p,
     return 0;
 }
 
+/* ------------------------------------------------------------- design cells ----
+ * Samples with identical model-matrix rows form a design CELL (modelMatrixGroups, R/core.R:2450).  Every factor
+ * design has a handful; a continuous covariate gives one cell per sample.  Cells are numbered in order of first
+ * appearance; xc[c*p + k] is the row of cell c; perm lists the samples grouped by cell (ascending sample index
+ * inside a cell), start[c] .. start[c+1] the members of cell c.  Returns the number of cells, or 0 when there are
+ * more than cmax (the callers then take the general per-sample path).                                           */
+#define ORC_CMAX 32
+static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc) {
+    int *cell_of = malloc(sizeof(int) * (m > 0 ? m : 1));
+    int C = 0;
+    for (int j = 0; j < m; j++) {
+        int c;
+        for (c = 0; c < C; c++) {
+            int same = 1;
+            for (int k = 0; k < p; k++) if (x[j + (long)m * k] != xc[c * p + k]) { same = 0; break; }
+            if (same) break;
+        }
+        if (c == C) {
+            if (C == cmax) { free(cell_of); return 0; }
+            for (int k = 0; k < p; k++) xc[C * p + k] = x[j + (long)m * k];
+            C++;
+        }
+        cell_of[j] = c;
+    }
+    for (int c = 0; c <= C; c++) start[c] = 0;
+    for (int j = 0; j < m; j++) start[cell_of[j] + 1]++;
+    for (int c = 0; c < C; c++) start[c + 1] += start[c];
+    int fill[ORC_CMAX];
+    for (int c = 0; c < C; c++) fill[c] = start[c];
+    for (int j = 0; j < m; j++) perm[fill[cell_of[j]]++] = j;
+    free(cell_of);
+    return C;
+}
+
+static void householder_ls(int M, int p, double *A, double *b, double *beta, int serial);
+
+/* fitBeta in CELL MODE (at most ORC_CMAX design cells).  Within a cell every sample has the same design row x_c, so
+ *   - the linear predictor is one value eta_c per cell, mu_j = max(nf_j exp(eta_c), minmu)       (:324-327, bits as
+ *     in the general path);
+ *   - the weighted least squares of an IRLS step depends on the samples only through S_c = sum_{j in c} w_j and
+ *     T_c = sum_{j in c} w_j z_j: it is solved on the COLLAPSED (C + p) x p system with rows sqrt(S_c) x_c and
+ *     right-hand side T_c / sqrt(S_c) -- the normal equations X'WX + ridge, X'Wz of :344-356 / :398 -- by the same
+ *     Householder QR (useQR) or LU; z_j = eta_c + (y_j - mu_j)/mu_j where mu_j is not clamped (log(mu/nf) = eta_c);
+ *   - the deviance -2 sum [wts] log NB(y; 1/alpha, mu) splits into the mu-independent constants K (summed once per
+ *     gene) and the two bd0 terms per sample and iteration: dev = -2 (K + D);
+ *   - post-loop: X'WX = sum_c S_c x_c x_c', hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c.
+ * Sums over the samples run cell by cell, in wave order over the RANK of the sample inside its cell (partial l takes
+ * the members of rank l, l+64, ...; the 64 partials of a per-gene sum -- the deviance, K -- keep accumulating across
+ * the cells in cell order).  Every convergence rule is that of the general path.                                */
+static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int *start, const double *xc,
+                                const double *yrow, const double *nfrow, const double *wts, int useWeights,
+                                double alpha, const double *lambda, const double *contrast, double *beta_hat,
+                                double tol, int maxit, int useQR, double minmu, int sum_mode,
+                                double *A, double *bb, double *beta_var, double *it_out, double *hat,
+                                double *cnum, double *cden, double *dev_out) {
+    const double large = 30.0;
+    const double size = 1.0 / alpha;
+    double eta_c[ORC_CMAX], exp_c[ORC_CMAX], exp_prev[ORC_CMAX], Sc[ORC_CMAX], Tc[ORC_CMAX];
+    double K = 0.0;
+    #define CELL_ETA() \
+        for (int c = 0; c < C; c++) { \
+            double eta = xc[c * p] * beta_hat[0]; \
+            for (int k = 1; k < p; k++) eta = fma(xc[c * p + k], beta_hat[k], eta); \
+            eta_c[c] = eta; exp_c[c] = orc_exp(eta); }
+    /* one sweep over the samples at the current beta: S_c, T_c (for the next least squares / the post-loop block)
+     * and, when asked, the deviance parts */
+    #define CELL_SWEEP(WITH_DEV, WITH_K) do { \
+        wsum_t sd, sk; wsum_init(&sd, sum_mode); wsum_init(&sk, sum_mode); \
+        for (int c = 0; c < C; c++) { \
+            wsum_t s1, s2; wsum_init(&s1, sum_mode); wsum_init(&s2, sum_mode); \
+            for (int k = start[c]; k < start[c + 1]; k++) { \
+                const int j = perm[k], r = k - start[c]; \
+                const double raw = nfrow[j] * exp_c[c]; \
+                const double mu = fmax(raw, minmu); \
+                const double wv = useWeights ? (wts[j] * mu) / (1.0 + alpha * mu) : mu / (1.0 + alpha * mu); \
+                const double lg = (raw >= minmu) ? eta_c[c] : orc_log(mu / nfrow[j]); \
+                const double zj = lg + (yrow[j] - mu) / mu; \
+                wsum_add(&s1, r, wv); wsum_add(&s2, r, wv * zj); \
+                if (WITH_DEV || WITH_K) { \
+                    double cst, itv; \
+                    const int gen = orc_dnb_const(yrow[j], size, st_size, log_size, &cst); \
+                    if (WITH_K) wsum_add(&sk, r, useWeights ? wts[j] * cst : cst); \
+                    if (WITH_DEV) { \
+                        double t; \
+                        if (gen && orc_dnb_iter(yrow[j], size, mu, &itv)) t = itv; \
+                        else t = orc_dnbinom_mu_log(yrow[j], size, mu) - cst; \
+                        wsum_add(&sd, r, useWeights ? wts[j] * t : t); \
+                    } \
+                } \
+            } \
+            Sc[c] = wsum_total(&s1); Tc[c] = wsum_total(&s2); \
+        } \
+        if (WITH_K) K = wsum_total(&sk); \
+        if (WITH_DEV) dev = -2.0 * (K + wsum_total(&sd)); \
+    } while (0)
+    const double st_size = orc_stirlerr(size), log_size = orc_log(size);
+    double dev = 0.0, dev_old = 0.0, it = 0.0;
+    CELL_ETA();
+    CELL_SWEEP(0, 1);
+    for (int t = 0; t < maxit; t++) {
+        it += 1.0;
+        for (int c = 0; c < C; c++) exp_prev[c] = exp_c[c];
+        if (useQR) {
+            for (int c = 0; c < C; c++) {
+                double sS = sqrt(Sc[c]);
+                for (int k = 0; k < p; k++) A[(long)c * p + k] = xc[c * p + k] * sS;
+                bb[c] = (sS > 0.0) ? Tc[c] / sS : 0.0;
+            }
+            for (int r = 0; r < p; r++) {
+                for (int c = 0; c < p; c++) A[(long)(C + r) * p + c] = (r == c) ? sqrt(lambda[c]) : 0.0;
+                bb[C + r] = 0.0;
+            }
+            householder_ls(C + p, p, A, bb, beta_hat, sum_mode);
+        } else {
+            double G[ORC_PMAX * ORC_PMAX], rhs[ORC_PMAX];
+            for (int a = 0; a < p; a++) {
+                for (int b = a; b < p; b++) {
+                    double v = 0.0;
+                    for (int c = 0; c < C; c++) v += xc[c * p + a] * (xc[c * p + b] * Sc[c]);
+                    G[a * p + b] = v; G[b * p + a] = v;
+                }
+                double v = 0.0;
+                for (int c = 0; c < C; c++) v += xc[c * p + a] * Tc[c];
+                rhs[a] = v;
+            }
+            for (int a = 0; a < p; a++) G[a * p + a] = G[a * p + a] + lambda[a];
+            int piv[ORC_PMAX]; double rdiag[ORC_PMAX];
+            lu_decomp(p, G, piv, rdiag);
+            lu_solve(p, G, piv, rdiag, rhs);
+            for (int a = 0; a < p; a++) beta_hat[a] = rhs[a];
+        }
+        int toolarge = 0;
+        for (int c = 0; c < p; c++) if (fabs(beta_hat[c]) > large) toolarge++;
+        if (toolarge > 0) {                  /* :357-360: beta is kept, mu (and so S_c) stay those of the last update */
+            it = (double)maxit;
+            for (int c = 0; c < C; c++) exp_c[c] = exp_prev[c];
+            break;
+        }
+        CELL_ETA();
+        CELL_SWEEP(1, 0);
+        double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);
+        if (isnan(conv_test)) { it = (double)maxit; break; }
+        if ((t > 0) & (conv_test < tol)) break;
+        dev_old = dev;
+    }
+    *dev_out = dev; *it_out = it;
+    /* post-loop (:427-455) from the cell sums of the final mu */
+    double G[ORC_PMAX * ORC_PMAX], Gr[ORC_PMAX * ORC_PMAX], Gi[ORC_PMAX * ORC_PMAX];
+    for (int a = 0; a < p; a++)
+        for (int b = a; b < p; b++) {
+            double v = 0.0;
+            for (int c = 0; c < C; c++) v += xc[c * p + a] * (xc[c * p + b] * Sc[c]);
+            G[a * p + b] = v; G[b * p + a] = v;
+        }
+    memcpy(Gr, G, sizeof(double) * p * p);
+    for (int a = 0; a < p; a++) Gr[a * p + a] = Gr[a * p + a] + lambda[a];
+    mat_inverse(p, Gr, Gi, NULL);
+    for (int c = 0; c < C; c++) {
+        double h = 0.0;
+        for (int i1 = 0; i1 < p; i1++)
+            for (int i2 = 0; i2 < p; i2++) h += xc[c * p + i1] * (xc[c * p + i2] * Gi[i2 * p + i1]);
+        for (int k = start[c]; k < start[c + 1]; k++) {
+            const int j = perm[k];
+            const double mu = fmax(nfrow[j] * exp_c[c], minmu);
+            const double wv = useWeights ? (wts[j] * mu) / (1.0 + alpha * mu) : mu / (1.0 + alpha * mu);
+            hat[j] = wv * h;
+        }
+    }
+    double T[ORC_PMAX * ORC_PMAX], Sg[ORC_PMAX * ORC_PMAX];
+    mat_mul(p, Gi, G, T); mat_mul(p, T, Gi, Sg);
+    double cn = 0.0;
+    for (int c = 0; c < p; c++) cn = fma(contrast[c], beta_hat[c], cn);
+    *cnum = cn;
+    double cd = 0.0;
+    for (int b = 0; b < p; b++) {
+        double r = 0.0;
+        for (int a = 0; a < p; a++) r = fma(contrast[a], Sg[a * p + b], r);
+        cd = fma(r, contrast[b], cd);
+    }
+    *cden = sqrt(cd);
+    for (int c = 0; c < p; c++) beta_var[c] = Sg[c * p + c];
+    #undef CELL_ETA
+    #undef CELL_SWEEP
+}
+
 /* ================================================================ fitBeta ==
  * DESeq2.cpp:283-465 */
 
@@ -564,9 +749,12 @@ int orc_fit_beta(int n, int m, int p,
                  const double *weights, int useWeights, double tol, int maxit, int useQR,
                  double minmu,
                  double *beta_mat, double *beta_var_mat, double *iter, double *hat_diagonals,
-                 double *contrast_num, double *contrast_denom, double *deviance, int sum_mode) {
+                 double *contrast_num, double *contrast_denom, double *deviance, int sum_mode, int cell_mode) {
     if (p > ORC_PMAX) return -1;
     const double large = 30.0;                                                   /* :316 */
+    int *cperm = malloc(sizeof(int) * (m > 0 ? m : 1)), cstart[ORC_CMAX + 1];
+    double *xc = malloc(sizeof(double) * ORC_CMAX * ORC_PMAX);
+    const int C = cell_mode ? design_cells(m, p, x, ORC_CMAX, cperm, cstart, xc) : 0;
 #pragma omp parallel
     {
     int M = m + p;
@@ -584,6 +772,15 @@ int orc_fit_beta(int n, int m, int p,
         }
         for (int c = 0; c < p; c++) beta_hat[c] = beta_init[i + (long)n * c];    /* :323 */
         double alpha = alpha_hat[i];
+        if (C > 0) {
+            double bvar[ORC_PMAX], itv, cn_, cd_, dv_;
+            fit_beta_gene_cells(m, p, C, cperm, cstart, xc, yrow, nfrow, wts, useWeights, alpha, lambda, contrast,
+                                beta_hat, tol, maxit, useQR, minmu, sum_mode, A, bb, bvar, &itv, z, &cn_, &cd_, &dv_);
+            for (int c = 0; c < p; c++) { beta_mat[i + (long)n * c] = beta_hat[c]; beta_var_mat[i + (long)n * c] = bvar[c]; }
+            for (int j = 0; j < m; j++) hat_diagonals[i + (long)n * j] = z[j];
+            iter[i] = itv; contrast_num[i] = cn_; contrast_denom[i] = cd_; deviance[i] = dv_;
+            continue;
+        }
         /* mu_hat = nfrow % exp(x * beta_hat), clamped                            :324-327 */
         #define ORC_UPDATE_MU() \
             for (int j = 0; j < m; j++) { \
@@ -697,6 +894,7 @@ int orc_fit_beta(int n, int m, int p,
     }
     free(yrow); free(nfrow); free(wts); free(mu); free(w_vec); free(w_sqrt); free(z); free(A); free(bb);
     }
+    free(cperm); free(xc);
     return 0;
 }
 

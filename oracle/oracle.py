@@ -111,7 +111,9 @@ def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP,
 
 def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lambdaSEXP,
             weightsSEXP, useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, sum_mode=0,
-            want_mu=False, mu_floor=0.0, want_hat=True):
+            want_mu=False, mu_floor=0.0, want_hat=True, cell_mode=1):
+    """cell_mode = 1 (the engine's default): designs with at most 32 distinct rows take the cell-collapsed path
+    (see fit_beta_gene_cells); 0 forces the general per-sample path (what a continuous covariate takes)"""
     y = _f(ySEXP); x = _f(xSEXP); nf = _f(nfSEXP); w = _f(weightsSEXP); b0 = _f(beta_matSEXP)
     n, m = y.shape; p = x.shape[1]
     assert x.shape[0] == m and nf.shape == (n, m) and w.shape == (n, m) and b0.shape == (n, p)
@@ -127,7 +129,8 @@ def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lam
         _p(contrast), _p(b0), _p(lam), _p(w), ctypes.c_int(int(bool(useWeightsSEXP))),
         ctypes.c_double(float(tolSEXP)), ctypes.c_int(int(maxitSEXP)), ctypes.c_int(int(bool(useQRSEXP))),
         ctypes.c_double(float(minmuSEXP)),
-        _p(beta_mat), _p(beta_var), _p(it), _p(H), _p(cn), _p(cd), _p(dev), ctypes.c_int(sum_mode))
+        _p(beta_mat), _p(beta_var), _p(it), _p(H), _p(cn), _p(cd), _p(dev), ctypes.c_int(sum_mode),
+        ctypes.c_int(int(cell_mode)))
     if rc != 0:
         raise RuntimeError("orc_fit_beta failed: %d" % rc)
     out = {"beta_mat": beta_mat, "beta_var_mat": beta_var, "iter": it, "hat_diagonals": H,

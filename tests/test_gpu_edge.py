@@ -133,13 +133,16 @@ def test_device_pointers_in_r_layout(oracle):
     def ptr(t):
         return C.c_void_p(t.data_ptr())
     y, x, nf, b0 = col(d["counts"], torch.int32), col(d["x"]), col(d["nf"]), col(d["beta_init"])
+    from deseq2_amd import native
+    cells = native.cell_index(d["x"])       # the design cells (the device entry point cannot read them off a device x)
     al, ct, lm = (torch.as_tensor(v, dtype=torch.float64, device=dev) for v in (d["alpha_init"], contrast, lam))
     out = {k: torch.zeros(s, dtype=torch.float64, device=dev) for k, s in
            (("beta_mat", (p, n)), ("beta_var_mat", (p, n)), ("iter", (n,)), ("hat", (m, n)), ("cn", (n,)), ("cd", (n,)),
             ("dev", (n,)), ("mu", (m, n)))}
     a = L.DsqFitBetaArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=ptr(y), y_type=L.DSQ_Y_INT32, x=ptr(x),
                          nf=ptr(nf), nf_is_vector=0, alpha_hat=ptr(al), contrast=ptr(ct), beta_mat=ptr(b0),
-                         lambda_=ptr(lm), weights=None, useWeights=0, tol=1e-8, maxit=100, useQR=1, minmu=0.5)
+                         lambda_=ptr(lm), weights=None, useWeights=0, tol=1e-8, maxit=100, useQR=1, minmu=0.5,
+                         cell_of=cells.ctypes.data_as(C.c_void_p), ncell=int(cells.max()) + 1)
     o = L.DsqFitBetaOut(beta_mat=ptr(out["beta_mat"]), beta_var_mat=ptr(out["beta_var_mat"]), iter=ptr(out["iter"]),
                         hat_diagonals=ptr(out["hat"]), contrast_num=ptr(out["cn"]), contrast_denom=ptr(out["cd"]),
                         deviance=ptr(out["dev"]), mu=ptr(out["mu"]), mu_floor=0.5)

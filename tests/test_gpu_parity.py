@@ -51,6 +51,28 @@ def test_fit_beta_matches_oracle(oracle, n, m, design, useW, useQR):
     assert (want["iter"] < 100).mean() > 0.9
 
 
+@pytest.mark.parametrize("n,m,base,useW,useQR", [(300, 100, "two_group", False, True), (200, 500, "batch_condition", False, True),
+                                                  (150, 70, ("factor", 6), True, True), (150, 90, "two_group", True, False),
+                                                  (60, 1500, "batch_condition", False, True)])
+def test_fit_beta_general_path_matches_oracle(oracle, n, m, base, useW, useQR):
+    """a design with a CONTINUOUS covariate has one cell per sample: the general per-sample kernel (Householder QR by
+    replay / normal equations) against the general path of the oracle -- the factor designs above all take the
+    cell-collapsed kernel"""
+    d = make_case(n, m, base, seed=5, weights=useW, sf_random=True)
+    rng = np.random.default_rng(m)
+    x = np.column_stack([d["x"], rng.normal(0.0, 0.3, m)])
+    d["x"] = x
+    d["beta_init"] = np.column_stack([d["beta_init"], np.zeros(d["beta_init"].shape[0])])
+    p = x.shape[1]
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    got, want = _fit_beta_both(oracle, d, d["alpha_init"], lam, useW, useQR)
+    for k in BETA_KEYS:
+        assert_same(got[k], want[k], "fitBeta(general)$" + k)
+    want0 = oracle.fitBeta(d["counts"], x, d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"], lam,
+                           d["weights"], useW, 1e-8, 100, useQR, 0.5, cell_mode=0)
+    assert_same(want["iter"], want0["iter"], "more than 32 cells = the general path")
+
+
 @pytest.mark.parametrize("n,m,design,useW", [(500, 100, "two_group", False), (300, 500, "batch_condition", False),
                                               (300, 200, "two_group", True), (600, 6, "two_group", False),
                                               (200, 70, ("factor", 6), True), (100, 130, ("factor", 10), False),

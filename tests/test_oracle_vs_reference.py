@@ -47,7 +47,7 @@ def live_cases():
     c = dict(golden_cases())
     c.update({
         "bc_m60": _case(300, 60, "batch_condition", 21),
-        "factor10_m100": _case(100, 100, ("factor", 10), 22),
+        "factor10_m100": _case(400, 100, ("factor", 10), 22),   # 400 genes: the 1 % tie budget needs a sample that can resolve it
         "two_m200_weights": _case(60, 200, "two_group", 23, weights=True),
         "bc_m36_zero_weights": _case(120, 36, "batch_condition", 24, weights=True, zero_w=True),
         "two_m8_ridge_ne": _case(200, 8, "two_group", 25, useQR=False, lam=2.0),
