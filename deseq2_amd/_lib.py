@@ -54,6 +54,7 @@ class DsqFitDispArgs(C.Structure):
         ("log_alpha_prior_sigmasq", C.c_double), ("min_log_alpha", C.c_double), ("kappa_0", C.c_double),
         ("tol", C.c_double), ("maxit", C.c_int32), ("usePrior", C.c_int32), ("weights", C.c_void_p),
         ("useWeights", C.c_int32), ("weightThreshold", C.c_double), ("useCR", C.c_int32),
+        ("cell_of", C.c_void_p), ("ncell", C.c_int32),
     ]
 
 
@@ -72,6 +73,7 @@ class DsqFitDispGridArgs(C.Structure):
         ("disp_grid", C.c_void_p), ("ngrid", C.c_int32), ("log_alpha_prior_mean", C.c_void_p),
         ("log_alpha_prior_sigmasq", C.c_double), ("usePrior", C.c_int32), ("weights", C.c_void_p),
         ("useWeights", C.c_int32), ("weightThreshold", C.c_double), ("useCR", C.c_int32),
+        ("cell_of", C.c_void_p), ("ncell", C.c_int32),
     ]
 
 

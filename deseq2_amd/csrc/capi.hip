@@ -449,7 +449,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
 // =============================================================== fitDisp (device)
 static int disp_common(int n, int m, int p, int layout, long ld_in, const void *y, int y_type, const double *x,
                        const double *mu_hat, const double *weights, int useWeights, hipStream_t st,
-                       DispKernelParams *kp, bool *ycheck) {
+                       DispKernelParams *kp, bool *ycheck, const int32_t *cell_of = nullptr, int ncell = 0) {
     if (n < 0 || m < 1 || p < 1) return fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", n, m, p);
     if (p > DSQ_P_WIDE)
         return fail(DSQ_ERR_UNSUPPORTED, "p=%d design columns: kernels are compiled for 1..%d", p, DSQ_P_WIDE);
@@ -474,6 +474,8 @@ static int disp_common(int n, int m, int p, int layout, long ld_in, const void *
     }
     kp->x = x;
     kp->useWeights = useWeights ? 1 : 0;
+    if (cell_of && ncell > 0 && p >= DSQ_DISP_CELL_MINP)
+        kp->ncell = capi_upload_cells(cell_of, m, WS_CELLS_BETA, st, &kp->cell_perm, &kp->cell_start);
     if (is_wide(p)) {           // zero-padded design, unit diagonal on the padding in the Cox-Reid matrix
         rc = wide_pad_x(m, p, x, st, &kp->x, &kp->padmask);
         if (rc) return rc;
@@ -504,7 +506,7 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     DispKernelParams kp;
     bool ycheck = false;
     int rc = disp_common(a->n, a->m, a->p, a->layout, a->ld, a->y, a->y_type, a->x, a->mu_hat, a->weights,
-                         a->useWeights, st, &kp, &ycheck);
+                         a->useWeights, st, &kp, &ycheck, a->cell_of, a->ncell);
     if (rc) return rc;
     if (a->n == 0) return DSQ_OK;
     kp.log_alpha_in = a->log_alpha; kp.prior_mean = a->log_alpha_prior_mean;
@@ -536,7 +538,7 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     DispKernelParams kp;
     bool ycheck = false;
     int rc = disp_common(a->n, a->m, a->p, a->layout, a->ld, a->y, a->y_type, a->x, a->mu_hat, a->weights,
-                         a->useWeights, st, &kp, &ycheck);
+                         a->useWeights, st, &kp, &ycheck, a->cell_of, a->ncell);
     if (rc) return rc;
     if (a->n == 0) return DSQ_OK;
     kp.prior_mean = a->log_alpha_prior_mean; kp.prior_sigmasq = a->log_alpha_prior_sigmasq;
@@ -1039,6 +1041,11 @@ int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
     od.log_alpha = ov; od.last_change = ov + n; od.initial_lp = ov + 2 * n; od.initial_dlp = ov + 3 * n;
     od.last_lp = ov + 4 * n; od.last_dlp = ov + 5 * n; od.last_d2lp = ov + 6 * n;
     od.iter = (int32_t *)(ov + 7 * n); od.iter_accept = od.iter + n;
+    std::vector<int32_t> labels;
+    if (!a->cell_of) {
+        cells_of_host_design(a->x, a->m, a->p, &labels);
+        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
+    }
     rc = fit_disp_dev_locked(&d, &od, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
@@ -1080,6 +1087,11 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
     d.log_alpha_prior_mean = vec; d.disp_grid = vec + n;
     if ((rc = ws_get(WS_H_OUTVEC, n * 8, &v))) return rc;
     od.log_alpha = (double *)v;
+    std::vector<int32_t> labels;
+    if (!a->cell_of) {
+        cells_of_host_design(a->x, a->m, a->p, &labels);
+        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
+    }
     rc = fit_disp_grid_dev_locked(&d, &od, st);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));

@@ -30,6 +30,9 @@ struct DispKernelParams {
     int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
     unsigned padmask;        // WIDE kernels: bit c set = design column c is zero padding
     const double *prior_sigmasq_dev;   // non-null: the prior variance is read from the device (fused pipeline)
+    // design cells (see BetaKernelParams): ncell > 0 -> the Cox-Reid matrices are assembled from per-cell sums
+    const int32_t *cell_perm, *cell_start;
+    int ncell;
     // fused pipeline (pipeline.hip): the launch covers the genes rows[0 .. *n_dev) of full-size arrays (rows == nullptr:
     // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
     const int32_t *rows;
@@ -173,7 +176,8 @@ size_t trend_fit_workspace_bytes();
 // the Cox-Reid matrix, which leaves every quantity of the real coefficients unchanged (capi.hip, "wide designs").
 #define DSQ_P_WIDE0 16
 #define DSQ_P_WIDE 24
-#define DSQ_CMAX 32       // most design cells the cell-collapsed fitBeta kernel takes
+#define DSQ_CMAX 32       // most design cells the cell-collapsed paths take
+#define DSQ_DISP_CELL_MINP 5   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
 // doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they

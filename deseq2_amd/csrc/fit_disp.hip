@@ -8,6 +8,12 @@
 // 1 + p(p+1)/2 partial sums that are xor-butterflied across the wave; the p x p
 // determinant / inverse / traces are wave-uniform register math (LU, partial pivoting).
 // The Armijo line search itself is wave-uniform scalar control flow.
+// design widths from DSQ_DISP_WIDE_MIN up are built in the WIDE form (rolled p^3 loops, the wave-uniform p x p work
+// matrices once per wave in an LDS arena instead of once per lane in registers / scratch)
+#ifndef DSQ_DISP_WIDE_MIN
+#define DSQ_DISP_WIDE_MIN 11
+#endif
+#define DSQ_WIDE_MIN DSQ_DISP_WIDE_MIN
 #include "dsq_internal.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +60,9 @@ struct DispGene {
     // per DISTINCT count (often a handful) instead of once per sample
     const int32_t *dv, *dc;
     int nv;
+    // design cells (block-shared LDS): samples grouped by cell / cell offsets; C = 0 -> general per-sample Gram
+    const int32_t *cperm, *cstart;
+    int C;
     template <class T>
     DSQ_DEV T &arena_take() const {
         T *q = reinterpret_cast<T *>(arena + arena_off);
@@ -139,6 +148,68 @@ DSQ_UNROLL_P
     // matrix leaves det / inverse / traces equal to those of the compacted matrix.
     template <int K, class F>
     DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
+        if (C > 0) {
+            // CELL MODE: X' diag(wd) X = sum_c S_c x_c x_c', S_c = sum of wd over the kept samples of cell c (wave
+            // order over the rank inside the cell; lane c keeps S_c), outer products added serially in cell order.
+            // Per sample: K additions instead of K p(p+1)/2 multiply-adds; K C wave reductions instead of K p(p+1)/2.
+            double Sl[K];
+            _Pragma("unroll")
+            for (int k = 0; k < K; k++) Sl[k] = 0.0;
+            for (int c = 0; c < C; c++) {
+                const int s0 = cstart[c], s1 = cstart[c + 1];
+                double acc[K];
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++) acc[k] = 0.0;
+                for (int kk = s0 + lane; kk < s1; kk += 64) {
+                    const int j = cperm[kk];
+                    double wd[K];
+                    wfun(r.inv_mu(j), wd);
+                    if (keep_row(j)) {
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) acc[k] += wd[k];
+                    }
+                }
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++) {
+                    const double v = wave_allreduce(acc[k]);
+                    if (lane == c) Sl[k] = v;
+                }
+            }
+DSQ_UNROLL_P
+            for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                for (int b = a; b < P; b++)
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) B[k][a][b] = 0.0;
+            for (int c = 0; c < C; c++) {
+                const int j0 = cperm[cstart[c]];
+                double sc[K];
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++) {
+                    const double xa = r.x(j0, a);
+DSQ_UNROLL_P
+                    for (int b = a; b < P; b++) {
+                        const double xb = r.x(j0, b);
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) B[k][a][b] = B[k][a][b] + xa * (xb * sc[k]);
+                    }
+                }
+            }
+DSQ_UNROLL_P
+            for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                for (int b = a; b < P; b++)
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) B[k][b][a] = B[k][a][b];
+            if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+DSQ_UNROLL_P
+                for (int c = 0; c < P; c++)
+                    if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+            }
+            return;
+        }
         if constexpr (P >= DSQ_WIDE_MIN) {
             // WIDE build: K * P(P+1)/2 per-lane running sums do not fit in registers, and as a dynamically indexed
             // array they would live in scratch memory.  Two matrix rows per pass over the samples instead, the pass loop
@@ -498,6 +569,9 @@ __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
     return stage ? (size_t)m * (USE_W ? 3 : 2) + half + dist : dist;
 }
 
+// block-shared design-cell lists (int32: cell_start[DSQ_CMAX + 2] | cell_perm[m]) behind everything else
+__host__ __device__ inline size_t disp_cell_doubles(int m, int ncell) { return ncell > 0 ? ((size_t)m + DSQ_CMAX + 3) / 2 : 0; }
+
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
     return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true) + (size_t)waves * disp_arena_doubles(p);
@@ -529,14 +603,22 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     double *slab = smem + xoff + (size_t)wave * slab_d;
     // WIDE build: the work-matrix arena sits behind the slabs
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P);
+    // design cells: lists in block-shared LDS behind the slabs and arenas
+    int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P)));
+    int32_t *cperm_s = cstart_s + DSQ_CMAX + 2;
+    const int C = (kp.p >= DSQ_DISP_CELL_MINP) ? kp.ncell : 0;
+    if (C > 0) {
+        for (int t = threadIdx.x; t <= C; t += blockDim.x) cstart_s[t] = kp.cell_start[t];
+        for (int t = threadIdx.x; t < m; t += blockDim.x) cperm_s[t] = kp.cell_perm[t];
+    }
     if constexpr (STAGE) {
         if (kp.xlds) {
             for (int t = threadIdx.x; t < P * m; t += blockDim.x) smem[t] = kp.x[t];
-            __syncthreads();
         } else {
             xs = kp.x;
         }
     }
+    if (C > 0 || (STAGE && kp.xlds)) __syncthreads();
 
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
         const int g = DSQ_GENE(kp, wi);
@@ -573,6 +655,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.padmask = kp.padmask;
         G.arena = arena;
         G.arena_off = 0;
+        G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
         G.build_distinct(dist);
         G.setup_cr();
 
@@ -664,7 +747,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
-            size_t need = disp_lds_doubles<USE_W>(kp.m, P, w, xl) * sizeof(double);
+            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell)) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
             const int wcap = 4 * (DSQ_DISP_MINW);     // waves per CU the register budget of this build admits
@@ -677,10 +760,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
     const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P)) * sizeof(double);
+    const size_t cell_bytes = disp_cell_doubles(kp.m, kp.ncell) * sizeof(double);
     if (!stage)
-        while (waves > 1 && (size_t)waves * unstaged_wave > budget) waves >>= 1;
-    size_t lds = stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
-                       : (size_t)waves * unstaged_wave;   // unstaged: the distinct-count buffer + the WIDE arena
+        while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
+    size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
+                        : (size_t)waves * unstaged_wave) + cell_bytes;   // unstaged: distinct-count buffer + WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter

@@ -516,7 +516,7 @@ class DeviceEngine:
         la, pm = dv[:n], dv[n:]
         r = self._timed("fit_disp", n, lambda: self.native.fitDisp_dev(
             y, x, mu_hat, la, pm, prior_sigmasq, min_log_alpha, kappa_0, tol, maxit, usePrior, weights, useWeights,
-            weightThreshold, useCR, want_d2lp=self.want_d2lp))
+            weightThreshold, useCR, want_d2lp=self.want_d2lp, cells=self._cells.get(x.data_ptr())))
         def fetch():
             h = self._host(r.pop("_pack"))               # one copy; the views below index the host buffer
             keys = ("log_alpha", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp", "last_d2lp")
@@ -532,5 +532,6 @@ class DeviceEngine:
         pm = self._vec(np.broadcast_to(np.asarray(prior_mean, float), (n,)))
         gv = self._vec(disp_grid)
         r = self._timed("fit_disp_grid", n, lambda: self.native.fitDispGrid_dev(
-            y, x, mu_hat, gv, pm, prior_sigmasq, usePrior, weights, useWeights, weightThreshold, useCR))
+            y, x, mu_hat, gv, pm, prior_sigmasq, usePrior, weights, useWeights, weightThreshold, useCR,
+            cells=self._cells.get(x.data_ptr())))
         return {"log_alpha": self._host(r["log_alpha"]).numpy()}

@@ -389,7 +389,7 @@ def fitBeta_dev(y, x, nf, alpha_hat, contrast, beta_mat, lambda_, weights, useWe
 
 
 def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_sigmasq, min_log_alpha,
-                kappa_0, tol, maxit, usePrior, weights, useWeights, weightThreshold, useCR, want_d2lp=True):
+                kappa_0, tol, maxit, usePrior, weights, useWeights, weightThreshold, useCR, want_d2lp=True, cells=None):
     import torch
     assert isinstance(y, GeneMajor) and isinstance(mu_hat, GeneMajor) and mu_hat.ld == y.ld
     n, m, ld = y.n, y.m, y.ld
@@ -410,7 +410,9 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
                          min_log_alpha=float(min_log_alpha), kappa_0=float(kappa_0), tol=float(tol),
                          maxit=int(maxit), usePrior=int(bool(usePrior)),
                          weights=_t_ptr(weights.t) if useWeights else None, useWeights=int(bool(useWeights)),
-                         weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
+                         weightThreshold=float(weightThreshold), useCR=int(bool(useCR)),
+                         cell_of=_ptr(cells) if cells is not None else None,
+                         ncell=(int(cells.max()) + 1) if cells is not None else 0)
     o = L.DsqFitDispOut(**{k: _t_ptr(v) for k, v in out.items()})
     L.check(L.lib().dsq_fit_disp_dev(C.byref(a), C.byref(o), _stream()))
     out = {k: v for k, v in out.items() if v is not None}
@@ -419,7 +421,7 @@ def fitDisp_dev(y, x, mu_hat, log_alpha, log_alpha_prior_mean, log_alpha_prior_s
 
 
 def fitDispGrid_dev(y, x, mu_hat, disp_grid, log_alpha_prior_mean, log_alpha_prior_sigmasq, usePrior, weights,
-                    useWeights, weightThreshold, useCR):
+                    useWeights, weightThreshold, useCR, cells=None):
     import torch
     assert isinstance(y, GeneMajor) and isinstance(mu_hat, GeneMajor) and mu_hat.ld == y.ld
     n, m, ld = y.n, y.m, y.ld
@@ -431,7 +433,9 @@ def fitDispGrid_dev(y, x, mu_hat, disp_grid, log_alpha_prior_mean, log_alpha_pri
                              log_alpha_prior_mean=_t_ptr(log_alpha_prior_mean),
                              log_alpha_prior_sigmasq=float(log_alpha_prior_sigmasq), usePrior=int(bool(usePrior)),
                              weights=_t_ptr(weights.t) if useWeights else None, useWeights=int(bool(useWeights)),
-                             weightThreshold=float(weightThreshold), useCR=int(bool(useCR)))
+                             weightThreshold=float(weightThreshold), useCR=int(bool(useCR)),
+                             cell_of=_ptr(cells) if cells is not None else None,
+                             ncell=(int(cells.max()) + 1) if cells is not None else 0)
     o = L.DsqFitDispGridOut(log_alpha=_t_ptr(la))
     L.check(L.lib().dsq_fit_disp_grid_dev(C.byref(a), C.byref(o), _stream()))
     return {"log_alpha": la}

@@ -131,6 +131,8 @@ typedef struct {
     int32_t useWeights;
     double weightThreshold;
     int32_t useCR;
+    const int32_t *cell_of;             /* extension: design cells, as in DsqFitBetaArgs (HOST, may be NULL)   */
+    int32_t ncell;
 } DsqFitDispArgs;
 
 typedef struct {
@@ -170,6 +172,8 @@ typedef struct {
     int32_t useWeights;
     double weightThreshold;
     int32_t useCR;
+    const int32_t *cell_of;             /* extension: design cells (HOST, may be NULL)                         */
+    int32_t ncell;
 } DsqFitDispGridArgs;
 
 typedef struct {

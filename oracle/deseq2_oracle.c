@@ -154,6 +154,14 @@ static double trace_prod(int q, const double *a, const double *b) {
     return acc;
 }
 
+#define ORC_CMAX 32
+/* which designs take the cell-collapsed paths (the engine's rule): fitBeta with at most 10 columns (the
+ * register-resident kernels), the Cox-Reid matrices of fitDisp from 5 columns up (below that the per-sample
+ * accumulation of the p(p+1)/2 <= 10 entries is cheaper than the per-cell passes) */
+#define ORC_BETA_CELL_MAXP 10
+#define ORC_DISP_CELL_MINP 5
+static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc);
+
 /* ------------------------------------------------ one gene's row context ---- */
 typedef struct {
     int m, p;
@@ -174,6 +182,10 @@ typedef struct {
      * value (see log_posterior).  NULL with observation weights. */
     int nv;
     const double *dv, *dc;
+    /* design cells (0 = general path): the Cox-Reid matrices X' diag(wd) X are assembled from per-cell sums of wd */
+    int C;
+    const int *cperm, *cstart;
+    const double *xc;
 } gene_t;
 
 static int cmp_count(const void *a, const void *b) {
@@ -219,6 +231,29 @@ static void gene_setup_cr(gene_t *g, unsigned char *rowbuf) {
  * term = x_ja * (x_jb * wd_j)   (b = x.t() * (x.each_col() % w_diag), :45,83,129) */
 static void cr_gram(const gene_t *g, const double *wd, double *B) {
     int q = g->q, m = g->m;
+    if (g->C > 0) {
+        /* CELL MODE: every sample of a cell has the same design row x_c, so X' diag(wd) X = sum_c S_c x_c x_c' with
+         * S_c = sum of wd over the kept samples of the cell (wave order over the rank inside the cell), the outer
+         * products added serially in cell order */
+        double S[ORC_CMAX];
+        for (int c = 0; c < g->C; c++) {
+            wsum_t s; wsum_init(&s, g->serial);
+            for (int k = g->cstart[c]; k < g->cstart[c + 1]; k++) {
+                int j = g->cperm[k];
+                if (g->keeprow && !g->keeprow[j]) continue;
+                wsum_add(&s, k - g->cstart[c], wd[j]);
+            }
+            S[c] = wsum_total(&s);
+        }
+        for (int a = 0; a < q; a++)
+            for (int b = a; b < q; b++) {
+                double v = 0.0;
+                for (int c = 0; c < g->C; c++)
+                    v += g->xc[c * g->p + g->keepcol[a]] * (g->xc[c * g->p + g->keepcol[b]] * S[c]);
+                B[a * q + b] = v; B[b * q + a] = v;
+            }
+        return;
+    }
     for (int a = 0; a < q; a++)
         for (int b = a; b < q; b++) {
             const double *xa = g->x + (long)m * g->keepcol[a];
@@ -395,9 +430,12 @@ int orc_fit_disp(int n, int m, int p,
                  const double *weights, int useWeights, double weightThreshold, int useCR,
                  double *log_alpha_out, int *iter, int *iter_accept, double *last_change,
                  double *initial_lp, double *initial_dlp, double *last_lp,
-                 double *last_dlp, double *last_d2lp, int sum_mode) {
+                 double *last_dlp, double *last_d2lp, int sum_mode, int cell_mode) {
     if (p > ORC_PMAX) return -1;
     const double epsilon = 1.0e-4;                                               /* :175 */
+    int *cperm = malloc(sizeof(int) * (m > 0 ? m : 1)), cstart[ORC_CMAX + 1];
+    double *xc = malloc(sizeof(double) * ORC_CMAX * ORC_PMAX);
+    const int C = (cell_mode && p >= ORC_DISP_CELL_MINP) ? design_cells(m, p, x, ORC_CMAX, cperm, cstart, xc) : 0;
 #pragma omp parallel
     {
     double *yrow = malloc(sizeof(double) * m), *murow = malloc(sizeof(double) * m);
@@ -415,6 +453,7 @@ int orc_fit_disp(int n, int m, int p,
         g.prior_mean = log_alpha_prior_mean[i]; g.prior_sigmasq = log_alpha_prior_sigmasq;
         g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
         g.weightThreshold = weightThreshold; g.serial = sum_mode;
+        g.C = C; g.cperm = cperm; g.cstart = cstart; g.xc = xc;
         gene_setup_cr(&g, rowbuf);
         gene_setup_distinct(&g, vbuf, cbuf);
         double a = log_alpha_in[i];                                              /* :201 */
@@ -453,6 +492,7 @@ int orc_fit_disp(int n, int m, int p,
     }
     free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(vbuf); free(cbuf);
     }
+    free(cperm); free(xc);
     return 0;
 }
 
@@ -463,9 +503,12 @@ int orc_fit_disp_grid(int n, int m, int p,
                       const double *disp_grid, int ngrid,
                       const double *log_alpha_prior_mean, double log_alpha_prior_sigmasq,
                       int usePrior, const double *weights, int useWeights,
-                      double weightThreshold, int useCR, double *log_alpha_out, int sum_mode) {
+                      double weightThreshold, int useCR, double *log_alpha_out, int sum_mode, int cell_mode) {
     if (p > ORC_PMAX || ngrid < 2 || ngrid > 1024) return -1;
     double delta = disp_grid[1] - disp_grid[0];                                  /* :480 */
+    int *cperm = malloc(sizeof(int) * (m > 0 ? m : 1)), cstart[ORC_CMAX + 1];
+    double *xc = malloc(sizeof(double) * ORC_CMAX * ORC_PMAX);
+    const int C = (cell_mode && p >= ORC_DISP_CELL_MINP) ? design_cells(m, p, x, ORC_CMAX, cperm, cstart, xc) : 0;
 #pragma omp parallel
     {
     double *yrow = malloc(sizeof(double) * m), *murow = malloc(sizeof(double) * m);
@@ -484,6 +527,7 @@ int orc_fit_disp_grid(int n, int m, int p,
         g.prior_mean = log_alpha_prior_mean[i]; g.prior_sigmasq = log_alpha_prior_sigmasq;
         g.usePrior = usePrior; g.useWeights = useWeights; g.useCR = useCR;
         g.weightThreshold = weightThreshold; g.serial = sum_mode;
+        g.C = C; g.cperm = cperm; g.cstart = cstart; g.xc = xc;
         gene_setup_cr(&g, rowbuf);
         gene_setup_distinct(&g, vbuf, cbuf);
         for (int t = 0; t < ngrid; t++) lpv[t] = log_posterior(disp_grid[t], &g, scratch);  /* :496-500 */
@@ -503,6 +547,7 @@ int orc_fit_disp_grid(int n, int m, int p,
     }
     free(yrow); free(murow); free(wrow); free(scratch); free(rowbuf); free(lpv); free(fine); free(vbuf); free(cbuf);
     }
+    free(cperm); free(xc);
     return 0;
 }
 
@@ -512,7 +557,6 @@ int orc_fit_disp_grid(int n, int m, int p,
  * appearance; xc[c*p + k] is the row of cell c; perm lists the samples grouped by cell (ascending sample index
  * inside a cell), start[c] .. start[c+1] the members of cell c.  Returns the number of cells, or 0 when there are
  * more than cmax (the callers then take the general per-sample path).                                           */
-#define ORC_CMAX 32
 static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc) {
     int *cell_of = malloc(sizeof(int) * (m > 0 ? m : 1));
     int C = 0;
@@ -754,7 +798,7 @@ int orc_fit_beta(int n, int m, int p,
     const double large = 30.0;                                                   /* :316 */
     int *cperm = malloc(sizeof(int) * (m > 0 ? m : 1)), cstart[ORC_CMAX + 1];
     double *xc = malloc(sizeof(double) * ORC_CMAX * ORC_PMAX);
-    const int C = cell_mode ? design_cells(m, p, x, ORC_CMAX, cperm, cstart, xc) : 0;
+    const int C = (cell_mode && p <= ORC_BETA_CELL_MAXP) ? design_cells(m, p, x, ORC_CMAX, cperm, cstart, xc) : 0;
 #pragma omp parallel
     {
     int M = m + p;

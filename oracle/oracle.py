@@ -85,7 +85,7 @@ def set_threads(k):
 def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP,
             log_alpha_prior_sigmasqSEXP, min_log_alphaSEXP, kappa_0SEXP, tolSEXP, maxitSEXP,
             usePriorSEXP, weightsSEXP, useWeightsSEXP, weightThresholdSEXP, useCRSEXP,
-            sum_mode=0):
+            sum_mode=0, cell_mode=1):
     y = _f(ySEXP); x = _f(xSEXP); mu = _f(mu_hatSEXP); w = _f(weightsSEXP)
     n, m = y.shape; p = x.shape[1]
     assert x.shape[0] == m and mu.shape == (n, m) and w.shape == (n, m)
@@ -102,7 +102,7 @@ def fitDisp(ySEXP, xSEXP, mu_hatSEXP, log_alphaSEXP, log_alpha_prior_meanSEXP,
         ctypes.c_double(float(weightThresholdSEXP)), ctypes.c_int(int(bool(useCRSEXP))),
         _p(out["log_alpha"]), _p(it), _p(ita), _p(out["last_change"]), _p(out["initial_lp"]),
         _p(out["initial_dlp"]), _p(out["last_lp"]), _p(out["last_dlp"]), _p(out["last_d2lp"]),
-        ctypes.c_int(sum_mode))
+        ctypes.c_int(sum_mode), ctypes.c_int(int(cell_mode)))
     if rc != 0:
         raise RuntimeError("orc_fit_disp failed: %d" % rc)
     out["iter"] = it; out["iter_accept"] = ita
@@ -155,7 +155,7 @@ def fittedMu(xSEXP, nfSEXP, beta_mat, mu_floor=0.0):
 
 def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEXP,
                 log_alpha_prior_sigmasqSEXP, usePriorSEXP, weightsSEXP, useWeightsSEXP,
-                weightThresholdSEXP, useCRSEXP, sum_mode=0):
+                weightThresholdSEXP, useCRSEXP, sum_mode=0, cell_mode=1):
     y = _f(ySEXP); x = _f(xSEXP); mu = _f(mu_hatSEXP); w = _f(weightsSEXP)
     n, m = y.shape; p = x.shape[1]
     grid = np.ascontiguousarray(disp_gridSEXP, dtype=np.float64)
@@ -166,7 +166,7 @@ def fitDispGrid(ySEXP, xSEXP, mu_hatSEXP, disp_gridSEXP, log_alpha_prior_meanSEX
         ctypes.c_int(grid.size), _p(pm), ctypes.c_double(float(log_alpha_prior_sigmasqSEXP)),
         ctypes.c_int(int(bool(usePriorSEXP))), _p(w), ctypes.c_int(int(bool(useWeightsSEXP))),
         ctypes.c_double(float(weightThresholdSEXP)), ctypes.c_int(int(bool(useCRSEXP))), _p(la),
-        ctypes.c_int(sum_mode))
+        ctypes.c_int(sum_mode), ctypes.c_int(int(cell_mode)))
     if rc != 0:
         raise RuntimeError("orc_fit_disp_grid failed: %d" % rc)
     return {"log_alpha": la}

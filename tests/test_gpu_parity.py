@@ -73,6 +73,26 @@ def test_fit_beta_general_path_matches_oracle(oracle, n, m, base, useW, useQR):
     assert_same(want["iter"], want0["iter"], "more than 32 cells = the general path")
 
 
+@pytest.mark.parametrize("n,m,base,useW", [(200, 100, "two_group", False), (150, 500, "batch_condition", False),
+                                            (150, 70, ("factor", 6), True), (40, 1500, "batch_condition", False)])
+def test_fit_disp_general_path_matches_oracle(oracle, n, m, base, useW):
+    """a continuous covariate (one design cell per sample): the per-sample Cox-Reid Gram accumulation"""
+    from deseq2_amd import native
+    d = make_case(n, m, base, seed=6, weights=useW)
+    rng = np.random.default_rng(m + 1)
+    x = np.column_stack([d["x"], rng.normal(0.0, 0.3, m)])
+    mu = np.maximum(d["nf"] * np.exp(d["beta_init"] @ d["x"].T), 0.5)
+    w = np.maximum(d["weights"], 1e-6)
+    la0 = np.log(d["alpha_init"])
+    args = (d["counts"], x, mu, la0, la0 + 0.2, 0.8, np.log(1e-8 / 10), 1.0, 1e-6, 100, True, w, useW, 1e-2, True)
+    got, want = native.fitDisp(*args), oracle.fitDisp(*args)
+    for k in DISP_KEYS:
+        assert_same(got[k], want[k], "fitDisp(general)$" + k)
+    grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 20)
+    gargs = (d["counts"][:24], x, mu[:24], grid, la0[:24], 1.0, True, w[:24], useW, 1e-2, True)
+    assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"], "fitDispGrid(general)")
+
+
 @pytest.mark.parametrize("n,m,design,useW", [(500, 100, "two_group", False), (300, 500, "batch_condition", False),
                                               (300, 200, "two_group", True), (600, 6, "two_group", False),
                                               (200, 70, ("factor", 6), True), (100, 130, ("factor", 10), False),
