@@ -43,40 +43,43 @@ __global__ void __launch_bounds__(1024) compact_kernel(int mode, int n, int32_t 
                                                        const double *mean_in, const double *disp_in, double thresh,
                                                        int32_t *rows_out, double *mean_out, double *disp_out,
                                                        int32_t *count_out) {
-    __shared__ int cnt[1024];
-    const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    int c = 0;
-    for (int i = lo; i < hi; i++) {
-        bool keep;
-        if (mode == 0) {
-            int z = allZero[i] | (force_zero ? force_zero[i] : 0);
-            if (force_zero) allZero[i] = z ? 1 : 0;
-            keep = !z;
-        } else {
-            keep = disp_in[i] > thresh;
-        }
-        c += keep ? 1 : 0;
-    }
-    cnt[t] = c;
+    // tiles of 1024 consecutive elements (coalesced), kept elements ranked by wave ballots + a 16-entry prefix
+    __shared__ int wcnt[16];
+    __shared__ int base_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base_s = 0;
     __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int k = 0; k < 1024; k++) { int v = cnt[k]; cnt[k] = run; run += v; }
-        *count_out = run;
-    }
-    __syncthreads();
-    int o = cnt[t];
-    for (int i = lo; i < hi; i++) {
-        if (mode == 0) {
-            if (!allZero[i]) rows_out[o++] = i;
-        } else if (disp_in[i] > thresh) {
-            mean_out[o] = mean_in[i];
-            disp_out[o] = disp_in[i];
-            o++;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        bool keep = false;
+        if (i < n) {
+            if (mode == 0) {
+                int z = allZero[i] | (force_zero ? force_zero[i] : 0);
+                if (force_zero) allZero[i] = z ? 1 : 0;
+                keep = !z;
+            } else {
+                keep = disp_in[i] > thresh;
+            }
         }
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        off += __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) {
+            if (mode == 0) rows_out[off] = i;
+            else { mean_out[off] = mean_in[i]; disp_out[off] = disp_in[i]; }
+        }
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wcnt[w];
+            base_s += tot;
+        }
+        __syncthreads();
     }
+    if (t == 0) *count_out = base_s;
 }
 
 // ---- stats::mad of the log dispersion residuals + the prior variance (R/methods.R:172-181, R/core.R:1135-1208) ----
@@ -93,29 +96,47 @@ DSQ_DEV double double_of(uint64_t k) {
 
 template <class F>
 DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc) {
-    // the rank-th smallest (0-based) of value(i), i < n; every thread returns it
+    // the rank-th smallest (0-based) of value(i), i < n; every thread returns it.  Digits of 11, 11, 11, 11, 11, 9 bits.
     uint64_t prefix = 0, mask = 0;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    int shift = 64;
+    while (shift > 0) {
+        const int bits = shift >= 11 + 9 ? 11 : shift;         // 64 = 5 x 11 + 9
+        shift -= bits;
+        const unsigned nb = 1u << bits;
+        for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             uint64_t k = key_of(value(i));
-            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & (nb - 1u)], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        // the digit whose cumulative count passes `rank`: one wave scans the bins, 64 at a time
+        if (threadIdx.x < 64) {
             long r = rank;
-            int d = 0;
-            for (; d < 255; d++) {
-                if (r < (long)hist[d]) break;
-                r -= (long)hist[d];
+            int found = -1;
+            for (unsigned b0 = 0; b0 < nb && found < 0; b0 += 64) {
+                const unsigned h = hist[b0 + threadIdx.x];
+                unsigned incl = h;                              // inclusive prefix over the 64 lanes
+                for (int o = 1; o < 64; o <<= 1) {
+                    unsigned v = __shfl_up(incl, o, 64);
+                    if ((int)threadIdx.x >= o) incl += v;
+                }
+                const unsigned tot = __shfl(incl, 63, 64);
+                if (r < (long)tot) {
+                    const unsigned long long m = __ballot((long)incl > r);
+                    const int l = __ffsll((long long)m) - 1;
+                    const unsigned before = __shfl(incl, l, 64) - __shfl(h, l, 64);
+                    found = (int)b0 + l;
+                    r -= (long)before;
+                } else {
+                    r -= (long)tot;
+                }
             }
-            bc[0] = (unsigned long long)d;
-            bc[1] = (unsigned long long)r;
+            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; }
         }
         __syncthreads();
         prefix |= (uint64_t)bc[0] << shift;
-        mask |= (uint64_t)255 << shift;
+        mask |= (uint64_t)(nb - 1u) << shift;
         rank = (long)bc[1];
         __syncthreads();
     }
@@ -124,17 +145,31 @@ DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigne
 
 template <class F>
 DSQ_DEV double block_median(int n, long k, F &&value, unsigned *hist, unsigned long long *bc) {
-    // numpy.median of the k smallest-ranked (finite) values: invalid entries are +inf and sort last
-    if (k & 1) return block_select(n, k / 2, value, hist, bc);
-    double a = block_select(n, k / 2 - 1, value, hist, bc);
-    double b = block_select(n, k / 2, value, hist, bc);
+    // numpy.median of the k finite values (invalid entries are +inf and sort last): the lower middle order statistic
+    // by selection; for an even count the next one is either the same value (a tie) or the smallest value above it
+    const double a = block_select(n, (k - 1) / 2, value, hist, bc);
+    if (k & 1) return a;
+    __syncthreads();
+    if (threadIdx.x == 0) { bc[0] = 0ull; bc[1] = key_of(__builtin_inf()); }
+    __syncthreads();
+    unsigned long long le = 0, mn = key_of(__builtin_inf());
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = value(i);
+        if (v <= a) le++;
+        else { const unsigned long long kv = key_of(v); if (kv < mn) mn = kv; }
+    }
+    atomicAdd(&bc[0], le);
+    atomicMin(&bc[1], mn);
+    __syncthreads();
+    const double b = ((long)bc[0] > k / 2) ? a : double_of(bc[1]);
+    __syncthreads();
     return (a + b) * 0.5;
 }
 
 __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, const double *disp, int n, double minDisp,
                                                          double expVarLogDisp, int m_gt_p, double *resbuf,
                                                          double *scalars, int32_t *status) {
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[2048];
     __shared__ unsigned long long bc[2];
     __shared__ int kshared;
     const double inf = __builtin_inf();
