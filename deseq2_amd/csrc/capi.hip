@@ -12,8 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace dsq {
@@ -88,8 +91,10 @@ static void prof_clear() {
     for (auto &p : g_prof_list) { g_prof_free.push_back(p.e0); g_prof_free.push_back(p.e1); }
     g_prof_list.clear();
 }
+static std::mutex g_prof_mu;
 void capi_prof_begin(const char *name, int n, hipStream_t st) {
     if (!g_prof) return;
+    std::lock_guard<std::mutex> plk(g_prof_mu);
     ProfEntry p;
     snprintf(p.name, sizeof p.name, "%s", name);
     p.n = n; p.e0 = prof_event(); p.e1 = prof_event();
@@ -97,7 +102,9 @@ void capi_prof_begin(const char *name, int n, hipStream_t st) {
     g_prof_list.push_back(p);
 }
 void capi_prof_end(hipStream_t st) {
-    if (!g_prof || g_prof_list.empty()) return;
+    if (!g_prof) return;
+    std::lock_guard<std::mutex> plk(g_prof_mu);
+    if (g_prof_list.empty()) return;
     (void)hipEventRecord(g_prof_list.back().e1, st);
 }
 static void prof_begin(hipStream_t st) { capi_prof_begin("call", 0, st); }
@@ -108,8 +115,10 @@ static void prof_end(hipStream_t st) { capi_prof_end(st); }
 // deseq2_amd/parallel.py) must not share scratch, counters or staging buffers while both are in flight.
 // The stream of the current API call is latched at entry (WsScope, under g_mu).
 struct Slot { void *p = nullptr; size_t bytes = 0; };
+static constexpr int WS_SLOTS_MAX = DSQ_WS_COUNT;
 static std::map<hipStream_t, std::vector<Slot>> g_pool[64];
-static hipStream_t g_ws_stream = nullptr;
+static std::mutex g_pool_mu;      // the maps themselves (worker threads of a multi-device call look their slots up concurrently)
+static thread_local hipStream_t g_ws_stream = nullptr;
 struct WsScope { explicit WsScope(hipStream_t s) { g_ws_stream = s; } };
 std::mutex &capi_mutex() { return g_mu; }
 void capi_latch_stream(hipStream_t s) { g_ws_stream = s; }
@@ -118,9 +127,11 @@ static int ws_get(int slot, size_t bytes, void **out) {
     int dev = 0;
     DSQ_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(DSQ_ERR_DEVICE, "device index %d out of range", dev);
+    std::unique_lock<std::mutex> plk(g_pool_mu);
     auto &pool = g_pool[dev][g_ws_stream];
-    if ((int)pool.size() <= slot) pool.resize(slot + 1);
+    if ((int)pool.size() < WS_SLOTS_MAX) pool.resize(WS_SLOTS_MAX);     // never reallocated afterwards: `s` stays valid
     Slot &s = pool[slot];
+    plk.unlock();
     if (s.bytes < bytes) {
         if (s.p) { DSQ_HIP(hipDeviceSynchronize()); DSQ_HIP(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
         size_t want = bytes + bytes / 8 + 256;
@@ -281,7 +292,7 @@ int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, co
                       const int32_t **start_dev) {
     *perm_dev = *start_dev = nullptr;
     if (!labels || !tuning().beta_cells) return 0;
-    static std::vector<int32_t> buf;                     // (under the library lock)
+    static thread_local std::vector<int32_t> buf;
     std::map<int32_t, int> id;
     std::vector<int> cell(m);
     int C = 0;
@@ -375,7 +386,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     if (wide) {
         unsigned padmask;
         rc = wide_pad_x(a->m, a->p, a->x, st, &kp.x, &padmask); if (rc) return rc;
-        static double ones[DSQ_P_WIDE];
+        static thread_local double ones[DSQ_P_WIDE];
         for (int c = 0; c < DSQ_P_WIDE; c++) ones[c] = 1.0;
         void *v;
         rc = ws_get(WS_PAD_VEC, 2 * DSQ_P_WIDE * sizeof(double), &v); if (rc) return rc;
@@ -707,7 +718,7 @@ static int cooks_dev_locked(const DsqCooksArgs *a, const DsqCooksOut *o, hipStre
     if (a->layout == DSQ_LAYOUT_GENE_MAJOR && a->ld < a->m) return fail(DSQ_ERR_ARG, "ld < m");
     const int m = a->m;
     // design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags
-    static std::vector<int32_t> meta;
+    static thread_local std::vector<int32_t> meta;
     meta.assign((size_t)2 * m + a->ncell + 1, 0);
     int32_t *perm = meta.data(), *in3 = perm + m, *start = in3 + m;
     for (int j = 0; j < m; j++) {
@@ -784,7 +795,7 @@ static int replace_dev_locked(const DsqReplaceArgs *a, const DsqReplaceOut *o, h
     if (kp.nf_is_vector) kp.nf = a->nf;
     else { rc = prep_matrix(a->nf, a->layout, a->ld, a->n, m, WS_NF, st, &kp.nf, ld); if (rc) return rc; }
     rc = prep_matrix(a->cooks, a->layout, a->ld, a->n, m, WS_COOKS_IN, st, &kp.cooks, ld); if (rc) return rc;
-    static std::vector<int32_t> flags;
+    static thread_local std::vector<int32_t> flags;
     flags.assign(a->replaceable, a->replaceable + m);
     void *v;
     rc = ws_get(WS_CELLS, (size_t)m * sizeof(int32_t), &v); if (rc) return rc;
@@ -929,6 +940,259 @@ int dsq_from_gene_major_f64(const double *src_gm, double *dst_r, int32_t n, int3
 
 // ------------------------------------------------------------ host-pointer entries
 // (what src/r_shim.c binds: R memory in, R memory out, synchronous)
+//
+// Genes are independent inside every native routine (src/DESeq2.cpp:194,319,492) and the reference's only parallelism
+// splits them into contiguous ranges (R/parallel.R:10).  The host-pointer entry points do the same INSIDE the library:
+// [0, n) is cut into one range per visible device (idx <- sort(rep(seq_len(G), length.out = n))), each range is
+// uploaded / fitted / downloaded by a persistent worker thread bound to its device and its own stream, so an
+// unchanged R session calling .Call("fitBeta", ...) uses every GPU of the node.  DSQ_HOST_DEVICES caps the number
+// of devices, DSQ_HOST_SHARDS forces a number of ranges (ranges beyond the device count share devices: used by the
+// tests to exercise the split on one GPU).
+} // extern "C"
+
+namespace dsq {
+
+// rows [lo, lo + cnt) of a column-major n x cols host matrix <-> a column-major cnt x cols device matrix
+static int up_rows(int slot, const void *host, size_t elem, size_t n, size_t lo, size_t cnt, size_t cols, hipStream_t st,
+                   void **dev) {
+    int rc = ws_get(slot, cnt * cols * elem ? cnt * cols * elem : 8, dev);
+    if (rc) return rc;
+    if (!cnt || !cols) return DSQ_OK;
+    if (cnt == n) DSQ_HIP(hipMemcpyAsync(*dev, host, n * cols * elem, hipMemcpyHostToDevice, st));
+    else DSQ_HIP(hipMemcpy2DAsync(*dev, cnt * elem, (const char *)host + lo * elem, n * elem, cnt * elem, cols,
+                                  hipMemcpyHostToDevice, st));
+    return DSQ_OK;
+}
+static int down_rows(void *host, const void *dev, size_t elem, size_t n, size_t lo, size_t cnt, size_t cols, hipStream_t st) {
+    if (!cnt || !cols) return DSQ_OK;
+    if (cnt == n) DSQ_HIP(hipMemcpyAsync(host, dev, n * cols * elem, hipMemcpyDeviceToHost, st));
+    else DSQ_HIP(hipMemcpy2DAsync((char *)host + lo * elem, n * elem, dev, cnt * elem, cnt * elem, cols,
+                                  hipMemcpyDeviceToHost, st));
+    return DSQ_OK;
+}
+
+static int fit_beta_host_range(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, size_t lo, size_t cnt, hipStream_t st,
+                               const int32_t *cells, int ncell) {
+    const size_t n = a->n, m = a->m, p = a->p;
+    const size_t ye = a->y_type == DSQ_Y_INT32 ? 4 : 8;
+    DsqFitBetaArgs d = *a;
+    DsqFitBetaOut od = *o;
+    d.n = (int32_t)cnt;
+    d.cell_of = cells; d.ncell = ncell;
+    void *v;
+    int rc;
+    if ((rc = up_rows(WS_H_Y, a->y, ye, n, lo, cnt, m, st, &v))) return rc; d.y = v;
+    // x, alpha_hat, contrast, beta_mat, lambda share one staging buffer
+    size_t off_x = 0, off_alpha = off_x + m * p, off_con = off_alpha + cnt, off_beta = off_con + p,
+           off_lam = off_beta + cnt * p, tot = off_lam + p;
+    if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec + off_x, a->x, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_alpha, a->alpha_hat + lo, cnt * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_con, a->contrast, p * 8, hipMemcpyHostToDevice, st));
+    if (cnt == n) DSQ_HIP(hipMemcpyAsync(vec + off_beta, a->beta_mat, n * p * 8, hipMemcpyHostToDevice, st));
+    else DSQ_HIP(hipMemcpy2DAsync(vec + off_beta, cnt * 8, a->beta_mat + lo, n * 8, cnt * 8, p, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_lam, a->lambda, p * 8, hipMemcpyHostToDevice, st));
+    d.x = vec + off_x; d.alpha_hat = vec + off_alpha; d.contrast = vec + off_con; d.beta_mat = vec + off_beta;
+    d.lambda = vec + off_lam;
+    if (a->nf_is_vector) { if ((rc = up_rows(WS_H_NF, a->nf, 8, m, 0, m, 1, st, &v))) return rc; }
+    else if ((rc = up_rows(WS_H_NF, a->nf, 8, n, lo, cnt, m, st, &v))) return rc;
+    d.nf = (double *)v;
+    if (a->useWeights) { if ((rc = up_rows(WS_H_W, a->weights, 8, n, lo, cnt, m, st, &v))) return rc; d.weights = (double *)v; }
+    else d.weights = nullptr;
+    // outputs
+    size_t o_beta = 0, o_var = o_beta + cnt * p, o_iter = o_var + cnt * p, o_cn = o_iter + cnt, o_cd = o_cn + cnt,
+           o_dev = o_cd + cnt, o_tot = o_dev + cnt;
+    if ((rc = ws_get(WS_H_OUTVEC, o_tot * 8, &v))) return rc;
+    double *ov = (double *)v;
+    od.beta_mat = ov + o_beta; od.beta_var_mat = ov + o_var; od.iter = ov + o_iter; od.contrast_num = ov + o_cn;
+    od.contrast_denom = ov + o_cd; od.deviance = ov + o_dev;
+    double *hat_d = nullptr, *mu_d = nullptr;
+    if (o->hat_diagonals) { if ((rc = ws_get(WS_H_OUTMAT, cnt * m * 8, &v))) return rc; hat_d = (double *)v; }
+    if (o->mu) { if ((rc = ws_get(WS_H_OUTMAT2, cnt * m * 8, &v))) return rc; mu_d = (double *)v; }
+    od.hat_diagonals = hat_d; od.mu = mu_d;
+    rc = fit_beta_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    if ((rc = down_rows(o->beta_mat, od.beta_mat, 8, n, lo, cnt, p, st))) return rc;
+    if ((rc = down_rows(o->beta_var_mat, od.beta_var_mat, 8, n, lo, cnt, p, st))) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->iter + lo, od.iter, cnt * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->contrast_num + lo, od.contrast_num, cnt * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->contrast_denom + lo, od.contrast_denom, cnt * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->deviance + lo, od.deviance, cnt * 8, hipMemcpyDeviceToHost, st));
+    if (hat_d && (rc = down_rows(o->hat_diagonals, hat_d, 8, n, lo, cnt, m, st))) return rc;
+    if (mu_d && (rc = down_rows(o->mu, mu_d, 8, n, lo, cnt, m, st))) return rc;
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+static int disp_host_stage(size_t n, size_t lo, size_t cnt, int m_, int p_, const void *y, int y_type, const double *x,
+                           const double *mu_hat, const double *weights, int useWeights, hipStream_t st, const void **yd,
+                           const double **xd, const double **mud, const double **wd) {
+    const size_t m = m_, p = p_;
+    void *v;
+    int rc;
+    if ((rc = up_rows(WS_H_Y, y, y_type == DSQ_Y_INT32 ? 4 : 8, n, lo, cnt, m, st, &v))) return rc; *yd = v;
+    if ((rc = up_rows(WS_H_X, x, 8, m, 0, m, p, st, &v))) return rc; *xd = (double *)v;
+    if ((rc = up_rows(WS_H_MU, mu_hat, 8, n, lo, cnt, m, st, &v))) return rc; *mud = (double *)v;
+    if (useWeights) { if ((rc = up_rows(WS_H_W, weights, 8, n, lo, cnt, m, st, &v))) return rc; *wd = (double *)v; }
+    else *wd = nullptr;
+    return DSQ_OK;
+}
+
+static int fit_disp_host_range(const DsqFitDispArgs *a, const DsqFitDispOut *o, size_t lo, size_t cnt, hipStream_t st,
+                               const int32_t *cells, int ncell) {
+    const size_t n = a->n;
+    DsqFitDispArgs d = *a;
+    DsqFitDispOut od = *o;
+    d.n = (int32_t)cnt;
+    d.cell_of = cells; d.ncell = ncell;
+    int rc = disp_host_stage(n, lo, cnt, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
+                             &d.y, &d.x, &d.mu_hat, &d.weights);
+    if (rc) return rc;
+    void *v;
+    if ((rc = ws_get(WS_H_VEC, 2 * cnt * 8 + 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha + lo, cnt * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + cnt, a->log_alpha_prior_mean + lo, cnt * 8, hipMemcpyHostToDevice, st));
+    d.log_alpha = vec; d.log_alpha_prior_mean = vec + cnt;
+    if ((rc = ws_get(WS_H_OUTVEC, 8 * cnt * 8 + 8, &v))) return rc;
+    double *ov = (double *)v;
+    od.log_alpha = ov; od.last_change = ov + cnt; od.initial_lp = ov + 2 * cnt; od.initial_dlp = ov + 3 * cnt;
+    od.last_lp = ov + 4 * cnt; od.last_dlp = ov + 5 * cnt; od.last_d2lp = ov + 6 * cnt;
+    od.iter = (int32_t *)(ov + 7 * cnt); od.iter_accept = od.iter + cnt;
+    rc = fit_disp_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    double *const dst[7] = {o->log_alpha, o->last_change, o->initial_lp, o->initial_dlp, o->last_lp, o->last_dlp, o->last_d2lp};
+    for (int k = 0; k < 7; k++) DSQ_HIP(hipMemcpyAsync(dst[k] + lo, ov + k * cnt, cnt * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->iter + lo, od.iter, cnt * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->iter_accept + lo, od.iter_accept, cnt * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+static int fit_disp_grid_host_range(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o, size_t lo, size_t cnt,
+                                    hipStream_t st, const int32_t *cells, int ncell) {
+    const size_t n = a->n, ng = a->ngrid;
+    DsqFitDispGridArgs d = *a;
+    DsqFitDispGridOut od = *o;
+    d.n = (int32_t)cnt;
+    d.cell_of = cells; d.ncell = ncell;
+    int rc = disp_host_stage(n, lo, cnt, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
+                             &d.y, &d.x, &d.mu_hat, &d.weights);
+    if (rc) return rc;
+    void *v;
+    if ((rc = ws_get(WS_H_VEC, (cnt + ng) * 8, &v))) return rc;
+    double *vec = (double *)v;
+    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha_prior_mean + lo, cnt * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + cnt, a->disp_grid, ng * 8, hipMemcpyHostToDevice, st));
+    d.log_alpha_prior_mean = vec; d.disp_grid = vec + cnt;
+    if ((rc = ws_get(WS_H_OUTVEC, cnt * 8 + 8, &v))) return rc;
+    od.log_alpha = (double *)v;
+    rc = fit_disp_grid_dev_locked(&d, &od, st);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(o->log_alpha + lo, od.log_alpha, cnt * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return DSQ_OK;
+}
+
+// ---- worker threads: one per (device, lane); each owns a stream and (through thread_local state) its workspaces ----
+struct HostWorker {
+    int dev = 0;
+    hipStream_t st = nullptr;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false;
+    int rc = 0;
+    char err[512] = "";
+    void loop() {
+        (void)hipSetDevice(dev);
+        (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return has_job; });
+            std::function<int()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            g_ws_stream = st;
+            int r = j();
+            lk.lock();
+            rc = r;
+            snprintf(err, sizeof err, "%s", g_err);
+            done = true;
+            cv.notify_all();
+        }
+    }
+};
+static std::vector<HostWorker *> g_workers;      // grown under g_mu; worker k serves device k % ndev
+
+static HostWorker *host_worker(int k, int ndev) {
+    while ((int)g_workers.size() <= k) {
+        HostWorker *w = new HostWorker();
+        w->dev = (int)g_workers.size() % ndev;
+        w->th = std::thread([w] { w->loop(); });
+        w->th.detach();
+        g_workers.push_back(w);
+    }
+    return g_workers[k];
+}
+
+// number of gene ranges of a host-pointer call over n genes, and the devices they go to
+static void host_plan(size_t n, int *nshards, int *ndev) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) cnt = 1;
+    const int cap = env_int("DSQ_HOST_DEVICES", 0);
+    if (cap > 0 && cap < cnt) cnt = cap;
+    int s = env_int("DSQ_HOST_SHARDS", 0);
+    if (s <= 0) s = cnt;
+    if ((size_t)s > n) s = (int)n;
+    if (s < 1) s = 1;
+    *nshards = s; *ndev = cnt;
+}
+
+// run f(lo, cnt, stream) over the ranges of R/parallel.R:10; one range: on the caller's thread, device and null stream
+template <class F>
+static int host_sharded(size_t n, F &&f) {
+    int S, ndev;
+    host_plan(n, &S, &ndev);
+    if (S <= 1) return f((size_t)0, n, (hipStream_t) nullptr);
+    std::vector<HostWorker *> ws(S);
+    const size_t big = n / S + 1, nbig = n % S, small = n / S;      // the first n %% S ranges hold one gene more
+    size_t lo = 0;
+    for (int k = 0; k < S; k++) {
+        const size_t cnt = (size_t)k < nbig ? big : small;
+        HostWorker *w = ws[k] = host_worker(k, ndev);
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->job = [&f, lo, cnt, w] { return f(lo, cnt, w->st); };
+            w->has_job = true; w->done = false;
+        }
+        w->cv.notify_all();
+        lo += cnt;
+    }
+    int rc = DSQ_OK;
+    for (int k = 0; k < S; k++) {
+        HostWorker *w = ws[k];
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc && !rc) { rc = w->rc; snprintf(g_err, sizeof g_err, "%s", w->err); }
+    }
+    return rc;
+}
+
+static void host_cells(const double *x, int m, int p, const int32_t *given, int ngiven, std::vector<int32_t> *labels,
+                       const int32_t **cells, int *ncell) {
+    *cells = given; *ncell = ngiven;
+    if (given) return;
+    cells_of_host_design(x, m, p, labels);          // R hands over the design matrix itself: find its cells here
+    if (!labels->empty()) { *cells = labels->data(); *ncell = 1 + *std::max_element(labels->begin(), labels->end()); }
+}
+
+}  // namespace dsq
+
+extern "C" {
+
 int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
@@ -942,71 +1206,12 @@ int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
         return fail(DSQ_ERR_ARG, "NULL output array");
     if (int rc = check_device()) return rc;
     if (a->n == 0) return DSQ_OK;
-    hipStream_t st = nullptr;
-    const size_t n = a->n, m = a->m, p = a->p;
-    const size_t ybytes = n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8);
-    DsqFitBetaArgs d = *a;
-    DsqFitBetaOut od = *o;
-    void *v;
-    int rc;
-    if ((rc = up(WS_H_Y, a->y, ybytes, st, &v))) return rc; d.y = v;
-    // x, alpha_hat, contrast, beta_mat, lambda share one staging buffer
-    size_t off_x = 0, off_alpha = off_x + m * p, off_con = off_alpha + n, off_beta = off_con + p,
-           off_lam = off_beta + n * p, tot = off_lam + p;
-    if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
-    double *vec = (double *)v;
-    DSQ_HIP(hipMemcpyAsync(vec + off_x, a->x, m * p * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + off_alpha, a->alpha_hat, n * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + off_con, a->contrast, p * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + off_beta, a->beta_mat, n * p * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + off_lam, a->lambda, p * 8, hipMemcpyHostToDevice, st));
-    d.x = vec + off_x; d.alpha_hat = vec + off_alpha; d.contrast = vec + off_con; d.beta_mat = vec + off_beta;
-    d.lambda = vec + off_lam;
-    if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
-    if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
-    else d.weights = nullptr;
-    // outputs
-    size_t o_beta = 0, o_var = o_beta + n * p, o_iter = o_var + n * p, o_cn = o_iter + n, o_cd = o_cn + n,
-           o_dev = o_cd + n, o_tot = o_dev + n;
-    if ((rc = ws_get(WS_H_OUTVEC, o_tot * 8, &v))) return rc;
-    double *ov = (double *)v;
-    od.beta_mat = ov + o_beta; od.beta_var_mat = ov + o_var; od.iter = ov + o_iter; od.contrast_num = ov + o_cn;
-    od.contrast_denom = ov + o_cd; od.deviance = ov + o_dev;
-    double *hat_d = nullptr, *mu_d = nullptr;
-    if (o->hat_diagonals) { if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc; hat_d = (double *)v; }
-    if (o->mu) { if ((rc = ws_get(WS_H_OUTMAT2, n * m * 8, &v))) return rc; mu_d = (double *)v; }
-    od.hat_diagonals = hat_d; od.mu = mu_d;
     std::vector<int32_t> labels;
-    if (!a->cell_of) {                       // R hands over the design matrix itself: find its cells here
-        cells_of_host_design(a->x, a->m, a->p, &labels);
-        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
-    }
-    rc = fit_beta_dev_locked(&d, &od, st);
-    if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(o->beta_mat, od.beta_mat, n * p * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->beta_var_mat, od.beta_var_mat, n * p * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->iter, od.iter, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->contrast_num, od.contrast_num, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->contrast_denom, od.contrast_denom, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->deviance, od.deviance, n * 8, hipMemcpyDeviceToHost, st));
-    if (hat_d) DSQ_HIP(hipMemcpyAsync(o->hat_diagonals, hat_d, n * m * 8, hipMemcpyDeviceToHost, st));
-    if (mu_d) DSQ_HIP(hipMemcpyAsync(o->mu, mu_d, n * m * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipStreamSynchronize(st));
-    return DSQ_OK;
-}
-
-static int disp_host_stage(int n_, int m_, int p_, const void *y, int y_type, const double *x, const double *mu_hat,
-                           const double *weights, int useWeights, hipStream_t st, const void **yd,
-                           const double **xd, const double **mud, const double **wd) {
-    const size_t n = n_, m = m_, p = p_;
-    void *v;
-    int rc;
-    if ((rc = up(WS_H_Y, y, n * m * (y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; *yd = v;
-    if ((rc = up(WS_H_X, x, m * p * 8, st, &v))) return rc; *xd = (double *)v;
-    if ((rc = up(WS_H_MU, mu_hat, n * m * 8, st, &v))) return rc; *mud = (double *)v;
-    if (useWeights) { if ((rc = up(WS_H_W, weights, n * m * 8, st, &v))) return rc; *wd = (double *)v; }
-    else *wd = nullptr;
-    return DSQ_OK;
+    const int32_t *cells; int ncell;
+    host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
+    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+        return fit_beta_host_range(a, o, lo, cnt, st, cells, ncell);
+    });
 }
 
 int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
@@ -1023,42 +1228,12 @@ int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
         return fail(DSQ_ERR_ARG, "NULL output array");
     if (int rc = check_device()) return rc;
     if (a->n == 0) return DSQ_OK;
-    hipStream_t st = nullptr;
-    const size_t n = a->n;
-    DsqFitDispArgs d = *a;
-    DsqFitDispOut od = *o;
-    int rc = disp_host_stage(a->n, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
-                             &d.y, &d.x, &d.mu_hat, &d.weights);
-    if (rc) return rc;
-    void *v;
-    if ((rc = ws_get(WS_H_VEC, 2 * n * 8, &v))) return rc;
-    double *vec = (double *)v;
-    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha, n * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + n, a->log_alpha_prior_mean, n * 8, hipMemcpyHostToDevice, st));
-    d.log_alpha = vec; d.log_alpha_prior_mean = vec + n;
-    if ((rc = ws_get(WS_H_OUTVEC, 8 * n * 8, &v))) return rc;
-    double *ov = (double *)v;
-    od.log_alpha = ov; od.last_change = ov + n; od.initial_lp = ov + 2 * n; od.initial_dlp = ov + 3 * n;
-    od.last_lp = ov + 4 * n; od.last_dlp = ov + 5 * n; od.last_d2lp = ov + 6 * n;
-    od.iter = (int32_t *)(ov + 7 * n); od.iter_accept = od.iter + n;
     std::vector<int32_t> labels;
-    if (!a->cell_of) {
-        cells_of_host_design(a->x, a->m, a->p, &labels);
-        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
-    }
-    rc = fit_disp_dev_locked(&d, &od, st);
-    if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->last_change, od.last_change, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->initial_lp, od.initial_lp, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->initial_dlp, od.initial_dlp, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->last_lp, od.last_lp, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->last_dlp, od.last_dlp, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->last_d2lp, od.last_d2lp, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->iter, od.iter, n * 4, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipMemcpyAsync(o->iter_accept, od.iter_accept, n * 4, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipStreamSynchronize(st));
-    return DSQ_OK;
+    const int32_t *cells; int ncell;
+    host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
+    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+        return fit_disp_host_range(a, o, lo, cnt, st, cells, ncell);
+    });
 }
 
 int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
@@ -1072,31 +1247,12 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
     if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
     if (int rc = check_device()) return rc;
     if (a->n == 0) return DSQ_OK;
-    hipStream_t st = nullptr;
-    const size_t n = a->n, ng = a->ngrid;
-    DsqFitDispGridArgs d = *a;
-    DsqFitDispGridOut od = *o;
-    int rc = disp_host_stage(a->n, a->m, a->p, a->y, a->y_type, a->x, a->mu_hat, a->weights, a->useWeights, st,
-                             &d.y, &d.x, &d.mu_hat, &d.weights);
-    if (rc) return rc;
-    void *v;
-    if ((rc = ws_get(WS_H_VEC, (n + ng) * 8, &v))) return rc;
-    double *vec = (double *)v;
-    DSQ_HIP(hipMemcpyAsync(vec, a->log_alpha_prior_mean, n * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + n, a->disp_grid, ng * 8, hipMemcpyHostToDevice, st));
-    d.log_alpha_prior_mean = vec; d.disp_grid = vec + n;
-    if ((rc = ws_get(WS_H_OUTVEC, n * 8, &v))) return rc;
-    od.log_alpha = (double *)v;
     std::vector<int32_t> labels;
-    if (!a->cell_of) {
-        cells_of_host_design(a->x, a->m, a->p, &labels);
-        if (!labels.empty()) { d.cell_of = labels.data(); d.ncell = 1 + *std::max_element(labels.begin(), labels.end()); }
-    }
-    rc = fit_disp_grid_dev_locked(&d, &od, st);
-    if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(o->log_alpha, od.log_alpha, n * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipStreamSynchronize(st));
-    return DSQ_OK;
+    const int32_t *cells; int ncell;
+    host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
+    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+        return fit_disp_grid_host_range(a, o, lo, cnt, st, cells, ncell);
+    });
 }
 
 int dsq_parametric_dispersion_fit_dev(const double *means, const double *disps, int64_t n, double *coefs,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include <string.h>
 
 namespace dsq {
 
@@ -203,6 +204,16 @@ hipError_t launch_transpose_gm_to_r_i32(const int32_t *src, int32_t *dst, int n,
 hipError_t launch_test_math(int op, const double *a, const double *b, const double *c, double *out, long n, hipStream_t st);
 
 int device_cu_count();
+// launch-geometry caches are per host thread (the multi-device host entry points drive one device per worker thread)
+// and are dropped when that thread moves to another device: the MaxDynamicSharedMemorySize attribute and the occupancy
+// figure belong to a device
+#define DSQ_CACHE_PER_DEVICE(a, b)                                                        \
+    do {                                                                                  \
+        static thread_local int cache_dev_ = -1;                                          \
+        int dev_now_ = 0;                                                                 \
+        (void)hipGetDevice(&dev_now_);                                                    \
+        if (dev_now_ != cache_dev_) { memset(a, 0, sizeof a); memset(b, 0, sizeof b); cache_dev_ = dev_now_; } \
+    } while (0)
 
 // ---- shared by capi.hip and pipeline.hip (the fused DESeq() chain) ------------------------------------------
 int capi_fail(int code, const char *fmt, ...);

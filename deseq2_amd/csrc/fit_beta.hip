@@ -772,8 +772,9 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
     const size_t lds = (size_t)DSQ_CMAX * P * sizeof(double) + ((size_t)DSQ_CMAX + 2 + kp.m) * sizeof(int32_t);
     const int waves = 4;
     const void *fn = kp.useWeights ? (const void *)fit_beta_cell_kernel<P, true> : (const void *)fit_beta_cell_kernel<P, false>;
-    static int bpc_cache[2];
-    static size_t lds_cache[2];
+    static thread_local int bpc_cache[2];
+    static thread_local size_t lds_cache[2];
+    DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
     const int wi = kp.useWeights ? 1 : 0;
     if (lds_cache[wi] != lds || bpc_cache[wi] == 0) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -806,7 +807,7 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     // the register budget of these kernels admits 2 waves per SIMD = 8 per CU.  Ties: bigger blocks
     // (X shared by more genes), then X in LDS.
     const size_t budget = (size_t)tu.beta_lds_kb * 1024, cu_lds = 160 * 1024;
-    const int wmax = tu.beta_waves > 0 ? tu.beta_waves : 4;
+    const int wmax = tu.beta_waves >= 4 ? 4 : tu.beta_waves >= 2 ? 2 : tu.beta_waves == 1 ? 1 : 4;
     int best = -1, best_wpc = 0;
     *stage = false; *waves = wmax; *xlds = 0;
     for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
@@ -827,8 +828,9 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
         while (*waves > 1 && (size_t)*waves * beta_arena_doubles(P) * sizeof(double) > budget) *waves >>= 1;
     *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double)
                   : (size_t)*waves * beta_arena_doubles(P) * sizeof(double);     // unstaged: only the WIDE arena
-    static int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
-    static size_t lds_cache[2][2][8];
+    static thread_local int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
+    static thread_local size_t lds_cache[2][2][8];
+    DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
     if (lds_cache[*stage][useW][*waves] != *lds) { bpc_cache[*stage][useW][*waves] = 0; lds_cache[*stage][useW][*waves] = *lds; }
     int bpc = bpc_cache[*stage][useW][*waves];
     const void *fn = *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true> : (const void *)fit_beta_kernel<P, false, true>)

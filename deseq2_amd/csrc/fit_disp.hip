@@ -742,7 +742,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
     // same choice as fit_beta: maximise resident waves per CU (LDS 160 KiB, registers allow 8 waves)
     const size_t budget = (size_t)tu.disp_lds_kb * 1024, cu_lds = 160 * 1024;
-    const int wmax = tu.disp_waves > 0 ? tu.disp_waves : 4;
+    const int wmax = tu.disp_waves >= 4 ? 4 : tu.disp_waves >= 2 ? 2 : tu.disp_waves == 1 ? 1 : 4;
     int best = -1, best_wpc = 0, waves = wmax, xlds = 0;
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
@@ -769,8 +769,9 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     kq.xlds = xlds;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
-    static int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
-    static size_t lds_cache[2][8];
+    static thread_local int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
+    static thread_local size_t lds_cache[2][8];
+    DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
     if (lds_cache[stage][waves] != lds) { bpc_cache[stage][waves] = 0; lds_cache[stage][waves] = lds; }
     int bpc = bpc_cache[stage][waves];
     if (bpc == 0) {

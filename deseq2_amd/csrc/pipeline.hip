@@ -745,7 +745,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     // dynamic-scheduling counters of the fit launches of THIS call; the row-list counters of the phases it runs
     PIPE_HIP(hipMemsetAsync(P.work_counters, 0, 64 * sizeof(int32_t), st));
     {   // the ridge (R/fitNbinomGLMs.R:73,162) and the default contrast (R/wrappers.R:105-108)
-        static double host[2 * DSQ_P_REG + 8];      // (under the library lock; pageable copies are staged at once)
+        static thread_local double host[2 * DSQ_P_REG + 8];   // (pageable copies are staged at once)
         for (int c = 0; c < p; c++) { host[c] = a->lambda[c]; host[p + c] = (c == 0) ? 1.0 : 0.0; }
         PIPE_HIP(hipMemcpyAsync(P.lam, host, 2 * (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
     }
@@ -810,7 +810,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     // ================================================================ count outliers
     if (a->phases & DSQ_PH_OUTLIERS) {
         // design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags (nOrMoreInCell, :2366)
-        static std::vector<int32_t> meta;             // (under the library lock; staged by the copy below)
+        static thread_local std::vector<int32_t> meta;   // (staged by the copy below)
         meta.assign((size_t)4 * m + a->ncell + 1, 0);
         int32_t *perm = meta.data(), *in3 = perm + m, *repl = in3 + m, *use3 = repl + m, *start = use3 + m;
         for (int j = 0; j < m; j++) {

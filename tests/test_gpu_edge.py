@@ -153,3 +153,40 @@ def test_device_pointers_in_r_layout(oracle):
     assert_same(out["hat"].cpu().numpy().T, want["hat_diagonals"], "hat_diagonals")
     assert_same(out["mu"].cpu().numpy().T, oracle.fittedMu(d["x"], d["nf"], want["beta_mat"], 0.5), "mu")
     assert_same(out["dev"].cpu().numpy(), want["deviance"], "deviance")
+
+
+@pytest.mark.parametrize("shards", [2, 3, 7])
+def test_host_entry_points_shard_genes_inside_the_library(oracle, shards, monkeypatch):
+    """the host-pointer entry points (what the .Call shim binds) cut [0, n) into the contiguous ranges of
+    R/parallel.R:10 and fit them on worker threads with their own streams -- one per visible device; DSQ_HOST_SHARDS
+    forces the split on this one GPU.  Sharded == single call == oracle, every output (test_parallel.R:27-37)."""
+    from deseq2_amd import native
+    from tests.helpers import make_case
+    d = make_case(203, 40, "batch_condition", seed=23, weights=True, sf_random=True)
+    p = d["x"].shape[1]
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    bargs = (d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"], lam,
+             d["weights"], True, 1e-8, 100, True, 0.5)
+    one = native.fitBeta(*bargs, want_mu=True, mu_floor=0.5)
+    mu = one["mu"]
+    la0 = np.log(d["alpha_init"])
+    dargs = (d["counts"], d["x"], mu, la0, la0 - 0.1, 0.9, np.log(1e-9), 1.0, 1e-6, 100, True,
+             np.maximum(d["weights"], 1e-6), True, 1e-2, True)
+    done = native.fitDisp(*dargs)
+    grid = np.linspace(np.log(1e-8), np.log(40.0), 20)
+    gargs = (d["counts"], d["x"], mu, grid, la0, 1.0, True, d["weights"], True, 1e-2, True)
+    gone = native.fitDispGrid(*gargs)
+    monkeypatch.setenv("DSQ_HOST_SHARDS", str(shards))
+    many = native.fitBeta(*bargs, want_mu=True, mu_floor=0.5)
+    dmany = native.fitDisp(*dargs)
+    gmany = native.fitDispGrid(*gargs)
+    monkeypatch.delenv("DSQ_HOST_SHARDS")
+    for k in ("beta_mat", "beta_var_mat", "iter", "hat_diagonals", "contrast_num", "contrast_denom", "deviance", "mu"):
+        assert_same(many[k], one[k], "sharded fitBeta$" + k)
+    for k in ("log_alpha", "iter", "iter_accept", "last_change", "initial_lp", "initial_dlp", "last_lp", "last_dlp",
+              "last_d2lp"):
+        assert_same(dmany[k], done[k], "sharded fitDisp$" + k)
+    assert_same(gmany["log_alpha"], gone["log_alpha"], "sharded fitDispGrid")
+    want = oracle.fitBeta(*bargs)
+    assert_same(many["beta_mat"], want["beta_mat"], "sharded fitBeta vs oracle")
+    assert_same(dmany["iter"], oracle.fitDisp(*dargs)["iter"], "sharded fitDisp vs oracle")
