@@ -182,6 +182,7 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
+    "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows",
     "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
     "dsq_profile_count", "dsq_profile_get",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
@@ -217,6 +218,8 @@ def lib():
         getattr(L, name).restype = C.c_int
         getattr(L, name + "_dev").argtypes = [C.POINTER(a), C.POINTER(o), C.c_void_p]
         getattr(L, name + "_dev").restype = C.c_int
+        getattr(L, name + "_rows").argtypes = [C.POINTER(a), C.POINTER(o), C.c_int64, C.c_int64]
+        getattr(L, name + "_rows").restype = C.c_int
     L.dsq_to_gene_major_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     L.dsq_to_gene_major_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
     L.dsq_counts_f64_to_gene_major_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,

@@ -1153,7 +1153,8 @@ static void host_plan(size_t n, int *nshards, int *ndev) {
 
 // run f(lo, cnt, stream) over the ranges of R/parallel.R:10; one range: on the caller's thread, device and null stream
 template <class F>
-static int host_sharded(size_t n, F &&f) {
+static int host_sharded(size_t row_lo, size_t n, F &&f0) {
+    auto f = [&](size_t lo, size_t cnt, hipStream_t st) { return f0(row_lo + lo, cnt, st); };
     int S, ndev;
     host_plan(n, &S, &ndev);
     if (S <= 1) return f((size_t)0, n, (hipStream_t) nullptr);
@@ -1193,7 +1194,9 @@ static void host_cells(const double *x, int m, int p, const int32_t *given, int 
 
 extern "C" {
 
-int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
+int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) { return dsq_fit_beta_rows(a, o, 0, a ? a->n : 0); }
+
+int dsq_fit_beta_rows(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, int64_t row_lo, int64_t row_cnt) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
@@ -1205,16 +1208,19 @@ int dsq_fit_beta(const DsqFitBetaArgs *a, const DsqFitBetaOut *o) {
     if (!o->beta_mat || !o->beta_var_mat || !o->iter || !o->contrast_num || !o->contrast_denom || !o->deviance)
         return fail(DSQ_ERR_ARG, "NULL output array");
     if (int rc = check_device()) return rc;
-    if (a->n == 0) return DSQ_OK;
+    if (row_lo < 0 || row_cnt < 0 || row_lo + row_cnt > a->n) return fail(DSQ_ERR_ARG, "row range outside [0, n)");
+    if (row_cnt == 0) return DSQ_OK;
     std::vector<int32_t> labels;
     const int32_t *cells; int ncell;
     host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
-    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+    return host_sharded((size_t)row_lo, (size_t)row_cnt, [&](size_t lo, size_t cnt, hipStream_t st) {
         return fit_beta_host_range(a, o, lo, cnt, st, cells, ncell);
     });
 }
 
-int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
+int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) { return dsq_fit_disp_rows(a, o, 0, a ? a->n : 0); }
+
+int dsq_fit_disp_rows(const DsqFitDispArgs *a, const DsqFitDispOut *o, int64_t row_lo, int64_t row_cnt) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
@@ -1227,16 +1233,19 @@ int dsq_fit_disp(const DsqFitDispArgs *a, const DsqFitDispOut *o) {
         !o->last_lp || !o->last_dlp || !o->last_d2lp)
         return fail(DSQ_ERR_ARG, "NULL output array");
     if (int rc = check_device()) return rc;
-    if (a->n == 0) return DSQ_OK;
+    if (row_lo < 0 || row_cnt < 0 || row_lo + row_cnt > a->n) return fail(DSQ_ERR_ARG, "row range outside [0, n)");
+    if (row_cnt == 0) return DSQ_OK;
     std::vector<int32_t> labels;
     const int32_t *cells; int ncell;
     host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
-    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+    return host_sharded((size_t)row_lo, (size_t)row_cnt, [&](size_t lo, size_t cnt, hipStream_t st) {
         return fit_disp_host_range(a, o, lo, cnt, st, cells, ncell);
     });
 }
 
-int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
+int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) { return dsq_fit_disp_grid_rows(a, o, 0, a ? a->n : 0); }
+
+int dsq_fit_disp_grid_rows(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o, int64_t row_lo, int64_t row_cnt) {
     std::lock_guard<std::mutex> lk(g_mu);
     WsScope ws(nullptr);
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
@@ -1246,11 +1255,12 @@ int dsq_fit_disp_grid(const DsqFitDispGridArgs *a, const DsqFitDispGridOut *o) {
         return fail(DSQ_ERR_ARG, "NULL array");
     if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
     if (int rc = check_device()) return rc;
-    if (a->n == 0) return DSQ_OK;
+    if (row_lo < 0 || row_cnt < 0 || row_lo + row_cnt > a->n) return fail(DSQ_ERR_ARG, "row range outside [0, n)");
+    if (row_cnt == 0) return DSQ_OK;
     std::vector<int32_t> labels;
     const int32_t *cells; int ncell;
     host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
-    return host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st) {
+    return host_sharded((size_t)row_lo, (size_t)row_cnt, [&](size_t lo, size_t cnt, hipStream_t st) {
         return fit_disp_grid_host_range(a, o, lo, cnt, st, cells, ncell);
     });
 }

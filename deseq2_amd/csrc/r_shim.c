@@ -6,8 +6,9 @@
  * tests/testthat/test_dispersions.R:67) work unchanged.
  *
  * Uses only Rinternals.h (no Rcpp, no Armadillo).  R is NOT installed in the build image
- * of this repository, so this file is compiled only where R exists:
- *     R CMD SHLIB -o DESeq2.so r_shim.c -I../../include -L.. -ldeseq2_mi355x
+ * of this repository, so this file is compiled only where R exists (the whole file is inside
+ * #ifdef DSQ_HAVE_R so that a build without R headers yields an empty object):
+ *     PKG_CPPFLAGS="-DDSQ_HAVE_R -I../../include" PKG_LIBS="-L.. -ldeseq2_mi355x" R CMD SHLIB -o DESeq2.so r_shim.c
  * (see INTEGRATION.md).  It contains no arithmetic: all computation is in the HIP library.
  */
 #ifdef DSQ_HAVE_R
@@ -30,6 +31,21 @@ static const void *counts_ptr(SEXP y, int *type) {
     Rf_error("ySEXP must be an integer or numeric matrix");
     return NULL;
 }
+/* the raw pointers handed to the library are trusted to hold n x m (n x p, n, p) values: check what R passed */
+static void need_matrix(SEXP s, int nr, int nc, const char *what) {
+    if (!Rf_isMatrix(s) || Rf_nrows(s) != nr || Rf_ncols(s) != nc)
+        Rf_error("%s must be a %d x %d matrix", what, nr, nc);
+}
+static void need_length(SEXP s, int n, const char *what) {
+    if (Rf_length(s) != n) Rf_error("%s must have length %d", what, n);
+}
+/* genes per library call: between two calls R_CheckUserInterrupt() runs (the reference polls every 100 genes,
+ * src/DESeq2.cpp:195,320,493; a range here is ~50 ms of GPU work) */
+static int rows_per_call(int n, int m) {
+    double r = 2.5e7 / (double)(m > 0 ? m : 1);
+    if (r < 4096.0) r = 4096.0;
+    return r > (double)n ? n : (int)r;
+}
 static double scalar_d(SEXP s) { return Rf_asReal(s); }
 static int scalar_i(SEXP s) { return Rf_asInteger(s); }      /* maxit may arrive as double 100 */
 static int scalar_b(SEXP s) { return Rf_asLogical(s) == TRUE; }
@@ -49,6 +65,9 @@ SEXP _DESeq2_fitBeta(SEXP ySEXP, SEXP xSEXP, SEXP nfSEXP, SEXP alpha_hatSEXP, SE
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    need_matrix(xSEXP, m, p, "xSEXP"); need_matrix(nfSEXP, n, m, "nfSEXP"); need_matrix(beta_matSEXP, n, p, "beta_matSEXP");
+    need_matrix(weightsSEXP, n, m, "weightsSEXP"); need_length(alpha_hatSEXP, n, "alpha_hatSEXP");
+    need_length(contrastSEXP, p, "contrastSEXP"); need_length(lambdaSEXP, p, "lambdaSEXP");
     SEXP x = as_real(xSEXP, &np), nf = as_real(nfSEXP, &np), alpha = as_real(alpha_hatSEXP, &np);
     SEXP con = as_real(contrastSEXP, &np), b0 = as_real(beta_matSEXP, &np), lam = as_real(lambdaSEXP, &np);
     SEXP w = as_real(weightsSEXP, &np);
@@ -69,7 +88,10 @@ SEXP _DESeq2_fitBeta(SEXP ySEXP, SEXP xSEXP, SEXP nfSEXP, SEXP alpha_hatSEXP, SE
     DsqFitBetaOut o = {0};
     o.beta_mat = REAL(beta); o.beta_var_mat = REAL(var); o.iter = REAL(iter); o.hat_diagonals = REAL(hat);
     o.contrast_num = REAL(cn); o.contrast_denom = REAL(cd); o.deviance = REAL(dev);
-    chk(dsq_fit_beta(&a, &o));
+    for (int lo = 0, step = rows_per_call(n, m); lo < n; lo += step) {
+        chk(dsq_fit_beta_rows(&a, &o, lo, (lo + step < n) ? step : n - lo));
+        R_CheckUserInterrupt();
+    }
     const char *names[] = {"beta_mat", "beta_var_mat", "iter", "hat_diagonals", "contrast_num",
                            "contrast_denom", "deviance"};                        /* src/DESeq2.cpp:458-464 */
     SEXP vals[] = {beta, var, iter, hat, cn, cd, dev};
@@ -86,6 +108,8 @@ SEXP _DESeq2_fitDisp(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP log_alphaSEXP
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    need_matrix(xSEXP, m, p, "xSEXP"); need_matrix(mu_hatSEXP, n, m, "mu_hatSEXP"); need_matrix(weightsSEXP, n, m, "weightsSEXP");
+    need_length(log_alphaSEXP, n, "log_alphaSEXP"); need_length(log_alpha_prior_meanSEXP, n, "log_alpha_prior_meanSEXP");
     SEXP x = as_real(xSEXP, &np), mu = as_real(mu_hatSEXP, &np), la = as_real(log_alphaSEXP, &np);
     SEXP pm = as_real(log_alpha_prior_meanSEXP, &np), w = as_real(weightsSEXP, &np);
     DsqFitDispArgs a = {0};
@@ -107,7 +131,10 @@ SEXP _DESeq2_fitDisp(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP log_alphaSEXP
     o.log_alpha = REAL(vals[0]); o.iter = INTEGER(vals[1]); o.iter_accept = INTEGER(vals[2]);
     o.last_change = REAL(vals[3]); o.initial_lp = REAL(vals[4]); o.initial_dlp = REAL(vals[5]);
     o.last_lp = REAL(vals[6]); o.last_dlp = REAL(vals[7]); o.last_d2lp = REAL(vals[8]);
-    chk(dsq_fit_disp(&a, &o));
+    for (int lo = 0, step = rows_per_call(n, m); lo < n; lo += step) {
+        chk(dsq_fit_disp_rows(&a, &o, lo, (lo + step < n) ? step : n - lo));
+        R_CheckUserInterrupt();
+    }
     SEXP out = named_list(9, names, vals);
     UNPROTECT(np);
     return out;
@@ -131,7 +158,10 @@ SEXP _DESeq2_fitDispGrid(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP disp_grid
     SEXP la = PROTECT(Rf_allocVector(REALSXP, n)); np++;
     DsqFitDispGridOut o = {0};
     o.log_alpha = REAL(la);
-    chk(dsq_fit_disp_grid(&a, &o));
+    for (int lo = 0, step = rows_per_call(n, m); lo < n; lo += step) {
+        chk(dsq_fit_disp_grid_rows(&a, &o, lo, (lo + step < n) ? step : n - lo));
+        R_CheckUserInterrupt();
+    }
     const char *names[] = {"log_alpha"};                                         /* src/DESeq2.cpp:512 */
     SEXP vals[] = {la};
     SEXP out = named_list(1, names, vals);

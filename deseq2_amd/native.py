@@ -43,7 +43,9 @@ def _scalar_len1(v, name):
 
 def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lambdaSEXP, weightsSEXP,
             useWeightsSEXP, tolSEXP, maxitSEXP, useQRSEXP, minmuSEXP, want_mu=False, mu_floor=0.0,
-            want_hat=True):
+            want_hat=True, row_ranges=None):
+    """row_ranges: [(lo, cnt), ...] walks the genes range by range through dsq_fit_beta_rows, as the R shim does
+    between its R_CheckUserInterrupt() polls (the outputs of rows outside the ranges stay zero)"""
     y, ytype = _counts(ySEXP)
     x = _fcol(xSEXP); nf = _fcol(nfSEXP); b0 = _fcol(beta_matSEXP)
     if y.ndim != 2 or x.ndim != 2:
@@ -75,7 +77,11 @@ def fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP, beta_matSEXP, lam
                         iter=_ptr(out["iter"]), hat_diagonals=_ptr(out["hat_diagonals"]),
                         contrast_num=_ptr(out["contrast_num"]), contrast_denom=_ptr(out["contrast_denom"]),
                         deviance=_ptr(out["deviance"]), mu=_ptr(mu), mu_floor=float(mu_floor))
-    L.check(L.lib().dsq_fit_beta(C.byref(a), C.byref(o)))
+    if row_ranges is None:
+        L.check(L.lib().dsq_fit_beta(C.byref(a), C.byref(o)))
+    else:
+        for lo, cnt in row_ranges:
+            L.check(L.lib().dsq_fit_beta_rows(C.byref(a), C.byref(o), int(lo), int(cnt)))
     if want_mu:
         out["mu"] = mu
     return out

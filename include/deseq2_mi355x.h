@@ -183,6 +183,14 @@ typedef struct {
 int dsq_fit_disp_grid(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out);
 int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, void *stream);
 
+/* The same three routines on the gene rows [row_lo, row_lo + row_cnt) of the SAME full n x . arrays (inputs read, outputs
+ * written at those rows only).  Genes are independent (src/DESeq2.cpp:194,319,492), so a caller may walk a large
+ * problem range by range -- the R shim does, polling R_CheckUserInterrupt() between ranges as the reference does every
+ * 100 genes (:195,320,493).  dsq_fit_*(a, o) == dsq_fit_*_rows(a, o, 0, a->n).                                     */
+int dsq_fit_beta_rows(const DsqFitBetaArgs *args, const DsqFitBetaOut *out, int64_t row_lo, int64_t row_cnt);
+int dsq_fit_disp_rows(const DsqFitDispArgs *args, const DsqFitDispOut *out, int64_t row_lo, int64_t row_cnt);
+int dsq_fit_disp_grid_rows(const DsqFitDispGridArgs *args, const DsqFitDispGridOut *out, int64_t row_lo, int64_t row_cnt);
+
 /* ---- extensions beyond the three .Call routines ----------------------
  * dsq_prefit_moments: what estimateDispersionsGeneEst / fitNbinomGLMs compute in R before the
  * first native call -- baseMean, baseVar, allZero (R/core.R:2138-2146), roughDispEstimate

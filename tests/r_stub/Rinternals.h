@@ -17,7 +17,7 @@ int TYPEOF(SEXP); int *INTEGER(SEXP); double *REAL(SEXP); int *LOGICAL(SEXP);
 double Rf_asReal(SEXP); int Rf_asInteger(SEXP); int Rf_asLogical(SEXP);
 SEXP Rf_coerceVector(SEXP, int); SEXP Rf_allocVector(int, long); SEXP Rf_allocMatrix(int, int, int);
 SEXP Rf_protect(SEXP); void Rf_unprotect(int); SEXP Rf_mkChar(const char*); void SET_VECTOR_ELT(SEXP,long,SEXP); void SET_STRING_ELT(SEXP,long,SEXP);
-SEXP Rf_setAttrib(SEXP,SEXP,SEXP); int Rf_nrows(SEXP); int Rf_ncols(SEXP); int Rf_length(SEXP);
+SEXP Rf_setAttrib(SEXP,SEXP,SEXP); int Rf_nrows(SEXP); int Rf_ncols(SEXP); int Rf_length(SEXP); int Rf_isMatrix(SEXP);
 void Rf_error(const char*, ...); char *R_alloc(size_t, int);
 #define PROTECT(x) Rf_protect(x)
 #define UNPROTECT(n) Rf_unprotect(n)

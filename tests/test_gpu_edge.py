@@ -190,3 +190,20 @@ def test_host_entry_points_shard_genes_inside_the_library(oracle, shards, monkey
     want = oracle.fitBeta(*bargs)
     assert_same(many["beta_mat"], want["beta_mat"], "sharded fitBeta vs oracle")
     assert_same(dmany["iter"], oracle.fitDisp(*dargs)["iter"], "sharded fitDisp vs oracle")
+
+
+def test_row_range_entry_point_equals_whole_call():
+    """dsq_fit_beta_rows over consecutive ranges (what r_shim.c does between interrupt polls) == one call"""
+    from deseq2_amd import native
+    from tests.helpers import make_case
+    d = make_case(150, 30, "two_group", seed=29, sf_random=True)
+    p = d["x"].shape[1]
+    args = (d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
+            np.full(p, 1e-6) / np.log(2) ** 2, d["weights"], False, 1e-8, 100, True, 0.5)
+    n = d["counts"].shape[0]
+    whole = native.fitBeta(*args, want_mu=True)
+    parts = native.fitBeta(*args, want_mu=True, row_ranges=[(0, 64), (64, 1), (65, n - 65)])
+    for k in ("beta_mat", "beta_var_mat", "iter", "hat_diagonals", "deviance", "mu"):
+        assert_same(parts[k], whole[k], "rows$" + k)
+    with pytest.raises(Exception):
+        native.fitBeta(*args, row_ranges=[(n - 3, 5)])
