@@ -115,6 +115,20 @@ class DsqInterceptOut(C.Structure):
     _fields_ = [("beta_log2", C.c_void_p), ("betaSE", C.c_void_p), ("mu", C.c_void_p), ("hat", C.c_void_p)]
 
 
+class DsqOptimArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
+        ("y", C.c_void_p), ("y_type", C.c_int32), ("x", C.c_void_p), ("nf", C.c_void_p), ("nf_is_vector", C.c_int32),
+        ("alpha_hat", C.c_void_p), ("lambda_", C.c_void_p), ("weights", C.c_void_p), ("useWeights", C.c_int32),
+        ("beta_start", C.c_void_p), ("minmu", C.c_double),
+    ]
+
+
+class DsqOptimOut(C.Structure):
+    _fields_ = [("beta", C.c_void_p), ("betaSE", C.c_void_p), ("conv", C.c_void_p), ("mu", C.c_void_p),
+                ("logLike", C.c_void_p)]
+
+
 class DsqCooksArgs(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("layout", C.c_int32), ("ld", C.c_int64),
@@ -182,7 +196,7 @@ EXPORTED_SYMBOLS = [
     "dsq_profile_enable", "dsq_profile_last_ms",
     "dsq_prefit_moments", "dsq_prefit_moments_dev", "dsq_nbinom_loglike", "dsq_nbinom_loglike_dev",
     "dsq_parametric_dispersion_fit", "dsq_parametric_dispersion_fit_dev",
-    "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows",
+    "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows", "dsq_optim_rows",
     "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
     "dsq_profile_count", "dsq_profile_get",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
@@ -237,6 +251,7 @@ def lib():
     L.dsq_linear_mu_dev.argtypes = [C.POINTER(DsqPrefitArgs), C.c_double, C.c_void_p, C.c_void_p]
     L.dsq_intercept_fit.argtypes = [C.POINTER(DsqInterceptArgs), C.POINTER(DsqInterceptOut)]
     L.dsq_intercept_fit_dev.argtypes = [C.POINTER(DsqInterceptArgs), C.POINTER(DsqInterceptOut), C.c_void_p]
+    L.dsq_optim_rows.argtypes = [C.POINTER(DsqOptimArgs), C.POINTER(DsqOptimOut)]
     L.dsq_cooks_distance.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut)]
     L.dsq_cooks_distance_dev.argtypes = [C.POINTER(DsqCooksArgs), C.POINTER(DsqCooksOut), C.c_void_p]
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]

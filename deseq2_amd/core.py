@@ -215,58 +215,53 @@ def _dnbinom_mu_log(k, size, mu):
 
 def fitNbinomGLMsOptim(E, y, nf, x, lam, rowsForOptim, rowStable, alpha_hat, weights, useWeights, betaMatrix,
                        betaSE, betaConv, beta_mat_init, logLike, minmu=0.5):
-    """R/fitNbinomGLMs.R:340-407: per-row L-BFGS-B on the penalised NB log-posterior for rows the
-    IRLS did not fit.  A host loop in the reference too; only the few affected rows come back
-    from the device."""
-    from scipy.optimize import minimize
-    from scipy.stats import norm
+    """R/fitNbinomGLMs.R:340-407: the rows the IRLS did not fit are re-fitted by maximising the penalised NB log
+    posterior over beta in [-30, 30]^p.  The reference loops over them in R with optim(method = "L-BFGS-B"); the
+    engine fits them in one launch (damped Fisher scoring on the same objective and box, E.optim_rows), everything
+    after the optimum -- mu, betaSE, logLike -- as :382-400."""
     rows = np.asarray(rowsForOptim)
-    yh = E.to_numpy(E.take_rows(y, rows)).astype(np.float64)
-    nfh = E.to_numpy(E.take_rows(nf, rows))
-    wh = E.to_numpy(E.take_rows(weights, rows)) if useWeights else None
-    lambdaNatLogScale = lam / np.log(2) ** 2
     large = 30.0
-    mu_rows = np.empty_like(yh)
+    start = np.empty((rows.size, x.shape[1]))
     for r, row in enumerate(rows):
         if rowStable[row] and (np.abs(betaMatrix[row]) < large).all():
-            betaRow = betaMatrix[row].copy()                                       # :351-352
+            start[r] = betaMatrix[row]                                             # :351-352
         else:
-            betaRow = np.asarray(beta_mat_init[row], float).copy()                 # :354
-        nf, k, alpha = nfh[r], yh[r], alpha_hat[row]
-        w = wh[r] if useWeights else None
+            start[r] = np.asarray(beta_mat_init[row], float)                       # :354 (the natural-log start, as in R)
+    o = E.optim_rows(E.take_rows(y, rows), E.take_rows(nf, rows), x, np.asarray(alpha_hat)[rows], lam,
+                     E.take_rows(weights, rows) if useWeights else None, useWeights, start, minmu)
+    betaConv[rows[np.asarray(o["conv"], bool)]] = True                             # :378-380
+    betaMatrix[rows] = o["beta"]                                                   # :382
+    betaSE[rows] = o["betaSE"]                                                     # :397
+    logLike[rows] = o["logLike"]                                                   # :398-399
+    return betaMatrix, betaSE, betaConv, rows, np.asarray(o["mu"]), logLike
 
-        def objectiveFn(pv):                                                       # :359-370
-            mu_row = nf * 2.0 ** (x @ pv)
-            with np.errstate(all="ignore"):
-                ll = _dnbinom_mu_log(k, 1.0 / alpha, mu_row)
-                logLike_ = np.sum(w * ll) if useWeights else np.sum(ll)
-                logPrior = np.sum(norm.logpdf(pv, 0.0, np.sqrt(1.0 / lam)))
-            v = -1.0 * (logLike_ + logPrior)
-            return v if np.isfinite(v) else 1e300
 
-        def gradFn(pv):                      # stats::optim's numerical gradient: central, ndeps = 1e-3, clipped
-            g = np.empty_like(pv)
-            for i in range(pv.size):
-                hi, lo = pv.copy(), pv.copy()
-                hi[i], lo[i] = min(pv[i] + 1e-3, large), max(pv[i] - 1e-3, -large)
-                g[i] = (objectiveFn(hi) - objectiveFn(lo)) / (hi[i] - lo[i])
-            return g
-        o = minimize(objectiveFn, betaRow, jac=gradFn, method="L-BFGS-B", bounds=[(-large, large)] * len(betaRow),
-                     options=dict(maxcor=5, ftol=1e7 * np.finfo(float).eps, gtol=0.0, maxiter=100))   # :371
-        if o.success:
-            betaConv[row] = True                                                   # :378-380
-        betaMatrix[row] = o.x                                                      # :382
-        mu_row = nf * 2.0 ** (x @ o.x)
-        mu_rows[r] = mu_row                                                        # :386
-        mu_c = np.maximum(mu_row, minmu)                                           # :387
-        wdiag = (w if useWeights else 1.0) / (1.0 / mu_c + alpha)                  # :388-392
-        xtwx = x.T @ (x * np.asarray(wdiag)[:, None])
-        xtwxRidgeInv = np.linalg.inv(xtwx + np.diag(lambdaNatLogScale))
-        sigma = xtwxRidgeInv @ xtwx @ xtwxRidgeInv                                 # :395
-        betaSE[row] = LOG2E * np.sqrt(np.maximum(np.diag(sigma), 0))               # :397
-        llv = _dnbinom_mu_log(k, 1.0 / alpha, mu_c)                                # :398 (clamped mu_row)
-        logLike[row] = np.sum(w * llv) if useWeights else np.sum(llv)
-    return betaMatrix, betaSE, betaConv, rows, mu_rows, logLike
+def fitNbinomGLMsOptim_scipy(yh, nfh, x, lam, alpha, wh, useWeights, start):
+    """the reference's own route for ONE row -- L-BFGS-B with optim's numerical gradient and stopping parameters
+    (R/fitNbinomGLMs.R:359-371) -- kept as the cross-check of the engine's optimiser (tests), not used by the chain"""
+    from scipy.optimize import minimize
+    from scipy.stats import norm
+    large = 30.0
+
+    def objectiveFn(pv):                                                           # :359-370
+        mu_row = nfh * 2.0 ** (x @ pv)
+        with np.errstate(all="ignore"):
+            ll = _dnbinom_mu_log(yh, 1.0 / alpha, mu_row)
+            logLike_ = np.sum(wh * ll) if useWeights else np.sum(ll)
+            logPrior = np.sum(norm.logpdf(pv, 0.0, np.sqrt(1.0 / lam)))
+        v = -1.0 * (logLike_ + logPrior)
+        return v if np.isfinite(v) else 1e300
+
+    def gradFn(pv):                      # stats::optim's numerical gradient: central, ndeps = 1e-3, clipped
+        g = np.empty_like(pv)
+        for i in range(pv.size):
+            hi, lo = pv.copy(), pv.copy()
+            hi[i], lo[i] = min(pv[i] + 1e-3, large), max(pv[i] - 1e-3, -large)
+            g[i] = (objectiveFn(hi) - objectiveFn(lo)) / (hi[i] - lo[i])
+        return g
+    o = minimize(objectiveFn, np.asarray(start, float), jac=gradFn, method="L-BFGS-B", bounds=[(-large, large)] * len(start),
+                 options=dict(maxcor=5, ftol=1e7 * np.finfo(float).eps, gtol=0.0, maxiter=100))   # :371
+    return o.x, bool(o.success), objectiveFn
 
 
 def _host_vector(v):

@@ -239,12 +239,17 @@ struct DispatchP {
         if (p == P) { *ok = true; return launch_fit_disp_p<P>(kp, st, grid); }
         return DispatchP<P - 1>::disp(p, kp, st, grid, ok);
     }
+    static hipError_t optim(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok) {
+        if (p == P) { *ok = true; return launch_optim_p<P>(kp, st); }
+        return DispatchP<P - 1>::optim(p, kp, st, ok);
+    }
 };
 template <>
 struct DispatchP<0> {
     static hipError_t beta(int, const BetaKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
     static void beta_scratch(int, int, int, int, size_t *slab, size_t *cscr) { *slab = 0; *cscr = 0; }
     static hipError_t disp(int, const DispKernelParams &, hipStream_t, bool, bool *ok) { *ok = false; return hipSuccess; }
+    static hipError_t optim(int, const OptimKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
 };
 
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok) {
@@ -1457,6 +1462,76 @@ int dsq_intercept_fit(const DsqInterceptArgs *a, const DsqInterceptOut *o) {
     if (o->hat) DSQ_HIP(hipMemcpyAsync(o->hat, od.hat, n * m * 8, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;
+}
+
+int dsq_optim_rows(const DsqOptimArgs *a, const DsqOptimOut *o) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    WsScope ws(nullptr);
+    if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
+    if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
+    if (a->p > DSQ_P_REG) return fail(DSQ_ERR_UNSUPPORTED, "dsq_optim_rows: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (!a->y || !a->x || !a->nf || !a->alpha_hat || !a->lambda || !a->beta_start) return fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
+    if (!o->beta || !o->betaSE || !o->conv || !o->mu || !o->logLike) return fail(DSQ_ERR_ARG, "NULL output array");
+    if (int rc = check_device()) return rc;
+    if (a->n == 0) return DSQ_OK;
+    hipStream_t st = nullptr;
+    const size_t n = a->n, m = a->m, p = a->p;
+    void *v;
+    int rc;
+    OptimKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = a->n; kp.m = a->m; kp.p = a->p; kp.minmu = a->minmu;
+    if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc;
+    bool ycheck = false;
+    long ld = 0;
+    rc = prep_counts(v, a->y_type, DSQ_LAYOUT_R, 0, a->n, a->m, st, &kp.y, &ld, &ycheck);
+    if (rc) return rc;
+    kp.ld = ld;
+    if (a->nf_is_vector) { if ((rc = up(WS_H_NF, a->nf, m * 8, st, &v))) return rc; kp.nf = (double *)v; kp.nf_is_vector = 1; }
+    else {
+        if ((rc = up(WS_H_NF, a->nf, n * m * 8, st, &v))) return rc;
+        if ((rc = prep_matrix((double *)v, DSQ_LAYOUT_R, 0, a->n, a->m, WS_NF, st, &kp.nf, ld))) return rc;
+    }
+    if (a->useWeights) {
+        if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc;
+        if ((rc = prep_matrix((double *)v, DSQ_LAYOUT_R, 0, a->n, a->m, WS_W, st, &kp.weights, ld))) return rc;
+        kp.useWeights = 1;
+    }
+    // x | alpha | lambda (natural-log scale) | beta_start
+    const size_t off_x = 0, off_al = m * p, off_lam = off_al + n, off_b = off_lam + p, tot = off_b + n * p;
+    if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
+    double *vec = (double *)v;
+    static thread_local double lamnat[DSQ_P_REG];
+    const double ln2 = 0.6931471805599453;
+    for (size_t c = 0; c < p; c++) lamnat[c] = a->lambda[c] / (ln2 * ln2);
+    DSQ_HIP(hipMemcpyAsync(vec + off_x, a->x, m * p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_al, a->alpha_hat, n * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_lam, lamnat, p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_b, a->beta_start, n * p * 8, hipMemcpyHostToDevice, st));
+    kp.x = vec + off_x; kp.alpha_hat = vec + off_al; kp.lamnat = vec + off_lam; kp.beta_start = vec + off_b;
+    // outputs: beta | betaSE | loglike | conv ; mu (gene-major, then R layout)
+    if ((rc = ws_get(WS_H_OUTVEC, (2 * n * p + 2 * n) * 8, &v))) return rc;
+    double *ov = (double *)v;
+    kp.beta = ov; kp.betaSE = ov + n * p; kp.loglike = ov + 2 * n * p; kp.conv = (int32_t *)(ov + 2 * n * p + n);
+    void *mu_gm, *mu_r;
+    if ((rc = ws_get(WS_MUOUT, n * (size_t)ld * 8, &mu_gm))) return rc;
+    if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &mu_r))) return rc;
+    kp.mu_out = (double *)mu_gm;
+    bool ok = false;
+    prof_begin(st);
+    DSQ_HIP(DispatchP<DSQ_P_REG>::optim(a->p, kp, st, &ok));
+    prof_end(st);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    DSQ_HIP(launch_transpose_gm_to_r_f64(kp.mu_out, (double *)mu_r, a->n, a->m, ld, st));
+    DSQ_HIP(hipMemcpyAsync(o->beta, kp.beta, n * p * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->betaSE, kp.betaSE, n * p * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->logLike, kp.loglike, n * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->conv, kp.conv, n * 4, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(o->mu, mu_r, n * m * 8, hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipStreamSynchronize(st));
+    return finish_ycheck(ycheck, st);
 }
 
 int dsq_cooks_distance_dev(const DsqCooksArgs *args, const DsqCooksOut *out, void *stream) {

@@ -123,6 +123,25 @@ struct InterceptKernelParams {
     const int32_t *n_dev;
 };
 
+struct OptimKernelParams {
+    int n, m, p;
+    long ld;
+    const int32_t *y;
+    const double *nf;
+    int nf_is_vector;
+    const double *weights;
+    int useWeights;
+    const double *x;           // m x p column-major
+    const double *alpha_hat;   // n
+    const double *lamnat;      // p: prior precisions on the natural-log scale
+    const double *beta_start;  // n x p column-major, log2 scale
+    double minmu;
+    double *beta, *betaSE;     // n x p column-major, log2 scale
+    int32_t *conv;             // n
+    double *mu_out;            // n x ld
+    double *loglike;           // n
+};
+
 struct CooksKernelParams {
     int n, m, p;
     long ld;
@@ -181,6 +200,7 @@ size_t trend_fit_workspace_bytes();
 #define DSQ_DISP_CELL_MINP 5   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
+template <int P> hipError_t launch_optim_p(const OptimKernelParams &kp, hipStream_t st);
 // doubles of global scratch one fitBeta launch needs: `slab` (per-wave mu/sqrt(w)/sqrt(w)z when they
 // do not fit in LDS, else 0) and `cscr` (hoisted NB-density constants)
 template <int P> void fit_beta_scratch_doubles(int n, int m, int use_weights, size_t *slab, size_t *cscr);

@@ -793,6 +793,169 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
     return hipGetLastError();
 }
 
+// ---- rows the IRLS did not fit (fitNbinomGLMsOptim, R/fitNbinomGLMs.R:340-407) ---------------------------------------
+// Damped Fisher scoring on the penalised NB log posterior over beta in [-30, 30]^p (log2 scale), one wavefront per
+// row; the test suite's CPU checker states the same iteration operation for operation.  A handful of rows
+// per analysis: no staging, every pass re-reads the row through L2.
+#if DSQ_P < DSQ_WIDE_MIN
+template <int P, bool USE_W>
+__global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
+    const int lane = threadIdx.x;
+    const int m = kp.m;
+    constexpr int N = SymNB<P>::value;
+    const double ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
+    const double bound = 30.0 * ln2;
+    for (int g = blockIdx.x; g < kp.n; g += gridDim.x) {
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double alpha = kp.alpha_hat[g], size = 1.0 / alpha;
+        double lam[P], gam[P], trial[P];
+#pragma unroll
+        for (int c = 0; c < P; c++) {
+            lam[c] = kp.lamnat[c];
+            gam[c] = __builtin_fmin(__builtin_fmax(kp.beta_start[(size_t)g + (size_t)kp.n * c] * ln2, -bound), bound);
+        }
+        auto eta_of = [&](const double (&b)[P], int j) {
+            double eta = kp.x[j] * b[0];
+#pragma unroll
+            for (int c = 1; c < P; c++) eta = __builtin_fma(kp.x[(size_t)c * m + j], b[c], eta);
+            return eta;
+        };
+        auto objective = [&](const double (&b)[P]) {
+            double acc = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                double d = dnbinom_mu_log((double)yg[j], size, nfg[j] * dexp(eta_of(b, j)));
+                if constexpr (USE_W) d = wg[j] * d;
+                acc += d;
+            }
+            const double ll = wave_allreduce(acc);
+            double pen = 0.0;
+#pragma unroll
+            for (int c = 0; c < P; c++) pen = __builtin_fma(0.5 * lam[c], b[c] * b[c], pen);
+            const double f = pen - ll;
+            return dfinite(f) ? f : 1e300;
+        };
+        double F = objective(gam);
+        int converged = 0;
+        for (int it = 0; it < 100 && !converged; it++) {
+            double acc[N + P];
+#pragma unroll
+            for (int i = 0; i < N + P; i++) acc[i] = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                const double mu = nfg[j] * dexp(eta_of(gam, j));
+                double wv, rv;
+                if constexpr (USE_W) { wv = (wg[j] * mu) / (1.0 + alpha * mu); rv = (wg[j] * ((double)yg[j] - mu)) / (1.0 + alpha * mu); }
+                else { wv = mu / (1.0 + alpha * mu); rv = ((double)yg[j] - mu) / (1.0 + alpha * mu); }
+                double xr[P];
+#pragma unroll
+                for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+#pragma unroll
+                    for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
+                    acc[N + a] += xr[a] * rv;
+                }
+            }
+            wave_allreduce_n(acc);
+            LU<P> lu;
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
+            double rhs[P];
+#pragma unroll
+            for (int a = 0; a < P; a++) { lu.a[a][a] = lu.a[a][a] + lam[a]; rhs[a] = acc[N + a] - lam[a] * gam[a]; }
+            lu.factor();
+            lu.solve(rhs);
+            double t = 1.0, Ft = 0.0;
+            int accepted = 0;
+            for (int h = 0; h < 40; h++) {
+#pragma unroll
+                for (int c = 0; c < P; c++) trial[c] = __builtin_fmin(__builtin_fmax(gam[c] + t * rhs[c], -bound), bound);
+                Ft = objective(trial);
+                if (uniform(Ft < F)) { accepted = 1; break; }
+                t = t * 0.5;
+            }
+            if (!accepted) { converged = 1; break; }
+            const double dec = F - Ft;
+#pragma unroll
+            for (int c = 0; c < P; c++) gam[c] = trial[c];
+            F = Ft;
+            if (uniform(dec <= 1e-10 * (__builtin_fabs(F) + 1e-10))) converged = 1;
+        }
+        // (:382-400)
+        double gacc[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) gacc[i] = 0.0;
+        double lacc = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            const double mu = nfg[j] * dexp(eta_of(gam, j));
+            kp.mu_out[(size_t)g * kp.ld + j] = mu;
+            const double muc = __builtin_fmax(mu, kp.minmu);
+            double wv;
+            if constexpr (USE_W) wv = wg[j] / (1.0 / muc + alpha);
+            else wv = 1.0 / (1.0 / muc + alpha);
+            double xr[P];
+#pragma unroll
+            for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
+            double d = dnbinom_mu_log((double)yg[j], size, muc);
+            if constexpr (USE_W) d = wg[j] * d;
+            lacc += d;
+        }
+        wave_allreduce_n(gacc);
+        const double ll = wave_allreduce(lacc);
+        double G[P][P], Gi[P][P], T[P][P], Sg[P][P];
+        {
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = a; b < P; b++) { G[a][b] = gacc[idx]; G[b][a] = gacc[idx]; idx++; }
+            LU<P> lu;
+#pragma unroll
+            for (int a = 0; a < P; a++)
+#pragma unroll
+                for (int b = 0; b < P; b++) lu.a[a][b] = G[a][b];
+#pragma unroll
+            for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lam[a];
+            lu.factor();
+            lu.inverse(Gi);
+        }
+        mat_mul<P>(Gi, G, T);
+        mat_mul<P>(T, Gi, Sg);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < P; c++) {
+                kp.beta[(size_t)g + (size_t)kp.n * c] = log2e * gam[c];
+                kp.betaSE[(size_t)g + (size_t)kp.n * c] = log2e * __builtin_sqrt(__builtin_fmax(Sg[c][c], 0.0));
+            }
+            kp.conv[g] = converged;
+            kp.loglike[g] = ll;
+        }
+    }
+}
+
+template <>
+hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &kp, hipStream_t st) {
+    int grid = kp.n < 4096 ? kp.n : 4096;
+    if (grid < 1) grid = 1;
+    if (kp.useWeights) hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, true>), dim3(grid), dim3(64), 0, st, kp);
+    else hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, false>), dim3(grid), dim3(64), 0, st, kp);
+    return hipGetLastError();
+}
+#else
+template <>
+hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &, hipStream_t) { return hipErrorNotSupported; }
+#endif
+
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.

@@ -185,6 +185,10 @@ class HostEngine:
         """nbinomLogLike, R/core.R:2208-2217"""
         return self.fns.nbinomLogLike(y, mu, disp, weights if useWeights else None, useWeights)
 
+    def optim_rows(self, y, nf, x, alpha, lam, weights, useWeights, beta_start, minmu):
+        """fitNbinomGLMsOptim on the rows handed over (R/fitNbinomGLMs.R:340-407); mu comes back as a host array"""
+        return self.fns.optimRows(y, x, nf, alpha, lam, weights if useWeights else None, useWeights, beta_start, minmu)
+
     def intercept_fit(self, y, nf, alpha, weights, useWeights, mu_floor=0.0, want_hat=True):
         """closed form of the intercept-only model, R/fitNbinomGLMs.R:99-137"""
         return self.fns.interceptFit(y, nf, alpha, weights if useWeights else None, useWeights, mu_floor, want_hat)
@@ -441,6 +445,11 @@ class DeviceEngine:
         dv = self._vec(disp)
         o = self._timed("nbinom_loglike", y.n, lambda: self.native.nbinomLogLike_dev(y, mu, dv, weights, useWeights))
         return LaunchedVector(lambda: self._host(o).numpy())
+
+    def optim_rows(self, y, nf, x, alpha, lam, weights, useWeights, beta_start, minmu):
+        """the handful of rows the IRLS left: gathered rows go through the host-pointer entry point"""
+        return self.native.optimRows(self.to_numpy(y), x, self.to_numpy(nf), alpha, lam,
+                                     self.to_numpy(weights) if useWeights else None, useWeights, beta_start, minmu)
 
     def intercept_fit(self, y, nf, alpha, weights, useWeights, mu_floor=0.0, want_hat=True):
         av = self._vec(np.broadcast_to(np.asarray(alpha, float), (y.n,)))

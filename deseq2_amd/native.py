@@ -236,6 +236,27 @@ def interceptFit(counts, nf, alpha, weights=None, useWeights=False, mu_floor=0.0
     return {"beta": b, "betaSE": se, "mu": mu, "hat_diagonals": hat}
 
 
+def optimRows(counts, x, nf, alpha, lam, weights, useWeights, beta_start, minmu=0.5):
+    """fitNbinomGLMsOptim (R/fitNbinomGLMs.R:340-407) on the given rows through dsq_optim_rows.  lam: prior
+    precisions on the log2 scale; beta_start: log2-scale start values."""
+    y, ytype = _counts(counts)
+    x = _fcol(x); nf = _fcol(nf)
+    n, m = y.shape
+    p = x.shape[1]
+    w = _fcol(weights) if useWeights else None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, np.float64).reshape(-1), (n,)))
+    lam = np.ascontiguousarray(np.asarray(lam, np.float64).reshape(-1))
+    b0 = _fcol(np.asarray(beta_start, np.float64).reshape(n, p))
+    beta = np.zeros((n, p), order="F"); se = np.zeros((n, p), order="F")
+    conv = np.zeros(n, dtype=np.int32); mu = np.zeros((n, m), order="F"); ll = np.zeros(n)
+    args = L.DsqOptimArgs(n=n, m=m, p=p, layout=L.DSQ_LAYOUT_R, ld=0, y=_ptr(y), y_type=ytype, x=_ptr(x), nf=_ptr(nf),
+                          nf_is_vector=0, alpha_hat=_ptr(a), lambda_=_ptr(lam), weights=_ptr(w),
+                          useWeights=int(bool(useWeights)), beta_start=_ptr(b0), minmu=float(minmu))
+    out = L.DsqOptimOut(beta=_ptr(beta), betaSE=_ptr(se), conv=_ptr(conv), mu=_ptr(mu), logLike=_ptr(ll))
+    L.check(L.lib().dsq_optim_rows(C.byref(args), C.byref(out)))
+    return {"beta": beta, "betaSE": se, "conv": conv.astype(bool), "mu": mu, "logLike": ll}
+
+
 _CELL_CACHE = {}
 
 

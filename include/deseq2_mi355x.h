@@ -269,6 +269,38 @@ typedef struct {
 int dsq_intercept_fit(const DsqInterceptArgs *args, const DsqInterceptOut *out);
 int dsq_intercept_fit_dev(const DsqInterceptArgs *args, const DsqInterceptOut *out, void *stream);
 
+/* dsq_optim_rows: fitNbinomGLMsOptim (R/fitNbinomGLMs.R:340-407) -- the rows fitBeta left unconverged (or with NA /
+ * non-positive variance) re-fitted by maximising the penalised NB log posterior over beta in [-30, 30]^p.  The
+ * reference runs stats::optim(method = "L-BFGS-B") per row in R; here one wavefront per row runs a damped
+ * Fisher-scoring iteration on the same objective over the same box.  The caller passes ONLY those rows
+ * (n of them).  lambda: prior precisions on the log2 scale (R's `lambda`); beta_start / beta / betaSE on the log2
+ * scale; conv = optim's convergence == 0; mu = nf 2^(x beta) unclamped (:386); logLike at mu clamped to minmu (:398). */
+typedef struct {
+    int32_t n, m, p;
+    int32_t layout;
+    int64_t ld;
+    const void *y;
+    int32_t y_type;
+    const double *x;
+    const double *nf;
+    int32_t nf_is_vector;
+    const double *alpha_hat;   /* n */
+    const double *lambda;      /* p */
+    const double *weights;
+    int32_t useWeights;
+    const double *beta_start;  /* n x p column-major */
+    double minmu;
+} DsqOptimArgs;
+
+typedef struct {
+    double *beta, *betaSE;     /* n x p column-major */
+    int32_t *conv;             /* n */
+    double *mu;                /* n x m */
+    double *logLike;           /* n */
+} DsqOptimOut;
+
+int dsq_optim_rows(const DsqOptimArgs *args, const DsqOptimOut *out);
+
 /* dsq_parametric_dispersion_fit: parametricDispersionFit (R/core.R:2166-2190), the all-gene Gamma-GLM
  * trend disp ~ asymptDisp + extraPois/mean between the two dispersion passes.  means / disps: n values
  * (the genes with dispGeneEst > 100*minDisp, R/core.R:870).  coefs: 2 doubles.  *status: 0 ok,

@@ -942,6 +942,136 @@ int orc_fit_beta(int n, int m, int p,
     return 0;
 }
 
+/* ================================================ rows the IRLS did not fit ==
+ * R/fitNbinomGLMs.R:340-407 (fitNbinomGLMsOptim): rows with betaConv = FALSE, NA coefficients or a non-positive
+ * variance are re-fitted by maximising the penalised log posterior  sum [w] log NB(y; mu = nf 2^(x beta), 1/alpha) +
+ * sum log N(beta_k; 0, 1/lambda_k)  over beta in [-30, 30]^p.  The reference hands this to stats::optim(method =
+ * "L-BFGS-B") with a numerical gradient -- R's lbfgsb.c is not in the reference tree and its iterates cannot be
+ * reproduced.  The engine maximises the SAME objective over the SAME box with a damped Fisher-scoring iteration
+ * (analytic score X'[w (y - mu)/(1 + alpha mu)] - ridge beta, information X' diag(w mu/(1 + alpha mu)) X + ridge,
+ * step halving until the objective decreases, projection onto the box), which converges to the same optimum; the
+ * test suite checks its objective value against scipy's L-BFGS-B on the same rows.  betaConv = the relative decrease
+ * fell under 1e-10 (or no descent step exists) within 100 iterations (optim's convergence == 0).  Everything after
+ * the optimum -- mu, betaSE from (X'WX + ridge)^-1 X'WX (X'WX + ridge)^-1 at mu clamped to minmu, logLike at the
+ * clamped mu -- follows :382-400.  Natural-log scale inside, log2 in and out like the reference.  Wave-order sums. */
+static double optim_objective(int m, int p, const double *x, const double *yrow, const double *nfrow, const double *wts,
+                              int useWeights, double size, const double *lamnat, const double *gam, int sum_mode) {
+    wsum_t s; wsum_init(&s, sum_mode);
+    for (int j = 0; j < m; j++) {
+        double eta = x[j] * gam[0];
+        for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], gam[c], eta);
+        double d = orc_dnbinom_mu_log(yrow[j], size, nfrow[j] * orc_exp(eta));
+        wsum_add(&s, j, useWeights ? wts[j] * d : d);
+    }
+    double pen = 0.0;
+    for (int c = 0; c < p; c++) pen = fma(0.5 * lamnat[c], gam[c] * gam[c], pen);
+    double f = pen - wsum_total(&s);
+    return isfinite(f) ? f : 1e300;                                             /* :369 */
+}
+
+int orc_optim_rows(int n, int m, int p, const double *y, const double *x, const double *nf, const double *alpha_hat,
+                   const double *lamnat, const double *weights, int useWeights, const double *beta_start, double minmu,
+                   double *beta_out, double *betaSE, int *conv, double *mu_out, double *loglike, int sum_mode) {
+    if (p > ORC_PMAX) return -1;
+    const double ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
+    const double bound = 30.0 * ln2;
+#pragma omp parallel
+    {
+    double *yrow = malloc(sizeof(double) * m), *nfrow = malloc(sizeof(double) * m), *wts = malloc(sizeof(double) * m);
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+        double gam[ORC_PMAX], trial[ORC_PMAX];
+        for (int j = 0; j < m; j++) {
+            yrow[j] = y[i + (long)n * j]; nfrow[j] = nf[i + (long)n * j];
+            wts[j] = weights ? weights[i + (long)n * j] : 1.0;
+        }
+        const double alpha = alpha_hat[i], size = 1.0 / alpha;
+        for (int c = 0; c < p; c++) gam[c] = fmin(fmax(beta_start[i + (long)n * c] * ln2, -bound), bound);
+        double F = optim_objective(m, p, x, yrow, nfrow, wts, useWeights, size, lamnat, gam, sum_mode);
+        int converged = 0;
+        for (int it = 0; it < 100 && !converged; it++) {
+            double G[ORC_PMAX * ORC_PMAX], rhs[ORC_PMAX];
+            for (int a = 0; a < p; a++) {
+                for (int b = a; b < p; b++) {
+                    wsum_t s; wsum_init(&s, sum_mode);
+                    for (int j = 0; j < m; j++) {
+                        double eta = x[j] * gam[0];
+                        for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], gam[c], eta);
+                        double mu = nfrow[j] * orc_exp(eta);
+                        double wv = useWeights ? (wts[j] * mu) / (1.0 + alpha * mu) : mu / (1.0 + alpha * mu);
+                        wsum_add(&s, j, x[j + (long)m * a] * (x[j + (long)m * b] * wv));
+                    }
+                    double v = wsum_total(&s);
+                    G[a * p + b] = v; G[b * p + a] = v;
+                }
+                wsum_t s; wsum_init(&s, sum_mode);
+                for (int j = 0; j < m; j++) {
+                    double eta = x[j] * gam[0];
+                    for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], gam[c], eta);
+                    double mu = nfrow[j] * orc_exp(eta);
+                    double rv = useWeights ? (wts[j] * (yrow[j] - mu)) / (1.0 + alpha * mu) : (yrow[j] - mu) / (1.0 + alpha * mu);
+                    wsum_add(&s, j, x[j + (long)m * a] * rv);
+                }
+                rhs[a] = wsum_total(&s) - lamnat[a] * gam[a];
+            }
+            for (int a = 0; a < p; a++) G[a * p + a] = G[a * p + a] + lamnat[a];
+            int piv[ORC_PMAX]; double rdiag[ORC_PMAX];
+            lu_decomp(p, G, piv, rdiag);
+            lu_solve(p, G, piv, rdiag, rhs);                       /* rhs <- Fisher-scoring step */
+            double t = 1.0, Ft = 0.0;
+            int accepted = 0;
+            for (int h = 0; h < 40; h++) {
+                for (int c = 0; c < p; c++) trial[c] = fmin(fmax(gam[c] + t * rhs[c], -bound), bound);
+                Ft = optim_objective(m, p, x, yrow, nfrow, wts, useWeights, size, lamnat, trial, sum_mode);
+                if (Ft < F) { accepted = 1; break; }
+                t = t * 0.5;
+            }
+            if (!accepted) { converged = 1; break; }               /* no descent along the scoring direction */
+            double dec = F - Ft;
+            for (int c = 0; c < p; c++) gam[c] = trial[c];
+            F = Ft;
+            if (dec <= 1e-10 * (fabs(F) + 1e-10)) converged = 1;
+        }
+        conv[i] = converged;
+        /* :382-400 */
+        double G[ORC_PMAX * ORC_PMAX], Gr[ORC_PMAX * ORC_PMAX], Gi[ORC_PMAX * ORC_PMAX], T[ORC_PMAX * ORC_PMAX], Sg[ORC_PMAX * ORC_PMAX];
+        for (int a = 0; a < p; a++)
+            for (int b = a; b < p; b++) {
+                wsum_t s; wsum_init(&s, sum_mode);
+                for (int j = 0; j < m; j++) {
+                    double eta = x[j] * gam[0];
+                    for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], gam[c], eta);
+                    double muc = fmax(nfrow[j] * orc_exp(eta), minmu);
+                    double wv = useWeights ? wts[j] / (1.0 / muc + alpha) : 1.0 / (1.0 / muc + alpha);
+                    wsum_add(&s, j, x[j + (long)m * a] * (x[j + (long)m * b] * wv));
+                }
+                double v = wsum_total(&s);
+                G[a * p + b] = v; G[b * p + a] = v;
+            }
+        memcpy(Gr, G, sizeof(double) * p * p);
+        for (int a = 0; a < p; a++) Gr[a * p + a] = Gr[a * p + a] + lamnat[a];
+        mat_inverse(p, Gr, Gi, NULL);
+        mat_mul(p, Gi, G, T); mat_mul(p, T, Gi, Sg);
+        wsum_t sl; wsum_init(&sl, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double eta = x[j] * gam[0];
+            for (int c = 1; c < p; c++) eta = fma(x[j + (long)m * c], gam[c], eta);
+            double mu = nfrow[j] * orc_exp(eta);
+            mu_out[i + (long)n * j] = mu;
+            double d = orc_dnbinom_mu_log(yrow[j], size, fmax(mu, minmu));
+            wsum_add(&sl, j, useWeights ? wts[j] * d : d);
+        }
+        loglike[i] = wsum_total(&sl);
+        for (int c = 0; c < p; c++) {
+            beta_out[i + (long)n * c] = log2e * gam[c];
+            betaSE[i + (long)n * c] = log2e * sqrt(fmax(Sg[c * p + c], 0.0));
+        }
+    }
+    free(yrow); free(nfrow); free(wts);
+    }
+    return 0;
+}
+
 /* ======================================================== nbinomLogLike ==
  * R/core.R:2208-2217: rowSums([weights *] dnbinom(counts, mu = mu, size = 1/disp, log = TRUE)).
  * (called from R/fitNbinomGLMs.R:182 and, per model, from nbinomLRT R/core.R:1850-1877)

@@ -281,3 +281,22 @@ def interceptFit(counts, nf, alpha, weights=None, useWeights=False, mu_floor=0.0
                             _p(a), ctypes.c_double(float(mu_floor)), _p(b), _p(se), _p(mu), _p(hat),
                             ctypes.c_int(sum_mode))
     return {"beta": b, "betaSE": se, "mu": mu, "hat_diagonals": hat}
+
+
+def optimRows(counts, x, nf, alpha, lam, weights, useWeights, beta_start, minmu=0.5, sum_mode=0):
+    """fitNbinomGLMsOptim (R/fitNbinomGLMs.R:340-407) on the given rows: damped Fisher scoring on the penalised NB
+    posterior over [-30, 30]^p.  lam: prior precisions on the log2 scale; beta_start: log2-scale start values."""
+    y = _f(counts); x = _f(x); nf = _f(nf)
+    n, m = y.shape; p = x.shape[1]
+    w = _f(weights) if useWeights else None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, float), (n,)))
+    lamnat = np.ascontiguousarray(np.asarray(lam, float) / np.log(2) ** 2)
+    b0 = _f(np.asarray(beta_start, float).reshape(n, p))
+    beta = np.zeros((n, p), order="F"); se = np.zeros((n, p), order="F")
+    conv = np.zeros(n, dtype=np.int32); mu = np.zeros((n, m), order="F"); ll = np.zeros(n)
+    rc = lib().orc_optim_rows(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(p), _p(y), _p(x), _p(nf), _p(a), _p(lamnat),
+                              _p(w), ctypes.c_int(int(bool(useWeights))), _p(b0), ctypes.c_double(float(minmu)),
+                              _p(beta), _p(se), _p(conv), _p(mu), _p(ll), ctypes.c_int(sum_mode))
+    if rc != 0:
+        raise RuntimeError("orc_optim_rows failed: %d" % rc)
+    return {"beta": beta, "betaSE": se, "conv": conv.astype(bool), "mu": mu, "logLike": ll}

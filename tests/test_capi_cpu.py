@@ -34,7 +34,7 @@ def test_struct_layout_matches_header():
     from deseq2_amd import _lib
     names = ["DsqFitBetaArgs", "DsqFitBetaOut", "DsqFitDispArgs", "DsqFitDispOut", "DsqFitDispGridArgs",
              "DsqFitDispGridOut", "DsqPrefitArgs", "DsqPrefitOut", "DsqLogLikeArgs", "DsqInterceptArgs",
-             "DsqInterceptOut", "DsqCooksArgs", "DsqCooksOut", "DsqReplaceArgs", "DsqReplaceOut", "DsqDeseqArgs",
+             "DsqInterceptOut", "DsqOptimArgs", "DsqOptimOut", "DsqCooksArgs", "DsqCooksOut", "DsqReplaceArgs", "DsqReplaceOut", "DsqDeseqArgs",
              "DsqDeseqOut"]
     lines = []
     for nm in names:

@@ -218,3 +218,23 @@ def test_parametric_dispersion_fit_matches_oracle(oracle):
                     "parametricDispersionFit n=%d" % n)
     with pytest.raises(RuntimeError):
         native.parametricDispersionFit(bm, 1e-3 + 0.5 * bm / bm.max())
+
+
+@pytest.mark.parametrize("design,useW", [("two_group", False), ("batch_condition", True), (("factor", 3), False)])
+def test_optim_rows_matches_oracle(oracle, design, useW):
+    """dsq_optim_rows (fitNbinomGLMsOptim's rows, one wavefront each) == the oracle's iteration, every output"""
+    from deseq2_amd import native
+    d = make_case(40, 24, design, seed=12, weights=useW)
+    y = d["counts"].copy()
+    y[3] = 0; y[3, 5:9] = 1000                      # rows the IRLS cannot fit
+    y[11] = 0; y[11, -1] = 7
+    y[20, :12] = 0
+    p = d["x"].shape[1]
+    lam = np.full(p, 1e-6)
+    lam[-1] = 0.5                                   # a coefficient with a real prior
+    start = np.random.default_rng(3).normal(0, 1.0, (y.shape[0], p))
+    args = (y, d["x"], d["nf"], d["alpha_init"], lam, d["weights"], useW, start, 0.5)
+    got, want = native.optimRows(*args), oracle.optimRows(*args)
+    for k in ("beta", "betaSE", "conv", "mu", "logLike"):
+        assert_same(np.asarray(got[k], float), np.asarray(want[k], float), "optimRows$" + k)
+    assert want["conv"].mean() > 0.9

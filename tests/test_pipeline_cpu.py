@@ -278,3 +278,36 @@ def test_weights_failing_rows_count_as_all_zero(oracle):
     assert dds.mcols["weightsFail"][5] and dds.mcols["weightsFail"].sum() == 1
     assert dds.mcols["allZero"][5] and np.isnan(dds.mcols["dispersion"][5])
     assert np.isfinite(np.delete(dds.mcols["dispersion"], 5)).all()
+
+
+def test_optim_rows_against_lbfgsb(oracle):
+    """the rows the IRLS leaves (R/fitNbinomGLMs.R:340-407): the engine's damped Fisher scoring reaches an objective
+    value no worse than L-BFGS-B with optim's settings on the same rows, and the same coefficients where the optimum
+    is well determined (the reference's own non-convergence example is flat along the separating direction)"""
+    x = simulate.design_two_group(10)
+    y = np.array([[0, 0, 0, 0, 0, 1000, 1000, 0, 0, 0],            # tests/testthat/test_optim.R:30-39
+                  [0, 0, 0, 0, 0, 0, 0, 0, 0, 3],
+                  [5, 0, 0, 0, 900, 0, 1, 0, 0, 2000],
+                  [10, 12, 9, 11, 10, 100, 120, 90, 110, 95]], dtype=float)
+    nf = np.ones_like(y)
+    alpha = np.array([0.5, 0.2, 1.0, 0.05])
+    lam = np.full(2, 1e-6)
+    w = np.random.default_rng(1).uniform(0.2, 1.0, y.shape)
+    for useW in (False, True):
+        r = oracle.optimRows(y, x, nf, alpha, lam, w, useW, np.zeros((4, 2)))
+        assert r["conv"].all()
+        for i in range(4):
+            xs, ok, obj = core.fitNbinomGLMsOptim_scipy(y[i], nf[i], x, lam, alpha[i], w[i], useW, np.zeros(2))
+            assert obj(r["beta"][i]) <= obj(xs) + 1e-7 * abs(obj(xs))
+        np.testing.assert_allclose(r["beta"][3], core.fitNbinomGLMsOptim_scipy(y[3], nf[3], x, lam, alpha[3], w[3], useW,
+                                                                               np.zeros(2))[0], rtol=1e-4)
+        mu = nf * 2.0 ** (r["beta"] @ x.T)
+        np.testing.assert_allclose(r["mu"], mu, rtol=1e-12)
+    # and through the chain: the reference's example gene ends with betaConv = TRUE after the fallback
+    d = simulate.make_counts(60, x, seed=2)
+    counts = d["counts"].copy()
+    counts[7] = y[0]
+    dds = core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], engine=HostEngine(oracle))
+    core.DESeq(dds, minReplicatesForReplace=np.inf)
+    assert 7 in set(dds.mcols["rowsForOptim"]) and dds.mcols["betaConv"][7]
+    assert np.isfinite(dds.mcols["beta"][7]).all() and np.isfinite(dds.mcols["betaSE"][7]).all()
