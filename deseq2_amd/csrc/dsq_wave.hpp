@@ -242,4 +242,60 @@ DSQ_UNROLL_P
     return acc;
 }
 
+// ---- distinct counts of a gene ---------------------------------------------------------------------------------------
+// wave-private LDS ordering point (one wave owns the slab: no workgroup barrier needed)
+DSQ_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sort the gene's m counts (bitonic network in the wave's LDS slice buf), keep the first of every run and its length.
+// buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m); on return the distinct values (ascending) are
+// buf[0..nv), their multiplicities buf[m..m+nv); returns nv.  yfun(k) = count of sample k as int32.
+template <class F>
+DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
+    int n2 = 2;
+    while (n2 < m) n2 <<= 1;
+    wave_lds_sync();
+    for (int k = lane; k < n2; k += 64) buf[k] = k < m ? yfun(k) : 0x7fffffff;
+    wave_lds_sync();
+    for (int kk = 2; kk <= n2; kk <<= 1)
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (int t = lane; t < (n2 >> 1); t += 64) {
+                int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                int hi = lo | jj;
+                bool asc = (lo & kk) == 0;
+                int32_t a = buf[lo], c = buf[hi];
+                if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
+            }
+            wave_lds_sync();
+        }
+    int base = 0;
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        const bool valid = k < m;
+        const int32_t v = valid ? buf[k] : 0;
+        const int32_t prev = (valid && k > 0) ? buf[k - 1] : -1;
+        const bool head = valid && (k == 0 || v != prev);
+        const unsigned long long mask = __ballot(head);
+        const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
+        wave_lds_sync();                                  // every lane has read before any lane writes
+        if (head) { buf[rank] = v; buf[m + rank] = k; }
+        base += __popcll(mask);
+        wave_lds_sync();
+    }
+    const int nv = base;
+    for (int i0 = 0; i0 < nv; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < nv;
+        const int s0 = valid ? buf[m + i] : 0;
+        const int s1 = valid ? ((i + 1 < nv) ? buf[m + i + 1] : m) : 0;
+        wave_lds_sync();
+        if (valid) buf[m + i] = s1 - s0;
+        wave_lds_sync();
+    }
+    return nv;
+}
+
 }  // namespace dsq

@@ -475,19 +475,29 @@ DSQ_UNROLL_P
 //     for the NEXT step (the mu-independent part of the NB density is summed once per gene): mu is never stored, so
 //     the kernel has no per-wave LDS slab at all and occupancy is set by registers alone;
 //   * post-loop: X'WX = sum_c S_c x_c x_c', hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c.
-// Sums over samples run cell by cell in wave order over the rank inside the cell.  Arithmetic spec = the CPU checker's
+// Sums over samples run cell by cell in wave order over the position in the cell-sorted sample sequence (so a sweep
+// is ceil(m / 64) FULL trips whatever the cell sizes).  Arithmetic spec = the CPU checker's
 // fit_beta_gene_cells; results are bit-identical to it.
 #ifndef DSQ_BETA_CELL_MINW
 #define DSQ_BETA_CELL_MINW (DSQ_P <= 6 ? 3 : DSQ_P <= 10 ? 2 : 1)
 #endif
 
-// the rarely taken branch of the deviance sweep (a sample off the general branch of the NB density, e.g. a zero
-// count): kept out of line so that its registers do not count against the sweep's
-__device__ __noinline__ static double nb_offbranch(double y, double size, double mu, double st_size, double log_size,
-                                                   int gen_need_const) {
-    double cst = 0.0;
-    if (gen_need_const) cst = dnb_const(y, size, st_size, log_size);
-    return dnbinom_mu_log(y, size, mu) - cst;
+// LDS carve of the cell kernel, in doubles: ints (cell_start, pc) rounded to 16 bytes; per-wave slab
+__host__ __device__ static inline size_t beta_cell_int_doubles(int m) { return (((size_t)DSQ_CMAX + 2 + m + 3) / 4) * 2; }
+__host__ __device__ static inline size_t beta_cell_wave_doubles(int m, bool use_w) {
+    (void)m; (void)use_w;
+    return 4 * (size_t)DSQ_CMAX;
+}
+
+// the rarely taken branch of the deviance sweep (a sample whose log density does not follow the closed split, e.g. a
+// count below 1e-10 size): the full dnbinom_mu, kept out of line so that its registers do not count against the sweep's
+__device__ __noinline__ static double nb_offbranch(double y, double size, double mu) { return dnbinom_mu_log(y, size, mu); }
+
+// 0: log NB(y; size, mu) = K_j + y lg - (y + size) log1p(alpha mu)  (zero counts and the general branch of dnbinom_mu)
+DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
+    const double n = y + size;
+    const bool gen = (y > 0.0) && dfinite(y) && !(y < 1e-10 * size) && (n != size) && dfinite(n);
+    return fast && (y == 0.0 || gen);
 }
 
 template <int P, bool USE_W>
@@ -501,17 +511,25 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
     const int Mrows = C + P;
     const int nwork = DSQ_NWORK(kp);
     if (blockIdx.x * waves >= nwork) return;
-    // block-shared: x_c (C x P doubles) | cell_start (C + 1) | cell_perm (m)
+    // block-shared: x_c (C x P doubles) | cell_start (C + 1) | pc (m: sample | cell << 26, in cell-sorted order);
+    // per wave: cell slab (4 doubles per cell: exp(eta), eta, exp(eta) of the reported means, hat factor)
     double *xcs = smem;
     int32_t *starts = reinterpret_cast<int32_t *>(smem + (size_t)DSQ_CMAX * P);
-    int32_t *perm = starts + DSQ_CMAX + 2;
+    int32_t *pc = starts + DSQ_CMAX + 2;
+    const size_t shared_doubles = (size_t)DSQ_CMAX * P + beta_cell_int_doubles(m);
+    const size_t wave_doubles = beta_cell_wave_doubles(m, USE_W);
+    double *slab = smem + shared_doubles + (size_t)wave * wave_doubles;
     for (int t = threadIdx.x; t <= C; t += blockDim.x) starts[t] = kp.cell_start[t];
-    for (int t = threadIdx.x; t < m; t += blockDim.x) perm[t] = kp.cell_perm[t];
+    for (int c = 0; c < C; c++) {
+        const int s0 = kp.cell_start[c], s1 = kp.cell_start[c + 1];
+        for (int t = s0 + (int)threadIdx.x; t < s1; t += blockDim.x) pc[t] = kp.cell_perm[t] | (c << 26);
+    }
     for (int t = threadIdx.x; t < C * P; t += blockDim.x) {
         const int c = t / P, k = t - c * P;
         xcs[t] = kp.x[(size_t)k * m + kp.cell_perm[kp.cell_start[c]]];
     }
     __syncthreads();
+    const int last_lane_of_tail = (m - 1) & 63;
     double lambda[P], contrast[P];
 #pragma unroll
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
@@ -540,55 +558,84 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 expl = dexp(eta);
             }
         };
-        const bool with_dev_ever = kp.maxit > 0;
-        const double st_size = with_dev_ever ? dstirlerr(size) : 0.0, log_size = with_dev_ever ? dlog(size) : 0.0;
+        const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
+        const bool with_dev_ever = (kp.maxit > 0) && fast;
         double K = 0.0, dev = 0.0;
-        // one sweep over the samples at the current beta
-        auto sweep = [&](bool with_dev, bool with_k) {
-            double dacc = 0.0, kacc = 0.0;
-            for (int c = 0; c < C; c++) {
-                const double e = lane_read(expl, c), eta = lane_read(etal, c);
-                const int s0 = starts[c], s1 = starts[c + 1];
-                double a1 = 0.0, a2 = 0.0;
-                for (int k = s0 + lane; k < s1; k += 64) {
-                    const int j = perm[k];
+        // the mu-independent part of the log densities, once per gene (samples in their natural order):
+        // K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j,  n = y + size;  0 for y = 0
+        if (with_dev_ever) {
+            const double st_size = dstirlerr(size), log_size = dlog(size);
+            double kacc = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                const double y = (double)yg[j];
+                double kj = 0.0;
+                if (y != 0.0 && cell_dev_closed(y, size, fast)) {
+                    const double n = y + size;
+                    kj = dnb_const(y, size, st_size, log_size) + ((n * dlog1p(alpha * y) - y * dlog(y)) + y * dlog(nfg[j]));
+                }
+                if constexpr (USE_W) kacc += wg[j] * kj;
+                else kacc += kj;
+            }
+            K = wave_allreduce(kacc);
+        }
+        // one sweep over the samples at the current beta: positions k = lane, lane + 64, ... of the cell-sorted
+        // sequence (full trips); the sums of a cell are closed when the sweep leaves it.  Deviance term of a sample:
+        // y lg - (y + size) log1p(alpha mu), lg = log(mu / nf) -- one logarithm (of the rounded 1 + alpha mu, plus
+        // its rounding residual) per sample and iteration
+        auto sweep = [&](bool with_dev) {
+            wave_lds_sync();
+            if (lane < C) { slab[4 * lane] = expl; slab[4 * lane + 1] = etal; }
+            wave_lds_sync();
+            double dacc = 0.0;
+            double a1 = 0.0, a2 = 0.0;
+            int cur = 0;
+            auto close_cell = [&]() {
+                const double s = wave_allreduce(a1), tt = wave_allreduce(a2);
+                if (lane == cur) { Sl = s; Tl = tt; }
+                a1 = 0.0; a2 = 0.0;
+            };
+            for (int k0 = 0; k0 < m; k0 += 64) {
+                const int k = k0 + lane;
+                const bool valid = k < m;
+                const int pk = pc[valid ? k : m - 1];
+                const int j = pk & 0x3ffffff, cmy = valid ? (pk >> 26) : -1;
+                double wv = 0.0, wz = 0.0;
+                if (valid) {
+                    const double e = slab[4 * cmy], eta = slab[4 * cmy + 1];
                     const double nf = nfg[j], y = (double)yg[j];
                     const double raw = nf * e;
                     const double mu = __builtin_fmax(raw, minmu);
-                    double wv;
-                    if constexpr (USE_W) wv = (wg[j] * mu) / (1.0 + alpha * mu);
-                    else wv = mu / (1.0 + alpha * mu);
+                    const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
+                    if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
+                    else wv = mu * rcp;
                     const double lg = (raw >= minmu) ? eta : dlog(mu / nf);
                     const double zj = lg + (y - mu) / mu;
-                    a1 += wv;
-                    a2 += wv * zj;
-                    if (with_dev || with_k) {
-                        const bool gen = dnb_general(y, size);
-                        double cst = 0.0;
-                        if (with_k) {
-                            if (gen) cst = dnb_const(y, size, st_size, log_size);
-                            if constexpr (USE_W) kacc += wg[j] * cst;
-                            else kacc += cst;
-                        }
-                        if (with_dev) {
-                            double t, itv;
-                            if (gen && dnb_iter(y, size, mu, itv)) t = itv;
-                            else if (gen && with_k) t = dnbinom_mu_log(y, size, mu) - cst;     // (the start sweep has no deviance)
-                            else t = nb_offbranch(y, size, mu, st_size, log_size, gen ? 1 : 0);
-                            if constexpr (USE_W) dacc += wg[j] * t;
-                            else dacc += t;
-                        }
+                    wz = wv * zj;
+                    if (with_dev) {
+                        double t;
+                        if (cell_dev_closed(y, size, fast)) {
+                            const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
+                            t = y * lg - (y + size) * l1p;
+                        } else t = nb_offbranch(y, size, mu);
+                        if constexpr (USE_W) dacc += wg[j] * t;
+                        else dacc += t;
                     }
                 }
-                const double s = wave_allreduce(a1), tt = wave_allreduce(a2);
-                if (lane == c) { Sl = s; Tl = tt; }
+                const int c_lo = __builtin_amdgcn_readfirstlane(cmy);
+                const int c_hi = __builtin_amdgcn_readlane(cmy, (k0 + 64 <= m) ? 63 : last_lane_of_tail);
+                for (int c = c_lo; c <= c_hi; c++) {
+                    if (c != cur) { close_cell(); cur = c; }
+                    const bool mine = cmy == c;
+                    a1 += mine ? wv : 0.0;
+                    a2 += mine ? wz : 0.0;
+                }
             }
-            if (with_k) K = wave_allreduce(kacc);
+            close_cell();
             if (with_dev) dev = -2.0 * (K + wave_allreduce(dacc));
         };
 
         cell_eta();
-        sweep(false, with_dev_ever);
+        sweep(false);
         double dev_old = 0.0, it = 0.0;
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
@@ -675,7 +722,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
             if (uniform(toolarge > 0)) { it = (double)kp.maxit; expl = exp_prev; break; }          // (:357-360)
             cell_eta();
-            sweep(true, false);
+            sweep(true);
             const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
             if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }                  // (:375-378)
             if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
@@ -706,36 +753,37 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         }
         if (kp.hat_diagonals || kp.mu_out) {
             // fitted means from the FINAL coefficients (also when they diverged), as the general kernel reports them
-            double eo = 0.0;
+            wave_lds_sync();
             if (lane < C) {
                 double eta = xcs[lane * P] * beta[0];
 #pragma unroll
                 for (int k = 1; k < P; k++) eta = __builtin_fma(xcs[lane * P + k], beta[k], eta);
-                eo = dexp(eta);
-            }
-            for (int c = 0; c < C; c++) {
                 double h = 0.0;
 #pragma unroll
                 for (int i1 = 0; i1 < P; i1++)
 #pragma unroll
-                    for (int i2 = 0; i2 < P; i2++) h += xcs[c * P + i1] * (xcs[c * P + i2] * Gi[i2][i1]);
-                const double e = lane_read(expl, c), eout = lane_read(eo, c);
-                const int s0 = starts[c], s1 = starts[c + 1];
-                for (int k = s0 + lane; k < s1; k += 64) {
-                    const int j = perm[k];
-                    const double nf = nfg[j];
-                    if (kp.hat_diagonals) {
-                        const double mu = __builtin_fmax(nf * e, minmu);
-                        double wv;
-                        if constexpr (USE_W) wv = (wg[j] * mu) / (1.0 + alpha * mu);
-                        else wv = mu / (1.0 + alpha * mu);
-                        kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * h;
-                    }
-                    if (kp.mu_out) {
-                        double v = nf * eout;
-                        if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
-                        kp.mu_out[(size_t)g * kp.ld + j] = v;
-                    }
+                    for (int i2 = 0; i2 < P; i2++) h += xcs[lane * P + i1] * (xcs[lane * P + i2] * Gi[i2][i1]);
+                slab[4 * lane] = expl;
+                slab[4 * lane + 2] = dexp(eta);
+                slab[4 * lane + 3] = h;
+            }
+            wave_lds_sync();
+            for (int k = lane; k < m; k += 64) {
+                const int pk = pc[k];
+                const int j = pk & 0x3ffffff, c = pk >> 26;
+                const double nf = nfg[j];
+                if (kp.hat_diagonals) {
+                    const double mu = __builtin_fmax(nf * slab[4 * c], minmu);
+                    const double rcp = 1.0 / (1.0 + alpha * mu);
+                    double wv;
+                    if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
+                    else wv = mu * rcp;
+                    kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * slab[4 * c + 3];
+                }
+                if (kp.mu_out) {
+                    double v = nf * slab[4 * c + 2];
+                    if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
+                    kp.mu_out[(size_t)g * kp.ld + j] = v;
                 }
             }
         }
@@ -769,8 +817,8 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
 
 template <int P>
 static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) {
-    const size_t lds = (size_t)DSQ_CMAX * P * sizeof(double) + ((size_t)DSQ_CMAX + 2 + kp.m) * sizeof(int32_t);
     const int waves = 4;
+    const size_t lds = ((size_t)DSQ_CMAX * P + beta_cell_int_doubles(kp.m) + waves * beta_cell_wave_doubles(kp.m, kp.useWeights != 0)) * sizeof(double);
     const void *fn = kp.useWeights ? (const void *)fit_beta_cell_kernel<P, true> : (const void *)fit_beta_cell_kernel<P, false>;
     static thread_local int bpc_cache[2];
     static thread_local size_t lds_cache[2];

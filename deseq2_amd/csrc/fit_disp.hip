@@ -74,53 +74,10 @@ struct DispGene {
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
         if constexpr (USE_W) { dv = dc = nullptr; nv = 0; return; }
-        int n2 = 2;
-        while (n2 < m) n2 <<= 1;
-        lds_sync();
-        for (int k = lane; k < n2; k += 64) buf[k] = k < m ? (int32_t)r.y(k) : 0x7fffffff;
-        lds_sync();
-        for (int kk = 2; kk <= n2; kk <<= 1)
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int t = lane; t < (n2 >> 1); t += 64) {
-                    int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                    int hi = lo | jj;
-                    bool asc = (lo & kk) == 0;
-                    int32_t a = buf[lo], c = buf[hi];
-                    if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
-                }
-                lds_sync();
-            }
-        int base = 0;
-        for (int k0 = 0; k0 < m; k0 += 64) {
-            const int k = k0 + lane;
-            const bool valid = k < m;
-            const int32_t v = valid ? buf[k] : 0;
-            const int32_t prev = (valid && k > 0) ? buf[k - 1] : -1;
-            const bool head = valid && (k == 0 || v != prev);
-            const unsigned long long mask = __ballot(head);
-            const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
-            lds_sync();                                  // every lane has read before any lane writes
-            if (head) { buf[rank] = v; buf[m + rank] = k; }
-            base += __popcll(mask);
-            lds_sync();
-        }
-        nv = base;
-        for (int i0 = 0; i0 < nv; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < nv;
-            const int s0 = valid ? buf[m + i] : 0;
-            const int s1 = valid ? ((i + 1 < nv) ? buf[m + i + 1] : m) : 0;
-            lds_sync();
-            if (valid) buf[m + i] = s1 - s0;
-            lds_sync();
-        }
+        nv = wave_distinct_counts(buf, m, lane, [&](int k) { return (int32_t)r.y(k); });
         dv = buf; dc = buf + m;
     }
-    DSQ_DEV static void lds_sync() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    DSQ_DEV static void lds_sync() { wave_lds_sync(); }
 
     DSQ_DEV bool keep_row(int j) const {
         if constexpr (USE_W) return r.w(j) > thr;

@@ -17,12 +17,6 @@
 
 namespace dsq {
 
-DSQ_DEV void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ascending bitonic sort of b[0..n2), n2 a power of two >= 2, by one wavefront
 DSQ_DEV void wave_sort(double *b, int n2, int lane) {
     wave_lds_sync();

@@ -586,6 +586,16 @@ static int design_cells(int m, int p, const double *x, int cmax, int *perm, int 
 
 static void householder_ls(int M, int p, double *A, double *b, double *beta, int serial);
 
+/* 0: the sample's log density follows the closed split of fit_beta_gene_cells (a zero count, or a count on the general
+ * branch of dnbinom_mu); 1: evaluate dnbinom_mu in full (tiny count / size ratios, degenerate size) */
+static int cell_dev_class(double y, double size, int fast) {
+    if (!fast) return 1;
+    if (y == 0.0) return 0;
+    const double n = y + size;
+    const int gen = (y > 0.0) && isfinite(y) && !(y < 1e-10 * size) && (n != size) && isfinite(n);
+    return gen ? 0 : 1;
+}
+
 /* fitBeta in CELL MODE (at most ORC_CMAX design cells).  Within a cell every sample has the same design row x_c, so
  *   - the linear predictor is one value eta_c per cell, mu_j = max(nf_j exp(eta_c), minmu)       (:324-327, bits as
  *     in the general path);
@@ -593,12 +603,17 @@ static void householder_ls(int M, int p, double *A, double *b, double *beta, int
  *     T_c = sum_{j in c} w_j z_j: it is solved on the COLLAPSED (C + p) x p system with rows sqrt(S_c) x_c and
  *     right-hand side T_c / sqrt(S_c) -- the normal equations X'WX + ridge, X'Wz of :344-356 / :398 -- by the same
  *     Householder QR (useQR) or LU; z_j = eta_c + (y_j - mu_j)/mu_j where mu_j is not clamped (log(mu/nf) = eta_c);
- *   - the deviance -2 sum [wts] log NB(y; 1/alpha, mu) splits into the mu-independent constants K (summed once per
- *     gene) and the two bd0 terms per sample and iteration: dev = -2 (K + D);
+ *   - the deviance -2 sum [wts] log NB(y; 1/alpha, mu): on the saddle-point form of dnbinom_mu the two bd0 terms are
+ *     -bd0(size, n p) - bd0(y, n q) = -n [log1p(alpha mu) - log1p(alpha y)] - y [log y - log mu]  (n = y + size), so
+ *     log f_j = K_j + y_j lg_j - n_j log1p(alpha mu_j)  with lg_j = log(mu_j / nf_j) (the value z_j already uses) and
+ *     K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j  independent of mu; K = sum K_j once
+ *     per gene, one logarithm per sample and iteration: dev = -2 (K + D).  (y = 0: K_j = 0, same D_j.)  The split
+ *     keeps every logarithm on an argument that carries full relative accuracy (log1p forms), so dev agrees with the
+ *     bd0 evaluation to ~1e-14 relative -- six orders below the convergence tolerance it is compared with;
  *   - post-loop: X'WX = sum_c S_c x_c x_c', hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c.
- * Sums over the samples run cell by cell, in wave order over the RANK of the sample inside its cell (partial l takes
- * the members of rank l, l+64, ...; the 64 partials of a per-gene sum -- the deviance, K -- keep accumulating across
- * the cells in cell order).  Every convergence rule is that of the general path.                                */
+ * Sums over the samples run cell by cell, in wave order over the POSITION k of the sample in the cell-sorted sequence
+ * (partial k mod 64; the 64 partials of the deviance keep accumulating across the cells); K runs over the samples in
+ * their natural order.  Every convergence rule is that of the general path.                                */
 static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int *start, const double *xc,
                                 const double *yrow, const double *nfrow, const double *wts, int useWeights,
                                 double alpha, const double *lambda, const double *contrast, double *beta_hat,
@@ -616,39 +631,53 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
             eta_c[c] = eta; exp_c[c] = orc_exp(eta); }
     /* one sweep over the samples at the current beta: S_c, T_c (for the next least squares / the post-loop block)
      * and, when asked, the deviance parts */
-    #define CELL_SWEEP(WITH_DEV, WITH_K) do { \
-        wsum_t sd, sk; wsum_init(&sd, sum_mode); wsum_init(&sk, sum_mode); \
+    #define CELL_SWEEP(WITH_DEV) do { \
+        wsum_t sd; wsum_init(&sd, sum_mode); \
         for (int c = 0; c < C; c++) { \
             wsum_t s1, s2; wsum_init(&s1, sum_mode); wsum_init(&s2, sum_mode); \
             for (int k = start[c]; k < start[c + 1]; k++) { \
-                const int j = perm[k], r = k - start[c]; \
+                const int j = perm[k], r = k;   /* wave order over the position in the cell-sorted sequence */ \
                 const double raw = nfrow[j] * exp_c[c]; \
                 const double mu = fmax(raw, minmu); \
-                const double wv = useWeights ? (wts[j] * mu) / (1.0 + alpha * mu) : mu / (1.0 + alpha * mu); \
+                const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm; \
+                const double wv = useWeights ? (wts[j] * mu) * rcp : mu * rcp; \
                 const double lg = (raw >= minmu) ? eta_c[c] : orc_log(mu / nfrow[j]); \
                 const double zj = lg + (yrow[j] - mu) / mu; \
                 wsum_add(&s1, r, wv); wsum_add(&s2, r, wv * zj); \
-                if (WITH_DEV || WITH_K) { \
-                    double cst, itv; \
-                    const int gen = orc_dnb_const(yrow[j], size, st_size, log_size, &cst); \
-                    if (WITH_K) wsum_add(&sk, r, useWeights ? wts[j] * cst : cst); \
-                    if (WITH_DEV) { \
-                        double t; \
-                        if (gen && orc_dnb_iter(yrow[j], size, mu, &itv)) t = itv; \
-                        else t = orc_dnbinom_mu_log(yrow[j], size, mu) - cst; \
-                        wsum_add(&sd, r, useWeights ? wts[j] * t : t); \
-                    } \
+                if (WITH_DEV) { \
+                    double t; \
+                    if (cell_dev_class(yrow[j], size, fast) == 0) { \
+                        /* log1p(alpha mu) from the rounded 1 + alpha mu and its rounding residual */ \
+                        const double l1p = orc_log(opm) + (am - (opm - 1.0)) * rcp; \
+                        t = yrow[j] * lg - (yrow[j] + size) * l1p; \
+                    } else t = orc_dnbinom_mu_log(yrow[j], size, mu); \
+                    wsum_add(&sd, r, useWeights ? wts[j] * t : t); \
                 } \
             } \
             Sc[c] = wsum_total(&s1); Tc[c] = wsum_total(&s2); \
         } \
-        if (WITH_K) K = wsum_total(&sk); \
         if (WITH_DEV) dev = -2.0 * (K + wsum_total(&sd)); \
     } while (0)
-    const double st_size = orc_stirlerr(size), log_size = orc_log(size);
+    const int fast = (alpha > 0.0) && isfinite(alpha) && isfinite(size) && (size > 0.0);
+    const double st_size = (maxit > 0 && fast) ? orc_stirlerr(size) : 0.0, log_size = (maxit > 0 && fast) ? orc_log(size) : 0.0;
     double dev = 0.0, dev_old = 0.0, it = 0.0;
+    if (maxit > 0 && fast) {
+        /* the mu-independent part, once per gene, samples in their natural order */
+        wsum_t sk; wsum_init(&sk, sum_mode);
+        for (int j = 0; j < m; j++) {
+            double kj = 0.0;
+            if (yrow[j] != 0.0 && cell_dev_class(yrow[j], size, fast) == 0) {
+                double cst;
+                orc_dnb_const(yrow[j], size, st_size, log_size, &cst);
+                const double y = yrow[j], n = y + size;
+                kj = cst + ((n * orc_log1p(alpha * y) - y * orc_log(y)) + y * orc_log(nfrow[j]));
+            }
+            wsum_add(&sk, j, useWeights ? wts[j] * kj : kj);
+        }
+        K = wsum_total(&sk);
+    }
     CELL_ETA();
-    CELL_SWEEP(0, 1);
+    CELL_SWEEP(0);
     for (int t = 0; t < maxit; t++) {
         it += 1.0;
         for (int c = 0; c < C; c++) exp_prev[c] = exp_c[c];
@@ -689,7 +718,7 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
             break;
         }
         CELL_ETA();
-        CELL_SWEEP(1, 0);
+        CELL_SWEEP(1);
         double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);
         if (isnan(conv_test)) { it = (double)maxit; break; }
         if ((t > 0) & (conv_test < tol)) break;
@@ -714,7 +743,8 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
         for (int k = start[c]; k < start[c + 1]; k++) {
             const int j = perm[k];
             const double mu = fmax(nfrow[j] * exp_c[c], minmu);
-            const double wv = useWeights ? (wts[j] * mu) / (1.0 + alpha * mu) : mu / (1.0 + alpha * mu);
+            const double rcp = 1.0 / (1.0 + alpha * mu);
+            const double wv = useWeights ? (wts[j] * mu) * rcp : mu * rcp;
             hat[j] = wv * h;
         }
     }
@@ -806,7 +836,7 @@ int orc_fit_beta(int n, int m, int p,
     double *wts = malloc(sizeof(double) * m), *mu = malloc(sizeof(double) * m);
     double *w_vec = malloc(sizeof(double) * m), *w_sqrt = malloc(sizeof(double) * m);
     double *z = malloc(sizeof(double) * m);
-    double *A = malloc(sizeof(double) * (size_t)M * p), *bb = malloc(sizeof(double) * M);
+    double *A = malloc(sizeof(double) * ((size_t)M * p + (size_t)(ORC_CMAX + p) * p + 2 * (size_t)m)), *bb = malloc(sizeof(double) * (M + ORC_CMAX));
 #pragma omp for schedule(static)
     for (int i = 0; i < n; i++) {                                                /* :319 */
         double beta_hat[ORC_PMAX];
