@@ -58,7 +58,7 @@ const Tuning &tuning() {
                        env_int("DSQ_DISP_WAVES", 4), env_int("DSQ_DISP_STAGE", -1), env_int("DSQ_DISP_BPC", 0),
                        env_int("DSQ_DISP_LDS_KB", 160), env_int("DSQ_ABLATE", 0), env_int("DSQ_FORCE_ITERS", 0),
                        env_int("DSQ_DISP_XLDS", 1), env_int("DSQ_BETA_XLDS", 1), env_int("DSQ_DYNAMIC", 1),
-                       env_int("DSQ_BETA_CELLS", 1)};
+                       env_int("DSQ_BETA_CELLS", 1), env_int("DSQ_DISP_CELL_MINP", DSQ_DISP_CELL_MINP)};
     return t;
 }
 
@@ -490,7 +490,7 @@ static int disp_common(int n, int m, int p, int layout, long ld_in, const void *
     }
     kp->x = x;
     kp->useWeights = useWeights ? 1 : 0;
-    if (cell_of && ncell > 0 && p >= DSQ_DISP_CELL_MINP)
+    if (cell_of && ncell > 0 && p >= tuning().disp_cell_minp)
         kp->ncell = capi_upload_cells(cell_of, m, WS_CELLS_BETA, st, &kp->cell_perm, &kp->cell_start);
     if (is_wide(p)) {           // zero-padded design, unit diagonal on the padding in the Cox-Reid matrix
         rc = wide_pad_x(m, p, x, st, &kp->x, &kp->padmask);

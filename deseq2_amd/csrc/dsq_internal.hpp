@@ -213,6 +213,7 @@ struct Tuning {
     int disp_xlds, beta_xlds;
     int dynamic;             // DSQ_DYNAMIC (default 1): dynamic gene scheduling in the fit kernels
     int beta_cells;          // DSQ_BETA_CELLS (default 1): cell-collapsed fitBeta for designs with <= DSQ_CMAX cells
+    int disp_cell_minp;      // DSQ_DISP_CELL_MINP (profiling; default = the macro): fitDisp cell mode from this width up
 };
 const Tuning &tuning();
 

@@ -21,13 +21,11 @@ namespace dsq {
 struct RowsLds {
     const int32_t *y_;   // m (counts stay int32 in LDS: 4 B/sample)
     const double *mu_;   // m
-    const double *imu_;  // m: 1/mu, computed once per gene (it does not depend on alpha)
     const double *w_;    // m or nullptr
     const double *x_;    // p x m (column c at x_ + c*m)
     int m;
     DSQ_DEV double y(int j) const { return (double)y_[j]; }
     DSQ_DEV double mu(int j) const { return mu_[j]; }
-    DSQ_DEV double inv_mu(int j) const { return imu_[j]; }
     DSQ_DEV double w(int j) const { return w_[j]; }
     DSQ_DEV double x(int j, int c) const { return x_[c * m + j]; }
 };
@@ -40,7 +38,6 @@ struct RowsGlobal {
     int m;
     DSQ_DEV double y(int j) const { return (double)y_[j]; }
     DSQ_DEV double mu(int j) const { return mu_[j]; }
-    DSQ_DEV double inv_mu(int j) const { return 1.0 / mu_[j]; }
     DSQ_DEV double w(int j) const { return w_[j]; }
     DSQ_DEV double x(int j, int c) const { return x_[c * m + j]; }
 };

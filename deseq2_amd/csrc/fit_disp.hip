@@ -60,7 +60,8 @@ struct DispGene {
     // per DISTINCT count (often a handful) instead of once per sample
     const int32_t *dv, *dc;
     int nv;
-    // design cells (block-shared LDS): samples grouped by cell / cell offsets; C = 0 -> general per-sample Gram
+    // design cells (block-shared LDS): cperm[k] = sample | cell << 26 at position k of the cell-sorted sequence, cell
+    // offsets; C = 0 -> general per-sample Gram
     const int32_t *cperm, *cstart;
     int C;
     template <class T>
@@ -100,38 +101,61 @@ DSQ_UNROLL_P
         }
     }
 
-    // K matrices X' diag(wd_k) X over the kept rows; wfun(1/mu, wd[K]) gives the diagonals.
-    // A dropped column contributes exact zeros; putting 1 on its diagonal in the first
-    // matrix leaves det / inverse / traces equal to those of the compacted matrix.
+    // ONE pass over the samples of the gene.  f(j, wd, lik): the caller's per-sample work -- when lik, add the sample's
+    // likelihood terms to the caller's own running sums (f captures them); when useCR, also return in wd[0..K) the
+    // sample's diagonals of the K Cox-Reid matrices X' diag(wd_k) X, which the pass accumulates over the kept rows.
+    // The diagonals come from the reciprocal the likelihood needs anyway (w = mu r, r = 1 / (1 + mu alpha)), so a fused
+    // pass costs one division and one logarithm per sample.  Order of the samples: their natural order, or -- CELL MODE --
+    // the cell-sorted sequence (position k, partial k mod 64, for the caller's sums as well).
+    // A dropped column contributes exact zeros; putting 1 on its diagonal in the first matrix leaves det / inverse /
+    // traces equal to those of the compacted matrix.
     template <int K, class F>
-    DSQ_DEV void gram(F &&wfun, double (&B)[K][P][P]) const {
+    DSQ_DEV void pass(F &&f, double (&B)[K][P][P]) const {
         if (C > 0) {
-            // CELL MODE: X' diag(wd) X = sum_c S_c x_c x_c', S_c = sum of wd over the kept samples of cell c (wave
-            // order over the rank inside the cell; lane c keeps S_c), outer products added serially in cell order.
+            // CELL MODE: X' diag(wd) X = sum_c S_c x_c x_c', S_c = sum of wd over the kept samples of cell c (lane c keeps
+            // S_c; a cell's sums are closed when the sweep leaves it), outer products added serially in cell order.
             // Per sample: K additions instead of K p(p+1)/2 multiply-adds; K C wave reductions instead of K p(p+1)/2.
-            double Sl[K];
+            double Sl[K], acc[K];
             _Pragma("unroll")
-            for (int k = 0; k < K; k++) Sl[k] = 0.0;
-            for (int c = 0; c < C; c++) {
-                const int s0 = cstart[c], s1 = cstart[c + 1];
-                double acc[K];
-                _Pragma("unroll")
-                for (int k = 0; k < K; k++) acc[k] = 0.0;
-                for (int kk = s0 + lane; kk < s1; kk += 64) {
-                    const int j = cperm[kk];
-                    double wd[K];
-                    wfun(r.inv_mu(j), wd);
-                    if (keep_row(j)) {
-                        _Pragma("unroll")
-                        for (int k = 0; k < K; k++) acc[k] += wd[k];
-                    }
-                }
+            for (int k = 0; k < K; k++) { Sl[k] = 0.0; acc[k] = 0.0; }
+            int cur = 0;
+            auto close_cell = [&]() {
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++) {
                     const double v = wave_allreduce(acc[k]);
-                    if (lane == c) Sl[k] = v;
+                    if (lane == cur) Sl[k] = v;
+                    acc[k] = 0.0;
+                }
+            };
+            const int tail_lane = (m - 1) & 63;
+            for (int k0 = 0; k0 < m; k0 += 64) {
+                const int kk = k0 + lane;
+                const bool valid = kk < m;
+                const int pk = cperm[valid ? kk : m - 1];
+                const int j = pk & 0x3ffffff, cmy = valid ? (pk >> 26) : -1;
+                double wd[K];
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++) wd[k] = 0.0;
+                if (valid) {
+                    f(j, wd, true);
+                    if (!keep_row(j)) {
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) wd[k] = 0.0;
+                    }
+                }
+                if (useCR) {
+                    const int c_lo = __builtin_amdgcn_readfirstlane(cmy);
+                    const int c_hi = __builtin_amdgcn_readlane(cmy, (k0 + 64 <= m) ? 63 : tail_lane);
+                    for (int c = c_lo; c <= c_hi; c++) {
+                        if (c != cur) { close_cell(); cur = c; }
+                        const bool mine = cmy == c;
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) acc[k] += mine ? wd[k] : 0.0;
+                    }
                 }
             }
+            if (!useCR) return;
+            close_cell();
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
@@ -139,7 +163,7 @@ DSQ_UNROLL_P
                     _Pragma("unroll")
                     for (int k = 0; k < K; k++) B[k][a][b] = 0.0;
             for (int c = 0; c < C; c++) {
-                const int j0 = cperm[cstart[c]];
+                const int j0 = cperm[cstart[c]] & 0x3ffffff;
                 double sc[K];
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
@@ -167,11 +191,19 @@ DSQ_UNROLL_P
             }
             return;
         }
+        if (!useCR) {
+            for (int j = lane; j < m; j += 64) {
+                double wd[K];
+                f(j, wd, true);
+            }
+            return;
+        }
         if constexpr (P >= DSQ_WIDE_MIN) {
             // WIDE build: K * P(P+1)/2 per-lane running sums do not fit in registers, and as a dynamically indexed
             // array they would live in scratch memory.  Two matrix rows per pass over the samples instead, the pass loop
             // and the column loops fully unrolled so that the sums of a pass ARE registers; the diagonals are
-            // recomputed per pass (a division per sample).  Same terms, same order per entry, same wave reduction.
+            // recomputed per pass (a division per sample), the caller's likelihood terms added in the first pass only.
+            // Same terms, same order per entry, same wave reduction.
             constexpr int RB = 2;
             _Pragma("unroll")
             for (int a0 = 0; a0 < P; a0 += RB) {
@@ -184,7 +216,7 @@ DSQ_UNROLL_P
                         for (int b = 0; b < P; b++) acc[k][i][b] = 0.0;
                 for (int j = lane; j < m; j += 64) {
                     double wd[K];
-                    wfun(r.inv_mu(j), wd);
+                    f(j, wd, a0 == 0);
                     if (keep_row(j)) {
                         double xr[P];
                         _Pragma("unroll")
@@ -215,7 +247,7 @@ DSQ_UNROLL_P
             for (int i = 0; i < K * N; i++) acc[i] = 0.0;
             for (int j = lane; j < m; j += 64) {
                 double wd[K];
-                wfun(r.inv_mu(j), wd);
+                f(j, wd, true);
                 if (keep_row(j)) {
                     double xr[P];
 DSQ_UNROLL_P
@@ -252,46 +284,51 @@ DSQ_UNROLL_P
         }
     }
 
-    // log_posterior, src/DESeq2.cpp:31-64
+    // log_posterior, src/DESeq2.cpp:31-64.  log(mu + 1/alpha) = log(1 + mu alpha) - log alpha: one logarithm per sample;
+    // without weights the lgamma terms run over the distinct counts (:53,55 regrouped; the CPU checker states the same)
     DSQ_DEV double lp(double la) const {
-        double alpha = dexp(la);
+        const double alpha = dexp(la);
+        const double an1 = 1.0 / alpha;
+        const double lg_an1 = dlgamma(an1);
+        double acc = 0.0;
         double cr_term = 0.0;
-        if (useCR) {
+        {
             DSQ_WORK_SCOPE;
             DSQ_WORK(DsqMat1, B);
-            gram<1>([&](double imu, double(&wd)[1]) { wd[0] = 1.0 / (imu + alpha); }, B);
-            DSQ_WORK(LU<P>, lu);
+            pass<1>(
+                [&](int j, double(&wd)[1], bool lik) {
+                    const double y = r.y(j), mu = r.mu(j);
+                    const double opm = 1.0 + mu * alpha;
+                    if (useCR) wd[0] = mu * (1.0 / opm);
+                    if (lik) {
+                        const double l1 = dlog(opm);
+                        if constexpr (USE_W) {
+                            const double t = dlgamma(y + an1) - lg_an1 - y * (l1 - la) - an1 * l1;
+                            acc += r.w(j) * t;
+                        } else {
+                            acc += -(y * (l1 - la)) - an1 * l1;
+                        }
+                    }
+                },
+                B);
+            if (useCR) {
+                DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
+                for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-            lu.factor();
-            cr_term = -0.5 * dlog(lu.det());
+                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                lu.factor();
+                cr_term = -0.5 * dlog(lu.det());
+            }
             DSQ_WORK_END;
         }
-        double an1 = 1.0 / alpha;
-        double lg_an1 = dlgamma(an1);
-        // log(mu + 1/alpha) = log(1 + mu alpha) - log alpha: one logarithm per sample; without weights the lgamma terms
-        // run over the distinct counts (src/DESeq2.cpp:53,55 regrouped; the CPU checker states the same grouping)
-        double acc = 0.0;
         double ll_part;
         if constexpr (USE_W) {
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double l1 = dlog(1.0 + mu * alpha);
-                double t = dlgamma(y + an1) - lg_an1 - y * (l1 - la) - an1 * l1;
-                acc += r.w(j) * t;
-            }
             ll_part = wave_allreduce(acc);
         } else {
             double accv = 0.0;
             for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dlgamma((double)dv[i] + an1) - lg_an1);
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double l1 = dlog(1.0 + mu * alpha);
-                acc += -(y * (l1 - la)) - an1 * l1;
-            }
-            double sv = wave_allreduce(accv);
+            const double sv = wave_allreduce(accv);
             ll_part = sv + wave_allreduce(acc);
         }
         double prior_part = 0.0;
@@ -304,78 +341,76 @@ DSQ_UNROLL_P
 
     // log_posterior AND dlog_posterior at the same point (src/DESeq2.cpp:31-64, 68-107).  The line
     // search needs both at every accepted point (:233/:246 and :205/:206); they share exp(la), the
-    // Cox-Reid Gram matrix and its LU, log(1 + mu alpha), mu + 1/alpha, and -- inside lgamma and
+    // Cox-Reid Gram matrix and its LU, log(1 + mu alpha), its reciprocal, and -- inside lgamma and
     // digamma of the same argument -- the shift, log(xs) and 1/xs.  Each shared value is produced
     // by the very expression the separate functions use, so lp and dlp keep their bits.
     DSQ_DEV double lp_dlp(double la, bool withPrior, double &dlp_out) const {
-        double alpha = dexp(la);
-        double cr_lp = 0.0, cr_dlp = 0.0;
-        if (useCR) {
-            DSQ_WORK_SCOPE;
-            DSQ_WORK(DsqMat2, B);
-            gram<2>(
-                [&](double imu, double(&wd)[2]) {
-                    double t = imu + alpha;
-                    wd[0] = 1.0 / t;
-                    wd[1] = -1.0 * (1.0 / (t * t));
-                },
-                B);
-            DSQ_WORK(LU<P>, lu);
-DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-            lu.factor();
-            double detb = lu.det();
-            cr_lp = -0.5 * dlog(detb);
-            DSQ_WORK(DsqMat, Bi);
-            lu.inverse(Bi);
-            double ddetb = detb * trace_prod<P>(Bi, B[1]);
-            cr_dlp = -0.5 * ddetb / detb;
-            DSQ_WORK_END;
-        }
-        double an1 = 1.0 / alpha;
-        double an2 = 1.0 / (alpha * alpha);
+        const double alpha = dexp(la);
+        const double an1 = 1.0 / alpha;
+        const double an2 = 1.0 / (alpha * alpha);
         double lg_an1, dg_an1;
         dlgamma_digamma(an1, lg_an1, dg_an1);
         double acc = 0.0, acc2 = 0.0;
+        double cr_lp = 0.0, cr_dlp = 0.0;
+        {
+            DSQ_WORK_SCOPE;
+            DSQ_WORK(DsqMat2, B);
+            pass<2>(
+                [&](int j, double(&wd)[2], bool lik) {
+                    const double y = r.y(j), mu = r.mu(j);
+                    const double ma = mu * alpha;
+                    const double opm = 1.0 + ma;
+                    const double rr = 1.0 / opm;
+                    if (useCR) {
+                        const double w0 = mu * rr;
+                        wd[0] = w0;
+                        wd[1] = -(w0 * w0);
+                    }
+                    if (lik) {
+                        const double l1 = dlog(opm);
+                        if constexpr (USE_W) {
+                            double lg, dg;
+                            dlgamma_digamma(y + an1, lg, dg);
+                            const double t = lg - lg_an1 - y * (l1 - la) - an1 * l1;
+                            const double t2 = dg_an1 + l1 - ma * rr - dg + y * (alpha * rr);
+                            const double w = r.w(j);
+                            acc += w * t;
+                            acc2 += w * t2;
+                        } else {
+                            acc += -(y * (l1 - la)) - an1 * l1;
+                            acc2 += l1 - ma * rr + y * (alpha * rr);
+                        }
+                    }
+                },
+                B);
+            if (useCR) {
+                DSQ_WORK(LU<P>, lu);
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                lu.factor();
+                double detb = lu.det();
+                cr_lp = -0.5 * dlog(detb);
+                DSQ_WORK(DsqMat, Bi);
+                lu.inverse(Bi);
+                double ddetb = detb * trace_prod<P>(Bi, B[1]);
+                cr_dlp = -0.5 * ddetb / detb;
+            }
+            DSQ_WORK_END;
+        }
         double ll_part, ll_dpart;
         if constexpr (USE_W) {
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double ma = mu * alpha;
-                double opm = 1.0 + ma;
-                double l1 = dlog(opm);
-                double rr = 1.0 / opm;
-                double lg, dg;
-                dlgamma_digamma(y + an1, lg, dg);
-                double t = lg - lg_an1 - y * (l1 - la) - an1 * l1;
-                double t2 = dg_an1 + l1 - ma * rr - dg + y * (alpha * rr);
-                double w = r.w(j);
-                acc += w * t;
-                acc2 += w * t2;
-            }
             ll_part = wave_allreduce(acc);
             ll_dpart = an2 * wave_allreduce(acc2);
         } else {
             double accv = 0.0, accv2 = 0.0;
-            if (!(ablate & 2))          // profiling only
             for (int i = lane; i < nv; i += 64) {
                 double lg, dg;
                 dlgamma_digamma((double)dv[i] + an1, lg, dg);
                 const double c = (double)dc[i];
                 accv += c * (lg - lg_an1);
                 accv2 += c * (dg_an1 - dg);
-            }
-            if (!(ablate & 1))          // profiling only
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double ma = mu * alpha;
-                double opm = 1.0 + ma;
-                double l1 = dlog(opm);
-                double rr = 1.0 / opm;
-                acc += -(y * (l1 - la)) - an1 * l1;
-                acc2 += l1 - ma * rr + y * (alpha * rr);
             }
             double sv = wave_allreduce(accv), sv2 = wave_allreduce(accv2);
             ll_part = sv + wave_allreduce(acc);
@@ -393,54 +428,56 @@ DSQ_UNROLL_P
 
     // dlog_posterior, src/DESeq2.cpp:68-107
     DSQ_DEV double dlp(double la, bool withPrior) const {
-        double alpha = dexp(la);
+        const double alpha = dexp(la);
+        const double an1 = 1.0 / alpha;
+        const double an2 = 1.0 / (alpha * alpha);
+        const double dg_an1 = ddigamma(an1);
+        double acc = 0.0;
         double cr_term = 0.0;
-        if (useCR) {
+        {
             DSQ_WORK_SCOPE;
             DSQ_WORK(DsqMat2, B);
-            gram<2>(
-                [&](double imu, double(&wd)[2]) {
-                    double t = imu + alpha;
-                    wd[0] = 1.0 / t;
-                    wd[1] = -1.0 * (1.0 / (t * t));
+            pass<2>(
+                [&](int j, double(&wd)[2], bool lik) {
+                    const double y = r.y(j), mu = r.mu(j);
+                    const double ma = mu * alpha;
+                    const double rr = 1.0 / (1.0 + ma);
+                    if (useCR) {
+                        const double w0 = mu * rr;
+                        wd[0] = w0;
+                        wd[1] = -(w0 * w0);
+                    }
+                    if (lik) {
+                        if constexpr (USE_W) {
+                            const double t = dg_an1 + dlog(1.0 + ma) - ma * rr - ddigamma(y + an1) + y * (alpha * rr);
+                            acc += r.w(j) * t;
+                        } else {
+                            acc += dlog(1.0 + ma) - ma * rr + y * (alpha * rr);
+                        }
+                    }
                 },
                 B);
-            DSQ_WORK(LU<P>, lu);
+            if (useCR) {
+                DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
+                for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-            lu.factor();
-            double detb = lu.det();
-            DSQ_WORK(DsqMat, Bi);
-            lu.inverse(Bi);
-            double ddetb = detb * trace_prod<P>(Bi, B[1]);
-            cr_term = -0.5 * ddetb / detb;
+                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                lu.factor();
+                double detb = lu.det();
+                DSQ_WORK(DsqMat, Bi);
+                lu.inverse(Bi);
+                double ddetb = detb * trace_prod<P>(Bi, B[1]);
+                cr_term = -0.5 * ddetb / detb;
+            }
             DSQ_WORK_END;
         }
-        double an1 = 1.0 / alpha;
-        double an2 = 1.0 / (alpha * alpha);
-        double dg_an1 = ddigamma(an1);
-        double acc = 0.0;
         double ll_sum;
         if constexpr (USE_W) {
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double ma = mu * alpha;
-                double rr = 1.0 / (1.0 + ma);
-                double t = dg_an1 + dlog(1.0 + ma) - ma * rr - ddigamma(y + an1) + y * (alpha * rr);
-                acc += r.w(j) * t;
-            }
             ll_sum = wave_allreduce(acc);
         } else {
             double accv = 0.0;
             for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dg_an1 - ddigamma((double)dv[i] + an1));
-            for (int j = lane; j < m; j += 64) {
-                double y = r.y(j), mu = r.mu(j);
-                double ma = mu * alpha;
-                double rr = 1.0 / (1.0 + ma);
-                acc += dlog(1.0 + ma) - ma * rr + y * (alpha * rr);
-            }
             double sv = wave_allreduce(accv);
             ll_sum = sv + wave_allreduce(acc);
         }
@@ -452,57 +489,63 @@ DSQ_UNROLL_P
 
     // d2log_posterior, src/DESeq2.cpp:111-158
     DSQ_DEV double d2lp(double la) const {
-        double alpha = dexp(la);
+        const double alpha = dexp(la);
+        const double an1 = 1.0 / alpha;
+        const double an2 = 1.0 / (alpha * alpha);
+        const double an3 = 1.0 / (alpha * (alpha * alpha));
+        const double dg_an1 = ddigamma(an1), tg_an1 = dtrigamma(an1);
+        double acc1 = 0.0, acc2 = 0.0;
         double cr_term = 0.0;
-        if (useCR) {
+        {
             DSQ_WORK_SCOPE;
             DSQ_WORK(DsqMat3, B);
-            gram<3>(
-                [&](double imu, double(&wd)[3]) {
-                    double t = imu + alpha;
-                    wd[0] = 1.0 / t;
-                    wd[1] = -1.0 * (1.0 / (t * t));
-                    wd[2] = 2.0 * (1.0 / (t * t * t));
+            pass<3>(
+                [&](int j, double(&wd)[3], bool lik) {
+                    const double y = r.y(j), mu = r.mu(j);
+                    const double ma = mu * alpha, opm = 1.0 + ma;
+                    const double rr = 1.0 / opm;
+                    if (useCR) {
+                        const double w0 = mu * rr;
+                        wd[0] = w0;
+                        wd[1] = -(w0 * w0);
+                        wd[2] = 2.0 * (w0 * (w0 * w0));
+                    }
+                    if (lik) {
+                        const double mpa = mu + an1;
+                        double t1 = dg_an1 + dlog(opm) - ma * rr - ddigamma(y + an1) + y * (1.0 / mpa);
+                        double t2 = -1.0 * an2 * tg_an1 + (mu * mu) * alpha * (1.0 / (opm * opm)) +
+                                    an2 * dtrigamma(y + an1) + an2 * y * (1.0 / (mpa * mpa));
+                        if constexpr (USE_W) {
+                            const double w = r.w(j);
+                            t1 = w * t1;
+                            t2 = w * t2;
+                        }
+                        acc1 += t1;
+                        acc2 += t2;
+                    }
                 },
                 B);
-            DSQ_WORK(LU<P>, lu);
+            if (useCR) {
+                DSQ_WORK(LU<P>, lu);
 DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
+                for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-            lu.factor();
-            double detb = lu.det();
-            DSQ_WORK(DsqMat, Bi);
-            DSQ_WORK(DsqMat, M);
-            lu.inverse(Bi);
-            double tr1 = trace_prod<P>(Bi, B[1]);
-            double ddetb = detb * tr1;
-            mat_mul<P>(Bi, B[1], M);
-            double tr2 = trace_prod<P>(M, M);
-            double tr3 = trace_prod<P>(Bi, B[2]);
-            double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
-            double rr = ddetb / detb;
-            cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;
-            DSQ_WORK_END;
-        }
-        double an1 = 1.0 / alpha;
-        double an2 = 1.0 / (alpha * alpha);
-        double an3 = 1.0 / (alpha * (alpha * alpha));
-        double dg_an1 = ddigamma(an1), tg_an1 = dtrigamma(an1);
-        double acc1 = 0.0, acc2 = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double y = r.y(j), mu = r.mu(j);
-            double ma = mu * alpha, opm = 1.0 + ma, mpa = mu + an1;
-            double t1 = dg_an1 + dlog(opm) - ma * (1.0 / opm) - ddigamma(y + an1) + y * (1.0 / mpa);
-            double t2 = -1.0 * an2 * tg_an1 + (mu * mu) * alpha * (1.0 / (opm * opm)) +
-                        an2 * dtrigamma(y + an1) + an2 * y * (1.0 / (mpa * mpa));
-            if constexpr (USE_W) {
-                double w = r.w(j);
-                t1 = w * t1;
-                t2 = w * t2;
+                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                lu.factor();
+                double detb = lu.det();
+                DSQ_WORK(DsqMat, Bi);
+                DSQ_WORK(DsqMat, M);
+                lu.inverse(Bi);
+                double tr1 = trace_prod<P>(Bi, B[1]);
+                double ddetb = detb * tr1;
+                mat_mul<P>(Bi, B[1], M);
+                double tr2 = trace_prod<P>(M, M);
+                double tr3 = trace_prod<P>(Bi, B[2]);
+                double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
+                double rr = ddetb / detb;
+                cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;
             }
-            acc1 += t1;
-            acc2 += t2;
+            DSQ_WORK_END;
         }
         double s1 = wave_allreduce(acc1), s2 = wave_allreduce(acc2);
         double ll_part = -2.0 * an3 * s1 + an2 * s2;
@@ -514,7 +557,7 @@ DSQ_UNROLL_P
 
 // ---- staging --------------------------------------------------------------------
 // LDS carve (doubles): [ X: p*m ][ per wave slab ][ per wave WIDE arena ]
-//   staged slab    : mu m | 1/mu m | (w m) | y int32 m | (distinct counts: 2 m int32, unweighted only)
+//   staged slab    : mu m | (w m) | y int32 m | (distinct counts: 2 m int32, unweighted only)
 //   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
 // WIDE build: doubles of per-wave LDS arena for the work matrices (the largest user, d2lp: B[3], LU, Bi, M)
 __host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 4 * p + 16 : 0; }
@@ -523,10 +566,11 @@ template <bool USE_W>
 __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
     const size_t half = ((size_t)m + 1) / 2;                 // m int32
     const size_t dist = USE_W ? 0 : (size_t)m;               // 2 m int32
-    return stage ? (size_t)m * (USE_W ? 3 : 2) + half + dist : dist;
+    return stage ? (size_t)m * (USE_W ? 2 : 1) + half + dist : dist;
 }
 
-// block-shared design-cell lists (int32: cell_start[DSQ_CMAX + 2] | cell_perm[m]) behind everything else
+// block-shared design-cell lists (int32: cell_start[DSQ_CMAX + 2] | m entries sample | cell << 26 in cell-sorted order)
+// behind everything else
 __host__ __device__ inline size_t disp_cell_doubles(int m, int ncell) { return ncell > 0 ? ((size_t)m + DSQ_CMAX + 3) / 2 : 0; }
 
 template <bool USE_W>
@@ -563,10 +607,13 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     // design cells: lists in block-shared LDS behind the slabs and arenas
     int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P)));
     int32_t *cperm_s = cstart_s + DSQ_CMAX + 2;
-    const int C = (kp.p >= DSQ_DISP_CELL_MINP) ? kp.ncell : 0;
+    const int C = kp.ncell;      // (the host passes cells only for the design widths that take the cell mode)
     if (C > 0) {
         for (int t = threadIdx.x; t <= C; t += blockDim.x) cstart_s[t] = kp.cell_start[t];
-        for (int t = threadIdx.x; t < m; t += blockDim.x) cperm_s[t] = kp.cell_perm[t];
+        for (int c = 0; c < C; c++) {
+            const int s0 = kp.cell_start[c], s1 = kp.cell_start[c + 1];
+            for (int t = s0 + (int)threadIdx.x; t < s1; t += blockDim.x) cperm_s[t] = kp.cell_perm[t] | (c << 26);
+        }
     }
     if constexpr (STAGE) {
         if (kp.xlds) {
@@ -587,17 +634,16 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         DispGene<P, USE_W, Rows> G;
         int32_t *dist;
         if constexpr (STAGE) {
-            double *ms = slab, *is = slab + m, *ws = slab + 2 * (size_t)m;
-            int32_t *ys = reinterpret_cast<int32_t *>(slab + (size_t)m * (USE_W ? 3 : 2));
+            double *ms = slab, *ws = slab + (size_t)m;
+            int32_t *ys = reinterpret_cast<int32_t *>(slab + (size_t)m * (USE_W ? 2 : 1));
             dist = ys + 2 * (((size_t)m + 1) / 2);
             for (int j = lane; j < m; j += 64) {
                 double mu = mug[j];
                 ys[j] = yg[j];
                 ms[j] = mu;
-                is[j] = 1.0 / mu;
                 if constexpr (USE_W) ws[j] = wg[j];
             }
-            G.r.y_ = ys; G.r.mu_ = ms; G.r.imu_ = is; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
+            G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
             dist = reinterpret_cast<int32_t *>(slab);
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;

@@ -530,7 +530,7 @@ static int launch_fit_disp(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.usePrior = usePrior ? 1 : 0; kp.useCR = useCR ? 1 : 0;
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
-    if (P.p >= DSQ_DISP_CELL_MINP) { kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell; }
+    if (P.p >= tuning().disp_cell_minp) { kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell; }
     if (grid) {
         kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = P.la_grid;
     } else {

@@ -233,7 +233,8 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
     int q = g->q, m = g->m;
     if (g->C > 0) {
         /* CELL MODE: every sample of a cell has the same design row x_c, so X' diag(wd) X = sum_c S_c x_c x_c' with
-         * S_c = sum of wd over the kept samples of the cell (wave order over the rank inside the cell), the outer
+         * S_c = sum of wd over the kept samples of the cell (wave order over the position k in the cell-sorted
+         * sequence), the outer
          * products added serially in cell order */
         double S[ORC_CMAX];
         for (int c = 0; c < g->C; c++) {
@@ -241,7 +242,7 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
             for (int k = g->cstart[c]; k < g->cstart[c + 1]; k++) {
                 int j = g->cperm[k];
                 if (g->keeprow && !g->keeprow[j]) continue;
-                wsum_add(&s, k - g->cstart[c], wd[j]);
+                wsum_add(&s, k, wd[j]);
             }
             S[c] = wsum_total(&s);
         }
@@ -269,13 +270,18 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
 }
 
 /* DESeq2.cpp:31-64 */
+/* the sample at position k of a per-sample sum: the natural order, or -- with design cells -- the cell-sorted sequence
+ * (one fused pass over the samples then feeds the likelihood sums and the per-cell Cox-Reid sums) */
+#define POS_J(g, k) ((g)->C > 0 ? (g)->cperm[k] : (k))
+
 static double log_posterior(double log_alpha, const gene_t *g, double *scratch) {
     double prior_part, cr_term;
     double alpha = orc_exp(log_alpha);
     int m = g->m;
     if (g->useCR) {
         double *wd = scratch;
-        for (int j = 0; j < m; j++) wd[j] = 1.0 / (1.0 / g->mu[j] + alpha);      /* :36 */
+        /* :36  w = 1 / (1/mu + alpha) = mu r,  r = 1 / (1 + mu alpha): the reciprocal the likelihood derivative uses */
+        for (int j = 0; j < m; j++) wd[j] = g->mu[j] * (1.0 / (1.0 + g->mu[j] * alpha));
         double B[ORC_PMAX * ORC_PMAX];
         cr_gram(g, wd, B);                                                       /* :45 */
         cr_term = -0.5 * orc_log(mat_det(g->q, B));                              /* :46 */
@@ -292,18 +298,20 @@ static double log_posterior(double log_alpha, const gene_t *g, double *scratch) 
         wsum_t sv; wsum_init(&sv, g->serial);
         for (int i = 0; i < g->nv; i++)
             wsum_add(&sv, i, g->dc[i] * (orc_lgamma(g->dv[i] + alpha_neg1) - lg_an1));
-        for (int j = 0; j < m; j++) {
+        for (int k = 0; k < m; k++) {
+            const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
             double l1 = orc_log(1.0 + mu * alpha);
-            wsum_add(&s, j, -(y * (l1 - log_alpha)) - alpha_neg1 * l1);
+            wsum_add(&s, k, -(y * (l1 - log_alpha)) - alpha_neg1 * l1);
         }
         ll_part = wsum_total(&sv) + wsum_total(&s);
     } else {
-        for (int j = 0; j < m; j++) {
+        for (int k = 0; k < m; k++) {
+            const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
             double l1 = orc_log(1.0 + mu * alpha);
             double t = orc_lgamma(y + alpha_neg1) - lg_an1 - y * (l1 - log_alpha) - alpha_neg1 * l1;
-            wsum_add(&s, j, g->w[j] * t);
+            wsum_add(&s, k, g->w[j] * t);
         }
         ll_part = wsum_total(&s);
     }
@@ -322,9 +330,9 @@ static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch)
     if (g->useCR) {
         double *wd = scratch, *dwd = scratch + m;
         for (int j = 0; j < m; j++) {
-            double t = 1.0 / g->mu[j] + alpha;
-            wd[j] = 1.0 / t;                                                     /* :73 */
-            dwd[j] = -1.0 * (1.0 / (t * t));                                     /* :74 */
+            double w0 = g->mu[j] * (1.0 / (1.0 + g->mu[j] * alpha));
+            wd[j] = w0;                                                          /* :73  1 / (1/mu + alpha) */
+            dwd[j] = -(w0 * w0);                                                 /* :74  -(1/mu + alpha)^-2 */
         }
         int q = g->q;
         double B[ORC_PMAX * ORC_PMAX], dB[ORC_PMAX * ORC_PMAX], Bi[ORC_PMAX * ORC_PMAX], detb;
@@ -345,20 +353,22 @@ static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch)
         wsum_t sv; wsum_init(&sv, g->serial);
         for (int i = 0; i < g->nv; i++)
             wsum_add(&sv, i, g->dc[i] * (dg_an1 - orc_digamma(g->dv[i] + alpha_neg1)));
-        for (int j = 0; j < m; j++) {
+        for (int k = 0; k < m; k++) {
+            const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
             double ma = mu * alpha;
             double r = 1.0 / (1.0 + ma);
-            wsum_add(&s, j, orc_log(1.0 + ma) - ma * r + y * (alpha * r));
+            wsum_add(&s, k, orc_log(1.0 + ma) - ma * r + y * (alpha * r));
         }
         ll_sum = wsum_total(&sv) + wsum_total(&s);
     } else {
-        for (int j = 0; j < m; j++) {
+        for (int k = 0; k < m; k++) {
+            const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
             double ma = mu * alpha;
             double r = 1.0 / (1.0 + ma);
             double t = dg_an1 + orc_log(1.0 + ma) - ma * r - orc_digamma(y + alpha_neg1) + y * (alpha * r);
-            wsum_add(&s, j, g->w[j] * t);
+            wsum_add(&s, k, g->w[j] * t);
         }
         ll_sum = wsum_total(&s);
     }
@@ -376,10 +386,10 @@ static double d2log_posterior(double log_alpha, const gene_t *g, double *scratch
     if (g->useCR) {
         double *wd = scratch, *dwd = scratch + m, *d2wd = scratch + 2 * (long)m;
         for (int j = 0; j < m; j++) {
-            double t = 1.0 / g->mu[j] + alpha;
-            wd[j] = 1.0 / t;                                                     /* :117 */
-            dwd[j] = -1.0 * (1.0 / (t * t));                                     /* :118 */
-            d2wd[j] = 2.0 * (1.0 / (t * t * t));                                 /* :119 */
+            double w0 = g->mu[j] * (1.0 / (1.0 + g->mu[j] * alpha));
+            wd[j] = w0;                                                          /* :117 */
+            dwd[j] = -(w0 * w0);                                                 /* :118 */
+            d2wd[j] = 2.0 * (w0 * (w0 * w0));                                    /* :119 */
         }
         int q = g->q;
         double B[ORC_PMAX * ORC_PMAX], dB[ORC_PMAX * ORC_PMAX], d2B[ORC_PMAX * ORC_PMAX];
@@ -400,7 +410,8 @@ static double d2log_posterior(double log_alpha, const gene_t *g, double *scratch
     double alpha_neg3 = 1.0 / (alpha * (alpha * alpha));   /* R_pow_di(alpha,-3): xn=x; x=x*x; xn*=x */
     double dg_an1 = orc_digamma(alpha_neg1), tg_an1 = orc_trigamma(alpha_neg1);
     wsum_t s1, s2; wsum_init(&s1, g->serial); wsum_init(&s2, g->serial);
-    for (int j = 0; j < m; j++) {                                                /* :143,145 */
+    for (int k = 0; k < m; k++) {                                                /* :143,145 */
+        const int j = POS_J(g, k);
         double y = g->y[j], mu = g->mu[j];
         double ma = mu * alpha, opm = 1.0 + ma, mpa = mu + alpha_neg1;
         double t1 = dg_an1 + orc_log(opm) - ma * (1.0 / opm)
@@ -409,7 +420,7 @@ static double d2log_posterior(double log_alpha, const gene_t *g, double *scratch
                     + alpha_neg2 * orc_trigamma(y + alpha_neg1)
                     + alpha_neg2 * y * (1.0 / (mpa * mpa));
         if (g->useWeights) { t1 = g->w[j] * t1; t2 = g->w[j] * t2; }
-        wsum_add(&s1, j, t1); wsum_add(&s2, j, t2);
+        wsum_add(&s1, k, t1); wsum_add(&s2, k, t2);
     }
     double ll_part = -2.0 * alpha_neg3 * wsum_total(&s1) + alpha_neg2 * wsum_total(&s2);
     if (g->usePrior) prior_part = -1.0 / g->prior_sigmasq;                       /* :149 */
