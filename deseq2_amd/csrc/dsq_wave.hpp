@@ -117,6 +117,11 @@ DSQ_DEV int next_gene(int *counter, int g, int stride, int lane) {
 // wave-uniform predicate -> scalar branch
 DSQ_DEV bool uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
 
+// widest LU<P> whose solve() swaps the right-hand side with select chains (see solve): P = 5, 6 with observation
+// weights came out wrong on the device in that form (fitDisp, round 2), so only the narrow widths keep it
+#ifndef DSQ_LU_SELECT_MAXP
+#define DSQ_LU_SELECT_MAXP 4
+#endif
 // ---- P x P LU with partial pivoting (first maximum wins), reciprocal pivots -----
 template <int P>
 struct LU {
@@ -169,7 +174,7 @@ DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
             int pr = piv[k];
             if (pr != k) {
-                if constexpr (P <= 6) {
+                if constexpr (P <= DSQ_LU_SELECT_MAXP) {
                     // b[k] <-> b[pr] as select chains: written as a conditional swap the compiler turns it into a
                     // dynamically indexed access, which moves b[] (a register array otherwise) into scratch memory
                     // (fit_disp<4>: 48 B/lane of scratch and ~90 scratch accesses per evaluation, 209 -> 177 VGPRs
@@ -219,6 +224,134 @@ DSQ_UNROLL_P
     }
 };
 
+// ---- P x P algebra with ONE COLUMN PER LANE -------------------------------------------------------------------------
+// Lane j (< P) holds column j of a matrix in P registers (a[i] = A[i][j]); lanes >= P idle.  A wave-uniform P x P matrix
+// costs 2 P^2 VGPRs in every lane (512-register kernels that spill from P = 7 up); a lane-column matrix costs 2 P.  The
+// factorisation broadcasts one multiplier at a time (v_readlane), every lane updates its own column: the SAME operations
+// on the same values as LU<P> above (first maximum wins, reciprocal pivots, fma(-l, u, a)), so the results keep their
+// bits; a solve runs P right-hand sides at once (lane c owns right-hand side c), which turns the P^3 inverse into P^2.
+template <int P>
+struct LaneLU {
+    double a[P];
+    double rdiag[P];   // wave-uniform
+    int piv[P];        // wave-uniform
+    int sign;
+
+    DSQ_DEV void factor(int lane) {
+        sign = 1;
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            // pivot search: lane k scans its own column
+            int pr = k;
+            double best = __builtin_fabs(a[k]);
+#pragma unroll
+            for (int i = k + 1; i < P; i++) {
+                double v = __builtin_fabs(a[i]);
+                if (v > best) { best = v; pr = i; }
+            }
+            pr = __builtin_amdgcn_readlane(pr, k);
+            piv[k] = pr;
+            if (pr != k) {
+                sign = -sign;
+                // rows k <-> pr in every column, as selects on the wave-uniform pr (a conditional swap would make
+                // a[] a dynamically indexed array, i.e. scratch memory)
+#pragma unroll
+                for (int i = k + 1; i < P; i++) {
+                    const bool sw = (i == pr);
+                    const double ai = a[i], ak = a[k];
+                    a[i] = sw ? ak : ai;
+                    a[k] = sw ? ai : ak;
+                }
+            }
+            const double rinv = 1.0 / lane_read(a[k], k);
+            rdiag[k] = rinv;
+#pragma unroll
+            for (int i = k + 1; i < P; i++) {
+                const double l = lane_read(a[i], k) * rinv;
+                const double upd = __builtin_fma(-l, a[k], a[i]);
+                a[i] = (lane == k) ? l : (lane > k ? upd : a[i]);
+            }
+        }
+    }
+    DSQ_DEV double det() const {
+        double d = lane_read(a[0], 0);
+#pragma unroll
+        for (int i = 1; i < P; i++) d = d * lane_read(a[i], i);
+        return sign < 0 ? -d : d;
+    }
+    // lane c: b = right-hand side c on entry, solution c on return
+    DSQ_DEV void solve(double (&b)[P]) const {
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            const int pr = piv[k];
+            if (pr != k) {
+#pragma unroll
+                for (int i = k + 1; i < P; i++) {
+                    const bool sw = (i == pr);
+                    const double bi = b[i], bk = b[k];
+                    b[i] = sw ? bk : bi;
+                    b[k] = sw ? bi : bk;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            double t = b[i];
+#pragma unroll
+            for (int j = 0; j < i; j++) t = __builtin_fma(-lane_read(a[i], j), b[j], t);
+            b[i] = t;
+        }
+#pragma unroll
+        for (int i = P - 1; i >= 0; i--) {
+            double t = b[i];
+#pragma unroll
+            for (int j = i + 1; j < P; j++) t = __builtin_fma(-lane_read(a[i], j), b[j], t);
+            b[i] = t * rdiag[i];
+        }
+    }
+    // lane c: column c of the inverse
+    DSQ_DEV void inverse(double (&inv)[P], int lane) const {
+#pragma unroll
+        for (int i = 0; i < P; i++) inv[i] = (i == lane) ? 1.0 : 0.0;
+        solve(inv);
+    }
+};
+
+// C = A B, all three in lane columns (lane j: c[i] = sum_k fma(A[i][k], B[k][j]), k ascending as in mat_mul)
+template <int P>
+DSQ_DEV void lane_mat_mul(const double (&a)[P], const double (&b)[P], double (&c)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; k++) acc = __builtin_fma(lane_read(a[i], k), b[k], acc);
+        c[i] = acc;
+    }
+}
+
+// trace(A B) for a SYMMETRIC B: sum over the columns k (ascending) of t_k = sum_i fma(A[i][k], B[i][k]) (i ascending)
+template <int P>
+DSQ_DEV double lane_trace_sym(const double (&a)[P], const double (&b)[P]) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) t = __builtin_fma(a[i], b[i], t);
+    double tr = 0.0;
+#pragma unroll
+    for (int k = 0; k < P; k++) tr = tr + lane_read(t, k);
+    return tr;
+}
+
+// trace(A B), general: the fma chain over (i, k) of A[i][k] B[k][i] of trace_prod
+template <int P>
+DSQ_DEV double lane_trace_prod(const double (&a)[P], const double (&b)[P]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int k = 0; k < P; k++) acc = __builtin_fma(lane_read(a[i], k), lane_read(b[k], i), acc);
+    return acc;
+}
+
 template <int P>
 DSQ_DEV void mat_mul(const double (&a)[P][P], const double (&b)[P][P], double (&c)[P][P]) {
 DSQ_UNROLL_P
@@ -240,6 +373,20 @@ DSQ_UNROLL_P
 DSQ_UNROLL_P
         for (int k = 0; k < P; k++) acc = __builtin_fma(a[i][k], b[k][i], acc);
     return acc;
+}
+
+// trace(A B) for a SYMMETRIC B (wave-uniform matrices): the same sums as lane_trace_sym
+template <int P>
+DSQ_DEV double trace_sym(const double (&a)[P][P], const double (&b)[P][P]) {
+    double tr = 0.0;
+DSQ_UNROLL_P
+    for (int k = 0; k < P; k++) {
+        double t = 0.0;
+DSQ_UNROLL_P
+        for (int i = 0; i < P; i++) t = __builtin_fma(a[i][k], b[i][k], t);
+        tr = tr + t;
+    }
+    return tr;
 }
 
 // ---- distinct counts of a gene ---------------------------------------------------------------------------------------

@@ -8,8 +8,7 @@
 // 1 + p(p+1)/2 partial sums that are xor-butterflied across the wave; the p x p
 // determinant / inverse / traces are wave-uniform register math (LU, partial pivoting).
 // The Armijo line search itself is wave-uniform scalar control flow.
-// design widths from DSQ_DISP_WIDE_MIN up are built in the WIDE form (rolled p^3 loops, the wave-uniform p x p work
-// matrices once per wave in an LDS arena instead of once per lane in registers / scratch)
+// design widths from DSQ_DISP_WIDE_MIN up are served by two zero-padded builds (p = 16, 24)
 #ifndef DSQ_DISP_WIDE_MIN
 #define DSQ_DISP_WIDE_MIN 11
 #endif
@@ -23,15 +22,10 @@
 
 namespace dsq {
 
-// a wave-uniform work matrix of DispGene: registers in the per-width builds, the wave's LDS arena in the WIDE build
-#if DSQ_P >= DSQ_WIDE_MIN
-#define DSQ_WORK(T, name) T &name = this->template arena_take<T>()
-#define DSQ_WORK_SCOPE const int dsq_arena_mark_ = arena_off
-#define DSQ_WORK_END arena_off = dsq_arena_mark_
-#else
-#define DSQ_WORK(T, name) T name
-#define DSQ_WORK_SCOPE
-#define DSQ_WORK_END
+// design widths from DSQ_DISP_LANE_MIN up keep the p x p Cox-Reid matrices ONE COLUMN PER LANE (LaneLU, dsq_wave.hpp)
+// instead of wave-uniform in every lane's registers: 2 p instead of 2 p^2 VGPRs per matrix, p^2 instead of p^3 work
+#ifndef DSQ_DISP_LANE_MIN
+#define DSQ_DISP_LANE_MIN 7
 #endif
 typedef double DsqMat1[1][DSQ_P][DSQ_P];
 typedef double DsqMat2[2][DSQ_P][DSQ_P];
@@ -43,6 +37,10 @@ struct SymN { static constexpr int value = P * (P + 1) / 2; };
 
 template <int P, bool USE_W, class Rows>
 struct DispGene {
+    static constexpr bool LANE = (P >= DSQ_DISP_LANE_MIN);
+    // K Cox-Reid matrices: wave-uniform B[k][a][b], or lane columns B[k][i] = entry (i, lane)
+    template <int K>
+    using Bmat = typename std::conditional<LANE, double[K][P], double[K][P][P]>::type;
     Rows r;
     int m, lane;
     double prior_mean, prior_sigmasq, thr;
@@ -50,11 +48,7 @@ struct DispGene {
     unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
     unsigned padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
-    // WIDE build only: the wave-uniform p x p work matrices live ONCE per wave in LDS (every lane reads and writes
-    // the same addresses with the same values) instead of once per lane in scratch memory, which is what a rolled
-    // loop over a local array would give -- 64 copies per wave, gigabytes for the resident waves.
-    double *arena;
-    mutable int arena_off;
+    double *arena;      // lane-column builds: K P P doubles of wave-private LDS (general-mode Cox-Reid rows)
     // unweighted genes: the distinct count values (ascending) and their multiplicities, in wave-private LDS -- the
     // lgamma / digamma terms of the likelihood depend on a sample only through its count, so they are evaluated once
     // per DISTINCT count (often a handful) instead of once per sample
@@ -64,13 +58,6 @@ struct DispGene {
     // offsets; C = 0 -> general per-sample Gram
     const int32_t *cperm, *cstart;
     int C;
-    template <class T>
-    DSQ_DEV T &arena_take() const {
-        T *q = reinterpret_cast<T *>(arena + arena_off);
-        arena_off += (int)((sizeof(T) + 7) / 8);
-        return *q;
-    }
-
     // sort the gene's counts (bitonic network in the wave's LDS slice), keep the first of every run and its length.
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
@@ -110,7 +97,7 @@ DSQ_UNROLL_P
     // A dropped column contributes exact zeros; putting 1 on its diagonal in the first matrix leaves det / inverse /
     // traces equal to those of the compacted matrix.
     template <int K, class F>
-    DSQ_DEV void pass(F &&f, double (&B)[K][P][P]) const {
+    DSQ_DEV void pass(F &&f, Bmat<K> &B) const {
         if (C > 0) {
             // CELL MODE: X' diag(wd) X = sum_c S_c x_c x_c', S_c = sum of wd over the kept samples of cell c (lane c keeps
             // S_c; a cell's sums are closed when the sweep leaves it), outer products added serially in cell order.
@@ -156,38 +143,65 @@ DSQ_UNROLL_P
             }
             if (!useCR) return;
             close_cell();
-DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                for (int b = a; b < P; b++)
-                    _Pragma("unroll")
-                    for (int k = 0; k < K; k++) B[k][a][b] = 0.0;
-            for (int c = 0; c < C; c++) {
-                const int j0 = cperm[cstart[c]] & 0x3ffffff;
-                double sc[K];
+            if constexpr (LANE) {
+                // lane b builds column b: entry (i, b) = sum_c (x_c[i] x_c[b]) S_c, cells in order
+                const int bl = lane < P ? lane : 0;
                 _Pragma("unroll")
-                for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++) {
-                    const double xa = r.x(j0, a);
-DSQ_UNROLL_P
-                    for (int b = a; b < P; b++) {
-                        const double xb = r.x(j0, b);
+                for (int k = 0; k < K; k++)
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) B[k][i] = 0.0;
+                for (int c = 0; c < C; c++) {
+                    const int j0 = cperm[cstart[c]] & 0x3ffffff;
+                    double sc[K];
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
+                    const double xb = r.x(j0, bl);
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) {
+                        const double xx = r.x(j0, i) * xb;
                         _Pragma("unroll")
-                        for (int k = 0; k < K; k++) B[k][a][b] = B[k][a][b] + xa * (xb * sc[k]);
+                        for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
                     }
                 }
-            }
-DSQ_UNROLL_P
-            for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                for (int b = a; b < P; b++)
+                if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
                     _Pragma("unroll")
-                    for (int k = 0; k < K; k++) B[k][b][a] = B[k][a][b];
-            if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+                    for (int i = 0; i < P; i++)
+                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                }
+            } else {
 DSQ_UNROLL_P
-                for (int c = 0; c < P; c++)
-                    if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+                for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                    for (int b = a; b < P; b++)
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) B[k][a][b] = 0.0;
+                for (int c = 0; c < C; c++) {
+                    const int j0 = cperm[cstart[c]] & 0x3ffffff;
+                    double sc[K];
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++) {
+                        const double xa = r.x(j0, a);
+DSQ_UNROLL_P
+                        for (int b = a; b < P; b++) {
+                            const double xx = xa * r.x(j0, b);
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) B[k][a][b] = B[k][a][b] + xx * sc[k];
+                        }
+                    }
+                }
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                    for (int b = a; b < P; b++)
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) B[k][b][a] = B[k][a][b];
+                if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+DSQ_UNROLL_P
+                    for (int c = 0; c < P; c++)
+                        if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+                }
             }
             return;
         }
@@ -198,48 +212,69 @@ DSQ_UNROLL_P
             }
             return;
         }
-        if constexpr (P >= DSQ_WIDE_MIN) {
-            // WIDE build: K * P(P+1)/2 per-lane running sums do not fit in registers, and as a dynamically indexed
-            // array they would live in scratch memory.  Two matrix rows per pass over the samples instead, the pass loop
-            // and the column loops fully unrolled so that the sums of a pass ARE registers; the diagonals are
-            // recomputed per pass (a division per sample), the caller's likelihood terms added in the first pass only.
-            // Same terms, same order per entry, same wave reduction.
-            constexpr int RB = 2;
-            _Pragma("unroll")
-            for (int a0 = 0; a0 < P; a0 += RB) {
-                double acc[K][RB][P];
+        if constexpr (LANE) {
+            // K * P(P+1)/2 per-lane running sums do not fit in registers.  One matrix row per pass over the samples
+            // instead (a rolled loop over the rows; the diagonals are recomputed per pass, a division per sample, the
+            // caller's likelihood terms added in the first pass only).  Same terms, same order per entry, same wave
+            // reduction.  The reduced rows go through the wave's LDS arena (K P P doubles), from which every lane then
+            // takes its column.
+            bool first = true;
+            for (int a0 = 0; a0 < P; a0++) {
+                if ((dropmask >> a0) & 1u) continue;              // a dropped / padding column: exact zeros, left out
+                double acc[K][P];
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++)
                     _Pragma("unroll")
-                    for (int i = 0; i < RB; i++)
-                        _Pragma("unroll")
-                        for (int b = 0; b < P; b++) acc[k][i][b] = 0.0;
+                    for (int b = 0; b < P; b++) acc[k][b] = 0.0;
                 for (int j = lane; j < m; j += 64) {
                     double wd[K];
-                    f(j, wd, a0 == 0);
+                    f(j, wd, first);
                     if (keep_row(j)) {
-                        double xr[P];
+                        const double xa = r.x(j, a0);
                         _Pragma("unroll")
-                        for (int c = a0; c < P; c++) xr[c] = r.x(j, c);
-                        _Pragma("unroll")
-                        for (int i = 0; i < RB; i++)
+                        for (int b = 0; b < P; b++) {
+                            const double xb = r.x(j, b);
                             _Pragma("unroll")
-                            for (int b = a0 + i; b < P; b++)
-                                _Pragma("unroll")
-                                for (int k = 0; k < K; k++) acc[k][i][b] += xr[a0 + i] * (xr[b] * wd[k]);
+                            for (int k = 0; k < K; k++) acc[k][b] += xa * (xb * wd[k]);
+                        }
                     }
                 }
                 _Pragma("unroll")
-                for (int i = 0; i < RB; i++)
+                for (int b = 0; b < P; b++) {
+                    if (b < a0) continue;                         // (wave-uniform) the lower triangle is the mirror
                     _Pragma("unroll")
-                    for (int b = a0 + i; b < P; b++)
-                        _Pragma("unroll")
-                        for (int k = 0; k < K; k++) {
-                            double v = wave_allreduce(acc[k][i][b]);
-                            B[k][a0 + i][b] = v;
-                            B[k][b][a0 + i] = v;
+                    for (int k = 0; k < K; k++) {
+                        const double v = wave_allreduce(acc[k][b]);
+                        if (lane == 0) {
+                            arena[(k * P + a0) * P + b] = v;
+                            arena[(k * P + b) * P + a0] = v;
                         }
+                    }
+                }
+                first = false;
             }
+            if (first) {                                          // every column dropped: the caller's sums still run
+                for (int j = lane; j < m; j += 64) {
+                    double wd[K];
+                    f(j, wd, true);
+                }
+            }
+            wave_lds_sync();
+            const int bl = lane < P ? lane : 0;
+            _Pragma("unroll")
+            for (int k = 0; k < K; k++)
+                _Pragma("unroll")
+                for (int i = 0; i < P; i++) {
+                    const bool dropped = (((dropmask >> i) | (dropmask >> bl)) & 1u) != 0;
+                    B[k][i] = dropped ? 0.0 : arena[(k * P + i) * P + bl];
+                }
+            wave_lds_sync();
+            if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+                _Pragma("unroll")
+                for (int i = 0; i < P; i++)
+                    if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+            }
+            return;
         } else {
             constexpr int N = SymN<P>::value;
             double acc[K * N];
@@ -277,10 +312,35 @@ DSQ_UNROLL_P
                     }
             }
         }
-        if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+        if constexpr (!LANE && USE_W) {
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++)
                 if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+        }
+    }
+
+    // det(B0) and trace(B0^-1 B1) of the Cox-Reid term (:46, :85)
+    DSQ_DEV void cr_algebra(const Bmat<2> &B, double &detb, double &tr1) const {
+        if constexpr (LANE) {
+            LaneLU<P> lu;
+            _Pragma("unroll")
+            for (int i = 0; i < P; i++) lu.a[i] = B[0][i];
+            lu.factor(lane);
+            detb = lu.det();
+            double Bi[P];
+            lu.inverse(Bi, lane);
+            tr1 = lane_trace_sym<P>(Bi, B[1]);
+        } else {
+            LU<P> lu;
+DSQ_UNROLL_P
+            for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+            lu.factor();
+            detb = lu.det();
+            DsqMat Bi;
+            lu.inverse(Bi);
+            tr1 = trace_sym<P>(Bi, B[1]);
         }
     }
 
@@ -293,8 +353,7 @@ DSQ_UNROLL_P
         double acc = 0.0;
         double cr_term = 0.0;
         {
-            DSQ_WORK_SCOPE;
-            DSQ_WORK(DsqMat1, B);
+            Bmat<1> B;
             pass<1>(
                 [&](int j, double(&wd)[1], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
@@ -312,15 +371,22 @@ DSQ_UNROLL_P
                 },
                 B);
             if (useCR) {
-                DSQ_WORK(LU<P>, lu);
+                if constexpr (LANE) {
+                    LaneLU<P> lu;
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) lu.a[i] = B[0][i];
+                    lu.factor(lane);
+                    cr_term = -0.5 * dlog(lu.det());
+                } else {
+                    LU<P> lu;
 DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
+                    for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-                lu.factor();
-                cr_term = -0.5 * dlog(lu.det());
+                        for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                    lu.factor();
+                    cr_term = -0.5 * dlog(lu.det());
+                }
             }
-            DSQ_WORK_END;
         }
         double ll_part;
         if constexpr (USE_W) {
@@ -353,8 +419,7 @@ DSQ_UNROLL_P
         double acc = 0.0, acc2 = 0.0;
         double cr_lp = 0.0, cr_dlp = 0.0;
         {
-            DSQ_WORK_SCOPE;
-            DSQ_WORK(DsqMat2, B);
+            Bmat<2> B;
             pass<2>(
                 [&](int j, double(&wd)[2], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
@@ -384,20 +449,12 @@ DSQ_UNROLL_P
                 },
                 B);
             if (useCR) {
-                DSQ_WORK(LU<P>, lu);
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-                lu.factor();
-                double detb = lu.det();
+                double detb, tr1;
+                cr_algebra(B, detb, tr1);
                 cr_lp = -0.5 * dlog(detb);
-                DSQ_WORK(DsqMat, Bi);
-                lu.inverse(Bi);
-                double ddetb = detb * trace_prod<P>(Bi, B[1]);
+                double ddetb = detb * tr1;
                 cr_dlp = -0.5 * ddetb / detb;
             }
-            DSQ_WORK_END;
         }
         double ll_part, ll_dpart;
         if constexpr (USE_W) {
@@ -435,8 +492,7 @@ DSQ_UNROLL_P
         double acc = 0.0;
         double cr_term = 0.0;
         {
-            DSQ_WORK_SCOPE;
-            DSQ_WORK(DsqMat2, B);
+            Bmat<2> B;
             pass<2>(
                 [&](int j, double(&wd)[2], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
@@ -458,19 +514,11 @@ DSQ_UNROLL_P
                 },
                 B);
             if (useCR) {
-                DSQ_WORK(LU<P>, lu);
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-                lu.factor();
-                double detb = lu.det();
-                DSQ_WORK(DsqMat, Bi);
-                lu.inverse(Bi);
-                double ddetb = detb * trace_prod<P>(Bi, B[1]);
+                double detb, tr1;
+                cr_algebra(B, detb, tr1);
+                double ddetb = detb * tr1;
                 cr_term = -0.5 * ddetb / detb;
             }
-            DSQ_WORK_END;
         }
         double ll_sum;
         if constexpr (USE_W) {
@@ -497,8 +545,7 @@ DSQ_UNROLL_P
         double acc1 = 0.0, acc2 = 0.0;
         double cr_term = 0.0;
         {
-            DSQ_WORK_SCOPE;
-            DSQ_WORK(DsqMat3, B);
+            Bmat<3> B;
             pass<3>(
                 [&](int j, double(&wd)[3], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
@@ -526,26 +573,39 @@ DSQ_UNROLL_P
                 },
                 B);
             if (useCR) {
-                DSQ_WORK(LU<P>, lu);
+                double detb, tr1, tr2, tr3;
+                if constexpr (LANE) {
+                    LaneLU<P> lu;
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) lu.a[i] = B[0][i];
+                    lu.factor(lane);
+                    detb = lu.det();
+                    double Bi[P], M[P];
+                    lu.inverse(Bi, lane);
+                    tr1 = lane_trace_sym<P>(Bi, B[1]);
+                    lane_mat_mul<P>(Bi, B[1], M);
+                    tr2 = lane_trace_prod<P>(M, M);
+                    tr3 = lane_trace_sym<P>(Bi, B[2]);
+                } else {
+                    LU<P> lu;
 DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
+                    for (int a = 0; a < P; a++)
 DSQ_UNROLL_P
-                    for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
-                lu.factor();
-                double detb = lu.det();
-                DSQ_WORK(DsqMat, Bi);
-                DSQ_WORK(DsqMat, M);
-                lu.inverse(Bi);
-                double tr1 = trace_prod<P>(Bi, B[1]);
+                        for (int b = 0; b < P; b++) lu.a[a][b] = B[0][a][b];
+                    lu.factor();
+                    detb = lu.det();
+                    DsqMat Bi, M;
+                    lu.inverse(Bi);
+                    tr1 = trace_sym<P>(Bi, B[1]);
+                    mat_mul<P>(Bi, B[1], M);
+                    tr2 = trace_prod<P>(M, M);
+                    tr3 = trace_sym<P>(Bi, B[2]);
+                }
                 double ddetb = detb * tr1;
-                mat_mul<P>(Bi, B[1], M);
-                double tr2 = trace_prod<P>(M, M);
-                double tr3 = trace_prod<P>(Bi, B[2]);
                 double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
                 double rr = ddetb / detb;
                 cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;
             }
-            DSQ_WORK_END;
         }
         double s1 = wave_allreduce(acc1), s2 = wave_allreduce(acc2);
         double ll_part = -2.0 * an3 * s1 + an2 * s2;
@@ -556,11 +616,12 @@ DSQ_UNROLL_P
 };
 
 // ---- staging --------------------------------------------------------------------
-// LDS carve (doubles): [ X: p*m ][ per wave slab ][ per wave WIDE arena ]
+// LDS carve (doubles): [ X: p*m ][ per wave slab ]
 //   staged slab    : mu m | (w m) | y int32 m | (distinct counts: 2 m int32, unweighted only)
 //   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
-// WIDE build: doubles of per-wave LDS arena for the work matrices (the largest user, d2lp: B[3], LU, Bi, M)
-__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 4 * p + 16 : 0; }
+// lane-column builds: per-wave LDS arena through which the general-mode pass hands the reduced Cox-Reid rows to the
+// lanes (3 p p doubles: the second-derivative kernel has three matrices)
+__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_DISP_LANE_MIN ? (size_t)3 * p * p : 0; }
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
@@ -581,7 +642,7 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
 #ifndef DSQ_DISP_MINW
 /* p <= 4: the search kernel needs 177 registers, so 3 waves per SIMD cost ten spills and pay (6.42 -> 6.15 ms
  * at C3); p = 5, 6: 2 waves; wider designs already spill at 512 registers */
-#define DSQ_DISP_MINW (DSQ_P <= 4 ? 3 : DSQ_P <= 6 ? 2 : 1)
+#define DSQ_DISP_MINW (DSQ_P <= 4 ? 3 : DSQ_P <= 10 ? 2 : 1)
 #endif
 
 // MODE 0: fitDisp line search (all outputs but last_d2lp); MODE 1: fitDispGrid; MODE 2: last_d2lp only,
@@ -602,7 +663,6 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
-    // WIDE build: the work-matrix arena sits behind the slabs
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P);
     // design cells: lists in block-shared LDS behind the slabs and arenas
     int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P)));
@@ -657,7 +717,6 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.ablate = kp.ablate;
         G.padmask = kp.padmask;
         G.arena = arena;
-        G.arena_off = 0;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
         G.build_distinct(dist);
         G.setup_cr();

@@ -154,6 +154,18 @@ static double trace_prod(int q, const double *a, const double *b) {
     return acc;
 }
 
+/* trace(A B) for a SYMMETRIC B: the sum over the columns k (ascending) of t_k = sum_i fma(A[i][k], B[i][k]) -- the form
+ * the engine evaluates with one matrix column per lane (trace(B^-1 dB) of the Cox-Reid derivative, DESeq2.cpp:85,133) */
+static double trace_sym(int q, const double *a, const double *b) {
+    double tr = 0.0;
+    for (int k = 0; k < q; k++) {
+        double t = 0.0;
+        for (int i = 0; i < q; i++) t = fma(a[i * q + k], b[i * q + k], t);
+        tr = tr + t;
+    }
+    return tr;
+}
+
 #define ORC_CMAX 32
 /* which designs take the cell-collapsed paths (the engine's rule): fitBeta with at most 10 columns (the
  * register-resident kernels), the Cox-Reid matrices of fitDisp from 5 columns up (below that the per-sample
@@ -250,7 +262,7 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
             for (int b = a; b < q; b++) {
                 double v = 0.0;
                 for (int c = 0; c < g->C; c++)
-                    v += g->xc[c * g->p + g->keepcol[a]] * (g->xc[c * g->p + g->keepcol[b]] * S[c]);
+                    v += (g->xc[c * g->p + g->keepcol[a]] * g->xc[c * g->p + g->keepcol[b]]) * S[c];
                 B[a * q + b] = v; B[b * q + a] = v;
             }
         return;
@@ -338,7 +350,7 @@ static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch)
         double B[ORC_PMAX * ORC_PMAX], dB[ORC_PMAX * ORC_PMAX], Bi[ORC_PMAX * ORC_PMAX], detb;
         cr_gram(g, wd, B); cr_gram(g, dwd, dB);                                  /* :83,84 */
         mat_inverse(q, B, Bi, &detb);
-        double ddetb = detb * trace_prod(q, Bi, dB);                             /* :85 */
+        double ddetb = detb * trace_sym(q, Bi, dB);                              /* :85 */
         cr_term = -0.5 * ddetb / detb;                                           /* :86 */
     } else cr_term = 0.0;
     double alpha_neg1 = 1.0 / alpha;
@@ -396,11 +408,11 @@ static double d2log_posterior(double log_alpha, const gene_t *g, double *scratch
         double Bi[ORC_PMAX * ORC_PMAX], M[ORC_PMAX * ORC_PMAX], detb;
         cr_gram(g, wd, B); cr_gram(g, dwd, dB); cr_gram(g, d2wd, d2B);           /* :129-132 */
         mat_inverse(q, B, Bi, &detb);
-        double tr1 = trace_prod(q, Bi, dB);
+        double tr1 = trace_sym(q, Bi, dB);
         double ddetb = detb * tr1;                                               /* :133 */
         mat_mul(q, Bi, dB, M);
         double tr2 = trace_prod(q, M, M);                  /* trace(b_i*db*b_i*db) */
-        double tr3 = trace_prod(q, Bi, d2B);
+        double tr3 = trace_sym(q, Bi, d2B);
         double d2detb = detb * (tr1 * tr1 - tr2 + tr3);                          /* :134 */
         double rr = ddetb / detb;
         cr_term = 0.5 * (rr * rr) - 0.5 * d2detb / detb;                         /* :135 */
