@@ -381,7 +381,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     kp.maxit = a->maxit; kp.useQR = a->useQR ? 1 : 0; kp.useWeights = a->useWeights ? 1 : 0;
     kp.ablate = tuning().ablate; kp.force_iters = tuning().force_iters;
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
-    if (a->cell_of && a->ncell > 0 && a->p <= DSQ_P_REG)
+    if (a->cell_of && a->ncell > 0)
         kp.ncell = capi_upload_cells(a->cell_of, a->m, WS_CELLS_BETA, st, &kp.cell_perm, &kp.cell_start);
     kp.beta_mat = o->beta_mat; kp.beta_var_mat = o->beta_var_mat; kp.iter = o->iter;
     kp.contrast_num = o->contrast_num; kp.contrast_denom = o->contrast_denom; kp.deviance = o->deviance;

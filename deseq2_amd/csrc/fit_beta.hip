@@ -478,6 +478,10 @@ DSQ_UNROLL_P
 // Sums over samples run cell by cell in wave order over the position in the cell-sorted sample sequence (so a sweep
 // is ceil(m / 64) FULL trips whatever the cell sizes).  Arithmetic spec = the CPU checker's
 // fit_beta_gene_cells; results are bit-identical to it.
+// design widths from DSQ_BETA_LANE_MIN up keep the p x p matrices of the cell kernel one column per lane (LaneLU)
+#ifndef DSQ_BETA_LANE_MIN
+#define DSQ_BETA_LANE_MIN 7
+#endif
 #ifndef DSQ_BETA_CELL_MINW
 #define DSQ_BETA_CELL_MINW (DSQ_P <= 6 ? 3 : DSQ_P <= 10 ? 2 : 1)
 #endif
@@ -530,9 +534,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
     }
     __syncthreads();
     const int last_lane_of_tail = (m - 1) & 63;
-    double lambda[P], contrast[P];
+    double lambda[P], contrast[P];            // (used by the wave-uniform builds only: P < DSQ_BETA_LANE_MIN)
 #pragma unroll
     for (int c = 0; c < P; c++) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
+    // the ridge rows of the collapsed least squares: lane C + k holds sqrt(lambda_k) in column k
+    const double sqrt_lam_lane = (lane >= C && lane < Mrows) ? __builtin_sqrt(kp.lambda[lane - C]) : 0.0;
     const double large = 30.0;
     const double minmu = kp.minmu;
 
@@ -648,7 +654,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 for (int k = 0; k < P; k++) {
                     double v = 0.0;
                     if (lane < C) v = xcs[lane * P + k] * sS;
-                    else if (lane - C == k) v = __builtin_sqrt(lambda[k]);
+                    else if (lane - C == k) v = sqrt_lam_lane;
                     a[k] = v;
                 }
                 if (lane < C) b = (sS > 0.0) ? Tl / sS : 0.0;
@@ -695,6 +701,29 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     for (int j = i + 1; j < P; j++) tt = __builtin_fma(-lane_read(a[j], i), beta[j], tt);
                     beta[i] = tt / lane_read(a[i], i);
                 }
+            } else if constexpr (P >= DSQ_BETA_LANE_MIN) {
+                // normal equations with one column of X'WX + ridge per lane (LaneLU): entry (i, b) = sum_c (x_c[i] x_c[b]) S_c
+                LaneLU<P> lu;
+                const int bl = lane < P ? lane : 0;
+#pragma unroll
+                for (int i = 0; i < P; i++) lu.a[i] = 0.0;
+                double rh = 0.0;
+                for (int c = 0; c < C; c++) {
+                    const double sc = lane_read(Sl, c), tc = lane_read(Tl, c);
+                    const double xb = xcs[c * P + bl];
+#pragma unroll
+                    for (int i = 0; i < P; i++) lu.a[i] = lu.a[i] + (xcs[c * P + i] * xb) * sc;
+                    rh += xb * tc;
+                }
+#pragma unroll
+                for (int i = 0; i < P; i++) lu.a[i] = (lane == i) ? lu.a[i] + kp.lambda[i] : lu.a[i];
+                lu.factor(lane);
+                double rhs[P];
+#pragma unroll
+                for (int i = 0; i < P; i++) rhs[i] = lane_read(rh, i);
+                lu.solve(rhs);
+#pragma unroll
+                for (int i = 0; i < P; i++) beta[i] = rhs[i];
             } else {
                 LU<P> lu;
                 double rhs[P];
@@ -703,7 +732,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
 #pragma unroll
                     for (int b = a; b < P; b++) {
                         double v = 0.0;
-                        for (int c = 0; c < C; c++) v += xcs[c * P + a] * (xcs[c * P + b] * lane_read(Sl, c));
+                        for (int c = 0; c < C; c++) v += (xcs[c * P + a] * xcs[c * P + b]) * lane_read(Sl, c);
                         lu.a[a][b] = v; lu.a[b][a] = v;
                     }
                     double v = 0.0;
@@ -731,13 +760,98 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         }
 
         // ---- post-loop block (:427-455) from the cell sums of the final mu ----------------------------------------
+        if constexpr (P >= DSQ_BETA_LANE_MIN) {
+            // one matrix column per lane: X'WX, its ridge inverse and sigma = Gi G Gi cost 2 P registers each
+            const int bl = lane < P ? lane : 0;
+            double Gc[P], Gic[P];
+#pragma unroll
+            for (int i = 0; i < P; i++) Gc[i] = 0.0;
+            for (int c = 0; c < C; c++) {
+                const double sc = lane_read(Sl, c);
+                const double xb = xcs[c * P + bl];
+#pragma unroll
+                for (int i = 0; i < P; i++) Gc[i] = Gc[i] + (xcs[c * P + i] * xb) * sc;
+            }
+            {
+                LaneLU<P> lu;
+#pragma unroll
+                for (int i = 0; i < P; i++) lu.a[i] = (lane == i) ? Gc[i] + kp.lambda[i] : Gc[i];
+                lu.factor(lane);
+                lu.inverse(Gic, lane);
+            }
+            if (kp.hat_diagonals || kp.mu_out) {
+                wave_lds_sync();
+                {
+                    const int cl = lane < C ? lane : 0;
+                    double eta = xcs[cl * P] * beta[0];
+#pragma unroll
+                    for (int k = 1; k < P; k++) eta = __builtin_fma(xcs[cl * P + k], beta[k], eta);
+                    double h = 0.0;
+#pragma unroll
+                    for (int i1 = 0; i1 < P; i1++) {
+                        const double x1 = xcs[cl * P + i1];
+#pragma unroll
+                        for (int i2 = 0; i2 < P; i2++) h += x1 * (xcs[cl * P + i2] * lane_read(Gic[i2], i1));
+                    }
+                    if (lane < C) {
+                        slab[4 * lane] = expl;
+                        slab[4 * lane + 2] = dexp(eta);
+                        slab[4 * lane + 3] = h;
+                    }
+                }
+                wave_lds_sync();
+                for (int k = lane; k < m; k += 64) {
+                    const int pk = pc[k];
+                    const int j = pk & 0x3ffffff, c = pk >> 26;
+                    const double nf = nfg[j];
+                    if (kp.hat_diagonals) {
+                        const double mu = __builtin_fmax(nf * slab[4 * c], minmu);
+                        const double rcp = 1.0 / (1.0 + alpha * mu);
+                        double wv;
+                        if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
+                        else wv = mu * rcp;
+                        kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * slab[4 * c + 3];
+                    }
+                    if (kp.mu_out) {
+                        double v = nf * slab[4 * c + 2];
+                        if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
+                        kp.mu_out[(size_t)g * kp.ld + j] = v;
+                    }
+                }
+            }
+            double Tc[P], Sgc[P];
+            lane_mat_mul<P>(Gic, Gc, Tc);
+            lane_mat_mul<P>(Tc, Gic, Sgc);
+            double cn = 0.0;
+#pragma unroll
+            for (int c = 0; c < P; c++) cn = __builtin_fma(kp.contrast[c], beta[c], cn);
+            double rr = 0.0;
+#pragma unroll
+            for (int a = 0; a < P; a++) rr = __builtin_fma(kp.contrast[a], Sgc[a], rr);
+            double cd = 0.0;
+#pragma unroll
+            for (int b = 0; b < P; b++) cd = __builtin_fma(lane_read(rr, b), kp.contrast[b], cd);
+            double sdiag = 0.0, bsel = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; i++) { sdiag = (lane == i) ? Sgc[i] : sdiag; bsel = (lane == i) ? beta[i] : bsel; }
+            if (lane < P) {
+                kp.beta_mat[(size_t)g + (size_t)kp.n * lane] = bsel;
+                kp.beta_var_mat[(size_t)g + (size_t)kp.n * lane] = sdiag;
+            }
+            if (lane == 0) {
+                kp.iter[g] = it;
+                kp.deviance[g] = dev;
+                kp.contrast_num[g] = cn;
+                kp.contrast_denom[g] = __builtin_sqrt(cd);
+            }
+        } else {
         double G[P][P], Gi[P][P];
 #pragma unroll
         for (int a = 0; a < P; a++)
 #pragma unroll
             for (int b = a; b < P; b++) {
                 double v = 0.0;
-                for (int c = 0; c < C; c++) v += xcs[c * P + a] * (xcs[c * P + b] * lane_read(Sl, c));
+                for (int c = 0; c < C; c++) v += (xcs[c * P + a] * xcs[c * P + b]) * lane_read(Sl, c);
                 G[a][b] = v; G[b][a] = v;
             }
         {
@@ -811,6 +925,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             kp.deviance[g] = dev;
             kp.contrast_num[g] = cn;
             kp.contrast_denom[g] = __builtin_sqrt(cd);
+        }
         }
     }
 }

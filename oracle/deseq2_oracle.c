@@ -167,10 +167,10 @@ static double trace_sym(int q, const double *a, const double *b) {
 }
 
 #define ORC_CMAX 32
-/* which designs take the cell-collapsed paths (the engine's rule): fitBeta with at most 10 columns (the
- * register-resident kernels), the Cox-Reid matrices of fitDisp from 5 columns up (below that the per-sample
- * accumulation of the p(p+1)/2 <= 10 entries is cheaper than the per-cell passes) */
-#define ORC_BETA_CELL_MAXP 10
+/* which designs take the cell-collapsed paths (the engine's rule): fitBeta at every width, the Cox-Reid
+ * matrices of fitDisp from 5 columns up (below that the per-sample accumulation of the p(p+1)/2 <= 10 entries is
+ * cheaper than the per-cell passes) */
+#define ORC_BETA_CELL_MAXP 24
 #define ORC_DISP_CELL_MINP 5
 static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc);
 
@@ -720,7 +720,7 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
             for (int a = 0; a < p; a++) {
                 for (int b = a; b < p; b++) {
                     double v = 0.0;
-                    for (int c = 0; c < C; c++) v += xc[c * p + a] * (xc[c * p + b] * Sc[c]);
+                    for (int c = 0; c < C; c++) v += (xc[c * p + a] * xc[c * p + b]) * Sc[c];
                     G[a * p + b] = v; G[b * p + a] = v;
                 }
                 double v = 0.0;
@@ -753,7 +753,7 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
     for (int a = 0; a < p; a++)
         for (int b = a; b < p; b++) {
             double v = 0.0;
-            for (int c = 0; c < C; c++) v += xc[c * p + a] * (xc[c * p + b] * Sc[c]);
+            for (int c = 0; c < C; c++) v += (xc[c * p + a] * xc[c * p + b]) * Sc[c];
             G[a * p + b] = v; G[b * p + a] = v;
         }
     memcpy(Gr, G, sizeof(double) * p * p);
