@@ -612,11 +612,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     const double raw = nf * e;
                     const double mu = __builtin_fmax(raw, minmu);
                     const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
-                    if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
-                    else wv = mu * rcp;
+                    double rw = rcp;
+                    if constexpr (USE_W) rw = wg[j] * rcp;
+                    wv = mu * rw;
                     const double lg = (raw >= minmu) ? eta : dlog(mu / nf);
-                    const double zj = lg + (y - mu) / mu;
-                    wz = wv * zj;
+                    wz = wv * lg + rw * (y - mu);       // w z, with w / mu = [wts] / (1 + alpha mu): no second division
                     if (with_dev) {
                         double t;
                         if (cell_dev_closed(y, size, fast)) {
@@ -808,7 +808,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                         const double mu = __builtin_fmax(nf * slab[4 * c], minmu);
                         const double rcp = 1.0 / (1.0 + alpha * mu);
                         double wv;
-                        if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
+                        if constexpr (USE_W) wv = mu * (wg[j] * rcp);
                         else wv = mu * rcp;
                         kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * slab[4 * c + 3];
                     }
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     const double mu = __builtin_fmax(nf * slab[4 * c], minmu);
                     const double rcp = 1.0 / (1.0 + alpha * mu);
                     double wv;
-                    if constexpr (USE_W) wv = (wg[j] * mu) * rcp;
+                    if constexpr (USE_W) wv = mu * (wg[j] * rcp);
                     else wv = mu * rcp;
                     kp.hat_diagonals[(size_t)g * kp.ld + j] = wv * slab[4 * c + 3];
                 }

@@ -25,7 +25,12 @@ namespace dsq {
 // design widths from DSQ_DISP_LANE_MIN up keep the p x p Cox-Reid matrices ONE COLUMN PER LANE (LaneLU, dsq_wave.hpp)
 // instead of wave-uniform in every lane's registers: 2 p instead of 2 p^2 VGPRs per matrix, p^2 instead of p^3 work
 #ifndef DSQ_DISP_LANE_MIN
-#define DSQ_DISP_LANE_MIN 7
+#define DSQ_DISP_LANE_MIN 4
+#endif
+// ... and from DSQ_DISP_ROWPASS_MIN up the general (non-cell) pass accumulates one matrix row per sweep over the samples
+// (the K p(p+1)/2 running sums of a single sweep no longer fit in registers)
+#ifndef DSQ_DISP_ROWPASS_MIN
+#define DSQ_DISP_ROWPASS_MIN 7
 #endif
 typedef double DsqMat1[1][DSQ_P][DSQ_P];
 typedef double DsqMat2[2][DSQ_P][DSQ_P];
@@ -212,7 +217,7 @@ DSQ_UNROLL_P
             }
             return;
         }
-        if constexpr (LANE) {
+        if constexpr (P >= DSQ_DISP_ROWPASS_MIN) {
             // K * P(P+1)/2 per-lane running sums do not fit in registers.  One matrix row per pass over the samples
             // instead (a rolled loop over the rows; the diagonals are recomputed per pass, a division per sample, the
             // caller's likelihood terms added in the first pass only).  Same terms, same order per entry, same wave
@@ -299,17 +304,39 @@ DSQ_UNROLL_P
                 }
             }
             wave_allreduce_n(acc);
-DSQ_UNROLL_P
-            for (int k = 0; k < K; k++) {
-                int idx = 0;
-DSQ_UNROLL_P
-                for (int a = 0; a < P; a++)
-DSQ_UNROLL_P
-                    for (int b = a; b < P; b++) {
-                        B[k][a][b] = acc[k * N + idx];
-                        B[k][b][a] = acc[k * N + idx];
-                        idx++;
+            if constexpr (LANE) {
+                // the reduced entries are wave-uniform: lane b picks column b
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++)
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) {
+                        double v = 0.0;
+                        _Pragma("unroll")
+                        for (int b = 0; b < P; b++) {
+                            const int lo = i < b ? i : b, hi = i < b ? b : i;
+                            const int idx = lo * P - (lo * (lo - 1)) / 2 + (hi - lo);
+                            v = (lane == b) ? acc[k * N + idx] : v;
+                        }
+                        B[k][i] = v;
                     }
+                if constexpr (USE_W) {
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++)
+                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                }
+            } else {
+DSQ_UNROLL_P
+                for (int k = 0; k < K; k++) {
+                    int idx = 0;
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                        for (int b = a; b < P; b++) {
+                            B[k][a][b] = acc[k * N + idx];
+                            B[k][b][a] = acc[k * N + idx];
+                            idx++;
+                        }
+                }
             }
         }
         if constexpr (!LANE && USE_W) {
@@ -349,7 +376,8 @@ DSQ_UNROLL_P
     DSQ_DEV double lp(double la) const {
         const double alpha = dexp(la);
         const double an1 = 1.0 / alpha;
-        const double lg_an1 = dlgamma(an1);
+        double lg_an1 = 0.0;
+        if constexpr (USE_W) lg_an1 = dlgamma(an1);
         double acc = 0.0;
         double cr_term = 0.0;
         {
@@ -392,8 +420,15 @@ DSQ_UNROLL_P
         if constexpr (USE_W) {
             ll_part = wave_allreduce(acc);
         } else {
+            // distinct counts at positions 1 .. nv; position 0 (lane 0 of the first trip) evaluates lgamma(1/alpha) itself
             double accv = 0.0;
-            for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dlgamma((double)dv[i] + an1) - lg_an1);
+            for (int q0 = 0; q0 <= nv; q0 += 64) {
+                const int q = q0 + lane;
+                const bool live = (q > 0) && (q <= nv);
+                const double lg = dlgamma((live || q == 0) ? (live ? (double)dv[q - 1] : 0.0) + an1 : 20.0);
+                if (q0 == 0) lg_an1 = lane_read(lg, 0);
+                if (live) accv += (double)dc[q - 1] * (lg - lg_an1);
+            }
             const double sv = wave_allreduce(accv);
             ll_part = sv + wave_allreduce(acc);
         }
@@ -414,8 +449,8 @@ DSQ_UNROLL_P
         const double alpha = dexp(la);
         const double an1 = 1.0 / alpha;
         const double an2 = 1.0 / (alpha * alpha);
-        double lg_an1, dg_an1;
-        dlgamma_digamma(an1, lg_an1, dg_an1);
+        double lg_an1 = 0.0, dg_an1 = 0.0;
+        if constexpr (USE_W) dlgamma_digamma(an1, lg_an1, dg_an1);
         double acc = 0.0, acc2 = 0.0;
         double cr_lp = 0.0, cr_dlp = 0.0;
         {
@@ -462,12 +497,17 @@ DSQ_UNROLL_P
             ll_dpart = an2 * wave_allreduce(acc2);
         } else {
             double accv = 0.0, accv2 = 0.0;
-            for (int i = lane; i < nv; i += 64) {
+            for (int q0 = 0; q0 <= nv; q0 += 64) {        // position 0: lgamma / digamma of 1/alpha itself (see lp)
+                const int q = q0 + lane;
+                const bool live = (q > 0) && (q <= nv);
                 double lg, dg;
-                dlgamma_digamma((double)dv[i] + an1, lg, dg);
-                const double c = (double)dc[i];
-                accv += c * (lg - lg_an1);
-                accv2 += c * (dg_an1 - dg);
+                dlgamma_digamma((live || q == 0) ? (live ? (double)dv[q - 1] : 0.0) + an1 : 20.0, lg, dg);
+                if (q0 == 0) { lg_an1 = lane_read(lg, 0); dg_an1 = lane_read(dg, 0); }
+                if (live) {
+                    const double c = (double)dc[q - 1];
+                    accv += c * (lg - lg_an1);
+                    accv2 += c * (dg_an1 - dg);
+                }
             }
             double sv = wave_allreduce(accv), sv2 = wave_allreduce(accv2);
             ll_part = sv + wave_allreduce(acc);
@@ -488,7 +528,8 @@ DSQ_UNROLL_P
         const double alpha = dexp(la);
         const double an1 = 1.0 / alpha;
         const double an2 = 1.0 / (alpha * alpha);
-        const double dg_an1 = ddigamma(an1);
+        double dg_an1 = 0.0;
+        if constexpr (USE_W) dg_an1 = ddigamma(an1);
         double acc = 0.0;
         double cr_term = 0.0;
         {
@@ -525,7 +566,13 @@ DSQ_UNROLL_P
             ll_sum = wave_allreduce(acc);
         } else {
             double accv = 0.0;
-            for (int i = lane; i < nv; i += 64) accv += (double)dc[i] * (dg_an1 - ddigamma((double)dv[i] + an1));
+            for (int q0 = 0; q0 <= nv; q0 += 64) {        // position 0: digamma(1/alpha) itself (see lp)
+                const int q = q0 + lane;
+                const bool live = (q > 0) && (q <= nv);
+                const double dg = ddigamma((live || q == 0) ? (live ? (double)dv[q - 1] : 0.0) + an1 : 20.0);
+                if (q0 == 0) dg_an1 = lane_read(dg, 0);
+                if (live) accv += (double)dc[q - 1] * (dg_an1 - dg);
+            }
             double sv = wave_allreduce(accv);
             ll_sum = sv + wave_allreduce(acc);
         }
@@ -621,7 +668,7 @@ DSQ_UNROLL_P
 //   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
 // lane-column builds: per-wave LDS arena through which the general-mode pass hands the reduced Cox-Reid rows to the
 // lanes (3 p p doubles: the second-derivative kernel has three matrices)
-__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_DISP_LANE_MIN ? (size_t)3 * p * p : 0; }
+__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_DISP_ROWPASS_MIN ? (size_t)3 * p * p : 0; }
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {

@@ -303,13 +303,14 @@ static double log_posterior(double log_alpha, const gene_t *g, double *scratch) 
     /* :53,55  sum_j [w_j] ( lgamma(y_j + 1/a) - lgamma(1/a) - y_j log(mu_j + 1/a) - (1/a) log(1 + mu_j a) ), with
      *   log(mu + 1/a) = log(1 + mu a) - log a      (one logarithm per sample instead of two), and, without weights,
      *   sum_j (lgamma(y_j + 1/a) - lgamma(1/a)) = sum_v c_v (lgamma(v + 1/a) - lgamma(1/a))  over the distinct
-     *   counts v with multiplicity c_v (one lgamma per distinct count instead of one per sample).               */
+     *   counts v with multiplicity c_v (one lgamma per distinct count instead of one per sample); distinct value i
+     *   goes to partial i + 1 (slot 0 of the engine's first trip evaluates lgamma(1/a) itself).                 */
     wsum_t s; wsum_init(&s, g->serial);
     double ll_part;
     if (g->dv) {
         wsum_t sv; wsum_init(&sv, g->serial);
         for (int i = 0; i < g->nv; i++)
-            wsum_add(&sv, i, g->dc[i] * (orc_lgamma(g->dv[i] + alpha_neg1) - lg_an1));
+            wsum_add(&sv, i + 1, g->dc[i] * (orc_lgamma(g->dv[i] + alpha_neg1) - lg_an1));
         for (int k = 0; k < m; k++) {
             const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
@@ -364,7 +365,7 @@ static double dlog_posterior(double log_alpha, const gene_t *g, double *scratch)
     if (g->dv) {
         wsum_t sv; wsum_init(&sv, g->serial);
         for (int i = 0; i < g->nv; i++)
-            wsum_add(&sv, i, g->dc[i] * (dg_an1 - orc_digamma(g->dv[i] + alpha_neg1)));
+            wsum_add(&sv, i + 1, g->dc[i] * (dg_an1 - orc_digamma(g->dv[i] + alpha_neg1)));
         for (int k = 0; k < m; k++) {
             const int j = POS_J(g, k);
             double y = g->y[j], mu = g->mu[j];
@@ -663,10 +664,11 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
                 const double raw = nfrow[j] * exp_c[c]; \
                 const double mu = fmax(raw, minmu); \
                 const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm; \
-                const double wv = useWeights ? (wts[j] * mu) * rcp : mu * rcp; \
+                const double rw = useWeights ? wts[j] * rcp : rcp; \
+                const double wv = mu * rw; \
                 const double lg = (raw >= minmu) ? eta_c[c] : orc_log(mu / nfrow[j]); \
-                const double zj = lg + (yrow[j] - mu) / mu; \
-                wsum_add(&s1, r, wv); wsum_add(&s2, r, wv * zj); \
+                /* w z = w log(mu/nf) + w (y - mu)/mu, and w / mu = [wts] / (1 + alpha mu): no second division */ \
+                wsum_add(&s1, r, wv); wsum_add(&s2, r, wv * lg + rw * (yrow[j] - mu)); \
                 if (WITH_DEV) { \
                     double t; \
                     if (cell_dev_class(yrow[j], size, fast) == 0) { \
@@ -767,7 +769,7 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
             const int j = perm[k];
             const double mu = fmax(nfrow[j] * exp_c[c], minmu);
             const double rcp = 1.0 / (1.0 + alpha * mu);
-            const double wv = useWeights ? (wts[j] * mu) * rcp : mu * rcp;
+            const double wv = mu * (useWeights ? wts[j] * rcp : rcp);
             hat[j] = wv * h;
         }
     }
