@@ -197,7 +197,7 @@ size_t trend_fit_workspace_bytes();
 #define DSQ_P_WIDE0 16
 #define DSQ_P_WIDE 24
 #define DSQ_CMAX 32       // most design cells the cell-collapsed paths take
-#define DSQ_DISP_CELL_MINP 5   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
+#define DSQ_DISP_CELL_MINP 4   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
 template <int P> hipError_t launch_fit_beta_p(const BetaKernelParams &kp, hipStream_t st);
 template <int P> hipError_t launch_optim_p(const OptimKernelParams &kp, hipStream_t st);

@@ -168,10 +168,10 @@ static double trace_sym(int q, const double *a, const double *b) {
 
 #define ORC_CMAX 32
 /* which designs take the cell-collapsed paths (the engine's rule): fitBeta at every width, the Cox-Reid
- * matrices of fitDisp from 5 columns up (below that the per-sample accumulation of the p(p+1)/2 <= 10 entries is
+ * matrices of fitDisp from 4 columns up (below that the per-sample accumulation of the p(p+1)/2 <= 6 entries is
  * cheaper than the per-cell passes) */
 #define ORC_BETA_CELL_MAXP 24
-#define ORC_DISP_CELL_MINP 5
+#define ORC_DISP_CELL_MINP 4
 static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc);
 
 /* ------------------------------------------------ one gene's row context ---- */

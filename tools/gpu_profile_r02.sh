@@ -14,7 +14,8 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 cd $R
 python profiles/summarize_rocpd.py $(find $O/prof -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
 P1=$(dirname $(find $O/pmc1 -name "p_counter_collection.csv" | head -1)); P2=$(dirname $(find $O/pmc2 -name "p_counter_collection.csv" | head -1)); P3=$(dirname $(find $O/pmc3 -name "p_counter_collection.csv" | head -1))
-python tools/pmc_summary.py $P2 $P3 $P1 $O/pmc.json > $O/pmc_summary.log 2>&1
+NG=$(python -c "import bench; print(bench.CONFIGS['$CFG']['genes'])")
+python tools/pmc_summary.py $P2 $P3 $P1 $O/pmc.json $NG "rocprofv3 --pmc passes (SQ_*, FETCH_SIZE, WRITE_SIZE separately) of bench.py --config $CFG --steps 2 --warmup 1, state $TAG; means over the launches with the largest grid of each kernel; FETCH_SIZE x2 (gfx950 note) + WRITE_SIZE; tools/gpu_profile_r02.sh" > $O/pmc_summary.log 2>&1
 # keep the merge small: drop the raw traces
 rm -rf $O/prof $O/pmc1 $O/pmc2 $O/pmc3
 head -30 $O/kernel_stats.md; tail -5 $O/pmc_summary.log; tail -2 $O/prof.log

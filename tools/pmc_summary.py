@@ -39,6 +39,11 @@ def main(fetch_dir, write_dir, sq_dir, out):
         if "SQ_ACTIVE_INST_VALU" in r and "SQ_WAVE_CYCLES" in r and r["SQ_WAVE_CYCLES"]:
             r["valu_active_frac_of_wave_cycles"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"]
         res[k] = r
+    if "fit_beta_cell" in res and "fit_beta" not in res:
+        res["fit_beta"] = dict(res["fit_beta_cell"])       # factor designs run the cell-collapsed fitBeta kernel
+    if len(sys.argv) > 5:
+        res["_genes_per_launch"] = int(sys.argv[5])
+        res["_note"] = sys.argv[6] if len(sys.argv) > 6 else ""
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
