@@ -140,10 +140,25 @@ def main():
     comm_dev = None if one_dev else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
+        if one_dev or os.environ.get("DSQ_BENCH_COMM") == "gloo":
             dist.init_process_group(backend="gloo")
+            comm_dev = None
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            # RCCL for the two small n-vector all-gathers of the chain; if it cannot come up on this node the same
+            # exchange runs through the host (gloo) -- the data path has no collective either way
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:                                   # noqa: BLE001
+                print("bench.py: RCCL unavailable (%r), exchanging the n-vectors over gloo" % (e,), file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:                                    # noqa: BLE001
+                    pass
+                dist.init_process_group(backend="gloo")
+                comm_dev = None
 
     from deseq2_amd import core, fused, simulate, parallel
     from deseq2_amd.engine import DeviceEngine

@@ -78,6 +78,21 @@ DSQ_DEV double wave_allreduce(double v) {
     return v;
 }
 
+// all-reduce of a value that is +0.0 outside lanes [0, nlive) (nlive wave-uniform): when the live lanes sit in the first
+// row(s) of 16 the cross-row steps only ever add +0.0, which is done here without the permlane swaps.  Lanes < nlive end
+// with the same bits as wave_allreduce gives (x + 0.0 keeps the -0.0 -> +0.0 behaviour of the skipped additions); the
+// other lanes do NOT hold the total.
+DSQ_DEV double wave_allreduce_low(double v, int nlive) {
+    v = v + lane_xor1(v);
+    v = v + lane_xor2(v);
+    v = v + lane_xor4(v);
+    v = v + lane_xor8(v);
+    double a, b;
+    if (nlive > 16) { lane_pair16(v, a, b); v = a + b; } else v = v + 0.0;
+    if (nlive > 32) { lane_pair32(v, a, b); v = a + b; } else v = v + 0.0;
+    return v;
+}
+
 template <int N>
 DSQ_DEV void wave_allreduce_n(double (&v)[N]) {
 DSQ_UNROLL_P

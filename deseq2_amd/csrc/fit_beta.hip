@@ -570,14 +570,18 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         // the mu-independent part of the log densities, once per gene (samples in their natural order):
         // K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j,  n = y + size;  0 for y = 0
         if (with_dev_ever) {
-            const double st_size = dstirlerr(size), log_size = dlog(size);
+            const double st_size = dstirlerr(size);
             double kacc = 0.0;
             for (int j = lane; j < m; j += 64) {
                 const double y = (double)yg[j];
                 double kj = 0.0;
                 if (y != 0.0 && cell_dev_closed(y, size, fast)) {
+                    // saddle-point constants with their logarithms folded: log(size/(size+y)) = -L,
+                    // log1p(-size/n) = log y - log size - L, L = log1p(alpha y)
                     const double n = y + size;
-                    kj = dnb_const(y, size, st_size, log_size) + ((n * dlog1p(alpha * y) - y * dlog(y)) + y * dlog(nfg[j]));
+                    const double L = dlog1p(alpha * y), ly = dlog(y);
+                    const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
+                    kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * dlog(nfg[j]));
                 }
                 if constexpr (USE_W) kacc += wg[j] * kj;
                 else kacc += kj;
@@ -666,7 +670,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     for (int j = k; j < P; j++) acc[j] = below ? a[k] * a[j] : 0.0;
                     acc[P] = below ? a[k] * b : 0.0;
 #pragma unroll
-                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);
+                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce_low(acc[j], Mrows);   // (only rows < Mrows use them)
                     double prow[P + 1];
 #pragma unroll
                     for (int j = k; j < P; j++) prow[j] = lane_read(a[j], k);

@@ -684,7 +684,7 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
         if (WITH_DEV) dev = -2.0 * (K + wsum_total(&sd)); \
     } while (0)
     const int fast = (alpha > 0.0) && isfinite(alpha) && isfinite(size) && (size > 0.0);
-    const double st_size = (maxit > 0 && fast) ? orc_stirlerr(size) : 0.0, log_size = (maxit > 0 && fast) ? orc_log(size) : 0.0;
+    const double st_size = (maxit > 0 && fast) ? orc_stirlerr(size) : 0.0;
     double dev = 0.0, dev_old = 0.0, it = 0.0;
     if (maxit > 0 && fast) {
         /* the mu-independent part, once per gene, samples in their natural order */
@@ -692,10 +692,12 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
         for (int j = 0; j < m; j++) {
             double kj = 0.0;
             if (yrow[j] != 0.0 && cell_dev_class(yrow[j], size, fast) == 0) {
-                double cst;
-                orc_dnb_const(yrow[j], size, st_size, log_size, &cst);
+                /* saddle-point constants of dnbinom_mu with their logarithms folded: log(size/(size+y)) = -L and
+                 * log1p(-size/n) = log y - log size - L,  L = log1p(alpha y)  -- three logarithms per sample */
                 const double y = yrow[j], n = y + size;
-                kj = cst + ((n * orc_log1p(alpha * y) - y * orc_log(y)) + y * orc_log(nfrow[j]));
+                const double L = orc_log1p(alpha * y), ly = orc_log(y);
+                const double c0 = orc_stirlerr(n) - st_size - orc_stirlerr(n - size);
+                kj = -L + (c0 - 0.5 * (1.837877066409345483560659472811 /* ln 2 pi */ + ly - L)) + ((n * L - y * ly) + y * orc_log(nfrow[j]));
             }
             wsum_add(&sk, j, useWeights ? wts[j] * kj : kj);
         }
