@@ -42,6 +42,32 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_FACTS = {}
+
+
+def _design_facts(E, x, minReplicatesForReplace):
+    """what the chain needs to know about the DESIGN alone (cells, replaceable samples, the Cook's cutoff quantile,
+    whether the design is one group per column, trigamma((m - p) / 2)): host work, memoised per design like the QR"""
+    key = (x.shape, x.tobytes(), float(minReplicatesForReplace))
+    f = _FACTS.get(key)
+    if f is None:
+        from scipy.stats import f as fdist
+        from scipy import special as sps
+        m, p = x.shape
+        finite = bool(np.isfinite(minReplicatesForReplace))
+        rep = core.nOrMoreInCell(x, minReplicatesForReplace) if finite else np.zeros(m, bool)
+        f = dict(cells=np.ascontiguousarray(E.native.cell_index(x), dtype=np.int32),
+                 do_replace=bool(finite and rep.any()),
+                 replaceable=np.ascontiguousarray(rep.astype(np.int32)),
+                 cutoff=float(fdist.ppf(.99, p, m - p)),
+                 groups_eq_p=bool(len(np.unique(core.modelMatrixGroups(x))) == p),
+                 expVarLogDisp=float(sps.polygamma(1, (m - p) / 2.0)) if m > p else 0.0)
+        if len(_FACTS) > 16:
+            _FACTS.clear()
+        _FACTS[key] = f
+    return f
+
+
 class _Run:
     """buffers + argument block of one analysis"""
 
@@ -93,16 +119,14 @@ class _Run:
         self.grid = E._vec(grid)
         self.lam = np.ascontiguousarray(np.full(p, 1e-6) / np.log(2) ** 2)          # R/fitNbinomGLMs.R:73,162
         xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
-        cells = E.native.cell_index(x)
-        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
-        do_replace = bool(np.isfinite(minReplicatesForReplace) and core.nOrMoreInCell(x, minReplicatesForReplace).any())
+        facts = _design_facts(E, x, minReplicatesForReplace)
+        cells = facts["cells"]
+        self.cells = cells
+        do_replace = facts["do_replace"]
         self.do_replace = do_replace
-        rep = core.nOrMoreInCell(x, minReplicatesForReplace) if np.isfinite(minReplicatesForReplace) else np.zeros(m, bool)
-        self.replaceable = np.ascontiguousarray(rep.astype(np.int32))
-        from scipy.stats import f as fdist
-        from scipy import special as sps
-        cutoff = float(fdist.ppf(.99, p, m - p))                                     # R/core.R:2081
-        linearMu = (len(np.unique(core.modelMatrixGroups(x))) == p) and not self.useWeights   # :735-742
+        self.replaceable = facts["replaceable"]
+        cutoff = facts["cutoff"]                                                     # R/core.R:2081
+        linearMu = facts["groups_eq_p"] and not self.useWeights                      # :735-742
         self.args = L.DsqDeseqArgs(
             n=n, m=m, p=p, ld=ld, phases=0, y=_ptr(dds.y.t), nf=_ptr(dds.nf.t), nf_is_vector=0,
             useWeights=int(self.useWeights),
@@ -114,7 +138,7 @@ class _Run:
             betaTol=kw.get("betaTol", 1e-8), minmu=kw.get("minmu", 0.5), maxit=int(kw.get("disp_maxit", 100)),
             useCR=int(kw.get("useCR", True)), useQR=int(kw.get("useQR", True)), betaMaxit=int(kw.get("maxit", 100)),
             disp_grid=_ptr(self.grid), ngrid=20,
-            expVarLogDisp=float(sps.polygamma(1, (m - p) / 2.0)) if m > p else 0.0,
+            expVarLogDisp=facts["expVarLogDisp"],
             trend_mean=None, trend_disp=None, n_trend=int(n_trend), lambda_=self.lam.ctypes.data_as(C.c_void_p),
             min_log_alpha=float(np.log(minDisp / 10)), workspace=_ptr(self.workspace), workspace_bytes=wsb,
             test=0 if test == "Wald" else 1, cell_of=self.cells.ctypes.data_as(C.c_void_p),
