@@ -90,15 +90,49 @@ DSQ_DEV void beta_gram_wide(const double *xs, int m, int lane, FW &&wz, double (
 }
 
 // per-sample state a wave keeps across passes: sqrt(w); mu and sqrt(w)*z sharing one slot (mu is
-// dead once pass A has turned it into the working response); two of the three hoisted NB-density
-// constants.  The third (read once per iteration, streaming) lives in an L2-resident scratch row so
-// that X and the slabs of 4 genes still fit twice into a CU's 160 KiB of LDS at m = 500.
-static constexpr int kSlabVecs = 4;
+// dead once pass A has turned it into the working response); log(mu / nf) of the current mu (z and the
+// closed-form deviance both use it)
+static constexpr int kSlabVecs = 3;      // sqrt(w) | mu (or sqrt(w) z) | log(mu / nf)
 
 // min waves per SIMD the register allocator must leave room for (2 => <= 256 unified registers)
 #ifndef DSQ_BETA_MINW
 #define DSQ_BETA_MINW (DSQ_P <= 6 ? 2 : 1)   /* wide designs already spill at 512 registers */
 #endif
+
+// the rarely taken branch of the deviance sweep (a sample whose log density does not follow the closed split, e.g. a
+// count below 1e-10 size): the full dnbinom_mu, kept out of line so that its registers do not count against the sweep's
+__device__ __noinline__ static double nb_offbranch(double y, double size, double mu) { return dnbinom_mu_log(y, size, mu); }
+
+// 0: log NB(y; size, mu) = K_j + y lg - (y + size) log1p(alpha mu)  (zero counts and the general branch of dnbinom_mu)
+DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
+    const double n = y + size;
+    const bool gen = (y > 0.0) && dfinite(y) && !(y < 1e-10 * size) && (n != size) && dfinite(n);
+    return fast && (y == 0.0 || gen);
+}
+
+// K = sum_j [wts_j] K_j, the mu-independent part of the IRLS deviance, samples in their natural order:
+// K_j = [saddle-point constants of dnbinom_mu, logarithms folded] + n log1p(alpha y) - y log y + y log nf_j  (0 for y = 0)
+template <bool USE_W>
+DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double *wg, int m, int lane, double alpha,
+                              double size, bool fast) {
+    if (!fast) return 0.0;
+    const double st_size = dstirlerr(size);
+    double kacc = 0.0;
+    for (int j = lane; j < m; j += 64) {
+        const double y = (double)yg[j];
+        double kj = 0.0;
+        if (y != 0.0 && cell_dev_closed(y, size, fast)) {
+            // log(size/(size+y)) = -L, log1p(-size/n) = log y - log size - L, L = log1p(alpha y)
+            const double n = y + size;
+            const double L = dlog1p(alpha * y), ly = dlog(y);
+            const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
+            kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * dlog(nfg[j]));
+        }
+        if constexpr (USE_W) kacc += wg[j] * kj;
+        else kacc += kj;
+    }
+    return wave_allreduce(kacc);
+}
 
 template <int P, bool USE_W, bool STAGE>
 __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernelParams kp) {
@@ -131,8 +165,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     int arena_off = 0;
 #endif
     double *sw_s = slab, *mu_s = slab + m, *b_s = mu_s;   // mu and sqrt(w)*z share a slot
-    double *cs = slab + 2 * (size_t)m;                     // c0 | c2   (LDS)
-    double *cg = kp.cscratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m;   // c1 (L2)
+    double *lg_s = slab + 2 * (size_t)m;                   // log(mu / nf) of the current mu
 
     DSQ_BWORK(DsqVecP, lambda);
     DSQ_BWORK(DsqVecP, contrast);
@@ -160,7 +193,9 @@ DSQ_UNROLL_P
                 double eta = xs[j] * beta[0];
 DSQ_UNROLL_P
                 for (int c = 1; c < P; c++) eta = __builtin_fma(xs[c * m + j], beta[c], eta);
-                mu_s[j] = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
+                const double mu = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
+                mu_s[j] = mu;
+                lg_s[j] = dlog(mu / nfg[j]);             // used by z (:349,:397) and by the deviance
             }
         };
         // w_vec / w_sqrt_vec                                      (:336-342, :390-396, :430-436)
@@ -171,13 +206,11 @@ DSQ_UNROLL_P
 
         update_mu();
         const int abl = kp.ablate;   // profiling only: 0 in production
-        if (kp.maxit > 0 && !(abl & 16)) {
-            const double st_size = dstirlerr(size), log_size = dlog(size);   // wave-uniform
-            for (int j = lane; j < m; j += 64) {
-                DnbConst c = dnb_prepare((double)yg[j], size, st_size, log_size);
-                cs[j] = c.c0; cs[m + j] = c.c2; cg[j] = c.c1;
-            }
-        }
+        // dev = -2 (K + D): the mu-independent part of the NB log densities once per gene, one logarithm per sample and
+        // iteration for the rest (the closed split of the cell kernel below)
+        const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
+        double K = 0.0;
+        if (kp.maxit > 0 && !(abl & 16)) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast);
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
         DSQ_BWORK(DsqVecP, beta_prev);   // beta the current mu slot was computed from
@@ -198,7 +231,7 @@ DSQ_UNROLL_P
                 for (int j = lane; j < m; j += 64) {
                     double mu = mu_s[j];
                     double sw = __builtin_sqrt(wvec(j, mu));
-                    double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                    double z = lg_s[j] + ((double)yg[j] - mu) / mu;
                     sw_s[j] = sw;
                     b_s[j] = z * sw;
                 }
@@ -286,7 +319,7 @@ DSQ_UNROLL_Q
                     beta_gram_wide<P, true>(xs, m, lane, [&](int j, double &wv, double &zw) {
                         double mu = mu_s[j];
                         wv = wvec(j, mu);
-                        double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                        double z = lg_s[j] + ((double)yg[j] - mu) / mu;
                         zw = z * wv;
                     }, lu.a, rhs);
 DSQ_UNROLL_P
@@ -302,7 +335,7 @@ DSQ_UNROLL_P
                     for (int j = lane; j < m; j += 64) {
                         double mu = mu_s[j];
                         double wv = wvec(j, mu);
-                        double z = dlog(mu / nfg[j]) + ((double)yg[j] - mu) / mu;
+                        double z = lg_s[j] + ((double)yg[j] - mu) / mu;
                         double xr[P];
 DSQ_UNROLL_P
                         for (int c = 0; c < P; c++) xr[c] = xs[c * m + j];
@@ -340,15 +373,17 @@ DSQ_UNROLL_P
             double dacc = 0.0;                                                            // (:365-373)
             if (!(abl & 8))
             for (int j = lane; j < m; j += 64) {
-                DnbConst c;
-                c.c0 = cs[j]; c.c2 = cs[m + j]; c.c1 = cg[j];
-                double d = dnb_eval((double)yg[j], size, mu_s[j], c);
-                double term;
-                if constexpr (USE_W) term = (-2.0 * wg[j]) * d;
-                else term = -2.0 * d;
-                dacc += term;
+                const double y = (double)yg[j], mu = mu_s[j];
+                double tj;
+                if (cell_dev_closed(y, size, fast)) {
+                    const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
+                    const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
+                    tj = y * lg_s[j] - (y + size) * l1p;
+                } else tj = nb_offbranch(y, size, mu);
+                if constexpr (USE_W) dacc += wg[j] * tj;
+                else dacc += tj;
             }
-            dev = wave_allreduce(dacc);
+            dev = -2.0 * (K + wave_allreduce(dacc));
             double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
             if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }        // (:375-378)
             if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
@@ -493,17 +528,6 @@ __host__ __device__ static inline size_t beta_cell_wave_doubles(int m, bool use_
     return 4 * (size_t)DSQ_CMAX;
 }
 
-// the rarely taken branch of the deviance sweep (a sample whose log density does not follow the closed split, e.g. a
-// count below 1e-10 size): the full dnbinom_mu, kept out of line so that its registers do not count against the sweep's
-__device__ __noinline__ static double nb_offbranch(double y, double size, double mu) { return dnbinom_mu_log(y, size, mu); }
-
-// 0: log NB(y; size, mu) = K_j + y lg - (y + size) log1p(alpha mu)  (zero counts and the general branch of dnbinom_mu)
-DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
-    const double n = y + size;
-    const bool gen = (y > 0.0) && dfinite(y) && !(y < 1e-10 * size) && (n != size) && dfinite(n);
-    return fast && (y == 0.0 || gen);
-}
-
 template <int P, bool USE_W>
 __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -569,25 +593,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         double K = 0.0, dev = 0.0;
         // the mu-independent part of the log densities, once per gene (samples in their natural order):
         // K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j,  n = y + size;  0 for y = 0
-        if (with_dev_ever) {
-            const double st_size = dstirlerr(size);
-            double kacc = 0.0;
-            for (int j = lane; j < m; j += 64) {
-                const double y = (double)yg[j];
-                double kj = 0.0;
-                if (y != 0.0 && cell_dev_closed(y, size, fast)) {
-                    // saddle-point constants with their logarithms folded: log(size/(size+y)) = -L,
-                    // log1p(-size/n) = log y - log size - L, L = log1p(alpha y)
-                    const double n = y + size;
-                    const double L = dlog1p(alpha * y), ly = dlog(y);
-                    const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
-                    kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * dlog(nfg[j]));
-                }
-                if constexpr (USE_W) kacc += wg[j] * kj;
-                else kacc += kj;
-            }
-            K = wave_allreduce(kacc);
-        }
+        if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast);
         // one sweep over the samples at the current beta: positions k = lane, lane + 64, ... of the cell-sorted
         // sequence (full trips); the sums of a cell are closed when the sweep leaves it.  Deviance term of a sample:
         // y lg - (y + size) log1p(alpha mu), lg = log(mu / nf) -- one logarithm (of the rounded 1 + alpha mu, plus

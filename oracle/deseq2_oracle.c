@@ -620,6 +620,28 @@ static int cell_dev_class(double y, double size, int fast) {
     return gen ? 0 : 1;
 }
 
+/* K = sum_j [wts_j] K_j, the mu-independent part of the IRLS deviance (see fit_beta_gene_cells), samples in their
+ * natural order; 0 when the closed split does not apply (fast = 0) */
+static double irls_constants(int m, const double *yrow, const double *nfrow, const double *wts, int useWeights,
+                             double alpha, double size, int fast, int sum_mode) {
+    if (!fast) return 0.0;
+    const double st_size = orc_stirlerr(size);
+    wsum_t sk; wsum_init(&sk, sum_mode);
+    for (int j = 0; j < m; j++) {
+        double kj = 0.0;
+        if (yrow[j] != 0.0 && cell_dev_class(yrow[j], size, fast) == 0) {
+            /* saddle-point constants of dnbinom_mu with their logarithms folded: log(size/(size+y)) = -L and
+             * log1p(-size/n) = log y - log size - L,  L = log1p(alpha y)  -- three logarithms per sample */
+            const double y = yrow[j], n = y + size;
+            const double L = orc_log1p(alpha * y), ly = orc_log(y);
+            const double c0 = orc_stirlerr(n) - st_size - orc_stirlerr(n - size);
+            kj = -L + (c0 - 0.5 * (1.837877066409345483560659472811 /* ln 2 pi */ + ly - L)) + ((n * L - y * ly) + y * orc_log(nfrow[j]));
+        }
+        wsum_add(&sk, j, useWeights ? wts[j] * kj : kj);
+    }
+    return wsum_total(&sk);
+}
+
 /* fitBeta in CELL MODE (at most ORC_CMAX design cells).  Within a cell every sample has the same design row x_c, so
  *   - the linear predictor is one value eta_c per cell, mu_j = max(nf_j exp(eta_c), minmu)       (:324-327, bits as
  *     in the general path);
@@ -684,25 +706,8 @@ static void fit_beta_gene_cells(int m, int p, int C, const int *perm, const int 
         if (WITH_DEV) dev = -2.0 * (K + wsum_total(&sd)); \
     } while (0)
     const int fast = (alpha > 0.0) && isfinite(alpha) && isfinite(size) && (size > 0.0);
-    const double st_size = (maxit > 0 && fast) ? orc_stirlerr(size) : 0.0;
     double dev = 0.0, dev_old = 0.0, it = 0.0;
-    if (maxit > 0 && fast) {
-        /* the mu-independent part, once per gene, samples in their natural order */
-        wsum_t sk; wsum_init(&sk, sum_mode);
-        for (int j = 0; j < m; j++) {
-            double kj = 0.0;
-            if (yrow[j] != 0.0 && cell_dev_class(yrow[j], size, fast) == 0) {
-                /* saddle-point constants of dnbinom_mu with their logarithms folded: log(size/(size+y)) = -L and
-                 * log1p(-size/n) = log y - log size - L,  L = log1p(alpha y)  -- three logarithms per sample */
-                const double y = yrow[j], n = y + size;
-                const double L = orc_log1p(alpha * y), ly = orc_log(y);
-                const double c0 = orc_stirlerr(n) - st_size - orc_stirlerr(n - size);
-                kj = -L + (c0 - 0.5 * (1.837877066409345483560659472811 /* ln 2 pi */ + ly - L)) + ((n * L - y * ly) + y * orc_log(nfrow[j]));
-            }
-            wsum_add(&sk, j, useWeights ? wts[j] * kj : kj);
-        }
-        K = wsum_total(&sk);
-    }
+    if (maxit > 0) K = irls_constants(m, yrow, nfrow, wts, useWeights, alpha, size, fast, sum_mode);
     CELL_ETA();
     CELL_SWEEP(0);
     for (int t = 0; t < maxit; t++) {
@@ -895,6 +900,9 @@ int orc_fit_beta(int n, int m, int p,
                                        : mu[j] / (1.0 + alpha * mu[j]); \
                 w_vec[j] = wv; w_sqrt[j] = sqrt(wv); }
         ORC_UPDATE_MU();
+        const double gsize = 1.0 / alpha;
+        const int gfast = (alpha > 0.0) && isfinite(alpha) && isfinite(gsize) && (gsize > 0.0);
+        const double gK = maxit > 0 ? irls_constants(m, yrow, nfrow, wts, useWeights, alpha, gsize, gfast, sum_mode) : 0.0;
         double dev = 0.0, dev_old = 0.0;                                         /* :329-330 */
         double it = 0.0;
         for (int t = 0; t < maxit; t++) {                                        /* :334 / :388 */
@@ -938,13 +946,19 @@ int orc_fit_beta(int n, int m, int p,
             for (int c = 0; c < p; c++) if (fabs(beta_hat[c]) > large) toolarge++;
             if (toolarge > 0) { it = (double)maxit; break; }                     /* :358-359 */
             ORC_UPDATE_MU();                                                     /* :361-364 */
-            wsum_t s; wsum_init(&s, sum_mode);                                   /* :365-373 */
+            /* :365-373  dev = -2 sum [wts] log NB(y; 1/alpha, mu) = -2 (K + D): the closed split of the cell path (see
+             * fit_beta_gene_cells), lg = log(mu/nf) -- the value z uses */
+            wsum_t s; wsum_init(&s, sum_mode);
             for (int j = 0; j < m; j++) {
-                double d = orc_dnbinom_mu_log(yrow[j], 1.0 / alpha, mu[j]);
-                double term = useWeights ? (-2.0 * wts[j]) * d : -2.0 * d;
-                wsum_add(&s, j, term);
+                double tj;
+                if (cell_dev_class(yrow[j], gsize, gfast) == 0) {
+                    const double am = alpha * mu[j], opm = 1.0 + am, rcp = 1.0 / opm;
+                    const double l1p = orc_log(opm) + (am - (opm - 1.0)) * rcp;
+                    tj = yrow[j] * orc_log(mu[j] / nfrow[j]) - (yrow[j] + gsize) * l1p;
+                } else tj = orc_dnbinom_mu_log(yrow[j], gsize, mu[j]);
+                wsum_add(&s, j, useWeights ? wts[j] * tj : tj);
             }
-            dev = wsum_total(&s);
+            dev = -2.0 * (gK + wsum_total(&s));
             double conv_test = fabs(dev - dev_old) / (fabs(dev) + 0.1);          /* :374 */
             if (isnan(conv_test)) { it = (double)maxit; break; }                 /* :375-378 */
             if ((t > 0) & (conv_test < tol)) break;                              /* :379-381 */

@@ -19,7 +19,15 @@ def one(job):
     n, m, design, seed, imean, alpha_mode, sfr = job
     from oracle import oracle, reference
     reference.use_fast(True)
-    d = make_case(n, m, design, seed=seed, sf_random=sfr, intercept_mean=imean)
+    cont = isinstance(design, tuple) and design[0] == "continuous"
+    d = make_case(n, m, design[1] if cont else design, seed=seed, sf_random=sfr, intercept_mean=imean)
+    if cont:
+        # a continuous covariate: one design cell per sample, i.e. the general (per-sample) path of the restatement
+        from tests.helpers import beta_init_qr
+        rng0 = np.random.default_rng(seed + 7)
+        d["x"] = np.column_stack([d["x"], rng0.normal(size=m)])
+        with np.errstate(all="ignore"):
+            d["beta_init"] = beta_init_qr(d["counts"].astype(float), d["nf"], d["x"])
     y = d["counts"].astype(float)
     nn = y.shape[0]
     rng = np.random.default_rng(seed)
@@ -47,7 +55,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     jobs = []
     seed = 100
-    for m, design in ((100, "batch_condition"), (500, "batch_condition"), (60, ("factor", 5)), (200, ("factor", 10)), (12, "two_group")):
+    designs = ((100, "batch_condition"), (500, "batch_condition"), (60, ("factor", 5)), (200, ("factor", 10)), (12, "two_group"))
+    if os.environ.get("STRESS_CONTINUOUS"):
+        designs = ((100, ("continuous", "batch_condition")), (60, ("continuous", "two_group")), (300, ("continuous", ("factor", 5))))
+    for m, design in designs:
         for imean in (4.0, 9.0, 14.0):
             for alpha_mode in ("rough", "floor", "wide"):
                 for sfr in (False, True):

@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""times the general (per-sample) kernels: a C3-shaped analysis whose design carries a continuous covariate"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from deseq2_amd import core, simulate
+from deseq2_amd.engine import DeviceEngine
+E = DeviceEngine("cuda:0")
+for n, m, extra in ((20000, 500, 1), (20000, 500, 3), (20000, 200, 6)):
+    x0 = simulate.design_batch_condition(m)
+    rng = np.random.default_rng(5)
+    x = np.column_stack([x0] + [rng.normal(size=m) for _ in range(extra)])
+    d = simulate.make_counts(n, x, seed=3, beta_sd=np.array([0.5] * (x.shape[1] - 2) + [1.0]) * 0.3)
+    dds = core.DESeqDataSet(d["counts"], x, engine=E)
+    for rep in range(2):
+        E.record = []
+        core.DESeq(dds, minReplicatesForReplace=np.inf)
+        rec, E.record = E.record, None
+    big = {}
+    for name, g, ms in rec:
+        if g > n // 2:
+            big.setdefault(name, []).append(ms)
+    print("p=%2d n=%d m=%d: " % (x.shape[1], dds.n, m) + "  ".join("%s %.2f ms" % (k, np.mean(v)) for k, v in big.items()), flush=True)
