@@ -58,7 +58,7 @@ struct BetaKernelParams {
     double *beta_mat, *beta_var_mat, *iter, *hat_diagonals, *contrast_num, *contrast_denom, *deviance;
     double *mu_out;
     double *scratch;        // global per-wave-slot scratch when rows are not staged in LDS
-    double *cscratch;       // per-wave-slot scratch for the hoisted NB-density constants (3 m doubles)
+    double *cscratch;       // (unused since the closed-form deviance; kept so that the launch plumbing stays put)
     int ablate, force_iters; // profiling only (env DSQ_ABLATE / DSQ_FORCE_ITERS): skip phases / fixed trip count
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
     int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)

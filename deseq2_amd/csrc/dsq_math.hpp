@@ -456,65 +456,4 @@ DSQ_DEV double dnbinom_mu_log(double x, double size, double mu) {
     return dlog(p) + ans;
 }
 
-// ---- NB log-density with the mu-independent part hoisted ----------------------------
-// dnbinom_mu_log(x, size, mu) on its general branch is
-//     log(size/(size+x)) + ( ((S(n) - S(size)) - S(n-size)) - bd0(size, n p) - bd0(n-size, n q)
-//                            - 0.5 (ln 2pi + log(size) + log1p(-size/n)) ),   n = x + size,
-// and only the two bd0 terms depend on mu.  During IRLS x and size are fixed per sample, so
-// the kernel computes c0 = (S(n)-S(size))-S(n-size), c1 = 0.5*lf, c2 = log(size/(size+x)) once
-// per gene and re-evaluates only bd0 per iteration -- same operations, same order, same bits.
-// c0 = NaN marks samples that are not on the general branch (x == 0, tiny x/size, ...): those
-// go through the full function every time.
-struct DnbConst { double c0, c1, c2; };
-
-// st_size = dstirlerr(size) and log_size = dlog(size) are the same for every sample of a gene:
-// the caller evaluates them once per gene.
-DSQ_DEV DnbConst dnb_prepare(double x, double size, double st_size, double log_size) {
-    DnbConst c;
-    c.c0 = dnan(); c.c1 = 0.0; c.c2 = 0.0;
-    double n = x + size;
-    bool general = (x > 0.0) && dfinite(x) && (size > 0.0) && dfinite(size) && !(x < 1e-10 * size) &&
-                   (n != size) && dfinite(n);
-    if (general) {
-        c.c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
-        double lf = kLn2Pi + log_size + dlog1p(-size / n);
-        c.c1 = 0.5 * lf;
-        c.c2 = dlog(size / (size + x));
-    }
-    return c;
-}
-
-// the same split with the constants folded into one value (cell-collapsed fitBeta: they are summed once per gene):
-// dnb_general = (x, size) is on the general branch; dnb_const = c2 + (c0 - c1); dnb_iter = -bd0(size, n p) - bd0(x, n q)
-DSQ_DEV bool dnb_general(double x, double size) {
-    const double n = x + size;
-    return (x > 0.0) && dfinite(x) && (size > 0.0) && dfinite(size) && !(x < 1e-10 * size) && (n != size) && dfinite(n);
-}
-DSQ_DEV double dnb_const(double x, double size, double st_size, double log_size) {
-    const double n = x + size;
-    const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
-    const double lf = kLn2Pi + log_size + dlog1p(-size / n);
-    const double c1 = 0.5 * lf;
-    const double c2 = dlog(size / (size + x));
-    return c2 + (c0 - c1);
-}
-DSQ_DEV bool dnb_iter(double x, double size, double mu, double &it) {
-    const double p = size / (size + mu), q = mu / (size + mu);
-    it = 0.0;
-    if (!(mu > 0.0 && p != 0.0 && q != 0.0)) return false;
-    const double n = x + size;
-    it = -dbd0(size, n * p) - dbd0(n - size, n * q);
-    return true;
-}
-
-DSQ_DEV double dnb_eval(double x, double size, double mu, const DnbConst &c) {
-    double p = size / (size + mu), q = mu / (size + mu);
-    if (c.c0 == c.c0 && mu > 0.0 && p != 0.0 && q != 0.0) {
-        double n = x + size;
-        double lc = c.c0 - dbd0(size, n * p) - dbd0(n - size, n * q);
-        return c.c2 + (lc - c.c1);
-    }
-    return dnbinom_mu_log(x, size, mu);
-}
-
 }  // namespace dsq

@@ -1196,7 +1196,7 @@ void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_
     size_t lds;
     beta_geometry<DSQ_P>(n, m, useW != 0, &waves, &stage, &xlds, &grid, &lds);
     *slab = stage ? 0 : (size_t)grid * waves * (size_t)m * kSlabVecs;
-    *cscr = (size_t)grid * waves * (size_t)m;
+    *cscr = 0;      // (the hoisted NB-density constants are gone: the deviance needs no per-sample scratch row)
 }
 
 template <>

@@ -327,35 +327,6 @@ double orc_dnbinom_mu_log(double x, double size, double mu) {
     }
 }
 
-/* dnbinom_mu(x, size, mu, log) on its general branch (x > 0, x >= 1e-10 size) is
- *     log(size/(size+x)) + ( S(n) - S(size) - S(n-size) - bd0(size, n p) - bd0(n-size, n q) - 0.5 lf ),  n = x + size,
- * and only the two bd0 terms depend on mu.  orc_dnb_const returns the mu-independent part c2 + (c0 - c1) (1 if (x,
- * size) is on that branch, else 0); orc_dnb_iter the mu-dependent part -bd0(size, n p) - bd0(n - size, n q) (1 if
- * mu > 0 and p, q != 0, the conditions under which dbinom_raw reaches its general expression).  st_size =
- * stirlerr(size), log_size = log(size): the same for every sample of a gene.                                     */
-int orc_dnb_const(double x, double size, double st_size, double log_size, double *cst) {
-    double n = x + size;
-    int general = (x > 0.0) && isfinite(x) && (size > 0.0) && isfinite(size) && !(x < 1e-10 * size) &&
-                  (n != size) && isfinite(n);
-    *cst = 0.0;
-    if (!general) return 0;
-    double c0 = orc_stirlerr(n) - st_size - orc_stirlerr(n - size);
-    double lf = ORC_LN_2PI + log_size + orc_log1p(-size / n);
-    double c1 = 0.5 * lf;
-    double c2 = orc_log(size / (size + x));
-    *cst = c2 + (c0 - c1);
-    return 1;
-}
-
-int orc_dnb_iter(double x, double size, double mu, double *it) {
-    double p = size / (size + mu), q = mu / (size + mu);
-    *it = 0.0;
-    if (!(mu > 0.0 && p != 0.0 && q != 0.0)) return 0;
-    double n = x + size;
-    *it = -orc_bd0(size, n * p) - orc_bd0(n - size, n * q);
-    return 1;
-}
-
 /* 2 * pnorm(|z|, lower.tail = FALSE): the Wald p-value (R/core.R:1507).  R's pnorm (nmath/pnorm.c) is Cody's
  * rational Chebyshev approximation of the normal distribution function (W. J. Cody, Math. Comp. 23 (1969); ACM
  * Algorithm 715): |z| <= 0.67448975 by a (4,4) rational in z^2, <= sqrt(32) by an (8,8) rational times

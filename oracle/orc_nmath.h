@@ -32,8 +32,6 @@ double orc_trigamma(double x); /* domain x > 0 */
 double orc_stirlerr(double n);
 double orc_bd0(double x, double np);
 double orc_dnbinom_mu_log(double x, double size, double mu);
-int orc_dnb_const(double x, double size, double st_size, double log_size, double *cst);
-int orc_dnb_iter(double x, double size, double mu, double *it);
 double orc_pnorm_upper2(double z);  /* 2 * pnorm(|z|, lower.tail = FALSE) */
 
 /* vector helpers for the ctypes tests: op selects the function */
