@@ -190,3 +190,45 @@ def test_linear_mu_matches_matrix_formula(oracle):
     np.testing.assert_allclose(mu, ref, rtol=1e-11, atol=1e-11)
     np.testing.assert_array_equal(oracle.linearMu(c[37:61], nf[37:61], x), mu[37:61])
     assert (oracle.linearMu(c, nf, x, mu_floor=0.5) >= 0.5).all()
+
+
+@pytest.mark.parametrize("design", ["cells", "continuous"])
+@pytest.mark.parametrize("use_w", [False, True])
+def test_irls_deviance_is_minus_two_log_likelihood(oracle, design, use_w):
+    """`src/DESeq2.cpp:365-373`: dev = -2 sum [wts] log NB(y; size = 1/alpha, mu) at the returned coefficients.  The
+    restatement evaluates it as -2 (K + D) (closed split of the saddle-point density); this checks the value against
+    scipy's NB log-pmf on both fitBeta paths, including dispersions at the 1e-8 floor and zero counts."""
+    rng = np.random.default_rng(77 if design == "cells" else 78)
+    n, m = 60, 48
+    x = np.column_stack([np.ones(m), np.repeat([0, 1], m // 2), np.tile([0, 1, 0], m // 3)]).astype(float)
+    if design == "continuous":
+        x = np.column_stack([x, rng.normal(size=m)])
+    p = x.shape[1]
+    alpha = 10 ** rng.uniform(-8, 0.5, n)
+    alpha[:5] = 1e-8
+    mu0 = 10 ** rng.uniform(-0.5, 4, (n, 1)) * np.exp(rng.normal(0, 0.3, (n, m)))
+    size = 1.0 / alpha[:, None]
+    y = rng.negative_binomial(np.minimum(size, 1e7), np.minimum(size, 1e7) / (np.minimum(size, 1e7) + mu0)).astype(float)
+    y[:, ::7] = 0
+    nf = np.exp(rng.normal(0, 0.3, (n, m)))
+    w = rng.uniform(0.1, 1.0, (n, m)) if use_w else np.ones((n, m))
+    b0 = np.linalg.lstsq(x, np.log(y / nf + 0.1).T, rcond=None)[0].T
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    r = oracle.fitBeta(y, x, nf, alpha, np.r_[1.0, np.zeros(p - 1)], b0, lam, w, use_w, 1e-8, 100, True, 0.5)
+    it = np.asarray(r["iter"]).ravel()
+    mu = np.maximum(nf * np.exp(np.asarray(r["beta_mat"]) @ x.T), 0.5)
+    # exact log-pmf with mpmath (scipy's gammaln differences lose ~1e-8 relative at size = 1e8)
+    import mpmath as mp
+    mp.mp.dps = 40
+
+    def logpmf(yv, sz, muv):
+        yv, sz, muv = mp.mpf(yv), mp.mpf(sz), mp.mpf(muv)
+        return (mp.loggamma(yv + sz) - mp.loggamma(sz) - mp.loggamma(yv + 1) + sz * mp.log(sz / (sz + muv)) +
+                yv * mp.log(muv / (sz + muv)))
+
+    ok = np.nonzero(it < 100)[0][:24]
+    assert ok.size >= 12
+    got = np.asarray(r["deviance"]).ravel()
+    for i in ok:
+        want = -2 * sum(mp.mpf(w[i, j]) * logpmf(y[i, j], size[i, 0], mu[i, j]) for j in range(m))
+        assert abs(mp.mpf(got[i]) - want) <= 1e-11 * abs(want) + 1e-10, (i, got[i], float(want))
