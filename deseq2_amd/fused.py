@@ -345,12 +345,16 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     hm = E._host(run.mat).numpy()
     hi = E._host(run.ivec).numpy()
     allZero = hi[0].astype(bool)
-    anyz = bool(allZero.any())
+    # rows that were all zero from the start carry NA in every column; a row that only BECAME all zero when its outlier
+    # was replaced (newAllZero, R/core.R:2492) keeps its "intermediate" columns and gets NA in the "results" columns
+    # only (:2534-2536) -- the device has already written those
+    zero0 = allZero & (hi[5] == 0) if run.do_replace else allZero
+    anyz = bool(zero0.any())
 
     def icol(v, as_bool=False):
         if anyz:
             out = v.astype(np.float64)
-            out[allZero] = np.nan
+            out[zero0] = np.nan
             return out
         return v.astype(bool) if as_bool else v.copy()
     mc = {"baseMean": hv[0], "baseVar": hv[1], "allZero": allZero, "dispGeneEst": hv[2], "dispGeneIter": icol(hi[1]),
@@ -383,7 +387,7 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
             dds.assays["replaceCounts"] = GM(run.replaceCounts, dds.m)
             dds.assays["replaceCooks"] = dds.assays["cooks"]
     if anyz:
-        dds.attrs["nz_rows"] = np.where(~allZero)[0]
+        dds.attrs["nz_rows"] = np.where(~zero0)[0]
     dds.dispersionFunction = fn
     dds._fused_run = run           # keeps the device buffers of the assays alive
     return dds

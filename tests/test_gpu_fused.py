@@ -131,3 +131,24 @@ def test_unsupported_settings_fall_back(E):
     assert not fused.supported(dds, test="LRT", reduced=x[:, :1] * 2)
     fused.DESeq(dds, betaPrior=True, factors={"condition": x[:, 1].astype(int)})
     assert "WaldPvalue" in dds.mcols and not dds.attrs.get("fused")
+
+
+@pytest.mark.parametrize("others_refit", [True, False])
+def test_row_that_becomes_all_zero_by_replacement(E, others_refit):
+    """a gene whose single non-zero count is an outlier: replaceOutliers turns the row into zeros (newAllZero,
+    R/core.R:2492) -- it keeps its dispersion ("intermediate") columns and gets NA in the "results" columns only
+    (:2534-2536); found by tests/gpu_fuzz_chain.py"""
+    x = simulate.design_factor(32, 4)                       # cells of 8 >= 7
+    d = simulate.make_counts(400, x, seed=21)
+    # with other replaced rows the refit runs and the new all-zero rows get NA results; when EVERY replaced row became
+    # all zero nothing is refit and nothing is overwritten (:2496, "handled by results()")
+    counts = _spike_outliers(d["counts"], np.random.default_rng(8), k=4) if others_refit else d["counts"].copy()
+    for g, j, v in ((17, 31, 21), (230, 5, 400)):
+        counts[g] = 0
+        counts[g, j] = v
+    a, b = _both(E, counts, x, d["size_factors"])
+    new_zero = np.asarray(a.mcols["allZero"], bool) & (np.nan_to_num(np.asarray(a.mcols["replace"], float)) == 1)
+    assert new_zero.sum() >= 1
+    assert np.isfinite(np.asarray(a.mcols["dispGeneIter"], float)[new_zero]).all()
+    assert np.isnan(np.asarray(a.mcols["betaIter"], float)[new_zero]).all() == others_refit
+    _compare(a, b, "newAllZero, others refit = %s" % others_refit)
