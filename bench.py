@@ -346,7 +346,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s; %d non-zero genes in total, sharded over %d GPU(s) in the contiguous ranges "
                                    "of R/parallel.R:10; inputs resident in HBM in R layout (int32 counts, f64 nf "
-                                   "matrix%s)" % (cfg["label"], n_total, world, ", f64 weights" if use_w else ""),
+                                   "matrix%s; the fused chain reads the size factors as the m-vector the matrix was "
+                                   "built from)" % (cfg["label"], n_total, world, ", f64 weights" if use_w else ""),
                        "name": args.config, "genes_total": n_total, "genes_this_gpu": n, "samples": m, "p": p,
                        "test": cfg["test"], "parallelism": "gene-shard x%d" % world,
                        "chain": "fused device-driven (dsq_deseq_dev)" if fused_used else "call-by-call (core.py)"},

@@ -94,7 +94,12 @@ class DESeqDataSet:
         self.counts_host = None
         self.sizeFactors = None if sizeFactors is None else np.asarray(sizeFactors, np.float64)
         self.y = engine.native.to_gene_major(counts_r)
-        self.nf = engine.native.to_gene_major(nf_r)
+        # with size factors the chain can run on the m-vector (nf[i, j] = s_j for every gene): the n x m matrix R
+        # passes is then converted only if some step asks for it
+        if self.sizeFactors is not None:
+            self._nf, self._nf_src = None, nf_r
+        else:
+            self.nf = engine.native.to_gene_major(nf_r)
         self.has_weights = weights is not None or weights_r is not None
         if weights_r is not None:
             self.weights_h = engine.native.to_gene_major(weights_r)
@@ -127,6 +132,20 @@ class DESeqDataSet:
     @property
     def p(self):
         return self.x.shape[1]
+
+    # normalization factors in the engine's gene-major layout; from_device() defers the conversion (see there)
+    _nf = None
+    _nf_src = None
+
+    @property
+    def nf(self):
+        if self._nf is None and self._nf_src is not None:
+            self._nf, self._nf_src = self.engine.native.to_gene_major(self._nf_src), None
+        return self._nf
+
+    @nf.setter
+    def nf(self, v):
+        self._nf, self._nf_src = v, None
 
 
 # ------------------------------------------------------------------ R/wrappers.R

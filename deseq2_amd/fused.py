@@ -127,8 +127,15 @@ class _Run:
         self.replaceable = facts["replaceable"]
         cutoff = facts["cutoff"]                                                     # R/core.R:2081
         linearMu = facts["groups_eq_p"] and not self.useWeights                      # :735-742
+        # size factors: every kernel of the chain reads the m-vector (same values as the rows of the n x m matrix R
+        # builds from them, R/core.R:2221-2227, so the same bits) -- 8 B less per sample and pass, no layout conversion
+        if dds.sizeFactors is not None:
+            self.sf_dev = E._vec(np.ascontiguousarray(dds.sizeFactors, np.float64))
+            nf_ptr, nf_vec = _ptr(self.sf_dev), 1
+        else:
+            nf_ptr, nf_vec = _ptr(dds.nf.t), 0
         self.args = L.DsqDeseqArgs(
-            n=n, m=m, p=p, ld=ld, phases=0, y=_ptr(dds.y.t), nf=_ptr(dds.nf.t), nf_is_vector=0,
+            n=n, m=m, p=p, ld=ld, phases=0, y=_ptr(dds.y.t), nf=nf_ptr, nf_is_vector=nf_vec,
             useWeights=int(self.useWeights),
             weights_raw=_ptr(dds.weights_h.t) if self.useWeights else None,
             weights_norm=_ptr(self.w_norm.t) if self.useWeights else None,
