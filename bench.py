@@ -104,8 +104,8 @@ def spawn_ranks(n_gpus, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
     ap.add_argument("--genes", type=int, default=0, help="override the config's gene count (tuning runs)")
     ap.add_argument("--samples", type=int, default=0, help="override the config's sample count (tuning runs)")
