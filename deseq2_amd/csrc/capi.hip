@@ -297,6 +297,7 @@ int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, co
                       const int32_t **start_dev) {
     *perm_dev = *start_dev = nullptr;
     if (!labels || !tuning().beta_cells) return 0;
+    if (m >= (1 << 26)) return 0;      // the kernels pack (sample | cell << 26) into one int32
     static thread_local std::vector<int32_t> buf;
     std::map<int32_t, int> id;
     std::vector<int> cell(m);
