@@ -1,8 +1,14 @@
-// fit_beta.hip -- gfx950 kernel replacing fitBeta (src/DESeq2.cpp:283-465): ridge-
+// fit_beta.hip -- gfx950 kernels replacing fitBeta (src/DESeq2.cpp:283-465): ridge-
 // penalised IRLS for the NB-GLM coefficients, hat diagonals, sandwich covariance and
-// contrast, one wavefront per gene.
+// contrast, one wavefront per gene.  Two kernels:
+//   fit_beta_cell_kernel  designs with at most 32 distinct rows (every factor design, any p <= 24): one linear predictor
+//                         per design cell, the least squares on the collapsed (C + p) x p system, one sweep over the
+//                         samples per iteration -- see the comment above it;
+//   fit_beta_kernel       everything else (continuous covariates), described here.
+// Both evaluate the deviance as -2 (K + D): K, the mu-independent part of the NB log densities, once per gene; D with one
+// logarithm per sample and iteration (irls_constants / cell_dev_closed below).
 //
-// Per IRLS iteration a wave makes lane-strided passes over its gene's m samples:
+// fit_beta_kernel: per IRLS iteration a wave makes lane-strided passes over its gene's m samples:
 //   A  w = [wts] mu/(1+alpha mu), sqrt(w), z = log(mu/nf) + (y-mu)/mu   -> wave slab
 //   B  weighted least squares for beta
 //        useQR : Householder QR of [sqrt(w) X ; sqrt(ridge)] ((m+p) x p), LAPACK dgeqr2
@@ -11,9 +17,9 @@
 //                reflector parameters, so each of the p stages re-derives its rows on the
 //                fly ("replay") and needs one round of p-k+1 wave reductions.
 //        else  : normal equations X'WX + ridge by one pass + LU (partial pivoting)
-//   C  mu = max(nf exp(X beta), minmu); deviance = -2 sum [wts] log NB(y; 1/alpha, mu)
+//   C  mu = max(nf exp(X beta), minmu), log(mu / nf) kept for z; deviance = -2 sum [wts] log NB(y; 1/alpha, mu)
 // The convergence test and the |beta| > 30 / NaN aborts are wave-uniform scalar flow.
-// Slab (mu, sqrt(w), sqrt(w) z per sample) lives in wave-private LDS, X in a block-shared
+// Slab (sqrt(w); mu, later sqrt(w) z; log(mu / nf) per sample) lives in wave-private LDS, X in a block-shared
 // LDS slab; when m*p is too large for that both fall back to L2-resident global memory.
 #include "dsq_internal.hpp"
 #include <cstdio>
@@ -506,10 +512,12 @@ DSQ_UNROLL_P
 //   * an IRLS step needs the samples only through S_c = sum w_j, T_c = sum w_j z_j: the weighted least squares is the
 //     Householder QR of the COLLAPSED (C + p) x p matrix [sqrt(S_c) x_c ; sqrt(ridge)] -- one row per LANE, no pass
 //     over the samples, no replay (the general kernel re-derives every sample row in every one of the p stages);
-//   * one sweep over the samples per iteration computes mu, the two bd0 terms of the deviance, w, z and the cell sums
-//     for the NEXT step (the mu-independent part of the NB density is summed once per gene): mu is never stored, so
-//     the kernel has no per-wave LDS slab at all and occupancy is set by registers alone;
-//   * post-loop: X'WX = sum_c S_c x_c x_c', hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c.
+//   * one sweep over the samples per iteration computes mu, r = 1 / (1 + alpha mu), the deviance term
+//     y lg - (y + size) log1p(alpha mu), w = [wts] mu r and w z = w lg + [wts] r (y - mu), and the cell sums for the
+//     NEXT step (one division and one logarithm per sample): mu is never stored, so the kernel keeps only a 1 KB cell
+//     slab per wave in LDS and occupancy is set by registers alone;
+//   * post-loop: X'WX = sum_c (x_c x_c') S_c, hat diagonal h_j = w_j x_c'(X'WX + ridge)^-1 x_c; wave-uniform p x p
+//     matrices in registers up to p = 6, one matrix column per lane (LaneLU, dsq_wave.hpp) from p = 7.
 // Sums over samples run cell by cell in wave order over the position in the cell-sorted sample sequence (so a sweep
 // is ceil(m / 64) FULL trips whatever the cell sizes).  Arithmetic spec = the CPU checker's
 // fit_beta_gene_cells; results are bit-identical to it.

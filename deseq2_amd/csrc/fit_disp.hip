@@ -1,12 +1,16 @@
 // fit_disp.hip -- gfx950 kernels replacing fitDisp (src/DESeq2.cpp:164-277) and
 // fitDispGrid (:469-513): Cox-Reid adjusted profile-likelihood dispersion fit.
 //
-// One wavefront per gene.  Lane l owns samples l, l+64, ...; the gene's row (counts as
-// f64, mu_hat, weights) sits in a wave-private LDS slab and the design matrix X in a
-// block-shared slab, so the ~20 log_posterior / ~7 dlog_posterior evaluations per gene
-// re-read LDS, not HBM.  Each evaluation is one lane-strided pass producing
-// 1 + p(p+1)/2 partial sums that are xor-butterflied across the wave; the p x p
-// determinant / inverse / traces are wave-uniform register math (LU, partial pivoting).
+// One wavefront per gene.  Lane l owns samples l, l+64, ...; the gene's row (counts as int32, mu_hat,
+// weights) sits in a wave-private LDS slab and the design matrix X in a block-shared slab, so the ~13
+// log_posterior + dlog_posterior evaluations per gene re-read LDS, not HBM.  Each evaluation is
+//   * one pass over the DISTINCT counts of the gene (lgamma / digamma of v + 1/alpha, weighted by multiplicity;
+//     position 0 evaluates lgamma(1/alpha) itself),
+//   * one FUSED pass over the samples: r = 1 / (1 + mu alpha) and log(1 + mu alpha) give the likelihood terms AND the
+//     Cox-Reid diagonals w = mu r, -(w w), 2 w^3 (DispGene::pass): per-cell sums for factor designs (p >= 4), p(p+1)/2
+//     running sums otherwise (one matrix row per sweep through an LDS arena from p = 7),
+//   * the p x p algebra (LU with partial pivoting, determinant, inverse, traces): wave-uniform registers up to p = 3,
+//     one matrix column per lane (LaneLU, dsq_wave.hpp) from p = 4.
 // The Armijo line search itself is wave-uniform scalar control flow.
 // design widths from DSQ_DISP_WIDE_MIN up are served by two zero-padded builds (p = 16, 24)
 #ifndef DSQ_DISP_WIDE_MIN
