@@ -1,16 +1,16 @@
 // dsq_wave.hpp -- wavefront-level building blocks: one gfx950 wavefront (64 lanes)
 // owns one gene.  Lane l holds samples l, l+64, l+128, ...; every sum over samples is
 // "lane-serial then xor-butterfly", which is the summation order the arithmetic spec
-// fixes (DESIGN.md "Arithmetic").  The p x p matrices are wave-uniform and live in
-// registers of every lane (p is a template parameter; MFMA is pointless at p <= 16).
+// fixes (DESIGN.md "Arithmetic").  The p x p matrices are either wave-uniform in the
+// registers of every lane (LU<P>, narrow designs) or held one column per lane (LaneLU<P>);
+// p is a template parameter, and MFMA is pointless at p <= 24.
 #pragma once
 #include <hip/hip_runtime.h>
 
-// The register-resident kernels (one translation unit per design width, -DDSQ_P=p, p <= 10) want every p-loop
-// fully unrolled so that the p x p state stays in registers.  The WIDE translation unit (-DDSQ_P=16, serving
-// 11 <= p <= 16 on zero-padded designs) keeps them as loops: the state then lives in scratch memory -- slow,
-// but it compiles in seconds instead of tens of minutes and needs no second copy of the algorithms.
-// design widths from DSQ_WIDE_MIN up are built in the WIDE form (rolled p^3 loops, work arrays in the LDS arena)
+// The per-width kernels (one translation unit per design width, -DDSQ_P=p, p <= 10) want every p-loop of the
+// wave-uniform algebra fully unrolled so that the p x p state stays in registers.  The WIDE translation units
+// (-DDSQ_P=16 and 24, serving 11 <= p <= 24 on zero-padded designs) keep the loops of the general fitBeta kernel rolled,
+// with its work arrays in an LDS arena; everything built on LaneLU is unrolled at every width (2 p registers per matrix).
 #ifndef DSQ_WIDE_MIN
 #define DSQ_WIDE_MIN 11
 #endif
