@@ -311,3 +311,41 @@ def test_optim_rows_against_lbfgsb(oracle):
     core.DESeq(dds, minReplicatesForReplace=np.inf)
     assert 7 in set(dds.mcols["rowsForOptim"]) and dds.mcols["betaConv"][7]
     assert np.isfinite(dds.mcols["beta"][7]).all() and np.isfinite(dds.mcols["betaSE"][7]).all()
+
+
+def test_from_device_defers_the_nf_matrix_when_size_factors_are_known():
+    """DESeqDataSet.from_device: with size factors the n x m normalization-factor matrix is converted to the engine's
+    layout only when a step asks for `dds.nf` (the fused chain reads the m-vector instead)"""
+    from deseq2_amd import core
+
+    class _Native:
+        def __init__(self):
+            self.calls = []
+
+        def to_gene_major(self, t):
+            self.calls.append(t)
+            return ("gene-major", t)
+
+    class _Engine:
+        def __init__(self):
+            self.native = _Native()
+
+        def design(self, x):
+            return x
+
+    class _T:
+        def __init__(self, name, shape):
+            self.name, self.shape = name, shape
+
+    m, n = 6, 11
+    x = np.column_stack([np.ones(m), np.repeat([0, 1], 3)]).astype(float)
+    E = _Engine()
+    dds = core.DESeqDataSet.from_device(E, _T("counts", (m, n)), _T("nf", (m, n)), x, sizeFactors=np.ones(m))
+    assert [t.name for t in E.native.calls] == ["counts"]
+    assert dds.nf == ("gene-major", E.native.calls[-1]) and [t.name for t in E.native.calls] == ["counts", "nf"]
+    assert dds.nf[0] == "gene-major" and len(E.native.calls) == 2          # converted once
+    dds.nf = "override"
+    assert dds.nf == "override"
+    E2 = _Engine()
+    core.DESeqDataSet.from_device(E2, _T("counts", (m, n)), _T("nf", (m, n)), x)   # no size factors: converted at once
+    assert [t.name for t in E2.native.calls] == ["counts", "nf"]
