@@ -86,7 +86,9 @@ class DESeqDataSet:
         """Build from matrices ALREADY RESIDENT in HBM in R layout: `counts_r` (int32), `nf_r` and the optional
         `weights_r` (float64) are contiguous (m, n) torch tensors, i.e. column-major n x m exactly as
         R holds them.  Converts to the engine's gene-major layout on the device (no host copy).  (`weights`, a
-        host array, is uploaded when no `weights_r` is given.)"""
+        host array, is uploaded when no `weights_r` is given.)  `sizeFactors`: pass them only when `nf_r` is the matrix
+        R builds FROM them (`getSizeOrNormFactors`, R/core.R:2221-2227: no normalizationFactors) -- the chain may
+        then read the m-vector instead of the matrix."""
         self = cls.__new__(cls)
         self.m, self.n = counts_r.shape
         self.x = np.asarray(x, dtype=np.float64)
