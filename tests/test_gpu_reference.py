@@ -49,3 +49,14 @@ def test_hip_reproduces_reference_at_baseline_shapes(name):
     ref = load_golden(SHAPES, name)
     _close(got["aux"]["mu"][:HEAD], ref["aux"]["mu"], name + " mu", rtol=1e-9)
     compare(got, ref, d, name, min_well=0.95)
+
+
+@pytest.mark.parametrize("seed", (5, 6, 7))
+def test_hip_floor_regime_vs_reference(seed):
+    """the dispersion-floor regime (Poisson / NB mixture, > 25 % of the genes start at alpha_0 = 1e-8): everything R's
+    callers see -- fitBeta$iter, clamped dispGeneEst, dispGeneEstConv / refitDisp, MAP dispConv and dispMAP -- against
+    the compiled reference's stored outputs, with the budgets the reference's own libm build meets
+    (tests/floor_regime.py, tests/golden/reference_floor.npz)"""
+    from tests.floor_regime import assert_visible_parity, floor_case, load_floor_golden, visible_chain
+    from tests.test_floor_regime import GOLDEN as FLOOR
+    assert_visible_parity(visible_chain(native, floor_case(seed)), load_floor_golden(FLOOR, seed), "hip seed %d" % seed)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r02_parity.md: measured parity rates against the compiled reference's stored outputs
+"""profiles/r03_parity.md (r02_parity.md in round 2): measured parity rates against the compiled reference's stored outputs
 (tests/golden/reference_golden.npz, reference_shapes.npz).  `python tools/parity_report.py hip` on the GPU box
 (HIP path through the host-pointer C ABI), `python tools/parity_report.py oracle` anywhere (the C oracle)."""
 import os
@@ -32,3 +32,22 @@ print("| case | shape | fitBeta iter mismatches | prior-pass iter mismatches | w
       "max rel. err log_alpha (MLE / MAP) | grid identical |")
 print("|---|---|---|---|---|---|---|---|")
 print("\n".join(rows))
+
+# ---- the dispersion-floor regime (tests/floor_regime.py): what R's callers see, next to the reference's own
+# libm-double build against its binary128 build
+from tests import floor_regime as FR             # noqa: E402
+from tests.test_floor_regime import GOLDEN as FLOOR   # noqa: E402
+print("\n## Dispersion-floor regime (500 x 60, p = 4, NB / Poisson mixture; tests/floor_regime.py)\n")
+print("`floor` = genes whose start or final dispersion is below 1e-5.  Left: the %s path against the compiled reference "
+      "(binary128 special functions); right: the reference's OWN libm-double build against the same.\n" % which.upper())
+cols = ("floor_start", "floor", "beta_iter_mismatch", "iter_equal_floor", "iter_equal_rest", "conv_differs", "refit_differs",
+        "dge_rel_gt_1e6", "dge_abs_max", "map_conv_differs", "map_iter_equal", "map_rel_max")
+print("| seed | who | genes at alpha_0 = 1e-8 | floor genes | fitBeta$iter mismatches | fitDisp$iter equal (floor) | "
+      "fitDisp$iter equal (rest) | dispGeneEstConv differs | refitDisp differs | dispGeneEst > 1e-6 rel. | max abs diff "
+      "dispGeneEst | MAP dispConv differs | MAP iter equal | max rel. dispMAP |")
+print("|" + "---|" * 14)
+for seed in FR.SEEDS:
+    ref = FR.load_floor_golden(FLOOR, seed)
+    for who, got in ((which, FR.visible_chain(F, FR.floor_case(seed))), ("ref_fast", FR.load_floor_golden(FLOOR, seed, "ref_fast"))):
+        s = FR.assert_visible_parity(got, ref, who)
+        print("| %d | %s | " % (seed, who) + " | ".join(("%.3g" % s[c]) if isinstance(s[c], float) else str(s[c]) for c in cols) + " |")
