@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("DSQ_LIB") or os.path.join(_HERE, "libdeseq2_mi355x.so")   # DSQ_LIB: tuning builds only
 
 DSQ_OK = 0
+DSQ_ERR_ARG, DSQ_ERR_UNSUPPORTED, DSQ_ERR_DEVICE, DSQ_ERR_NOMEM, DSQ_ERR_VALUE = 1, 2, 3, 4, 5
 DSQ_LAYOUT_R = 0
 DSQ_LAYOUT_GENE_MAJOR = 1
 DSQ_Y_INT32 = 0

@@ -695,6 +695,10 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
     if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_REG);
     if (a->ld < a->m) return capi_fail(DSQ_ERR_ARG, "ld < m");
+    // estimateDispersionsPriorVar's branch for 1..3 residual degrees of freedom matches a seeded Monte-Carlo sample
+    // (R/core.R:1155-1190, R's RNG + loess): not reproducible here, so the prior variance is not computed at all
+    if ((a->phases & DSQ_PH_TREND) && a->m - a->p <= 3)
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is not available", a->m - a->p);
     if (!a->y || !a->nf || !a->x || !a->q || !a->a || !a->r || !a->disp_grid || a->ngrid < 2 || !a->lambda) return capi_fail(DSQ_ERR_ARG, "NULL input");
     if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");

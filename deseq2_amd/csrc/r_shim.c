@@ -146,6 +146,9 @@ SEXP _DESeq2_fitDispGrid(SEXP ySEXP, SEXP xSEXP, SEXP mu_hatSEXP, SEXP disp_grid
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(ySEXP), m = Rf_ncols(ySEXP), p = Rf_ncols(xSEXP);
+    need_matrix(xSEXP, m, p, "xSEXP"); need_matrix(mu_hatSEXP, n, m, "mu_hatSEXP"); need_matrix(weightsSEXP, n, m, "weightsSEXP");
+    need_length(log_alpha_prior_meanSEXP, n, "log_alpha_prior_meanSEXP");
+    if (Rf_length(disp_gridSEXP) < 2) Rf_error("disp_gridSEXP must hold at least 2 grid points");
     SEXP x = as_real(xSEXP, &np), mu = as_real(mu_hatSEXP, &np), grid = as_real(disp_gridSEXP, &np);
     SEXP pm = as_real(log_alpha_prior_meanSEXP, &np), w = as_real(weightsSEXP, &np);
     DsqFitDispGridArgs a = {0};

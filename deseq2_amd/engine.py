@@ -72,12 +72,25 @@ class LaunchedVector:
         return self._v
 
 
-def _gram_rank(G, tol=1e-10):
-    """rank of stacked symmetric p x p Gram matrices X'X (n, p, p): the number of eigenvalues above tol x the
-    largest -- the rank of X for the 0/1-and-weights design matrices these checks see (qr()$rank in R)"""
-    ev = np.linalg.eigvalsh(G)
-    top = np.maximum(ev[:, -1:], 1e-300)
-    return (ev > tol * top).sum(axis=1)
+def _gram_rank(G, tol=1e-7):
+    """qr()$rank of the matrices A whose Gram matrices A'A are stacked in G (n, p, p), as R computes it: LINPACK
+    dqrdc2's limited column pivoting -- going through the columns in order, a column counts when the norm of its part
+    orthogonal to the columns already counted is at least tol (1e-7, qr()'s default) times ITS OWN original norm (so
+    rescaling a column never changes its decision), and an exactly zero column never counts.  Evaluated on the Gram
+    matrix (a Cholesky factorisation that skips the rejected columns); the squared threshold 1e-14 is a hundred
+    roundings of a Gram entry."""
+    G = np.asarray(G, np.float64)
+    n, p, _ = G.shape
+    d0 = np.einsum("nii->ni", G)
+    C = np.zeros((n, p, p))                      # row k: <q_k, a_j> for every column j; zero when column k was rejected
+    rank = np.zeros(n, dtype=np.int64)
+    for j in range(p):
+        r = d0[:, j] - (C[:, :, j] ** 2).sum(axis=1)
+        ok = (d0[:, j] > 0) & (r >= (tol * tol) * d0[:, j])
+        num = G[:, j, :] - np.einsum("nk,nkj->nj", C[:, :, j], C)
+        C[:, j, :] = np.where(ok[:, None], num / np.sqrt(np.where(ok, r, 1.0))[:, None], 0.0)
+        rank += ok
+    return rank
 
 
 def _weights_ok_host(w, x, thr, full_rank):
@@ -411,10 +424,18 @@ class DeviceEngine:
                 ok &= ~((wv * xd[None, :, j]) == 0).all(dim=1)
             return ok
 
-        def rank(G):
-            ev = t.linalg.eigvalsh(G)
-            top = ev[:, -1:].clamp_min(1e-300)
-            return (ev > 1e-10 * top).sum(dim=1)
+        def rank(G, tol=1e-7):               # _gram_rank (dqrdc2's column-relative test) on the device
+            d0 = t.diagonal(G, dim1=1, dim2=2)
+            C = t.zeros_like(G)
+            rk = t.zeros(G.shape[0], dtype=t.int64, device=self.device)
+            for j in range(p):
+                r = d0[:, j] - (C[:, :, j] ** 2).sum(dim=1)
+                ok = (d0[:, j] > 0) & (r >= (tol * tol) * d0[:, j])
+                num = G[:, j, :] - t.einsum("nk,nkj->nj", C[:, :, j], C)
+                den = t.sqrt(t.where(ok, r, t.ones_like(r)))[:, None]
+                C[:, j, :] = t.where(ok[:, None], num / den, t.zeros_like(num))
+                rk += ok
+            return rk
         xx = (xd[:, :, None] * xd[:, None, :]).reshape(xd.shape[0], p * p)          # m x p^2
         G1 = ((wv * wv) @ xx).reshape(-1, p, p)
         keep = (wv > thr).to(t.float64)

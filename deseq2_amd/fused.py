@@ -25,9 +25,20 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
         return False
     if dds.p > 10 or dds.m <= dds.p:
         return False
+    # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3
+    # branch of estimateDispersionsPriorVar (seeded Monte-Carlo matching, R/core.R:1155-1190: not mirrored, core raises
+    # NotImplementedError) are left to the call-by-call code, which reports them
+    if dds.m - dds.p <= 3 or core._rank(dds.x) < dds.p:
+        return False
+    # normalization-factor MATRIX + outlier replacement: momentsDispEstimate of the refitted subset recomputes
+    # mean(1 / colMeans(nf)) over the subset's rows (R/core.R:2440-2444 on objectSub); the chain carries one xim
+    if dds.sizeFactors is None and np.isfinite(kw.get("minReplicatesForReplace", 7)) and \
+            core.nOrMoreInCell(dds.x, kw.get("minReplicatesForReplace", 7)).any():
+        return False
     if kw.get("betaPrior") or kw.get("modelMatrix") is not None or kw.get("useT") or not kw.get("useOptim", True):
         return False
-    if set(kw) - {"betaPrior", "modelMatrix", "useT", "useOptim", "betaTol", "maxit", "useQR", "minmu", "disp_maxit"}:
+    if set(kw) - {"betaPrior", "modelMatrix", "useT", "useOptim", "betaTol", "maxit", "useQR", "minmu", "disp_maxit",
+                  "minReplicatesForReplace"}:
         return False
     if test == "LRT":
         r = None if reduced is None else np.asarray(reduced)
@@ -288,7 +299,7 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
     chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
     over the gathered (baseMean, dispGeneEst) of all ranks."""
-    if not supported(dds, test=test, reduced=reduced, fitType=fitType, **kw):
+    if not supported(dds, test=test, reduced=reduced, fitType=fitType, minReplicatesForReplace=minReplicatesForReplace, **kw):
         from . import parallel
         if parallel.world_size() > 1:
             return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
@@ -325,7 +336,10 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
         run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST, trend=trend)
         st, sc = run.read_status()
-    if st["N_NONZERO"] == 0:
+    # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
+    # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
+    nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
+    if nnz == 0:
         raise ValueError("all genes have zero counts in every sample")
     if st["N_TREND"] == 0:
         raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")

@@ -133,6 +133,33 @@ def test_unsupported_settings_fall_back(E):
     assert "WaldPvalue" in dds.mcols and not dds.attrs.get("fused")
 
 
+def test_low_residual_df_and_rank_are_left_to_core(E):
+    """with 1..3 residual degrees of freedom the reference's prior variance is the seeded Monte-Carlo
+    matching of R/core.R:1155-1190 (not mirrored): the fused chain must not substitute the trigamma formula -- it hands
+    the analysis to core.DESeq(), which raises; the device entry point refuses the trend phase; a rank-deficient
+    design reports core's error."""
+    import ctypes as C
+    from deseq2_amd import _lib as L
+    x = simulate.design_two_group(4)                       # 2 vs 2: m - p = 2
+    d = simulate.make_counts(150, x, seed=4)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E)
+    assert not fused.supported(dds)
+    with pytest.raises(NotImplementedError):
+        fused.DESeq(dds)
+    with pytest.raises(NotImplementedError):
+        core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E))
+    run = fused._Run(dds, "Wald", 7, 0, {})
+    run.args.phases = L.DSQ_PH_TREND
+    rc = L.lib().dsq_deseq_dev(C.byref(run.args), C.byref(run.out), None)
+    assert rc == L.DSQ_ERR_UNSUPPORTED and b"residual degrees of freedom" in L.lib().dsq_last_error()
+    xr = np.column_stack([simulate.design_two_group(12), simulate.design_two_group(12)[:, 1]])   # duplicated column
+    d = simulate.make_counts(100, xr[:, :2], seed=5)
+    dds = core.DESeqDataSet(d["counts"], xr, sizeFactors=d["size_factors"], engine=E)
+    assert not fused.supported(dds)
+    with pytest.raises(ValueError, match="not full rank"):
+        fused.DESeq(dds)
+
+
 @pytest.mark.parametrize("others_refit", [True, False])
 def test_row_that_becomes_all_zero_by_replacement(E, others_refit):
     """a gene whose single non-zero count is an outlier: replaceOutliers turns the row into zeros (newAllZero,
