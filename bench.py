@@ -14,6 +14,7 @@ Workloads = BASELINE.json configs:
   C2  20 000 genes x  100 samples, 2-level factor (p = 2), Wald
   C3  50 000 genes x  500 samples, ~batch + condition (p = 4), Wald               <- the headline metric's config
   C4  60 000 genes x 2000 samples, 10-level factor (p = 10), nbinomLRT full vs ~1
+  C4R the same matrix, LRT against a 2-column reduced model (the reduced fit is an IRLS at p = 2), minmu = 1e-6
   C5  30 000 genes x  200 samples, 2-level condition, observation weights (2 % zeros) + betaPrior = TRUE
       (MLE pass on the standard design, prior pass on the expanded p = 3 design, R/fitNbinomGLMs.R:242-337)
 
@@ -52,6 +53,9 @@ CONFIGS = {
                label="BASELINE configs[2]: 50k genes x 500 samples, ~batch+condition (p=4), Wald"),
     "C4": dict(genes=60000, samples=2000, design=("factor", 10), test="LRT", intercept_mean=1.0,
                label="BASELINE configs[3]: 60k genes x 2000 samples, 10-level factor (p=10), nbinomLRT full vs ~1"),
+    "C4R": dict(genes=60000, samples=2000, design=("factor", 10), test="LRT", intercept_mean=1.0, reduced2=True, minmu=1e-6,
+                label="BASELINE configs[3], second variant (SURVEY 8d): 60k genes x 2000 samples, 10-level factor (p=10), "
+                      "nbinomLRT full vs a 2-column reduced model (fitBeta runs at p=2 as well), minmu=1e-6"),
     "C5": dict(genes=30000, samples=200, design="two_group", test="Wald", weights=True, betaPrior=True,
                label="BASELINE configs[4]: 30k genes x 200 samples, 2-level condition, observation weights + "
                      "betaPrior (expanded design, p=3)"),
@@ -171,6 +175,8 @@ def main():
     use_w = bool(cfg.get("weights"))
     factors = {"condition": x[:, 1].astype(int)} if cfg.get("betaPrior") else None
     reduced = np.ones((m, 1)) if cfg["test"] == "LRT" else None
+    if cfg.get("reduced2"):
+        reduced = np.column_stack([np.ones(m), (np.arange(m) >= m // 2).astype(np.float64)])
     E = DeviceEngine(dev)
 
     def workload(seed, lo_hi=None):
@@ -202,6 +208,8 @@ def main():
             kw = dict(test=cfg["test"], reduced=reduced)
             if cfg.get("betaPrior"):
                 kw.update(betaPrior=True, factors=factors)
+            if cfg.get("minmu"):
+                kw.update(minmu=cfg["minmu"])
             if args.call_by_call:
                 if world > 1:
                     parallel.DESeqParallel(dds, comm_device=comm_dev, **kw)
@@ -272,9 +280,10 @@ def main():
                 "genes_per_gpu": W2["n"], "genes_total": ntw}
         W2 = None
 
-    hostpath = None
+    hostpath = hostpath_fused = None
     if world == 1 and not args.no_hostpath:
         hostpath = hostpath_ms(core, W, x, cfg, factors, reduced)
+        hostpath_fused = hostpath_fused_ms(W, x, cfg, reduced)
 
     if rank == 0:
         per = {}
@@ -306,7 +315,8 @@ def main():
         # passes of this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed under
         # profiles/ -- counters cannot be read from inside the process.
         traffic, valu, pmc_file = None, None, None
-        for cand in ("r02_pmc_%s.json" % args.config, "r01_pmc.json" if args.config == "C3" else None):
+        for cand in ("r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
+                     "r01_pmc.json" if args.config == "C3" else None):
             if cand and os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
                 break
@@ -332,6 +342,7 @@ def main():
         out = {
             "metric": "genes/sec for DESeq() disp+beta+%s fit, %s" % (
                 cfg["test"], {"C2": "20k x 100 x p=2", "C3": "50k x 500 x p=4", "C4": "60k x 2000 x p=10 (LRT)",
+                              "C4R": "60k x 2000 x p=10 (LRT vs 2-column reduced, minmu=1e-6)",
                               "C5": "30k x 200, weights + betaPrior"}[args.config]),
             "value": n_total * args.steps / dt,
             "unit": "genes/s",
@@ -363,8 +374,11 @@ def main():
         if hostpath is not None:
             out["hostpath_ms"] = hostpath["ms"]
             out["hostpath"] = hostpath
+        if hostpath_fused is not None:
+            out["hostpath_fused_ms"] = hostpath_fused["ms"]
+            out["hostpath_fused"] = hostpath_fused
         if world == 1 and not args.no_cpu_baseline:
-            k = args.cpu_sample_genes or {"C2": 8192, "C3": 4096, "C4": 768, "C5": 6144}[args.config]
+            k = args.cpu_sample_genes or {"C2": 8192, "C3": 4096, "C4": 768, "C4R": 768, "C5": 6144}[args.config]
             out["cpu_baseline"] = cpu_baseline(W["counts"], W["sf"], x, k, cfg, W["w"], factors, reduced)
         print(json.dumps(out))
     if world > 1:
@@ -398,15 +412,46 @@ def hostpath_ms(core, W, x, cfg, factors, reduced):
     kw = dict(test=cfg["test"], reduced=reduced)
     if cfg.get("betaPrior"):
         kw.update(betaPrior=True, factors=factors)
+    if cfg.get("minmu"):
+        kw.update(minmu=cfg["minmu"])
 
     def run():
+        # the object holds column-major host matrices, as an R session does before DESeq() is called: building it (a
+        # layout copy of the numpy inputs) is not part of what is timed
+        dds = core.DESeqDataSet(W["counts"], x, sizeFactors=W["sf"], weights=W["w"], engine=E)
         t0 = time.perf_counter()
-        core.DESeq(core.DESeqDataSet(W["counts"], x, sizeFactors=W["sf"], weights=W["w"], engine=E), **kw)
+        core.DESeq(dds, **kw)
         return time.perf_counter() - t0
     run()
-    dt = run()
+    dt = min(run(), run())
     return {"ms": dt * 1e3, "genes_per_s": W["n"] / dt,
-            "note": "full DESeq() through dsq_fit_* host-pointer entry points (upload + kernels + download per call)"}
+            "note": "full DESeq() through the per-call host-pointer entry points (dsq_fit_* and the SURVEY 8f extensions: "
+                    "upload + kernels + download per call, pinned staging)"}
+
+
+def hostpath_fused_ms(W, x, cfg, reduced):
+    """PCIe-inclusive, ONE call: dsq_deseq (what r_shim.c binds as _DESeq2_mi355x_DESeq) -- counts
+    up from pageable host memory once through pinned staging, the device-driven chain, the per-gene columns down
+    (the n x m assays stay on the device unless asked for; "with_assays" times the call that brings mu / H / cooks down).
+    None for the settings the entry point declines (betaPrior: C5)."""
+    from deseq2_amd import native
+    if cfg.get("betaPrior") or cfg.get("weights"):
+        return None
+    kw = dict(test=cfg["test"], reduced=reduced, minmu=cfg.get("minmu", 0.5))
+
+    counts_r = np.asfortranarray(W["counts"])      # column-major as R holds counts(dds): no layout copy inside the call
+
+    def run(assays):
+        t0 = time.perf_counter()
+        native.DESeq(counts_r, x, W["sf"], assays=assays, **kw)
+        return time.perf_counter() - t0
+    run(())
+    dt = min(run(()), run(()))
+    run(("mu", "H", "cooks"))
+    dta = run(("mu", "H", "cooks"))
+    return {"ms": dt * 1e3, "genes_per_s": W["n"] / dt, "with_assays_ms": dta * 1e3,
+            "note": "full DESeq() through ONE dsq_deseq host-pointer call (upload counts once + device-driven chain + "
+                    "per-gene columns down); with_assays also downloads mu / H / cooks (n x m f64 each)"}
 
 
 def profile_host(core, E, step, torch):
@@ -524,6 +569,8 @@ def cpu_baseline(counts, sf, x, k, cfg, weights, factors, reduced):
     kw = dict(test=cfg["test"], reduced=reduced)
     if cfg.get("betaPrior"):
         kw.update(betaPrior=True, factors=factors)
+    if cfg.get("minmu"):
+        kw.update(minmu=cfg["minmu"])
 
     # the all-core legs take a larger sample (8 x): with a few thousand genes on a few hundred workers the time is the
     # worker start-up, not the fits

@@ -18,8 +18,9 @@ DSQ_Y_INT32 = 0
 DSQ_Y_FLOAT64 = 1
 DSQ_MAX_P = 24
 
+DSQ_ERR_FIT = 6
 ERR_NAMES = {1: "DSQ_ERR_ARG", 2: "DSQ_ERR_UNSUPPORTED", 3: "DSQ_ERR_DEVICE", 4: "DSQ_ERR_NOMEM",
-             5: "DSQ_ERR_VALUE"}
+             5: "DSQ_ERR_VALUE", 6: "DSQ_ERR_FIT"}
 
 
 class DsqError(RuntimeError):
@@ -170,6 +171,8 @@ class DsqDeseqArgs(C.Structure):
         ("workspace_bytes", C.c_int64), ("test", C.c_int32),
         ("cell_of", C.c_void_p), ("ncell", C.c_int32), ("replaceable", C.c_void_p),
         ("cooksCutoff", C.c_double), ("trim", C.c_double), ("do_replace", C.c_int32),
+        ("x_red", C.c_void_p), ("q_red", C.c_void_p), ("a_red", C.c_void_p), ("r_red", C.c_void_p), ("p_red", C.c_int32),
+        ("cell_of_red", C.c_void_p), ("ncell_red", C.c_int32),
     ]
 
 
@@ -179,6 +182,26 @@ class DsqDeseqOut(C.Structure):
         "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
         "logLikeReduced", "maxCooks", "replace", "optim_geneest", "optim_test", "mu_hat", "mu", "H", "cooks",
         "replaceCounts", "status", "scalars")]
+
+
+class DsqDeseqHostArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("counts", C.c_void_p), ("y_type", C.c_int32),
+        ("x", C.c_void_p), ("sizeFactors", C.c_void_p), ("q", C.c_void_p), ("r", C.c_void_p), ("xrinv", C.c_void_p),
+        ("test", C.c_int32), ("x_reduced", C.c_void_p), ("q_reduced", C.c_void_p), ("r_reduced", C.c_void_p),
+        ("p_reduced", C.c_int32), ("minReplicatesForReplace", C.c_double), ("cooksCutoff", C.c_double),
+        ("expVarLogDisp", C.c_double), ("betaTol", C.c_double), ("minmu", C.c_double), ("maxit", C.c_int32),
+        ("useQR", C.c_int32), ("disp_maxit", C.c_int32), ("useCR", C.c_int32), ("disp_grid", C.c_void_p),
+        ("ngrid", C.c_int32),
+    ]
+
+
+class DsqDeseqHostOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
+        "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
+        "logLikeReduced", "maxCooks", "replace", "mu", "H", "cooks", "replaceCounts")] + [
+        ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16)]
 
 
 DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS = 1, 2, 4, 8
@@ -200,6 +223,7 @@ EXPORTED_SYMBOLS = [
     "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows", "dsq_optim_rows",
     "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
     "dsq_profile_count", "dsq_profile_get",
+    "dsq_deseq",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
@@ -258,6 +282,7 @@ def lib():
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]
     L.dsq_replace_outliers_dev.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut), C.c_void_p]
     L.dsq_deseq_dev.argtypes = [C.POINTER(DsqDeseqArgs), C.POINTER(DsqDeseqOut), C.c_void_p]
+    L.dsq_deseq.argtypes = [C.POINTER(DsqDeseqHostArgs), C.POINTER(DsqDeseqHostOut)]
     L.dsq_deseq_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.dsq_deseq_workspace_bytes.restype = C.c_int64
     L.dsq_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]

@@ -219,6 +219,14 @@ def getBaseMeansAndVariances(dds):
     return dds
 
 
+def xim_size_factors(sf):
+    """momentsDispEstimate's xim = mean(1 / sizeFactors) (R/core.R:2440-2444), summed in sample order (R's mean() is a
+    sequential sum too): ONE definition for the call-by-call chain, the fused chain and the library's own host entry
+    (csrc/deseq_host.hip), so that all three start the dispersion search from the same bits"""
+    sf = np.asarray(sf, np.float64)
+    return float(np.cumsum(1.0 / sf)[-1] / sf.size)
+
+
 def modelMatrixGroups(x):
     """R/core.R:2450-2452"""
     return _cells(x)[0]
@@ -387,7 +395,7 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
         else:
             roughDisp = E.prefit(dds.y, dds.nf, x, dds.weights_h if dds.has_weights else None)["roughDisp"]
         bm, bv = dds.mcols["baseMean"], dds.mcols["baseVar"]
-        xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
+        xim = xim_size_factors(dds.sizeFactors) if dds.sizeFactors is not None else E.xim(dds.nf)
         momentsDisp = (bv - xim * bm) / (bm * bm)                                   # :2439-2448
         alpha_hat = np.minimum(roughDisp, momentsDisp)
     else:

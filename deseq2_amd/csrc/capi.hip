@@ -261,6 +261,9 @@ void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
     return DispatchP<DSQ_P_REG>::disp(p, kp, st, grid, ok);
 }
+hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok) {
+    return DispatchP<DSQ_P_REG>::optim(p, kp, st, ok);
+}
 
 // ---- wide designs (DSQ_P_REG < p <= DSQ_P_WIDE): zero-padded to DSQ_P_WIDE columns --------------------------
 // A padded coefficient has an all-zero design column, ridge 1 and start value 0: its estimate is exactly 0 and the
@@ -822,8 +825,12 @@ static int replace_dev_locked(const DsqReplaceArgs *a, const DsqReplaceOut *o, h
 static int up(int slot, const void *host, size_t bytes, hipStream_t st, void **dev) {
     int rc = ws_get(slot, bytes ? bytes : 8, dev);
     if (rc) return rc;
-    if (bytes) DSQ_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, st));
+    if (bytes) return stage_h2d(*dev, host, 1, bytes, 0, bytes, 1, st);
     return DSQ_OK;
+}
+// device -> pageable host memory, complete on return
+static int down(void *host, const void *dev, size_t bytes, hipStream_t st) {
+    return stage_d2h(host, dev, 1, bytes, 0, bytes, 1, st);
 }
 
 }  // namespace dsq
@@ -963,18 +970,10 @@ static int up_rows(int slot, const void *host, size_t elem, size_t n, size_t lo,
                    void **dev) {
     int rc = ws_get(slot, cnt * cols * elem ? cnt * cols * elem : 8, dev);
     if (rc) return rc;
-    if (!cnt || !cols) return DSQ_OK;
-    if (cnt == n) DSQ_HIP(hipMemcpyAsync(*dev, host, n * cols * elem, hipMemcpyHostToDevice, st));
-    else DSQ_HIP(hipMemcpy2DAsync(*dev, cnt * elem, (const char *)host + lo * elem, n * elem, cnt * elem, cols,
-                                  hipMemcpyHostToDevice, st));
-    return DSQ_OK;
+    return stage_h2d(*dev, host, elem, n, lo, cnt, cols, st);
 }
 static int down_rows(void *host, const void *dev, size_t elem, size_t n, size_t lo, size_t cnt, size_t cols, hipStream_t st) {
-    if (!cnt || !cols) return DSQ_OK;
-    if (cnt == n) DSQ_HIP(hipMemcpyAsync(host, dev, n * cols * elem, hipMemcpyDeviceToHost, st));
-    else DSQ_HIP(hipMemcpy2DAsync((char *)host + lo * elem, n * elem, dev, cnt * elem, cnt * elem, cols,
-                                  hipMemcpyDeviceToHost, st));
-    return DSQ_OK;
+    return stage_d2h(host, dev, elem, n, lo, cnt, cols, st);
 }
 
 static int fit_beta_host_range(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, size_t lo, size_t cnt, hipStream_t st,
@@ -1157,13 +1156,14 @@ static void host_plan(size_t n, int *nshards, int *ndev) {
     *nshards = s; *ndev = cnt;
 }
 
-// run f(lo, cnt, stream) over the ranges of R/parallel.R:10; one range: on the caller's thread, device and null stream
+// run f(lo, cnt, stream, range index, number of ranges) over the ranges of R/parallel.R:10; one range: on the caller's
+// thread, device and null stream
 template <class F>
-static int host_sharded(size_t row_lo, size_t n, F &&f0) {
-    auto f = [&](size_t lo, size_t cnt, hipStream_t st) { return f0(row_lo + lo, cnt, st); };
+static int host_sharded_ix(size_t row_lo, size_t n, F &&f0) {
     int S, ndev;
     host_plan(n, &S, &ndev);
-    if (S <= 1) return f((size_t)0, n, (hipStream_t) nullptr);
+    auto f = [&](size_t lo, size_t cnt, hipStream_t st, int k) { return f0(row_lo + lo, cnt, st, k, S < 1 ? 1 : S); };
+    if (S <= 1) return f((size_t)0, n, (hipStream_t) nullptr, 0);
     std::vector<HostWorker *> ws(S);
     const size_t big = n / S + 1, nbig = n % S, small = n / S;      // the first n %% S ranges hold one gene more
     size_t lo = 0;
@@ -1172,7 +1172,7 @@ static int host_sharded(size_t row_lo, size_t n, F &&f0) {
         HostWorker *w = ws[k] = host_worker(k, ndev);
         {
             std::lock_guard<std::mutex> lk(w->m);
-            w->job = [&f, lo, cnt, w] { return f(lo, cnt, w->st); };
+            w->job = [&f, lo, cnt, w, k] { return f(lo, cnt, w->st, k); };
             w->has_job = true; w->done = false;
         }
         w->cv.notify_all();
@@ -1186,6 +1186,20 @@ static int host_sharded(size_t row_lo, size_t n, F &&f0) {
         if (w->rc && !rc) { rc = w->rc; snprintf(g_err, sizeof g_err, "%s", w->err); }
     }
     return rc;
+}
+
+template <class F>
+static int host_sharded(size_t row_lo, size_t n, F &&f0) {
+    return host_sharded_ix(row_lo, n, [&](size_t lo, size_t cnt, hipStream_t st, int, int) { return f0(lo, cnt, st); });
+}
+// (deseq_host.hip) the caller holds the library's call lock
+int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f) {
+    return host_sharded_ix((size_t)0, n, f);
+}
+int capi_host_shards(size_t n) {
+    int S, ndev;
+    host_plan(n, &S, &ndev);
+    return S < 1 ? 1 : S;
 }
 
 static void host_cells(const double *x, int m, int p, const int32_t *given, int ngiven, std::vector<int32_t> *labels,
@@ -1389,9 +1403,7 @@ int dsq_linear_mu(const DsqPrefitArgs *a, double mu_floor, double *mu) {
     if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &v))) return rc;
     rc = linear_mu_dev_locked(&d, mu_floor, (double *)v, st);
     if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(mu, v, n * m * 8, hipMemcpyDeviceToHost, st));
-    DSQ_HIP(hipStreamSynchronize(st));
-    return DSQ_OK;
+    return down(mu, v, n * m * 8, st);
 }
 
 int dsq_nbinom_loglike(const DsqLogLikeArgs *a, double *loglike) {
@@ -1459,8 +1471,8 @@ int dsq_intercept_fit(const DsqInterceptArgs *a, const DsqInterceptOut *o) {
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(o->beta_log2, od.beta_log2, n * 8, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipMemcpyAsync(o->betaSE, od.betaSE, n * 8, hipMemcpyDeviceToHost, st));
-    if (o->mu) DSQ_HIP(hipMemcpyAsync(o->mu, od.mu, n * m * 8, hipMemcpyDeviceToHost, st));
-    if (o->hat) DSQ_HIP(hipMemcpyAsync(o->hat, od.hat, n * m * 8, hipMemcpyDeviceToHost, st));
+    if (o->mu && (rc = down(o->mu, od.mu, n * m * 8, st))) return rc;
+    if (o->hat && (rc = down(o->hat, od.hat, n * m * 8, st))) return rc;
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;
 }
@@ -1571,7 +1583,7 @@ int dsq_cooks_distance(const DsqCooksArgs *a, const DsqCooksOut *o) {
     od.maxCooks = (double *)v; od.robustDisp = (double *)v + n;
     rc = cooks_dev_locked(&d, &od, st);
     if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(o->cooks, od.cooks, n * m * 8, hipMemcpyDeviceToHost, st));
+    if ((rc = down(o->cooks, od.cooks, n * m * 8, st))) return rc;
     DSQ_HIP(hipMemcpyAsync(o->maxCooks, od.maxCooks, n * 8, hipMemcpyDeviceToHost, st));
     if (o->robustDisp) DSQ_HIP(hipMemcpyAsync(o->robustDisp, od.robustDisp, n * 8, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
@@ -1601,7 +1613,7 @@ int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
     if ((rc = ws_get(WS_H_OUTVEC, n * 4, &v))) return rc; od.replace = (int32_t *)v;
     rc = replace_dev_locked(&d, &od, st);
     if (rc) return rc;
-    DSQ_HIP(hipMemcpyAsync(o->newCounts, od.newCounts, n * m * 4, hipMemcpyDeviceToHost, st));
+    if ((rc = down(o->newCounts, od.newCounts, n * m * 4, st))) return rc;
     DSQ_HIP(hipMemcpyAsync(o->replace, od.replace, n * 4, hipMemcpyDeviceToHost, st));
     DSQ_HIP(hipStreamSynchronize(st));
     return DSQ_OK;

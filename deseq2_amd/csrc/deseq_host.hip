@@ -1,0 +1,376 @@
+// deseq_host.hip -- dsq_deseq: the whole DESeq() chain behind ONE host-pointer call (include/deseq2_mi355x.h).
+//
+// The R-side caller (the patch of R/core.R:388-426) hands over counts(dds), the model matrix, the size
+// factors and three design-only quantities R has functions for (qr.Q / qr.R, qf, trigamma).  Here:
+//   * the design facts the chain needs (design cells as nOrMoreInCell sees them R/core.R:2366-2371, replaceable samples
+//     :2101, "one group per column" :735-742, mean(1 / sizeFactors) :2440-2444, the dispersion grid R/wrappers.R:70-72)
+//     are derived on the host -- O(m p) work;
+//   * the genes are cut into the contiguous ranges of R/parallel.R:10, one per visible device, each driven by a
+//     persistent worker thread with its own stream (capi.hip: host_sharded);
+//   * a range uploads its rows of the count matrix ONCE (pinned staging, stage.hip), converts them to the gene-major
+//     layout on the device, enqueues the device-driven chain of pipeline.hip (every phase, no host decision), and
+//     downloads the per-gene columns; n x m assays only on request;
+//   * with more than one range, the two n-vectors of the dispersion trend (baseMean, dispGeneEst) are exchanged
+//     through host memory between the gene-wise phase and the trend, exactly the exchange of DESeqParallel
+//     (R/parallel.R:27-40): every range then fits the same trend over the same gathered vectors.
+// No arithmetic on the data path here: everything per-gene is in the kernels.
+#include "../../include/deseq2_mi355x.h"
+#include "dsq_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace dsq {
+
+int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st);      // pipeline.hip
+int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f);   // capi.hip
+int capi_host_shards(size_t n);
+
+#define HD_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return capi_fail(e_ == hipErrorOutOfMemory ? DSQ_ERR_NOMEM : DSQ_ERR_DEVICE, "%s: %s", #expr, \
+                             hipGetErrorString(e_));                                                     \
+    } while (0)
+
+namespace {
+
+enum {   // device workspace slots of a range (grow-only, cached per (device, stream): a second call allocates nothing)
+    HD_YR = DSQ_WS_HOSTDESEQ, HD_Y, HD_VEC, HD_MAT, HD_IVEC, HD_MUHAT, HD_MU, HD_H, HD_COOKS, HD_REPC, HD_STAT, HD_WORK,
+    HD_DESIGN, HD_TREND, HD_OUTR, HD_END
+};
+static_assert(HD_END <= DSQ_WS_COUNT, "workspace slots");
+
+enum { V_BASEMEAN = 0, V_BASEVAR, V_DGE, V_DFIT, V_DMAP, V_DISP, V_BITER, V_LL, V_LLR, V_MAXCOOKS, V_COUNT };
+enum { I_ALLZERO = 0, I_DGITER, I_DITER, I_DOUTLIER, I_BCONV, I_REPLACE, I_OPT1, I_OPT2, I_COUNT };
+
+// what the chain needs to know about the design alone
+struct Facts {
+    std::vector<int32_t> cells, replaceable, cells_red;
+    int ncell = 0, do_replace = 0, linearMu = 0, ncell_red = 0;
+    std::vector<double> a, grid, lam, a_red;
+    double xim = 0.0;
+};
+
+// A = X R^-1 by back substitution over the columns (linearModelMuNormalized, R/core.R:2455-2457)
+static void x_rinv(const double *x, const double *r, int m, int p, std::vector<double> *out) {
+    out->assign((size_t)m * p, 0.0);
+    for (int j = 0; j < p; j++)
+        for (int i = 0; i < m; i++) {
+            double v = x[i + (size_t)m * j];
+            for (int k = 0; k < j; k++) v -= (*out)[i + (size_t)m * k] * r[k + (size_t)p * j];
+            (*out)[i + (size_t)m * j] = v / r[j + (size_t)p * j];
+        }
+}
+
+// samples with identical model-matrix rows share a cell; cells numbered in the lexicographic order of their rows
+static void design_cells(const double *x, int m, int p, std::vector<int32_t> *cell, int *ncell) {
+    std::vector<int> rep;                         // first sample of every distinct row
+    std::vector<int> of(m);
+    auto same = [&](int i, int j) {
+        for (int k = 0; k < p; k++) if (x[i + (size_t)m * k] != x[j + (size_t)m * k]) return false;
+        return true;
+    };
+    for (int j = 0; j < m; j++) {
+        int f = -1;
+        for (size_t c = 0; c < rep.size() && f < 0; c++) if (same(j, rep[c])) f = (int)c;
+        if (f < 0) { f = (int)rep.size(); rep.push_back(j); }
+        of[j] = f;
+    }
+    std::vector<int> order(rep.size());
+    for (size_t c = 0; c < rep.size(); c++) order[c] = (int)c;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        for (int k = 0; k < p; k++) {
+            const double va = x[rep[a] + (size_t)m * k], vb = x[rep[b] + (size_t)m * k];
+            if (va != vb) return va < vb;
+        }
+        return false;
+    });
+    std::vector<int> rank(rep.size());
+    for (size_t r = 0; r < order.size(); r++) rank[order[r]] = (int)r;
+    cell->resize(m);
+    for (int j = 0; j < m; j++) (*cell)[j] = rank[of[j]];
+    *ncell = (int)rep.size();
+}
+
+static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
+    const int m = a->m, p = a->p;
+    design_cells(a->x, m, p, &f->cells, &f->ncell);
+    std::vector<int> size(f->ncell, 0);
+    for (int j = 0; j < m; j++) size[f->cells[j]]++;
+    f->replaceable.assign(m, 0);
+    if (std::isfinite(a->minReplicatesForReplace))
+        for (int j = 0; j < m; j++)
+            if ((double)size[f->cells[j]] >= a->minReplicatesForReplace) { f->replaceable[j] = 1; f->do_replace = 1; }
+    f->linearMu = (f->ncell == p) ? 1 : 0;                                  // R/core.R:735-742 (no weights here)
+    if (a->xrinv) f->a.assign(a->xrinv, a->xrinv + (size_t)m * p);
+    else x_rinv(a->x, a->r, m, p, &f->a);
+    if (a->x_reduced) {
+        design_cells(a->x_reduced, m, a->p_reduced, &f->cells_red, &f->ncell_red);
+        x_rinv(a->x_reduced, a->r_reduced, m, a->p_reduced, &f->a_red);      // (feeds only outputs nobody reads)
+    }
+    // the 20-point grid of fitDispGridWrapper (R/wrappers.R:70-72): seq(log(1e-8), log(max(10, m)), length = 20)
+    if (a->disp_grid && a->ngrid >= 2) f->grid.assign(a->disp_grid, a->disp_grid + a->ngrid);
+    else {
+        const double lo = std::log(1e-8), hi = std::log(m > 10 ? (double)m : 10.0);
+        f->grid.resize(20);
+        const double step = (hi - lo) / 19.0;
+        for (int k = 0; k < 20; k++) f->grid[k] = (k == 19) ? hi : lo + (double)k * step;
+    }
+    const double ln2 = 0.6931471805599453;
+    f->lam.assign(p, 1e-6 / (ln2 * ln2));                                    // R/fitNbinomGLMs.R:73,162
+    double s = 0.0;                                                          // mean(1 / sizeFactors), in sample order
+    for (int j = 0; j < m; j++) s += 1.0 / a->sizeFactors[j];
+    f->xim = s / (double)m;
+}
+
+// the gene ranges meet here between the gene-wise phase and the trend
+struct Exchange {
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, target = 1;
+    bool failed = false;
+    std::vector<double> bm, dge;
+    std::vector<int32_t> status;       // target x DSQ_ST_COUNT
+    std::vector<double> scalars;       // target x DSQ_SC_COUNT
+    bool wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (++arrived >= target) cv.notify_all();
+        else cv.wait(lk, [&] { return arrived >= target || failed; });
+        return !failed;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
+static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
+    if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
+    if (a->n < 1 || a->m < 2 || a->p < 1) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
+    if (!a->counts || !a->x || !a->sizeFactors || !a->q || !a->r) return capi_fail(DSQ_ERR_ARG, "NULL input array");
+    if (a->y_type != DSQ_Y_INT32 && a->y_type != DSQ_Y_FLOAT64) return capi_fail(DSQ_ERR_ARG, "unknown y_type %d", a->y_type);
+    if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
+    if (a->x_reduced && (a->test != 1 || !a->q_reduced || !a->r_reduced || a->p_reduced < 1 || a->p_reduced >= a->p))
+        return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with qr.Q / qr.R of its model matrix and 1 <= p_reduced < p");
+    if (a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "the number of samples and the number of model coefficients are equal");
+    if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (a->m - a->p <= 3)
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is not available", a->m - a->p);
+    if (!(a->cooksCutoff > 0.0) || !(a->expVarLogDisp > 0.0)) return capi_fail(DSQ_ERR_ARG, "cooksCutoff = qf(.99, p, m - p) and expVarLogDisp = trigamma((m - p) / 2) must be given");
+    if (a->maxit < 1 || a->disp_maxit < 1 || !(a->betaTol > 0.0) || !(a->minmu > 0.0)) return capi_fail(DSQ_ERR_ARG, "betaTol / maxit / minmu / disp_maxit");
+    if (!(a->minReplicatesForReplace >= 3.0)) return capi_fail(DSQ_ERR_ARG, "at least 3 replicates are necessary in order to indentify a sample as a count outlier");
+    for (int j = 0; j < a->m; j++)
+        if (!(a->sizeFactors[j] > 0.0) || !std::isfinite(a->sizeFactors[j])) return capi_fail(DSQ_ERR_VALUE, "sizeFactors[%d] is not a positive finite number", j);
+    if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
+        !o->dispersion || !o->dispIter || !o->dispOutlier || !o->beta || !o->betaSE || !o->betaConv || !o->betaIter ||
+        !o->logLike || !o->maxCooks || !o->replace)
+        return capi_fail(DSQ_ERR_ARG, "NULL output column");
+    if (a->test == 0 && (!o->stat || !o->pvalue)) return capi_fail(DSQ_ERR_ARG, "the Wald test needs the stat / pvalue outputs");
+    if (a->test == 1 && !o->logLikeReduced) return capi_fail(DSQ_ERR_ARG, "the LRT needs logLikeReduced");
+    return DSQ_OK;
+}
+
+// one gene range: rows [lo, lo + cnt) of the analysis
+static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Facts &F, Exchange &X, size_t lo, size_t cnt,
+                       hipStream_t st, int shard, int nshards) {
+    const size_t n = a->n, m = a->m, p = a->p;
+    const long ld = ((long)m + 7) & ~7L;
+    int rc;
+    void *v;
+    // ---- counts: R layout rows -> device -> gene-major int32
+    const size_t ye = a->y_type == DSQ_Y_INT32 ? 4 : 8;
+    if ((rc = capi_ws_get(HD_YR, cnt * m * ye, &v))) return rc;
+    void *y_r = v;
+    if ((rc = stage_h2d(y_r, a->counts, ye, n, lo, cnt, m, st))) return rc;
+    if ((rc = capi_ws_get(HD_Y, cnt * (size_t)ld * 4, &v))) return rc;
+    int32_t *y = (int32_t *)v;
+    // ---- status block first (the REALSXP conversion flags bad counts in it)
+    if ((rc = capi_ws_get(HD_STAT, (DSQ_ST_COUNT + 2) * 4 + DSQ_SC_COUNT * 8 + 64, &v))) return rc;
+    double *scalars = (double *)v;
+    int32_t *status = (int32_t *)(scalars + DSQ_SC_COUNT), *bad = status + DSQ_ST_COUNT;
+    HD_HIP(hipMemsetAsync(v, 0, (DSQ_ST_COUNT + 2) * 4 + DSQ_SC_COUNT * 8, st));
+    if (a->y_type == DSQ_Y_INT32) HD_HIP(launch_transpose_r_to_gm_i32((const int32_t *)y_r, y, (int)cnt, (int)m, ld, st));
+    else HD_HIP(launch_counts_f64_to_gm_i32((const double *)y_r, y, (int)cnt, (int)m, ld, bad, st));
+    // ---- design: x | q | a | r | grid | size factors, one small staging vector
+    const size_t pr = a->x_reduced ? (size_t)a->p_reduced : 0;
+    const size_t off_x = 0, off_q = off_x + m * p, off_a = off_q + m * p, off_r = off_a + m * p, off_g = off_r + p * p,
+                 off_sf = off_g + F.grid.size(), off_xr = off_sf + m, off_qr = off_xr + m * pr, off_ar = off_qr + m * pr,
+                 off_rr = off_ar + m * pr, dtot = off_rr + pr * pr;
+    if ((rc = capi_ws_get(HD_DESIGN, dtot * 8, &v))) return rc;
+    double *dd = (double *)v;
+    {
+        static thread_local std::vector<double> hb;
+        hb.resize(dtot);
+        memcpy(hb.data() + off_x, a->x, m * p * 8); memcpy(hb.data() + off_q, a->q, m * p * 8);
+        memcpy(hb.data() + off_a, F.a.data(), m * p * 8); memcpy(hb.data() + off_r, a->r, p * p * 8);
+        memcpy(hb.data() + off_g, F.grid.data(), F.grid.size() * 8); memcpy(hb.data() + off_sf, a->sizeFactors, m * 8);
+        if (pr) {
+            memcpy(hb.data() + off_xr, a->x_reduced, m * pr * 8); memcpy(hb.data() + off_qr, a->q_reduced, m * pr * 8);
+            memcpy(hb.data() + off_ar, F.a_red.data(), m * pr * 8); memcpy(hb.data() + off_rr, a->r_reduced, pr * pr * 8);
+        }
+        HD_HIP(hipMemcpyAsync(dd, hb.data(), dtot * 8, hipMemcpyHostToDevice, st));      // (pageable: staged at once)
+    }
+    // ---- outputs
+    if ((rc = capi_ws_get(HD_VEC, V_COUNT * cnt * 8, &v))) return rc;
+    double *vec = (double *)v;
+    if ((rc = capi_ws_get(HD_MAT, 4 * p * cnt * 8, &v))) return rc;
+    double *mat = (double *)v;
+    if ((rc = capi_ws_get(HD_IVEC, I_COUNT * cnt * 4, &v))) return rc;
+    int32_t *ivec = (int32_t *)v;
+    double *mats[4];
+    const int slots[4] = {HD_MUHAT, HD_MU, HD_H, HD_COOKS};
+    for (int k = 0; k < 4; k++) { if ((rc = capi_ws_get(slots[k], cnt * (size_t)ld * 8, &v))) return rc; mats[k] = (double *)v; }
+    if ((rc = capi_ws_get(HD_REPC, cnt * (size_t)ld * 4, &v))) return rc;
+    int32_t *repc = (int32_t *)v;
+    const int nt = nshards > 1 ? (int)n : 0;
+    const int64_t wsb = dsq_deseq_workspace_bytes((int32_t)cnt, (int32_t)m, (int32_t)p, nt);
+    if ((rc = capi_ws_get(HD_WORK, (size_t)wsb, &v))) return rc;
+    void *work = v;
+
+    DsqDeseqArgs d;
+    memset(&d, 0, sizeof d);
+    d.n = (int32_t)cnt; d.m = (int32_t)m; d.p = (int32_t)p; d.ld = ld;
+    d.y = y; d.nf = dd + off_sf; d.nf_is_vector = 1; d.useWeights = 0;
+    d.x = dd + off_x; d.q = dd + off_q; d.a = dd + off_a; d.r = dd + off_r;
+    d.xim = F.xim; d.linearMu = F.linearMu;
+    d.minDisp = 1e-8; d.kappa_0 = 1.0; d.dispTol = 1e-6; d.weightThreshold = 1e-2; d.outlierSD = 2.0;
+    d.betaTol = a->betaTol; d.minmu = a->minmu; d.maxit = a->disp_maxit; d.useCR = a->useCR ? 1 : 0; d.useQR = a->useQR ? 1 : 0;
+    d.betaMaxit = a->maxit;
+    d.disp_grid = dd + off_g; d.ngrid = (int32_t)F.grid.size(); d.expVarLogDisp = a->expVarLogDisp;
+    d.n_trend = nt; d.lambda = F.lam.data(); d.min_log_alpha = std::log(1e-8 / 10.0);
+    d.workspace = work; d.workspace_bytes = wsb; d.test = a->test;
+    d.cell_of = F.cells.data(); d.ncell = F.ncell; d.replaceable = F.replaceable.data();
+    d.cooksCutoff = a->cooksCutoff; d.trim = 0.2; d.do_replace = F.do_replace;
+    if (pr) {
+        d.x_red = dd + off_xr; d.q_red = dd + off_qr; d.a_red = dd + off_ar; d.r_red = dd + off_rr; d.p_red = (int32_t)pr;
+        d.cell_of_red = F.cells_red.data(); d.ncell_red = F.ncell_red;
+    }
+    DsqDeseqOut od;
+    memset(&od, 0, sizeof od);
+    od.baseMean = vec + V_BASEMEAN * cnt; od.baseVar = vec + V_BASEVAR * cnt; od.dispGeneEst = vec + V_DGE * cnt;
+    od.dispFit = vec + V_DFIT * cnt; od.dispMAP = vec + V_DMAP * cnt; od.dispersion = vec + V_DISP * cnt;
+    od.betaIter = vec + V_BITER * cnt; od.logLike = vec + V_LL * cnt; od.logLikeReduced = vec + V_LLR * cnt;
+    od.maxCooks = vec + V_MAXCOOKS * cnt;
+    od.beta = mat; od.betaSE = mat + p * cnt;
+    od.stat = a->test == 0 ? mat + 2 * p * cnt : nullptr; od.pvalue = a->test == 0 ? mat + 3 * p * cnt : nullptr;
+    od.allZero = ivec + I_ALLZERO * cnt; od.dispGeneIter = ivec + I_DGITER * cnt; od.dispIter = ivec + I_DITER * cnt;
+    od.dispOutlier = ivec + I_DOUTLIER * cnt; od.betaConv = ivec + I_BCONV * cnt; od.replace = ivec + I_REPLACE * cnt;
+    od.optim_geneest = ivec + I_OPT1 * cnt; od.optim_test = ivec + I_OPT2 * cnt;
+    od.mu_hat = mats[0]; od.mu = mats[1]; od.H = mats[2]; od.cooks = mats[3]; od.replaceCounts = repc;
+    od.status = status; od.scalars = scalars;
+
+    // ---- the chain
+    if (nshards == 1) {
+        d.phases = DSQ_PH_GENE_EST | DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
+        if ((rc = pipeline_run(&d, &od, st))) return rc;
+    } else {
+        d.phases = DSQ_PH_GENE_EST;
+        if ((rc = pipeline_run(&d, &od, st))) return rc;
+        // the trend's input vectors of all ranges, through host memory (R/parallel.R:27-28)
+        HD_HIP(hipMemcpyAsync(X.bm.data() + lo, od.baseMean, cnt * 8, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipMemcpyAsync(X.dge.data() + lo, od.dispGeneEst, cnt * 8, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipStreamSynchronize(st));
+        if (!X.wait()) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
+        if ((rc = capi_ws_get(HD_TREND, 2 * n * 8, &v))) return rc;
+        double *tv = (double *)v;
+        HD_HIP(hipMemcpyAsync(tv, X.bm.data(), n * 8, hipMemcpyHostToDevice, st));
+        HD_HIP(hipMemcpyAsync(tv + n, X.dge.data(), n * 8, hipMemcpyHostToDevice, st));
+        d.trend_mean = tv; d.trend_disp = tv + n;
+        d.phases = DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
+        if ((rc = pipeline_run(&d, &od, st))) return rc;
+    }
+
+    // ---- per-gene columns down: three packed blocks, scattered into the caller's columns at this range's rows
+    static thread_local std::vector<double> hv;
+    static thread_local std::vector<int32_t> hi;
+    hv.resize((V_COUNT + 4 * p) * cnt + DSQ_SC_COUNT + DSQ_ST_COUNT);
+    hi.resize(I_COUNT * cnt);
+    double *hvec = hv.data(), *hmat = hvec + V_COUNT * cnt, *hsc = hmat + 4 * p * cnt;
+    int32_t *hst = (int32_t *)(hsc + DSQ_SC_COUNT);
+    HD_HIP(hipMemcpyAsync(hsc, scalars, DSQ_SC_COUNT * 8 + (DSQ_ST_COUNT + 2) * 4, hipMemcpyDeviceToHost, st));
+    if ((rc = stage_d2h(hvec, vec, 1, V_COUNT * cnt * 8, 0, V_COUNT * cnt * 8, 1, st))) return rc;
+    if ((rc = stage_d2h(hmat, mat, 1, 4 * p * cnt * 8, 0, 4 * p * cnt * 8, 1, st))) return rc;
+    if ((rc = stage_d2h(hi.data(), ivec, 1, I_COUNT * cnt * 4, 0, I_COUNT * cnt * 4, 1, st))) return rc;
+    HD_HIP(hipStreamSynchronize(st));
+    if (hst[DSQ_ST_COUNT] != 0) return capi_fail(DSQ_ERR_VALUE, "count matrix holds negative, non-finite or non-integer values");
+    memcpy(X.status.data() + (size_t)shard * DSQ_ST_COUNT, hst, DSQ_ST_COUNT * 4);
+    memcpy(X.scalars.data() + (size_t)shard * DSQ_SC_COUNT, hsc, DSQ_SC_COUNT * 8);
+    double *const dcol[V_COUNT] = {o->baseMean, o->baseVar, o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter,
+                                   o->logLike, o->logLikeReduced, o->maxCooks};
+    for (int k = 0; k < V_COUNT; k++)
+        if (dcol[k]) memcpy(dcol[k] + lo, hvec + (size_t)k * cnt, cnt * 8);
+    double *const mcol[4] = {o->beta, o->betaSE, o->stat, o->pvalue};
+    for (int k = 0; k < 4; k++)
+        if (mcol[k] && (k < 2 || a->test == 0))
+            for (size_t c = 0; c < p; c++) memcpy(mcol[k] + c * n + lo, hmat + ((size_t)k * p + c) * cnt, cnt * 8);
+    int32_t *const icol[6] = {o->allZero, o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv, o->replace};
+    for (int k = 0; k < 6; k++) memcpy(icol[k] + lo, hi.data() + (size_t)k * cnt, cnt * 4);
+    // `replace` is NA on the rows that were all zero from the start (and everywhere without a replaceable sample)
+    for (size_t i = 0; i < cnt; i++)
+        if (!F.do_replace || (o->allZero[lo + i] && o->replace[lo + i] == 0)) o->replace[lo + i] = -1;
+
+    // ---- assays on request: gene-major -> R layout on the device -> the caller's n x m matrix
+    double *const want[3] = {o->mu, o->H, o->cooks};
+    for (int k = 0; k < 3; k++) {
+        if (!want[k]) continue;
+        if ((rc = capi_ws_get(HD_OUTR, cnt * m * 8, &v))) return rc;
+        HD_HIP(launch_transpose_gm_to_r_f64(mats[k + 1], (double *)v, (int)cnt, (int)m, ld, st));
+        if ((rc = stage_d2h(want[k], v, 8, n, lo, cnt, m, st))) return rc;
+    }
+    if (o->replaceCounts) {
+        if ((rc = capi_ws_get(HD_OUTR, cnt * m * 8, &v))) return rc;
+        HD_HIP(launch_transpose_gm_to_r_i32(repc, (int32_t *)v, (int)cnt, (int)m, ld, st));
+        if ((rc = stage_d2h(o->replaceCounts, v, 4, n, lo, cnt, m, st))) return rc;
+    }
+    return DSQ_OK;
+}
+
+}  // namespace
+}  // namespace dsq
+
+using namespace dsq;
+
+extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
+    std::lock_guard<std::mutex> lk(capi_mutex());
+    capi_latch_stream(nullptr);
+    int rc = check_args(a, o);
+    if (rc) return rc;
+    if ((rc = capi_check_device())) return rc;
+    Facts F;
+    design_facts(a, &F);
+    Exchange X;
+    const int S = capi_host_shards((size_t)a->n);
+    X.target = S;
+    if (S > 1) { X.bm.resize(a->n); X.dge.resize(a->n); }
+    X.status.assign((size_t)S * DSQ_ST_COUNT, 0);
+    X.scalars.assign((size_t)S * DSQ_SC_COUNT, 0.0);
+    rc = capi_host_sharded((size_t)a->n, [&](size_t lo, size_t cnt, hipStream_t st, int shard, int nshards) {
+        const int r = deseq_range(a, o, F, X, lo, cnt, st, shard, nshards);
+        if (r) X.fail();             // (ranges waiting at the exchange give up instead of waiting for this one)
+        return r;
+    });
+    if (rc) return rc;
+    // counters: per-range counts add up; the trend's (fitted by every range over the same gathered vectors) are range 0's
+    memset(o->status, 0, sizeof o->status);
+    for (int s = 0; s < S; s++)
+        for (int k = 0; k < DSQ_ST_COUNT; k++)
+            if (k != DSQ_ST_N_TREND && k != DSQ_ST_TREND_STATUS && k != DSQ_ST_N_ABOVE_MIN) o->status[k] += X.status[(size_t)s * DSQ_ST_COUNT + k];
+    o->status[DSQ_ST_N_TREND] = X.status[DSQ_ST_N_TREND];
+    o->status[DSQ_ST_TREND_STATUS] = X.status[DSQ_ST_TREND_STATUS];
+    o->status[DSQ_ST_N_ABOVE_MIN] = X.status[DSQ_ST_N_ABOVE_MIN];
+    for (int k = 0; k < 4; k++) o->dispersionFunction[k] = X.scalars[k];
+    if (o->status[DSQ_ST_N_NONZERO] == 0) return capi_fail(DSQ_ERR_FIT, "all genes have zero counts in every sample");
+    if (o->status[DSQ_ST_N_TREND] == 0)
+        return capi_fail(DSQ_ERR_FIT, "all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value");
+    if (o->status[DSQ_ST_TREND_STATUS] != 0 || o->status[DSQ_ST_N_ABOVE_MIN] == 0)
+        return capi_fail(DSQ_ERR_FIT, "the parametric dispersion trend did not fit (status %d): use the call-by-call routines with fitType = 'local' / 'mean' (R/core.R:885-893)", o->status[DSQ_ST_TREND_STATUS]);
+    return DSQ_OK;
+}

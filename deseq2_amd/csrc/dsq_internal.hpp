@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <mutex>
 #include <string.h>
 
@@ -140,6 +141,11 @@ struct OptimKernelParams {
     int32_t *conv;             // n
     double *mu_out;            // n x ld
     double *loglike;           // n
+    double mu_floor;           // > 0: the fitted means are stored floored at it (fitMu[fitMu < minmu] <- minmu, R/core.R:763)
+    // fused pipeline (pipeline.hip): the launch covers the rows rows[0 .. *n_dev) of full-size arrays (n = their
+    // capacity / leading dimension); rows == nullptr: rows 0 .. n-1
+    const int32_t *rows;
+    const int32_t *n_dev;
 };
 
 struct CooksKernelParams {
@@ -247,8 +253,14 @@ void capi_latch_stream(hipStream_t s);                           // workspace ke
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok);
 void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr);
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok);
+hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok);
 void capi_prof_begin(const char *name, int n, hipStream_t st);   // no-ops unless dsq_profile_enable(1)
 void capi_prof_end(hipStream_t st);
-enum { DSQ_WS_PIPE = 40, DSQ_WS_PIPE_SCRATCH = 41, DSQ_WS_PIPE_META = 42, DSQ_WS_COUNT = 48 };
+// stage.hip: pageable host memory <-> device through pinned chunks packed by a small thread pool; rows [lo, lo + cnt) of
+// a column-major n_total x cols host matrix <-> a contiguous column-major cnt x cols device matrix.  stage_d2h returns
+// when the host rows are complete.
+int stage_h2d(void *dev, const void *host, size_t e, size_t n_total, size_t lo, size_t cnt, size_t cols, hipStream_t st);
+int stage_d2h(void *host, const void *dev, size_t e, size_t n_total, size_t lo, size_t cnt, size_t cols, hipStream_t st);
+enum { DSQ_WS_PIPE = 40, DSQ_WS_PIPE_SCRATCH = 41, DSQ_WS_PIPE_META = 42, DSQ_WS_HOSTDESEQ = 48, DSQ_WS_COUNT = 72 };
 
 }  // namespace dsq

@@ -986,7 +986,9 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
     constexpr int N = SymNB<P>::value;
     const double ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
     const double bound = 30.0 * ln2;
-    for (int g = blockIdx.x; g < kp.n; g += gridDim.x) {
+    const int nwork = DSQ_NWORK(kp);
+    for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -1074,7 +1076,8 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
         double lacc = 0.0;
         for (int j = lane; j < m; j += 64) {
             const double mu = nfg[j] * dexp(eta_of(gam, j));
-            kp.mu_out[(size_t)g * kp.ld + j] = mu;
+            // pmax(mu, mu_floor) as numpy.maximum / R's `[<-` on a comparison leave a NaN in place
+            kp.mu_out[(size_t)g * kp.ld + j] = (kp.mu_floor > 0.0 && mu < kp.mu_floor) ? kp.mu_floor : mu;
             const double muc = __builtin_fmax(mu, kp.minmu);
             double wv;
             if constexpr (USE_W) wv = wg[j] / (1.0 / muc + alpha);
@@ -1127,6 +1130,7 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
 template <>
 hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &kp, hipStream_t st) {
     int grid = kp.n < 4096 ? kp.n : 4096;
+    if (kp.rows && grid > 256) grid = 256;       // a row list (its length lives on the device): a handful of rows
     if (grid < 1) grid = 1;
     if (kp.useWeights) hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, true>), dim3(grid), dim3(64), 0, st, kp);
     else hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, false>), dim3(grid), dim3(64), 0, st, kp);

@@ -238,7 +238,12 @@ struct RuleParams {
     const double *beta_nat, *beta_var, *beta_iter, *logLike;
     double *beta, *betaSE, *stat, *pvalue, *betaIter_out;
     int32_t *betaConv, *optim_flag, *optim_count;
+    int32_t *optim_rows;           // the flagged rows, listed (any order) for the row-listed optim launch
     int wald;
+    // the rows fitNbinomGLMsOptim re-fits (R/fitNbinomGLMs.R:340-407)
+    const double *beta_init;       // the IRLS start values (natural-log scale)
+    double *opt_start;             // n x p, log2 scale
+    const int32_t *opt_conv;
 };
 
 // alpha_hat <- pmin(roughDisp, momentsDisp), bounded to [minDisp, maxDisp] (R/core.R:713-728, :2439-2448)
@@ -353,7 +358,35 @@ __global__ void beta_post_kernel(RuleParams q) {
     if (q.betaIter_out) q.betaIter_out[g] = it;
     const bool optim = !conv || !stable || !varpos;
     q.optim_flag[g] = optim ? 1 : 0;
-    if (optim) atomicAdd(q.optim_count, 1);
+    if (optim) {
+        const int k = atomicAdd(q.optim_count, 1);
+        if (q.optim_rows) q.optim_rows[k] = g;
+        // start values of the fallback (:350-355): the IRLS estimate (log2 scale) when it is finite and inside the box,
+        // else the IRLS's own start values -- on the natural-log scale, as the reference passes them
+        bool usable = stable;
+        for (int c = 0; c < q.p && usable; c++)
+            usable = __builtin_fabs(log2e * q.beta_nat[(size_t)g + (size_t)q.n * c]) < 30.0;
+        for (int c = 0; c < q.p; c++)
+            q.opt_start[(size_t)g + (size_t)q.n * c] = usable ? log2e * q.beta_nat[(size_t)g + (size_t)q.n * c]
+                                                              : q.beta_init[(size_t)g + (size_t)q.n * c];
+    }
+}
+
+// after the fallback: betaConv[row] <- TRUE where optim converged (:378-380); Wald statistic and p-value from its
+// coefficients (the optim kernel has written beta / betaSE / logLike / mu of these rows in place)
+__global__ void optim_post_kernel(RuleParams q) {
+    const int cnt = rows_count(q.rw);                       // (a handful: the grid is small and strides)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const int g = rows_gene(q.rw, i);
+        if (q.betaConv && q.opt_conv[g]) q.betaConv[g] = 1;
+        if (q.wald && q.stat) {
+            for (int c = 0; c < q.p; c++) {
+                const double z = q.beta[(size_t)g + (size_t)q.n * c] / q.betaSE[(size_t)g + (size_t)q.n * c];
+                q.stat[(size_t)g + (size_t)q.n * c] = z;
+                q.pvalue[(size_t)g + (size_t)q.n * c] = dpnorm_upper2(z);
+            }
+        }
+    }
 }
 
 // rows flagged -> list (order irrelevant: the listed launches write results at the gene's own position)
@@ -443,7 +476,13 @@ struct Pipe {
     double *roughDisp, *beta_init, *alpha_init, *la0, *la_out, *last_change, *initial_lp, *initial_dlp, *last_lp, *last_dlp;
     double *la_grid, *log_dfit, *la_init, *beta_nat, *beta_var, *beta_iter, *cnum, *cden, *dev, *lam, *contrast, *resbuf;
     double *trend_mean_c, *trend_disp_c, *robustDisp, *scratch, *cscratch;
+    double *opt_start, *opt_beta, *opt_se, *opt_ll;
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
+    int32_t *rows_opt, *opt_conv;
+    // nbinomLRT against a reduced model that is not ~1
+    double *red_binit, *red_beta, *red_se, *red_mu;
+    const int32_t *red_cell_perm, *red_cell_start;
+    int red_ncell;
     int32_t *cells_dev;            // perm | in3 | cell_start | use3 | replaceable
     void *trend_ws;
     int next_counter;
@@ -455,7 +494,7 @@ struct Pipe {
 };
 
 enum { CNT_NZ = 0, CNT_GRID1, CNT_TREND, CNT_GRID2, CNT_OPT1, CNT_OPT2, CNT_REP, CNT_REFIT, CNT_GRID1R, CNT_GRID2R,
-       CNT_OPT1R, CNT_OPT2R, CNT_N = 16 };
+       CNT_OPT1R, CNT_OPT2R, CNT_OPT3, CNT_OPT3R, CNT_N = 16 };
 
 static int *next_work_counter(Pipe &P) {
     int *c = P.work_counters + (P.next_counter % 60);
@@ -482,19 +521,21 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     q.dispFit = o->dispFit; q.log_dfit = P.log_dfit; q.la_init = P.la_init; q.dispMAP = o->dispMAP;
     q.dispersion = o->dispersion; q.dispIter = o->dispIter; q.dispOutlier = o->dispOutlier;
     q.beta_nat = P.beta_nat; q.beta_var = P.beta_var; q.beta_iter = P.beta_iter;
+    q.optim_rows = P.rows_opt; q.beta_init = P.beta_init; q.opt_start = P.opt_start; q.opt_conv = P.opt_conv;
     return q;
 }
 
 static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const double *alpha, const double *weights,
                            double *mu_out, double mu_floor, double *hat, double tol, int maxit, int useQR, double minmu,
-                           const char *name) {
+                           const char *name, bool reduced = false) {
     const DsqDeseqArgs *a = P.a;
     BetaKernelParams kp;
     memset(&kp, 0, sizeof kp);
-    kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld;
+    kp.n = P.n; kp.m = P.m; kp.p = reduced ? a->p_red : P.p; kp.ld = P.ld;
     kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
     kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
-    kp.x = a->x; kp.alpha_hat = alpha; kp.contrast = P.contrast; kp.beta_init = P.beta_init; kp.lambda = P.lam;
+    kp.x = reduced ? a->x_red : a->x; kp.alpha_hat = alpha; kp.contrast = P.contrast;
+    kp.beta_init = reduced ? P.red_binit : P.beta_init; kp.lambda = P.lam;
     kp.tol = tol; kp.minmu = minmu; kp.mu_floor = mu_floor; kp.maxit = maxit; kp.useQR = useQR ? 1 : 0;
     kp.beta_mat = P.beta_nat; kp.beta_var_mat = P.beta_var; kp.iter = P.beta_iter;
     kp.contrast_num = P.cnum; kp.contrast_denom = P.cden; kp.deviance = P.dev;
@@ -502,12 +543,13 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.scratch = P.scratch; kp.cscratch = P.cscratch;
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
-    kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell;
+    if (reduced) { kp.cell_perm = P.red_cell_perm; kp.cell_start = P.red_cell_start; kp.ncell = P.red_ncell; }
+    else { kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell; }
     bool ok = false;
     char nm[32];
     snprintf(nm, sizeof nm, "%s%s", name, P.tag);
     capi_prof_begin(nm, P.n, P.st);
-    PIPE_HIP(dispatch_fit_beta(P.p, kp, P.st, &ok));
+    PIPE_HIP(dispatch_fit_beta(kp.p, kp, P.st, &ok));
     capi_prof_end(P.st);
     if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no register kernel for p=%d", P.p);
     return DSQ_OK;
@@ -567,6 +609,31 @@ static int launch_prefit_rows(Pipe &P, const Rows &rw, const int32_t *y) {
     return DSQ_OK;
 }
 
+// fitNbinomGLMsOptim (R/fitNbinomGLMs.R:340-407) on the rows beta_post_kernel listed (their number lives on the device:
+// usually zero, the launch then finds nothing to do): start values from P.opt_start, coefficients / standard errors /
+// logLike / fitted means written at the rows' own positions
+static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *alpha, const double *weights, double minmu,
+                        double mu_floor, double *beta, double *betaSE, double *loglike, double *mu_out, bool reduced = false) {
+    const DsqDeseqArgs *a = P.a;
+    OptimKernelParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.n = P.n; kp.m = P.m; kp.p = reduced ? a->p_red : P.p; kp.ld = P.ld;
+    kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
+    kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
+    kp.x = reduced ? a->x_red : a->x; kp.alpha_hat = alpha; kp.lamnat = P.lam; kp.beta_start = P.opt_start;
+    kp.minmu = minmu; kp.mu_floor = mu_floor;
+    kp.beta = beta; kp.betaSE = betaSE; kp.conv = P.opt_conv; kp.mu_out = mu_out; kp.loglike = loglike;
+    kp.rows = P.rows_opt; kp.n_dev = P.counters + cnt_optim;
+    bool ok = false;
+    char nm[32];
+    snprintf(nm, sizeof nm, "optim_rows%s", P.tag);
+    capi_prof_begin(nm, P.n, P.st);
+    PIPE_HIP(dispatch_optim_rows(kp.p, kp, P.st, &ok));
+    capi_prof_end(P.st);
+    if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no optim kernel for p=%d", P.p);
+    return DSQ_OK;
+}
+
 // estimateDispersionsGeneEst on the rows `rw` of the count matrix y (R/core.R:657-860, niter = 1); mu-hat -> mu_hat
 static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, int cnt_grid, int cnt_optim,
                     int32_t *optim_flag) {
@@ -596,6 +663,9 @@ static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, i
         b.betaMaxit = 100;
         b.optim_flag = optim_flag; b.optim_count = P.counters + cnt_optim;
         hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+        // rows the IRLS left: the fallback's fitted means (floored at minmu, :763) replace theirs before the search
+        rc = launch_optim(P, cnt_optim, y, P.alpha_init, a->weights_norm, 0.5, 0.5, P.opt_beta, P.opt_se, P.opt_ll, mu_hat);
+        if (rc) return rc;
     }
     rc = launch_fit_disp(P, rw, y, mu_hat, P.la0, P.la0, false, a->weights_floor, a->useCR != 0, false, "fit_disp");
     if (rc) return rc;
@@ -646,7 +716,48 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
     b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
-    if (a->test == 1) {
+    // rows for the optim fallback (R/fitNbinomGLMs.R:203-227): coefficients, standard errors, logLike (:398-399) and
+    // fitted means (:386) of those rows in place, then betaConv and the Wald columns from them
+    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->beta, o->betaSE, o->logLike, mu_out);
+    if (rc) return rc;
+    {
+        const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
+        RuleParams ob = rule_params(P, orw);
+        ob.beta = o->beta; ob.betaSE = o->betaSE; ob.stat = o->stat; ob.pvalue = o->pvalue; ob.wald = b.wald;
+        ob.betaConv = o->betaConv;
+        hipLaunchKernelGGL(optim_post_kernel, dim3(16), dim3(256), 0, P.st, ob);
+    }
+    if (a->test == 1 && a->x_red) {
+        // nbinomLRT's reduced fit (R/core.R:1856-1868): fitNbinomGLMs on the reduced model matrix at the same
+        // dispersions -- QR start values, IRLS, logLik at its fitted means, its own optim-fallback rows
+        PrefitKernelParams pk;
+        memset(&pk, 0, sizeof pk);
+        pk.n = P.n; pk.m = P.m; pk.p = a->p_red; pk.ld = P.ld; pk.y = y; pk.nf = a->nf; pk.nf_is_vector = a->nf_is_vector;
+        pk.q = a->q_red; pk.a = a->a_red; pk.r = a->r_red;
+        pk.baseMean = P.cnum; pk.baseVar = P.cden; pk.roughDisp = P.dev; pk.allZero = P.opt_conv;      // (not read)
+        pk.beta_init = P.red_binit;
+        pk.rows = rw.rows; pk.n_dev = rw.n_dev;
+        bool ok = false;
+        capi_prof_begin(P.tag[0] ? "prefit_reduced:refit" : "prefit_reduced", P.n, P.st);
+        PIPE_HIP(launch_prefit(pk, P.st, &ok));
+        capi_prof_end(P.st);
+        if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: reduced design with p=%d", a->p_red);
+        rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, a->betaTol, a->betaMaxit, a->useQR,
+                             a->minmu, "fit_beta_reduced", true);
+        if (rc) return rc;
+        lk.mu = P.red_mu; lk.loglike = o->logLikeReduced;
+        capi_prof_begin(P.tag[0] ? "nbinom_loglike_red:refit" : "nbinom_loglike_red", P.n, P.st);
+        PIPE_HIP(launch_loglike(lk, P.st));
+        capi_prof_end(P.st);
+        const int cnt3 = P.tag[0] ? CNT_OPT3R : CNT_OPT3;
+        RuleParams rb = rule_params(P, rw);
+        rb.p = a->p_red; rb.beta_init = P.red_binit;
+        rb.optim_flag = P.grid_flag; rb.optim_count = P.counters + cnt3;      // (the grid flags are free between the searches)
+        hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, rb);
+        rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, a->minmu, 0.0, P.red_beta, P.red_se, o->logLikeReduced,
+                          P.red_mu, true);
+        if (rc) return rc;
+    } else if (a->test == 1) {
         InterceptKernelParams ik;
         memset(&ik, 0, sizeof ik);
         ik.n = P.n; ik.m = P.m; ik.ld = P.ld; ik.y = y; ik.nf = a->nf; ik.nf_is_vector = a->nf_is_vector;
@@ -665,8 +776,8 @@ static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 struct Carve {
     size_t o_rough, o_binit, o_ainit, o_la0, o_laout, o_lchg, o_ilp, o_idlp, o_llp, o_ldlp, o_lagrid, o_ldfit, o_lainit,
-        o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, dbl;
-    size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, ints;
+        o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, o_ostart, o_obeta, o_ose, o_oll, o_rbinit, o_rbeta, o_rse, dbl;
+    size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, i_opt, i_oconv, ints;
     size_t bytes;
 };
 
@@ -680,11 +791,14 @@ static Carve carve(int n, int p, int nt) {
     c.o_lagrid = takeD(nd); c.o_ldfit = takeD(nd); c.o_lainit = takeD(nd); c.o_bnat = takeD(np_); c.o_bvar = takeD(np_);
     c.o_biter = takeD(nd); c.o_cnum = takeD(nd); c.o_cden = takeD(nd); c.o_dev = takeD(nd); c.o_lam = takeD(2 * (size_t)p + 8);
     c.o_res = takeD(ntd); c.o_tm = takeD(ntd); c.o_td = takeD(ntd); c.o_robust = takeD(nd);
+    c.o_ostart = takeD(np_); c.o_obeta = takeD(np_); c.o_ose = takeD(np_); c.o_oll = takeD(nd);
+    c.o_rbinit = takeD(np_); c.o_rbeta = takeD(np_); c.o_rse = takeD(np_);
     c.dbl = d;
     size_t i = 0;
     auto takeI = [&](size_t k) { size_t off = i; i += align8(k); return off; };
     c.i_iter = takeI(nd); c.i_itacc = takeI(nd); c.i_gflag = takeI(nd); c.i_nz = takeI(nd); c.i_grid = takeI(nd);
     c.i_rep = takeI(nd); c.i_refit = takeI(nd); c.i_cnt = takeI(16); c.i_wc = takeI(64);
+    c.i_opt = takeI(nd); c.i_oconv = takeI(nd);
     c.ints = i;
     c.bytes = d * sizeof(double) + i * sizeof(int32_t) + 256;
     return c;
@@ -702,7 +816,9 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     if (!a->y || !a->nf || !a->x || !a->q || !a->a || !a->r || !a->disp_grid || a->ngrid < 2 || !a->lambda) return capi_fail(DSQ_ERR_ARG, "NULL input");
     if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
-    if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT vs ~1)");
+    if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
+    if (a->x_red && (a->test != 1 || !a->q_red || !a->a_red || !a->r_red || a->p_red < 1 || a->p_red >= a->p))
+        return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with its QR factors and 1 <= p_red < p");
     if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
         !o->dispersion || !o->dispIter || !o->dispOutlier || !o->beta || !o->betaSE || !o->betaConv || !o->betaIter ||
         !o->logLike || !o->maxCooks || !o->replace || !o->optim_geneest || !o->optim_test || !o->mu_hat || !o->mu || !o->H ||
@@ -738,9 +854,18 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
     P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = I + cv.i_cnt;
     P.work_counters = I + cv.i_wc;
+    P.opt_start = D + cv.o_ostart; P.opt_beta = D + cv.o_obeta; P.opt_se = D + cv.o_ose; P.opt_ll = D + cv.o_oll;
+    P.rows_opt = I + cv.i_opt; P.opt_conv = I + cv.i_oconv;
+    P.red_binit = D + cv.o_rbinit; P.red_beta = D + cv.o_rbeta; P.red_se = D + cv.o_rse;
     {
         size_t slab_d = 0, cscr_d = 0;
         dispatch_beta_scratch(p, n, m, a->useWeights, &slab_d, &cscr_d);
+        if (a->x_red) {
+            size_t s2 = 0, c2 = 0;
+            dispatch_beta_scratch(a->p_red, n, m, a->useWeights, &s2, &c2);
+            if (s2 > slab_d) slab_d = s2;
+            if (c2 > cscr_d) cscr_d = c2;
+        }
         void *b;
         rc = capi_ws_get(DSQ_WS_PIPE_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b);
         if (rc) return rc;
@@ -756,6 +881,14 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
     if (a->cell_of && a->ncell > 0)
         P.ncell = capi_upload_cells(a->cell_of, m, DSQ_WS_PIPE_META + 2, st, &P.cell_perm, &P.cell_start);
+    if (a->x_red) {
+        if (a->cell_of_red && a->ncell_red > 0)
+            P.red_ncell = capi_upload_cells(a->cell_of_red, m, DSQ_WS_PIPE_META + 3, st, &P.red_cell_perm, &P.red_cell_start);
+        void *b;        // the reduced fit's fitted means: read once by its logLik
+        rc = capi_ws_get(DSQ_WS_PIPE_META + 4, (size_t)n * P.ld * sizeof(double), &b);
+        if (rc) return rc;
+        P.red_mu = (double *)b;
+    }
 
     // ================================================================ gene-wise estimates
     if (a->phases & DSQ_PH_GENE_EST) {
@@ -806,6 +939,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     if (a->phases & DSQ_PH_MAP_TEST) {
         PIPE_HIP(hipMemsetAsync(P.counters + CNT_GRID2, 0, sizeof(int32_t), st));
         PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT2, 0, sizeof(int32_t), st));
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT3, 0, sizeof(int32_t), st));
         rc = map_est(P, nz, a->y, o->mu_hat, CNT_GRID2);
         if (rc) return rc;
         rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
@@ -915,6 +1049,9 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         PIPE_HIP(hipMemcpyAsync(o->status + kv[1], P.counters + kv[0], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return DSQ_OK;
 }
+
+// (deseq_host.hip: the host-pointer entry drives the same chain from its per-device worker threads, under the call lock)
+int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) { return run(a, o, st); }
 
 }  // namespace dsq
 

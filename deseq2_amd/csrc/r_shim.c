@@ -16,6 +16,7 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 #include <R_ext/Utils.h>
+#include <string.h>
 #include "deseq2_mi355x.h"
 
 static void chk(int rc) {
@@ -246,6 +247,101 @@ SEXP _DESeq2_mi355x_replace(SEXP ySEXP, SEXP nfSEXP, SEXP cooksSEXP, SEXP cutoff
     return out;
 }
 
+/* ---- DESeq() behind ONE call (dsq_deseq): what the patch of R/core.R:388-426 in INTEGRATION.md section 4 calls in place
+ * of estimateDispersions -> nbinomWaldTest / nbinomLRT -> refitWithoutOutliers.  Arguments: counts(object) (integer
+ * matrix), the model matrix, sizeFactors(object), qr.Q(qrx), qr.R(qrx) (qrx <- qr(modelMatrix), R/fitNbinomGLMs.R:139-143),
+ * test (0 Wald / 1 LRT), the reduced model matrix with its qr.Q / qr.R (NULL, or one column: reduced = ~1),
+ * minReplicatesForReplace, qf(.99, p, m - p) (R/core.R:2081),
+ * trigamma((m - p) / 2) (:1196), betaTol, maxit, useQR, minmu, the dispersion searches' maxit, useCR, and which n x m
+ * assays to bring back (a character-free bit mask: 1 mu, 2 H, 4 cooks, 8 replaceCounts).
+ * Returns NULL when the library declines the analysis (DSQ_ERR_UNSUPPORTED: betaPrior-free chain only, p <= 10,
+ * m - p > 3; DSQ_ERR_FIT: the parametric trend failed / no usable gene) -- the R caller then runs its unchanged code
+ * path over the three classic routines; any other failure is an R error. ---------------------------------------- */
+static SEXP int_col(const int *v, int n, int type, int *np) {      /* -1 -> NA */
+    SEXP s = PROTECT(Rf_allocVector(type, n)); (*np)++;
+    int *d = (type == LGLSXP) ? LOGICAL(s) : INTEGER(s);
+    for (int i = 0; i < n; i++) d[i] = (v[i] < 0) ? R_NaInt : v[i];
+    return s;
+}
+static void nan_to_na(SEXP s) {
+    double *d = REAL(s);
+    int k = Rf_length(s);
+    for (int i = 0; i < k; i++) if (ISNAN(d[i])) d[i] = NA_REAL;
+}
+
+SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEXP qSEXP, SEXP rSEXP, SEXP testSEXP,
+                          SEXP xRedSEXP, SEXP qRedSEXP, SEXP rRedSEXP, SEXP minReplicatesSEXP, SEXP cooksCutoffSEXP, SEXP expVarLogDispSEXP, SEXP betaTolSEXP,
+                          SEXP maxitSEXP, SEXP useQRSEXP, SEXP minmuSEXP, SEXP dispMaxitSEXP, SEXP useCRSEXP,
+                          SEXP assaysSEXP) {
+    int np = 0;
+    R_CheckUserInterrupt();
+    int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
+    need_matrix(xSEXP, m, p, "modelMatrix"); need_matrix(qSEXP, m, p, "qr.Q"); need_matrix(rSEXP, p, p, "qr.R");
+    need_length(sizeFactorsSEXP, m, "sizeFactors");
+    SEXP x = as_real(xSEXP, &np), sf = as_real(sizeFactorsSEXP, &np), q = as_real(qSEXP, &np), r = as_real(rSEXP, &np);
+    const int want = scalar_i(assaysSEXP), wald = scalar_i(testSEXP) == 0;
+    DsqDeseqHostArgs a = {0};
+    a.n = n; a.m = m; a.p = p;
+    a.counts = counts_ptr(countsSEXP, &a.y_type);
+    a.x = REAL(x); a.sizeFactors = REAL(sf); a.q = REAL(q); a.r = REAL(r); a.xrinv = NULL;
+    a.test = wald ? 0 : 1;
+    if (!wald && xRedSEXP != R_NilValue && !(Rf_ncols(xRedSEXP) == 1)) {       /* reduced = ~1: the closed form */
+        int pr = Rf_ncols(xRedSEXP);
+        need_matrix(xRedSEXP, m, pr, "reduced model matrix"); need_matrix(qRedSEXP, m, pr, "qr.Q(reduced)");
+        need_matrix(rRedSEXP, pr, pr, "qr.R(reduced)");
+        SEXP xr = as_real(xRedSEXP, &np), qr = as_real(qRedSEXP, &np), rr = as_real(rRedSEXP, &np);
+        a.x_reduced = REAL(xr); a.q_reduced = REAL(qr); a.r_reduced = REAL(rr); a.p_reduced = pr;
+    }
+    a.minReplicatesForReplace = scalar_d(minReplicatesSEXP);
+    a.cooksCutoff = scalar_d(cooksCutoffSEXP); a.expVarLogDisp = scalar_d(expVarLogDispSEXP);
+    a.betaTol = scalar_d(betaTolSEXP); a.maxit = scalar_i(maxitSEXP); a.useQR = scalar_b(useQRSEXP);
+    a.minmu = scalar_d(minmuSEXP); a.disp_maxit = scalar_i(dispMaxitSEXP); a.useCR = scalar_b(useCRSEXP);
+    /* double columns straight into fresh R vectors; integer columns through scratch (NA_integer_ / NA for -1) */
+    enum { BM, BV, DGE, DFIT, DMAP, DISP, BITER, LL, LLR, MAXC, NDBL };
+    SEXP dv[NDBL];
+    for (int k = 0; k < NDBL; k++) { dv[k] = PROTECT(Rf_allocVector(REALSXP, n)); np++; }
+    SEXP beta = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
+    SEXP se = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
+    SEXP stat = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
+    SEXP pval = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
+    int *iv = (int *)R_alloc((size_t)6 * n, sizeof(int));
+    SEXP mu = R_NilValue, H = R_NilValue, ck = R_NilValue, rc = R_NilValue;
+    if (want & 1) { mu = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
+    if (want & 2) { H = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
+    if (want & 4) { ck = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
+    if (want & 8) { rc = PROTECT(Rf_allocMatrix(INTSXP, n, m)); np++; }
+    DsqDeseqHostOut o;
+    memset(&o, 0, sizeof o);
+    o.baseMean = REAL(dv[BM]); o.baseVar = REAL(dv[BV]); o.dispGeneEst = REAL(dv[DGE]); o.dispFit = REAL(dv[DFIT]);
+    o.dispMAP = REAL(dv[DMAP]); o.dispersion = REAL(dv[DISP]); o.betaIter = REAL(dv[BITER]); o.logLike = REAL(dv[LL]);
+    o.logLikeReduced = wald ? NULL : REAL(dv[LLR]); o.maxCooks = REAL(dv[MAXC]);
+    o.beta = REAL(beta); o.betaSE = REAL(se); o.stat = wald ? REAL(stat) : NULL; o.pvalue = wald ? REAL(pval) : NULL;
+    o.allZero = iv; o.dispGeneIter = iv + n; o.dispIter = iv + 2 * (size_t)n; o.dispOutlier = iv + 3 * (size_t)n;
+    o.betaConv = iv + 4 * (size_t)n; o.replace = iv + 5 * (size_t)n;
+    if (want & 1) o.mu = REAL(mu);
+    if (want & 2) o.H = REAL(H);
+    if (want & 4) o.cooks = REAL(ck);
+    if (want & 8) o.replaceCounts = INTEGER(rc);
+    int status = dsq_deseq(&a, &o);
+    if (status == DSQ_ERR_UNSUPPORTED || status == DSQ_ERR_FIT) { UNPROTECT(np); return R_NilValue; }
+    chk(status);
+    for (int k = 0; k < NDBL; k++) nan_to_na(dv[k]);
+    nan_to_na(beta); nan_to_na(se); nan_to_na(stat); nan_to_na(pval);
+    SEXP fn = PROTECT(Rf_allocVector(REALSXP, 4)); np++;
+    for (int k = 0; k < 4; k++) REAL(fn)[k] = o.dispersionFunction[k];
+    const char *names[] = {"baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP",
+                           "dispersion", "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv",
+                           "betaIter", "logLike", "logLikeReduced", "maxCooks", "replace", "mu", "H", "cooks",
+                           "replaceCounts", "dispersionFunction"};
+    SEXP vals[] = {dv[BM], dv[BV], int_col(o.allZero, n, LGLSXP, &np), dv[DGE], int_col(o.dispGeneIter, n, INTSXP, &np),
+                   dv[DFIT], dv[DMAP], dv[DISP], int_col(o.dispIter, n, INTSXP, &np), int_col(o.dispOutlier, n, LGLSXP, &np),
+                   beta, se, stat, pval, int_col(o.betaConv, n, LGLSXP, &np), dv[BITER], dv[LL], dv[LLR], dv[MAXC],
+                   int_col(o.replace, n, LGLSXP, &np), mu, H, ck, rc, fn};
+    SEXP out = named_list(25, names, vals);
+    UNPROTECT(np);
+    return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_fitDisp", (DL_FUNC)&_DESeq2_fitDisp, 15},
     {"_DESeq2_fitBeta", (DL_FUNC)&_DESeq2_fitBeta, 13},
@@ -253,6 +349,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 19},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

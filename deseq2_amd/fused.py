@@ -3,13 +3,12 @@
 core.DESeq() mirrors the reference's R callers one call at a time: every decision rule between two native calls
 is host code on n-vectors, i.e. a device round trip.  Here the same rules run as kernels and the rows a rule sends
 on (fitDispGrid stragglers, replaced-outlier rows) are compacted on the device, so a whole phase is enqueued
-without a host decision.  The host looks at the device TWICE per analysis (after the test statistics, after the
-outlier refit): a few counters tell it whether any row needs the reference's host-side fallback (the L-BFGS-B
-rows of fitNbinomGLMsOptim, R/fitNbinomGLMs.R:340-407) -- those rows, and only those, are re-done through the
-call-by-call code of core.py on a row subset.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
+without a host decision -- including the rows that go to the reference's host-side fallback (fitNbinomGLMsOptim,
+R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
+the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 10, fitType = "parametric", betaPrior = FALSE, test = "Wald" or "LRT" against ~1,
-niter = 1.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
+Supported: DeviceEngine, p <= 10, fitType = "parametric", betaPrior = FALSE, test = "Wald" or "LRT" (any full-rank
+reduced model matrix), niter = 1, more than 3 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
 import ctypes as C
 
@@ -41,12 +40,20 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
                   "minReplicatesForReplace"}:
         return False
     if test == "LRT":
-        r = None if reduced is None else np.asarray(reduced)
-        if r is None or r.shape[1] != 1 or not (r == 1).all():
+        # reduced = ~1 takes the closed form (R/fitNbinomGLMs.R:99-137); any other reduced model matrix is fitted by the
+        # IRLS like the full one -- full rank (the rank-deficient start values of :146-155 are left to core.py)
+        r = None if reduced is None else np.asarray(reduced, np.float64)
+        if r is None or r.ndim != 2 or r.shape[0] != dds.m or not (1 <= r.shape[1] < dds.p):
+            return False
+        if not (np.abs(r).sum(axis=0) > 0).all() or (not _intercept_only(r) and core._rank(r) < r.shape[1]):
             return False
     elif test != "Wald":
         return False
     return True
+
+
+def _intercept_only(r):
+    return r.shape[1] == 1 and bool((r == 1).all())
 
 
 def _ptr(t):
@@ -82,7 +89,7 @@ def _design_facts(E, x, minReplicatesForReplace):
 class _Run:
     """buffers + argument block of one analysis"""
 
-    def __init__(self, dds, test, minReplicatesForReplace, n_trend, kw):
+    def __init__(self, dds, test, minReplicatesForReplace, n_trend, kw, reduced=None):
         E = dds.engine
         t = self.t = E.torch
         self.dds, self.E = dds, E
@@ -129,7 +136,7 @@ class _Run:
         grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 20)                    # R/wrappers.R:70-72
         self.grid = E._vec(grid)
         self.lam = np.ascontiguousarray(np.full(p, 1e-6) / np.log(2) ** 2)          # R/fitNbinomGLMs.R:73,162
-        xim = float(np.mean(1.0 / dds.sizeFactors)) if dds.sizeFactors is not None else E.xim(dds.nf)
+        xim = core.xim_size_factors(dds.sizeFactors) if dds.sizeFactors is not None else E.xim(dds.nf)
         facts = _design_facts(E, x, minReplicatesForReplace)
         cells = facts["cells"]
         self.cells = cells
@@ -163,6 +170,18 @@ class _Run:
             ncell=int(cells.max()) + 1, replaceable=self.replaceable.ctypes.data_as(C.c_void_p), cooksCutoff=cutoff,
             trim=0.2, do_replace=int(do_replace))
         self.cooksCutoff = cutoff
+        self.p_red = 1
+        if test == "LRT" and reduced is not None and not _intercept_only(np.asarray(reduced, np.float64)):
+            red = np.ascontiguousarray(reduced, dtype=np.float64)
+            xr = E.design(red)
+            rq, ra, rr = E._design_qr_dev(red)
+            self.red_cells = np.ascontiguousarray(E.native.cell_index(red), dtype=np.int32)
+            self.keep += [xr, rq, ra, rr]
+            self.p_red = red.shape[1]
+            self.args.x_red, self.args.q_red, self.args.a_red, self.args.r_red = _ptr(xr), _ptr(rq), _ptr(ra), _ptr(rr)
+            self.args.p_red = int(self.p_red)
+            self.args.cell_of_red = self.red_cells.ctypes.data_as(C.c_void_p)
+            self.args.ncell_red = int(self.red_cells.max()) + 1
         self.out = L.DsqDeseqOut(
             baseMean=_ptr(self.baseMean), baseVar=_ptr(self.baseVar), allZero=_ptr(self.allZero),
             dispGeneEst=_ptr(self.dispGeneEst), dispGeneIter=_ptr(self.dispGeneIter), dispFit=_ptr(self.dispFit),
@@ -211,90 +230,6 @@ class _Run:
         return st, sc
 
 
-def _rows_where(run, flag_tensor, extra=None):
-    t = run.t
-    f = flag_tensor != 0
-    if extra is not None:
-        f = f & extra
-    return run.E._host(f.nonzero().squeeze(1)).numpy()
-
-
-def _patch_gene_est(run, rows, kw):
-    """rows the gene-wise GLM fit left to the optim fallback: estimateDispersionsGeneEst of core.py on that subset
-    (genes are independent), written over the pipeline's dispGeneEst / dispGeneIter / mu-hat rows"""
-    dds, E, t = run.dds, run.E, run.t
-    sub = dds.subset(rows)
-    core.estimateDispersionsGeneEst(sub, maxit=kw.get("disp_maxit", 100))
-    ii = t.as_tensor(rows, device=E.device)
-    run.dispGeneEst[ii] = t.as_tensor(sub.mcols["dispGeneEst"], device=E.device)
-    run.dispGeneIter[ii] = t.as_tensor(np.asarray(sub.mcols["dispGeneIter"], np.int32), device=E.device)
-    run.mu_hat[ii] = sub.assays["mu"].t
-
-
-def _test_subset(run, sub, reduced, kw):
-    """nbinomWaldTest / nbinomLRT fits of core.py on a subset whose mcols dispersion is set; returns the columns the
-    pipeline keeps"""
-    tk = {k: v for k, v in kw.items() if k in ("betaTol", "maxit", "useQR", "minmu")}
-    E = sub.engine
-    weights, useWeights = core.getAndCheckWeights(sub)
-    fit = core.fitNbinomGLMs(sub, weights=weights, useWeights=useWeights, want_loglike=True, **tk)
-    out = {"beta": fit["betaMatrix"], "betaSE": fit["betaSE"], "betaConv": fit["betaConv"], "betaIter": fit["betaIter"],
-           "logLike": fit["logLike"], "mu": fit["mu"]}
-    if run.test == "Wald":
-        with np.errstate(divide="ignore", invalid="ignore"):
-            out["stat"] = fit["betaMatrix"] / fit["betaSE"]
-        out["pvalue"] = E.two_sided_normal_p(out["stat"])
-    else:
-        red = core.fitNbinomGLMs(sub, modelMatrix=reduced, weights=weights, useWeights=useWeights, want_hat=False,
-                                 want_loglike=True, **tk)
-        out["logLikeReduced"] = red["logLike"]
-    return out
-
-
-def _write_test_rows(run, rows, o, write_mu=True):
-    E, t = run.E, run.t
-    ii = t.as_tensor(rows, device=E.device)
-    dv = lambda a: t.as_tensor(np.ascontiguousarray(a), device=E.device)     # noqa: E731
-    run.mat[0][:, ii] = dv(np.asarray(o["beta"]).T)
-    run.mat[1][:, ii] = dv(np.asarray(o["betaSE"]).T)
-    if run.test == "Wald":
-        run.mat[2][:, ii] = dv(np.asarray(o["stat"]).T)
-        run.mat[3][:, ii] = dv(np.asarray(o["pvalue"]).T)
-    else:
-        run.logLikeReduced[ii] = dv(o["logLikeReduced"])
-    run.betaConv[ii] = dv(np.asarray(o["betaConv"]).astype(np.int32))
-    run.betaIter[ii] = dv(np.asarray(o["betaIter"], np.float64))
-    run.logLike[ii] = dv(o["logLike"])
-    if write_mu:
-        run.mu[ii] = o["mu"].t
-
-
-def _patch_test(run, rows, reduced, kw):
-    """rows of the final GLM fit that go to the optim fallback (R/fitNbinomGLMs.R:203-227)"""
-    sub = run.dds.subset(rows)
-    sub.mcols["dispersion"] = run.E._host(run.dispersion[run.t.as_tensor(rows, device=run.E.device)]).numpy()
-    _write_test_rows(run, rows, _test_subset(run, sub, reduced, kw))
-
-
-def _patch_refit(run, rows, reduced, kw, fn):
-    """replaced-outlier rows whose refit needs the optim fallback: the refit of core.refitWithoutOutliers on them"""
-    E, t = run.E, run.t
-    dds = run.dds
-    sub = dds.subset(rows, run.E.native.GeneMajor(run.replaceCounts, dds.m))
-    core.estimateDispersionsGeneEst(sub, maxit=kw.get("disp_maxit", 100))
-    sub.dispersionFunction = dict(fn)
-    sub.mcols["dispFit"] = fn["coefficients"][0] + fn["coefficients"][1] / sub.mcols["baseMean"]
-    core.estimateDispersionsMAP(sub, dispPriorVar=fn["dispPriorVar"], maxit=kw.get("disp_maxit", 100))
-    ii = t.as_tensor(rows, device=E.device)
-    dv = lambda a: t.as_tensor(np.ascontiguousarray(a), device=E.device)     # noqa: E731
-    for k, dst in (("dispGeneEst", run.dispGeneEst), ("dispFit", run.dispFit), ("dispMAP", run.dispMAP),
-                   ("dispersion", run.dispersion)):
-        dst[ii] = dv(sub.mcols[k])
-    for k, dst in (("dispGeneIter", run.dispGeneIter), ("dispIter", run.dispIter), ("dispOutlier", run.dispOutlier)):
-        dst[ii] = dv(np.asarray(sub.mcols[k]).astype(np.int32))
-    _write_test_rows(run, rows, _test_subset(run, sub, reduced, kw), write_mu=False)
-
-
 def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None, **kw):
     """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
     chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
@@ -315,27 +250,20 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     if world > 1:
         sizes = parallel.allgather_sizes(n, comm_device)
         n_all = int(max(sizes)) * world
-    run = _Run(dds, test, minReplicatesForReplace, n_all if world > 1 else 0, kw)
+    run = _Run(dds, test, minReplicatesForReplace, n_all if world > 1 else 0, kw, reduced=reduced)
 
-    def fallback(why):
-        raise RuntimeError(why)
-
-    trend = None
+    # Everything is enqueued without a host decision: the rows a rule sends on -- fitDispGrid stragglers, rows for the
+    # optim fallback (R/fitNbinomGLMs.R:203-227), replaced-outlier rows -- are row-listed launches whose lengths live
+    # on the device.  ONE look at the counters at the end (multi-GPU: one more before the all-gather of the trend's
+    # input vectors).
     if world == 1:
-        run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
-        st, sc = run.read_status()
-        if st["N_OPTIM_GENEEST"] > 0:
-            _patch_gene_est(run, _rows_where(run, run.optim_geneest), kw)
-            run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
-            st, sc = run.read_status()
+        run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     else:
         run.launch(L.DSQ_PH_GENE_EST)
-        st, sc = run.read_status()
-        if st["N_OPTIM_GENEEST"] > 0:
-            _patch_gene_est(run, _rows_where(run, run.optim_geneest), kw)
         trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
-        run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST, trend=trend)
-        st, sc = run.read_status()
+        run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS, trend=trend)
+    st, sc = run.read_status()
+    st2 = st
     # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
     # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
     nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
@@ -352,16 +280,6 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
                           minReplicatesForReplace=minReplicatesForReplace, **kw)
     fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
           "dispPriorVar": float(sc[3])}
-    if st["N_OPTIM_TEST"] > 0:
-        _patch_test(run, _rows_where(run, run.optim_test), reduced, kw)
-    run.launch(L.DSQ_PH_OUTLIERS)
-    # ---- results: one packed copy
-    st2, _ = run.read_status()
-    if run.do_replace and (st2["N_OPTIM_GENEEST_REFIT"] > 0 or st2["N_OPTIM_TEST_REFIT"] > 0):
-        refit = (run.replace != 0) & (run.allZero == 0)
-        rows = _rows_where(run, (run.optim_geneest != 0) | (run.optim_test != 0), refit)
-        if rows.size:
-            _patch_refit(run, rows, reduced, kw, fn)
     hv = E._host(run.vec).numpy()
     hm = E._host(run.mat).numpy()
     hi = E._host(run.ivec).numpy()
@@ -393,7 +311,7 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     else:
         from scipy.stats import chi2
         stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878
-        mc.update(LRTStatistic=stat, LRTPvalue=chi2.sf(stat, df=dds.p - 1),
+        mc.update(LRTStatistic=stat, LRTPvalue=chi2.sf(stat, df=dds.p - run.p_red),
                   fullBetaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
     if run.do_replace:
         mc["replace"] = icol(hi[5], True)

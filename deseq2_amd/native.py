@@ -257,6 +257,73 @@ def optimRows(counts, x, nf, alpha, lam, weights, useWeights, beta_start, minmu=
     return {"beta": beta, "betaSE": se, "conv": conv.astype(bool), "mu": mu, "logLike": ll}
 
 
+def DESeq(counts, x, sizeFactors, test="Wald", reduced=None, minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
+          minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks")):
+    """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
+    in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
+    design-only quantities the R caller computes with qr() / qf() / trigamma() come from numpy / scipy here.  Returns the
+    per-gene columns (NA = NaN; integer columns as float64 with NaN), the requested n x m assays, the dispersion
+    function and the status counters."""
+    from scipy import special as sps
+    from scipy.stats import f as fdist
+    y, ytype = _counts(counts)
+    x = _fcol(x)
+    n, m = y.shape
+    p = x.shape[1]
+    sf = np.ascontiguousarray(sizeFactors, dtype=np.float64)
+    q, a, r = design_qr(x)
+    if m - p > 0:
+        cutoff, evld = float(fdist.ppf(.99, p, m - p)), float(sps.polygamma(1, (m - p) / 2.0))
+    else:
+        cutoff, evld = 1.0, 1.0           # (the library rejects m <= p itself)
+    wald = test == "Wald"
+    if not wald and test != "LRT":
+        raise ValueError("test should be either 'Wald' or 'LRT'")
+    grid = np.ascontiguousarray(np.linspace(np.log(1e-8), np.log(max(10, m)), 20))          # R/wrappers.R:70-72
+    xr = qr_ = rr_ = None
+    p_red = 0
+    if not wald and reduced is not None:
+        red = _fcol(reduced)
+        if not (red.shape[1] == 1 and (red == 1).all()):
+            xr, p_red = red, red.shape[1]
+            qr_, _, rr_ = design_qr(red)
+    f64 = lambda *sh: np.full(sh, np.nan, order="F")                    # noqa: E731
+    i32 = lambda: np.full(n, -1, dtype=np.int32)                         # noqa: E731
+    d = {k: f64(n) for k in ("baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "betaIter",
+                             "logLike", "maxCooks")}
+    d.update({k: i32() for k in ("allZero", "dispGeneIter", "dispIter", "dispOutlier", "betaConv", "replace")})
+    d.update(beta=f64(n, p), betaSE=f64(n, p))
+    if wald:
+        d.update(stat=f64(n, p), pvalue=f64(n, p))
+    else:
+        d["logLikeReduced"] = f64(n)
+    for k in assays:
+        d[k] = np.zeros((n, m), order="F", dtype=np.int32 if k == "replaceCounts" else np.float64)
+    args = L.DsqDeseqHostArgs(
+        n=n, m=m, p=p, counts=_ptr(y), y_type=ytype, x=_ptr(x), sizeFactors=_ptr(sf), q=_ptr(q), r=_ptr(r), xrinv=_ptr(a),
+        test=0 if wald else 1, x_reduced=_ptr(xr), q_reduced=_ptr(qr_), r_reduced=_ptr(rr_), p_reduced=int(p_red),
+        minReplicatesForReplace=float(minReplicatesForReplace), cooksCutoff=cutoff,
+        expVarLogDisp=evld, betaTol=float(betaTol), minmu=float(minmu), maxit=int(maxit), useQR=int(bool(useQR)),
+        disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size))
+    out = L.DsqDeseqHostOut(**{k: _ptr(v) for k, v in d.items()})
+    L.check(L.lib().dsq_deseq(C.byref(args), C.byref(out)))
+    res = {}
+    for k, v in d.items():
+        if v.dtype == np.int32 and k != "replaceCounts":
+            f = v.astype(np.float64)
+            f[v < 0] = np.nan
+            res[k] = f
+        else:
+            res[k] = v
+    res["dispersionFunction"] = {"fitType": "parametric", "coefficients": np.array(out.dispersionFunction[0:2]),
+                                 "varLogDispEsts": float(out.dispersionFunction[2]),
+                                 "dispPriorVar": float(out.dispersionFunction[3])}
+    res["status"] = {k: int(out.status[i]) for k, i in L.DSQ_ST.items()}
+    res["cooksCutoff"] = cutoff
+    res["df"] = p - (p_red if p_red else 1)
+    return res
+
+
 _CELL_CACHE = {}
 
 

@@ -49,7 +49,10 @@ enum {
     DSQ_ERR_UNSUPPORTED = 2, /* p or m outside the compiled kernel range                  */
     DSQ_ERR_DEVICE = 3,      /* no gfx950 device, HIP runtime error, kernel launch error  */
     DSQ_ERR_NOMEM = 4,       /* device or host allocation failed                          */
-    DSQ_ERR_VALUE = 5        /* non-integer / negative count in a REALSXP count matrix    */
+    DSQ_ERR_VALUE = 5,       /* non-integer / negative count in a REALSXP count matrix    */
+    DSQ_ERR_FIT = 6          /* dsq_deseq: a condition the reference turns into an R error or a change of method
+                                (all rows zero; no gene above 100 * minDisp; the parametric dispersion trend failed,
+                                R/core.R:885-893) -- the caller falls back to the call-by-call routines          */
 };
 
 enum { DSQ_LAYOUT_R = 0, DSQ_LAYOUT_GENE_MAJOR = 1 };
@@ -402,7 +405,7 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
  *   DSQ_PH_GENE_EST   counts -> baseMean .. dispGeneEst, mu-hat
  *   DSQ_PH_TREND      parametric trend + prior variance over (trend_mean, trend_disp) [n_trend on the device] or,
  *                     when those are NULL, over this call's own genes (multi-GPU: the gathered vectors)
- *   DSQ_PH_MAP_TEST   dispFit, MAP dispersions, final GLM fit, Wald / LRT statistics
+ *   DSQ_PH_MAP_TEST   dispFit, MAP dispersions, final GLM fit [+ the reduced-model fit], Wald statistics / logLik pair
  *   DSQ_PH_OUTLIERS   Cook's distances, replaceOutliers, refit of the replaced rows, maxCooks
  * status[] (int32, device): see DSQ_ST_*; scalars[] (double, device): see DSQ_SC_*.                            */
 #define DSQ_PH_GENE_EST 1
@@ -444,13 +447,19 @@ typedef struct {
     void *workspace;               /* device, dsq_deseq_workspace_bytes(...): holds the row lists and counters of
                                       the analysis between phases -- the same buffer for all its phases           */
     int64_t workspace_bytes;
-    int32_t test;                  /* 0 Wald, 1 LRT with reduced = ~1                                            */
+    int32_t test;                  /* 0 Wald, 1 LRT (reduced = ~1 unless x_red is given)                         */
     /* outlier phase (all host arrays; R/core.R:2081,2101,2366-2371) */
     const int32_t *cell_of;        /* HOST: design cell of each sample                                           */
     int32_t ncell;
     const int32_t *replaceable;    /* HOST: m flags nOrMoreInCell(x, minReplicatesForReplace)                    */
     double cooksCutoff, trim;
     int32_t do_replace;            /* 0: Cook's distances only                                                   */
+    /* nbinomLRT against a reduced model that is not ~1 (R/core.R:1856-1868): its m x p_red model matrix, the thin QR
+     * of it (start values, R/fitNbinomGLMs.R:139-145) and its design cells; all NULL / 0 = the intercept-only closed form */
+    const double *x_red, *q_red, *a_red, *r_red;   /* device, column-major                                      */
+    int32_t p_red;
+    const int32_t *cell_of_red;    /* HOST                                                                       */
+    int32_t ncell_red;
 } DsqDeseqArgs;
 
 typedef struct {
@@ -476,6 +485,66 @@ typedef struct {
 
 int dsq_deseq_dev(const DsqDeseqArgs *args, const DsqDeseqOut *out, void *stream);
 int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_trend);
+
+/* ---- dsq_deseq: DESeq() behind ONE host-pointer call ------------------------------------------------------------
+ * What an R session binds as .Call("_DESeq2_mi355x_DESeq", ...) in place of the body of DESeq() between
+ * estimateSizeFactors and the final bookkeeping (R/core.R:388-426: estimateDispersions -> nbinomWaldTest / nbinomLRT
+ * -> refitWithoutOutliers): every array is a HOST pointer in R's layout (what INTEGER() / REAL() give), the call
+ * uploads the count matrix ONCE through pinned staging, runs the device-driven chain of dsq_deseq_dev (all four
+ * phases, the optim-fallback rows included, no host decision in between), and downloads the per-gene columns; the
+ * n x m assays (mu, H, cooks, replaceCounts) come down only when their output pointer is non-NULL.  Like the three
+ * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
+ * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
+ * through host memory, as DESeqParallel does (R/parallel.R:27-40).
+ * Covers what the fused chain covers: parametric trend, betaPrior = FALSE, Wald or LRT (any nested reduced model), p <= 10,
+ * m - p > 3, size factors (no normalization-factor matrix yet), no observation weights yet; anything else returns
+ * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
+ * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),
+ * trigamma((m - p) / 2) (R/core.R:1196).
+ * NA convention of the outputs: NaN in double columns, -1 in int32 columns (allZero rows; R/core.R:2534-2536).     */
+typedef struct {
+    int32_t n, m, p;
+    const void *counts;            /* n x m column-major                                                          */
+    int32_t y_type;                /* DSQ_Y_INT32 (counts(dds)) or DSQ_Y_FLOAT64                                  */
+    const double *x;               /* m x p model matrix, column-major, full rank                                 */
+    const double *sizeFactors;     /* m                                                                           */
+    const double *q, *r;           /* qr.Q(qr(x)) (m x p) and qr.R(qr(x)) (p x p), column-major                   */
+    const double *xrinv;           /* x %*% solve(R) (m x p), or NULL: computed here by back substitution         */
+    int32_t test;                  /* 0 Wald, 1 LRT (reduced = ~1 unless x_reduced is given)                      */
+    const double *x_reduced;       /* LRT: the reduced model matrix (m x p_reduced, nested in x, full rank) with its  */
+    const double *q_reduced, *r_reduced;   /* qr.Q / qr.R, or all NULL for reduced = ~1 (R/core.R:1856-1868)          */
+    int32_t p_reduced;
+    double minReplicatesForReplace;/* 7 by default; +Inf switches replaceOutliers / the refit off                 */
+    double cooksCutoff;            /* qf(.99, p, m - p)                                                           */
+    double expVarLogDisp;          /* trigamma((m - p) / 2)                                                       */
+    double betaTol, minmu;         /* nbinomWaldTest / nbinomLRT: 1e-8, 0.5                                       */
+    int32_t maxit, useQR;          /* 100, TRUE                                                                   */
+    int32_t disp_maxit, useCR;     /* estimateDispersions: 100, TRUE                                              */
+    const double *disp_grid;       /* fitDispGridWrapper's seq(log(1e-8), log(max(10, m)), length = 20) (R/wrappers.R:70-72) */
+    int32_t ngrid;                 /*   as the caller's own log() gives it; NULL / 0: computed here                */
+} DsqDeseqHostArgs;
+
+typedef struct {
+    /* mcols(dds): n each (beta .. pvalue: n x p column-major, log2 scale; stat / pvalue Wald only, else NULL)     */
+    double *baseMean, *baseVar;
+    int32_t *allZero;
+    double *dispGeneEst;
+    int32_t *dispGeneIter;
+    double *dispFit, *dispMAP, *dispersion;
+    int32_t *dispIter, *dispOutlier;
+    double *beta, *betaSE, *stat, *pvalue;
+    int32_t *betaConv;
+    double *betaIter, *logLike, *logLikeReduced /* LRT only, else NULL */, *maxCooks;
+    int32_t *replace;              /* NA (-1) on rows that were all zero from the start                           */
+    /* assays, n x m column-major, each optional (NULL = stays on the device)                                      */
+    double *mu, *H, *cooks;
+    int32_t *replaceCounts;
+    /* dispersionFunction(dds): coefficients asymptDisp / extraPois, varLogDispEsts, dispPriorVar                  */
+    double dispersionFunction[4];
+    int32_t status[16];            /* DSQ_ST_*                                                                    */
+} DsqDeseqHostOut;
+
+int dsq_deseq(const DsqDeseqHostArgs *args, DsqDeseqHostOut *out);
 
 /* kernel timings of the calls since dsq_profile_enable(1): one entry per bracketed launch */
 int dsq_profile_count(void);

@@ -10,7 +10,7 @@ typedef int Rboolean;
 #define LGLSXP 10
 #define VECSXP 19
 #define STRSXP 16
-extern SEXP R_NamesSymbol; extern double R_NaReal; 
+extern SEXP R_NamesSymbol; extern SEXP R_NilValue; extern double R_NaReal; extern int R_NaInt;
 #define NA_REAL R_NaReal
 #define ISNAN(x) ((x)!=(x))
 int TYPEOF(SEXP); int *INTEGER(SEXP); double *REAL(SEXP); int *LOGICAL(SEXP);

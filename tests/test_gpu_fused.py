@@ -123,12 +123,32 @@ def test_lrt_against_intercept(E):
     assert np.isfinite(b.mcols["LRTPvalue"]).all()
 
 
+def test_lrt_against_a_reduced_model_matrix(E):
+    """nbinomLRT with a reduced model that is not ~1 (R/core.R:1856-1868; BASELINE configs[3]'s second variant,
+    SURVEY 8d: 2-column reduced model, minmu = 1e-6): the reduced fit runs inside the chain -- QR start values, IRLS,
+    logLik, its own optim-fallback rows -- for the main pass and for the refit of the replaced rows"""
+    x = simulate.design_factor(48, 6)
+    d = simulate.make_counts(500, x, seed=31)
+    counts = _spike_outliers(d["counts"], np.random.default_rng(2), k=5)
+    counts[9] = 0
+    counts[9, 28:30] = 3000
+    red = np.column_stack([np.ones(48), (np.arange(48) >= 24).astype(float)])
+    a, b = _both(E, counts, x, d["size_factors"], test="LRT", reduced=red, minmu=1e-6)
+    _compare(a, b, "LRT vs 2-column reduced")
+    assert np.isfinite(b.mcols["LRTPvalue"][~np.asarray(b.mcols["allZero"], bool)]).all()
+    assert b.attrs["status"]["N_REFIT"] >= 2
+    red3 = np.column_stack([red, (np.arange(48) % 2).astype(float)])          # not nested in x: still a valid fit
+    a, b = _both(E, counts, x, d["size_factors"], test="LRT", reduced=red3, minReplicatesForReplace=np.inf)
+    _compare(a, b, "LRT vs 3-column reduced")
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)
     dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E)
     assert not fused.supported(dds, betaPrior=True)
-    assert not fused.supported(dds, test="LRT", reduced=x[:, :1] * 2)
+    assert not fused.supported(dds, test="LRT", reduced=np.column_stack([x[:, 0], x[:, 0] * 2, x[:, 1]]))   # p_red >= p
+    assert not fused.supported(dds, test="LRT", reduced=np.zeros((12, 1)))
     fused.DESeq(dds, betaPrior=True, factors={"condition": x[:, 1].astype(int)})
     assert "WaldPvalue" in dds.mcols and not dds.attrs.get("fused")
 
