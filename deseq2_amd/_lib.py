@@ -172,7 +172,8 @@ class DsqDeseqArgs(C.Structure):
         ("cell_of", C.c_void_p), ("ncell", C.c_int32), ("replaceable", C.c_void_p),
         ("cooksCutoff", C.c_double), ("trim", C.c_double), ("do_replace", C.c_int32),
         ("x_red", C.c_void_p), ("q_red", C.c_void_p), ("a_red", C.c_void_p), ("r_red", C.c_void_p), ("p_red", C.c_int32),
-        ("cell_of_red", C.c_void_p), ("ncell_red", C.c_int32),
+        ("cell_of_red", C.c_void_p), ("ncell_red", C.c_int32), ("defer_finish", C.c_int32),
+        ("n_refit_global", C.c_void_p),
     ]
 
 
@@ -204,7 +205,7 @@ class DsqDeseqHostOut(C.Structure):
         ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16)]
 
 
-DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS = 1, 2, 4, 8
+DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS, DSQ_PH_FINISH = 1, 2, 4, 8, 16
 DSQ_ST = {k: i for i, k in enumerate((
     "N_NONZERO", "N_GRID_GENEEST", "N_TREND", "TREND_STATUS", "N_ABOVE_MIN", "N_GRID_MAP", "N_OPTIM_GENEEST",
     "N_OPTIM_TEST", "N_REPLACE", "N_REFIT", "N_GRID_GENEEST_REFIT", "N_GRID_MAP_REFIT", "N_OPTIM_GENEEST_REFIT",

@@ -894,30 +894,36 @@ def _dispersion_function(dds, baseMean):
     return np.full(baseMean.shape, fn["coefficients"])
 
 
-def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace=7, disp_maxit=100, **kw):
+def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace=7, disp_maxit=100, count_all=None, **kw):
     """R/core.R:2484-2563: replace count outliers by the trimmed mean, then re-estimate the
     dispersion and refit the rows that had a replacement (all through the same engine entry
-    points, on the row subset)."""
+    points, on the row subset).  `count_all`: when `dds` is one shard of a gene-sharded analysis, a function that adds
+    a count up over all shards (called exactly once) -- the closing steps (NA results on the rows that became all zero,
+    maxCooks, :2535-2546) run when ANY row of the whole object was refitted (:2496), as on the unsharded object."""
     E = dds.engine
     kw = {k: v for k, v in kw.items() if k not in ("betaPrior", "betaPriorVar", "modelMatrixType", "factors")}
     replaceOutliers(dds, minReplicates=minReplicatesForReplace)
     if "replace" not in dds.mcols:
+        if count_all is not None:
+            count_all(0)
         return dds
     replace = dds.mcols["replace"]
     nrefit = int(replace.sum())
-    if nrefit == 0:
-        dds.assays.pop("replaceCounts", None)
-        return dds
-    idx_rep = np.where(replace)[0]
-    whole = dds.subset(idx_rep, dds.assays["replaceCounts"])
-    getBaseMeansAndVariances(whole)                                                   # :2491
-    for k in ("baseMean", "baseVar", "allZero"):
-        dds.mcols[k] = dds.mcols[k].copy()
-        dds.mcols[k][idx_rep] = whole.mcols[k]
-    newAllZero = idx_rep[whole.mcols["allZero"]]
-    if nrefit > newAllZero.size:                                                      # :2496
+    newAllZero = np.array([], int)
+    refitReplace = np.array([], int)
+    whole = None
+    if nrefit > 0:
+        idx_rep = np.where(replace)[0]
+        whole = dds.subset(idx_rep, dds.assays["replaceCounts"])
+        getBaseMeansAndVariances(whole)                                               # :2491
+        for k in ("baseMean", "baseVar", "allZero"):
+            dds.mcols[k] = dds.mcols[k].copy()
+            dds.mcols[k][idx_rep] = whole.mcols[k]
+        newAllZero = idx_rep[whole.mcols["allZero"]]
+        refitReplace = idx_rep[~whole.mcols["allZero"]]
+    n_refit_all = refitReplace.size if count_all is None else int(count_all(int(refitReplace.size)))
+    if refitReplace.size > 0:                                                         # :2496
         keep = ~whole.mcols["allZero"]
-        refitReplace = idx_rep[keep]
         sub = whole if keep.all() else dds.subset(refitReplace, dds.assays["replaceCounts"])
         estimateDispersionsGeneEst(sub, maxit=disp_maxit)                             # :2509
         sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
@@ -934,6 +940,7 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
             dst = np.array(dds.mcols[k], copy=True)
             dst[refitReplace] = v
             dds.mcols[k] = dst
+    if n_refit_all > 0:
         for k in _RESULT_COLS:                                                        # :2535
             if k in dds.mcols and newAllZero.size:
                 a = dds.mcols[k]
@@ -950,6 +957,9 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
                 dds.mcols["maxCooks"] = E.masked_row_max(dds.assays["cooks"], nOrMoreInCell(x, 3), replaceable)
             else:
                 dds.mcols["maxCooks"] = np.full(dds.n, np.nan)
+    if nrefit == 0:
+        dds.assays.pop("replaceCounts", None)
+        return dds
     dds.assays["replaceCooks"] = dds.assays["cooks"]                                   # :2551
     return dds
 

@@ -138,9 +138,11 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
         const double *mug = kp.mu + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
         const double size = 1.0 / kp.disp[g];
+        double st_size, lg_size;                 // stirlerr(size), log(size): one value per gene, not per sample
+        dnbinom_size_terms(size, st_size, lg_size);
         double acc = 0.0;
         for (int j = lane; j < m; j += 64) {
-            double d = dnbinom_mu_log((double)yg[j], size, mug[j]);
+            double d = dnbinom_mu_log((double)yg[j], size, mug[j], st_size, lg_size);
             if constexpr (USE_W) d = wg[j] * d;
             acc += d;
         }
@@ -186,9 +188,11 @@ __global__ void __launch_bounds__(256) intercept_fit_kernel(InterceptKernelParam
         const double xtwx = wave_allreduce(sw);
         if (kp.loglike) {
             const double size = 1.0 / alpha;
+            double st_size, lg_size;
+            dnbinom_size_terms(size, st_size, lg_size);
             double acc = 0.0;
             for (int j = lane; j < m; j += 64) {
-                double d = dnbinom_mu_log((double)yg[j], size, nfg[j] * eb);
+                double d = dnbinom_mu_log((double)yg[j], size, nfg[j] * eb, st_size, lg_size);
                 if constexpr (USE_W) d = wg[j] * d;
                 acc += d;
             }

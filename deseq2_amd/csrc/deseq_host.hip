@@ -134,15 +134,17 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
 struct Exchange {
     std::mutex mu;
     std::condition_variable cv;
-    int arrived = 0, target = 1;
+    int arrived[2] = {0, 0}, target = 1;
     bool failed = false;
     std::vector<double> bm, dge;
+    long n_refit = 0;                  // refitted rows over all ranges (stage 1)
     std::vector<int32_t> status;       // target x DSQ_ST_COUNT
     std::vector<double> scalars;       // target x DSQ_SC_COUNT
-    bool wait() {
+    bool wait(int stage, long add = 0) {
         std::unique_lock<std::mutex> lk(mu);
-        if (++arrived >= target) cv.notify_all();
-        else cv.wait(lk, [&] { return arrived >= target || failed; });
+        n_refit += add;
+        if (++arrived[stage] >= target) cv.notify_all();
+        else cv.wait(lk, [&] { return arrived[stage] >= target || failed; });
         return !failed;
     }
     void fail() {
@@ -278,14 +280,30 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         HD_HIP(hipMemcpyAsync(X.bm.data() + lo, od.baseMean, cnt * 8, hipMemcpyDeviceToHost, st));
         HD_HIP(hipMemcpyAsync(X.dge.data() + lo, od.dispGeneEst, cnt * 8, hipMemcpyDeviceToHost, st));
         HD_HIP(hipStreamSynchronize(st));
-        if (!X.wait()) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
+        if (!X.wait(0)) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
         if ((rc = capi_ws_get(HD_TREND, 2 * n * 8, &v))) return rc;
         double *tv = (double *)v;
         HD_HIP(hipMemcpyAsync(tv, X.bm.data(), n * 8, hipMemcpyHostToDevice, st));
         HD_HIP(hipMemcpyAsync(tv + n, X.dge.data(), n * 8, hipMemcpyHostToDevice, st));
         d.trend_mean = tv; d.trend_disp = tv + n;
         d.phases = DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
+        d.defer_finish = 1;
         if ((rc = pipeline_run(&d, &od, st))) return rc;
+        if (F.do_replace) {
+            // refitWithoutOutliers' closing steps ask whether ANY row of the whole object was refitted (R/core.R:2496):
+            // the ranges add up their counts, then each finishes its own rows
+            int32_t mine = 0;
+            HD_HIP(hipMemcpyAsync(&mine, status + DSQ_ST_N_REFIT, 4, hipMemcpyDeviceToHost, st));
+            HD_HIP(hipStreamSynchronize(st));
+            if (!X.wait(1, mine)) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
+            const int32_t total = (int32_t)(X.n_refit > 0x7fffffffL ? 0x7fffffffL : X.n_refit);
+            static thread_local int32_t total_h;
+            total_h = total;
+            HD_HIP(hipMemcpyAsync(bad + 1, &total_h, 4, hipMemcpyHostToDevice, st));      // (pageable: staged at once)
+            d.n_refit_global = bad + 1;
+            d.phases = DSQ_PH_FINISH;
+            if ((rc = pipeline_run(&d, &od, st))) return rc;
+        }
     }
 
     // ---- per-gene columns down: three packed blocks, scattered into the caller's columns at this range's rows

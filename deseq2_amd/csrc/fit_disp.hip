@@ -57,6 +57,11 @@ struct DispGene {
     unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
     unsigned padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
+    // every fitted mean of the gene lies in [0, 1e140): with alpha in [e^-30, e^10] (the search's clamp, :215-224) and
+    // on the dispersion grid, 1 + mu alpha is then a normal number far from the ends of the exponent range and its
+    // reciprocal takes the scaling-free division (drcp_n: same quotient, 4 instructions less per sample)
+    bool mu_ok;
+    DSQ_DEV double rcp1(double opm) const { return mu_ok ? drcp_n(opm) : 1.0 / opm; }
     double *arena;      // lane-column builds: K P P doubles of wave-private LDS (general-mode Cox-Reid rows)
     // unweighted genes: the distinct count values (ascending) and their multiplicities, in wave-private LDS -- the
     // lgamma / digamma terms of the likelihood depend on a sample only through its count, so they are evaluated once
@@ -390,7 +395,7 @@ DSQ_UNROLL_P
                 [&](int j, double(&wd)[1], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
                     const double opm = 1.0 + mu * alpha;
-                    if (useCR) wd[0] = mu * (1.0 / opm);
+                    if (useCR) wd[0] = mu * rcp1(opm);
                     if (lik) {
                         const double l1 = dlog(opm);
                         if constexpr (USE_W) {
@@ -464,7 +469,7 @@ DSQ_UNROLL_P
                     const double y = r.y(j), mu = r.mu(j);
                     const double ma = mu * alpha;
                     const double opm = 1.0 + ma;
-                    const double rr = 1.0 / opm;
+                    const double rr = rcp1(opm);
                     if (useCR) {
                         const double w0 = mu * rr;
                         wd[0] = w0;
@@ -542,7 +547,7 @@ DSQ_UNROLL_P
                 [&](int j, double(&wd)[2], bool lik) {
                     const double y = r.y(j), mu = r.mu(j);
                     const double ma = mu * alpha;
-                    const double rr = 1.0 / (1.0 + ma);
+                    const double rr = rcp1(1.0 + ma);
                     if (useCR) {
                         const double w0 = mu * rr;
                         wd[0] = w0;
@@ -760,6 +765,15 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
+        {
+            bool ok = true;
+            for (int j = lane; j < m; j += 64) { const double mu = G.r.mu(j); ok = ok && (mu >= 0.0) && (mu < 1e140); }
+            // log alpha: the search keeps its proposals in [-30, 10]; its start value and the grid come from the caller
+            bool la_ok;
+            if constexpr (MODE == 1) la_ok = kp.grid[0] >= -40.0 && kp.grid[kp.ngrid - 1] <= 40.0 && kp.grid[0] <= kp.grid[kp.ngrid - 1];
+            else { const double a0 = (MODE == 0) ? kp.log_alpha_in[g] : kp.log_alpha[g]; la_ok = a0 >= -40.0 && a0 <= 40.0; }
+            G.mu_ok = __all(ok) && la_ok;
+        }
         G.prior_mean = kp.prior_mean[g];
         G.prior_sigmasq = kp.prior_sigmasq_dev ? *kp.prior_sigmasq_dev : kp.prior_sigmasq;
         G.thr = kp.weightThreshold;

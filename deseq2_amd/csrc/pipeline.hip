@@ -772,6 +772,67 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     return DSQ_OK;
 }
 
+// design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags (nOrMoreInCell, R/core.R:2366), the
+// replaceable flags: small host arrays, uploaded for the outlier kernels
+struct OutlierMeta {
+    int32_t *dperm, *din3, *drepl, *duse3, *dstart;
+    int maxcell, any3, all_rep;
+};
+static int outlier_meta(const DsqDeseqArgs *a, int m, hipStream_t st, OutlierMeta *M) {
+    static thread_local std::vector<int32_t> meta;   // (staged by the copy below)
+    meta.assign((size_t)4 * m + a->ncell + 1, 0);
+    int32_t *perm = meta.data(), *in3 = perm + m, *repl = in3 + m, *use3 = repl + m, *start = use3 + m;
+    for (int j = 0; j < m; j++) {
+        if (a->cell_of[j] < 0 || a->cell_of[j] >= a->ncell) return capi_fail(DSQ_ERR_VALUE, "cell_of[%d] out of range", j);
+        start[a->cell_of[j] + 1]++;
+    }
+    int maxcell = 0, any3 = 0;
+    for (int c = 0; c < a->ncell; c++) {
+        int sz = start[c + 1];
+        if (sz > maxcell) maxcell = sz;
+        if (sz >= 3) any3 = 1;
+        start[c + 1] += start[c];
+    }
+    {
+        std::vector<int32_t> fill(start, start + a->ncell);
+        for (int j = 0; j < m; j++) perm[fill[a->cell_of[j]]++] = j;
+    }
+    int all_rep = 1;
+    for (int j = 0; j < m; j++) {
+        in3[j] = (start[a->cell_of[j] + 1] - start[a->cell_of[j]]) >= 3;
+        use3[j] = in3[j];
+        repl[j] = a->replaceable[j] ? 1 : 0;
+        if (!repl[j]) all_rep = 0;
+    }
+    void *mv;
+    int rc = capi_ws_get(DSQ_WS_PIPE_META + 1, meta.size() * sizeof(int32_t) + 64, &mv);
+    if (rc) return rc;
+    PIPE_HIP(hipMemcpyAsync(mv, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    M->dperm = (int32_t *)mv; M->din3 = M->dperm + m; M->drepl = M->din3 + m; M->duse3 = M->drepl + m; M->dstart = M->duse3 + m;
+    M->maxcell = maxcell; M->any3 = any3; M->all_rep = all_rep;
+    return DSQ_OK;
+}
+
+// the closing steps of refitWithoutOutliers that ask whether ANY row of the analysis was refitted (R/core.R:2496):
+// result columns of the rows that became all zero are NA (:2535), maxCooks is recomputed (:2538-2546)
+static int outlier_finish(Pipe &P, const Rows &nz, const Rows &rep, const OutlierMeta &M, const int32_t *n_refit) {
+    const DsqDeseqOut *o = P.o;
+    const int n = P.n, m = P.m, p = P.p;
+    NaRowsParams nr;
+    memset(&nr, 0, sizeof nr);
+    nr.rw = rep; nr.n = n; nr.p = p; nr.allZero = o->allZero; nr.n_refit = n_refit;
+    nr.beta = o->beta; nr.betaSE = o->betaSE; nr.stat = o->stat; nr.pvalue = o->pvalue; nr.betaIter = o->betaIter;
+    nr.logLike = o->logLike; nr.logLikeReduced = o->logLikeReduced; nr.maxCooks = o->maxCooks; nr.betaConv = o->betaConv;
+    hipLaunchKernelGGL(na_rows_kernel, ew_grid(n), dim3(256), 0, P.st, nr);
+    int grid = (n + 3) / 4, capg = device_cu_count() * 8;
+    if (grid > capg) grid = capg;
+    hipLaunchKernelGGL(masked_max_kernel, dim3(grid), dim3(256), 0, P.st, nz, m, P.ld, (const double *)o->cooks,
+                       (const int32_t *)M.duse3, (const int32_t *)M.drepl, M.all_rep, (m > p && M.any3) ? 1 : 0, n_refit,
+                       o->maxCooks);
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 struct Carve {
@@ -826,7 +887,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         return capi_fail(DSQ_ERR_ARG, "NULL output");
     if (a->test == 0 && (!o->stat || !o->pvalue)) return capi_fail(DSQ_ERR_ARG, "Wald test needs stat / pvalue outputs");
     if (a->test == 1 && !o->logLikeReduced) return capi_fail(DSQ_ERR_ARG, "LRT needs logLikeReduced");
-    if ((a->phases & DSQ_PH_OUTLIERS) && (!a->cell_of || !a->replaceable || a->ncell < 1)) return capi_fail(DSQ_ERR_ARG, "outlier phase needs cell_of / replaceable");
+    if ((a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_FINISH)) && (!a->cell_of || !a->replaceable || a->ncell < 1)) return capi_fail(DSQ_ERR_ARG, "outlier phase needs cell_of / replaceable");
     int rc = capi_check_device();
     if (rc) return rc;
 
@@ -947,37 +1008,11 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     }
     // ================================================================ count outliers
     if (a->phases & DSQ_PH_OUTLIERS) {
-        // design cells -> sample permutation grouped by cell, offsets, ">= 3 in cell" flags (nOrMoreInCell, :2366)
-        static thread_local std::vector<int32_t> meta;   // (staged by the copy below)
-        meta.assign((size_t)4 * m + a->ncell + 1, 0);
-        int32_t *perm = meta.data(), *in3 = perm + m, *repl = in3 + m, *use3 = repl + m, *start = use3 + m;
-        for (int j = 0; j < m; j++) {
-            if (a->cell_of[j] < 0 || a->cell_of[j] >= a->ncell) return capi_fail(DSQ_ERR_VALUE, "cell_of[%d] out of range", j);
-            start[a->cell_of[j] + 1]++;
-        }
-        int maxcell = 0, any3 = 0;
-        for (int c = 0; c < a->ncell; c++) {
-            int sz = start[c + 1];
-            if (sz > maxcell) maxcell = sz;
-            if (sz >= 3) any3 = 1;
-            start[c + 1] += start[c];
-        }
-        {
-            std::vector<int32_t> fill(start, start + a->ncell);
-            for (int j = 0; j < m; j++) perm[fill[a->cell_of[j]]++] = j;
-        }
-        int all_rep = 1;
-        for (int j = 0; j < m; j++) {
-            in3[j] = (start[a->cell_of[j] + 1] - start[a->cell_of[j]]) >= 3;
-            use3[j] = in3[j];
-            repl[j] = a->replaceable[j] ? 1 : 0;
-            if (!repl[j]) all_rep = 0;
-        }
-        void *mv;
-        rc = capi_ws_get(DSQ_WS_PIPE_META + 1, meta.size() * sizeof(int32_t) + 64, &mv);
+        OutlierMeta M;
+        rc = outlier_meta(a, m, st, &M);
         if (rc) return rc;
-        PIPE_HIP(hipMemcpyAsync(mv, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        int32_t *dperm = (int32_t *)mv, *din3 = dperm + m, *drepl = din3 + m, *duse3 = drepl + m, *dstart = duse3 + m;
+        int32_t *dperm = M.dperm, *din3 = M.din3, *drepl = M.drepl, *dstart = M.dstart;
+        const int any3 = M.any3, maxcell = M.maxcell;
         for (int k = CNT_REP; k < CNT_N; k++) PIPE_HIP(hipMemsetAsync(P.counters + k, 0, sizeof(int32_t), st));
 
         CooksKernelParams ck;
@@ -1025,19 +1060,21 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
             if (rc) return rc;
             rc = test_fit(P, rf, o->replaceCounts, o->mu_hat, nullptr, CNT_OPT2R);
             if (rc) return rc;
-            NaRowsParams nr;
-            memset(&nr, 0, sizeof nr);
-            nr.rw = rep; nr.n = n; nr.p = p; nr.allZero = o->allZero; nr.n_refit = P.counters + CNT_REFIT;
-            nr.beta = o->beta; nr.betaSE = o->betaSE; nr.stat = o->stat; nr.pvalue = o->pvalue; nr.betaIter = o->betaIter;
-            nr.logLike = o->logLike; nr.logLikeReduced = o->logLikeReduced; nr.maxCooks = o->maxCooks; nr.betaConv = o->betaConv;
-            hipLaunchKernelGGL(na_rows_kernel, ew_grid(n), dim3(256), 0, st, nr);
-            int grid = (n + 3) / 4, capg = device_cu_count() * 8;
-            if (grid > capg) grid = capg;
-            hipLaunchKernelGGL(masked_max_kernel, dim3(grid), dim3(256), 0, st, nz, m, P.ld, (const double *)o->cooks,
-                               (const int32_t *)duse3, (const int32_t *)drepl, all_rep, (m > p && any3) ? 1 : 0,
-                               (const int32_t *)(P.counters + CNT_REFIT), o->maxCooks);
-            PIPE_HIP(hipGetLastError());
+            if (!a->defer_finish) {
+                rc = outlier_finish(P, nz, rep, M, P.counters + CNT_REFIT);
+                if (rc) return rc;
+            }
         }
+    }
+    // ================================================================ (sharding callers) the closing steps, with the
+    // number of refitted rows over all shards
+    if ((a->phases & DSQ_PH_FINISH) && a->do_replace) {
+        OutlierMeta M;
+        rc = outlier_meta(a, m, st, &M);
+        if (rc) return rc;
+        const Rows rep = {P.rows_rep, P.counters + CNT_REP, n};
+        rc = outlier_finish(P, nz, rep, M, a->n_refit_global ? a->n_refit_global : P.counters + CNT_REFIT);
+        if (rc) return rc;
     }
     // counters -> status block (one small device-to-device copy per phase set)
     static const int map_[][2] = {{CNT_NZ, DSQ_ST_N_NONZERO}, {CNT_GRID1, DSQ_ST_N_GRID_GENEEST}, {CNT_TREND, DSQ_ST_N_TREND},

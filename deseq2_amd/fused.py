@@ -261,8 +261,16 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     else:
         run.launch(L.DSQ_PH_GENE_EST)
         trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
+        run.args.defer_finish = 1
         run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS, trend=trend)
     st, sc = run.read_status()
+    if world > 1 and run.do_replace:
+        # refitWithoutOutliers' closing steps (NA results on rows that became all zero, maxCooks) ask whether ANY row of
+        # the whole object was refitted (R/core.R:2496): the shards add up their counts, then each finishes its rows
+        total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
+        run.n_refit_all = t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=E.device)
+        run.args.n_refit_global = _ptr(run.n_refit_all)
+        run.launch(L.DSQ_PH_FINISH)
     st2 = st
     # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
     # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)

@@ -186,7 +186,14 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
     # outlier replacement + refit (R/core.R:419-426 after the parallel branch): per gene, so per shard;
     # the refit reads the global dispersion function / prior variance already on the shard
     if np.isfinite(minReplicatesForReplace) and core.nOrMoreInCell(dds.x, minReplicatesForReplace).any():
-        core.refitWithoutOutliers(dds, test=test, reduced=reduced,
+        # ... except its closing steps, which ask whether ANY row of the whole object was refitted (R/core.R:2496)
+        if group is not None:
+            count_all = lambda k: float(group.allgather(chunk, np.array([float(k)])).sum())      # noqa: E731
+        elif world_size() > 1:
+            count_all = lambda k: sum(allgather_sizes(k, comm_device))                          # noqa: E731
+        else:
+            count_all = None
+        core.refitWithoutOutliers(dds, test=test, reduced=reduced, count_all=count_all,
                                   minReplicatesForReplace=minReplicatesForReplace, **kw)
     return dds
 

@@ -407,11 +407,16 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
  *                     when those are NULL, over this call's own genes (multi-GPU: the gathered vectors)
  *   DSQ_PH_MAP_TEST   dispFit, MAP dispersions, final GLM fit [+ the reduced-model fit], Wald statistics / logLik pair
  *   DSQ_PH_OUTLIERS   Cook's distances, replaceOutliers, refit of the replaced rows, maxCooks
+ *   DSQ_PH_FINISH     (gene-sharding callers only, see below)
  * status[] (int32, device): see DSQ_ST_*; scalars[] (double, device): see DSQ_SC_*.                            */
 #define DSQ_PH_GENE_EST 1
 #define DSQ_PH_TREND    2
 #define DSQ_PH_MAP_TEST 4
 #define DSQ_PH_OUTLIERS 8
+#define DSQ_PH_FINISH   16   /* the two closing steps of refitWithoutOutliers that depend on whether ANY row of the whole
+                                analysis was refitted (R/core.R:2496, 2535-2546: NA results on rows that became all zero,
+                                maxCooks): part of DSQ_PH_OUTLIERS unless defer_finish is set -- a caller that shards the
+                                genes sets it, adds up N_REFIT over its shards and runs this phase with the total       */
 
 enum { DSQ_ST_N_NONZERO = 0, DSQ_ST_N_GRID_GENEEST, DSQ_ST_N_TREND, DSQ_ST_TREND_STATUS, DSQ_ST_N_ABOVE_MIN,
        DSQ_ST_N_GRID_MAP, DSQ_ST_N_OPTIM_GENEEST, DSQ_ST_N_OPTIM_TEST, DSQ_ST_N_REPLACE, DSQ_ST_N_REFIT,
@@ -460,6 +465,8 @@ typedef struct {
     int32_t p_red;
     const int32_t *cell_of_red;    /* HOST                                                                       */
     int32_t ncell_red;
+    int32_t defer_finish;          /* see DSQ_PH_FINISH                                                          */
+    const int32_t *n_refit_global; /* device int32 for DSQ_PH_FINISH: refitted rows over ALL shards (NULL: this call's) */
 } DsqDeseqArgs;
 
 typedef struct {

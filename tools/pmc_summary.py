@@ -12,8 +12,16 @@ def load(d):
     df = pd.read_csv(d + "/p_counter_collection.csv")
     df = df[df["Kernel_Name"].str.contains("dsq::")].copy()
     df["k"] = df["Kernel_Name"].str.extract(r"dsq::(\w+?)_kernel")
-    # full-size launches only (the outlier refit re-launches the fit kernels on a handful of rows)
-    df = df[df["Grid_Size"] == df.groupby("k")["Grid_Size"].transform("max")]
+    # full-size launches only (the outlier refit and the straggler passes re-launch the same kernels on a handful of
+    # rows, sometimes with the same grid): joined with the kernel trace of the SAME pass on the dispatch id, a launch
+    # counts when it ran for at least half of the kernel's longest launch (round 2 averaged both kinds together)
+    try:
+        kt = pd.read_csv(d + "/p_kernel_trace.csv")
+        kt["dur"] = kt["End_Timestamp"] - kt["Start_Timestamp"]
+        df = df.merge(kt[["Dispatch_Id", "dur"]], on="Dispatch_Id", how="left")
+        df = df[df["dur"] >= 0.5 * df.groupby("k")["dur"].transform("max")]
+    except (OSError, KeyError):
+        df = df[df["Grid_Size"] == df.groupby("k")["Grid_Size"].transform("max")]
     return df.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
 
 
@@ -22,9 +30,8 @@ def main(fetch_dir, write_dir, sq_dir, out):
     kt = pd.read_csv(sq_dir + "/p_kernel_trace.csv")
     kt = kt[kt["Kernel_Name"].str.contains("dsq::")].copy()
     kt["k"] = kt["Kernel_Name"].str.extract(r"dsq::(\w+?)_kernel")
-    gcol = "Grid_Size" if "Grid_Size" in kt.columns else "Grid_Size_X"
-    kt = kt[kt[gcol] == kt.groupby("k")[gcol].transform("max")]
     kt["ms"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e6
+    kt = kt[kt["ms"] >= 0.5 * kt.groupby("k")["ms"].transform("max")]
     res = {}
     for k in s.index:
         r = {"fetch_bytes_per_launch": float(f.loc[k, "FETCH_SIZE"]) * 1024 * 2 if k in f.index else None,
