@@ -173,7 +173,8 @@ class DsqDeseqArgs(C.Structure):
         ("cooksCutoff", C.c_double), ("trim", C.c_double), ("do_replace", C.c_int32),
         ("x_red", C.c_void_p), ("q_red", C.c_void_p), ("a_red", C.c_void_p), ("r_red", C.c_void_p), ("p_red", C.c_int32),
         ("cell_of_red", C.c_void_p), ("ncell_red", C.c_int32), ("defer_finish", C.c_int32),
-        ("n_refit_global", C.c_void_p),
+        ("n_refit_global", C.c_void_p), ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32),
+        ("prior_expanded", C.c_int32), ("prior_intercept", C.c_int32), ("lambda_prior", C.c_void_p),
     ]
 
 
@@ -182,7 +183,7 @@ class DsqDeseqOut(C.Structure):
         "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
         "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
         "logLikeReduced", "maxCooks", "replace", "optim_geneest", "optim_test", "mu_hat", "mu", "H", "cooks",
-        "replaceCounts", "status", "scalars")]
+        "replaceCounts", "status", "scalars", "mle_beta")]
 
 
 class DsqDeseqHostArgs(C.Structure):
@@ -205,7 +206,7 @@ class DsqDeseqHostOut(C.Structure):
         ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16)]
 
 
-DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS, DSQ_PH_FINISH = 1, 2, 4, 8, 16
+DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS, DSQ_PH_FINISH, DSQ_PH_PRIOR = 1, 2, 4, 8, 16, 32
 DSQ_ST = {k: i for i, k in enumerate((
     "N_NONZERO", "N_GRID_GENEEST", "N_TREND", "TREND_STATUS", "N_ABOVE_MIN", "N_GRID_MAP", "N_OPTIM_GENEEST",
     "N_OPTIM_TEST", "N_REPLACE", "N_REFIT", "N_GRID_GENEEST_REFIT", "N_GRID_MAP_REFIT", "N_OPTIM_GENEEST_REFIT",

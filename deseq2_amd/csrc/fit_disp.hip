@@ -72,6 +72,11 @@ struct DispGene {
     // offsets; C = 0 -> general per-sample Gram
     const int32_t *cperm, *cstart;
     int C;
+    // SORTED staging (unweighted staged rows of a factor design): the row sits in LDS in the cell-sorted order itself, so
+    // position k of the sweep reads slot k -- no sample indirection; cid[k] = cell of position k, crep[c] = a sample of cell c
+    bool sorted;
+    const uint8_t *cid;
+    const int32_t *crep;
     // sort the gene's counts (bitonic network in the wave's LDS slice), keep the first of every run and its length.
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
@@ -132,8 +137,9 @@ DSQ_UNROLL_P
             for (int k0 = 0; k0 < m; k0 += 64) {
                 const int kk = k0 + lane;
                 const bool valid = kk < m;
-                const int pk = cperm[valid ? kk : m - 1];
-                const int j = pk & 0x3ffffff, cmy = valid ? (pk >> 26) : -1;
+                int j, cmy;
+                if (sorted) { j = valid ? kk : m - 1; cmy = valid ? (int)cid[j] : -1; }
+                else { const int pk = cperm[valid ? kk : m - 1]; j = pk & 0x3ffffff; cmy = valid ? (pk >> 26) : -1; }
                 double wd[K];
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++) wd[k] = 0.0;
@@ -165,7 +171,7 @@ DSQ_UNROLL_P
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++) B[k][i] = 0.0;
                 for (int c = 0; c < C; c++) {
-                    const int j0 = cperm[cstart[c]] & 0x3ffffff;
+                    const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
                     double sc[K];
                     _Pragma("unroll")
                     for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
@@ -190,7 +196,7 @@ DSQ_UNROLL_P
                         _Pragma("unroll")
                         for (int k = 0; k < K; k++) B[k][a][b] = 0.0;
                 for (int c = 0; c < C; c++) {
-                    const int j0 = cperm[cstart[c]] & 0x3ffffff;
+                    const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
                     double sc[K];
                     _Pragma("unroll")
                     for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
@@ -688,7 +694,15 @@ __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
 
 // block-shared design-cell lists (int32: cell_start[DSQ_CMAX + 2] | m entries sample | cell << 26 in cell-sorted order)
 // behind everything else
-__host__ __device__ inline size_t disp_cell_doubles(int m, int ncell) { return ncell > 0 ? ((size_t)m + DSQ_CMAX + 3) / 2 : 0; }
+__host__ __device__ inline size_t disp_cell_doubles(int m, int ncell, bool sorted = false) {
+    if (ncell <= 0) return 0;
+    // sorted staging: cell_start[DSQ_CMAX + 2] | crep[DSQ_CMAX] int32 | m cell bytes
+    if (sorted) return ((size_t)(2 * DSQ_CMAX + 2) * 4 + (size_t)m + 7) / 8;
+    return ((size_t)m + DSQ_CMAX + 3) / 2;
+}
+// sorted staging applies to staged, unweighted rows of a design with cells
+template <bool USE_W>
+__host__ __device__ inline bool disp_sorted(bool stage, int ncell) { return stage && !USE_W && ncell > 0; }
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
@@ -723,12 +737,20 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     // design cells: lists in block-shared LDS behind the slabs and arenas
     int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P)));
     int32_t *cperm_s = cstart_s + DSQ_CMAX + 2;
+    int32_t *crep_s = cperm_s;                                           // sorted staging: crep[DSQ_CMAX] | cell bytes
+    uint8_t *cid_s = reinterpret_cast<uint8_t *>(crep_s + DSQ_CMAX);
     const int C = kp.ncell;      // (the host passes cells only for the design widths that take the cell mode)
+    const bool sorted = disp_sorted<USE_W>(STAGE, C);
     if (C > 0) {
         for (int t = threadIdx.x; t <= C; t += blockDim.x) cstart_s[t] = kp.cell_start[t];
         for (int c = 0; c < C; c++) {
             const int s0 = kp.cell_start[c], s1 = kp.cell_start[c + 1];
-            for (int t = s0 + (int)threadIdx.x; t < s1; t += blockDim.x) cperm_s[t] = kp.cell_perm[t] | (c << 26);
+            if (sorted) {
+                if (threadIdx.x == 0) crep_s[c] = kp.cell_perm[s0];
+                for (int t = s0 + (int)threadIdx.x; t < s1; t += blockDim.x) cid_s[t] = (uint8_t)c;
+            } else {
+                for (int t = s0 + (int)threadIdx.x; t < s1; t += blockDim.x) cperm_s[t] = kp.cell_perm[t] | (c << 26);
+            }
         }
     }
     if constexpr (STAGE) {
@@ -753,11 +775,19 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             double *ms = slab, *ws = slab + (size_t)m;
             int32_t *ys = reinterpret_cast<int32_t *>(slab + (size_t)m * (USE_W ? 2 : 1));
             dist = ys + 2 * (((size_t)m + 1) / 2);
-            for (int j = lane; j < m; j += 64) {
-                double mu = mug[j];
-                ys[j] = yg[j];
-                ms[j] = mu;
-                if constexpr (USE_W) ws[j] = wg[j];
+            if (sorted) {
+                for (int k = lane; k < m; k += 64) {              // slot k = position k of the cell-sorted sequence
+                    const int j = kp.cell_perm[k];
+                    ys[k] = yg[j];
+                    ms[k] = mug[j];
+                }
+            } else {
+                for (int j = lane; j < m; j += 64) {
+                    double mu = mug[j];
+                    ys[j] = yg[j];
+                    ms[j] = mu;
+                    if constexpr (USE_W) ws[j] = wg[j];
+                }
             }
             G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
@@ -783,6 +813,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.padmask = kp.padmask;
         G.arena = arena;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
+        G.sorted = sorted; G.cid = cid_s; G.crep = crep_s;
         G.build_distinct(dist);
         G.setup_cr();
 
@@ -874,7 +905,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
-            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell)) * sizeof(double);
+            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell))) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
             const int wcap = 4 * (DSQ_DISP_MINW);     // waves per CU the register budget of this build admits
@@ -887,7 +918,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
     const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P)) * sizeof(double);
-    const size_t cell_bytes = disp_cell_doubles(kp.m, kp.ncell) * sizeof(double);
+    const size_t cell_bytes = disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) * sizeof(double);
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)

@@ -479,7 +479,8 @@ struct Pipe {
     double *opt_start, *opt_beta, *opt_se, *opt_ll;
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
-    // nbinomLRT against a reduced model that is not ~1
+    double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
+    // nbinomLRT against a reduced model that is not ~1 / the beta-prior refit (never both: the prior is Wald only)
     double *red_binit, *red_beta, *red_se, *red_mu;
     const int32_t *red_cell_perm, *red_cell_start;
     int red_ncell;
@@ -525,17 +526,37 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     return q;
 }
 
+// which model matrix a GLM fit of the chain runs on: the design itself, nbinomLRT's reduced model, or the (expanded)
+// design of the beta-prior refit with its ridge 1 / betaPriorVar (R/fitNbinomGLMs.R:311-325)
+enum { DES_FULL = 0, DES_REDUCED = 1, DES_PRIOR = 2 };
+struct DesignSel {
+    const double *x, *beta_init, *lam;
+    int p;
+    const int32_t *cperm, *cstart;
+    int ncell;
+};
+static DesignSel design_of(const Pipe &P, int which) {
+    const DsqDeseqArgs *a = P.a;
+    DesignSel d;
+    if (which == DES_REDUCED) d = {a->x_red, P.red_binit, P.lam, a->p_red, P.red_cell_perm, P.red_cell_start, P.red_ncell};
+    else if (which == DES_PRIOR) d = {a->x_prior, a->prior_expanded ? P.red_binit : P.beta_init, P.lam_prior, a->p_prior,
+                                      P.cell_perm, P.cell_start, P.ncell};
+    else d = {a->x, P.beta_init, P.lam, P.p, P.cell_perm, P.cell_start, P.ncell};
+    return d;
+}
+
 static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const double *alpha, const double *weights,
                            double *mu_out, double mu_floor, double *hat, double tol, int maxit, int useQR, double minmu,
-                           const char *name, bool reduced = false) {
+                           const char *name, int which = DES_FULL) {
     const DsqDeseqArgs *a = P.a;
+    const DesignSel ds = design_of(P, which);
     BetaKernelParams kp;
     memset(&kp, 0, sizeof kp);
-    kp.n = P.n; kp.m = P.m; kp.p = reduced ? a->p_red : P.p; kp.ld = P.ld;
+    kp.n = P.n; kp.m = P.m; kp.p = ds.p; kp.ld = P.ld;
     kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
     kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
-    kp.x = reduced ? a->x_red : a->x; kp.alpha_hat = alpha; kp.contrast = P.contrast;
-    kp.beta_init = reduced ? P.red_binit : P.beta_init; kp.lambda = P.lam;
+    kp.x = ds.x; kp.alpha_hat = alpha; kp.contrast = P.contrast;
+    kp.beta_init = ds.beta_init; kp.lambda = ds.lam;
     kp.tol = tol; kp.minmu = minmu; kp.mu_floor = mu_floor; kp.maxit = maxit; kp.useQR = useQR ? 1 : 0;
     kp.beta_mat = P.beta_nat; kp.beta_var_mat = P.beta_var; kp.iter = P.beta_iter;
     kp.contrast_num = P.cnum; kp.contrast_denom = P.cden; kp.deviance = P.dev;
@@ -543,8 +564,7 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.scratch = P.scratch; kp.cscratch = P.cscratch;
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
-    if (reduced) { kp.cell_perm = P.red_cell_perm; kp.cell_start = P.red_cell_start; kp.ncell = P.red_ncell; }
-    else { kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell; }
+    kp.cell_perm = ds.cperm; kp.cell_start = ds.cstart; kp.ncell = ds.ncell;
     bool ok = false;
     char nm[32];
     snprintf(nm, sizeof nm, "%s%s", name, P.tag);
@@ -613,14 +633,15 @@ static int launch_prefit_rows(Pipe &P, const Rows &rw, const int32_t *y) {
 // usually zero, the launch then finds nothing to do): start values from P.opt_start, coefficients / standard errors /
 // logLike / fitted means written at the rows' own positions
 static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *alpha, const double *weights, double minmu,
-                        double mu_floor, double *beta, double *betaSE, double *loglike, double *mu_out, bool reduced = false) {
+                        double mu_floor, double *beta, double *betaSE, double *loglike, double *mu_out, int which = DES_FULL) {
     const DsqDeseqArgs *a = P.a;
+    const DesignSel ds = design_of(P, which);
     OptimKernelParams kp;
     memset(&kp, 0, sizeof kp);
-    kp.n = P.n; kp.m = P.m; kp.p = reduced ? a->p_red : P.p; kp.ld = P.ld;
+    kp.n = P.n; kp.m = P.m; kp.p = ds.p; kp.ld = P.ld;
     kp.y = y; kp.nf = a->nf; kp.nf_is_vector = a->nf_is_vector;
     kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
-    kp.x = reduced ? a->x_red : a->x; kp.alpha_hat = alpha; kp.lamnat = P.lam; kp.beta_start = P.opt_start;
+    kp.x = ds.x; kp.alpha_hat = alpha; kp.lamnat = ds.lam; kp.beta_start = P.opt_start;
     kp.minmu = minmu; kp.mu_floor = mu_floor;
     kp.beta = beta; kp.betaSE = betaSE; kp.conv = P.opt_conv; kp.mu_out = mu_out; kp.loglike = loglike;
     kp.rows = P.rows_opt; kp.n_dev = P.counters + cnt_optim;
@@ -696,10 +717,89 @@ static int map_est(Pipe &P, const Rows &rw, const int32_t *y, const double *mu_h
     return DSQ_OK;
 }
 
+// the start values of a GLM fit on a rank-deficient (expanded) model matrix (R/fitNbinomGLMs.R:146-155): the intercept
+// column starts at the log of the UNWEIGHTED mean normalized count, every other coefficient at 0 (or all at 1 when the
+// first column is not an intercept)
+__global__ void prior_start_kernel(Rows rw, int n, int p, int intercept, const double *bm, double *binit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_count(rw)) return;
+    const int g = rows_gene(rw, i);
+    for (int c = 0; c < p; c++) binit[(size_t)g + (size_t)n * c] = intercept ? (c == 0 ? dlog(bm[g]) : 0.0) : 1.0;
+}
+
+// fitGLMsWithPrior's first pass (R/fitNbinomGLMs.R:256-260): the MLE fit on the design with the wide prior.  Its fitted
+// means and hat diagonals are the ones the object keeps (R/core.R:1429-1431); its coefficients feed the prior variance.
+static int mle_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat) {
+    const DsqDeseqArgs *a = P.a;
+    const DsqDeseqOut *o = P.o;
+    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, a->betaTol, a->betaMaxit, a->useQR,
+                             a->minmu, "fit_beta_mle");
+    if (rc) return rc;
+    const int cnt3 = P.tag[0] ? CNT_OPT3R : CNT_OPT3;
+    RuleParams b = rule_params(P, rw);
+    b.beta = o->mle_beta; b.betaSE = P.red_se; b.wald = 0;
+    b.optim_flag = P.grid_flag; b.optim_count = P.counters + cnt3;           // (the grid flags are free between the searches)
+    hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->mle_beta, P.red_se, P.opt_ll, mu_out);
+    if (rc) return rc;
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
+// ... and its second pass (:311-325): the fit with lambda = 1 / betaPriorVar on the standard or the expanded model
+// matrix; coefficients, standard errors, Wald statistics, betaConv, betaIter and logLike are this fit's
+static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
+    const DsqDeseqArgs *a = P.a;
+    const DsqDeseqOut *o = P.o;
+    int rc;
+    if (a->prior_expanded) {
+        PrefitKernelParams pk;            // getBaseMeansAndVariances without weights on the intercept-only design
+        memset(&pk, 0, sizeof pk);
+        pk.n = P.n; pk.m = P.m; pk.p = 1; pk.ld = P.ld; pk.y = y; pk.nf = a->nf; pk.nf_is_vector = a->nf_is_vector;
+        pk.q = a->x_prior; pk.a = a->x_prior; pk.r = P.lam;                      // (only baseMean is read)
+        pk.baseMean = P.cnum; pk.baseVar = P.cden; pk.roughDisp = P.dev; pk.allZero = P.opt_conv; pk.beta_init = P.opt_ll;
+        pk.rows = rw.rows; pk.n_dev = rw.n_dev;
+        bool ok = false;
+        PIPE_HIP(launch_prefit(pk, P.st, &ok));
+        if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: prefit p=1");
+        hipLaunchKernelGGL(prior_start_kernel, ew_grid(P.n), dim3(256), 0, P.st, rw, P.n, a->p_prior, a->prior_intercept,
+                           (const double *)P.cnum, P.red_binit);
+    }
+    rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, a->betaTol, a->betaMaxit, a->useQR,
+                         a->minmu, "fit_beta_prior", DES_PRIOR);
+    if (rc) return rc;
+    LogLikeKernelParams lk;
+    memset(&lk, 0, sizeof lk);
+    lk.n = P.n; lk.m = P.m; lk.ld = P.ld; lk.y = y; lk.mu = P.red_mu; lk.disp = o->dispersion;
+    lk.weights = a->useWeights ? a->weights_norm : nullptr; lk.useWeights = a->useWeights ? 1 : 0;
+    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev;
+    capi_prof_begin(P.tag[0] ? "nbinom_loglike:refit" : "nbinom_loglike", P.n, P.st);
+    PIPE_HIP(launch_loglike(lk, P.st));
+    capi_prof_end(P.st);
+    const DesignSel ds = design_of(P, DES_PRIOR);
+    RuleParams b = rule_params(P, rw);
+    b.p = ds.p; b.beta_init = ds.beta_init;
+    b.beta = o->beta; b.betaSE = o->betaSE; b.stat = o->stat; b.pvalue = o->pvalue; b.wald = 1;
+    b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
+    b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
+    hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->beta, o->betaSE, o->logLike, P.red_mu,
+                      DES_PRIOR);
+    if (rc) return rc;
+    const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
+    RuleParams ob = rule_params(P, orw);
+    ob.p = ds.p;
+    ob.beta = o->beta; ob.betaSE = o->betaSE; ob.stat = o->stat; ob.pvalue = o->pvalue; ob.wald = 1; ob.betaConv = o->betaConv;
+    hipLaunchKernelGGL(optim_post_kernel, dim3(16), dim3(256), 0, P.st, ob);
+    PIPE_HIP(hipGetLastError());
+    return DSQ_OK;
+}
+
 // nbinomWaldTest / nbinomLRT(reduced = ~1) on the rows `rw` (R/core.R:1403-1408, 1471, 1507; 1850-1878)
 static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat, int cnt_optim) {
     const DsqDeseqArgs *a = P.a;
     const DsqDeseqOut *o = P.o;
+    if (a->betaPrior) return mle_fit(P, rw, y, mu_out, hat);         // (the prior fit follows once lambda is known)
     int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, a->betaTol, a->betaMaxit, a->useQR,
                              a->minmu, "fit_beta");
     if (rc) return rc;
@@ -743,7 +843,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         capi_prof_end(P.st);
         if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: reduced design with p=%d", a->p_red);
         rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, a->betaTol, a->betaMaxit, a->useQR,
-                             a->minmu, "fit_beta_reduced", true);
+                             a->minmu, "fit_beta_reduced", DES_REDUCED);
         if (rc) return rc;
         lk.mu = P.red_mu; lk.loglike = o->logLikeReduced;
         capi_prof_begin(P.tag[0] ? "nbinom_loglike_red:refit" : "nbinom_loglike_red", P.n, P.st);
@@ -755,7 +855,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         rb.optim_flag = P.grid_flag; rb.optim_count = P.counters + cnt3;      // (the grid flags are free between the searches)
         hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, rb);
         rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, a->minmu, 0.0, P.red_beta, P.red_se, o->logLikeReduced,
-                          P.red_mu, true);
+                          P.red_mu, DES_REDUCED);
         if (rc) return rc;
     } else if (a->test == 1) {
         InterceptKernelParams ik;
@@ -820,7 +920,7 @@ static int outlier_finish(Pipe &P, const Rows &nz, const Rows &rep, const Outlie
     const int n = P.n, m = P.m, p = P.p;
     NaRowsParams nr;
     memset(&nr, 0, sizeof nr);
-    nr.rw = rep; nr.n = n; nr.p = p; nr.allZero = o->allZero; nr.n_refit = n_refit;
+    nr.rw = rep; nr.n = n; nr.p = P.a->betaPrior ? P.a->p_prior : p; nr.allZero = o->allZero; nr.n_refit = n_refit;
     nr.beta = o->beta; nr.betaSE = o->betaSE; nr.stat = o->stat; nr.pvalue = o->pvalue; nr.betaIter = o->betaIter;
     nr.logLike = o->logLike; nr.logLikeReduced = o->logLikeReduced; nr.maxCooks = o->maxCooks; nr.betaConv = o->betaConv;
     hipLaunchKernelGGL(na_rows_kernel, ew_grid(n), dim3(256), 0, P.st, nr);
@@ -850,7 +950,7 @@ static Carve carve(int n, int p, int nt) {
     c.o_rough = takeD(nd); c.o_binit = takeD(np_); c.o_ainit = takeD(nd); c.o_la0 = takeD(nd); c.o_laout = takeD(nd);
     c.o_lchg = takeD(nd); c.o_ilp = takeD(nd); c.o_idlp = takeD(nd); c.o_llp = takeD(nd); c.o_ldlp = takeD(nd);
     c.o_lagrid = takeD(nd); c.o_ldfit = takeD(nd); c.o_lainit = takeD(nd); c.o_bnat = takeD(np_); c.o_bvar = takeD(np_);
-    c.o_biter = takeD(nd); c.o_cnum = takeD(nd); c.o_cden = takeD(nd); c.o_dev = takeD(nd); c.o_lam = takeD(2 * (size_t)p + 8);
+    c.o_biter = takeD(nd); c.o_cnum = takeD(nd); c.o_cden = takeD(nd); c.o_dev = takeD(nd); c.o_lam = takeD(3 * (size_t)p + 8);
     c.o_res = takeD(ntd); c.o_tm = takeD(ntd); c.o_td = takeD(ntd); c.o_robust = takeD(nd);
     c.o_ostart = takeD(np_); c.o_obeta = takeD(np_); c.o_ose = takeD(np_); c.o_oll = takeD(nd);
     c.o_rbinit = takeD(np_); c.o_rbeta = takeD(np_); c.o_rse = takeD(np_);
@@ -869,6 +969,13 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
     if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (a->betaPrior) {
+        if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: Wald test only (R/core.R:1787)");
+        if (!a->x_prior || a->p_prior < 1 || !o->mle_beta) return capi_fail(DSQ_ERR_ARG, "betaPrior needs x_prior / p_prior / mle_beta");
+        if (a->p_prior > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d columns in the prior pass > %d", a->p_prior, DSQ_P_REG);
+        if ((a->phases & DSQ_PH_PRIOR) && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "DSQ_PH_PRIOR needs lambda_prior");
+        if ((a->phases & DSQ_PH_OUTLIERS) && a->do_replace && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "betaPrior: the outlier refit needs lambda_prior");
+    }
     if (a->ld < a->m) return capi_fail(DSQ_ERR_ARG, "ld < m");
     // estimateDispersionsPriorVar's branch for 1..3 residual degrees of freedom matches a seeded Monte-Carlo sample
     // (R/core.R:1155-1190, R's RNG + loess): not reproducible here, so the prior variance is not computed at all
@@ -900,7 +1007,8 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     P.min_log_alpha = a->min_log_alpha;
     // ---- workspace carve (caller-owned: the row lists and counters persist between the phases of an analysis)
     const int nt_cap = a->n_trend > n ? a->n_trend : n;      // (n_trend is the capacity even in the phases without a trend)
-    Carve cv = carve(n, p, nt_cap);
+    const int pmax = (a->betaPrior && a->p_prior > p) ? a->p_prior : p;      // columns of the n x . work matrices
+    Carve cv = carve(n, pmax, nt_cap);
     if (!a->workspace || a->workspace_bytes < (int64_t)cv.bytes)
         return capi_fail(DSQ_ERR_ARG, "workspace of %lld bytes, dsq_deseq_workspace_bytes() asks for %zu",
                          (long long)a->workspace_bytes, cv.bytes);
@@ -910,7 +1018,8 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     P.la_out = D + cv.o_laout; P.last_change = D + cv.o_lchg; P.initial_lp = D + cv.o_ilp; P.initial_dlp = D + cv.o_idlp;
     P.last_lp = D + cv.o_llp; P.last_dlp = D + cv.o_ldlp; P.la_grid = D + cv.o_lagrid; P.log_dfit = D + cv.o_ldfit;
     P.la_init = D + cv.o_lainit; P.beta_nat = D + cv.o_bnat; P.beta_var = D + cv.o_bvar; P.beta_iter = D + cv.o_biter;
-    P.cnum = D + cv.o_cnum; P.cden = D + cv.o_cden; P.dev = D + cv.o_dev; P.lam = D + cv.o_lam; P.contrast = P.lam + p;
+    P.cnum = D + cv.o_cnum; P.cden = D + cv.o_cden; P.dev = D + cv.o_dev;
+    P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax;
     P.resbuf = D + cv.o_res; P.trend_mean_c = D + cv.o_tm; P.trend_disp_c = D + cv.o_td; P.robustDisp = D + cv.o_robust;
     P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
     P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = I + cv.i_cnt;
@@ -921,9 +1030,9 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     {
         size_t slab_d = 0, cscr_d = 0;
         dispatch_beta_scratch(p, n, m, a->useWeights, &slab_d, &cscr_d);
-        if (a->x_red) {
+        if (a->x_red || a->betaPrior) {
             size_t s2 = 0, c2 = 0;
-            dispatch_beta_scratch(a->p_red, n, m, a->useWeights, &s2, &c2);
+            dispatch_beta_scratch(a->betaPrior ? a->p_prior : a->p_red, n, m, a->useWeights, &s2, &c2);
             if (s2 > slab_d) slab_d = s2;
             if (c2 > cscr_d) cscr_d = c2;
         }
@@ -935,17 +1044,21 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     // dynamic-scheduling counters of the fit launches of THIS call; the row-list counters of the phases it runs
     PIPE_HIP(hipMemsetAsync(P.work_counters, 0, 64 * sizeof(int32_t), st));
     {   // the ridge (R/fitNbinomGLMs.R:73,162) and the default contrast (R/wrappers.R:105-108)
-        static thread_local double host[2 * DSQ_P_REG + 8];   // (pageable copies are staged at once)
-        for (int c = 0; c < p; c++) { host[c] = a->lambda[c]; host[p + c] = (c == 0) ? 1.0 : 0.0; }
-        PIPE_HIP(hipMemcpyAsync(P.lam, host, 2 * (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+        static thread_local double host[3 * DSQ_P_REG + 8];   // (pageable copies are staged at once)
+        for (int c = 0; c < pmax; c++) {
+            host[c] = c < p ? a->lambda[c] : 0.0;
+            host[pmax + c] = (c == 0) ? 1.0 : 0.0;
+            host[2 * pmax + c] = (a->betaPrior && a->lambda_prior && c < a->p_prior) ? a->lambda_prior[c] : 0.0;
+        }
+        PIPE_HIP(hipMemcpyAsync(P.lam, host, 3 * (size_t)pmax * sizeof(double), hipMemcpyHostToDevice, st));
     }
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
     if (a->cell_of && a->ncell > 0)
         P.ncell = capi_upload_cells(a->cell_of, m, DSQ_WS_PIPE_META + 2, st, &P.cell_perm, &P.cell_start);
-    if (a->x_red) {
-        if (a->cell_of_red && a->ncell_red > 0)
+    if (a->x_red || a->betaPrior) {
+        if (a->x_red && a->cell_of_red && a->ncell_red > 0)
             P.red_ncell = capi_upload_cells(a->cell_of_red, m, DSQ_WS_PIPE_META + 3, st, &P.red_cell_perm, &P.red_cell_start);
-        void *b;        // the reduced fit's fitted means: read once by its logLik
+        void *b;        // the reduced / prior fit's fitted means: read once by its logLik
         rc = capi_ws_get(DSQ_WS_PIPE_META + 4, (size_t)n * P.ld * sizeof(double), &b);
         if (rc) return rc;
         P.red_mu = (double *)b;
@@ -960,7 +1073,8 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
             PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(double), st));
         if (o->logLikeReduced) PIPE_HIP(hipMemsetAsync(o->logLikeReduced, 0xFF, (size_t)n * sizeof(double), st));
         for (double *v : {o->beta, o->betaSE, o->stat, o->pvalue})
-            if (v) PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * p * sizeof(double), st));
+            if (v) PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * (a->betaPrior ? a->p_prior : p) * sizeof(double), st));
+        if (a->betaPrior) PIPE_HIP(hipMemsetAsync(o->mle_beta, 0xFF, (size_t)n * p * sizeof(double), st));
         for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv})
             PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(int32_t), st));
         for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag})
@@ -1004,6 +1118,12 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         rc = map_est(P, nz, a->y, o->mu_hat, CNT_GRID2);
         if (rc) return rc;
         rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
+        if (rc) return rc;
+    }
+    // ================================================================ betaPrior: the pass with lambda = 1 / betaPriorVar
+    if ((a->phases & DSQ_PH_PRIOR) && a->betaPrior) {
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT2, 0, sizeof(int32_t), st));
+        rc = prior_fit(P, nz, a->y, CNT_OPT2);
         if (rc) return rc;
     }
     // ================================================================ count outliers
@@ -1060,6 +1180,10 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
             if (rc) return rc;
             rc = test_fit(P, rf, o->replaceCounts, o->mu_hat, nullptr, CNT_OPT2R);
             if (rc) return rc;
+            if (a->betaPrior) {
+                rc = prior_fit(P, rf, o->replaceCounts, CNT_OPT2R);
+                if (rc) return rc;
+            }
             if (!a->defer_finish) {
                 rc = outlier_finish(P, nz, rep, M, P.counters + CNT_REFIT);
                 if (rc) return rc;

@@ -7,8 +7,9 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 10, fitType = "parametric", betaPrior = FALSE, test = "Wald" or "LRT" (any full-rank
-reduced model matrix), niter = 1, more than 3 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
+Supported: DeviceEngine, p <= 10, fitType = "parametric", test = "Wald" (also with betaPrior = TRUE on the standard or
+the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
+residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
 import ctypes as C
 
@@ -34,10 +35,17 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     if dds.sizeFactors is None and np.isfinite(kw.get("minReplicatesForReplace", 7)) and \
             core.nOrMoreInCell(dds.x, kw.get("minReplicatesForReplace", 7)).any():
         return False
-    if kw.get("betaPrior") or kw.get("modelMatrix") is not None or kw.get("useT") or not kw.get("useOptim", True):
+    if kw.get("modelMatrix") is not None or not kw.get("useOptim", True):
         return False
-    if set(kw) - {"betaPrior", "modelMatrix", "useT", "useOptim", "betaTol", "maxit", "useQR", "minmu", "disp_maxit",
-                  "minReplicatesForReplace"}:
+    if kw.get("betaPrior"):
+        # nbinomWaldTest(betaPrior = TRUE): the MLE pass, the all-gene prior variance (host), the pass with the ridge
+        from . import parallel
+        if test != "Wald" or parallel.world_size() > 1 or _prior_design(dds, kw) is None:
+            return False
+    if kw.get("useT") and test != "Wald":
+        return False
+    if set(kw) - {"betaPrior", "betaPriorVar", "modelMatrixType", "factors", "modelMatrix", "useT", "df", "useOptim", "betaTol",
+                  "maxit", "useQR", "minmu", "disp_maxit", "minReplicatesForReplace"}:
         return False
     if test == "LRT":
         # reduced = ~1 takes the closed form (R/fitNbinomGLMs.R:99-137); any other reduced model matrix is fitted by the
@@ -50,6 +58,27 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     elif test != "Wald":
         return False
     return True
+
+
+def _prior_design(dds, kw):
+    """(model matrix of the beta-prior pass, its type, coefficient names) -- R/core.R:1374-1380, R/fitNbinomGLMs.R:311-325 --
+    or None when the chain does not take it (more than 10 columns; cells that differ from the design's)"""
+    factors = kw.get("factors")
+    mmt = kw.get("modelMatrixType") or ("expanded" if factors is not None else "standard")
+    if mmt == "expanded":
+        if factors is None:
+            return None
+        xe, _ = core.makeExpandedModelMatrix(factors)
+    else:
+        xe = dds.x
+    names = core.standard_model_matrix(factors)[1] if factors is not None else ["Intercept"] + ["V%d" % i for i in range(1, dds.p)]
+    xe = np.ascontiguousarray(xe, dtype=np.float64)
+    if xe.shape[0] != dds.m or xe.shape[1] > 10 or len(names) != dds.p:
+        return None
+    ca, cb = core._cells(dds.x)[0], core._cells(xe)[0]
+    if len(set(zip(ca.tolist(), cb.tolist()))) != len(set(ca.tolist())) or len(set(cb.tolist())) != len(set(ca.tolist())):
+        return None
+    return xe, mmt, names
 
 
 def _intercept_only(r):
@@ -113,7 +142,10 @@ class _Run:
         self.vec = t.empty((10, n), **f64)
         (self.baseMean, self.baseVar, self.dispGeneEst, self.dispFit, self.dispMAP, self.dispersion, self.betaIter,
          self.logLike, self.logLikeReduced, self.maxCooks) = self.vec
-        self.mat = t.empty((4, p, n), **f64)                      # beta, betaSE, stat, pvalue: (p, n) = column-major n x p
+        self.prior = _prior_design(dds, kw) if kw.get("betaPrior") else None
+        pcol = self.prior[0].shape[1] if self.prior is not None else p      # columns of beta / betaSE / stat / pvalue
+        self.mat = t.empty((4, pcol, n), **f64)                   # beta, betaSE, stat, pvalue: (p, n) = column-major n x p
+        self.mle = t.empty((p, n), **f64) if self.prior is not None else None
         self.ivec = t.empty((9, n), **i32)
         (self.allZero, self.dispGeneIter, self.dispIter, self.dispOutlier, self.betaConv, self.replace,
          self.optim_geneest, self.optim_test, _) = self.ivec
@@ -125,7 +157,7 @@ class _Run:
         self.status = t.zeros(L.DSQ_ST_COUNT, **i32)
         self.scalars = t.zeros(L.DSQ_SC_COUNT, **f64)
         lib = L.lib()
-        wsb = int(lib.dsq_deseq_workspace_bytes(n, m, p, int(n_trend)))
+        wsb = int(lib.dsq_deseq_workspace_bytes(n, m, max(p, pcol), int(n_trend)))
         self.workspace = t.empty(wsb, dtype=t.uint8, device=dev)
         # ---- design facts (host, memoised per design)
         x = dds.x
@@ -170,6 +202,13 @@ class _Run:
             ncell=int(cells.max()) + 1, replaceable=self.replaceable.ctypes.data_as(C.c_void_p), cooksCutoff=cutoff,
             trim=0.2, do_replace=int(do_replace))
         self.cooksCutoff = cutoff
+        if self.prior is not None:
+            xe = self.prior[0]
+            xp = E.design(xe)
+            self.keep.append(xp)
+            self.args.betaPrior, self.args.x_prior, self.args.p_prior = 1, _ptr(xp), int(xe.shape[1])
+            self.args.prior_expanded = int(core._rank(xe) < xe.shape[1])
+            self.args.prior_intercept = int(bool((xe[:, 0] == 1).all()))
         self.p_red = 1
         if test == "LRT" and reduced is not None and not _intercept_only(np.asarray(reduced, np.float64)):
             red = np.ascontiguousarray(reduced, dtype=np.float64)
@@ -192,7 +231,7 @@ class _Run:
             logLikeReduced=_ptr(self.logLikeReduced), maxCooks=_ptr(self.maxCooks), replace=_ptr(self.replace),
             optim_geneest=_ptr(self.optim_geneest), optim_test=_ptr(self.optim_test), mu_hat=_ptr(self.mu_hat),
             mu=_ptr(self.mu), H=_ptr(self.H), cooks=_ptr(self.cooks), replaceCounts=_ptr(self.replaceCounts),
-            status=_ptr(self.status), scalars=_ptr(self.scalars))
+            status=_ptr(self.status), scalars=_ptr(self.scalars), mle_beta=_ptr(self.mle))
 
     def launch(self, phases, trend=None):
         self.args.phases = int(phases)
@@ -256,7 +295,31 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     # optim fallback (R/fitNbinomGLMs.R:203-227), replaced-outlier rows -- are row-listed launches whose lengths live
     # on the device.  ONE look at the counters at the end (multi-GPU: one more before the all-gather of the trend's
     # input vectors).
-    if world == 1:
+    bpv = None
+    if run.prior is not None:
+        # betaPrior: the MLE pass, then ONE extra look at the device -- estimateBetaPriorVar (R/core.R:1601-1689) is an
+        # all-gene weighted quantile of the MLE coefficients, host code on n x p values -- then the pass with the ridge
+        run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
+        st0, sc0 = run.read_status()
+        if st0["N_NONZERO"] == 0:
+            raise ValueError("all genes have zero counts in every sample")
+        if st0["N_TREND"] == 0 or st0["TREND_STATUS"] != 0 or st0["N_ABOVE_MIN"] == 0:
+            return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
+                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+        bpv = kw.get("betaPriorVar")
+        if bpv is None:
+            h = E._host(t.cat([run.mle, run.baseMean[None], run.dispFit[None], run.allZero[None].to(t.float64)])).numpy()
+            nzr = h[-1] == 0
+            view = type("V", (), {"mcols": {"baseMean": h[dds.p][nzr], "dispFit": h[dds.p + 1][nzr]}})()
+            bpv, _ = core.estimateBetaPriorVar(view, h[:dds.p].T[nzr], run.prior[2], modelMatrixType=run.prior[1],
+                                               factors=kw.get("factors"))
+        bpv = np.asarray(bpv, np.float64)
+        if (bpv == 0).any():
+            raise ValueError("beta prior variances are equal to zero for some variables")
+        run.lam_prior = np.ascontiguousarray((1.0 / bpv) / np.log(2) ** 2)                 # R/fitNbinomGLMs.R:311,162
+        run.args.lambda_prior = run.lam_prior.ctypes.data_as(C.c_void_p)
+        run.launch(L.DSQ_PH_PRIOR | L.DSQ_PH_OUTLIERS)
+    elif world == 1:
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     else:
         run.launch(L.DSQ_PH_GENE_EST)
@@ -315,7 +378,19 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     conv = hi[4].astype(np.float64)
     conv[hi[4] < 0] = np.nan
     if test == "Wald":
-        mc.update(WaldStatistic=hm[2].T, WaldPvalue=hm[3].T, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
+        pval = hm[3].T
+        if kw.get("useT"):
+            # t-distribution p-values (R/core.R:1474-1503): a function of the statistic and the residual degrees of
+            # freedom alone, evaluated on the host from the downloaded column as core.nbinomWaldTest does
+            from scipy.stats import t as tdist
+            df = kw.get("df")
+            if df is None:
+                num = E.to_numpy(run.w_norm).sum(axis=1) if run.useWeights else np.full(dds.n, dds.m)   # (core's own sum)
+                df = num - dds.p
+            df = np.broadcast_to(np.asarray(df, float), (dds.n,))
+            df = np.where(df > 0, df, np.nan)
+            pval = 2 * tdist.sf(np.abs(hm[2].T), df=df[:, None])
+        mc.update(WaldStatistic=hm[2].T, WaldPvalue=pval, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
     else:
         from scipy.stats import chi2
         stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878
@@ -326,7 +401,10 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     dds.mcols = mc
     GM = E.native.GeneMajor
     dds.assays = {"mu": GM(run.mu, dds.m), "H": GM(run.H, dds.m), "cooks": GM(run.cooks, dds.m)}
-    dds.attrs.update(betaPrior=False, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
+    if run.prior is not None:
+        mc["MLE_beta"] = E._host(run.mle).numpy().T
+        dds.attrs.update(betaPriorVar=bpv, modelMatrixType=run.prior[1], factors=kw.get("factors"))
+    dds.attrs.update(betaPrior=run.prior is not None, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
                      status={**st, **{k: v for k, v in st2.items() if k.startswith(("N_REPLACE", "N_REFIT")) or k.endswith("_REFIT")}})
     if run.do_replace:
         dds.attrs["replaceable"] = run.replaceable.astype(bool)

@@ -413,6 +413,10 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
 #define DSQ_PH_TREND    2
 #define DSQ_PH_MAP_TEST 4
 #define DSQ_PH_OUTLIERS 8
+#define DSQ_PH_PRIOR    32   /* betaPrior = TRUE: the second pass of fitGLMsWithPrior (R/fitNbinomGLMs.R:311-325) with
+                                lambda_prior = 1 / betaPriorVar; DSQ_PH_MAP_TEST has run the MLE pass (:256-260) and the
+                                caller has turned mle_beta into the prior variance (estimateBetaPriorVar, R/core.R:1601-1689:
+                                an all-gene weighted quantile, host code).  Runs before DSQ_PH_OUTLIERS.                */
 #define DSQ_PH_FINISH   16   /* the two closing steps of refitWithoutOutliers that depend on whether ANY row of the whole
                                 analysis was refitted (R/core.R:2496, 2535-2546: NA results on rows that became all zero,
                                 maxCooks): part of DSQ_PH_OUTLIERS unless defer_finish is set -- a caller that shards the
@@ -467,6 +471,14 @@ typedef struct {
     int32_t ncell_red;
     int32_t defer_finish;          /* see DSQ_PH_FINISH                                                          */
     const int32_t *n_refit_global; /* device int32 for DSQ_PH_FINISH: refitted rows over ALL shards (NULL: this call's) */
+    /* nbinomWaldTest(betaPrior = TRUE) (R/core.R:1416-1432, R/fitNbinomGLMs.R:242-337), Wald only: the model matrix of
+     * the prior pass -- the design itself (modelMatrixType "standard") or the expanded one (R/expanded.R:1-18, rank
+     * deficient: start values of :146-155) -- with the same design cells as x; p, p_prior <= 10; the workspace is asked
+     * for with max(p, p_prior) columns.  beta / betaSE / stat / pvalue are then n x p_prior.                            */
+    int32_t betaPrior;
+    const double *x_prior;         /* device, m x p_prior column-major                                           */
+    int32_t p_prior, prior_expanded, prior_intercept;   /* expanded: rank-deficient start values; first column all ones */
+    const double *lambda_prior;    /* HOST, p_prior: 1 / betaPriorVar / log(2)^2; read by DSQ_PH_PRIOR / _OUTLIERS */
 } DsqDeseqArgs;
 
 typedef struct {
@@ -488,6 +500,7 @@ typedef struct {
     int32_t *replaceCounts;
     int32_t *status;                            /* DSQ_ST_COUNT */
     double *scalars;                            /* DSQ_SC_COUNT */
+    double *mle_beta;                           /* betaPrior: n x p, the MLE coefficients (mcols MLE_*), log2 scale */
 } DsqDeseqOut;
 
 int dsq_deseq_dev(const DsqDeseqArgs *args, const DsqDeseqOut *out, void *stream);

@@ -142,15 +142,62 @@ def test_lrt_against_a_reduced_model_matrix(E):
     _compare(a, b, "LRT vs 3-column reduced")
 
 
+def test_wald_t_distribution_pvalues(E):
+    """useT = TRUE (R/core.R:1474-1503): p-values from the t distribution with m - p (or sum(weights) - p) degrees of
+    freedom -- same statistic, the p-value column evaluated on the host from it"""
+    x = simulate.design_batch_condition(24)
+    d = simulate.make_counts(300, x, seed=17)
+    a, b = _both(E, d["counts"], x, d["size_factors"], useT=True, minReplicatesForReplace=np.inf)
+    _compare(a, b, "useT")
+    w = np.random.default_rng(3).uniform(0.3, 1.0, d["counts"].shape)
+    a, b = _both(E, d["counts"], x, d["size_factors"], weights=w, useT=True, minReplicatesForReplace=np.inf)
+    _compare(a, b, "useT + weights")
+    from scipy.stats import norm
+    assert not np.allclose(b.mcols["WaldPvalue"], 2 * norm.sf(np.abs(b.mcols["WaldStatistic"])), rtol=1e-3)
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)
     dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E)
-    assert not fused.supported(dds, betaPrior=True)
+    assert not fused.supported(dds, useOptim=False)
+    assert not fused.supported(dds, betaPrior=True, test="LRT", reduced=np.ones((12, 1)))
     assert not fused.supported(dds, test="LRT", reduced=np.column_stack([x[:, 0], x[:, 0] * 2, x[:, 1]]))   # p_red >= p
     assert not fused.supported(dds, test="LRT", reduced=np.zeros((12, 1)))
-    fused.DESeq(dds, betaPrior=True, factors={"condition": x[:, 1].astype(int)})
+    fused.DESeq(dds, useOptim=False)
     assert "WaldPvalue" in dds.mcols and not dds.attrs.get("fused")
+
+
+@pytest.mark.parametrize("mode", ["expanded_weights", "expanded_three_levels", "standard", "given_variance"])
+def test_beta_prior(E, mode):
+    """nbinomWaldTest(betaPrior = TRUE) (R/core.R:1416-1432, R/fitNbinomGLMs.R:242-337; BASELINE configs[4]): MLE pass ->
+    estimateBetaPriorVar on the host -> the pass with lambda = 1 / betaPriorVar on the expanded (rank-deficient) or the
+    standard model matrix, for the main rows and for the refit of the replaced rows; MLE_beta kept"""
+    rng = np.random.default_rng(12)
+    weights = None
+    kw = dict(betaPrior=True)
+    if mode == "expanded_three_levels":
+        factors = {"condition": np.repeat([0, 1, 2], 8)}
+    else:
+        factors = {"condition": np.repeat([0, 1], 10)}
+    x, _ = core.standard_model_matrix(factors)
+    d = simulate.make_counts(500, x, seed=44)
+    counts = _spike_outliers(d["counts"], np.random.default_rng(6), k=5)
+    counts[5] = 0
+    counts[5, -2:] = 4000                                    # a row for the optim fallback
+    if mode == "expanded_weights":
+        weights = rng.uniform(0.05, 1.0, counts.shape)
+        weights[rng.uniform(size=counts.shape) < 0.02] = 0.0
+    if mode != "standard":
+        kw["factors"] = factors
+    if mode == "given_variance":
+        kw["betaPriorVar"] = np.array([1e6, 0.8, 0.8])
+    a, b = _both(E, counts, x, d["size_factors"], weights=weights, **kw)
+    _compare(a, b, "betaPrior " + mode)
+    assert_same(np.asarray(a.attrs["betaPriorVar"]), np.asarray(b.attrs["betaPriorVar"]), "betaPriorVar")
+    assert b.mcols["beta"].shape[1] == (2 if mode == "standard" else x.shape[1] + 1)
+    assert b.mcols["MLE_beta"].shape[1] == x.shape[1]
+    assert b.attrs["status"]["N_REFIT"] >= 1 or weights is not None
 
 
 def test_low_residual_df_and_rank_are_left_to_core(E):

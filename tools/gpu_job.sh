@@ -43,6 +43,7 @@ PY
     stats)
       cfg=${F[1]}; d=$O/prof_$cfg; rm -rf "$d"
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$d" -o trace -- python "$R/bench.py" --config "$cfg" --steps 5 --warmup 2 --no-cpu-baseline --no-hostpath > "$O/stats_$cfg.log" 2>&1)
+      python tools/timeline.py "$(find "$d" -name '*.db' | head -1)" > "$O/timeline_$cfg.txt" 2>&1
       python profiles/summarize_rocpd.py "$(find "$d" -name '*.db' | head -1)" > "$O/stats_$cfg.md" 2>> "$O/stats_$cfg.log"; echo "[gpu_job] stats $cfg rc=$?"; head -25 "$O/stats_$cfg.md"
       rm -rf "$d";;
     pmc)
