@@ -78,6 +78,32 @@ DSQ_DEV double wave_allreduce(double v) {
     return v;
 }
 
+// value of lane `src` (a compile-time-known or wave-uniform lane) in every lane: v_readlane, no LDS
+DSQ_DEV double lane_read(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// all-reduce of TWO values at the price of little more than one: the first butterfly step hands the odd lanes the b sums
+// and the even lanes the a sums (each lane adds its own half to the partner's matching half -- the additions
+// a[l] + a[l^1] and b[l] + b[l^1] of the plain butterfly, each done once instead of twice), the remaining five steps
+// run on the one combined register (the partners l ^ 2 .. l ^ 32 have the parity of l).  Every even lane ends with the
+// bits wave_allreduce(a) gives, every odd lane with those of wave_allreduce(b); both are then read back wave-uniformly.
+DSQ_DEV void wave_allreduce_pair(double &a, double &b, int lane) {
+    const bool odd = (lane & 1) != 0;
+    const double keep = odd ? b : a, send = odd ? a : b;
+    double v = keep + lane_xor1(send);
+    v = v + lane_xor2(v);
+    v = v + lane_xor4(v);
+    v = v + lane_xor8(v);
+    double x, y;
+    lane_pair16(v, x, y); v = x + y;
+    lane_pair32(v, x, y); v = x + y;
+    a = lane_read(v, 0);
+    b = lane_read(v, 1);
+}
+
 // all-reduce of a value that is +0.0 outside lanes [0, nlive) (nlive wave-uniform): when the live lanes sit in the first
 // row(s) of 16 the cross-row steps only ever add +0.0, which is done here without the permlane swaps.  Lanes < nlive end
 // with the same bits as wave_allreduce gives (x + 0.0 keeps the -0.0 -> +0.0 behaviour of the skipped additions); the
@@ -111,12 +137,6 @@ DSQ_UNROLL_P
 
 DSQ_DEV double wave_bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
-// value of lane `src` (a compile-time-known or wave-uniform lane) in every lane: v_readlane, no LDS
-DSQ_DEV double lane_read(double v, int src) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 
 // Gene scheduling of the persistent fit kernels.  Every wave starts on gene (block * waves + wave); the
 // iteration counts of the fits are data dependent (2..100), so instead of a fixed grid stride the wave

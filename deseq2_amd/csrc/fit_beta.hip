@@ -614,7 +614,8 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             double a1 = 0.0, a2 = 0.0;
             int cur = 0;
             auto close_cell = [&]() {
-                const double s = wave_allreduce(a1), tt = wave_allreduce(a2);
+                double s = a1, tt = a2;
+                wave_allreduce_pair(s, tt, lane);               // the bits of two butterflies, about half the instructions
                 if (lane == cur) { Sl = s; Tl = tt; }
                 a1 = 0.0; a2 = 0.0;
             };
@@ -647,11 +648,28 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 }
                 const int c_lo = __builtin_amdgcn_readfirstlane(cmy);
                 const int c_hi = __builtin_amdgcn_readlane(cmy, (k0 + 64 <= m) ? 63 : last_lane_of_tail);
-                for (int c = c_lo; c <= c_hi; c++) {
-                    if (c != cur) { close_cell(); cur = c; }
-                    const bool mine = cmy == c;
-                    a1 += mine ? wv : 0.0;
-                    a2 += mine ? wz : 0.0;
+                // general form: for c = c_lo .. c_hi { if (c != cur) { close; cur = c; } a += (cmy == c) ? w : 0 }; a trip inside
+                // one cell (lanes past the end hold +0.0, what the masked form adds) and a trip across one boundary are
+                // written out -- the same additions in the same order, without the loop
+                if (c_lo == c_hi) {
+                    if (c_lo != cur) { close_cell(); cur = c_lo; }
+                    a1 += wv;
+                    a2 += wz;
+                } else if (c_hi == c_lo + 1) {
+                    if (c_lo != cur) { close_cell(); cur = c_lo; }
+                    const bool first = cmy == c_lo, second = cmy == c_hi;
+                    a1 += first ? wv : 0.0;
+                    a2 += first ? wz : 0.0;
+                    close_cell(); cur = c_hi;
+                    a1 += second ? wv : 0.0;
+                    a2 += second ? wz : 0.0;
+                } else {
+                    for (int c = c_lo; c <= c_hi; c++) {
+                        if (c != cur) { close_cell(); cur = c; }
+                        const bool mine = cmy == c;
+                        a1 += mine ? wv : 0.0;
+                        a2 += mine ? wz : 0.0;
+                    }
                 }
             }
             close_cell();

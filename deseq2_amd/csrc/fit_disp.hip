@@ -126,11 +126,18 @@ DSQ_UNROLL_P
             for (int k = 0; k < K; k++) { Sl[k] = 0.0; acc[k] = 0.0; }
             int cur = 0;
             auto close_cell = [&]() {
-                _Pragma("unroll")
-                for (int k = 0; k < K; k++) {
-                    const double v = wave_allreduce(acc[k]);
-                    if (lane == cur) Sl[k] = v;
-                    acc[k] = 0.0;
+                if constexpr (K == 2) {
+                    double s0 = acc[0], s1 = acc[1];
+                    wave_allreduce_pair(s0, s1, lane);          // same bits as two butterflies, ~half the instructions
+                    if (lane == cur) { Sl[0] = s0; Sl[1] = s1; }
+                    acc[0] = 0.0; acc[1] = 0.0;
+                } else {
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) {
+                        const double v = wave_allreduce(acc[k]);
+                        if (lane == cur) Sl[k] = v;
+                        acc[k] = 0.0;
+                    }
                 }
             };
             const int tail_lane = (m - 1) & 63;
@@ -153,11 +160,28 @@ DSQ_UNROLL_P
                 if (useCR) {
                     const int c_lo = __builtin_amdgcn_readfirstlane(cmy);
                     const int c_hi = __builtin_amdgcn_readlane(cmy, (k0 + 64 <= m) ? 63 : tail_lane);
-                    for (int c = c_lo; c <= c_hi; c++) {
-                        if (c != cur) { close_cell(); cur = c; }
-                        const bool mine = cmy == c;
+                    // the general form is: for c = c_lo .. c_hi { if (c != cur) { close; cur = c; } acc += (cmy == c) ? wd : 0 }.
+                    // A trip inside ONE cell (lanes past the end hold wd = +0.0, what the masked form adds for them) and
+                    // a trip across ONE boundary are written out: the same additions in the same order, without the loop
+                    if (c_lo == c_hi) {
+                        if (c_lo != cur) { close_cell(); cur = c_lo; }
                         _Pragma("unroll")
-                        for (int k = 0; k < K; k++) acc[k] += mine ? wd[k] : 0.0;
+                        for (int k = 0; k < K; k++) acc[k] += wd[k];
+                    } else if (c_hi == c_lo + 1) {
+                        if (c_lo != cur) { close_cell(); cur = c_lo; }
+                        const bool first = cmy == c_lo, second = cmy == c_hi;
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) acc[k] += first ? wd[k] : 0.0;
+                        close_cell(); cur = c_hi;
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) acc[k] += second ? wd[k] : 0.0;
+                    } else {
+                        for (int c = c_lo; c <= c_hi; c++) {
+                            if (c != cur) { close_cell(); cur = c; }
+                            const bool mine = cmy == c;
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) acc[k] += mine ? wd[k] : 0.0;
+                        }
                     }
                 }
             }

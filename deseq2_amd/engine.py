@@ -228,7 +228,7 @@ class HostEngine:
     def replace_outliers(self, y, nf, cooks, cooksCutoff, replaceable, trim=0.2):
         """replaceOutliers: new counts handle + per-gene `replace` flag"""
         r = self.fns.replaceOutliers(y, nf, cooks, cooksCutoff, replaceable, trim)
-        return {"counts": np.ascontiguousarray(r["counts"], dtype=np.int32), "replace": r["replace"]}
+        return {"counts": np.asfortranarray(r["counts"], dtype=np.int32), "replace": r["replace"]}     # (stays column-major)
 
     def masked_row_max(self, h, use, zero):
         """apply(h[, use], 1, max) after h[, zero] <- 0   (refitWithoutOutliers, R/core.R:2542-2545)"""
@@ -236,7 +236,10 @@ class HostEngine:
         return a[:, np.asarray(use, bool)].max(axis=1)
 
     def _ones(self, n, m):
-        """the all-ones weight matrix R passes when there are no weights (R/fitNbinomGLMs.R:85): one per shape"""
+        """the all-ones weight matrix R passes when there are no weights (R/fitNbinomGLMs.R:85): one per shape.  The
+        engine library never reads unused weights (useWeights = FALSE), so for it no matrix is built at all."""
+        if getattr(self.fns, "IGNORES_UNUSED_WEIGHTS", False):
+            return None
         if getattr(self, "_ones_cache", None) is None or self._ones_cache.shape != (n, m):
             self._ones_cache = np.ones((n, m), order="F")
         return self._ones_cache

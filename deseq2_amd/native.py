@@ -18,6 +18,9 @@ import numpy as np
 from . import _lib as L
 
 
+IGNORES_UNUSED_WEIGHTS = True      # weightsSEXP may be None when useWeightsSEXP is FALSE (HostEngine builds no all-ones matrix)
+
+
 def _fcol(a, dtype=np.float64):
     """numpy array in R memory order (column-major)"""
     return np.asfortranarray(np.asarray(a, dtype=dtype))
