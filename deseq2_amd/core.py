@@ -651,16 +651,23 @@ def makeExpandedModelMatrix(factors):
     return np.column_stack(cols), names
 
 
-def Hmisc_wtd_quantile(x, weights, prob, normwt=True):
-    """R/core.R:2762-2800 (type = 'quantile'), one probability"""
+def Hmisc_wtd_quantile(x, weights, prob, normwt=True, sorter=None):
+    """R/core.R:2762-2800 (type = 'quantile'), one probability.  `sorter(values)` may supply the stable ascending
+    order of `values` (an engine can sort on the device; the stable order of a vector is unique, so nothing changes)."""
     x = np.asarray(x, float); w = np.asarray(weights, float)
     keep = ~(np.isnan(w) | (w == 0))
     x, w = x[keep], w[keep]
     if normwt:
         w = w * x.size / w.sum()
-    o = np.argsort(x, kind="stable")
+    o = np.argsort(x, kind="stable") if sorter is None else np.asarray(sorter(x))
     x, w = x[o], w[o]
-    ux, inv = np.unique(x, return_inverse=True)
+    # the distinct values of the sorted vector and, per value, the sum of its weights in index order (what
+    # unique(return_inverse) + bincount give, without sorting a second time)
+    head = np.empty(x.size, bool)
+    head[:1] = True
+    np.not_equal(x[1:], x[:-1], out=head[1:])
+    ux = x[head]
+    inv = np.cumsum(head) - 1
     wts = np.bincount(inv, weights=w)
     n = wts.sum()
     order = 1 + (n - 1) * prob
@@ -675,9 +682,9 @@ def Hmisc_wtd_quantile(x, weights, prob, normwt=True):
     return (1 - frac) * stepq(low) + frac * stepq(high)
 
 
-def matchWeightedUpperQuantileForVariance(x, weights, upperQuantile=0.05):
+def matchWeightedUpperQuantileForVariance(x, weights, upperQuantile=0.05, sorter=None):
     """R/core.R:2416-2419"""
-    sdEst = Hmisc_wtd_quantile(np.abs(x), weights, 1 - upperQuantile, normwt=True) / sps.ndtri(1 - upperQuantile / 2)
+    sdEst = Hmisc_wtd_quantile(np.abs(x), weights, 1 - upperQuantile, normwt=True, sorter=sorter) / sps.ndtri(1 - upperQuantile / 2)
     return float(sdEst) ** 2
 
 
@@ -687,7 +694,7 @@ def matchUpperQuantileForVariance(x, upperQuantile=0.05):
 
 
 def estimateBetaPriorVar(dds, mleBetaMatrix, names, betaPriorMethod="weighted", upperQuantile=0.05,
-                         modelMatrixType="standard", factors=None):
+                         modelMatrixType="standard", factors=None, sorter=None):
     """R/core.R:1601-1689.  `mleBetaMatrix` (log2 scale) are the MLE coefficients of the standard
     design whose column names are `names`."""
     beta = np.asarray(mleBetaMatrix, float)
@@ -714,7 +721,7 @@ def estimateBetaPriorVar(dds, mleBetaMatrix, names, betaPriorMethod="weighted", 
         elif betaPriorMethod == "quantile":
             pv[c] = matchUpperQuantileForVariance(xcol[use], upperQuantile)
         else:
-            pv[c] = matchWeightedUpperQuantileForVariance(xcol[use], weights[use], upperQuantile)
+            pv[c] = matchWeightedUpperQuantileForVariance(xcol[use], weights[use], upperQuantile, sorter=sorter)
     for c, nm in enumerate(names):
         if nm == "Intercept":
             pv[c] = 1e6                                               # :1669-1671

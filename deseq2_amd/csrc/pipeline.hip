@@ -15,6 +15,7 @@
 #include "dsq_math.hpp"
 #include "dsq_wave.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -494,8 +495,13 @@ struct Pipe {
     int any3, maxcell, all_replaceable;
 };
 
-enum { CNT_NZ = 0, CNT_GRID1, CNT_TREND, CNT_GRID2, CNT_OPT1, CNT_OPT2, CNT_REP, CNT_REFIT, CNT_GRID1R, CNT_GRID2R,
-       CNT_OPT1R, CNT_OPT2R, CNT_OPT3, CNT_OPT3R, CNT_N = 16 };
+// the row-list counters of the chain ARE the caller's status block (no copies at the end of a call): a counter sits at
+// the index of the DSQ_ST_* entry that reports it; the two spare entries count the optim rows of the reduced / MLE fits
+enum { CNT_NZ = DSQ_ST_N_NONZERO, CNT_GRID1 = DSQ_ST_N_GRID_GENEEST, CNT_TREND = DSQ_ST_N_TREND, CNT_GRID2 = DSQ_ST_N_GRID_MAP,
+       CNT_OPT1 = DSQ_ST_N_OPTIM_GENEEST, CNT_OPT2 = DSQ_ST_N_OPTIM_TEST, CNT_REP = DSQ_ST_N_REPLACE, CNT_REFIT = DSQ_ST_N_REFIT,
+       CNT_GRID1R = DSQ_ST_N_GRID_GENEEST_REFIT, CNT_GRID2R = DSQ_ST_N_GRID_MAP_REFIT, CNT_OPT1R = DSQ_ST_N_OPTIM_GENEEST_REFIT,
+       CNT_OPT2R = DSQ_ST_N_OPTIM_TEST_REFIT, CNT_OPT3 = 14, CNT_OPT3R = 15, CNT_N = DSQ_ST_COUNT };
+static_assert(DSQ_ST_N_OPTIM_TEST_REFIT < 14 && DSQ_ST_COUNT == 16, "status block layout");
 
 static int *next_work_counter(Pipe &P) {
     int *c = P.work_counters + (P.next_counter % 60);
@@ -1022,7 +1028,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax;
     P.resbuf = D + cv.o_res; P.trend_mean_c = D + cv.o_tm; P.trend_disp_c = D + cv.o_td; P.robustDisp = D + cv.o_robust;
     P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
-    P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = I + cv.i_cnt;
+    P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = o->status;
     P.work_counters = I + cv.i_wc;
     P.opt_start = D + cv.o_ostart; P.opt_beta = D + cv.o_obeta; P.opt_se = D + cv.o_ose; P.opt_ll = D + cv.o_oll;
     P.rows_opt = I + cv.i_opt; P.opt_conv = I + cv.i_oconv;
@@ -1066,19 +1072,26 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
 
     // ================================================================ gene-wise estimates
     if (a->phases & DSQ_PH_GENE_EST) {
-        PIPE_HIP(hipMemsetAsync(P.counters, 0, CNT_N * sizeof(int32_t), st));
-        PIPE_HIP(hipMemsetAsync(o->status, 0, DSQ_ST_COUNT * sizeof(int32_t), st));
-        // results of rows that turn out all-zero stay NA: 0xFF bytes are a NaN / -1
-        for (double *v : {o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter, o->logLike, o->maxCooks})
-            PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(double), st));
-        if (o->logLikeReduced) PIPE_HIP(hipMemsetAsync(o->logLikeReduced, 0xFF, (size_t)n * sizeof(double), st));
+        // results of rows that turn out all-zero stay NA: 0xFF bytes are a NaN / -1.  The outputs of a caller usually sit
+        // side by side (packed blocks): neighbouring regions with the same fill byte are set by ONE memset
+        struct Fill { char *p; size_t bytes; int val; };
+        std::vector<Fill> fills;
+        auto fill = [&](void *p_, size_t bytes, int val) { if (p_ && bytes) fills.push_back({(char *)p_, bytes, val}); };
+        fill(o->status, DSQ_ST_COUNT * sizeof(int32_t), 0);
+        for (double *v : {o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter, o->logLike, o->maxCooks, o->logLikeReduced})
+            fill(v, (size_t)n * sizeof(double), 0xFF);
         for (double *v : {o->beta, o->betaSE, o->stat, o->pvalue})
-            if (v) PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * (a->betaPrior ? a->p_prior : p) * sizeof(double), st));
-        if (a->betaPrior) PIPE_HIP(hipMemsetAsync(o->mle_beta, 0xFF, (size_t)n * p * sizeof(double), st));
-        for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv})
-            PIPE_HIP(hipMemsetAsync(v, 0xFF, (size_t)n * sizeof(int32_t), st));
-        for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag})
-            PIPE_HIP(hipMemsetAsync(v, 0, (size_t)n * sizeof(int32_t), st));
+            fill(v, (size_t)n * (a->betaPrior ? a->p_prior : p) * sizeof(double), 0xFF);
+        if (a->betaPrior) fill(o->mle_beta, (size_t)n * p * sizeof(double), 0xFF);
+        for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv}) fill(v, (size_t)n * sizeof(int32_t), 0xFF);
+        for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag}) fill(v, (size_t)n * sizeof(int32_t), 0);
+        std::sort(fills.begin(), fills.end(), [](const Fill &x, const Fill &y) { return x.p < y.p; });
+        for (size_t i = 0; i < fills.size();) {
+            size_t j = i + 1, bytes = fills[i].bytes;
+            while (j < fills.size() && fills[j].val == fills[i].val && fills[j].p == fills[i].p + bytes) bytes += fills[j++].bytes;
+            PIPE_HIP(hipMemsetAsync(fills[i].p, fills[i].val, bytes, st));
+            i = j;
+        }
         const Rows all = {nullptr, nullptr, n};
         rc = launch_prefit_rows(P, all, a->y);                                   // getBaseMeansAndVariances + moments
         if (rc) return rc;
@@ -1133,7 +1146,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         if (rc) return rc;
         int32_t *dperm = M.dperm, *din3 = M.din3, *drepl = M.drepl, *dstart = M.dstart;
         const int any3 = M.any3, maxcell = M.maxcell;
-        for (int k = CNT_REP; k < CNT_N; k++) PIPE_HIP(hipMemsetAsync(P.counters + k, 0, sizeof(int32_t), st));
+        PIPE_HIP(hipMemsetAsync(P.counters + CNT_REP, 0, (CNT_N - CNT_REP) * sizeof(int32_t), st));      // REP .. OPT3R
 
         CooksKernelParams ck;
         memset(&ck, 0, sizeof ck);
@@ -1200,14 +1213,6 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         rc = outlier_finish(P, nz, rep, M, a->n_refit_global ? a->n_refit_global : P.counters + CNT_REFIT);
         if (rc) return rc;
     }
-    // counters -> status block (one small device-to-device copy per phase set)
-    static const int map_[][2] = {{CNT_NZ, DSQ_ST_N_NONZERO}, {CNT_GRID1, DSQ_ST_N_GRID_GENEEST}, {CNT_TREND, DSQ_ST_N_TREND},
-                                  {CNT_GRID2, DSQ_ST_N_GRID_MAP}, {CNT_OPT1, DSQ_ST_N_OPTIM_GENEEST}, {CNT_OPT2, DSQ_ST_N_OPTIM_TEST},
-                                  {CNT_REP, DSQ_ST_N_REPLACE}, {CNT_REFIT, DSQ_ST_N_REFIT}, {CNT_GRID1R, DSQ_ST_N_GRID_GENEEST_REFIT},
-                                  {CNT_GRID2R, DSQ_ST_N_GRID_MAP_REFIT}, {CNT_OPT1R, DSQ_ST_N_OPTIM_GENEEST_REFIT},
-                                  {CNT_OPT2R, DSQ_ST_N_OPTIM_TEST_REFIT}};
-    for (auto &kv : map_)
-        PIPE_HIP(hipMemcpyAsync(o->status + kv[1], P.counters + kv[0], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return DSQ_OK;
 }
 

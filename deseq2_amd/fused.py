@@ -138,24 +138,34 @@ class _Run:
             self.w_floor = E.clamp_min(self.w_norm, 1e-6)
             ok = E.weights_ok_dev(self.w_norm, dds.x, 1e-2, core._rank(dds.x) == p)
             self.force_zero = (~ok).to(t.int32)
-        # ---- outputs
-        self.vec = t.empty((10, n), **f64)
-        (self.baseMean, self.baseVar, self.dispGeneEst, self.dispFit, self.dispMAP, self.dispersion, self.betaIter,
-         self.logLike, self.logLikeReduced, self.maxCooks) = self.vec
+        # ---- outputs: every per-gene column in ONE device block (a single copy brings them all to the host):
+        #      vec (10 x n f64) | mat (4 x pcol x n f64) | [mle (p x n f64)] | scalars | ivec (9 x n i32) | status
         self.prior = _prior_design(dds, kw) if kw.get("betaPrior") else None
         pcol = self.prior[0].shape[1] if self.prior is not None else p      # columns of beta / betaSE / stat / pvalue
-        self.mat = t.empty((4, pcol, n), **f64)                   # beta, betaSE, stat, pvalue: (p, n) = column-major n x p
-        self.mle = t.empty((p, n), **f64) if self.prior is not None else None
-        self.ivec = t.empty((9, n), **i32)
+        nmle = p * n if self.prior is not None else 0
+        nd = 10 * n + 4 * pcol * n + nmle + L.DSQ_SC_COUNT
+        ni = 9 * n + L.DSQ_ST_COUNT + 2
+        self.blob = t.empty(nd * 8 + ni * 4, dtype=t.uint8, device=dev)
+        dpart, ipart = self.blob[: nd * 8].view(t.float64), self.blob[nd * 8:].view(t.int32)
+        self._nd, self._ni, self._pcol, self._nmle = nd, ni, pcol, nmle
+        self.vec = dpart[: 10 * n].view(10, n)
+        (self.baseMean, self.baseVar, self.dispGeneEst, self.dispFit, self.dispMAP, self.dispersion, self.betaIter,
+         self.logLike, self.logLikeReduced, self.maxCooks) = self.vec
+        self.mat = dpart[10 * n: 10 * n + 4 * pcol * n].view(4, pcol, n)   # beta, betaSE, stat, pvalue: (p, n) = column-major n x p
+        self.mle = dpart[10 * n + 4 * pcol * n: 10 * n + 4 * pcol * n + nmle].view(p, n) if nmle else None
+        self.scalars = dpart[nd - L.DSQ_SC_COUNT:]
+        self.ivec = ipart[: 9 * n].view(9, n)
+        self.status = ipart[9 * n: 9 * n + L.DSQ_ST_COUNT]
+        self.negflag = ipart[9 * n + L.DSQ_ST_COUNT:]
         (self.allZero, self.dispGeneIter, self.dispIter, self.dispOutlier, self.betaConv, self.replace,
          self.optim_geneest, self.optim_test, _) = self.ivec
+        if self.neg is not None:
+            self.negflag[0] = self.neg.to(t.int32)
         self.mu_hat = t.empty((n, ld), **f64)
         self.mu = t.empty((n, ld), **f64)
         self.H = t.empty((n, ld), **f64)
         self.cooks = t.empty((n, ld), **f64)
         self.replaceCounts = t.empty((n, ld), **i32)
-        self.status = t.zeros(L.DSQ_ST_COUNT, **i32)
-        self.scalars = t.zeros(L.DSQ_SC_COUNT, **f64)
         lib = L.lib()
         wsb = int(lib.dsq_deseq_workspace_bytes(n, m, max(p, pcol), int(n_trend)))
         self.workspace = t.empty(wsb, dtype=t.uint8, device=dev)
@@ -165,8 +175,9 @@ class _Run:
         self.keep = [dq, da, dr]
         minDisp = 1e-8
         self.minDisp = minDisp
-        grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 20)                    # R/wrappers.R:70-72
-        self.grid = E._vec(grid)
+        self.grid = E._cache.get(("grid", m))                                       # R/wrappers.R:70-72
+        if self.grid is None:
+            self.grid = E._cache[("grid", m)] = E._vec(np.linspace(np.log(1e-8), np.log(max(10, m)), 20))
         self.lam = np.ascontiguousarray(np.full(p, 1e-6) / np.log(2) ** 2)          # R/fitNbinomGLMs.R:73,162
         xim = core.xim_size_factors(dds.sizeFactors) if dds.sizeFactors is not None else E.xim(dds.nf)
         facts = _design_facts(E, x, minReplicatesForReplace)
@@ -180,7 +191,14 @@ class _Run:
         # size factors: every kernel of the chain reads the m-vector (same values as the rows of the n x m matrix R
         # builds from them, R/core.R:2221-2227, so the same bits) -- 8 B less per sample and pass, no layout conversion
         if dds.sizeFactors is not None:
-            self.sf_dev = E._vec(np.ascontiguousarray(dds.sizeFactors, np.float64))
+            sfh = np.ascontiguousarray(dds.sizeFactors, np.float64)
+            key = ("sf", sfh.tobytes())
+            self.sf_dev = E._cache.get(key)
+            if self.sf_dev is None:
+                if sum(1 for k in E._cache if k[0] == "sf") > 8:
+                    for k in [k for k in E._cache if k[0] == "sf"]:
+                        del E._cache[k]
+                self.sf_dev = E._cache[key] = E._vec(sfh)
             nf_ptr, nf_vec = _ptr(self.sf_dev), 1
         else:
             nf_ptr, nf_vec = _ptr(dds.nf.t), 0
@@ -268,6 +286,19 @@ class _Run:
             raise ValueError("all(weights >= 0) is not TRUE")
         return st, sc
 
+    def read_all(self):
+        """the whole result block in ONE device-to-host copy + stream sync: counters, scalars and every per-gene column"""
+        n, pc = self.n, self._pcol
+        h = self.E._host(self.blob).numpy()
+        hd, hi = h[: self._nd * 8].view(np.float64), h[self._nd * 8:].view(np.int32)
+        st = {k: int(hi[9 * n + i]) for k, i in L.DSQ_ST.items()}
+        if self.neg is not None and hi[9 * n + L.DSQ_ST_COUNT] != 0:
+            raise ValueError("all(weights >= 0) is not TRUE")
+        hv = hd[: 10 * n].reshape(10, n)
+        hm = hd[10 * n: 10 * n + 4 * pc * n].reshape(4, pc, n)
+        hmle = hd[10 * n + 4 * pc * n: 10 * n + 4 * pc * n + self._nmle].reshape(self.p, n) if self._nmle else None
+        return st, hd[self._nd - L.DSQ_SC_COUNT:], hv, hm, hi[: 9 * n].reshape(9, n), hmle
+
 
 def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None, **kw):
     """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
@@ -311,8 +342,10 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
             h = E._host(t.cat([run.mle, run.baseMean[None], run.dispFit[None], run.allZero[None].to(t.float64)])).numpy()
             nzr = h[-1] == 0
             view = type("V", (), {"mcols": {"baseMean": h[dds.p][nzr], "dispFit": h[dds.p + 1][nzr]}})()
+            def dev_sort(v):           # the (unique) stable order, sorted on the device: the host has nothing else to do
+                return E._host(t.sort(t.as_tensor(v, device=E.device), stable=True).indices).numpy()
             bpv, _ = core.estimateBetaPriorVar(view, h[:dds.p].T[nzr], run.prior[2], modelMatrixType=run.prior[1],
-                                               factors=kw.get("factors"))
+                                               factors=kw.get("factors"), sorter=dev_sort)
         bpv = np.asarray(bpv, np.float64)
         if (bpv == 0).any():
             raise ValueError("beta prior variances are equal to zero for some variables")
@@ -326,14 +359,15 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
         run.args.defer_finish = 1
         run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS, trend=trend)
-    st, sc = run.read_status()
     if world > 1 and run.do_replace:
+        st, sc = run.read_status()
         # refitWithoutOutliers' closing steps (NA results on rows that became all zero, maxCooks) ask whether ANY row of
         # the whole object was refitted (R/core.R:2496): the shards add up their counts, then each finishes its rows
         total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
         run.n_refit_all = t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=E.device)
         run.args.n_refit_global = _ptr(run.n_refit_all)
         run.launch(L.DSQ_PH_FINISH)
+    st, sc, hv, hm, hi, hmle = run.read_all()
     st2 = st
     # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
     # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
@@ -351,9 +385,6 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
                           minReplicatesForReplace=minReplicatesForReplace, **kw)
     fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
           "dispPriorVar": float(sc[3])}
-    hv = E._host(run.vec).numpy()
-    hm = E._host(run.mat).numpy()
-    hi = E._host(run.ivec).numpy()
     allZero = hi[0].astype(bool)
     # rows that were all zero from the start carry NA in every column; a row that only BECAME all zero when its outlier
     # was replaced (newAllZero, R/core.R:2492) keeps its "intermediate" columns and gets NA in the "results" columns
@@ -402,7 +433,7 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     GM = E.native.GeneMajor
     dds.assays = {"mu": GM(run.mu, dds.m), "H": GM(run.H, dds.m), "cooks": GM(run.cooks, dds.m)}
     if run.prior is not None:
-        mc["MLE_beta"] = E._host(run.mle).numpy().T
+        mc["MLE_beta"] = hmle.T
         dds.attrs.update(betaPriorVar=bpv, modelMatrixType=run.prior[1], factors=kw.get("factors"))
     dds.attrs.update(betaPrior=run.prior is not None, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
                      status={**st, **{k: v for k, v in st2.items() if k.startswith(("N_REPLACE", "N_REFIT")) or k.endswith("_REFIT")}})
