@@ -295,37 +295,35 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
         double b0 = c0, b1 = c1;
         bool converged = false, invalid = false;
         double devold = 0.0;
+        // One sweep over the genes and ONE grid reduction per IRLS pass: the deviance sums at the current (b0, b1) and
+        // the normal-equation sums the NEXT pass solves (they are taken at the same (b0, b1)) are accumulated together.
+        // Per sum the same terms in the same order as two separate sweeps give, so the bits are the separate sweeps';
+        // the normal-equation sums of a pass that turns out converged / invalid are simply not used.
+        double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         for (int pass = -1; pass < 25 && !invalid; pass++) {
             if (pass >= 0) {
-                double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-                for (long i = first; i < n; i += stride) {
-                    double mean = means[i], y = disps[i];
-                    double res = y / (c0 + c1 / mean);
-                    if (!((res > 1e-4) && (res < 15.0))) continue;
-                    double x = 1.0 / mean;
-                    double mu = b0 + b1 * x;
-                    double wgt = 1.0 / (mu * mu);
-                    double wx = wgt * x;
-                    a[0] += wgt; a[1] += wx; a[2] += wx * x; a[3] += wgt * y; a[4] += wx * y;
-                }
-                grid_sum<5>(a, red, ws, parity);
                 double det = a[0] * a[2] - a[1] * a[1];
                 b0 = (a[2] * a[3] - a[1] * a[4]) / det;
                 b1 = (a[0] * a[4] - a[1] * a[3]) / det;
             }
-            double d[3] = {0.0, 0.0, 0.0};      // sum log r, sum (r - 1), number of invalid means
+            double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // a[0..5) for the next pass | sum log r, sum (r - 1), # invalid means
             for (long i = first; i < n; i += stride) {
                 double mean = means[i], y = disps[i];
                 double res = y / (c0 + c1 / mean);
                 if (!((res > 1e-4) && (res < 15.0))) continue;
-                double mu = b0 + b1 * (1.0 / mean);
-                if (!(mu > 0.0)) { d[2] += 1.0; continue; }
+                double x = 1.0 / mean;
+                double mu = b0 + b1 * x;
+                double wgt = 1.0 / (mu * mu);
+                double wx = wgt * x;
+                v[0] += wgt; v[1] += wx; v[2] += wx * x; v[3] += wgt * y; v[4] += wx * y;
+                if (!(mu > 0.0)) { v[7] += 1.0; continue; }
                 double r = y / mu;
-                d[0] += dlog(r); d[1] += r - 1.0;
+                v[5] += dlog(r); v[6] += r - 1.0;
             }
-            grid_sum<3>(d, red, ws, parity);
-            if (d[2] > 0.0) { invalid = true; break; }
-            double dev = -2.0 * (d[0] - d[1]);
+            grid_sum<8>(v, red, ws, parity);
+            for (int k = 0; k < 5; k++) a[k] = v[k];
+            if (v[7] > 0.0) { invalid = true; break; }
+            double dev = -2.0 * (v[5] - v[6]);
             if (pass >= 0 && __builtin_fabs(dev - devold) / (__builtin_fabs(dev) + 0.1) < 1e-8) { converged = true; break; }
             devold = dev;
         }
