@@ -13,6 +13,12 @@
 
 namespace dsq {
 
+static inline int aux_grid_fwd(int n) {
+    int blocks = (n + 3) / 4;
+    int cap = device_cu_count() * 8;
+    return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
+}
+
 template <int P, bool USE_W>
 __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
     const int lane = threadIdx.x & 63;
@@ -255,7 +261,9 @@ __device__ __forceinline__ void grid_barrier(TrendWs *ws) {
 template <int K>
 __device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], TrendWs *ws, int &parity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_allreduce_n(v);
+    // (one value at a time: the interleaved form keeps 2 K extra registers live, and a 1024-thread block has 128 per lane)
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_allreduce(v[k]);
     __syncthreads();                      // previous use of `red` is complete
     if (lane == 0) {
 #pragma unroll
@@ -272,7 +280,8 @@ __device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], Trend
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double tot = 0.0;
-        for (int b = 0; b < kTrendBlocks; b++) {
+#pragma unroll 2
+        for (int b = 0; b < kTrendBlocks; b++) {       // (not unrolled further: K x 16 loads in flight would spill)
             double t = __longlong_as_double((long long)__hip_atomic_load(&ws->sums[parity][b][k], __ATOMIC_RELAXED,
                                                                         __HIP_MEMORY_SCOPE_AGENT));
             tot = (b == 0) ? t : tot + t;
@@ -307,6 +316,7 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
                 b1 = (a[0] * a[4] - a[1] * a[3]) / det;
             }
             double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // a[0..5) for the next pass | sum log r, sum (r - 1), # invalid means
+#pragma unroll 1
             for (long i = first; i < n; i += stride) {
                 double mean = means[i], y = disps[i];
                 double res = y / (c0 + c1 / mean);
@@ -340,6 +350,123 @@ __global__ void __launch_bounds__(1024) trend_fit_kernel(const double *means, co
 }
 
 size_t trend_fit_workspace_bytes() { return sizeof(TrendWs); }
+
+// ---- getAndCheckWeights (R/core.R:2697-2751) on resident weights -----------------------------------------------------
+// One wavefront per gene: w / max(w) (:2702), the same floored at 1e-6 for the gene-wise dispersion search (:702), the
+// all(weights >= 0) flag, and the two per-gene rank tests of :2711-2722 on the p x p Gram matrices of w_norm * X and of
+// the rows with w_norm > threshold (minus the columns those rows leave all zero) -- rank as qr() counts it: LINPACK
+// dqrdc2's column-relative test (tolerance 1e-7 on the norm a column keeps after the accepted columns are projected
+// out, relative to its own norm; an exactly zero column never counts), evaluated as a Cholesky factorisation of the
+// Gram matrix that skips rejected columns.  A decision, not a value: its sums need no order contract.
+struct WeightsPrepParams {
+    int n, m, p;
+    long ld;
+    const double *w_raw, *x;        // n x ld gene-major; m x p column-major
+    double thr;
+    double *w_norm, *w_floor;       // n x ld
+    int32_t *force_zero;            // n: 1 = the weights leave a degenerate design (weightsFail)
+    int32_t *neg;                   // 1 int: some weight is negative
+};
+
+DSQ_DEV int gram_rank(const double (&G)[DSQ_P_REG][DSQ_P_REG], int p) {
+    double Cm[DSQ_P_REG][DSQ_P_REG];
+    bool acc[DSQ_P_REG];
+    int rank = 0;
+    for (int j = 0; j < p; j++) {
+        double r = G[j][j];
+        for (int k = 0; k < j; k++) if (acc[k]) r -= Cm[k][j] * Cm[k][j];
+        const bool ok = (G[j][j] > 0.0) && (r >= 1e-14 * G[j][j]);
+        acc[j] = ok;
+        if (ok) {
+            const double inv = 1.0 / __builtin_sqrt(r);
+            for (int c = 0; c < p; c++) {
+                double num = G[j][c];
+                for (int k = 0; k < j; k++) if (acc[k]) num -= Cm[k][j] * Cm[k][c];
+                Cm[j][c] = num * inv;
+            }
+            rank++;
+        }
+    }
+    return rank;
+}
+
+__global__ void __launch_bounds__(256) weights_prep_kernel(WeightsPrepParams kp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int m = kp.m, p = kp.p;
+    for (int g = blockIdx.x * waves + wave; g < kp.n; g += gridDim.x * waves) {
+        const double *w = kp.w_raw + (size_t)g * kp.ld;
+        double mx = -__builtin_inf();
+        int isneg = 0, isnan_ = 0;
+        for (int j = lane; j < m; j += 64) {
+            const double v = w[j];
+            if (v < 0.0) isneg = 1;
+            if (v != v) isnan_ = 1;
+            if (v > mx) mx = v;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+        if (__any(isnan_)) mx = dnan();                                  // apply(weights, 1, max) is NA then
+        if (__any(isneg) && lane == 0) atomicOr(kp.neg, 1);
+        double G1[DSQ_P_REG][DSQ_P_REG], G2[DSQ_P_REG][DSQ_P_REG], cs[DSQ_P_REG];
+        for (int a = 0; a < p; a++) { cs[a] = 0.0; for (int b = a; b < p; b++) { G1[a][b] = 0.0; G2[a][b] = 0.0; } }
+        for (int j = lane; j < m; j += 64) {
+            const double wn = w[j] / mx;
+            kp.w_norm[(size_t)g * kp.ld + j] = wn;
+            kp.w_floor[(size_t)g * kp.ld + j] = (wn != wn) ? wn : (wn > 1e-6 ? wn : 1e-6);      // pmax(weights, 1e-6)
+            const double w2 = wn * wn, keep = (wn > kp.thr) ? 1.0 : 0.0;
+            for (int a = 0; a < p; a++) {
+                const double xa = kp.x[(size_t)a * m + j];
+                cs[a] += keep * __builtin_fabs(xa);
+                for (int b = a; b < p; b++) {
+                    const double xx = xa * kp.x[(size_t)b * m + j];
+                    G1[a][b] += w2 * xx;
+                    G2[a][b] += keep * xx;
+                }
+            }
+        }
+        for (int a = 0; a < p; a++) {
+            cs[a] = wave_allreduce(cs[a]);
+            for (int b = a; b < p; b++) {
+                G1[a][b] = wave_allreduce(G1[a][b]); G1[b][a] = G1[a][b];
+                G2[a][b] = wave_allreduce(G2[a][b]); G2[b][a] = G2[a][b];
+            }
+        }
+        if (lane == 0) {
+            int ncol = 0;
+            for (int a = 0; a < p; a++) ncol += cs[a] > 0.0 ? 1 : 0;
+            const bool ok = (gram_rank(G1, p) == p) && (gram_rank(G2, p) == ncol);
+            kp.force_zero[g] = ok ? 0 : 1;
+        }
+    }
+}
+
+hipError_t launch_weights_prep(const double *w_raw, const double *x, int n, int m, int p, long ld, double thr, double *w_norm,
+                               double *w_floor, int32_t *force_zero, int32_t *neg, hipStream_t st) {
+    WeightsPrepParams kp = {n, m, p, ld, w_raw, x, thr, w_norm, w_floor, force_zero, neg};
+    hipLaunchKernelGGL(weights_prep_kernel, dim3(aux_grid_fwd(n)), dim3(256), 0, st, kp);
+    return hipGetLastError();
+}
+
+// momentsDispEstimate's xim for a normalization-factor MATRIX (R/core.R:2440-2444): mean over the samples of
+// 1 / colMeans(nf).  One thread per sample sums its column down the genes in gene order (the order contract: a plain
+// sequential sum, like R's colMeans), one thread adds the m reciprocals in sample order.
+__global__ void __launch_bounds__(256) xim_kernel(const double *nf, int n, int m, long ld, double *colmean_recip) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int g = 0; g < n; g++) s += nf[(size_t)g * ld + j];
+    colmean_recip[j] = 1.0 / (s / (double)n);
+}
+__global__ void xim_final_kernel(const double *colmean_recip, int m, double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int j = 0; j < m; j++) s += colmean_recip[j];
+    *out = s / (double)m;
+}
+hipError_t launch_xim(const double *nf, int n, int m, long ld, double *scratch_m, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(xim_kernel, dim3((m + 255) / 256), dim3(256), 0, st, nf, n, m, ld, scratch_m);
+    hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
                             void *workspace, hipStream_t st) {

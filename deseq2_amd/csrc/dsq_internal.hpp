@@ -193,6 +193,11 @@ hipError_t launch_intercept_fit(const InterceptKernelParams &kp, hipStream_t st)
 hipError_t launch_trend_fit(const double *means, const double *disps, long n, double *coefs, int32_t *status,
                             void *workspace, hipStream_t st);
 size_t trend_fit_workspace_bytes();
+// getAndCheckWeights on resident weights: w / rowmax, pmax(., 1e-6), the weightsFail flags, the negative-weight flag
+hipError_t launch_weights_prep(const double *w_raw, const double *x, int n, int m, int p, long ld, double thr, double *w_norm,
+                               double *w_floor, int32_t *force_zero, int32_t *neg, hipStream_t st);
+// xim of a normalization-factor matrix -> *out (device); scratch_m: m doubles
+hipError_t launch_xim(const double *nf, int n, int m, long ld, double *scratch_m, double *out, hipStream_t st);
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).

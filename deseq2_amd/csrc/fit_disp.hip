@@ -81,6 +81,9 @@ struct DispGene {
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
         if constexpr (USE_W) { dv = dc = nullptr; nv = 0; return; }
+#ifdef DSQ_ABLATE_BUILD
+        if (ablate & 16) { dv = buf; dc = buf + m; nv = 0; return; }
+#endif
         nv = wave_distinct_counts(buf, m, lane, [&](int k) { return (int32_t)r.y(k); });
         dv = buf; dc = buf + m;
     }
@@ -387,6 +390,9 @@ DSQ_UNROLL_P
 
     // det(B0) and trace(B0^-1 B1) of the Cox-Reid term (:46, :85)
     DSQ_DEV void cr_algebra(const Bmat<2> &B, double &detb, double &tr1) const {
+#ifdef DSQ_ABLATE_BUILD
+        if (ablate & 8) { detb = 1.0; tr1 = 0.0; return; }
+#endif
         if constexpr (LANE) {
             LaneLU<P> lu;
             _Pragma("unroll")
@@ -499,14 +505,22 @@ DSQ_UNROLL_P
                     const double y = r.y(j), mu = r.mu(j);
                     const double ma = mu * alpha;
                     const double opm = 1.0 + ma;
+#ifdef DSQ_ABLATE_BUILD      // tuning build only (make ablate): skip one component to price it (tools/kbench.py, DSQ_ABLATE)
+                    const double rr = (ablate & 2) ? opm : rcp1(opm);
+#else
                     const double rr = rcp1(opm);
+#endif
                     if (useCR) {
                         const double w0 = mu * rr;
                         wd[0] = w0;
                         wd[1] = -(w0 * w0);
                     }
                     if (lik) {
+#ifdef DSQ_ABLATE_BUILD
+                        const double l1 = (ablate & 1) ? opm : dlog(opm);
+#else
                         const double l1 = dlog(opm);
+#endif
                         if constexpr (USE_W) {
                             double lg, dg;
                             dlgamma_digamma(y + an1, lg, dg);
@@ -536,6 +550,9 @@ DSQ_UNROLL_P
             ll_dpart = an2 * wave_allreduce(acc2);
         } else {
             double accv = 0.0, accv2 = 0.0;
+#ifdef DSQ_ABLATE_BUILD
+            if (!(ablate & 4))
+#endif
             for (int q0 = 0; q0 <= nv; q0 += 64) {        // position 0: lgamma / digamma of 1/alpha itself (see lp)
                 const int q = q0 + lane;
                 const bool live = (q > 0) && (q <= nv);
@@ -889,6 +906,15 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                 double theta_kappa = -1.0 * lp_try;
                 double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);
                 if (kp.force_iters > 0 && t + 1 >= kp.force_iters) break;   // profiling only
+#ifdef DSQ_ABLATE_BUILD
+                if (kp.force_iters > 0) {       // fixed work per gene: force_iters evaluations at one nearby point, no search logic
+                    dlp = dlp_try * 0.0 + 1.0e-3;
+                    lp = lp_try * 0.0 + lp;
+                    if (!(dlp == dlp)) dlp = 1.0e-3;
+                    if (!(lp == lp)) lp = 0.0;
+                    continue;
+                }
+#endif
                 if (uniform(theta_kappa <= theta_hat_kappa)) {
                     it_acc++;
                     a = a_try;

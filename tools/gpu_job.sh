@@ -7,6 +7,7 @@
 #   stats:CFG                  rocprofv3 --kernel-trace --stats of bench.py --config CFG (5 steps), summarised to <TAG>/stats_CFG.md
 #   pmc:CFG                    three separate rocprofv3 --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE) -> <TAG>/pmc_CFG.json
 #   py:SCRIPT[:ARGS...]        python SCRIPT ARGS
+#   sh:SCRIPT[:ARGS...]        bash SCRIPT ARGS
 #   env:NAME=VALUE             export for the following steps (DSQ_* tuning knobs)
 set -u
 TAG=$1; shift
@@ -58,6 +59,9 @@ PY
       python tools/pmc_summary.py "$P2" "$P3" "$P1" "$O/pmc_$cfg.json" "$NG" "rocprofv3 --pmc passes (SQ_*, FETCH_SIZE, WRITE_SIZE separately) of bench.py --config $cfg --steps 2 --warmup 1, state $TAG; means over the FULL-SIZE launches of each kernel (dispatches joined with the kernel trace of the same pass; a launch counts when it ran for >= half of the kernel's longest launch); FETCH_SIZE x2 (gfx950 note) + WRITE_SIZE; tools/gpu_job.sh pmc:$cfg" > "$O/pmc_$cfg.log" 2>&1
       echo "[gpu_job] pmc $cfg rc=$?"; tail -3 "$O/pmc_$cfg.log"
       rm -rf "$O/pmc1_$cfg" "$O/pmc2_$cfg" "$O/pmc3_$cfg";;
+    sh)
+      name=$(basename "${F[1]}" .sh)
+      timeout 900 bash "${F[1]}" "${F[@]:2}" > "$O/$name.log" 2>&1; echo "[gpu_job] sh ${F[1]} rc=$?"; tail -20 "$O/$name.log";;
     py)
       name=$(basename "${F[1]}" .py)
       timeout 900 python "${F[1]}" "${F[@]:2}" > "$O/$name.log" 2>&1; echo "[gpu_job] py ${F[1]} rc=$?"; tail -15 "$O/$name.log";;
