@@ -77,6 +77,9 @@ struct DispGene {
     bool sorted;
     const uint8_t *cid;
     const int32_t *crep;
+    // lane-column builds: the products x_c[i] x_c[b] of the cell rows (a property of the design, not of the gene), laid
+    // out [cell][i][b] in block-shared LDS once per block; nullptr when the table would be too large
+    const double *xxs;
     // sort the gene's counts (bitonic network in the wave's LDS slice), keep the first of every run and its length.
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
@@ -198,16 +201,25 @@ DSQ_UNROLL_P
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++) B[k][i] = 0.0;
                 for (int c = 0; c < C; c++) {
-                    const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
                     double sc[K];
                     _Pragma("unroll")
                     for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
-                    const double xb = r.x(j0, bl);
-                    _Pragma("unroll")
-                    for (int i = 0; i < P; i++) {
-                        const double xx = r.x(j0, i) * xb;
+                    if (xxs) {
                         _Pragma("unroll")
-                        for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
+                        for (int i = 0; i < P; i++) {
+                            const double xx = xxs[(c * P + i) * P + bl];
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
+                        }
+                    } else {
+                        const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
+                        const double xb = r.x(j0, bl);
+                        _Pragma("unroll")
+                        for (int i = 0; i < P; i++) {
+                            const double xx = r.x(j0, i) * xb;
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
+                        }
                     }
                 }
                 if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
@@ -741,6 +753,11 @@ __host__ __device__ inline size_t disp_cell_doubles(int m, int ncell, bool sorte
     if (sorted) return ((size_t)(2 * DSQ_CMAX + 2) * 4 + (size_t)m + 7) / 8;
     return ((size_t)m + DSQ_CMAX + 3) / 2;
 }
+// block-shared table of the cell-row products x_c[i] x_c[b] (lane-column builds, when it fits in 8 KiB)
+__host__ __device__ inline size_t disp_xx_doubles(int p, int ncell) {
+    const size_t k = (size_t)ncell * p * p;
+    return (p >= DSQ_DISP_LANE_MIN && ncell > 0 && k <= 1024) ? k : 0;
+}
 // sorted staging applies to staged, unweighted rows of a design with cells
 template <bool USE_W>
 __host__ __device__ inline bool disp_sorted(bool stage, int ncell) { return stage && !USE_W && ncell > 0; }
@@ -801,6 +818,16 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             xs = kp.x;
         }
     }
+    const double *xx_s = nullptr;
+    if (disp_xx_doubles(P, C) > 0) {
+        double *t_ = reinterpret_cast<double *>(cstart_s) + disp_cell_doubles(m, C, sorted);
+        for (int t = threadIdx.x; t < C * P * P; t += blockDim.x) {
+            const int c = t / (P * P), i = (t / P) % P, b = t % P;
+            const int j0 = kp.cell_perm[kp.cell_start[c]];
+            t_[t] = kp.x[(size_t)i * m + j0] * kp.x[(size_t)b * m + j0];
+        }
+        xx_s = t_;
+    }
     if (C > 0 || (STAGE && kp.xlds)) __syncthreads();
 
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
@@ -854,7 +881,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.padmask = kp.padmask;
         G.arena = arena;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
-        G.sorted = sorted; G.cid = cid_s; G.crep = crep_s;
+        G.sorted = sorted; G.cid = cid_s; G.crep = crep_s; G.xxs = xx_s;
         G.build_distinct(dist);
         G.setup_cr();
 
@@ -955,7 +982,8 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
-            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell))) * sizeof(double);
+            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell)) +
+                           disp_xx_doubles(P, kp.ncell)) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
             const int wcap = 4 * (DSQ_DISP_MINW);     // waves per CU the register budget of this build admits
@@ -968,7 +996,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
     const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P)) * sizeof(double);
-    const size_t cell_bytes = disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) * sizeof(double);
+    const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell)) * sizeof(double);
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
