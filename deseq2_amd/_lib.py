@@ -189,7 +189,8 @@ class DsqDeseqOut(C.Structure):
 class DsqDeseqHostArgs(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32), ("counts", C.c_void_p), ("y_type", C.c_int32),
-        ("x", C.c_void_p), ("sizeFactors", C.c_void_p), ("q", C.c_void_p), ("r", C.c_void_p), ("xrinv", C.c_void_p),
+        ("x", C.c_void_p), ("sizeFactors", C.c_void_p), ("normalizationFactors", C.c_void_p), ("weights", C.c_void_p),
+        ("q", C.c_void_p), ("r", C.c_void_p), ("xrinv", C.c_void_p),
         ("test", C.c_int32), ("x_reduced", C.c_void_p), ("q_reduced", C.c_void_p), ("r_reduced", C.c_void_p),
         ("p_reduced", C.c_int32), ("minReplicatesForReplace", C.c_double), ("cooksCutoff", C.c_double),
         ("expVarLogDisp", C.c_double), ("betaTol", C.c_double), ("minmu", C.c_double), ("maxit", C.c_int32),
@@ -202,7 +203,7 @@ class DsqDeseqHostOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in (
         "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
         "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
-        "logLikeReduced", "maxCooks", "replace", "mu", "H", "cooks", "replaceCounts")] + [
+        "logLikeReduced", "maxCooks", "replace", "weightsFail", "mu", "H", "cooks", "replaceCounts")] + [
         ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16)]
 
 
@@ -225,7 +226,7 @@ EXPORTED_SYMBOLS = [
     "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows", "dsq_optim_rows",
     "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
     "dsq_profile_count", "dsq_profile_get",
-    "dsq_deseq",
+    "dsq_deseq", "dsq_weights_prep_dev", "dsq_xim_dev",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
@@ -284,6 +285,9 @@ def lib():
     L.dsq_replace_outliers.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut)]
     L.dsq_replace_outliers_dev.argtypes = [C.POINTER(DsqReplaceArgs), C.POINTER(DsqReplaceOut), C.c_void_p]
     L.dsq_deseq_dev.argtypes = [C.POINTER(DsqDeseqArgs), C.POINTER(DsqDeseqOut), C.c_void_p]
+    L.dsq_weights_prep_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dsq_xim_dev.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dsq_deseq.argtypes = [C.POINTER(DsqDeseqHostArgs), C.POINTER(DsqDeseqHostOut)]
     L.dsq_deseq_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.dsq_deseq_workspace_bytes.restype = C.c_int64

@@ -921,6 +921,25 @@ int dsq_fit_disp_grid_dev(const DsqFitDispGridArgs *args, const DsqFitDispGridOu
     return fit_disp_grid_dev_locked(args, out, (hipStream_t)stream);
 }
 
+int dsq_weights_prep_dev(const double *weights_raw, const double *x, int32_t n, int32_t m, int32_t p, int64_t ld,
+                         double weightThreshold, double *w_norm, double *w_floor, int32_t *weightsFail,
+                         int32_t *any_negative, void *stream) {
+    if (!weights_raw || !x || !w_norm || !w_floor || !weightsFail || !any_negative || n < 0 || m < 1 || ld < m)
+        return fail(DSQ_ERR_ARG, "bad arguments");
+    if (p < 1 || p > DSQ_P_REG) return fail(DSQ_ERR_UNSUPPORTED, "dsq_weights_prep_dev: p=%d design columns (1..%d)", p, DSQ_P_REG);
+    if (int rc = check_device()) return rc;
+    if (n == 0) return DSQ_OK;
+    DSQ_HIP(launch_weights_prep(weights_raw, x, n, m, p, ld, weightThreshold, w_norm, w_floor, weightsFail, any_negative,
+                                (hipStream_t)stream));
+    return DSQ_OK;
+}
+int dsq_xim_dev(const double *nf, int32_t n, int32_t m, int64_t ld, double *scratch_m, double *out, void *stream) {
+    if (!nf || !scratch_m || !out || n < 1 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
+    if (int rc = check_device()) return rc;
+    DSQ_HIP(launch_xim(nf, n, m, ld, scratch_m, out, (hipStream_t)stream));
+    return DSQ_OK;
+}
+
 int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream) {
     if (!src_r || !dst_gm || n < 0 || m < 1 || ld < m) return fail(DSQ_ERR_ARG, "bad arguments");
     if (int rc = check_device()) return rc;

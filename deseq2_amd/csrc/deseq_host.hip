@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace dsq {
@@ -43,12 +44,12 @@ namespace {
 
 enum {   // device workspace slots of a range (grow-only, cached per (device, stream): a second call allocates nothing)
     HD_YR = DSQ_WS_HOSTDESEQ, HD_Y, HD_VEC, HD_MAT, HD_IVEC, HD_MUHAT, HD_MU, HD_H, HD_COOKS, HD_REPC, HD_STAT, HD_WORK,
-    HD_DESIGN, HD_TREND, HD_OUTR, HD_END
+    HD_DESIGN, HD_TREND, HD_OUTR, HD_NFR, HD_NF, HD_WRAW, HD_WNORM, HD_WFLOOR, HD_END
 };
 static_assert(HD_END <= DSQ_WS_COUNT, "workspace slots");
 
 enum { V_BASEMEAN = 0, V_BASEVAR, V_DGE, V_DFIT, V_DMAP, V_DISP, V_BITER, V_LL, V_LLR, V_MAXCOOKS, V_COUNT };
-enum { I_ALLZERO = 0, I_DGITER, I_DITER, I_DOUTLIER, I_BCONV, I_REPLACE, I_OPT1, I_OPT2, I_COUNT };
+enum { I_ALLZERO = 0, I_DGITER, I_DITER, I_DOUTLIER, I_BCONV, I_REPLACE, I_OPT1, I_OPT2, I_FORCEZERO, I_COUNT };
 
 // what the chain needs to know about the design alone
 struct Facts {
@@ -108,7 +109,7 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
     if (std::isfinite(a->minReplicatesForReplace))
         for (int j = 0; j < m; j++)
             if ((double)size[f->cells[j]] >= a->minReplicatesForReplace) { f->replaceable[j] = 1; f->do_replace = 1; }
-    f->linearMu = (f->ncell == p) ? 1 : 0;                                  // R/core.R:735-742 (no weights here)
+    f->linearMu = (f->ncell == p && !a->weights) ? 1 : 0;                   // R/core.R:735-742
     if (a->xrinv) f->a.assign(a->xrinv, a->xrinv + (size_t)m * p);
     else x_rinv(a->x, a->r, m, p, &f->a);
     if (a->x_reduced) {
@@ -125,9 +126,32 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
     }
     const double ln2 = 0.6931471805599453;
     f->lam.assign(p, 1e-6 / (ln2 * ln2));                                    // R/fitNbinomGLMs.R:73,162
-    double s = 0.0;                                                          // mean(1 / sizeFactors), in sample order
-    for (int j = 0; j < m; j++) s += 1.0 / a->sizeFactors[j];
-    f->xim = s / (double)m;
+    if (a->normalizationFactors) {
+        // mean over the samples of 1 / colMeans(normalizationFactors) (R/core.R:2440-2444): every column summed down the
+        // genes in gene order (what launch_xim does on a resident matrix), the columns split over a few host threads
+        const size_t n = a->n;
+        std::vector<double> rec(m);
+        unsigned T = std::thread::hardware_concurrency();
+        T = T < 1 ? 1 : (T > 8 ? 8 : T);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                for (int j = (int)t; j < m; j += (int)T) {
+                    const double *col = a->normalizationFactors + (size_t)j * n;
+                    double sum = 0.0;
+                    for (size_t i = 0; i < n; i++) sum += col[i];
+                    rec[j] = 1.0 / (sum / (double)n);
+                }
+            });
+        for (auto &x : th) x.join();
+        double s = 0.0;
+        for (int j = 0; j < m; j++) s += rec[j];
+        f->xim = s / (double)m;
+    } else {
+        double s = 0.0;                                                      // mean(1 / sizeFactors), in sample order
+        for (int j = 0; j < m; j++) s += 1.0 / a->sizeFactors[j];
+        f->xim = s / (double)m;
+    }
 }
 
 // the gene ranges meet here between the gene-wise phase and the trend
@@ -157,7 +181,8 @@ struct Exchange {
 static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
-    if (!a->counts || !a->x || !a->sizeFactors || !a->q || !a->r) return capi_fail(DSQ_ERR_ARG, "NULL input array");
+    if (!a->counts || !a->x || !a->q || !a->r) return capi_fail(DSQ_ERR_ARG, "NULL input array");
+    if (!a->sizeFactors == !a->normalizationFactors) return capi_fail(DSQ_ERR_ARG, "exactly one of sizeFactors / normalizationFactors must be given");
     if (a->y_type != DSQ_Y_INT32 && a->y_type != DSQ_Y_FLOAT64) return capi_fail(DSQ_ERR_ARG, "unknown y_type %d", a->y_type);
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
     if (a->x_reduced && (a->test != 1 || !a->q_reduced || !a->r_reduced || a->p_reduced < 1 || a->p_reduced >= a->p))
@@ -169,7 +194,7 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (!(a->cooksCutoff > 0.0) || !(a->expVarLogDisp > 0.0)) return capi_fail(DSQ_ERR_ARG, "cooksCutoff = qf(.99, p, m - p) and expVarLogDisp = trigamma((m - p) / 2) must be given");
     if (a->maxit < 1 || a->disp_maxit < 1 || !(a->betaTol > 0.0) || !(a->minmu > 0.0)) return capi_fail(DSQ_ERR_ARG, "betaTol / maxit / minmu / disp_maxit");
     if (!(a->minReplicatesForReplace >= 3.0)) return capi_fail(DSQ_ERR_ARG, "at least 3 replicates are necessary in order to indentify a sample as a count outlier");
-    for (int j = 0; j < a->m; j++)
+    for (int j = 0; a->sizeFactors && j < a->m; j++)
         if (!(a->sizeFactors[j] > 0.0) || !std::isfinite(a->sizeFactors[j])) return capi_fail(DSQ_ERR_VALUE, "sizeFactors[%d] is not a positive finite number", j);
     if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
         !o->dispersion || !o->dispIter || !o->dispOutlier || !o->beta || !o->betaSE || !o->betaConv || !o->betaIter ||
@@ -195,12 +220,35 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     if ((rc = capi_ws_get(HD_Y, cnt * (size_t)ld * 4, &v))) return rc;
     int32_t *y = (int32_t *)v;
     // ---- status block first (the REALSXP conversion flags bad counts in it)
-    if ((rc = capi_ws_get(HD_STAT, (DSQ_ST_COUNT + 2) * 4 + DSQ_SC_COUNT * 8 + 64, &v))) return rc;
+    if ((rc = capi_ws_get(HD_STAT, (DSQ_ST_COUNT + 4) * 4 + DSQ_SC_COUNT * 8 + 64, &v))) return rc;
     double *scalars = (double *)v;
-    int32_t *status = (int32_t *)(scalars + DSQ_SC_COUNT), *bad = status + DSQ_ST_COUNT;
-    HD_HIP(hipMemsetAsync(v, 0, (DSQ_ST_COUNT + 2) * 4 + DSQ_SC_COUNT * 8, st));
+    int32_t *status = (int32_t *)(scalars + DSQ_SC_COUNT), *bad = status + DSQ_ST_COUNT, *neg = bad + 1, *refit_total = bad + 2;
+    HD_HIP(hipMemsetAsync(v, 0, (DSQ_ST_COUNT + 4) * 4 + DSQ_SC_COUNT * 8, st));
     if (a->y_type == DSQ_Y_INT32) HD_HIP(launch_transpose_r_to_gm_i32((const int32_t *)y_r, y, (int)cnt, (int)m, ld, st));
     else HD_HIP(launch_counts_f64_to_gm_i32((const double *)y_r, y, (int)cnt, (int)m, ld, bad, st));
+    // ---- normalization-factor matrix / observation weights: rows up, gene-major on the device
+    const double *nf_gm = nullptr, *w_raw = nullptr;
+    double *w_norm = nullptr, *w_floor = nullptr;
+    if (a->normalizationFactors) {
+        void *r_, *g_;
+        if ((rc = capi_ws_get(HD_NFR, cnt * m * 8, &r_))) return rc;
+        if ((rc = stage_h2d(r_, a->normalizationFactors, 8, n, lo, cnt, m, st))) return rc;
+        if ((rc = capi_ws_get(HD_NF, cnt * (size_t)ld * 8, &g_))) return rc;
+        HD_HIP(launch_transpose_r_to_gm_f64((const double *)r_, (double *)g_, (int)cnt, (int)m, ld, st));
+        nf_gm = (const double *)g_;
+    }
+    if (a->weights) {
+        void *r_, *g_;
+        if ((rc = capi_ws_get(HD_NFR, cnt * m * 8, &r_))) return rc;      // (the staging slot is free again: same stream)
+        if ((rc = stage_h2d(r_, a->weights, 8, n, lo, cnt, m, st))) return rc;
+        if ((rc = capi_ws_get(HD_WRAW, cnt * (size_t)ld * 8, &g_))) return rc;
+        HD_HIP(launch_transpose_r_to_gm_f64((const double *)r_, (double *)g_, (int)cnt, (int)m, ld, st));
+        w_raw = (const double *)g_;
+        if ((rc = capi_ws_get(HD_WNORM, cnt * (size_t)ld * 8, &g_))) return rc;
+        w_norm = (double *)g_;
+        if ((rc = capi_ws_get(HD_WFLOOR, cnt * (size_t)ld * 8, &g_))) return rc;
+        w_floor = (double *)g_;
+    }
     // ---- design: x | q | a | r | grid | size factors, one small staging vector
     const size_t pr = a->x_reduced ? (size_t)a->p_reduced : 0;
     const size_t off_x = 0, off_q = off_x + m * p, off_a = off_q + m * p, off_r = off_a + m * p, off_g = off_r + p * p,
@@ -213,7 +261,8 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         hb.resize(dtot);
         memcpy(hb.data() + off_x, a->x, m * p * 8); memcpy(hb.data() + off_q, a->q, m * p * 8);
         memcpy(hb.data() + off_a, F.a.data(), m * p * 8); memcpy(hb.data() + off_r, a->r, p * p * 8);
-        memcpy(hb.data() + off_g, F.grid.data(), F.grid.size() * 8); memcpy(hb.data() + off_sf, a->sizeFactors, m * 8);
+        memcpy(hb.data() + off_g, F.grid.data(), F.grid.size() * 8);
+        if (a->sizeFactors) memcpy(hb.data() + off_sf, a->sizeFactors, m * 8);
         if (pr) {
             memcpy(hb.data() + off_xr, a->x_reduced, m * pr * 8); memcpy(hb.data() + off_qr, a->q_reduced, m * pr * 8);
             memcpy(hb.data() + off_ar, F.a_red.data(), m * pr * 8); memcpy(hb.data() + off_rr, a->r_reduced, pr * pr * 8);
@@ -240,7 +289,9 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     DsqDeseqArgs d;
     memset(&d, 0, sizeof d);
     d.n = (int32_t)cnt; d.m = (int32_t)m; d.p = (int32_t)p; d.ld = ld;
-    d.y = y; d.nf = dd + off_sf; d.nf_is_vector = 1; d.useWeights = 0;
+    d.y = y;
+    if (nf_gm) { d.nf = nf_gm; d.nf_is_vector = 0; } else { d.nf = dd + off_sf; d.nf_is_vector = 1; }
+    d.useWeights = a->weights ? 1 : 0;
     d.x = dd + off_x; d.q = dd + off_q; d.a = dd + off_a; d.r = dd + off_r;
     d.xim = F.xim; d.linearMu = F.linearMu;
     d.minDisp = 1e-8; d.kappa_0 = 1.0; d.dispTol = 1e-6; d.weightThreshold = 1e-2; d.outlierSD = 2.0;
@@ -266,6 +317,11 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     od.allZero = ivec + I_ALLZERO * cnt; od.dispGeneIter = ivec + I_DGITER * cnt; od.dispIter = ivec + I_DITER * cnt;
     od.dispOutlier = ivec + I_DOUTLIER * cnt; od.betaConv = ivec + I_BCONV * cnt; od.replace = ivec + I_REPLACE * cnt;
     od.optim_geneest = ivec + I_OPT1 * cnt; od.optim_test = ivec + I_OPT2 * cnt;
+    if (a->weights) {
+        // getAndCheckWeights (R/core.R:2697-2751): w / rowmax, its 1e-6 floor for the gene-wise search, the weightsFail rows
+        HD_HIP(launch_weights_prep(w_raw, d.x, (int)cnt, (int)m, (int)p, ld, 1e-2, w_norm, w_floor, ivec + I_FORCEZERO * cnt, neg, st));
+        d.weights_raw = w_raw; d.weights_norm = w_norm; d.weights_floor = w_floor; d.force_zero = ivec + I_FORCEZERO * cnt;
+    }
     od.mu_hat = mats[0]; od.mu = mats[1]; od.H = mats[2]; od.cooks = mats[3]; od.replaceCounts = repc;
     od.status = status; od.scalars = scalars;
 
@@ -299,8 +355,8 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
             const int32_t total = (int32_t)(X.n_refit > 0x7fffffffL ? 0x7fffffffL : X.n_refit);
             static thread_local int32_t total_h;
             total_h = total;
-            HD_HIP(hipMemcpyAsync(bad + 1, &total_h, 4, hipMemcpyHostToDevice, st));      // (pageable: staged at once)
-            d.n_refit_global = bad + 1;
+            HD_HIP(hipMemcpyAsync(refit_total, &total_h, 4, hipMemcpyHostToDevice, st));  // (pageable: staged at once)
+            d.n_refit_global = refit_total;
             d.phases = DSQ_PH_FINISH;
             if ((rc = pipeline_run(&d, &od, st))) return rc;
         }
@@ -313,12 +369,13 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     hi.resize(I_COUNT * cnt);
     double *hvec = hv.data(), *hmat = hvec + V_COUNT * cnt, *hsc = hmat + 4 * p * cnt;
     int32_t *hst = (int32_t *)(hsc + DSQ_SC_COUNT);
-    HD_HIP(hipMemcpyAsync(hsc, scalars, DSQ_SC_COUNT * 8 + (DSQ_ST_COUNT + 2) * 4, hipMemcpyDeviceToHost, st));
+    HD_HIP(hipMemcpyAsync(hsc, scalars, DSQ_SC_COUNT * 8 + (DSQ_ST_COUNT + 4) * 4, hipMemcpyDeviceToHost, st));
     if ((rc = stage_d2h(hvec, vec, 1, V_COUNT * cnt * 8, 0, V_COUNT * cnt * 8, 1, st))) return rc;
     if ((rc = stage_d2h(hmat, mat, 1, 4 * p * cnt * 8, 0, 4 * p * cnt * 8, 1, st))) return rc;
     if ((rc = stage_d2h(hi.data(), ivec, 1, I_COUNT * cnt * 4, 0, I_COUNT * cnt * 4, 1, st))) return rc;
     HD_HIP(hipStreamSynchronize(st));
     if (hst[DSQ_ST_COUNT] != 0) return capi_fail(DSQ_ERR_VALUE, "count matrix holds negative, non-finite or non-integer values");
+    if (hst[DSQ_ST_COUNT + 1] != 0) return capi_fail(DSQ_ERR_VALUE, "all(weights >= 0) is not TRUE");
     memcpy(X.status.data() + (size_t)shard * DSQ_ST_COUNT, hst, DSQ_ST_COUNT * 4);
     memcpy(X.scalars.data() + (size_t)shard * DSQ_SC_COUNT, hsc, DSQ_SC_COUNT * 8);
     double *const dcol[V_COUNT] = {o->baseMean, o->baseVar, o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter,
@@ -331,6 +388,10 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
             for (size_t c = 0; c < p; c++) memcpy(mcol[k] + c * n + lo, hmat + ((size_t)k * p + c) * cnt, cnt * 8);
     int32_t *const icol[6] = {o->allZero, o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv, o->replace};
     for (int k = 0; k < 6; k++) memcpy(icol[k] + lo, hi.data() + (size_t)k * cnt, cnt * 4);
+    if (o->weightsFail) {
+        if (a->weights) memcpy(o->weightsFail + lo, hi.data() + (size_t)I_FORCEZERO * cnt, cnt * 4);
+        else memset(o->weightsFail + lo, 0, cnt * 4);
+    }
     // `replace` is NA on the rows that were all zero from the start (and everywhere without a replaceable sample)
     for (size_t i = 0; i < cnt; i++)
         if (!F.do_replace || (o->allZero[lo + i] && o->replace[lo + i] == 0)) o->replace[lo + i] = -1;
@@ -364,6 +425,8 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     if ((rc = capi_check_device())) return rc;
     Facts F;
     design_facts(a, &F);
+    if (a->normalizationFactors && F.do_replace)
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: a normalization-factor matrix together with the outlier refit (R/core.R:2440-2444 re-averages the factors over the refitted rows): pass minReplicatesForReplace = Inf");
     Exchange X;
     const int S = capi_host_shards((size_t)a->n);
     X.target = S;

@@ -753,10 +753,11 @@ __host__ __device__ inline size_t disp_cell_doubles(int m, int ncell, bool sorte
     if (sorted) return ((size_t)(2 * DSQ_CMAX + 2) * 4 + (size_t)m + 7) / 8;
     return ((size_t)m + DSQ_CMAX + 3) / 2;
 }
-// block-shared table of the cell-row products x_c[i] x_c[b] (lane-column builds, when it fits in 8 KiB)
+// block-shared table of the cell-row products x_c[i] x_c[b] (lane-column builds, when it is small: 2 KiB -- a large
+// table costs a resident block on long-row shapes, measured at C4: 18.5 -> 26.9 ms with an 8 KiB table)
 __host__ __device__ inline size_t disp_xx_doubles(int p, int ncell) {
     const size_t k = (size_t)ncell * p * p;
-    return (p >= DSQ_DISP_LANE_MIN && ncell > 0 && k <= 1024) ? k : 0;
+    return (p >= DSQ_DISP_LANE_MIN && ncell > 0 && k <= 256) ? k : 0;
 }
 // sorted staging applies to staged, unweighted rows of a design with cells
 template <bool USE_W>

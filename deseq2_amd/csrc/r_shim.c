@@ -249,7 +249,8 @@ SEXP _DESeq2_mi355x_replace(SEXP ySEXP, SEXP nfSEXP, SEXP cooksSEXP, SEXP cutoff
 
 /* ---- DESeq() behind ONE call (dsq_deseq): what the patch of R/core.R:388-426 in INTEGRATION.md section 4 calls in place
  * of estimateDispersions -> nbinomWaldTest / nbinomLRT -> refitWithoutOutliers.  Arguments: counts(object) (integer
- * matrix), the model matrix, sizeFactors(object), qr.Q(qrx), qr.R(qrx) (qrx <- qr(modelMatrix), R/fitNbinomGLMs.R:139-143),
+ * matrix), the model matrix, sizeFactors(object), normalizationFactors(object) or NULL, assays(object)[["weights"]] or
+ * NULL, qr.Q(qrx), qr.R(qrx) (qrx <- qr(modelMatrix), R/fitNbinomGLMs.R:139-143),
  * test (0 Wald / 1 LRT), the reduced model matrix with its qr.Q / qr.R (NULL, or one column: reduced = ~1),
  * minReplicatesForReplace, qf(.99, p, m - p) (R/core.R:2081),
  * trigamma((m - p) / 2) (:1196), betaTol, maxit, useQR, minmu, the dispersion searches' maxit, useCR, and which n x m
@@ -269,7 +270,8 @@ static void nan_to_na(SEXP s) {
     for (int i = 0; i < k; i++) if (ISNAN(d[i])) d[i] = NA_REAL;
 }
 
-SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEXP qSEXP, SEXP rSEXP, SEXP testSEXP,
+SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEXP normFactorsSEXP, SEXP weightsSEXP,
+                          SEXP qSEXP, SEXP rSEXP, SEXP testSEXP,
                           SEXP xRedSEXP, SEXP qRedSEXP, SEXP rRedSEXP, SEXP minReplicatesSEXP, SEXP cooksCutoffSEXP, SEXP expVarLogDispSEXP, SEXP betaTolSEXP,
                           SEXP maxitSEXP, SEXP useQRSEXP, SEXP minmuSEXP, SEXP dispMaxitSEXP, SEXP useCRSEXP,
                           SEXP assaysSEXP) {
@@ -277,13 +279,26 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     R_CheckUserInterrupt();
     int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
     need_matrix(xSEXP, m, p, "modelMatrix"); need_matrix(qSEXP, m, p, "qr.Q"); need_matrix(rSEXP, p, p, "qr.R");
-    need_length(sizeFactorsSEXP, m, "sizeFactors");
-    SEXP x = as_real(xSEXP, &np), sf = as_real(sizeFactorsSEXP, &np), q = as_real(qSEXP, &np), r = as_real(rSEXP, &np);
+    SEXP x = as_real(xSEXP, &np), q = as_real(qSEXP, &np), r = as_real(rSEXP, &np);
     const int want = scalar_i(assaysSEXP), wald = scalar_i(testSEXP) == 0;
     DsqDeseqHostArgs a = {0};
     a.n = n; a.m = m; a.p = p;
     a.counts = counts_ptr(countsSEXP, &a.y_type);
-    a.x = REAL(x); a.sizeFactors = REAL(sf); a.q = REAL(q); a.r = REAL(r); a.xrinv = NULL;
+    a.x = REAL(x); a.q = REAL(q); a.r = REAL(r); a.xrinv = NULL;
+    if (normFactorsSEXP != R_NilValue) {              /* normalizationFactors(object) take precedence (R/core.R:2221-2227) */
+        need_matrix(normFactorsSEXP, n, m, "normalizationFactors");
+        SEXP nf = as_real(normFactorsSEXP, &np);
+        a.normalizationFactors = REAL(nf);
+    } else {
+        need_length(sizeFactorsSEXP, m, "sizeFactors");
+        SEXP sf = as_real(sizeFactorsSEXP, &np);
+        a.sizeFactors = REAL(sf);
+    }
+    if (weightsSEXP != R_NilValue) {
+        need_matrix(weightsSEXP, n, m, "weights");
+        SEXP w = as_real(weightsSEXP, &np);
+        a.weights = REAL(w);
+    }
     a.test = wald ? 0 : 1;
     if (!wald && xRedSEXP != R_NilValue && !(Rf_ncols(xRedSEXP) == 1)) {       /* reduced = ~1: the closed form */
         int pr = Rf_ncols(xRedSEXP);
@@ -304,7 +319,7 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     SEXP se = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
     SEXP stat = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
     SEXP pval = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
-    int *iv = (int *)R_alloc((size_t)6 * n, sizeof(int));
+    int *iv = (int *)R_alloc((size_t)7 * n, sizeof(int));
     SEXP mu = R_NilValue, H = R_NilValue, ck = R_NilValue, rc = R_NilValue;
     if (want & 1) { mu = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
     if (want & 2) { H = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
@@ -317,7 +332,7 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     o.logLikeReduced = wald ? NULL : REAL(dv[LLR]); o.maxCooks = REAL(dv[MAXC]);
     o.beta = REAL(beta); o.betaSE = REAL(se); o.stat = wald ? REAL(stat) : NULL; o.pvalue = wald ? REAL(pval) : NULL;
     o.allZero = iv; o.dispGeneIter = iv + n; o.dispIter = iv + 2 * (size_t)n; o.dispOutlier = iv + 3 * (size_t)n;
-    o.betaConv = iv + 4 * (size_t)n; o.replace = iv + 5 * (size_t)n;
+    o.betaConv = iv + 4 * (size_t)n; o.replace = iv + 5 * (size_t)n; o.weightsFail = iv + 6 * (size_t)n;
     if (want & 1) o.mu = REAL(mu);
     if (want & 2) o.H = REAL(H);
     if (want & 4) o.cooks = REAL(ck);
@@ -331,13 +346,13 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     for (int k = 0; k < 4; k++) REAL(fn)[k] = o.dispersionFunction[k];
     const char *names[] = {"baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP",
                            "dispersion", "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv",
-                           "betaIter", "logLike", "logLikeReduced", "maxCooks", "replace", "mu", "H", "cooks",
+                           "betaIter", "logLike", "logLikeReduced", "maxCooks", "replace", "weightsFail", "mu", "H", "cooks",
                            "replaceCounts", "dispersionFunction"};
     SEXP vals[] = {dv[BM], dv[BV], int_col(o.allZero, n, LGLSXP, &np), dv[DGE], int_col(o.dispGeneIter, n, INTSXP, &np),
                    dv[DFIT], dv[DMAP], dv[DISP], int_col(o.dispIter, n, INTSXP, &np), int_col(o.dispOutlier, n, LGLSXP, &np),
                    beta, se, stat, pval, int_col(o.betaConv, n, LGLSXP, &np), dv[BITER], dv[LL], dv[LLR], dv[MAXC],
-                   int_col(o.replace, n, LGLSXP, &np), mu, H, ck, rc, fn};
-    SEXP out = named_list(25, names, vals);
+                   int_col(o.replace, n, LGLSXP, &np), int_col(o.weightsFail, n, LGLSXP, &np), mu, H, ck, rc, fn};
+    SEXP out = named_list(26, names, vals);
     UNPROTECT(np);
     return out;
 }
@@ -349,7 +364,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
-    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 19},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 21},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

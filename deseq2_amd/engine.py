@@ -186,8 +186,15 @@ class HostEngine:
         return self.fns.prefitMoments(y, nf, x, weights, weights is not None)
 
     def xim(self, nf):
-        """momentsDispEstimate's xim, R/core.R:2440-2444"""
-        return float(np.mean(1.0 / nf.mean(axis=0)))
+        """momentsDispEstimate's xim, R/core.R:2440-2444: mean over the samples of 1 / colMeans(nf) -- every column summed
+        down the genes in gene order, the m reciprocals in sample order (the order contract of csrc/aux.hip xim_kernel
+        and of the library's host entry; numpy's own mean() sums pairwise)"""
+        nf = np.asarray(nf, np.float64)
+        n, m = nf.shape
+        rec = np.empty(m)
+        for j0 in range(0, m, 64):
+            rec[j0:j0 + 64] = 1.0 / (np.cumsum(nf[:, j0:j0 + 64], axis=0)[-1] / n)
+        return float(np.cumsum(rec)[-1] / m)
 
     def linear_mu(self, y, nf, x):
         """linearModelMuNormalized, R/core.R:2465-2471 (engine kernel: a BLAS product on the host would make
@@ -459,7 +466,34 @@ class DeviceEngine:
                 "beta_init": o["beta_init"]}        # (p, n) device tensor, consumed by fit_beta in place
 
     def xim(self, nf):
-        return float((1.0 / nf.view().mean(dim=0)).mean())
+        """momentsDispEstimate's xim (R/core.R:2440-2444) by the library's kernel: columns summed down the genes in gene
+        order, the same definition the one-call host entry uses"""
+        from . import _lib
+        import ctypes as C
+        t = self.torch
+        buf = t.empty(nf.m + 1, dtype=t.float64, device=self.device)
+        st = C.c_void_p(t.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().dsq_xim_dev(C.c_void_p(nf.t.data_ptr()), nf.n, nf.m, nf.ld, C.c_void_p(buf.data_ptr()),
+                                          C.c_void_p(buf[nf.m:].data_ptr()), st))
+        return float(self._host(buf[nf.m:])[0])
+
+    def weights_prep(self, w, x, thr=1e-2):
+        """getAndCheckWeights (R/core.R:2697-2751) in ONE kernel on the resident weights: (w / rowmax, its 1e-6 floor,
+        weightsFail flags (int32 device tensor), any-negative flag (int32 device tensor of one element))"""
+        from . import _lib
+        import ctypes as C
+        t = self.torch
+        xd = self.design(x)
+        wn, wf = t.zeros_like(w.t), t.zeros_like(w.t)
+        fz = t.empty(w.n, dtype=t.int32, device=self.device)
+        neg = t.zeros(1, dtype=t.int32, device=self.device)
+        st = C.c_void_p(t.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().dsq_weights_prep_dev(C.c_void_p(w.t.data_ptr()), C.c_void_p(xd.data_ptr()), w.n, w.m,
+                                                   int(np.asarray(x).shape[1]), w.ld, float(thr), C.c_void_p(wn.data_ptr()),
+                                                   C.c_void_p(wf.data_ptr()), C.c_void_p(fz.data_ptr()),
+                                                   C.c_void_p(neg.data_ptr()), st))
+        GM = self.native.GeneMajor
+        return GM(wn, w.m), GM(wf, w.m), fz, neg
 
     def linear_mu(self, y, nf, x_dev):
         dq, da, _ = self._design_qr_dev(x_dev.t().cpu().numpy())

@@ -133,11 +133,7 @@ class _Run:
         self.neg = None
         self.force_zero = None
         if self.useWeights:
-            self.neg = (dds.weights_h.view() < 0).any()
-            self.w_norm = E.row_max_normalize(dds.weights_h)
-            self.w_floor = E.clamp_min(self.w_norm, 1e-6)
-            ok = E.weights_ok_dev(self.w_norm, dds.x, 1e-2, core._rank(dds.x) == p)
-            self.force_zero = (~ok).to(t.int32)
+            self.w_norm, self.w_floor, self.force_zero, self.neg = E.weights_prep(dds.weights_h, dds.x, 1e-2)
         # ---- outputs: every per-gene column in ONE device block (a single copy brings them all to the host):
         #      vec (10 x n f64) | mat (4 x pcol x n f64) | [mle (p x n f64)] | scalars | ivec (9 x n i32) | status
         self.prior = _prior_design(dds, kw) if kw.get("betaPrior") else None
@@ -160,7 +156,7 @@ class _Run:
         (self.allZero, self.dispGeneIter, self.dispIter, self.dispOutlier, self.betaConv, self.replace,
          self.optim_geneest, self.optim_test, _) = self.ivec
         if self.neg is not None:
-            self.negflag[0] = self.neg.to(t.int32)
+            self.negflag[:1] = self.neg
         self.mu_hat = t.empty((n, ld), **f64)
         self.mu = t.empty((n, ld), **f64)
         self.H = t.empty((n, ld), **f64)
@@ -278,7 +274,7 @@ class _Run:
         t = self.t
         parts = [self.status.to(t.float64), self.scalars]
         if self.neg is not None:
-            parts.append(self.neg.to(t.float64).reshape(1))
+            parts.append(self.neg.to(t.float64))
         h = self.E._host(t.cat(parts)).numpy()
         st = {k: int(h[i]) for k, i in L.DSQ_ST.items()}
         sc = h[L.DSQ_ST_COUNT: L.DSQ_ST_COUNT + L.DSQ_SC_COUNT]

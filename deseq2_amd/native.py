@@ -260,7 +260,8 @@ def optimRows(counts, x, nf, alpha, lam, weights, useWeights, beta_start, minmu=
     return {"beta": beta, "betaSE": se, "conv": conv.astype(bool), "mu": mu, "logLike": ll}
 
 
-def DESeq(counts, x, sizeFactors, test="Wald", reduced=None, minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
+def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationFactors=None, weights=None,
+          minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
           minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks")):
     """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
     in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
@@ -273,7 +274,9 @@ def DESeq(counts, x, sizeFactors, test="Wald", reduced=None, minReplicatesForRep
     x = _fcol(x)
     n, m = y.shape
     p = x.shape[1]
-    sf = np.ascontiguousarray(sizeFactors, dtype=np.float64)
+    sf = None if sizeFactors is None or normalizationFactors is not None else np.ascontiguousarray(sizeFactors, dtype=np.float64)
+    nfm = None if normalizationFactors is None else _fcol(normalizationFactors)
+    wts = None if weights is None else _fcol(weights)
     q, a, r = design_qr(x)
     if m - p > 0:
         cutoff, evld = float(fdist.ppf(.99, p, m - p)), float(sps.polygamma(1, (m - p) / 2.0))
@@ -294,7 +297,7 @@ def DESeq(counts, x, sizeFactors, test="Wald", reduced=None, minReplicatesForRep
     i32 = lambda: np.full(n, -1, dtype=np.int32)                         # noqa: E731
     d = {k: f64(n) for k in ("baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "betaIter",
                              "logLike", "maxCooks")}
-    d.update({k: i32() for k in ("allZero", "dispGeneIter", "dispIter", "dispOutlier", "betaConv", "replace")})
+    d.update({k: i32() for k in ("allZero", "dispGeneIter", "dispIter", "dispOutlier", "betaConv", "replace", "weightsFail")})
     d.update(beta=f64(n, p), betaSE=f64(n, p))
     if wald:
         d.update(stat=f64(n, p), pvalue=f64(n, p))
@@ -303,7 +306,8 @@ def DESeq(counts, x, sizeFactors, test="Wald", reduced=None, minReplicatesForRep
     for k in assays:
         d[k] = np.zeros((n, m), order="F", dtype=np.int32 if k == "replaceCounts" else np.float64)
     args = L.DsqDeseqHostArgs(
-        n=n, m=m, p=p, counts=_ptr(y), y_type=ytype, x=_ptr(x), sizeFactors=_ptr(sf), q=_ptr(q), r=_ptr(r), xrinv=_ptr(a),
+        n=n, m=m, p=p, counts=_ptr(y), y_type=ytype, x=_ptr(x), sizeFactors=_ptr(sf), normalizationFactors=_ptr(nfm),
+        weights=_ptr(wts), q=_ptr(q), r=_ptr(r), xrinv=_ptr(a),
         test=0 if wald else 1, x_reduced=_ptr(xr), q_reduced=_ptr(qr_), r_reduced=_ptr(rr_), p_reduced=int(p_red),
         minReplicatesForReplace=float(minReplicatesForReplace), cooksCutoff=cutoff,
         expVarLogDisp=evld, betaTol=float(betaTol), minmu=float(minmu), maxit=int(maxit), useQR=int(bool(useQR)),

@@ -364,6 +364,17 @@ typedef struct {
 int dsq_replace_outliers(const DsqReplaceArgs *args, const DsqReplaceOut *out);
 int dsq_replace_outliers_dev(const DsqReplaceArgs *args, const DsqReplaceOut *out, void *stream);
 
+/* getAndCheckWeights (R/core.R:2697-2751) on resident gene-major weights: w_norm = w / rowmax (:2702), w_floor =
+ * pmax(w_norm, 1e-6) (:702), weightsFail[i] = 1 when the weights of gene i leave a degenerate design (the two per-gene
+ * qr() rank tests of :2711-2722, full-rank model matrices, p <= 10), *any_negative |= 1 when a weight is negative
+ * (the caller zeroes it first).  All device pointers; x: m x p column-major.                                      */
+int dsq_weights_prep_dev(const double *weights_raw, const double *x, int32_t n, int32_t m, int32_t p, int64_t ld,
+                         double weightThreshold, double *w_norm, double *w_floor, int32_t *weightsFail,
+                         int32_t *any_negative, void *stream);
+/* momentsDispEstimate's xim for a resident normalization-factor matrix (R/core.R:2440-2444): mean over the samples of
+ * 1 / colMeans(nf), every column summed down the genes in gene order.  scratch_m: m doubles; *out on the device.  */
+int dsq_xim_dev(const double *nf, int32_t n, int32_t m, int64_t ld, double *scratch_m, double *out, void *stream);
+
 /* ---- layout helpers (device pointers, async on stream) --------------------------
  * R layout (column-major n x m) <-> gene-major (row-major, leading dimension ld).   */
 int dsq_to_gene_major_f64(const double *src_r, double *dst_gm, int32_t n, int32_t m, int64_t ld, void *stream);
@@ -517,7 +528,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
  * Covers what the fused chain covers: parametric trend, betaPrior = FALSE, Wald or LRT (any nested reduced model), p <= 10,
- * m - p > 3, size factors (no normalization-factor matrix yet), no observation weights yet; anything else returns
+ * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
  * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),
  * trigamma((m - p) / 2) (R/core.R:1196).
@@ -527,7 +538,12 @@ typedef struct {
     const void *counts;            /* n x m column-major                                                          */
     int32_t y_type;                /* DSQ_Y_INT32 (counts(dds)) or DSQ_Y_FLOAT64                                  */
     const double *x;               /* m x p model matrix, column-major, full rank                                 */
-    const double *sizeFactors;     /* m                                                                           */
+    const double *sizeFactors;     /* m, or NULL when normalizationFactors is given                               */
+    const double *normalizationFactors;  /* n x m column-major (normalizationFactors(object)), or NULL.  With a matrix the
+                                      outlier refit is not available (its momentsDispEstimate re-averages the factors over
+                                      the refitted rows, R/core.R:2440-2444): pass minReplicatesForReplace = Inf or get
+                                      DSQ_ERR_UNSUPPORTED                                                            */
+    const double *weights;         /* n x m column-major (assays(object)[["weights"]]), or NULL                   */
     const double *q, *r;           /* qr.Q(qr(x)) (m x p) and qr.R(qr(x)) (p x p), column-major                   */
     const double *xrinv;           /* x %*% solve(R) (m x p), or NULL: computed here by back substitution         */
     int32_t test;                  /* 0 Wald, 1 LRT (reduced = ~1 unless x_reduced is given)                      */
@@ -556,6 +572,8 @@ typedef struct {
     int32_t *betaConv;
     double *betaIter, *logLike, *logLikeReduced /* LRT only, else NULL */, *maxCooks;
     int32_t *replace;              /* NA (-1) on rows that were all zero from the start                           */
+    int32_t *weightsFail;          /* optional (NULL): rows whose weights leave a degenerate design, treated as all zero
+                                      (getAndCheckWeights, R/core.R:2736-2747)                                    */
     /* assays, n x m column-major, each optional (NULL = stays on the device)                                      */
     double *mu, *H, *cooks;
     int32_t *replaceCounts;

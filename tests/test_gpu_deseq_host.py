@@ -51,7 +51,16 @@ def _cases():
     c4 = _spike(d4["counts"], 4, 5)
     c4[7] = 0
     c4[7, 30:32] = 2500                                              # a row for the optim fallback in both fits
+    # observation weights (incl. a gene whose weights leave a degenerate design -> weightsFail, treated as all zero)
+    rng = np.random.default_rng(21)
+    w5 = rng.uniform(0.05, 1.0, c2.shape)
+    w5[rng.uniform(size=c2.shape) < 0.03] = 0.0
+    w5[17, x2[:, 1] == 1] = 0.0
+    # a normalization-factor matrix (no outlier refit with it: see include/deseq2_mi355x.h)
+    nf6 = np.exp(rng.normal(0, 0.2, d1["counts"].shape))
     return {"bc_outliers": (c1, x1, d1["size_factors"], {}),
+            "two_group_weights": (c2, x2, d2["size_factors"], {"weights": w5}),
+            "bc_nf_matrix": (d1["counts"], x1, None, {"normalizationFactors": nf6, "minReplicatesForReplace": np.inf}),
             "factor6_lrt_reduced2": (c4, x4, d4["size_factors"], {"test": "LRT", "reduced": red4, "minmu": 1e-6}),
             "two_group_optim_rows": (c2, x2, d2["size_factors"], {}),
             "factor5_lrt": (_spike(d3["counts"], 2, 4), x3, d3["size_factors"], {"test": "LRT"}),
@@ -63,11 +72,17 @@ CASES = _cases()
 
 def _host_entry(counts, x, sf, kw, assays=("mu", "H", "cooks")):
     return native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"), minmu=kw.get("minmu", 0.5),
+                        normalizationFactors=kw.get("normalizationFactors"), weights=kw.get("weights"),
                         minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=assays)
 
 
+def _dataset(counts, x, sf, kw, engine):
+    return core.DESeqDataSet(counts, x, sizeFactors=sf, normalizationFactors=kw.get("normalizationFactors"),
+                             weights=kw.get("weights"), engine=engine)
+
+
 def _chain_kw(kw, x):
-    kw = dict(kw)
+    kw = {k: v for k, v in kw.items() if k not in ("weights", "normalizationFactors")}
     if kw.get("test") == "LRT" and "reduced" not in kw:
         kw["reduced"] = np.ones((x.shape[0], 1))
     return kw
@@ -85,6 +100,8 @@ def _mcols_of(res, test):
         mc.update(LRTStatistic=2 * (res["logLike"] - res["logLikeReduced"]), fullBetaConv=res["betaConv"])
     if not np.isnan(res["replace"]).all():
         mc["replace"] = res["replace"]
+    if np.nan_to_num(res["weightsFail"]).any():
+        mc["weightsFail"] = res["weightsFail"]
     return mc
 
 
@@ -97,9 +114,9 @@ def _f(v):
 def test_host_entry_equals_fused_chain(E, name, shards):
     counts, x, sf, kw = CASES[name]
     test = kw.get("test", "Wald")
-    b = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+    b = _dataset(counts, x, sf, kw, E)
     fkw = _chain_kw(kw, x)
-    assert fused.supported(b, **{k: v for k, v in fkw.items() if k != "minReplicatesForReplace"})
+    assert fused.supported(b, **fkw)
     fused.DESeq(b, **fkw)
     assert b.attrs.get("fused")
     old = os.environ.get("DSQ_HOST_SHARDS")
@@ -142,9 +159,8 @@ ORACLE_COLS = ["baseMean", "baseVar", "dispGeneEst", "dispGeneIter", "dispFit", 
 
 
 def _oracle_chain(oracle, counts, x, sf, kw):
-    kw = _chain_kw(kw, x)
-    dds = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=HostEngine(oracle))
-    core.DESeq(dds, **kw)
+    dds = _dataset(counts, x, sf, kw, HostEngine(oracle))
+    core.DESeq(dds, **_chain_kw(kw, x))
     return dds
 
 
@@ -176,7 +192,7 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     reference side of the comparison"""
     counts, x, sf, kw = CASES[name]
     test = kw.get("test", "Wald")
-    b = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+    b = _dataset(counts, x, sf, kw, E)
     fused.DESeq(b, **_chain_kw(kw, x))
     assert b.attrs.get("fused")
     o = _oracle_chain(oracle, counts, x, sf, kw)
