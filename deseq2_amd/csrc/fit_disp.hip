@@ -736,7 +736,11 @@ DSQ_UNROLL_P
 //   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
 // lane-column builds: per-wave LDS arena through which the general-mode pass hands the reduced Cox-Reid rows to the
 // lanes (3 p p doubles: the second-derivative kernel has three matrices)
-__host__ __device__ inline size_t disp_arena_doubles(int p) { return p >= DSQ_DISP_ROWPASS_MIN ? (size_t)3 * p * p : 0; }
+// (only the general-mode pass uses it: with design cells the sums are per cell and the arena is not carved -- at
+// p = 10, m = 2000 its 9.6 KiB per block were what kept a second block off the CU)
+__host__ __device__ inline size_t disp_arena_doubles(int p, int ncell) {
+    return (p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0) ? (size_t)3 * p * p : 0;
+}
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
@@ -764,10 +768,18 @@ template <bool USE_W>
 __host__ __device__ inline bool disp_sorted(bool stage, int ncell) { return stage && !USE_W && ncell > 0; }
 
 template <bool USE_W>
-__host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds = 1) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true) + (size_t)waves * disp_arena_doubles(p);
+__host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds, int ncell) {
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true) + (size_t)waves * disp_arena_doubles(p, ncell);
 }
 
+// 1: the line search evaluates the likelihood alone at a proposal and the derivative only after the Armijo test accepts
+// it (what src/DESeq2.cpp:225-246 does); 0: both in one fused evaluation per proposal.  More than half of the proposals
+// are rejected (C3: 52 % in the gene-wise fit, 61 % in the MAP fit), yet the fused form wins -- the likelihood alone and
+// the derivative alone each cost ~0.8 of the fused evaluation, they share the logarithm, the reciprocal and the Cox-Reid
+// sweep.  Measured (same bits either way): C3 3.07 ms fused vs 3.44 ms split; C4 18.8 vs 23.3 ms (profiles/r03_ablation.md)
+#ifndef DSQ_DISP_SPLIT
+#define DSQ_DISP_SPLIT 0
+#endif
 #ifndef DSQ_DISP_MINW
 /* p <= 4: the search kernel needs 177 registers, so 3 waves per SIMD cost ten spills and pay (6.42 -> 6.15 ms
  * at C3); p = 5, 6: 2 waves; wider designs already spill at 512 registers */
@@ -792,9 +804,9 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
-    double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P);
+    double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
     // design cells: lists in block-shared LDS behind the slabs and arenas
-    int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P)));
+    int32_t *cstart_s = reinterpret_cast<int32_t *>(smem + xoff + (size_t)waves * (slab_d + disp_arena_doubles(P, kp.ncell)));
     int32_t *cperm_s = cstart_s + DSQ_CMAX + 2;
     int32_t *crep_s = cperm_s;                                           // sorted staging: crep[DSQ_CMAX] | cell bytes
     uint8_t *cid_s = reinterpret_cast<uint8_t *>(crep_s + DSQ_CMAX);
@@ -915,7 +927,12 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             const double epsilon = 1.0e-4;
             double a = kp.log_alpha_in[g];
             double dlp;
+#if DSQ_DISP_SPLIT
+            double lp = G.lp(a);
+            dlp = G.dlp(a, G.usePrior);
+#else
             double lp = G.lp_dlp(a, G.usePrior, dlp);
+#endif
             double kappa = kp.kappa_0;
             const double initial_lp = lp, initial_dlp = dlp;
             double change = -1.0;
@@ -929,8 +946,14 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                 // the reference evaluates log_posterior(a + kappa*dlp) for the Armijo test and
                 // again after accepting (:225,:233): same argument, same value -> evaluated once;
                 // the derivative it asks for after accepting (:246) is at that same point too
-                double dlp_try;
+                // ... evaluated together with it, or (DSQ_DISP_SPLIT) only after the test accepts and the search goes on;
+                // lp() / dlp() / lp_dlp() return the same bits for the same argument
+                double dlp_try = 0.0;
+#if DSQ_DISP_SPLIT
+                const double lp_try = G.lp(a_try);
+#else
                 const double lp_try = G.lp_dlp(a_try, G.usePrior, dlp_try);
+#endif
                 double theta_kappa = -1.0 * lp_try;
                 double theta_hat_kappa = -1.0 * lp - kappa * epsilon * (dlp * dlp);
                 if (kp.force_iters > 0 && t + 1 >= kp.force_iters) break;   // profiling only
@@ -951,7 +974,11 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
                     if (uniform(change < kp.tol)) { lp = lpnew; break; }
                     if (uniform(a < kp.min_log_alpha)) break;
                     lp = lpnew;
+#if DSQ_DISP_SPLIT
+                    dlp = G.dlp(a, G.usePrior);
+#else
                     dlp = dlp_try;
+#endif
                     kappa = __builtin_fmin(kappa * 1.1, kp.kappa_0);
                     if (it_acc % 5 == 0) kappa = kappa / 2.0;
                 } else {
@@ -983,7 +1010,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     bool stage = false;
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
-            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell)) +
+            size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl, kp.ncell) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell)) +
                            disp_xx_doubles(P, kp.ncell)) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
@@ -996,11 +1023,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
-    const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P)) * sizeof(double);
+    const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell)) * sizeof(double);
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
-    size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds) * sizeof(double)
+    size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds, kp.ncell) * sizeof(double)
                         : (size_t)waves * unstaged_wave) + cell_bytes;   // unstaged: distinct-count buffer + WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
