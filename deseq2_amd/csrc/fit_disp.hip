@@ -31,6 +31,10 @@ namespace dsq {
 #ifndef DSQ_DISP_LANE_MIN
 #define DSQ_DISP_LANE_MIN 4
 #endif
+// rows read through L2 (not staged in LDS): the cell sweep issues the loads of this many trips together
+#ifndef DSQ_DISP_TRIP_BATCH
+#define DSQ_DISP_TRIP_BATCH 4
+#endif
 // ... and from DSQ_DISP_ROWPASS_MIN up the general (non-cell) pass accumulates one matrix row per sweep over the samples
 // (the K p(p+1)/2 running sums of a single sweep no longer fit in registers)
 #ifndef DSQ_DISP_ROWPASS_MIN
@@ -78,8 +82,9 @@ struct DispGene {
     const uint8_t *cid;
     const int32_t *crep;
     // lane-column builds: the products x_c[i] x_c[b] of the cell rows (a property of the design, not of the gene), laid
-    // out [cell][i][b] in block-shared LDS once per block; nullptr when the table would be too large
-    const double *xxs;
+    // out [cell][i][b] in block-shared LDS once per block; nullptr when the table would be too large -- then xcs, the
+    // cell rows themselves ([cell][i], ncell p doubles), and the product is formed on the fly
+    const double *xxs, *xcs;
     // sort the gene's counts (bitonic network in the wave's LDS slice), keep the first of every run and its length.
     // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m), then dv = buf[0..nv), dc = buf[m..m+nv)
     DSQ_DEV void build_distinct(int32_t *buf) {
@@ -147,17 +152,13 @@ DSQ_UNROLL_P
                 }
             };
             const int tail_lane = (m - 1) & 63;
-            for (int k0 = 0; k0 < m; k0 += 64) {
-                const int kk = k0 + lane;
-                const bool valid = kk < m;
-                int j, cmy;
-                if (sorted) { j = valid ? kk : m - 1; cmy = valid ? (int)cid[j] : -1; }
-                else { const int pk = cperm[valid ? kk : m - 1]; j = pk & 0x3ffffff; cmy = valid ? (pk >> 26) : -1; }
+            // one trip of the sweep: positions k0 .. k0 + 63 (lane l takes k0 + l), count and mean already loaded
+            auto trip = [&](int k0, bool valid, int j, int cmy, double yv, double mv) {
                 double wd[K];
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++) wd[k] = 0.0;
                 if (valid) {
-                    f(j, wd, true);
+                    f(j, yv, mv, wd, true);
                     if (!keep_row(j)) {
                         _Pragma("unroll")
                         for (int k = 0; k < K; k++) wd[k] = 0.0;
@@ -190,6 +191,27 @@ DSQ_UNROLL_P
                         }
                     }
                 }
+            };
+            // rows read through L2 (long rows, not staged): the loads of NB trips are issued together, so that a wave pays
+            // the memory latency once per NB trips instead of once per trip (two resident waves per SIMD do not hide it)
+            constexpr int NB = std::is_same<Rows, RowsGlobal>::value ? DSQ_DISP_TRIP_BATCH : 1;
+            for (int k0 = 0; k0 < m; k0 += 64 * NB) {
+                int jb[NB], cb[NB];
+                bool vb[NB];
+                double yb[NB], mb[NB];
+                _Pragma("unroll")
+                for (int b = 0; b < NB; b++) {
+                    const int kk = k0 + 64 * b + lane;
+                    const bool valid = kk < m;
+                    int j, cmy;
+                    if (sorted) { j = valid ? kk : m - 1; cmy = valid ? (int)cid[j] : -1; }
+                    else { const int pk = cperm[valid ? kk : m - 1]; j = pk & 0x3ffffff; cmy = valid ? (pk >> 26) : -1; }
+                    jb[b] = j; cb[b] = cmy; vb[b] = valid;
+                    yb[b] = r.y(j); mb[b] = r.mu(j);
+                }
+                _Pragma("unroll")
+                for (int b = 0; b < NB; b++)
+                    if (k0 + 64 * b < m) trip(k0 + 64 * b, vb[b], jb[b], cb[b], yb[b], mb[b]);
             }
             if (!useCR) return;
             close_cell();
@@ -212,11 +234,10 @@ DSQ_UNROLL_P
                             for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
                         }
                     } else {
-                        const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
-                        const double xb = r.x(j0, bl);
+                        const double xb = xcs[c * P + bl];
                         _Pragma("unroll")
                         for (int i = 0; i < P; i++) {
-                            const double xx = r.x(j0, i) * xb;
+                            const double xx = xcs[c * P + i] * xb;
                             _Pragma("unroll")
                             for (int k = 0; k < K; k++) B[k][i] = B[k][i] + xx * sc[k];
                         }
@@ -267,7 +288,7 @@ DSQ_UNROLL_P
         if (!useCR) {
             for (int j = lane; j < m; j += 64) {
                 double wd[K];
-                f(j, wd, true);
+                f(j, r.y(j), r.mu(j), wd, true);
             }
             return;
         }
@@ -287,7 +308,7 @@ DSQ_UNROLL_P
                     for (int b = 0; b < P; b++) acc[k][b] = 0.0;
                 for (int j = lane; j < m; j += 64) {
                     double wd[K];
-                    f(j, wd, first);
+                    f(j, r.y(j), r.mu(j), wd, first);
                     if (keep_row(j)) {
                         const double xa = r.x(j, a0);
                         _Pragma("unroll")
@@ -315,7 +336,7 @@ DSQ_UNROLL_P
             if (first) {                                          // every column dropped: the caller's sums still run
                 for (int j = lane; j < m; j += 64) {
                     double wd[K];
-                    f(j, wd, true);
+                    f(j, r.y(j), r.mu(j), wd, true);
                 }
             }
             wave_lds_sync();
@@ -341,7 +362,7 @@ DSQ_UNROLL_P
             for (int i = 0; i < K * N; i++) acc[i] = 0.0;
             for (int j = lane; j < m; j += 64) {
                 double wd[K];
-                f(j, wd, true);
+                f(j, r.y(j), r.mu(j), wd, true);
                 if (keep_row(j)) {
                     double xr[P];
 DSQ_UNROLL_P
@@ -440,8 +461,7 @@ DSQ_UNROLL_P
         {
             Bmat<1> B;
             pass<1>(
-                [&](int j, double(&wd)[1], bool lik) {
-                    const double y = r.y(j), mu = r.mu(j);
+                [&](int j, double y, double mu, double(&wd)[1], bool lik) {
                     const double opm = 1.0 + mu * alpha;
                     if (useCR) wd[0] = mu * rcp1(opm);
                     if (lik) {
@@ -513,8 +533,7 @@ DSQ_UNROLL_P
         {
             Bmat<2> B;
             pass<2>(
-                [&](int j, double(&wd)[2], bool lik) {
-                    const double y = r.y(j), mu = r.mu(j);
+                [&](int j, double y, double mu, double(&wd)[2], bool lik) {
                     const double ma = mu * alpha;
                     const double opm = 1.0 + ma;
 #ifdef DSQ_ABLATE_BUILD      // tuning build only (make ablate): skip one component to price it (tools/kbench.py, DSQ_ABLATE)
@@ -603,8 +622,7 @@ DSQ_UNROLL_P
         {
             Bmat<2> B;
             pass<2>(
-                [&](int j, double(&wd)[2], bool lik) {
-                    const double y = r.y(j), mu = r.mu(j);
+                [&](int j, double y, double mu, double(&wd)[2], bool lik) {
                     const double ma = mu * alpha;
                     const double rr = rcp1(1.0 + ma);
                     if (useCR) {
@@ -662,8 +680,7 @@ DSQ_UNROLL_P
         {
             Bmat<3> B;
             pass<3>(
-                [&](int j, double(&wd)[3], bool lik) {
-                    const double y = r.y(j), mu = r.mu(j);
+                [&](int j, double y, double mu, double(&wd)[3], bool lik) {
                     const double ma = mu * alpha, opm = 1.0 + ma;
                     const double rr = 1.0 / opm;
                     if (useCR) {
@@ -763,6 +780,10 @@ __host__ __device__ inline size_t disp_xx_doubles(int p, int ncell) {
     const size_t k = (size_t)ncell * p * p;
     return (p >= DSQ_DISP_LANE_MIN && ncell > 0 && k <= 256) ? k : 0;
 }
+// ... else the cell rows themselves (ncell p doubles)
+__host__ __device__ inline size_t disp_xc_doubles(int p, int ncell) {
+    return (p >= DSQ_DISP_LANE_MIN && ncell > 0 && disp_xx_doubles(p, ncell) == 0) ? (size_t)ncell * p : 0;
+}
 // sorted staging applies to staged, unweighted rows of a design with cells
 template <bool USE_W>
 __host__ __device__ inline bool disp_sorted(bool stage, int ncell) { return stage && !USE_W && ncell > 0; }
@@ -841,6 +862,15 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         }
         xx_s = t_;
     }
+    const double *xc_s = nullptr;
+    if (disp_xc_doubles(P, C) > 0) {
+        double *t_ = reinterpret_cast<double *>(cstart_s) + disp_cell_doubles(m, C, sorted);
+        for (int t = threadIdx.x; t < C * P; t += blockDim.x) {
+            const int c = t / P, i = t % P;
+            t_[t] = kp.x[(size_t)i * m + kp.cell_perm[kp.cell_start[c]]];
+        }
+        xc_s = t_;
+    }
     if (C > 0 || (STAGE && kp.xlds)) __syncthreads();
 
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
@@ -894,7 +924,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.padmask = kp.padmask;
         G.arena = arena;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
-        G.sorted = sorted; G.cid = cid_s; G.crep = crep_s; G.xxs = xx_s;
+        G.sorted = sorted; G.cid = cid_s; G.crep = crep_s; G.xxs = xx_s; G.xcs = xc_s;
         G.build_distinct(dist);
         G.setup_cr();
 
@@ -1011,7 +1041,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     for (int xl = tu.disp_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
             size_t need = (disp_lds_doubles<USE_W>(kp.m, P, w, xl, kp.ncell) + disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(true, kp.ncell)) +
-                           disp_xx_doubles(P, kp.ncell)) * sizeof(double);
+                           disp_xx_doubles(P, kp.ncell) + disp_xc_doubles(P, kp.ncell)) * sizeof(double);
             if (need > budget) continue;
             int blocks = (int)(cu_lds / need);
             const int wcap = 4 * (DSQ_DISP_MINW);     // waves per CU the register budget of this build admits
@@ -1024,7 +1054,8 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
     const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P, kp.ncell)) * sizeof(double);
-    const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell)) * sizeof(double);
+    const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
+                               disp_xc_doubles(P, kp.ncell)) * sizeof(double);
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds, kp.ncell) * sizeof(double)

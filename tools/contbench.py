@@ -7,8 +7,13 @@ import torch  # noqa: F401
 from deseq2_amd import core, simulate
 from deseq2_amd.engine import DeviceEngine
 E = DeviceEngine("cuda:0")
-for n, m, extra in ((20000, 500, 1), (20000, 500, 3), (20000, 200, 6)):
-    x0 = simulate.design_batch_condition(m)
+SHAPES = [(20000, 500, 1, None), (20000, 500, 3, None), (20000, 200, 6, None),
+          # a factor with p - 1 levels and ONE continuous covariate, 20 000 x 200
+          (20000, 200, 1, 9), (20000, 200, 1, 15), (20000, 240, 1, 23)]
+if os.environ.get("CONTBENCH_ONLY"):
+    SHAPES = [SHAPES[int(k)] for k in os.environ["CONTBENCH_ONLY"].split(",")]
+for n, m, extra, levels in SHAPES:
+    x0 = simulate.design_batch_condition(m) if levels is None else simulate.design_factor(m, levels)
     rng = np.random.default_rng(5)
     x = np.column_stack([x0] + [rng.normal(size=m) for _ in range(extra)])
     d = simulate.make_counts(n, x, seed=3, beta_sd=np.array([0.5] * (x.shape[1] - 2) + [1.0]) * 0.3)
