@@ -525,6 +525,10 @@ DSQ_UNROLL_P
 #ifndef DSQ_BETA_LANE_MIN
 #define DSQ_BETA_LANE_MIN 7
 #endif
+// the sweep of the cell kernel issues the loads of this many trips together
+#ifndef DSQ_BETA_TRIP_BATCH
+#define DSQ_BETA_TRIP_BATCH 4
+#endif
 #ifndef DSQ_BETA_CELL_MINW
 #define DSQ_BETA_CELL_MINW (DSQ_P <= 6 ? 3 : DSQ_P <= 10 ? 2 : 1)
 #endif
@@ -619,20 +623,17 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 if (lane == cur) { Sl = s; Tl = tt; }
                 a1 = 0.0; a2 = 0.0;
             };
-            for (int k0 = 0; k0 < m; k0 += 64) {
-                const int k = k0 + lane;
-                const bool valid = k < m;
-                const int pk = pc[valid ? k : m - 1];
-                const int j = pk & 0x3ffffff, cmy = valid ? (pk >> 26) : -1;
+            // one trip: positions k0 .. k0 + 63 of the cell-sorted sequence; the sample's count, normalization factor (and
+            // weight) were loaded by the caller
+            auto trip = [&](int k0, bool valid, int cmy, double nf, double y, double wt) {
                 double wv = 0.0, wz = 0.0;
                 if (valid) {
                     const double e = slab[4 * cmy], eta = slab[4 * cmy + 1];
-                    const double nf = nfg[j], y = (double)yg[j];
                     const double raw = nf * e;
                     const double mu = __builtin_fmax(raw, minmu);
                     const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
                     double rw = rcp;
-                    if constexpr (USE_W) rw = wg[j] * rcp;
+                    if constexpr (USE_W) rw = wt * rcp;
                     wv = mu * rw;
                     const double lg = (raw >= minmu) ? eta : dlog(mu / nf);
                     wz = wv * lg + rw * (y - mu);       // w z, with w / mu = [wts] / (1 + alpha mu): no second division
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                             const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
                             t = y * lg - (y + size) * l1p;
                         } else t = nb_offbranch(y, size, mu);
-                        if constexpr (USE_W) dacc += wg[j] * t;
+                        if constexpr (USE_W) dacc += wt * t;
                         else dacc += t;
                     }
                 }
@@ -671,6 +672,30 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                         a2 += mine ? wz : 0.0;
                     }
                 }
+            };
+            // the row is read through L2 in every sweep: the loads of NB trips are issued together, so that a wave pays
+            // the memory latency once per NB trips (few resident waves per SIMD: they do not hide it)
+            constexpr int NB = DSQ_BETA_TRIP_BATCH;
+            for (int k0 = 0; k0 < m; k0 += 64 * NB) {
+                int cb[NB];
+                bool vb[NB];
+                double nb_[NB], yb[NB], wb[NB];
+                _Pragma("unroll")
+                for (int b = 0; b < NB; b++) {
+                    const int k = k0 + 64 * b + lane;
+                    const bool valid = k < m;
+                    const int pk = pc[valid ? k : m - 1];
+                    const int j = pk & 0x3ffffff;
+                    cb[b] = valid ? (pk >> 26) : -1;
+                    vb[b] = valid;
+                    nb_[b] = nfg[j];
+                    yb[b] = (double)yg[j];
+                    wb[b] = 1.0;
+                    if constexpr (USE_W) wb[b] = wg[j];
+                }
+                _Pragma("unroll")
+                for (int b = 0; b < NB; b++)
+                    if (k0 + 64 * b < m) trip(k0 + 64 * b, vb[b], cb[b], nb_[b], yb[b], wb[b]);
             }
             close_cell();
             if (with_dev) dev = -2.0 * (K + wave_allreduce(dacc));
