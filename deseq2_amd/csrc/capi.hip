@@ -262,6 +262,9 @@ hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, 
     return DispatchP<DSQ_P_REG>::disp(p, kp, st, grid, ok);
 }
 hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok) {
+    // (wide designs: the caller passes the padded width, dsq_optim_rows)
+    if (p == DSQ_P_WIDE0) { *ok = true; return launch_optim_p<DSQ_P_WIDE0>(kp, st); }
+    if (p == DSQ_P_WIDE) { *ok = true; return launch_optim_p<DSQ_P_WIDE>(kp, st); }
     return DispatchP<DSQ_P_REG>::optim(p, kp, st, ok);
 }
 
@@ -1502,19 +1505,20 @@ int dsq_optim_rows(const DsqOptimArgs *a, const DsqOptimOut *o) {
     if (!a || !o) return fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->layout != DSQ_LAYOUT_R) return fail(DSQ_ERR_ARG, "host entry points take R layout only");
     if (a->n < 0 || a->m < 1 || a->p < 1) return fail(DSQ_ERR_ARG, "bad dimensions");
-    if (a->p > DSQ_P_REG) return fail(DSQ_ERR_UNSUPPORTED, "dsq_optim_rows: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (a->p > DSQ_P_WIDE) return fail(DSQ_ERR_UNSUPPORTED, "dsq_optim_rows: p=%d > %d design columns", a->p, DSQ_P_WIDE);
     if (!a->y || !a->x || !a->nf || !a->alpha_hat || !a->lambda || !a->beta_start) return fail(DSQ_ERR_ARG, "NULL input array");
     if (a->useWeights && !a->weights) return fail(DSQ_ERR_ARG, "useWeights set but weights is NULL");
     if (!o->beta || !o->betaSE || !o->conv || !o->mu || !o->logLike) return fail(DSQ_ERR_ARG, "NULL output array");
     if (int rc = check_device()) return rc;
     if (a->n == 0) return DSQ_OK;
     hipStream_t st = nullptr;
-    const size_t n = a->n, m = a->m, p = a->p;
+    // wide designs (see above): the kernel runs at the padded width pk -- zero design columns, ridge 1, start value 0
+    const size_t n = a->n, m = a->m, p = a->p, pk = is_wide(a->p) ? wide_width(a->p) : a->p;
     void *v;
     int rc;
     OptimKernelParams kp;
     memset(&kp, 0, sizeof kp);
-    kp.n = a->n; kp.m = a->m; kp.p = a->p; kp.minmu = a->minmu;
+    kp.n = a->n; kp.m = a->m; kp.p = (int)pk; kp.minmu = a->minmu;
     if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc;
     bool ycheck = false;
     long ld = 0;
@@ -1532,28 +1536,29 @@ int dsq_optim_rows(const DsqOptimArgs *a, const DsqOptimOut *o) {
         kp.useWeights = 1;
     }
     // x | alpha | lambda (natural-log scale) | beta_start
-    const size_t off_x = 0, off_al = m * p, off_lam = off_al + n, off_b = off_lam + p, tot = off_b + n * p;
+    const size_t off_x = 0, off_al = m * pk, off_lam = off_al + n, off_b = off_lam + pk, tot = off_b + n * pk;
     if ((rc = ws_get(WS_H_VEC, tot * 8, &v))) return rc;
     double *vec = (double *)v;
-    static thread_local double lamnat[DSQ_P_REG];
+    static thread_local double lamnat[DSQ_P_WIDE];
     const double ln2 = 0.6931471805599453;
-    for (size_t c = 0; c < p; c++) lamnat[c] = a->lambda[c] / (ln2 * ln2);
+    for (size_t c = 0; c < pk; c++) lamnat[c] = c < p ? a->lambda[c] / (ln2 * ln2) : 1.0;
+    if (pk != p) DSQ_HIP(hipMemsetAsync(vec, 0, tot * 8, st));
     DSQ_HIP(hipMemcpyAsync(vec + off_x, a->x, m * p * 8, hipMemcpyHostToDevice, st));
     DSQ_HIP(hipMemcpyAsync(vec + off_al, a->alpha_hat, n * 8, hipMemcpyHostToDevice, st));
-    DSQ_HIP(hipMemcpyAsync(vec + off_lam, lamnat, p * 8, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipMemcpyAsync(vec + off_lam, lamnat, pk * 8, hipMemcpyHostToDevice, st));
     DSQ_HIP(hipMemcpyAsync(vec + off_b, a->beta_start, n * p * 8, hipMemcpyHostToDevice, st));
     kp.x = vec + off_x; kp.alpha_hat = vec + off_al; kp.lamnat = vec + off_lam; kp.beta_start = vec + off_b;
     // outputs: beta | betaSE | loglike | conv ; mu (gene-major, then R layout)
-    if ((rc = ws_get(WS_H_OUTVEC, (2 * n * p + 2 * n) * 8, &v))) return rc;
+    if ((rc = ws_get(WS_H_OUTVEC, (2 * n * pk + 2 * n) * 8, &v))) return rc;
     double *ov = (double *)v;
-    kp.beta = ov; kp.betaSE = ov + n * p; kp.loglike = ov + 2 * n * p; kp.conv = (int32_t *)(ov + 2 * n * p + n);
+    kp.beta = ov; kp.betaSE = ov + n * pk; kp.loglike = ov + 2 * n * pk; kp.conv = (int32_t *)(ov + 2 * n * pk + n);
     void *mu_gm, *mu_r;
     if ((rc = ws_get(WS_MUOUT, n * (size_t)ld * 8, &mu_gm))) return rc;
     if ((rc = ws_get(WS_H_OUTMAT, n * m * 8, &mu_r))) return rc;
     kp.mu_out = (double *)mu_gm;
     bool ok = false;
     prof_begin(st);
-    DSQ_HIP(DispatchP<DSQ_P_REG>::optim(a->p, kp, st, &ok));
+    DSQ_HIP(dispatch_optim_rows((int)pk, kp, st, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     DSQ_HIP(launch_transpose_gm_to_r_f64(kp.mu_out, (double *)mu_r, a->n, a->m, ld, st));

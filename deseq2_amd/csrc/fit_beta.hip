@@ -1021,30 +1021,42 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
 // Damped Fisher scoring on the penalised NB log posterior over beta in [-30, 30]^p (log2 scale), one wavefront per
 // row; the test suite's CPU checker states the same iteration operation for operation.  A handful of rows
 // per analysis: no staging, every pass re-reads the row through L2.
-#if DSQ_P < DSQ_WIDE_MIN
+// Wide builds (p > 10, zero-padded to 16 / 24 columns: a padded coefficient has a zero design column, ridge 1 and start
+// value 0, so it stays exactly 0 and adds exact zeros to everything else): the wave-uniform p x p work lives once per
+// wave in LDS (DSQ_BWORK) and the Gram matrices are accumulated two rows per pass (beta_gram_wide) -- same terms, same
+// order per entry as the one-pass form.
 template <int P, bool USE_W>
 __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
+#if DSQ_P >= DSQ_WIDE_MIN
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *arena = smem;
+    int arena_off = 0;
+#endif
     const int lane = threadIdx.x;
     const int m = kp.m;
     constexpr int N = SymNB<P>::value;
     const double ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
     const double bound = 30.0 * ln2;
     const int nwork = DSQ_NWORK(kp);
+    DSQ_BWORK(DsqVecP, lam);
+    DSQ_BWORK(DsqVecP, gam);
+    DSQ_BWORK(DsqVecP, trial);
+    DSQ_BMARK(row_mark);
     for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        DSQ_BRESET(row_mark);
         const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
         const double alpha = kp.alpha_hat[g], size = 1.0 / alpha;
-        double lam[P], gam[P], trial[P];
-#pragma unroll
+DSQ_UNROLL_P
         for (int c = 0; c < P; c++) {
             lam[c] = kp.lamnat[c];
             gam[c] = __builtin_fmin(__builtin_fmax(kp.beta_start[(size_t)g + (size_t)kp.n * c] * ln2, -bound), bound);
         }
         auto eta_of = [&](const double (&b)[P], int j) {
             double eta = kp.x[j] * b[0];
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 1; c < P; c++) eta = __builtin_fma(kp.x[(size_t)c * m + j], b[c], eta);
             return eta;
         };
@@ -1057,49 +1069,61 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
             }
             const double ll = wave_allreduce(acc);
             double pen = 0.0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) pen = __builtin_fma(0.5 * lam[c], b[c] * b[c], pen);
             const double f = pen - ll;
             return dfinite(f) ? f : 1e300;
         };
+        // the scoring weights of a sample at gam: w = [wts] mu / (1 + alpha mu), r = [wts] (y - mu) / (1 + alpha mu)
+        auto score_terms = [&](int j, double &wv, double &rv) {
+            const double mu = nfg[j] * dexp(eta_of(gam, j));
+            if constexpr (USE_W) { wv = (wg[j] * mu) / (1.0 + alpha * mu); rv = (wg[j] * ((double)yg[j] - mu)) / (1.0 + alpha * mu); }
+            else { wv = mu / (1.0 + alpha * mu); rv = ((double)yg[j] - mu) / (1.0 + alpha * mu); }
+        };
         double F = objective(gam);
         int converged = 0;
+        DSQ_BMARK(iter_mark);
         for (int it = 0; it < 100 && !converged; it++) {
-            double acc[N + P];
-#pragma unroll
-            for (int i = 0; i < N + P; i++) acc[i] = 0.0;
-            for (int j = lane; j < m; j += 64) {
-                const double mu = nfg[j] * dexp(eta_of(gam, j));
-                double wv, rv;
-                if constexpr (USE_W) { wv = (wg[j] * mu) / (1.0 + alpha * mu); rv = (wg[j] * ((double)yg[j] - mu)) / (1.0 + alpha * mu); }
-                else { wv = mu / (1.0 + alpha * mu); rv = ((double)yg[j] - mu) / (1.0 + alpha * mu); }
-                double xr[P];
-#pragma unroll
-                for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
-                int idx = 0;
-#pragma unroll
-                for (int a = 0; a < P; a++) {
-#pragma unroll
-                    for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
-                    acc[N + a] += xr[a] * rv;
+            DSQ_BRESET(iter_mark);
+            DSQ_BWORK(LU<P>, lu);
+            DSQ_BWORK(DsqVecP, rhs);
+            if constexpr (P >= DSQ_WIDE_MIN) {
+                beta_gram_wide<P, true>(kp.x, m, lane, score_terms, lu.a, rhs);
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++) { lu.a[a][a] = lu.a[a][a] + lam[a]; rhs[a] = rhs[a] - lam[a] * gam[a]; }
+            } else {
+                double acc[N + P];
+DSQ_UNROLL_P
+                for (int i = 0; i < N + P; i++) acc[i] = 0.0;
+                for (int j = lane; j < m; j += 64) {
+                    double wv, rv;
+                    score_terms(j, wv, rv);
+                    double xr[P];
+DSQ_UNROLL_P
+                    for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
+                    int idx = 0;
+DSQ_UNROLL_P
+                    for (int a = 0; a < P; a++) {
+DSQ_UNROLL_P
+                        for (int b = a; b < P; b++) acc[idx++] += xr[a] * (xr[b] * wv);
+                        acc[N + a] += xr[a] * rv;
+                    }
                 }
+                wave_allreduce_n(acc);
+                int idx = 0;
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                    for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++) { lu.a[a][a] = lu.a[a][a] + lam[a]; rhs[a] = acc[N + a] - lam[a] * gam[a]; }
             }
-            wave_allreduce_n(acc);
-            LU<P> lu;
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < P; a++)
-#pragma unroll
-                for (int b = a; b < P; b++) { lu.a[a][b] = acc[idx]; lu.a[b][a] = acc[idx]; idx++; }
-            double rhs[P];
-#pragma unroll
-            for (int a = 0; a < P; a++) { lu.a[a][a] = lu.a[a][a] + lam[a]; rhs[a] = acc[N + a] - lam[a] * gam[a]; }
             lu.factor();
             lu.solve(rhs);
             double t = 1.0, Ft = 0.0;
             int accepted = 0;
             for (int h = 0; h < 40; h++) {
-#pragma unroll
+DSQ_UNROLL_P
                 for (int c = 0; c < P; c++) trial[c] = __builtin_fmin(__builtin_fmax(gam[c] + t * rhs[c], -bound), bound);
                 Ft = objective(trial);
                 if (uniform(Ft < F)) { accepted = 1; break; }
@@ -1107,51 +1131,73 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
             }
             if (!accepted) { converged = 1; break; }
             const double dec = F - Ft;
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) gam[c] = trial[c];
             F = Ft;
             if (uniform(dec <= 1e-10 * (__builtin_fabs(F) + 1e-10))) converged = 1;
         }
         // (:382-400)
-        double gacc[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) gacc[i] = 0.0;
+        DSQ_BRESET(iter_mark);
+        DSQ_BWORK(DsqMatP, G);
+        DSQ_BWORK(DsqMatP, Gi);
+        DSQ_BWORK(DsqMatP, T);
+        DSQ_BWORK(DsqMatP, Sg);
+        // pmax(mu, minmu) enters the covariance and the log likelihood; the reported mean keeps the caller's floor
+        auto final_w = [&](int j, double muc) {
+            if constexpr (USE_W) return wg[j] / (1.0 / muc + alpha);
+            else return 1.0 / (1.0 / muc + alpha);
+        };
         double lacc = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            const double mu = nfg[j] * dexp(eta_of(gam, j));
-            // pmax(mu, mu_floor) as numpy.maximum / R's `[<-` on a comparison leave a NaN in place
-            kp.mu_out[(size_t)g * kp.ld + j] = (kp.mu_floor > 0.0 && mu < kp.mu_floor) ? kp.mu_floor : mu;
-            const double muc = __builtin_fmax(mu, kp.minmu);
-            double wv;
-            if constexpr (USE_W) wv = wg[j] / (1.0 / muc + alpha);
-            else wv = 1.0 / (1.0 / muc + alpha);
-            double xr[P];
-#pragma unroll
-            for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
+        if constexpr (P >= DSQ_WIDE_MIN) {
+            for (int j = lane; j < m; j += 64) {
+                const double mu = nfg[j] * dexp(eta_of(gam, j));
+                kp.mu_out[(size_t)g * kp.ld + j] = (kp.mu_floor > 0.0 && mu < kp.mu_floor) ? kp.mu_floor : mu;
+                double d = dnbinom_mu_log((double)yg[j], size, __builtin_fmax(mu, kp.minmu));
+                if constexpr (USE_W) d = wg[j] * d;
+                lacc += d;
+            }
+            beta_gram_wide<P, false>(kp.x, m, lane, [&](int j, double &wv, double &zw) {
+                const double mu = nfg[j] * dexp(eta_of(gam, j));
+                wv = final_w(j, __builtin_fmax(mu, kp.minmu));
+                zw = 0.0;
+            }, G, nullptr);
+        } else {
+            double gacc[N];
+DSQ_UNROLL_P
+            for (int i = 0; i < N; i++) gacc[i] = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                const double mu = nfg[j] * dexp(eta_of(gam, j));
+                // pmax(mu, mu_floor) as numpy.maximum / R's `[<-` on a comparison leave a NaN in place
+                kp.mu_out[(size_t)g * kp.ld + j] = (kp.mu_floor > 0.0 && mu < kp.mu_floor) ? kp.mu_floor : mu;
+                const double muc = __builtin_fmax(mu, kp.minmu);
+                const double wv = final_w(j, muc);
+                double xr[P];
+DSQ_UNROLL_P
+                for (int c = 0; c < P; c++) xr[c] = kp.x[(size_t)c * m + j];
+                int idx = 0;
+DSQ_UNROLL_P
+                for (int a = 0; a < P; a++)
+DSQ_UNROLL_P
+                    for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
+                double d = dnbinom_mu_log((double)yg[j], size, muc);
+                if constexpr (USE_W) d = wg[j] * d;
+                lacc += d;
+            }
+            wave_allreduce_n(gacc);
             int idx = 0;
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
-                for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
-            double d = dnbinom_mu_log((double)yg[j], size, muc);
-            if constexpr (USE_W) d = wg[j] * d;
-            lacc += d;
-        }
-        wave_allreduce_n(gacc);
-        const double ll = wave_allreduce(lacc);
-        double G[P][P], Gi[P][P], T[P][P], Sg[P][P];
-        {
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = a; b < P; b++) { G[a][b] = gacc[idx]; G[b][a] = gacc[idx]; idx++; }
-            LU<P> lu;
-#pragma unroll
+        }
+        const double ll = wave_allreduce(lacc);
+        {
+            DSQ_BWORK(LU<P>, lu);
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
-#pragma unroll
+DSQ_UNROLL_P
                 for (int b = 0; b < P; b++) lu.a[a][b] = G[a][b];
-#pragma unroll
+DSQ_UNROLL_P
             for (int a = 0; a < P; a++) lu.a[a][a] = lu.a[a][a] + lam[a];
             lu.factor();
             lu.inverse(Gi);
@@ -1159,7 +1205,7 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
         mat_mul<P>(Gi, G, T);
         mat_mul<P>(T, Gi, Sg);
         if (lane == 0) {
-#pragma unroll
+DSQ_UNROLL_P
             for (int c = 0; c < P; c++) {
                 kp.beta[(size_t)g + (size_t)kp.n * c] = log2e * gam[c];
                 kp.betaSE[(size_t)g + (size_t)kp.n * c] = log2e * __builtin_sqrt(__builtin_fmax(Sg[c][c], 0.0));
@@ -1170,19 +1216,21 @@ __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
     }
 }
 
+// LDS of one single-wave block of the wide build: lam, gam, trial | LU, rhs | G, Gi, T, Sg (+ the final LU)
+__host__ __device__ static inline size_t optim_arena_doubles(int p) {
+    return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 12 * p + 32 : 0;
+}
+
 template <>
 hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &kp, hipStream_t st) {
     int grid = kp.n < 4096 ? kp.n : 4096;
     if (kp.rows && grid > 256) grid = 256;       // a row list (its length lives on the device): a handful of rows
     if (grid < 1) grid = 1;
-    if (kp.useWeights) hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, true>), dim3(grid), dim3(64), 0, st, kp);
-    else hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, false>), dim3(grid), dim3(64), 0, st, kp);
+    const size_t lds = optim_arena_doubles(DSQ_P) * sizeof(double);
+    if (kp.useWeights) hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, true>), dim3(grid), dim3(64), lds, st, kp);
+    else hipLaunchKernelGGL((optim_rows_kernel<DSQ_P, false>), dim3(grid), dim3(64), lds, st, kp);
     return hipGetLastError();
 }
-#else
-template <>
-hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &, hipStream_t) { return hipErrorNotSupported; }
-#endif
 
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent

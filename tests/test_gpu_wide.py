@@ -45,6 +45,45 @@ def test_wide_native_routines_match_oracle(oracle, levels, m, useW, useQR):
     assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"], "fitDispGrid")
 
 
+@pytest.mark.parametrize("levels,m,useW", [(11, 66, False), (16, 96, True), (20, 100, False), (24, 120, True)])
+def test_wide_optim_rows_match_oracle(oracle, levels, m, useW):
+    """dsq_optim_rows on a wide design (the rows fitNbinomGLMsOptim re-fits, R/fitNbinomGLMs.R:340-407): the padded
+    kernel against the oracle's iteration at the true p, every output"""
+    d = make_case(24, m, ("factor", levels), seed=3 * levels + m, weights=useW, sf_random=True)
+    y = d["counts"].copy()
+    y[3] = 0; y[3, 5:9] = 1000                      # rows the IRLS cannot fit
+    y[11] = 0; y[11, -1] = 7
+    y[20, : m // 2] = 0
+    p = levels
+    lam = np.full(p, 1e-6)
+    lam[-1] = 0.5
+    start = np.random.default_rng(3).normal(0, 1.0, (y.shape[0], p))
+    args = (y, d["x"], d["nf"], d["alpha_init"], lam, d["weights"], useW, start, 0.5)
+    got, want = native.optimRows(*args), oracle.optimRows(*args)
+    for k in ("beta", "betaSE", "conv", "mu", "logLike"):
+        assert_same(np.asarray(got[k], float), np.asarray(want[k], float), "wide optimRows$" + k)
+    assert want["conv"].mean() > 0.8
+
+
+def test_wide_chain_with_optim_rows_matches_oracle(oracle):
+    """a wide analysis with rows the IRLS does not fit (a continuous covariate next to a 15-level factor): the
+    call-by-call chain on the device, optim rows included, against the oracle chain"""
+    m = 90
+    x = np.column_stack([simulate.design_factor(m, 15), np.random.default_rng(5).normal(size=m)])
+    d = simulate.make_counts(150, x, seed=8, beta_sd=np.array([0.5] * 14 + [0.3]))
+    y = d["counts"].copy()
+    y[7] = 0; y[7, 40:43] = 3000
+    y[19] = 0; y[19, -1] = 11
+    E = DeviceEngine("cuda:0")
+    calls, inner = [], E.optim_rows
+    E.optim_rows = lambda *a_, **k_: (calls.append(a_[0].shape[0] if hasattr(a_[0], "shape") else 1), inner(*a_, **k_))[1]
+    a = core.DESeq(core.DESeqDataSet(y, x, engine=E), minReplicatesForReplace=np.inf)
+    assert calls, "no row went to the optim fallback: the case does not exercise it"
+    b = core.DESeq(core.DESeqDataSet(y, x, engine=HostEngine(oracle)), minReplicatesForReplace=np.inf)
+    for k in ("dispGeneEst", "dispersion", "beta", "betaSE", "WaldStatistic", "betaConv", "betaIter", "deviance"):
+        assert_same(a.mcols[k], b.mcols[k], "wide DESeq() with optim rows$" + k)
+
+
 def test_wide_chain_lrt_matches_oracle(oracle):
     """12-level factor, nbinomLRT against the intercept: the whole DESeq() chain on the HBM-resident engine"""
     m = 96
