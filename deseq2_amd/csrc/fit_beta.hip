@@ -21,6 +21,17 @@
 // The convergence test and the |beta| > 30 / NaN aborts are wave-uniform scalar flow.
 // Slab (sqrt(w); mu, later sqrt(w) z; log(mu / nf) per sample) lives in wave-private LDS, X in a block-shared
 // LDS slab; when m*p is too large for that both fall back to L2-resident global memory.
+// From DSQ_BETA_WIDE_MIN design columns up the general and the optim kernel are built the "wide" way: the wave-uniform
+// p x p work (four p x p matrices in the post-loop block alone: 800 VGPRs at p = 10) lives ONCE per wave in an LDS arena
+// instead of in every lane's registers, the loops over p are rolled, the Gram matrices are accumulated two rows per
+// pass.  Measured at p = 10: 512 VGPRs + 372 spilled (one wave per SIMD) -> 228, no spill; 20 000 genes, one
+// continuous covariate: m = 100 4.9 -> 4.5 ms, m = 200 7.3 -> 7.1 ms, m = 500 12.9 -> 8.5 ms.  At p = 7, 8, 9 the
+// register build is still the faster one (p = 9, m = 500: 9.0 vs 11.9 ms), hence the threshold
+// (profiles/r03_general_path.txt).  The cell kernel is not affected (its own unrolling, LaneLU from p = 7).
+#ifndef DSQ_BETA_WIDE_MIN
+#define DSQ_BETA_WIDE_MIN 10
+#endif
+#define DSQ_WIDE_MIN DSQ_BETA_WIDE_MIN
 #include "dsq_internal.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -32,10 +43,11 @@ namespace dsq {
 template <int P>
 struct SymNB { static constexpr int value = P * (P + 1) / 2; };
 
-// WIDE build (DSQ_P > 10, see fit_disp.hip): the wave-uniform work arrays live ONCE per wave in an LDS arena instead
+#define DSQ_BETA_ARENA_MIN DSQ_WIDE_MIN
+// WIDE build (DSQ_P >= DSQ_WIDE_MIN, see above and fit_disp.hip): the wave-uniform work arrays live ONCE per wave in an LDS arena instead
 // of once per lane in scratch memory, and the Householder-stage loops stay fully unrolled so that a lane's row and
 // its partial sums are registers.  In the per-width builds the macros expand to the plain local declarations.
-#if DSQ_P >= DSQ_WIDE_MIN
+#if DSQ_P >= DSQ_BETA_ARENA_MIN
 #define DSQ_BWORK(T, name) T &name = *reinterpret_cast<T *>(arena + arena_off); arena_off += (int)((sizeof(T) + 7) / 8)
 #define DSQ_BMARK(name) const int name = arena_off
 #define DSQ_BRESET(name) arena_off = name
@@ -52,7 +64,7 @@ typedef double DsqMatP1[DSQ_P][DSQ_P + 1];
 
 // doubles of per-wave LDS arena the WIDE build needs: lambda, contrast, beta, beta_prev, then the larger of the
 // QR stage state (scalS, tS, Rm, gamma) and the post-loop block (G, Gi, T, Sg, LU)
-__host__ __device__ inline size_t beta_arena_doubles(int p) { return p >= DSQ_WIDE_MIN ? (size_t)5 * p * p + 12 * p + 32 : 0; }
+__host__ __device__ inline size_t beta_arena_doubles(int p) { return p >= DSQ_BETA_ARENA_MIN ? (size_t)5 * p * p + 12 * p + 32 : 0; }
 
 // WIDE build: G[a][b] = sum_j x_ja (x_jb w_j) (b >= a, mirrored) and, optionally, rhs[a] = sum_j x_ja zw_j, two
 // matrix rows per pass over the samples with the pass and column loops unrolled (register sums); per-sample weights
@@ -140,8 +152,18 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
     return wave_allreduce(kacc);
 }
 
-template <int P, bool USE_W, bool STAGE>
-__global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernelParams kp) {
+// QRROWS (staged rows, useQR, p >= DSQ_BETA_QRROWS_MIN): the rows of [sqrt(w) X ; sqrt(ridge) | sqrt(w) z] live in
+// the wave's LDS and every Householder stage applies the previous reflection to them in place -- the operations of the
+// replay on the same values in the same order (hence the same bits), p^2 instead of p^3 work per row, and the
+// wave-uniform reflector state shrinks from 2 p^2 registers (512 VGPRs + spills at p = 10) to one reflector.
+#ifndef DSQ_BETA_QRROWS_MIN
+#define DSQ_BETA_QRROWS_MIN DSQ_BETA_WIDE_MIN
+#endif
+__host__ __device__ static inline size_t beta_qr_doubles(int m, int p) { return (size_t)(m + p) * (p + 1) + (size_t)p * p + p; }
+
+template <int P, bool USE_W, bool STAGE, bool QRROWS>
+__global__ void __launch_bounds__(256, (QRROWS ? 2 : DSQ_BETA_MINW)) fit_beta_kernel(BetaKernelParams kp) {
+    static_assert(!QRROWS || STAGE, "stored rows need the staged layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -164,7 +186,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
     } else {
         slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * (size_t)m * kSlabVecs;
     }
-#if DSQ_P >= DSQ_WIDE_MIN
+#if DSQ_P >= DSQ_BETA_ARENA_MIN
     double *arena = STAGE ? smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs +
                                 (size_t)wave * beta_arena_doubles(P)
                           : smem + (size_t)wave * beta_arena_doubles(P);
@@ -172,6 +194,14 @@ __global__ void __launch_bounds__(256, DSQ_BETA_MINW) fit_beta_kernel(BetaKernel
 #endif
     double *sw_s = slab, *mu_s = slab + m, *b_s = mu_s;   // mu and sqrt(w)*z share a slot
     double *lg_s = slab + 2 * (size_t)m;                   // log(mu / nf) of the current mu
+    // QRROWS: behind all slabs (and arenas), per wave: the (m + P) x (P + 1) matrix column by column, then R and gamma
+    double *qa = nullptr, *qR = nullptr, *qg = nullptr;
+    if constexpr (QRROWS) {
+        qa = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(P) +
+             (size_t)wave * beta_qr_doubles(m, P);
+        qR = qa + (size_t)M * (P + 1);
+        qg = qR + P * P;
+    }
 
     DSQ_BWORK(DsqVecP, lambda);
     DSQ_BWORK(DsqVecP, contrast);
@@ -231,7 +261,92 @@ DSQ_UNROLL_P
             for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
             if (abl & 2) {
                 // (ablated: no least-squares solve)
-            } else if (kp.useQR) {
+            } else if (QRROWS && kp.useQR) {
+                if constexpr (QRROWS) {
+                // pass A: the rows of the least squares into LDS (column c of row i at qa[c M + i]; column P = sqrt(w) z)
+                for (int i = lane; i < M; i += 64) {
+                    if (i < m) {
+                        const double mu = mu_s[i];
+                        const double sw = __builtin_sqrt(wvec(i, mu));
+                        const double z = lg_s[i] + ((double)yg[i] - mu) / mu;
+                        sw_s[i] = sw;
+DSQ_UNROLL_Q
+                        for (int c = 0; c < P; c++) qa[(size_t)c * M + i] = xs[c * m + i] * sw;
+                        qa[(size_t)P * M + i] = z * sw;
+                    } else {
+DSQ_UNROLL_Q
+                        for (int c = 0; c < P; c++) qa[(size_t)c * M + i] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
+                        qa[(size_t)P * M + i] = 0.0;
+                    }
+                }
+                // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
+                double tprev[P + 1];
+                double scal_prev = 0.0;
+DSQ_UNROLL_Q
+                for (int j = 0; j <= P; j++) tprev[j] = 0.0;
+DSQ_UNROLL_Q
+                for (int k = 0; k < P; k++) {
+                    double acc[P + 1], prow[P + 1];
+DSQ_UNROLL_Q
+                    for (int j = 0; j <= P; j++) { acc[j] = 0.0; prow[j] = 0.0; }
+                    for (int i = lane; i < M; i += 64) {
+                        if (i < k) continue;                       // finished rows of R
+                        double a[P + 1];
+DSQ_UNROLL_Q
+                        for (int j = (k > 0 ? k - 1 : 0); j <= P; j++) a[j] = qa[(size_t)j * M + i];
+                        if (k > 0) {                               // (i >= k > k - 1: the reflection applies)
+                            const double v = a[k - 1] * scal_prev;
+DSQ_UNROLL_Q
+                            for (int j = k; j <= P; j++) {
+                                a[j] = __builtin_fma(v, tprev[j], a[j]);
+                                qa[(size_t)j * M + i] = a[j];
+                            }
+                        }
+                        if (i > k) {
+DSQ_UNROLL_Q
+                            for (int j = k; j < P; j++) acc[j] += a[k] * a[j];
+                            acc[P] += a[k] * a[P];
+                        } else {
+DSQ_UNROLL_Q
+                            for (int j = k; j <= P; j++) prow[j] = a[j];
+                        }
+                    }
+DSQ_UNROLL_Q
+                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);
+DSQ_UNROLL_Q
+                    for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
+                    const double alpha_k = prow[k];
+                    double tau, scal, bet;
+                    if (acc[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                    else {
+                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acc[k]), alpha_k);
+                        tau = (bet - alpha_k) / bet;
+                        scal = 1.0 / (alpha_k - bet);
+                    }
+                    scal_prev = scal;
+DSQ_UNROLL_Q
+                    for (int j = k + 1; j <= P; j++) {
+                        const double wj = prow[j] + scal * acc[j];
+                        tprev[j] = -tau * wj;
+                    }
+                    if (lane == 0) {
+                        qR[k * P + k] = bet;
+DSQ_UNROLL_Q
+                        for (int j = k + 1; j < P; j++) qR[k * P + j] = prow[j] + tprev[j];
+                        qg[k] = prow[P] + tprev[P];
+                    }
+                }
+                wave_lds_sync();
+DSQ_UNROLL_Q
+                for (int i = P - 1; i >= 0; i--) {
+                    double tt = qg[i];
+DSQ_UNROLL_Q
+                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[i * P + j], beta[j], tt);
+                    beta[i] = tt / qR[i * P + i];
+                }
+                wave_lds_sync();
+                }
+            } else if (!QRROWS && kp.useQR) {
                 // pass A                                                       (:336-353)
                 if (!(abl & 1))
                 for (int j = lane; j < m; j += 64) {
@@ -374,7 +489,7 @@ DSQ_UNROLL_P
             int toolarge = 0;
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
-            if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0); break; }   // (:357-360)
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0) && !QRROWS; break; }   // (:357-360)
             if (!(abl & 4)) update_mu();
             double dacc = 0.0;                                                            // (:365-373)
             if (!(abl & 8))
@@ -1027,7 +1142,7 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
 // order per entry as the one-pass form.
 template <int P, bool USE_W>
 __global__ void __launch_bounds__(64) optim_rows_kernel(OptimKernelParams kp) {
-#if DSQ_P >= DSQ_WIDE_MIN
+#if DSQ_P >= DSQ_BETA_ARENA_MIN
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *arena = smem;
     int arena_off = 0;
@@ -1218,7 +1333,7 @@ DSQ_UNROLL_P
 
 // LDS of one single-wave block of the wide build: lam, gam, trial | LU, rhs | G, Gi, T, Sg (+ the final LU)
 __host__ __device__ static inline size_t optim_arena_doubles(int p) {
-    return p >= DSQ_WIDE_MIN ? (size_t)6 * p * p + 12 * p + 32 : 0;
+    return p >= DSQ_BETA_ARENA_MIN ? (size_t)6 * p * p + 12 * p + 32 : 0;
 }
 
 template <>
@@ -1235,12 +1350,14 @@ hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &kp, hipStream_t st) {
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
-static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(p);
+static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds, bool qrrows = false) {
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(p) +
+           (qrrows ? (size_t)waves * beta_qr_doubles(m, p) : 0);
 }
 
 template <int P>
-static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *xlds, int *grid, size_t *lds) {
+static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *xlds, int *grid, size_t *lds,
+                          bool want_qrrows = false, bool *qrrows = nullptr) {
     const Tuning &tu = tuning();
     // Pick (waves per block, X in LDS?) maximising resident waves per CU: 160 KiB of LDS per CU, and
     // the register budget of these kernels admits 2 waves per SIMD = 8 per CU.  Ties: bigger blocks
@@ -1249,6 +1366,23 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     const int wmax = tu.beta_waves >= 4 ? 4 : tu.beta_waves >= 2 ? 2 : tu.beta_waves == 1 ? 1 : 4;
     int best = -1, best_wpc = 0;
     *stage = false; *waves = wmax; *xlds = 0;
+    // stored-row QR: taken when its LDS leaves at least 4 waves on a CU (the replay kernel runs 4 at p >= 7)
+    bool qr = false;
+    if (want_qrrows && P >= DSQ_BETA_QRROWS_MIN && tu.beta_stage != 0) {
+        int qbest = -1, qw = 0, qx = 0;
+        for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
+            for (int w = wmax; w >= 1; w >>= 1) {
+                size_t need = beta_lds_doubles(m, P, w, xl, true) * sizeof(double);
+                if (need > budget) continue;
+                int wpc = w * (int)(cu_lds / need);
+                if (wpc > 8) wpc = 8;
+                int score = wpc * 100 + w * 2 + xl;
+                if (wpc >= 4 && score > qbest) { qbest = score; qw = w; qx = xl; }
+            }
+        if (qbest >= 0) { qr = true; *stage = true; *waves = qw; *xlds = qx; }
+    }
+    if (qrrows) *qrrows = qr;
+    if (!qr)
     for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
             size_t need = beta_lds_doubles(m, P, w, xl) * sizeof(double);
@@ -1260,25 +1394,28 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
         }
     // Long rows (m >~ 1000): the LDS slabs leave fewer than 6 waves per CU and staging loses to plain L2-resident
     // rows at full occupancy (measured, p = 4: m = 1250 10.6 vs 9.1 ms, m = 2000 18.5 vs 9.1 ms; m = 800 5.1 vs 5.6).
-    if (*stage && best_wpc < 6 && tu.beta_stage < 0) { *stage = false; *waves = wmax; }
+    if (!qr && *stage && best_wpc < 6 && tu.beta_stage < 0) { *stage = false; *waves = wmax; }
     if (tu.beta_stage == 0) *stage = false;
     if (!*stage) *xlds = 0;
     if (!*stage)
         while (*waves > 1 && (size_t)*waves * beta_arena_doubles(P) * sizeof(double) > budget) *waves >>= 1;
-    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds) * sizeof(double)
+    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds, qr) * sizeof(double)
                   : (size_t)*waves * beta_arena_doubles(P) * sizeof(double);     // unstaged: only the WIDE arena
-    static thread_local int bpc_cache[2][2][8];   // [stage][useW][waves]: the occupancy query costs ~1 ms, ask once
-    static thread_local size_t lds_cache[2][2][8];
+    static thread_local int bpc_cache[3][2][8];   // [stage + stored rows][useW][waves]: the occupancy query costs ~1 ms, ask once
+    static thread_local size_t lds_cache[3][2][8];
     DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
-    if (lds_cache[*stage][useW][*waves] != *lds) { bpc_cache[*stage][useW][*waves] = 0; lds_cache[*stage][useW][*waves] = *lds; }
-    int bpc = bpc_cache[*stage][useW][*waves];
-    const void *fn = *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true> : (const void *)fit_beta_kernel<P, false, true>)
-                            : (useW ? (const void *)fit_beta_kernel<P, true, false> : (const void *)fit_beta_kernel<P, false, false>);
+    const int ci = qr ? 2 : (*stage ? 1 : 0);
+    if (lds_cache[ci][useW][*waves] != *lds) { bpc_cache[ci][useW][*waves] = 0; lds_cache[ci][useW][*waves] = *lds; }
+    int bpc = bpc_cache[ci][useW][*waves];
+    const void *fn = qr ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRROWS_MIN)>
+                                : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRROWS_MIN)>)
+                  : *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true, false> : (const void *)fit_beta_kernel<P, false, true, false>)
+                           : (useW ? (const void *)fit_beta_kernel<P, true, false, false> : (const void *)fit_beta_kernel<P, false, false, false>);
     if (bpc == 0) {
         if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
-        bpc_cache[*stage][useW][*waves] = bpc;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d xlds=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, *xlds, *lds, bpc);
+        bpc_cache[ci][useW][*waves] = bpc;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d stored-rows=%d xlds=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, (int)qr, *xlds, *lds, bpc);
     }
     if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();
@@ -1308,20 +1445,28 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
     int waves, grid, xlds;
     bool stage;
     size_t lds;
-    beta_geometry<DSQ_P>(kp0.n, kp0.m, kp0.useWeights != 0, &waves, &stage, &xlds, &grid, &lds);
+    bool qr = false;
+    beta_geometry<DSQ_P>(kp0.n, kp0.m, kp0.useWeights != 0, &waves, &stage, &xlds, &grid, &lds,
+                         kp0.useQR != 0 && kp0.maxit > 0, &qr);
     BetaKernelParams kp = kp0;
     kp.xlds = xlds;
     if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();   // a row list: its length lives on the device
-    if (stage) {
+    constexpr bool kQr = (DSQ_P >= DSQ_BETA_QRROWS_MIN);
+    if (qr) {
         if (kp.useWeights)
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, kQr>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, kQr>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    } else if (stage) {
+        if (kp.useWeights)
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+        else
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
     } else {
         if (kp.useWeights)
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
     }
     return hipGetLastError();
 }

@@ -9,7 +9,9 @@ from deseq2_amd.engine import DeviceEngine
 E = DeviceEngine("cuda:0")
 SHAPES = [(20000, 500, 1, None), (20000, 500, 3, None), (20000, 200, 6, None),
           # a factor with p - 1 levels and ONE continuous covariate, 20 000 x 200
-          (20000, 200, 1, 9), (20000, 200, 1, 15), (20000, 240, 1, 23)]
+          (20000, 200, 1, 9), (20000, 200, 1, 15), (20000, 240, 1, 23),
+          # threshold sweep for the wide-style build of the general kernels (DSQ_BETA_WIDE_MIN)
+          (20000, 200, 1, 6), (20000, 200, 1, 7), (20000, 200, 1, 8), (20000, 500, 1, 8), (20000, 500, 1, 9), (20000, 100, 1, 9)]
 if os.environ.get("CONTBENCH_ONLY"):
     SHAPES = [SHAPES[int(k)] for k in os.environ["CONTBENCH_ONLY"].split(",")]
 for n, m, extra, levels in SHAPES:
