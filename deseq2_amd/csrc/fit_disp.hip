@@ -67,6 +67,7 @@ struct DispGene {
     bool mu_ok;
     DSQ_DEV double rcp1(double opm) const { return mu_ok ? drcp_n(opm) : 1.0 / opm; }
     double *arena;      // lane-column builds: K P P doubles of wave-private LDS (general-mode Cox-Reid rows)
+    double *wdbuf;      // general mode, entry-per-lane Gram: K m doubles of wave-private LDS (the samples' diagonals)
     // unweighted genes: the distinct count values (ascending) and their multiplicities, in wave-private LDS -- the
     // lgamma / digamma terms of the likelihood depend on a sample only through its count, so they are evaluated once
     // per DISTINCT count (often a handful) instead of once per sample
@@ -293,6 +294,61 @@ DSQ_UNROLL_P
             return;
         }
         if constexpr (P >= DSQ_DISP_ROWPASS_MIN) {
+            if (wdbuf) {
+                // ENTRY PER LANE: one sweep over the samples leaves the K diagonals of every sample in LDS (zero for a
+                // row below the weight threshold), then lane e owns entry e = (a, b), a <= b, of the upper triangle and adds
+                // its m terms x_ja (x_jb wd_j) SERIALLY in sample order -- no cross-lane reduction at all (the one-row-per-
+                // sweep form below needs K p (p + 1) / 2 butterflies and p sweeps).  The order of these sums is part of
+                // the arithmetic spec: the CPU checker (oracle/deseq2_oracle.c: cr_gram) takes them serially under the same
+                // condition (disp_serial_gram).
+                for (int j = lane; j < m; j += 64) {
+                    double wd[K];
+                    f(j, r.y(j), r.mu(j), wd, true);
+                    const bool keep = keep_row(j);
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) wdbuf[(size_t)k * m + j] = keep ? wd[k] : 0.0;
+                }
+                wave_lds_sync();
+                constexpr int NE = SymN<P>::value;
+                for (int e0 = 0; e0 < NE; e0 += 64) {
+                    const int e = e0 + lane;
+                    int a = 0, rem = e < NE ? e : 0;
+                    while (rem >= P - a) { rem -= P - a; a++; }
+                    const int b = a + rem;
+                    const bool live = e < NE && !(((dropmask >> a) | (dropmask >> b)) & 1u);
+                    double acc[K];
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) acc[k] = 0.0;
+                    if (live) {
+                        for (int j = 0; j < m; j++) {
+                            const double xa = r.x(j, a), xb = r.x(j, b);
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) acc[k] += xa * (xb * wdbuf[(size_t)k * m + j]);
+                        }
+                    }
+                    if (e < NE) {
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) {
+                            arena[(k * P + a) * P + b] = acc[k];
+                            arena[(k * P + b) * P + a] = acc[k];
+                        }
+                    }
+                }
+                wave_lds_sync();
+                const int bl = lane < P ? lane : 0;
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++)
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++) B[k][i] = arena[(k * P + i) * P + bl];
+                wave_lds_sync();
+                if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
+                    _Pragma("unroll")
+                    for (int i = 0; i < P; i++)
+                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                }
+                return;
+            }
+            // (long rows: one matrix row per sweep, wave-order sums)
             // K * P(P+1)/2 per-lane running sums do not fit in registers.  One matrix row per pass over the samples
             // instead (a rolled loop over the rows; the diagonals are recomputed per pass, a division per sample, the
             // caller's likelihood terms added in the first pass only).  Same terms, same order per entry, same wave
@@ -759,11 +815,26 @@ __host__ __device__ inline size_t disp_arena_doubles(int p, int ncell) {
     return (p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0) ? (size_t)3 * p * p : 0;
 }
 
+// general mode (no design cells) from DSQ_DISP_ROWPASS_MIN columns up, rows of at most DSQ_DISP_SERIAL_MAXM samples:
+// the Cox-Reid Gram sums are taken ONE MATRIX ENTRY PER LANE, serially over the samples (see DispGene::pass); the
+// per-sample diagonals go through 3 m doubles of the wave's LDS
+// (measured, 20 000 genes: p = 10, m = 200: 6.1 -> 3.6 ms; p = 16: 35.9 -> 20.2; p = 24: 90.8 -> 47.3; p = 10, m = 500:
+// 17.6 -> 15.7; but p = 7, m = 500: 5.6 -> 12.9 -- m serial steps on 28 of 64 lanes and 12 KB more LDS per wave lose to
+// seven sweeps: narrow designs take it for short rows only)
+#ifndef DSQ_DISP_SERIAL_MAXM
+#define DSQ_DISP_SERIAL_MAXM 1024
+#endif
+#ifndef DSQ_DISP_SERIAL_MAXM_NARROW
+#define DSQ_DISP_SERIAL_MAXM_NARROW 256
+#endif
+__host__ __device__ inline bool disp_serial_gram(int p, int ncell, int m) {
+    return p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0 && m <= (p >= 10 ? DSQ_DISP_SERIAL_MAXM : DSQ_DISP_SERIAL_MAXM_NARROW);
+}
 template <bool USE_W>
-__host__ __device__ inline size_t disp_slab_doubles(int m, bool stage) {
+__host__ __device__ inline size_t disp_slab_doubles(int m, bool stage, bool serial) {
     const size_t half = ((size_t)m + 1) / 2;                 // m int32
     const size_t dist = USE_W ? 0 : (size_t)m;               // 2 m int32
-    return stage ? (size_t)m * (USE_W ? 2 : 1) + half + dist : dist;
+    return (stage ? (size_t)m * (USE_W ? 2 : 1) + half + dist : dist) + (serial ? (size_t)3 * m : 0);
 }
 
 // block-shared design-cell lists (int32: cell_start[DSQ_CMAX + 2] | m entries sample | cell << 26 in cell-sorted order)
@@ -790,7 +861,8 @@ __host__ __device__ inline bool disp_sorted(bool stage, int ncell) { return stag
 
 template <bool USE_W>
 __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int xlds, int ncell) {
-    return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true) + (size_t)waves * disp_arena_doubles(p, ncell);
+    return (xlds ? (size_t)p * m : 0) + (size_t)waves * disp_slab_doubles<USE_W>(m, true, disp_serial_gram(p, ncell, m)) +
+           (size_t)waves * disp_arena_doubles(p, ncell);
 }
 
 // 1: the line search evaluates the likelihood alone at a proposal and the derivative only after the Armijo test accepts
@@ -822,7 +894,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     if (blockIdx.x * waves >= nwork) return;     // (row-listed launches size the grid without knowing the count)
 
     const double *xs = smem;
-    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE);
+    const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
+    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
@@ -923,6 +996,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         G.ablate = kp.ablate;
         G.padmask = kp.padmask;
         G.arena = arena;
+        G.wdbuf = serial_gram ? slab + slab_d - (size_t)3 * m : nullptr;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
         G.sorted = sorted; G.cid = cid_s; G.crep = crep_s; G.xxs = xx_s; G.xcs = xc_s;
         G.build_distinct(dist);
@@ -1053,7 +1127,8 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
     if (tu.disp_stage == 0) stage = false;
-    const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false) + disp_arena_doubles(P, kp.ncell)) * sizeof(double);
+    const size_t unstaged_wave = (disp_slab_doubles<USE_W>(kp.m, false, disp_serial_gram(P, kp.ncell, kp.m)) +
+                                  disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
     if (!stage)

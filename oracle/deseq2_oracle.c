@@ -40,7 +40,9 @@
  *     reference's own summation order is unspecified (Rcpp sugar / BLAS dgemm /
  *     LAPACK, all implementation-dependent), so fixing one is within its contract.
  *     sum_mode = 1 switches to plain serial sums, used only to measure how many
- *     iteration counts move between two equally valid orders;
+ *     iteration counts move between two equally valid orders.  ONE exception (round 3): the Cox-Reid Gram sums of
+ *     fitDisp in general mode (no design cells) with p >= 7 and m <= 256 (p >= 10: m <= 1024) are serial sums in
+ *     sample order (cr_gram);
  *   - p x p work: LU with partial pivoting (first maximum wins), reciprocal
  *     pivots, as LAPACK dgetf2; QR by unblocked Householder reflections as LAPACK
  *     dgeqr2/dlarfg (what qr_econ reaches for p < 32).
@@ -267,11 +269,16 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
             }
         return;
     }
+    /* general mode from 7 design columns up, rows of at most 256 samples (1024 from 10 columns up): the engine takes
+     * these sums one matrix entry per lane, SERIALLY over the samples (csrc/fit_disp.hip: disp_serial_gram,
+     * DispGene::pass) -- the order is part of the arithmetic spec, so the checker takes them serially under the same
+     * condition */
+    const int serial_gram = g->serial || (g->p >= 7 && m <= (g->p >= 10 ? 1024 : 256));
     for (int a = 0; a < q; a++)
         for (int b = a; b < q; b++) {
             const double *xa = g->x + (long)m * g->keepcol[a];
             const double *xb = g->x + (long)m * g->keepcol[b];
-            wsum_t s; wsum_init(&s, g->serial);
+            wsum_t s; wsum_init(&s, serial_gram);
             for (int j = 0; j < m; j++) {
                 if (g->keeprow && !g->keeprow[j]) continue;
                 wsum_add(&s, j, xa[j] * (xb[j] * wd[j]));

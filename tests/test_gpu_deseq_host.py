@@ -199,6 +199,29 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     _against_oracle(b.mcols, o, name, test)
 
 
+def test_a_gene_range_of_all_zero_rows_is_legal():
+    """R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero joins the exchange with
+    nothing to contribute (the per-shard N_NONZERO check must be global)"""
+    counts, x, sf, kw = CASES["bc_outliers"]
+    counts = counts.copy()
+    n = counts.shape[0]
+    counts[n // 3: 2 * (n // 3) + 5] = 0                       # the whole middle range (and a bit of the last)
+    one = _host_entry(counts, x, sf, kw, assays=())
+    old = os.environ.get("DSQ_HOST_SHARDS")
+    try:
+        os.environ["DSQ_HOST_SHARDS"] = "3"
+        three = _host_entry(counts, x, sf, kw, assays=())
+    finally:
+        if old is None:
+            os.environ.pop("DSQ_HOST_SHARDS", None)
+        else:
+            os.environ["DSQ_HOST_SHARDS"] = old
+    for k in ("baseMean", "dispGeneEst", "dispFit", "dispersion", "beta", "betaSE", "stat", "pvalue", "maxCooks", "allZero",
+              "betaConv", "replace", "logLike"):
+        assert_same(_f(three[k]), _f(one[k]), "all-zero range: " + k)
+    assert three["status"]["N_NONZERO"] == one["status"]["N_NONZERO"] < n - n // 3
+
+
 def test_host_entry_argument_errors():
     counts, x, sf, kw = CASES["two_group_optim_rows"]
     from deseq2_amd import _lib as L
