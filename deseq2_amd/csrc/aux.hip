@@ -462,6 +462,23 @@ __global__ void xim_final_kernel(const double *colmean_recip, int m, double *out
     for (int j = 0; j < m; j++) s += colmean_recip[j];
     *out = s / (double)m;
 }
+// the same over the genes rows[0 .. *n_dev) (ascending): estimateDispersionsGeneEst works on the rows that are not all
+// zero (objectNZ, R/core.R:693-700), so the column means are taken over those
+__global__ void __launch_bounds__(256) xim_rows_kernel(const double *nf, const int32_t *rows, const int32_t *n_dev, int m, long ld,
+                                                       double *colmean_recip) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int cnt = *n_dev;
+    double s = 0.0;
+    for (int i = 0; i < cnt; i++) s += nf[(size_t)rows[i] * ld + j];
+    colmean_recip[j] = 1.0 / (s / (double)cnt);
+}
+hipError_t launch_xim_rows(const double *nf, const int32_t *rows, const int32_t *n_dev, int m, long ld, double *scratch_m,
+                           double *out, hipStream_t st) {
+    hipLaunchKernelGGL(xim_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, nf, rows, n_dev, m, ld, scratch_m);
+    hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);
+    return hipGetLastError();
+}
 hipError_t launch_xim(const double *nf, int n, int m, long ld, double *scratch_m, double *out, hipStream_t st) {
     hipLaunchKernelGGL(xim_kernel, dim3((m + 255) / 256), dim3(256), 0, st, nf, n, m, ld, scratch_m);
     hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);

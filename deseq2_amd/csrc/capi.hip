@@ -1181,9 +1181,10 @@ static void host_plan(size_t n, int *nshards, int *ndev) {
 // run f(lo, cnt, stream, range index, number of ranges) over the ranges of R/parallel.R:10; one range: on the caller's
 // thread, device and null stream
 template <class F>
-static int host_sharded_ix(size_t row_lo, size_t n, F &&f0) {
+static int host_sharded_ix(size_t row_lo, size_t n, F &&f0, int max_shards = 0) {
     int S, ndev;
     host_plan(n, &S, &ndev);
+    if (max_shards > 0 && S > max_shards) S = max_shards;
     auto f = [&](size_t lo, size_t cnt, hipStream_t st, int k) { return f0(row_lo + lo, cnt, st, k, S < 1 ? 1 : S); };
     if (S <= 1) return f((size_t)0, n, (hipStream_t) nullptr, 0);
     std::vector<HostWorker *> ws(S);
@@ -1215,8 +1216,8 @@ static int host_sharded(size_t row_lo, size_t n, F &&f0) {
     return host_sharded_ix(row_lo, n, [&](size_t lo, size_t cnt, hipStream_t st, int, int) { return f0(lo, cnt, st); });
 }
 // (deseq_host.hip) the caller holds the library's call lock
-int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f) {
-    return host_sharded_ix((size_t)0, n, f);
+int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f, int max_shards) {
+    return host_sharded_ix((size_t)0, n, f, max_shards);
 }
 int capi_host_shards(size_t n) {
     int S, ndev;

@@ -29,7 +29,7 @@
 namespace dsq {
 
 int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st);      // pipeline.hip
-int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f);   // capi.hip
+int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f, int max_shards);   // capi.hip
 int capi_host_shards(size_t n);
 
 #define HD_HIP(expr)                                                                                     \
@@ -127,26 +127,7 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
     const double ln2 = 0.6931471805599453;
     f->lam.assign(p, 1e-6 / (ln2 * ln2));                                    // R/fitNbinomGLMs.R:73,162
     if (a->normalizationFactors) {
-        // mean over the samples of 1 / colMeans(normalizationFactors) (R/core.R:2440-2444): every column summed down the
-        // genes in gene order (what launch_xim does on a resident matrix), the columns split over a few host threads
-        const size_t n = a->n;
-        std::vector<double> rec(m);
-        unsigned T = std::thread::hardware_concurrency();
-        T = T < 1 ? 1 : (T > 8 ? 8 : T);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; t++)
-            th.emplace_back([&, t] {
-                for (int j = (int)t; j < m; j += (int)T) {
-                    const double *col = a->normalizationFactors + (size_t)j * n;
-                    double sum = 0.0;
-                    for (size_t i = 0; i < n; i++) sum += col[i];
-                    rec[j] = 1.0 / (sum / (double)n);
-                }
-            });
-        for (auto &x : th) x.join();
-        double s = 0.0;
-        for (int j = 0; j < m; j++) s += rec[j];
-        f->xim = s / (double)m;
+        f->xim = 0.0;       // (the chain takes mean(1 / colMeans(nf)) over the rows that are not all zero itself)
     } else {
         double s = 0.0;                                                      // mean(1 / sizeFactors), in sample order
         for (int j = 0; j < m; j++) s += 1.0 / a->sizeFactors[j];
@@ -428,7 +409,9 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     if (a->normalizationFactors && F.do_replace)
         return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: a normalization-factor matrix together with the outlier refit (R/core.R:2440-2444 re-averages the factors over the refitted rows): pass minReplicatesForReplace = Inf");
     Exchange X;
-    const int S = capi_host_shards((size_t)a->n);
+    // a normalization-factor matrix: momentsDispEstimate averages it over ALL non-zero rows of the object, a sum that
+    // gene ranges could only reproduce in another order -- one range
+    const int S = a->normalizationFactors ? 1 : capi_host_shards((size_t)a->n);
     X.target = S;
     if (S > 1) { X.bm.resize(a->n); X.dge.resize(a->n); }
     X.status.assign((size_t)S * DSQ_ST_COUNT, 0);
@@ -437,7 +420,7 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
         const int r = deseq_range(a, o, F, X, lo, cnt, st, shard, nshards);
         if (r) X.fail();             // (ranges waiting at the exchange give up instead of waiting for this one)
         return r;
-    });
+    }, S);
     if (rc) return rc;
     // counters: per-range counts add up; the trend's (fitted by every range over the same gathered vectors) are range 0's
     memset(o->status, 0, sizeof o->status);

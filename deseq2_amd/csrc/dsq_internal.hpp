@@ -198,6 +198,8 @@ hipError_t launch_weights_prep(const double *w_raw, const double *x, int n, int 
                                double *w_floor, int32_t *force_zero, int32_t *neg, hipStream_t st);
 // xim of a normalization-factor matrix -> *out (device); scratch_m: m doubles
 hipError_t launch_xim(const double *nf, int n, int m, long ld, double *scratch_m, double *out, hipStream_t st);
+hipError_t launch_xim_rows(const double *nf, const int32_t *rows, const int32_t *n_dev, int m, long ld, double *scratch_m,
+                           double *out, hipStream_t st);
 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).

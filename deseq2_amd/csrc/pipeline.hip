@@ -222,6 +222,7 @@ struct RuleParams {
     int n;                       // capacity / leading dimension of the n x p matrices
     int p;
     double minDisp, maxDisp, xim, outlierSD;
+    const double *xim_dev;       // normalization-factor matrix: xim over the non-zero rows, computed by the chain
     int maxit, betaMaxit;
     const double *baseMean, *baseVar, *roughDisp;
     double *alpha_init, *la0;
@@ -253,7 +254,8 @@ __global__ void alpha_init_kernel(RuleParams q) {
     if (i >= rows_count(q.rw)) return;
     const int g = rows_gene(q.rw, i);
     const double bm = q.baseMean[g], bv = q.baseVar[g];
-    const double mom = (bv - q.xim * bm) / (bm * bm);
+    const double xim = q.xim_dev ? *q.xim_dev : q.xim;
+    const double mom = (bv - xim * bm) / (bm * bm);
     double a = np_min(q.roughDisp[g], mom);
     a = np_min(np_max(q.minDisp, a), q.maxDisp);
     q.alpha_init[g] = a;
@@ -481,6 +483,8 @@ struct Pipe {
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
     double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
+    double *xim_dev;               // normalization-factor matrix: mean(1 / colMeans(nf)) over the non-zero rows (one double
+                                   // behind the lambda block of the caller's workspace: it persists between the phases)
     // nbinomLRT against a reduced model that is not ~1 / the beta-prior refit (never both: the prior is Wald only)
     double *red_binit, *red_beta, *red_se, *red_mu;
     const int32_t *red_cell_perm, *red_cell_start;
@@ -518,6 +522,7 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     const DsqDeseqOut *o = P.o;
     q.rw = rw; q.n = P.n; q.p = P.p;
     q.minDisp = a->minDisp; q.maxDisp = P.maxDisp; q.xim = a->xim; q.outlierSD = a->outlierSD;
+    q.xim_dev = a->nf_is_vector ? nullptr : P.xim_dev;
     q.maxit = a->maxit; q.betaMaxit = a->betaMaxit;
     q.baseMean = o->baseMean; q.baseVar = o->baseVar; q.roughDisp = P.roughDisp;
     q.alpha_init = P.alpha_init; q.la0 = P.la0;
@@ -1025,7 +1030,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     P.last_lp = D + cv.o_llp; P.last_dlp = D + cv.o_ldlp; P.la_grid = D + cv.o_lagrid; P.log_dfit = D + cv.o_ldfit;
     P.la_init = D + cv.o_lainit; P.beta_nat = D + cv.o_bnat; P.beta_var = D + cv.o_bvar; P.beta_iter = D + cv.o_biter;
     P.cnum = D + cv.o_cnum; P.cden = D + cv.o_cden; P.dev = D + cv.o_dev;
-    P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax;
+    P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax; P.xim_dev = P.lam + 3 * (size_t)pmax;
     P.resbuf = D + cv.o_res; P.trend_mean_c = D + cv.o_tm; P.trend_disp_c = D + cv.o_td; P.robustDisp = D + cv.o_robust;
     P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
     P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = o->status;
@@ -1098,6 +1103,14 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
         hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, 0, n, o->allZero, a->force_zero,
                            (const double *)nullptr, (const double *)nullptr, 0.0, P.rows_nz, (double *)nullptr,
                            (double *)nullptr, P.counters + CNT_NZ);
+        if (!a->nf_is_vector) {
+            // momentsDispEstimate's mean(1 / colMeans(normalizationFactors)) over the rows that are not all zero
+            // (R/core.R:2440-2444 on objectNZ): columns summed down the listed genes in gene order
+            void *b;
+            rc = capi_ws_get(DSQ_WS_PIPE_META + 5, ((size_t)m + 8) * sizeof(double), &b);
+            if (rc) return rc;
+            PIPE_HIP(launch_xim_rows(a->nf, P.rows_nz, P.counters + CNT_NZ, m, P.ld, (double *)b, P.xim_dev, st));
+        }
         rc = gene_est(P, nz, a->y, o->mu_hat, CNT_GRID1, CNT_OPT1, o->optim_geneest);
         if (rc) return rc;
     }

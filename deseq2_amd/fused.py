@@ -175,7 +175,8 @@ class _Run:
         if self.grid is None:
             self.grid = E._cache[("grid", m)] = E._vec(np.linspace(np.log(1e-8), np.log(max(10, m)), 20))
         self.lam = np.ascontiguousarray(np.full(p, 1e-6) / np.log(2) ** 2)          # R/fitNbinomGLMs.R:73,162
-        xim = core.xim_size_factors(dds.sizeFactors) if dds.sizeFactors is not None else E.xim(dds.nf)
+        # (a normalization-factor matrix: the chain takes mean(1 / colMeans(nf)) over its non-zero rows itself)
+        xim = core.xim_size_factors(dds.sizeFactors) if dds.sizeFactors is not None else 0.0
         facts = _design_facts(E, x, minReplicatesForReplace)
         cells = facts["cells"]
         self.cells = cells

@@ -453,7 +453,9 @@ typedef struct {
     const int32_t *force_zero;     /* n flags or NULL: rows treated as all-zero (weightsFail, R/core.R:2737)     */
     const double *x;               /* m x p design, column-major                                                 */
     const double *q, *a, *r;       /* thin QR of the design: Q, X R^-1 (m x p), R (p x p), column-major          */
-    double xim;                    /* momentsDispEstimate's mean(1 / sizeFactors) (R/core.R:2440-2444)           */
+    double xim;                    /* momentsDispEstimate's mean(1 / sizeFactors) (R/core.R:2440-2444); with a
+                                      normalization-factor MATRIX (nf_is_vector = 0) it is not read: the chain takes
+                                      mean(1 / colMeans(nf)) over the rows that are not all zero itself              */
     int32_t linearMu;              /* R/core.R:735-742                                                           */
     double minDisp, kappa_0, dispTol, weightThreshold, outlierSD, betaTol, minmu;
     int32_t maxit, useCR, useQR, betaMaxit;

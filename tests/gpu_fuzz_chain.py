@@ -1,7 +1,10 @@
 """GPU fuzz of the whole chain (run by hand on a GPU box): the fused device-driven DESeq() against the call-by-call
 chain of core.py on the same engine, random small analyses -- designs (factor, factor + factor, two-group; with a
-continuous covariate the general kernels), samples per cell, size factors, weights, spiked outliers, all-zero rows,
-Wald / LRT -- every per-gene column, the assays and the trend bit for bit (tests/test_gpu_fused.py's comparison).
+continuous covariate the general kernels), samples per cell, size factors or a normalization-factor matrix, weights,
+spiked outliers, all-zero rows, Wald (useT, betaPrior) / LRT against ~1 or a nested reduced model -- every per-gene
+column, the assays and the trend bit for bit (tests/test_gpu_fused.py's comparison); where the one-call host entry
+covers the analysis (dsq_deseq: no betaPrior, no useT) it is run too, over a random number of in-library gene ranges,
+and compared with the fused chain column by column.
 
     python tests/gpu_fuzz_chain.py [first_seed] [n_seeds]
 """
@@ -12,9 +15,43 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401,E402
-from deseq2_amd import core, fused, simulate  # noqa: E402
+from deseq2_amd import core, fused, native, simulate  # noqa: E402
 from deseq2_amd.engine import DeviceEngine  # noqa: E402
+from tests.helpers import assert_same  # noqa: E402
 from tests.test_gpu_fused import _compare, _spike_outliers  # noqa: E402
+
+
+def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
+    """dsq_deseq on the same analysis: every column it returns against the fused chain's"""
+    shards = int(rng.integers(1, 5))
+    old = os.environ.get("DSQ_HOST_SHARDS")
+    try:
+        os.environ["DSQ_HOST_SHARDS"] = str(shards)
+        res = native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"),
+                           normalizationFactors=nfm, weights=weights, minmu=kw.get("minmu", 0.5),
+                           minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=("mu", "cooks"))
+    finally:
+        if old is None:
+            os.environ.pop("DSQ_HOST_SHARDS", None)
+        else:
+            os.environ["DSQ_HOST_SHARDS"] = old
+    f = lambda v: np.asarray(v, dtype=np.float64)      # noqa: E731
+    pairs = {"baseMean": "baseMean", "dispGeneEst": "dispGeneEst", "dispFit": "dispFit", "dispMAP": "dispMAP",
+             "dispersion": "dispersion", "dispIter": "dispIter", "beta": "beta", "betaSE": "betaSE", "betaIter": "betaIter",
+             "maxCooks": "maxCooks", "allZero": "allZero"}
+    for k, kb in pairs.items():
+        assert_same(f(res[k]), f(b.mcols[kb]), "%s host entry (%d ranges): %s" % (tag, shards, k))
+    assert_same(-2 * f(res["logLike"]), f(b.mcols["deviance"]), tag + " host entry: deviance")
+    if kw.get("test") == "LRT":
+        assert_same(2 * (f(res["logLike"]) - f(res["logLikeReduced"])), f(b.mcols["LRTStatistic"]), tag + " host entry: LRT")
+    else:
+        assert_same(f(res["stat"]), f(b.mcols["WaldStatistic"]), tag + " host entry: Wald statistic")
+        assert_same(f(res["pvalue"]), f(b.mcols["WaldPvalue"]), tag + " host entry: Wald p-value")
+    nz = ~np.asarray(b.mcols["allZero"], bool) | (np.nan_to_num(f(b.mcols.get("replace", np.zeros(b.n)))) == 1)
+    E = b.engine
+    for k in ("mu", "cooks"):
+        if k in b.assays:
+            assert_same(res[k][nz], E.to_numpy(b.assays[k])[nz], tag + " host entry: assays$" + k)
 
 
 def one(E, seed):
@@ -47,10 +84,28 @@ def one(E, seed):
         weights = rng.uniform(0.05, 1.0, counts.shape)
         weights[rng.uniform(size=counts.shape) < 0.02] = 0.0
     kw = {}
-    if rng.uniform() < 0.3:
-        kw.update(test="LRT", reduced=np.ones((m, 1)))
-    tag = "seed %d: kind=%d n=%d m=%d p=%d weights=%d %s" % (seed, kind, counts.shape[0], m, x.shape[1], weights is not None, kw.get("test", "Wald"))
-    a = core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], weights=weights, engine=E)
+    p = x.shape[1]
+    u = rng.uniform()
+    if u < 0.3:
+        q = 1 if (p == 1 or rng.uniform() < 0.5) else int(rng.integers(1, p))
+        kw.update(test="LRT", reduced=np.ones((m, 1)) if q == 1 else np.ascontiguousarray(x[:, :q]))
+        if q > 1 and rng.uniform() < 0.5:
+            kw["minmu"] = 1e-6                                   # R/core.R:1856-1868 (glmGamPoi-style floor)
+    elif u < 0.45:
+        kw.update(useT=True)
+    elif u < 0.6 and kind in (0, 2):
+        # betaPrior on the expanded model matrix of a one-factor design (R/core.R:1374-1380)
+        lev = (x[:, 1:] @ np.arange(1, p)).astype(int) if p > 1 else np.zeros(m, int)
+        kw.update(betaPrior=True, factors={"condition": lev})
+    nfm = None
+    if rng.uniform() < 0.15 and not kw.get("betaPrior"):
+        nfm = np.exp(rng.normal(0, 0.2, counts.shape)) * d["size_factors"][None, :]
+        kw["minReplicatesForReplace"] = np.inf                  # (a factor matrix + the outlier refit is left to core)
+    sfv = None if nfm is not None else d["size_factors"]
+    tag = "seed %d: kind=%d n=%d m=%d p=%d weights=%d nf=%d %s%s%s" % (
+        seed, kind, counts.shape[0], m, p, weights is not None, nfm is not None, kw.get("test", "Wald"),
+        " reduced=%d" % kw["reduced"].shape[1] if "reduced" in kw else "", " useT" if kw.get("useT") else " betaPrior" if kw.get("betaPrior") else "")
+    a = core.DESeqDataSet(counts, x, sizeFactors=sfv, normalizationFactors=nfm, weights=weights, engine=E)
     try:
         core.DESeq(a, **kw)
     except NotImplementedError as e:       # e.g. residual df <= 3: the prior-variance branch that needs R's RNG
@@ -59,11 +114,14 @@ def one(E, seed):
         if "contain NA" in str(e):         # counts carry weight 0: R stops there as well
             return tag + " SKIP NA guard"
         raise
-    b = core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], weights=weights, engine=E)
+    b = core.DESeqDataSet(counts, x, sizeFactors=sfv, normalizationFactors=nfm, weights=weights, engine=E)
     fused.DESeq(b, **kw)
     if not b.attrs.get("fused"):           # (a failed parametric trend hands the analysis to core.DESeq)
         return tag + " SKIP not fused"
     _compare(a, b, tag)
+    if not kw.get("betaPrior") and not kw.get("useT"):
+        _host_entry_check(b, counts, x, sfv, nfm, weights, kw, rng, tag)
+        tag += " +host"
     return tag
 
 
