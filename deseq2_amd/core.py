@@ -821,11 +821,24 @@ def nbinomWaldTest(dds, betaTol=1e-8, maxit=100, useOptim=True, useT=False, df=N
     return dds
 
 
+def pchisq_upper(stat, df):
+    """pchisq(stat, df, lower.tail = FALSE) (R/core.R:1878) -- the value scipy.stats.chi2.sf returns (its _sf IS
+    scipy.special.chdtrc) without the distribution machinery around it (argument broadcasting / masking: a quarter of
+    its 4 ms per 60 000 genes, which shows in a C4 step on the device chain)"""
+    stat = np.asarray(stat, np.float64)
+    if not (np.ndim(df) == 0 and df > 0):
+        from scipy.stats import chi2
+        return chi2.sf(stat, df=df)
+    from scipy.special import chdtrc
+    out = chdtrc(float(df), stat)
+    out[np.isnan(stat)] = np.nan
+    return out
+
+
 def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, minmu=0.5):
     """R/core.R:1787-2012: full vs reduced model matrices (betaPrior = FALSE).  `reduced` is a
     model matrix whose column space is nested in dds.x; an intercept-only reduced model takes
     the closed form of R/fitNbinomGLMs.R:99-137."""
-    from scipy.stats import chi2
     E = dds.engine
     reduced = np.asarray(reduced, np.float64)
     weights, useWeights = getAndCheckWeights(dds)
@@ -838,7 +851,7 @@ def nbinomLRT(dds, reduced, betaTol=1e-8, maxit=100, useOptim=True, useQR=True, 
                         want_loglike=True)                        # closed form when reduced is ~1 (:99-137)
     ll_red = red["logLike"]
     LRTStatistic = 2 * (ll_full - ll_red)                                            # :1877
-    LRTPvalue = chi2.sf(LRTStatistic, df=full["nterms"] - red["nterms"])             # :1878
+    LRTPvalue = pchisq_upper(LRTStatistic, full["nterms"] - red["nterms"])            # :1878
     dds.assays["mu"] = full["mu"]
     dds.assays["H"] = full["hat_diagonals"]
     dds.attrs.update(betaPrior=False, test="LRT", reduced=reduced)

@@ -142,6 +142,22 @@ def test_lrt_against_a_reduced_model_matrix(E):
     _compare(a, b, "LRT vs 3-column reduced")
 
 
+def test_lrt_pvalues_computed_during_the_outlier_phase(E):
+    """from 4096 genes up the LRT p-values (host pchisq, R/core.R:1878) are computed from an early side-stream copy of
+    the log likelihoods while the device runs the outlier phase; the rows that phase refits are recomputed: same
+    columns as the call-by-call chain, refitted rows included"""
+    x = simulate.design_factor(32, 4)                       # cells of 8: replacement + refit
+    d = simulate.make_counts(5000, x, seed=77)
+    counts = _spike_outliers(d["counts"], np.random.default_rng(3), k=12)
+    counts[::97] = 0
+    for red in (np.ones((32, 1)), np.column_stack([np.ones(32), (np.arange(32) % 4 == 1).astype(float)])):
+        a, b = _both(E, counts, x, d["size_factors"], test="LRT", reduced=red)
+        _compare(a, b, "LRT, early p-values, reduced p=%d" % red.shape[1])
+        assert b.attrs["status"]["N_REFIT"] >= 3
+        refit = np.nan_to_num(np.asarray(b.mcols["replace"], float)) == 1
+        assert refit.sum() >= 3 and np.isfinite(np.asarray(b.mcols["LRTPvalue"])[refit]).all()
+
+
 def test_wald_t_distribution_pvalues(E):
     """useT = TRUE (R/core.R:1474-1503): p-values from the t distribution with m - p (or sum(weights) - p) degrees of
     freedom -- same statistic, the p-value column evaluated on the host from it"""
