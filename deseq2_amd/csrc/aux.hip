@@ -13,6 +13,8 @@
 
 namespace dsq {
 
+static constexpr int kAuxBatch = 4;          // trips whose loads are issued together (dsq_wave.hpp: sweep_batched)
+
 static inline int aux_grid_fwd(int n) {
     int blocks = (n + 3) / 4;
     int cap = device_cu_count() * 8;
@@ -36,29 +38,36 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        // (every pass re-reads the row through L1 / L2: the loads of kAuxBatch trips are issued together, sweep_batched)
+        int32_t yb[kAuxBatch];
+        double nb[kAuxBatch], wb[kAuxBatch];
+        auto load_row = [&](int j, int b) {
+            yb[b] = yg[j]; nb[b] = nfg[j];
+            if constexpr (USE_W) wb[b] = wg[j];
+        };
         double a2[2] = {0.0, 0.0};
-        for (int j = lane; j < m; j += 64) {
-            double yy = (double)yg[j];
-            double cn = yy / nfg[j];
-            if constexpr (USE_W) cn = wg[j] * cn;
+        sweep_batched<kAuxBatch>(m, lane, load_row, [&](int, int b) {
+            double yy = (double)yb[b];
+            double cn = yy / nb[b];
+            if constexpr (USE_W) cn = wb[b] * cn;
             a2[0] += cn;
             a2[1] += yy;
-        }
+        });
         wave_allreduce_n(a2);
         const double mean = a2[0] / (double)m;
         double av = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double cn = (double)yg[j] / nfg[j];
-            if constexpr (USE_W) cn = wg[j] * cn;
+        sweep_batched<kAuxBatch>(m, lane, load_row, [&](int, int b) {
+            double cn = (double)yb[b] / nb[b];
+            if constexpr (USE_W) cn = wb[b] * cn;
             double dlt = cn - mean;
             av += dlt * dlt;
-        }
+        });
         av = wave_allreduce(av);
         double tu[2 * P];
 #pragma unroll
         for (int c = 0; c < 2 * P; c++) tu[c] = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double yn = (double)yg[j] / nfg[j];
+        sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
+            double yn = (double)yb[b] / nb[b];
             double ly = dlog(yn + 0.1);
 #pragma unroll
             for (int c = 0; c < P; c++) {
@@ -66,18 +75,18 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
                 tu[c] += yn * qv;
                 tu[P + c] += ly * qv;
             }
-        }
+        });
         wave_allreduce_n(tu);
         double ae = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double yn = (double)yg[j] / nfg[j];
+        sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
+            double yn = (double)yb[b] / nb[b];
             double mu = tu[0] * kp.a[j];
 #pragma unroll
             for (int c = 1; c < P; c++) mu = __builtin_fma(tu[c], kp.a[(size_t)c * m + j], mu);
             mu = __builtin_fmax(1.0, mu);
             double d = yn - mu;
             ae += (d * d - mu) / (mu * mu);
-        }
+        });
         ae = wave_allreduce(ae);
         double b[P];
 #pragma unroll
@@ -113,10 +122,14 @@ __global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, d
         double tu[P];
 #pragma unroll
         for (int c = 0; c < P; c++) tu[c] = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double yn = (double)yg[j] / nfg[j];
+        {
+            int32_t yb[kAuxBatch];
+            double nb[kAuxBatch];
+            sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
+                double yn = (double)yb[b] / nb[b];
 #pragma unroll
-            for (int c = 0; c < P; c++) tu[c] += yn * kp.q[(size_t)c * m + j];
+                for (int c = 0; c < P; c++) tu[c] += yn * kp.q[(size_t)c * m + j];
+            });
         }
         wave_allreduce_n(tu);
         double *mg = mu_out + (size_t)g * kp.ld;

@@ -480,4 +480,25 @@ DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
     return nv;
 }
 
+// Lane-strided sweep over the samples j = lane, lane + 64, ... < m of a row that is read through L1 / L2: `load(j, b)`
+// issues the loads of sample j into register slot b, `use(j, b)` consumes them -- in ascending j per lane, so every
+// per-lane running sum sees its terms in the usual order -- with the loads of NB trips in flight together.  A wave that
+// issues one trip's loads and waits pays the L2 / MALL latency once per trip; the streaming kernels around the fits
+// (moments, Cook's distances, replacement, the intercept fit) ran at 30-40 % issue at m = 2000 for that reason.
+template <int NB, class LoadF, class UseF>
+DSQ_DEV void sweep_batched(int m, int lane, LoadF &&load, UseF &&use) {
+    for (int j0 = lane; j0 < m; j0 += 64 * NB) {
+        _Pragma("unroll")
+        for (int b = 0; b < NB; b++) {
+            const int j = j0 + 64 * b;
+            if (j < m) load(j, b);
+        }
+        _Pragma("unroll")
+        for (int b = 0; b < NB; b++) {
+            const int j = j0 + 64 * b;
+            if (j < m) use(j, b);
+        }
+    }
+}
+
 }  // namespace dsq

@@ -14,6 +14,7 @@
 #include "dsq_internal.hpp"
 #include "dsq_math.hpp"
 #include "dsq_wave.hpp"
+#include <type_traits>
 
 namespace dsq {
 
@@ -49,6 +50,61 @@ DSQ_DEV void wave_merge_bitonic(double *b, int n2, int lane) {
     }
 }
 
+// ---- the same networks on REGISTERS: element e = lane * R + r sits in register r of lane `lane` (64 R elements).
+// Compare-exchanges at a distance below R pair two registers of one lane, the others pair the same register of two lanes
+// (xor-shuffle over DPP / permlane swaps): the comparators of the LDS network above on the same element indices, so even
+// the intermediate states are the same -- without an LDS round trip and a wave fence per stage.
+DSQ_DEV double lane_xor_any(double v, int d, int lane) {
+    double a, b;
+    switch (d) {
+    case 1: return lane_xor1(v);
+    case 2: return lane_xor2(v);
+    case 4: return lane_xor4(v);
+    case 8: return lane_xor8(v);
+    case 16: lane_pair16(v, a, b); return (lane & 16) ? a : b;
+    default: lane_pair32(v, a, b); return (lane & 32) ? a : b;
+    }
+}
+
+// stages j = k/2 .. 1 of level k (k = 0: the final merge level, every block ascending)
+template <int R>
+DSQ_DEV void sort_level_regs(double (&v)[R], int lane, int k) {
+    const int keff = k ? k : 64 * R;
+    _Pragma("unroll")
+    for (int j = 64 * R / 2; j > 0; j >>= 1) {
+        if (j >= keff) continue;
+        if (j < R) {
+            _Pragma("unroll")
+            for (int r = 0; r < R; r++) {
+                if ((r & j) != 0) continue;
+                const int r2 = r | j;
+                const bool asc = (keff < R) ? ((r & keff) == 0) : ((lane & (keff / R)) == 0);
+                const double a = v[r], c = v[r2];
+                const bool sw = (a > c) == asc;
+                v[r] = sw ? c : a;
+                v[r2] = sw ? a : c;
+            }
+        } else {
+            const int d = j / R;
+            const bool lower = (lane & d) == 0;
+            const bool asc = (lane & (keff / R)) == 0;
+            _Pragma("unroll")
+            for (int r = 0; r < R; r++) {
+                const double own = v[r];
+                const double oth = lane_xor_any(own, d, lane);
+                const double a = lower ? own : oth, c = lower ? oth : own;
+                const bool sw = (a > c) == asc;
+                v[r] = sw ? oth : own;
+            }
+        }
+    }
+}
+template <int R>
+DSQ_DEV void wave_sort_regs(double (&v)[R], int lane) {
+    _Pragma("unroll")
+    for (int k = 2; k <= 64 * R; k <<= 1) sort_level_regs<R>(v, lane, k);
+}
+
 DSQ_DEV int pow2_at_least(int n) {
     int v = 2;
     while (v < n) v <<= 1;
@@ -75,6 +131,8 @@ DSQ_DEV double wave_max(double v) {
     return v;
 }
 
+static constexpr int kOutlierBatch = 4;      // trips whose loads are issued together (dsq_wave.hpp: sweep_batched)
+
 __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63;
@@ -90,10 +148,15 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         double acc = 0.0;
-        for (int j = lane; j < m; j += 64) {
-            double v = (double)yg[j] / nfg[j];
-            cn[j] = v;
-            acc += v;
+        {
+            int32_t yb[kOutlierBatch];
+            double nb[kOutlierBatch];
+            sweep_batched<kOutlierBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; },
+                                         [&](int j, int b) {
+                                             const double v = (double)yb[b] / nb[b];
+                                             cn[j] = v;
+                                             acc += v;
+                                         });
         }
         const double mean_all = wave_allreduce(acc) / (double)m;
         double v;
@@ -106,18 +169,54 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                 const double trim = tf == 0 ? 1.0 / 3.0 : (tf == 1 ? 1.0 / 4.0 : 1.0 / 8.0);
                 const double scale = tf == 0 ? 2.04 : (tf == 1 ? 1.86 : 1.51);
                 const int n2 = pow2_at_least(nc);
-                wave_lds_sync();
-                for (int k = lane; k < n2; k += 64) buf[k] = k < nc ? cn[kp.perm[s0 + k]] : inf;
-                wave_sort(buf, n2, lane);
-                const double cm = trimmed_mean_sorted(buf, nc, trim, lane);
-                wave_lds_sync();
-                // squared deviations of the SORTED values: falling, then rising (+inf padding keeps rising)
-                for (int k = lane; k < nc; k += 64) {
-                    double d = buf[k] - cm;
-                    buf[k] = d * d;
+                double ve;
+                // cells of up to 512 samples: both sorts in registers (element lane * R + r), the sorted values
+                // through LDS only for the rank-ordered trimmed sums
+                auto in_regs = [&](auto rtag) {
+                    constexpr int R = decltype(rtag)::value;
+                    double w[R];
+                    wave_lds_sync();
+                    _Pragma("unroll")
+                    for (int r = 0; r < R; r++) {
+                        const int e = lane * R + r;
+                        w[r] = e < nc ? cn[kp.perm[s0 + e]] : inf;
+                    }
+                    wave_sort_regs<R>(w, lane);
+                    _Pragma("unroll")
+                    for (int r = 0; r < R; r++) buf[lane * R + r] = w[r];
+                    wave_lds_sync();
+                    const double cm = trimmed_mean_sorted(buf, nc, trim, lane);
+                    // squared deviations of the SORTED values: falling, then rising (+inf padding keeps rising)
+                    _Pragma("unroll")
+                    for (int r = 0; r < R; r++) {
+                        const double d = w[r] - cm;
+                        w[r] = (lane * R + r) < nc ? d * d : inf;
+                    }
+                    sort_level_regs<R>(w, lane, 0);
+                    wave_lds_sync();
+                    _Pragma("unroll")
+                    for (int r = 0; r < R; r++) buf[lane * R + r] = w[r];
+                    wave_lds_sync();
+                    return scale * trimmed_mean_sorted(buf, nc, trim, lane);
+                };
+                if (n2 <= 64) ve = in_regs(std::integral_constant<int, 1>());
+                else if (n2 == 128) ve = in_regs(std::integral_constant<int, 2>());
+                else if (n2 == 256) ve = in_regs(std::integral_constant<int, 4>());
+                else if (n2 == 512) ve = in_regs(std::integral_constant<int, 8>());
+                else {
+                    wave_lds_sync();
+                    for (int k = lane; k < n2; k += 64) buf[k] = k < nc ? cn[kp.perm[s0 + k]] : inf;
+                    wave_sort(buf, n2, lane);
+                    const double cm = trimmed_mean_sorted(buf, nc, trim, lane);
+                    wave_lds_sync();
+                    // squared deviations of the SORTED values: falling, then rising (+inf padding keeps rising)
+                    for (int k = lane; k < nc; k += 64) {
+                        double d = buf[k] - cm;
+                        buf[k] = d * d;
+                    }
+                    wave_merge_bitonic(buf, n2, lane);
+                    ve = scale * trimmed_mean_sorted(buf, nc, trim, lane);
                 }
-                wave_merge_bitonic(buf, n2, lane);
-                const double ve = scale * trimmed_mean_sorted(buf, nc, trim, lane);
                 if (ve > v) v = ve;
             }
         } else {
@@ -140,19 +239,25 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
         double *ckg = kp.cooks + (size_t)g * kp.ld;
         double mx = -inf;
         int isnan_ = 0, anyc = 0;
-        for (int j = lane; j < m; j += 64) {
-            double mj = mug[j], hj = hg[j], yj = (double)yg[j];
-            double V = mj + alpha * (mj * mj);
-            double d = yj - mj;
-            double pr = (d * d) / V;
-            double omh = 1.0 - hj;
-            double ck = pr / (double)kp.p * hj / (omh * omh);
-            ckg[j] = ck;
-            if (kp.in3[j]) {
-                anyc = 1;
-                if (ck != ck) isnan_ = 1;
-                if (ck > mx) mx = ck;
-            }
+        {
+            double mb[kOutlierBatch], hb[kOutlierBatch];
+            int32_t yb[kOutlierBatch], ib[kOutlierBatch];
+            sweep_batched<kOutlierBatch>(m, lane,
+                                         [&](int j, int b) { mb[b] = mug[j]; hb[b] = hg[j]; yb[b] = yg[j]; ib[b] = kp.in3[j]; },
+                                         [&](int j, int b) {
+                                             const double mj = mb[b], hj = hb[b], yj = (double)yb[b];
+                                             const double V = mj + alpha * (mj * mj);
+                                             const double d = yj - mj;
+                                             const double pr = (d * d) / V;
+                                             const double omh = 1.0 - hj;
+                                             const double ck = pr / (double)kp.p * hj / (omh * omh);
+                                             ckg[j] = ck;
+                                             if (ib[b]) {
+                                                 anyc = 1;
+                                                 if (ck != ck) isnan_ = 1;
+                                                 if (ck > mx) mx = ck;
+                                             }
+                                         });
         }
         mx = wave_max(mx);
         if (lane == 0) {
@@ -179,14 +284,18 @@ __global__ void __launch_bounds__(256) replace_kernel(ReplaceKernelParams kp) {
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *ckg = kp.cooks + (size_t)g * kp.ld;
         int any = 0;
-        for (int k = lane; k < m; k += 64)
-            if (ckg[k] > kp.cutoff) any = 1;
+        {
+            double cb[kOutlierBatch];
+            sweep_batched<kOutlierBatch>(m, lane, [&](int j, int b) { cb[b] = ckg[j]; },
+                                         [&](int, int b) { if (cb[b] > kp.cutoff) any = 1; });
+        }
         any = __any(any);
         int32_t *og = kp.newCounts + (size_t)g * kp.ld;
         if (!any) {
             // no distance above the cutoff (almost every gene): the counts pass through, and the trimmed base mean
             // -- the sort -- is never needed
-            for (int j = lane; j < m; j += 64) og[j] = yg[j];
+            int32_t yb[kOutlierBatch];
+            sweep_batched<kOutlierBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; }, [&](int j, int b) { og[j] = yb[b]; });
         } else {
             wave_lds_sync();
             for (int k = lane; k < n2; k += 64) buf[k] = k < m ? (double)yg[k] / nfg[k] : inf;
@@ -230,7 +339,9 @@ static hipError_t launch_outlier(F fn, const KP &kp, size_t doubles_per_wave, hi
     return hipGetLastError();
 }
 
-hipError_t launch_cooks(const CooksKernelParams &kp, hipStream_t st, bool *ok) {
+hipError_t launch_cooks(const CooksKernelParams &kp0, hipStream_t st, bool *ok) {
+    CooksKernelParams kp = kp0;
+    if (kp.sortcap < 64) kp.sortcap = 64;      // the register sort hands back 64 R elements (R >= 1), padding included
     return launch_outlier(cooks_kernel, kp, (size_t)kp.m + kp.sortcap, st, ok);
 }
 
