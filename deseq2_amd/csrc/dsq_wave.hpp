@@ -5,6 +5,7 @@
 // registers of every lane (LU<P>, narrow designs) or held one column per lane (LaneLU<P>);
 // p is a template parameter, and MFMA is pointless at p <= 24.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 // The per-width kernels (one translation unit per design width, -DDSQ_P=p, p <= 10) want every p-loop of the
@@ -432,6 +433,85 @@ DSQ_DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- bitonic networks on REGISTERS -------------------------------------------------------------------------------
+// Element e = lane * R + r sits in register r of lane `lane` (64 R elements).  Compare-exchanges at a distance below R
+// pair two registers of one lane, the others pair the same register of two lanes (xor-shuffle over DPP / permlane
+// swaps): the comparators of the LDS networks (outlier.hip: wave_sort; wave_distinct_counts below) on the same element
+// indices, so even the intermediate states are the same -- without an LDS round trip and a wave fence per stage.
+DSQ_DEV double lane_xor_any(double v, int d, int lane) {
+    double a, b;
+    switch (d) {
+    case 1: return lane_xor1(v);
+    case 2: return lane_xor2(v);
+    case 4: return lane_xor4(v);
+    case 8: return lane_xor8(v);
+    case 16: lane_pair16(v, a, b); return (lane & 16) ? a : b;
+    default: lane_pair32(v, a, b); return (lane & 32) ? a : b;
+    }
+}
+DSQ_DEV int32_t lane_xor_any(int32_t v, int d, int lane) {
+    switch (d) {
+    case 1: return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+    case 2: return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+    case 4: {
+        int l2 = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);
+        return __builtin_amdgcn_update_dpp(l2, v, 0x114, 0xF, 0xA, false);
+    }
+    case 8: return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);
+    case 16: {
+        dsq_u2 p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return (int32_t)((lane & 16) ? p[0] : p[1]);
+    }
+    default: {
+        dsq_u2 p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (int32_t)((lane & 32) ? p[0] : p[1]);
+    }
+    }
+}
+
+// stages j = keff/2 .. 1 of the level with block size keff (keff = 64 R: the final merge level, every block ascending).
+// Fully unrolled: levels, stages and registers are compile-time constants after inlining (a rolled form with the stage
+// as a run-time value was measured 3x slower: the shuffle distance has to be a constant).
+template <class T, int R>
+DSQ_DEV void sort_level_regs(T (&v)[R], int lane, int keff) {
+    _Pragma("unroll")
+    for (int j = 64 * R / 2; j > 0; j >>= 1) {
+        if (j >= keff) continue;
+        if (j < R) {
+            _Pragma("unroll")
+            for (int r = 0; r < R; r++) {
+                if ((r & j) != 0) continue;
+                const int r2 = r | j;
+                const bool asc = (keff < R) ? ((r & keff) == 0) : ((lane & (keff / R)) == 0);
+                const T a = v[r], c = v[r2];
+                const bool sw = (a > c) == asc;
+                v[r] = sw ? c : a;
+                v[r2] = sw ? a : c;
+            }
+        } else {
+            const int d = j / R;
+            const bool lower = (lane & d) == 0;
+            const bool asc = (lane & (keff / R)) == 0;
+            _Pragma("unroll")
+            for (int r = 0; r < R; r++) {
+                const T own = v[r];
+                const T oth = lane_xor_any(own, d, lane);
+                const T a = lower ? own : oth, c = lower ? oth : own;
+                const bool sw = (a > c) == asc;
+                v[r] = sw ? oth : own;
+            }
+        }
+    }
+}
+template <class T, int R>
+DSQ_DEV void wave_sort_regs(T (&v)[R], int lane) {
+    _Pragma("unroll")
+    for (int k = 2; k <= 64 * R; k <<= 1) sort_level_regs<T, R>(v, lane, k);
+}
+// ascending sort of a BITONIC sequence (first falling, then rising): the last level is enough
+template <class T, int R>
+DSQ_DEV void wave_merge_regs(T (&v)[R], int lane) { sort_level_regs<T, R>(v, lane, 64 * R); }
+
 // Sort the gene's m counts (bitonic network in the wave's LDS slice buf), keep the first of every run and its length.
 // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m); on return the distinct values (ascending) are
 // buf[0..nv), their multiplicities buf[m..m+nv); returns nv.  yfun(k) = count of sample k as int32.
@@ -440,6 +520,28 @@ DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
     int n2 = 2;
     while (n2 < m) n2 <<= 1;
     wave_lds_sync();
+    // rows of up to 512 samples: the sort in registers (element lane * R + r), the sorted values then go to buf
+    auto in_regs = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        int32_t w[R];
+        _Pragma("unroll")
+        for (int r = 0; r < R; r++) {
+            const int e = lane * R + r;
+            w[r] = e < m ? yfun(e) : 0x7fffffff;
+        }
+        wave_sort_regs<int32_t, R>(w, lane);
+        _Pragma("unroll")
+        for (int r = 0; r < R; r++)
+            if (lane * R + r < n2) buf[lane * R + r] = w[r];
+        wave_lds_sync();
+    };
+    bool sorted_in_regs = true;
+    if (n2 <= 64) in_regs(std::integral_constant<int, 1>());
+    else if (n2 == 128) in_regs(std::integral_constant<int, 2>());
+    else if (n2 == 256) in_regs(std::integral_constant<int, 4>());
+    else if (n2 == 512) in_regs(std::integral_constant<int, 8>());
+    else sorted_in_regs = false;                 // (longer rows: the LDS network below)
+    if (!sorted_in_regs) {
     for (int k = lane; k < n2; k += 64) buf[k] = k < m ? yfun(k) : 0x7fffffff;
     wave_lds_sync();
     for (int kk = 2; kk <= n2; kk <<= 1)
@@ -453,6 +555,7 @@ DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
             }
             wave_lds_sync();
         }
+    }
     int base = 0;
     for (int k0 = 0; k0 < m; k0 += 64) {
         const int k = k0 + lane;

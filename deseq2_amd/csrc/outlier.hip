@@ -50,61 +50,6 @@ DSQ_DEV void wave_merge_bitonic(double *b, int n2, int lane) {
     }
 }
 
-// ---- the same networks on REGISTERS: element e = lane * R + r sits in register r of lane `lane` (64 R elements).
-// Compare-exchanges at a distance below R pair two registers of one lane, the others pair the same register of two lanes
-// (xor-shuffle over DPP / permlane swaps): the comparators of the LDS network above on the same element indices, so even
-// the intermediate states are the same -- without an LDS round trip and a wave fence per stage.
-DSQ_DEV double lane_xor_any(double v, int d, int lane) {
-    double a, b;
-    switch (d) {
-    case 1: return lane_xor1(v);
-    case 2: return lane_xor2(v);
-    case 4: return lane_xor4(v);
-    case 8: return lane_xor8(v);
-    case 16: lane_pair16(v, a, b); return (lane & 16) ? a : b;
-    default: lane_pair32(v, a, b); return (lane & 32) ? a : b;
-    }
-}
-
-// stages j = k/2 .. 1 of level k (k = 0: the final merge level, every block ascending)
-template <int R>
-DSQ_DEV void sort_level_regs(double (&v)[R], int lane, int k) {
-    const int keff = k ? k : 64 * R;
-    _Pragma("unroll")
-    for (int j = 64 * R / 2; j > 0; j >>= 1) {
-        if (j >= keff) continue;
-        if (j < R) {
-            _Pragma("unroll")
-            for (int r = 0; r < R; r++) {
-                if ((r & j) != 0) continue;
-                const int r2 = r | j;
-                const bool asc = (keff < R) ? ((r & keff) == 0) : ((lane & (keff / R)) == 0);
-                const double a = v[r], c = v[r2];
-                const bool sw = (a > c) == asc;
-                v[r] = sw ? c : a;
-                v[r2] = sw ? a : c;
-            }
-        } else {
-            const int d = j / R;
-            const bool lower = (lane & d) == 0;
-            const bool asc = (lane & (keff / R)) == 0;
-            _Pragma("unroll")
-            for (int r = 0; r < R; r++) {
-                const double own = v[r];
-                const double oth = lane_xor_any(own, d, lane);
-                const double a = lower ? own : oth, c = lower ? oth : own;
-                const bool sw = (a > c) == asc;
-                v[r] = sw ? oth : own;
-            }
-        }
-    }
-}
-template <int R>
-DSQ_DEV void wave_sort_regs(double (&v)[R], int lane) {
-    _Pragma("unroll")
-    for (int k = 2; k <= 64 * R; k <<= 1) sort_level_regs<R>(v, lane, k);
-}
-
 DSQ_DEV int pow2_at_least(int n) {
     int v = 2;
     while (v < n) v <<= 1;
@@ -181,7 +126,7 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                         const int e = lane * R + r;
                         w[r] = e < nc ? cn[kp.perm[s0 + e]] : inf;
                     }
-                    wave_sort_regs<R>(w, lane);
+                    wave_sort_regs<double, R>(w, lane);
                     _Pragma("unroll")
                     for (int r = 0; r < R; r++) buf[lane * R + r] = w[r];
                     wave_lds_sync();
@@ -192,7 +137,7 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                         const double d = w[r] - cm;
                         w[r] = (lane * R + r) < nc ? d * d : inf;
                     }
-                    sort_level_regs<R>(w, lane, 0);
+                    wave_merge_regs<double, R>(w, lane);
                     wave_lds_sync();
                     _Pragma("unroll")
                     for (int r = 0; r < R; r++) buf[lane * R + r] = w[r];
