@@ -520,7 +520,7 @@ DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
     int n2 = 2;
     while (n2 < m) n2 <<= 1;
     wave_lds_sync();
-    // rows of up to 512 samples: the sort in registers (element lane * R + r), the sorted values then go to buf
+    // rows of up to 2048 samples: the sort in registers (element lane * R + r), the sorted values then go to buf
     auto in_regs = [&](auto rtag) {
         constexpr int R = decltype(rtag)::value;
         int32_t w[R];
@@ -540,6 +540,8 @@ DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
     else if (n2 == 128) in_regs(std::integral_constant<int, 2>());
     else if (n2 == 256) in_regs(std::integral_constant<int, 4>());
     else if (n2 == 512) in_regs(std::integral_constant<int, 8>());
+    else if (n2 == 1024) in_regs(std::integral_constant<int, 16>());
+    else if (n2 == 2048) in_regs(std::integral_constant<int, 32>());
     else sorted_in_regs = false;                 // (longer rows: the LDS network below)
     if (!sorted_in_regs) {
     for (int k = lane; k < n2; k += 64) buf[k] = k < m ? yfun(k) : 0x7fffffff;

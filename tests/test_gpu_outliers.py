@@ -38,9 +38,9 @@ def _inputs(n, x, seed, nf_matrix=True):
 
 CASES = [(300, 6, "two"), (300, 12, "bc"), (257, 24, "bc"), (200, 70, "two"), (100, 5, "unrep"), (150, 130, "two"),
          (120, 500, "bc"), (64, 1000, "two"), (40, 2000, "f10"), (90, 37, "unrep"), (1, 9, "two"),
-         # cell sizes on every branch of the sort: registers with 1 / 2 / 4 / 8 values per lane (cells of <= 64 / 128 /
-         # 256 / 512 samples), the LDS network above that
-         (40, 600, "two"), (30, 2400, "two"), (50, 128, "two"), (50, 258, "two")]
+         # cell sizes on every branch of the sort: registers with 1 ... 32 values per lane (cells of <= 64 ... 2048
+         # samples), the LDS network above that
+         (40, 600, "two"), (30, 2400, "two"), (50, 128, "two"), (50, 258, "two"), (20, 4200, "two"), (30, 1300, "two")]
 
 
 @pytest.mark.parametrize("n,m,kind", CASES)
