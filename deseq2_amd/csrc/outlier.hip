@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                 const double scale = tf == 0 ? 2.04 : (tf == 1 ? 1.86 : 1.51);
                 const int n2 = pow2_at_least(nc);
                 double ve;
-                // cells of up to 2048 samples: both sorts in registers (element lane * R + r), the sorted values
+                // cells of up to 512 samples: both sorts in registers (more values per lane cost the kernel its occupancy: C3
+                // 0.48 -> 0.63 ms with the 16 / 32-value variants compiled in) (element lane * R + r), the sorted values
                 // through LDS only for the rank-ordered trimmed sums
                 auto in_regs = [&](auto rtag) {
                     constexpr int R = decltype(rtag)::value;
@@ -148,8 +149,6 @@ __global__ void __launch_bounds__(256) cooks_kernel(CooksKernelParams kp) {
                 else if (n2 == 128) ve = in_regs(std::integral_constant<int, 2>());
                 else if (n2 == 256) ve = in_regs(std::integral_constant<int, 4>());
                 else if (n2 == 512) ve = in_regs(std::integral_constant<int, 8>());
-                else if (n2 == 1024) ve = in_regs(std::integral_constant<int, 16>());
-                else if (n2 == 2048) ve = in_regs(std::integral_constant<int, 32>());
                 else {
                     wave_lds_sync();
                     for (int k = lane; k < n2; k += 64) buf[k] = k < nc ? cn[kp.perm[s0 + k]] : inf;
