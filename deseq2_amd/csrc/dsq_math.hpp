@@ -387,6 +387,15 @@ DSQ_DEV double dstirlerr(double n) {
         return dlgamma(n + 1.0) - (n + 0.5) * dlog(n) + n - kLnSqrt2Pi;
     }
     double nn = n * n;
+    // 15 < n < 1e100 in every lane: divisors and quotients are normal numbers far from the ends of the exponent range
+    // and the scaling-free division gives the same (correctly rounded) quotients -- 2 to 5 divisions per call, and a
+    // wave whose lanes fall into several ranges runs all of them
+    if (!__any(!(n < 1e100))) {
+        if (n > 500.0) return ddiv_n(kS0 - ddiv_n(kS1, nn), n);
+        if (n > 80.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2, nn), nn), n);
+        if (n > 35.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3, nn), nn), nn), n);
+        return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3 - ddiv_n(kS4, nn), nn), nn), nn), n);
+    }
     if (n > 500.0) return (kS0 - kS1 / nn) / n;
     if (n > 80.0) return (kS0 - (kS1 - kS2 / nn) / nn) / n;
     if (n > 35.0) return (kS0 - (kS1 - (kS2 - kS3 / nn) / nn) / nn) / n;
@@ -399,10 +408,12 @@ DSQ_DEV double dstirlerr(double n) {
 // rounded quotient (Markstein's final-rounding theorem; checked against x/d on 1.3e9 random
 // x for every odd d <= 131), i.e. the SAME bits as the division in the oracle, at 3 instead
 // of ~11 instructions.  Outside a safe exponent range (or past the table) the true division runs.
-DSQ_DEV double dbd0(double x, double np) {
+// fastdiv: the caller vouches (dnbinom_mu_log's guard) that x, np and x / np are normal numbers well inside the exponent
+// range in every active lane: the two divisions then take the scaling-free form (same quotients)
+DSQ_DEV double dbd0(double x, double np, bool fastdiv = false) {
     if (!dfinite(x) || !dfinite(np) || np == 0.0) return dnan();
     if (__builtin_fabs(x - np) < 0.1 * (x + np)) {
-        double v = (x - np) / (x + np);
+        double v = fastdiv ? ddiv_n(x - np, x + np) : (x - np) / (x + np);
         double s = (x - np) * v;
         if (__builtin_fabs(s) < kDblMin) return s;
         double ej = 2.0 * x * v;
@@ -433,13 +444,13 @@ DSQ_DEV double dbd0(double x, double np) {
             s = s1;
         }
     }
-    return x * dlog(x / np) + np - x;
+    return x * dlog(fastdiv ? ddiv_n(x, np) : x / np) + np - x;
 }
 
 // st_x / lg_x: dstirlerr(x) and dlog(x) when the caller already holds them (x = size is one value per gene in
 // nbinomLogLike: evaluated once per gene instead of once per sample -- the same function on the same argument, hence
 // the same bits); NaN = not given.
-DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q, double st_x, double lg_x) {
+DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q, double st_x, double lg_x, bool fastdiv = false) {
     if (p == 0.0) return (x == 0.0) ? 0.0 : -kInf;
     if (q == 0.0) return (x == n) ? 0.0 : -kInf;
     if (x == 0.0) {
@@ -450,8 +461,8 @@ DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q, double st_
         return (q < 0.1) ? -dbd0(n, n * p) - n * q : n * dlog(p);
     }
     if (x < 0.0 || x > n) return -kInf;
-    double lc = dstirlerr(n) - st_x - dstirlerr(n - x) - dbd0(x, n * p) - dbd0(n - x, n * q);
-    double lf = kLn2Pi + lg_x + dlog1p(-x / n);
+    double lc = dstirlerr(n) - st_x - dstirlerr(n - x) - dbd0(x, n * p, fastdiv) - dbd0(n - x, n * q, fastdiv);
+    double lf = kLn2Pi + lg_x + dlog1p(fastdiv ? ddiv_n(-x, n) : -x / n);
     return lc - 0.5 * lf;
 }
 DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q) {
@@ -482,6 +493,18 @@ DSQ_DEV double dnbinom_mu_log(double x, double size, double mu, double st_size, 
     if (x < 1e-10 * size) {
         double p = (size < mu ? dlog(size / (1.0 + size / mu)) : dlog(mu / (1.0 + mu / size)));
         return x * p - mu - dlgamma(x + 1.0) + dlog1p(x * (x - 1.0) / (2.0 * size));
+    }
+    // the common regime -- size, count and mean positive and between 1e-60 and 1e60 in every active lane: every
+    // divisor and quotient below (down to n p ~ 1e-180, up to x / (n p) ~ 1e240) is a normal number inside the
+    // exponent range, and the divisions take the
+    // scaling-free form (dsq_math.hpp: ddiv_n -- the same correctly rounded quotients, 7 instead of 11 instructions;
+    // a sample costs about a dozen of them)
+    const bool ok = size > 1e-60 && size < 1e60 && mu > 1e-60 && mu < 1e60 && x < 1e60;
+    if (!__any(!ok)) {
+        const double spm = size + mu;
+        const double p = ddiv_n(size, size + x);
+        const double ans = dbinom_raw_log(size, x + size, ddiv_n(size, spm), ddiv_n(mu, spm), st_size, lg_size, true);
+        return dlog(p) + ans;
     }
     double p = size / (size + x);
     double ans = dbinom_raw_log(size, x + size, size / (size + mu), mu / (size + mu), st_size, lg_size);
