@@ -84,6 +84,54 @@ def test_wide_chain_with_optim_rows_matches_oracle(oracle):
         assert_same(a.mcols[k], b.mcols[k], "wide DESeq() with optim rows$" + k)
 
 
+@pytest.mark.parametrize("p,m,useW,useQR", [
+    (10, 200, False, True), (10, 500, True, True), (10, 130, False, False),       # stored-row QR (LDS) from p = 10
+    (9, 250, False, True), (9, 300, True, True), (7, 256, False, True), (7, 257, False, True),   # serial Gram up to m = 256 below p = 10
+    (16, 120, False, True), (16, 400, True, True), (24, 100, False, True), (24, 260, False, True), (12, 1100, False, True)])
+def test_general_path_kernels_match_oracle(oracle, p, m, useW, useQR):
+    """designs with a CONTINUOUS covariate (one design cell per sample) at the widths where round 3 changed the general
+    kernels: fitBeta's stored-row Householder QR (rows of the least squares in LDS, p >= 10; the replay where they do
+    not fit) and fitDisp's entry-per-lane Cox-Reid Gram (serial sums, p >= 7 and m <= 256 / 1024) -- every output
+    identical to the oracle at the true p, on both sides of each threshold"""
+    rng = np.random.default_rng(100 * p + m)
+    levels = p - 1
+    x = np.column_stack([simulate.design_factor(m, levels), rng.normal(0.0, 0.5, m)])
+    assert x.shape[1] == p and np.linalg.matrix_rank(x) == p
+    d = simulate.make_counts(90, x, seed=p + m, beta_sd=np.array([0.5] * (p - 2) + [0.3]),
+                             size_factors=np.exp(rng.normal(0, 0.2, m)))
+    counts = d["counts"]
+    n = counts.shape[0]
+    nf = np.broadcast_to(d["size_factors"][None, :], (n, m)).copy()
+    w = np.ones((n, m))
+    if useW:
+        w = rng.uniform(0.05, 1.0, (n, m))
+        w[rng.uniform(size=(n, m)) < 0.02] = 0.0
+        w = w / w.max(axis=1, keepdims=True)
+    from tests.helpers import beta_init_qr, rough_alpha
+    with np.errstate(all="ignore"):
+        binit = beta_init_qr(counts.astype(float), nf, x)
+        alpha = np.nan_to_num(rough_alpha(counts.astype(float), nf, x), nan=0.1)
+    alpha = np.clip(alpha, 1e-8, max(10, m))
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    contrast = np.zeros(p); contrast[-1] = 1.0
+    bargs = (counts, x, nf, alpha, contrast, binit, lam, w, useW, 1e-8, 100, useQR, 0.5)
+    gb, ob = native.fitBeta(*bargs), oracle.fitBeta(*bargs)
+    for k in BETA_KEYS:
+        assert_same(gb[k], ob[k], "general fitBeta$" + k)
+    mu = oracle.fittedMu(x, nf, ob["beta_mat"], 0.5)
+    mu = np.where(np.isfinite(mu), mu, 0.5)
+    la = np.log(alpha)
+    wd = np.maximum(w, 1e-6) if useW else w
+    for prior in (False, True):
+        dargs = (counts, x, mu, la, la - 0.1, 0.8, np.log(1e-9), 1.0, 1e-6, 100, prior, wd, useW, 1e-2, True)
+        gd, od = native.fitDisp(*dargs), oracle.fitDisp(*dargs)
+        for k in DISP_KEYS:
+            assert_same(gd[k], od[k], "general fitDisp$" + k)
+    grid = np.linspace(np.log(1e-8), np.log(max(10, m)), 12)
+    gargs = (counts[:24], x, mu[:24], grid, la[:24], 1.0, True, wd[:24], useW, 1e-2, True)
+    assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"], "general fitDispGrid")
+
+
 def test_wide_chain_lrt_matches_oracle(oracle):
     """12-level factor, nbinomLRT against the intercept: the whole DESeq() chain on the HBM-resident engine"""
     m = 96
