@@ -191,11 +191,12 @@ def main():
             w = None if w is None else w[lo:hi]
         n = counts.shape[0]
         sf = d["size_factors"]
+        sizes = [len(r) for r in parallel.shard_ranges(n_all, world)] if (lo_hi is not None and world > 1) else None
         counts_r = torch.as_tensor(np.ascontiguousarray(counts.T), device=dev)                 # (m, n) int32
         nf_r = torch.ones((m, n), dtype=torch.float64, device=dev) * torch.as_tensor(sf, device=dev)[:, None]
         w_r = None if w is None else torch.as_tensor(np.ascontiguousarray(w.T), device=dev)
         torch.cuda.synchronize()
-        return dict(counts=counts, counts_r=counts_r, nf_r=nf_r, w=w, w_r=w_r, sf=sf, n=n, n_all=n_all)
+        return dict(counts=counts, counts_r=counts_r, nf_r=nf_r, w=w, w_r=w_r, sf=sf, n=n, n_all=n_all, shard_sizes=sizes)
 
     def shard(n_all):
         r = parallel.shard_ranges(n_all, world)[rank]
@@ -218,7 +219,7 @@ def main():
             else:
                 # the fused device-driven chain (deseq2_amd/fused.py); settings it does not cover (betaPrior: C5) run
                 # the call-by-call chain of core.py
-                fused.DESeq(dds, comm_device=comm_dev, **kw)
+                fused.DESeq(dds, comm_device=comm_dev, shard_sizes=W.get("shard_sizes"), **kw)
             return [dds]
         return step
 

@@ -321,7 +321,39 @@ class _Run:
         return st, hd[self._nd - L.DSQ_SC_COUNT:], hv, hm, hi[: 9 * n].reshape(9, n), hmle
 
 
-def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None, **kw):
+_DEVICE_REDUCE_OK = None      # the device all-reduce of N_REFIT: None = not yet checked against the host exchange
+
+
+def _global_refit_count(run, comm_device, t):
+    """refitWithoutOutliers' closing steps ask whether ANY row of the whole object was refitted (R/core.R:2496): the
+    shards add up their counts.  With a device communicator (RCCL) the sum is an all-reduce of the one device counter,
+    enqueued behind the chain -- no host look at the device in the middle of the analysis; the FIRST call also runs the
+    host exchange and keeps the device route only if the two agree.  Ranks sharing a device (tests): through the host."""
+    global _DEVICE_REDUCE_OK
+    from . import parallel
+    if comm_device is not None and _DEVICE_REDUCE_OK is not False:
+        import torch.distributed as dist
+        try:
+            tot = run.status[L.DSQ_ST["N_REFIT"]: L.DSQ_ST["N_REFIT"] + 1].to(t.int64)
+            dist.all_reduce(tot)
+            dev_total = tot.clamp(max=2 ** 31 - 1).to(t.int32)
+            if _DEVICE_REDUCE_OK is None:
+                st, _ = run.read_status()
+                host_total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
+                mine = int(dev_total.item()) == min(host_total, 2 ** 31 - 1)
+                # (every rank must take the same route from now on: the verdict is the ranks' common one)
+                _DEVICE_REDUCE_OK = all(parallel.allgather_sizes(int(mine), comm_device))
+            if _DEVICE_REDUCE_OK:
+                return dev_total
+        except Exception:                                            # noqa: BLE001  (fall back to the host exchange)
+            _DEVICE_REDUCE_OK = False
+    st, _ = run.read_status()
+    total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
+    return t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=run.E.device)
+
+
+def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None,
+          shard_sizes=None, **kw):
     """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
     chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
     over the gathered (baseMean, dispGeneEst) of all ranks."""
@@ -339,7 +371,9 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     n = dds.n
     n_all = n
     if world > 1:
-        sizes = parallel.allgather_sizes(n, comm_device)
+        # (the caller may pass the shard sizes of all ranks -- bench.py cuts the shards itself -- and save the exchange)
+        sizes = list(shard_sizes) if shard_sizes is not None else parallel.allgather_sizes(n, comm_device)
+        assert len(sizes) == world and sizes[parallel.rank()] == n, "shard_sizes: one entry per rank, this rank's = n"
         n_all = int(max(sizes)) * world
     run = _Run(dds, test, minReplicatesForReplace, n_all if world > 1 else 0, kw, reduced=reduced)
 
@@ -390,21 +424,21 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.args.defer_finish = 1
         run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS, trend=trend)
     if world > 1 and run.do_replace:
-        st, sc = run.read_status()
-        # refitWithoutOutliers' closing steps (NA results on rows that became all zero, maxCooks) ask whether ANY row of
-        # the whole object was refitted (R/core.R:2496): the shards add up their counts, then each finishes its rows
-        total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
-        run.n_refit_all = t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=E.device)
+        # refitWithoutOutliers' closing steps (NA results on rows that became all zero, maxCooks) need the GLOBAL count of
+        # refitted rows; then each shard finishes its own rows
+        run.n_refit_all = _global_refit_count(run, comm_device, t)
         run.args.n_refit_global = _ptr(run.n_refit_all)
         run.launch(L.DSQ_PH_FINISH)
     st, sc, hv, hm, hi, hmle = run.read_all()
     st2 = st
     # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
     # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
-    nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
-    if nnz == 0:
-        raise ValueError("all genes have zero counts in every sample")
+    # (N_TREND is the same on every rank, so all ranks take this branch -- and its exchange -- together; an analysis that
+    # fits a trend has non-zero rows somewhere and needs no exchange to know it)
     if st["N_TREND"] == 0:
+        nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
+        if nnz == 0:
+            raise ValueError("all genes have zero counts in every sample")
         raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
     if st["TREND_STATUS"] != 0 or st["N_ABOVE_MIN"] == 0:
         # the reference falls back to a local / mean fit here (R/core.R:885-893): not on the fused path

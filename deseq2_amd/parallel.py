@@ -49,6 +49,14 @@ def world_size():
         return 1
 
 
+def rank():
+    try:
+        import torch.distributed as dist
+        return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    except ImportError:
+        return 0
+
+
 def allgather_sizes(n, device=None):
     """the shard sizes of all ranks, in rank order"""
     import torch
