@@ -224,3 +224,50 @@ def test_bench_spawns_its_own_ranks():
     assert j2["weak"]["genes_total"] > j2["config"]["genes_total"]
     assert j2["config"]["genes_this_gpu"] * 2 - j2["config"]["genes_total"] in (0, 1)
     assert j2["result_digest"] == j1["result_digest"]          # sharded == serial, every per-gene result column
+
+
+def test_global_refit_count_over_rccl_single_rank():
+    """fused._global_refit_count with a DEVICE communicator (RCCL, backend "nccl"): the device all-reduce of the N_REFIT
+    counter, its one-time check against the host exchange and the ranks' consensus -- exercised on a 1-rank group (the
+    box has one GPU; the N > 1 path itself runs with ranks sharing the device over gloo, test above)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from deseq2_amd import fused, _lib as L
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+try:
+    dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=dev)
+    probe = torch.ones(1, device=dev); dist.all_reduce(probe); torch.cuda.synchronize()
+except Exception as e:
+    print("SKIP", repr(e)); sys.exit(0)
+class Stub:
+    pass
+run = Stub(); run.E = Stub(); run.E.device = dev
+run.status = torch.zeros(L.DSQ_ST_COUNT, dtype=torch.int32, device=dev)
+run.status[L.DSQ_ST["N_REFIT"]] = 37
+run.read_status = lambda: ({k: int(run.status[i].item()) for k, i in L.DSQ_ST.items()}, None)
+for rep in range(2):
+    tot = fused._global_refit_count(run, dev, torch)
+    assert tot.dtype == torch.int32 and tot.device.type == "cuda" and int(tot.item()) == 37, tot
+assert fused._DEVICE_REDUCE_OK is True
+# the other two exchanges of the N > 1 chain on the same communicator: shard sizes, the trend's two n-vectors
+from deseq2_amd import parallel
+assert parallel.allgather_sizes(123, dev) == [123]
+a = torch.arange(5, dtype=torch.float64, device=dev); b = a * 2
+ga, gb = parallel.allgather_device_pairs(a, b, 8, dev, torch)
+assert ga.numel() == 8 and torch.equal(ga[:5], a) and torch.isnan(ga[5:]).all() and torch.equal(gb[:5], b)
+print("OK device route")
+dist.destroy_process_group()
+'''
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    if "SKIP" in r.stdout:
+        pytest.skip("RCCL did not come up on this box: " + r.stdout.strip())
+    assert "OK device route" in r.stdout, r.stdout + r.stderr
