@@ -387,19 +387,23 @@ DSQ_DEV double dstirlerr(double n) {
         return dlgamma(n + 1.0) - (n + 0.5) * dlog(n) + n - kLnSqrt2Pi;
     }
     double nn = n * n;
-    // 15 < n < 1e100 in every lane: divisors and quotients are normal numbers far from the ends of the exponent range
-    // and the scaling-free division gives the same (correctly rounded) quotients -- 2 to 5 divisions per call, and a
-    // wave whose lanes fall into several ranges runs all of them
-    if (!__any(!(n < 1e100))) {
-        if (n > 500.0) return ddiv_n(kS0 - ddiv_n(kS1, nn), n);
-        if (n > 80.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2, nn), nn), n);
-        if (n > 35.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3, nn), nn), nn), n);
-        return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3 - ddiv_n(kS4, nn), nn), nn), nn), n);
-    }
     if (n > 500.0) return (kS0 - kS1 / nn) / n;
     if (n > 80.0) return (kS0 - (kS1 - kS2 / nn) / nn) / n;
     if (n > 35.0) return (kS0 - (kS1 - (kS2 - kS3 / nn) / nn) / nn) / n;
     return (kS0 - (kS1 - (kS2 - (kS3 - kS4 / nn) / nn) / nn) / nn) / n;
+}
+// the same for an argument the CALLER knows to be below 1e100 in every active lane (dnbinom_mu_log's range guard):
+// above 15 the divisors and quotients are normal numbers far from the ends of the exponent range and the scaling-free
+// division gives the same (correctly rounded) quotients -- 2 to 5 divisions per call, and a wave whose lanes fall into
+// several ranges runs all of them.  (Used by the density only: in fitBeta's once-per-gene constants the plain form
+// measured faster -- the compiler shares the refinement of 1 / nn between its divisions.)
+DSQ_DEV double dstirlerr_n(double n) {
+    if (n <= 15.0) return dstirlerr(n);
+    double nn = n * n;
+    if (n > 500.0) return ddiv_n(kS0 - ddiv_n(kS1, nn), n);
+    if (n > 80.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2, nn), nn), n);
+    if (n > 35.0) return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3, nn), nn), nn), n);
+    return ddiv_n(kS0 - ddiv_n(kS1 - ddiv_n(kS2 - ddiv_n(kS3 - ddiv_n(kS4, nn), nn), nn), nn), n);
 }
 
 // ---------------------------------------------------------------------- bd0
@@ -461,7 +465,8 @@ DSQ_DEV double dbinom_raw_log(double x, double n, double p, double q, double st_
         return (q < 0.1) ? -dbd0(n, n * p) - n * q : n * dlog(p);
     }
     if (x < 0.0 || x > n) return -kInf;
-    double lc = dstirlerr(n) - st_x - dstirlerr(n - x) - dbd0(x, n * p, fastdiv) - dbd0(n - x, n * q, fastdiv);
+    double lc = (fastdiv ? dstirlerr_n(n) : dstirlerr(n)) - st_x - (fastdiv ? dstirlerr_n(n - x) : dstirlerr(n - x)) -
+                dbd0(x, n * p, fastdiv) - dbd0(n - x, n * q, fastdiv);
     double lf = kLn2Pi + lg_x + dlog1p(fastdiv ? ddiv_n(-x, n) : -x / n);
     return lc - 0.5 * lf;
 }
