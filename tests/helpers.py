@@ -34,6 +34,10 @@ def make_case(n, m, design, seed=1, weights=False, sf_random=False, **kw):
         x = simulate.design_batch_condition(m)
     elif isinstance(design, tuple) and design[0] == "factor":
         x = simulate.design_factor(m, design[1])
+    elif isinstance(design, tuple) and design[0] == "factor_cont":
+        # a factor and ONE continuous covariate: one design cell per sample -> the general (per-sample) paths
+        x = np.column_stack([simulate.design_factor(m, design[1]),
+                             np.random.Generator(np.random.PCG64(seed + 77)).normal(0.0, 0.5, m)])
     else:
         raise ValueError(design)
     rng = np.random.Generator(np.random.PCG64(seed + 1000))

@@ -51,6 +51,13 @@ def live_cases():
         "two_m200_weights": _case(60, 200, "two_group", 23, weights=True),
         "bc_m36_zero_weights": _case(120, 36, "batch_condition", 24, weights=True, zero_w=True),
         "two_m8_ridge_ne": _case(200, 8, "two_group", 25, useQR=False, lam=2.0),
+        # designs with a continuous covariate (general mode).  From p = 7 the Cox-Reid Gram sums of fitDisp are taken
+        # serially (rows of <= 256 samples; <= 1024 from p = 10) -- round 3's re-specified order, held to the same budgets
+        "cont_p5_m40": _case(150, 40, ("factor_cont", 4), 26),
+        "cont_p8_m60_serial": _case(150, 60, ("factor_cont", 7), 27),
+        "cont_p10_m120_serial_weights": _case(120, 120, ("factor_cont", 9), 28, weights=True),
+        "cont_p9_m300_waveorder": _case(100, 300, ("factor_cont", 8), 29),
+        "cont_p12_m90_serial_ne": _case(100, 90, ("factor_cont", 11), 30, useQR=False),
     })
     return c
 
