@@ -132,7 +132,7 @@ DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
 // K_j = [saddle-point constants of dnbinom_mu, logarithms folded] + n log1p(alpha y) - y log y + y log nf_j  (0 for y = 0)
 template <bool USE_W>
 DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double *wg, int m, int lane, double alpha,
-                              double size, bool fast) {
+                              double size, bool fast, const double *lnf = nullptr) {
     if (!fast) return 0.0;
     const double st_size = dstirlerr(size);
     double kacc = 0.0;
@@ -144,7 +144,9 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
             const double n = y + size;
             const double L = dlog1p(alpha * y), ly = dlog(y);
             const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
-            kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * dlog(nfg[j]));
+            // (lnf: log nf_j from the block's table when the factors are the size-factor vector -- the same function of
+            // the same value, evaluated once per block instead of once per gene)
+            kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * (lnf ? lnf[j] : dlog(nfg[j])));
         }
         if constexpr (USE_W) kacc += wg[j] * kj;
         else kacc += kj;
@@ -671,8 +673,12 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
     double *xcs = smem;
     int32_t *starts = reinterpret_cast<int32_t *>(smem + (size_t)DSQ_CMAX * P);
     int32_t *pc = starts + DSQ_CMAX + 2;
-    const size_t shared_doubles = (size_t)DSQ_CMAX * P + beta_cell_int_doubles(m);
+    const size_t lnf_doubles = kp.nf_is_vector ? (size_t)m : 0;      // log of the size factors: one table per block
+    const size_t shared_doubles = (size_t)DSQ_CMAX * P + beta_cell_int_doubles(m) + lnf_doubles;
     const size_t wave_doubles = beta_cell_wave_doubles(m, USE_W);
+    double *lnf_s = kp.nf_is_vector ? smem + (size_t)DSQ_CMAX * P + beta_cell_int_doubles(m) : nullptr;
+    if (lnf_s)
+        for (int t = threadIdx.x; t < m; t += blockDim.x) lnf_s[t] = dlog(kp.nf[t]);
     double *slab = smem + shared_doubles + (size_t)wave * wave_doubles;
     for (int t = threadIdx.x; t <= C; t += blockDim.x) starts[t] = kp.cell_start[t];
     for (int c = 0; c < C; c++) {
@@ -720,7 +726,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         double K = 0.0, dev = 0.0;
         // the mu-independent part of the log densities, once per gene (samples in their natural order):
         // K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j,  n = y + size;  0 for y = 0
-        if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast);
+        if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, lnf_s);
         // one sweep over the samples at the current beta: positions k = lane, lane + 64, ... of the cell-sorted
         // sequence (full trips); the sums of a cell are closed when the sweep leaves it.  Deviance term of a sample:
         // y lg - (y + size) log1p(alpha mu), lg = log(mu / nf) -- one logarithm (of the rounded 1 + alpha mu, plus
@@ -1109,7 +1115,8 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
 template <int P>
 static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) {
     const int waves = 4;
-    const size_t lds = ((size_t)DSQ_CMAX * P + beta_cell_int_doubles(kp.m) + waves * beta_cell_wave_doubles(kp.m, kp.useWeights != 0)) * sizeof(double);
+    const size_t lds = ((size_t)DSQ_CMAX * P + beta_cell_int_doubles(kp.m) + (kp.nf_is_vector ? (size_t)kp.m : 0) +
+                        waves * beta_cell_wave_doubles(kp.m, kp.useWeights != 0)) * sizeof(double);
     const void *fn = kp.useWeights ? (const void *)fit_beta_cell_kernel<P, true> : (const void *)fit_beta_cell_kernel<P, false>;
     static thread_local int bpc_cache[2];
     static thread_local size_t lds_cache[2];
