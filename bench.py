@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--no-hostpath", action="store_true", help="skip the PCIe-inclusive (host-pointer ABI) pass")
     ap.add_argument("--cpu-sample-genes", type=int, default=0, help="genes of the CPU baseline sample (0 = by config)")
     ap.add_argument("--profile-host", action="store_true", help="print wall time per pipeline phase (adds syncs)")
+    ap.add_argument("--hold-results", action="store_true",
+                    help="diagnostic: keep EVERY step's result object alive, so that each step allocates its device buffers "
+                         "and pinned result block afresh from the driver -- what a host that leaks a step's buffers pays "
+                         "on this box (round 3's dds <-> run reference cycle did that until the cyclic collector ran)")
     ap.add_argument("--call-by-call", action="store_true",
                     help="time core.DESeq() (the R-side decision rules as host code between the native calls) instead "
                          "of the fused device-driven chain")
@@ -229,17 +233,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def alloc_counters():
+        """calls that reached the DRIVER (hipMalloc / hipHostMalloc), not the caching allocators' hits: a steady-state
+        step must not make any (a step that does pays milliseconds on some hosts -- round 3's 27.8 ms vs 13.0 ms)"""
+        c = {"device": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))}
+        try:
+            c["pinned_host"] = int(torch.cuda.host_memory_stats().get("num_host_alloc", 0))
+        except Exception:                                            # noqa: BLE001  (older torch: no host counters)
+            c["pinned_host"] = None
+        return c
+
     def timed(step, n_local):
+        import gc
         for _ in range(args.warmup):
             step()
+        gc.collect()
         barrier()
+        a0 = alloc_counters()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        marks = []
         t0 = time.perf_counter()
         dds = None
-        for _ in range(args.steps):
+        held = []
+        for k in range(args.steps):
+            if args.hold_results:
+                held.append(dds)
             dds = None          # release the previous step's HBM tensors before allocating the next ones
-            dds = step()
+            ev[k][0].record()
+            dds = step()        # (ends with the one device-to-host copy of the result block + stream sync)
+            ev[k][1].record()
+            marks.append(time.perf_counter())
         barrier()
         dt = time.perf_counter() - t0
+        a1 = alloc_counters()
+        held = None
+        per = np.diff(np.r_[t0, marks]) * 1e3
+        span = np.array([a.elapsed_time(b) for a, b in ev])
+        stats = {"step_ms": {"min": float(per.min()), "median": float(np.median(per)), "max": float(per.max())},
+                 # first enqueue of a step -> its last copy has landed, on the device's clock (HIP events on the chain's
+                 # stream); step wall time minus this = host code after the results are down
+                 "gpu_span_ms": {"min": float(span.min()), "median": float(np.median(span)), "max": float(span.max())},
+                 "driver_allocs_in_timed_region": {k: (None if a0[k] is None else a1[k] - a0[k]) for k in a0}}
         if world > 1:
             cdev = dev if comm_dev is not None else torch.device("cpu")
             tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -250,7 +284,7 @@ def main():
             n_total = int(nn.item())
         else:
             n_total = n_local
-        return dt, n_total, dds
+        return dt, n_total, dds, stats
 
     # ---- headline: STRONG scaling, the config's genes in total -----------------------------------------------
     W = workload(1, shard if world > 1 else None)
@@ -260,7 +294,7 @@ def main():
     if args.profile_host and rank == 0:
         return profile_host(core, E, step, torch)
 
-    dt, n_total, dds = timed(step, n)
+    dt, n_total, dds, step_stats = timed(step, n)
     fused_used = bool(dds[0].attrs.get("fused"))
 
     # per-kernel launch durations: two extra UNTIMED passes with HIP events around each kernel (recorded inside
@@ -276,7 +310,7 @@ def main():
     if world > 1 and not args.no_weak:
         dds = step = None
         W2 = workload(1 + rank)
-        dtw, ntw, _ = timed(make_step(W2), W2["n"])
+        dtw, ntw, _, _ = timed(make_step(W2), W2["n"])
         weak = {"value": ntw * args.steps / dtw, "unit": "genes/s", "ms_per_step": dtw / args.steps * 1e3,
                 "genes_per_gpu": W2["n"], "genes_total": ntw}
         W2 = None
@@ -302,6 +336,8 @@ def main():
                     dst[k] = {"launches": len(vv), "avg_ms": float(np.mean([t for _, t in vv])),
                               "genes_per_launch": float(np.mean([g for g, _ in vv]))}
         share = {k: kern[k]["avg_ms"] * kern[k]["launches"] for k in kern}
+        # every launch the library timed in the two profiling passes (full-size and row-listed), per step
+        kernel_sum = float(sum(ms for _, _, ms in rec)) / 2.0
         dom = max(("fit_beta", "fit_disp"), key=lambda k: share.get(k, 0.0))
         nfull = n
         avg_ms = kern[dom]["avg_ms"]
@@ -351,6 +387,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "step_ms": step_stats["step_ms"],
+            "gpu_span_ms": step_stats["gpu_span_ms"],
+            "kernel_sum_ms": kernel_sum,
+            "driver_allocs_in_timed_region": step_stats["driver_allocs_in_timed_region"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -427,8 +427,9 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
             # does the host half of fitNbinomGLMs (row checks, optim fallback) run -- overlapping the search.  Genes
             # are independent: rows whose mu the optim fallback replaces (:386) get their search redone below.
             pend = fitNbinomGLMs(dds, rows=idx, alpha_hat=alpha_hat if every else alpha_hat[idx], modelMatrix=modelMatrix,
-                                 weights=weights_glm, useWeights=useWeights, mu_floor=minmu, minmu=minmu, want_hat=False,
-                                 defer=True)                                        # :755-757
+                                 weights=weights_glm, useWeights=useWeights, mu_floor=minmu, want_hat=False,
+                                 defer=True)                                        # :755-757 (the IRLS keeps ITS default
+                                                                                    # minmu = 0.5; `minmu` is the floor of :763)
             dispRes = fit_disp(y_f, pend.mu, la_f, w_f)
             fit = pend.finish()
             fitMu = fit["mu"]                                                       # clamped at minmu (:763)
@@ -921,7 +922,10 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
     a count up over all shards (called exactly once) -- the closing steps (NA results on the rows that became all zero,
     maxCooks, :2535-2546) run when ANY row of the whole object was refitted (:2496), as on the unsharded object."""
     E = dds.engine
-    kw = {k: v for k, v in kw.items() if k not in ("betaPrior", "betaPriorVar", "modelMatrixType", "factors")}
+    # the refit runs estimateDispersionsGeneEst / MAP and nbinomWaldTest / nbinomLRT on their DEFAULTS: DESeq()'s betaTol,
+    # maxit, useQR, minmu, useT, df are not handed on (:2509-2531) -- refitted rows carry normal-distribution p-values
+    # even in a useT analysis
+    kw = {}
     replaceOutliers(dds, minReplicates=minReplicatesForReplace)
     if "replace" not in dds.mcols:
         if count_all is not None:
@@ -1009,7 +1013,7 @@ def cooksOutlier(dds, cooksCutoff=None):
 
 
 def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, disp_maxit=100, **kw):
-    estimateDispersions(dds, fitType=fitType, maxit=disp_maxit)
+    estimateDispersions(dds, fitType=fitType, maxit=disp_maxit, minmu=kw.get("minmu", 0.5))      # R/core.R:393
     if test == "Wald":
         nbinomWaldTest(dds, **kw)
     elif test == "LRT":

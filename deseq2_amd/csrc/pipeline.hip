@@ -495,6 +495,13 @@ struct Pipe {
     const int32_t *cell_perm, *cell_start;   // design cells for the cell-collapsed fitBeta kernel (ncell = 0: general)
     int ncell;
     const char *tag;               // appended to the profile names of the refit chain's launches
+    // settings of the test's GLM fits and the floor of the gene-wise estimate's fitted means.  The main chain takes the
+    // caller's (DESeq() hands betaTol / maxit / useQR / minmu to nbinomWaldTest / nbinomLRT and minmu to
+    // estimateDispersions -> estimateDispersionsGeneEst, R/core.R:393-405, R/methods.R:552, where it is the floor of
+    // :763 -- the IRLS inside that fitNbinomGLMs call keeps its own default minmu = 0.5, :755-757); the refit of the
+    // replaced rows runs every step on its DEFAULTS (refitWithoutOutliers passes none of them on, R/core.R:2509-2531)
+    double t_tol, t_minmu, ge_floor;
+    int t_maxit, t_useQR;
     // host-side facts of the design cells
     int any3, maxcell, all_replaceable;
 };
@@ -523,7 +530,7 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     q.rw = rw; q.n = P.n; q.p = P.p;
     q.minDisp = a->minDisp; q.maxDisp = P.maxDisp; q.xim = a->xim; q.outlierSD = a->outlierSD;
     q.xim_dev = a->nf_is_vector ? nullptr : P.xim_dev;
-    q.maxit = a->maxit; q.betaMaxit = a->betaMaxit;
+    q.maxit = a->maxit; q.betaMaxit = P.t_maxit;
     q.baseMean = o->baseMean; q.baseVar = o->baseVar; q.roughDisp = P.roughDisp;
     q.alpha_init = P.alpha_init; q.la0 = P.la0;
     q.la_out = P.la_out; q.initial_lp = P.initial_lp; q.last_lp = P.last_lp; q.iter = P.iter; q.la_grid = P.la_grid;
@@ -681,22 +688,22 @@ static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, i
         kp.rows = rw.rows; kp.n_dev = rw.n_dev;
         bool ok = false;
         capi_prof_begin("linear_mu", P.n, P.st);
-        PIPE_HIP(launch_linear_mu(kp, 0.5, mu_hat, P.st, &ok));            // minmu of estimateDispersionsGeneEst
+        PIPE_HIP(launch_linear_mu(kp, P.ge_floor, mu_hat, P.st, &ok));     // minmu of estimateDispersionsGeneEst (:763)
         capi_prof_end(P.st);
         if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d", P.p);
     } else {
         // fitNbinomGLMs(alpha_hat = alpha_hat) with mu floored at minmu (R/core.R:755-763); rows the IRLS leaves
         // to the optim fallback are flagged for the caller
-        // (the arguments of THIS fitNbinomGLMs call are its defaults: DESeq()'s betaTol / maxit / useQR / minmu reach
-        // only the test's fit, R/core.R:401-411)
-        rc = launch_fit_beta(P, rw, y, P.alpha_init, a->weights_norm, mu_hat, 0.5, nullptr, 1e-8, 100, 1, 0.5, "fit_beta");
+        // (the arguments of THIS fitNbinomGLMs call are its defaults -- betaTol 1e-8, maxit 100, QR, the IRLS's own minmu
+        // 0.5, R/core.R:755-757; the caller's minmu is the FLOOR of the fitted means it hands to the search, :763)
+        rc = launch_fit_beta(P, rw, y, P.alpha_init, a->weights_norm, mu_hat, P.ge_floor, nullptr, 1e-8, 100, 1, 0.5, "fit_beta");
         if (rc) return rc;
         RuleParams b = rule_params(P, rw);
         b.betaMaxit = 100;
         b.optim_flag = optim_flag; b.optim_count = P.counters + cnt_optim;
         hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
         // rows the IRLS left: the fallback's fitted means (floored at minmu, :763) replace theirs before the search
-        rc = launch_optim(P, cnt_optim, y, P.alpha_init, a->weights_norm, 0.5, 0.5, P.opt_beta, P.opt_se, P.opt_ll, mu_hat);
+        rc = launch_optim(P, cnt_optim, y, P.alpha_init, a->weights_norm, 0.5, P.ge_floor, P.opt_beta, P.opt_se, P.opt_ll, mu_hat);
         if (rc) return rc;
     }
     rc = launch_fit_disp(P, rw, y, mu_hat, P.la0, P.la0, false, a->weights_floor, a->useCR != 0, false, "fit_disp");
@@ -743,15 +750,15 @@ __global__ void prior_start_kernel(Rows rw, int n, int p, int intercept, const d
 static int mle_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat) {
     const DsqDeseqArgs *a = P.a;
     const DsqDeseqOut *o = P.o;
-    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, a->betaTol, a->betaMaxit, a->useQR,
-                             a->minmu, "fit_beta_mle");
+    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, P.t_tol, P.t_maxit, P.t_useQR,
+                             P.t_minmu, "fit_beta_mle");
     if (rc) return rc;
     const int cnt3 = P.tag[0] ? CNT_OPT3R : CNT_OPT3;
     RuleParams b = rule_params(P, rw);
     b.beta = o->mle_beta; b.betaSE = P.red_se; b.wald = 0;
     b.optim_flag = P.grid_flag; b.optim_count = P.counters + cnt3;           // (the grid flags are free between the searches)
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
-    rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->mle_beta, P.red_se, P.opt_ll, mu_out);
+    rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, o->mle_beta, P.red_se, P.opt_ll, mu_out);
     if (rc) return rc;
     PIPE_HIP(hipGetLastError());
     return DSQ_OK;
@@ -776,8 +783,8 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
         hipLaunchKernelGGL(prior_start_kernel, ew_grid(P.n), dim3(256), 0, P.st, rw, P.n, a->p_prior, a->prior_intercept,
                            (const double *)P.cnum, P.red_binit);
     }
-    rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, a->betaTol, a->betaMaxit, a->useQR,
-                         a->minmu, "fit_beta_prior", DES_PRIOR);
+    rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, P.t_tol, P.t_maxit, P.t_useQR,
+                         P.t_minmu, "fit_beta_prior", DES_PRIOR);
     if (rc) return rc;
     LogLikeKernelParams lk;
     memset(&lk, 0, sizeof lk);
@@ -794,7 +801,7 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
     b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
     b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
-    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->beta, o->betaSE, o->logLike, P.red_mu,
+    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, o->beta, o->betaSE, o->logLike, P.red_mu,
                       DES_PRIOR);
     if (rc) return rc;
     const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
@@ -811,8 +818,8 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     const DsqDeseqArgs *a = P.a;
     const DsqDeseqOut *o = P.o;
     if (a->betaPrior) return mle_fit(P, rw, y, mu_out, hat);         // (the prior fit follows once lambda is known)
-    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, a->betaTol, a->betaMaxit, a->useQR,
-                             a->minmu, "fit_beta");
+    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, P.t_tol, P.t_maxit, P.t_useQR,
+                             P.t_minmu, "fit_beta");
     if (rc) return rc;
     LogLikeKernelParams lk;
     memset(&lk, 0, sizeof lk);
@@ -829,7 +836,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
     // rows for the optim fallback (R/fitNbinomGLMs.R:203-227): coefficients, standard errors, logLike (:398-399) and
     // fitted means (:386) of those rows in place, then betaConv and the Wald columns from them
-    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, a->minmu, 0.0, o->beta, o->betaSE, o->logLike, mu_out);
+    rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, o->beta, o->betaSE, o->logLike, mu_out);
     if (rc) return rc;
     {
         const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
@@ -853,8 +860,8 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         PIPE_HIP(launch_prefit(pk, P.st, &ok));
         capi_prof_end(P.st);
         if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: reduced design with p=%d", a->p_red);
-        rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, a->betaTol, a->betaMaxit, a->useQR,
-                             a->minmu, "fit_beta_reduced", DES_REDUCED);
+        rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, P.t_tol, P.t_maxit, P.t_useQR,
+                             P.t_minmu, "fit_beta_reduced", DES_REDUCED);
         if (rc) return rc;
         lk.mu = P.red_mu; lk.loglike = o->logLikeReduced;
         capi_prof_begin(P.tag[0] ? "nbinom_loglike_red:refit" : "nbinom_loglike_red", P.n, P.st);
@@ -865,7 +872,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         rb.p = a->p_red; rb.beta_init = P.red_binit;
         rb.optim_flag = P.grid_flag; rb.optim_count = P.counters + cnt3;      // (the grid flags are free between the searches)
         hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, rb);
-        rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, a->minmu, 0.0, P.red_beta, P.red_se, o->logLikeReduced,
+        rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, P.red_beta, P.red_se, o->logLikeReduced,
                           P.red_mu, DES_REDUCED);
         if (rc) return rc;
     } else if (a->test == 1) {
@@ -1012,6 +1019,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     Pipe P;
     memset(&P, 0, sizeof P);
     P.a = a; P.o = o; P.st = st; P.tag = "";
+    P.t_tol = a->betaTol; P.t_maxit = a->betaMaxit; P.t_useQR = a->useQR; P.t_minmu = a->minmu; P.ge_floor = a->minmu;
     const int n = P.n = a->n, m = P.m = a->m, p = P.p = a->p;
     P.ld = a->ld;
     P.maxDisp = m > 10 ? (double)m : 10.0;
@@ -1200,6 +1208,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
             // the same chain on the replaced rows; their mu-hat and fitted means go to the (now dead) mu_hat matrix,
             // assays mu / H keep the original fit as in R (the refit runs on a subset object, :2500-2531)
             P.tag = ":refit";
+            P.t_tol = 1e-8; P.t_maxit = 100; P.t_useQR = 1; P.t_minmu = 0.5; P.ge_floor = 0.5;
             rc = gene_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID1R, CNT_OPT1R, o->optim_geneest);
             if (rc) return rc;
             rc = map_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID2R);

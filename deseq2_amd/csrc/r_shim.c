@@ -300,7 +300,17 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
         a.weights = REAL(w);
     }
     a.test = wald ? 0 : 1;
-    if (!wald && xRedSEXP != R_NilValue && !(Rf_ncols(xRedSEXP) == 1)) {       /* reduced = ~1: the closed form */
+    /* the closed form of R/fitNbinomGLMs.R:99-137 is taken only for a reduced model matrix that IS the intercept: one
+     * column AND all(modelMatrix == 1) (:99-103).  Any other one-column reduced model (~ 0 + x) is fitted by the IRLS
+     * like a wider one. */
+    int red_is_intercept = (xRedSEXP == R_NilValue);
+    if (!wald && xRedSEXP != R_NilValue && Rf_ncols(xRedSEXP) == 1) {
+        need_matrix(xRedSEXP, m, 1, "reduced model matrix");
+        SEXP x1 = as_real(xRedSEXP, &np);
+        red_is_intercept = 1;
+        for (int j = 0; j < m; j++) if (REAL(x1)[j] != 1.0) { red_is_intercept = 0; break; }
+    }
+    if (!wald && !red_is_intercept) {
         int pr = Rf_ncols(xRedSEXP);
         need_matrix(xRedSEXP, m, pr, "reduced model matrix"); need_matrix(qRedSEXP, m, pr, "qr.Q(reduced)");
         need_matrix(rRedSEXP, pr, pr, "qr.R(reduced)");

@@ -121,7 +121,12 @@ class _Run:
     def __init__(self, dds, test, minReplicatesForReplace, n_trend, kw, reduced=None):
         E = dds.engine
         t = self.t = E.torch
-        self.dds, self.E = dds, E
+        # (no reference back to `dds`: DESeq() below hangs this object on dds._fused_run, and a dds <-> run cycle would
+        #  keep the ~26 n x m bytes per gene of device buffers -- and the pinned result block -- alive until Python's
+        #  CYCLIC collector gets to them, so that every step of a loop would miss torch's caching allocators and pay
+        #  fresh hipMalloc / hipHostMalloc calls; with the plain reference the buffers go back to the caches the moment
+        #  the caller drops the object)
+        self.E = E
         dev = E.device
         n, m, p, ld = dds.n, dds.m, dds.p, dds.y.ld
         self.n, self.m, self.p, self.ld = n, m, p, ld
@@ -484,7 +489,13 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
                 df = num - dds.p
             df = np.broadcast_to(np.asarray(df, float), (dds.n,))
             df = np.where(df > 0, df, np.nan)
-            pval = 2 * tdist.sf(np.abs(hm[2].T), df=df[:, None])
+            pval_t = 2 * tdist.sf(np.abs(hm[2].T), df=df[:, None])
+            if run.do_replace and st["N_REFIT"] > 0:
+                # refitWithoutOutliers calls nbinomWaldTest WITHOUT useT (R/core.R:2524-2527): the refitted rows keep the
+                # normal-distribution p-values the device wrote
+                refit = (hi[5] != 0) & ~allZero
+                pval_t[refit] = pval[refit]
+            pval = pval_t
         mc.update(WaldStatistic=hm[2].T, WaldPvalue=pval, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
     else:
         stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878

@@ -262,3 +262,46 @@ def test_row_that_becomes_all_zero_by_replacement(E, others_refit):
     assert np.isfinite(np.asarray(a.mcols["dispGeneIter"], float)[new_zero]).all()
     assert np.isnan(np.asarray(a.mcols["betaIter"], float)[new_zero]).all() == others_refit
     _compare(a, b, "newAllZero, others refit = %s" % others_refit)
+
+
+def test_a_loop_of_analyses_allocates_nothing_once_warm(E):
+    """the buffers of an analysis go back to the caching allocators by REFERENCE COUNT when the caller drops the object
+    (no dds <-> run cycle waiting for the cyclic collector), so a loop of same-shape analyses -- bench.py's timed
+    region -- makes no hipMalloc / hipHostMalloc call once warm (round 3: the driver measured 27.8 ms against 13.0)"""
+    import gc
+    import weakref
+    import torch
+    x = simulate.design_batch_condition(48)
+    d = simulate.make_counts(600, x, seed=8)
+    cr = torch.as_tensor(np.ascontiguousarray(d["counts"].T), device=E.device)
+    nf = torch.ones((48, d["counts"].shape[0]), dtype=torch.float64, device=E.device)
+
+    def step():
+        dds = core.DESeqDataSet.from_device(E, cr, nf, x, sizeFactors=np.ones(48))
+        fused.DESeq(dds)
+        assert dds.attrs.get("fused")
+        return dds
+    gc.collect()
+    gc.disable()
+    try:
+        dds = step()
+        ref = weakref.ref(dds._fused_run)
+        ptr = dds._fused_run.mu.data_ptr()
+        dds = None
+        assert ref() is None, "the run outlived its dataset: reference cycle"
+        for _ in range(3):
+            dds = None
+            dds = step()
+        assert dds._fused_run.mu.data_ptr() == ptr, "the n x m buffers were not recycled"
+        torch.cuda.synchronize()
+        a0 = torch.cuda.memory_stats(E.device)["num_device_alloc"]
+        h0 = torch.cuda.host_memory_stats().get("num_host_alloc") if hasattr(torch.cuda, "host_memory_stats") else None
+        for _ in range(5):
+            dds = None
+            dds = step()
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_stats(E.device)["num_device_alloc"] == a0
+        if h0 is not None:
+            assert torch.cuda.host_memory_stats().get("num_host_alloc") == h0
+    finally:
+        gc.enable()

@@ -417,3 +417,53 @@ def test_from_device_defers_the_nf_matrix_when_size_factors_are_known():
     E2 = _Engine()
     core.DESeqDataSet.from_device(E2, _T("counts", (m, n)), _T("nf", (m, n)), x)   # no size factors: converted at once
     assert [t.name for t in E2.native.calls] == ["counts", "nf"]
+
+
+class _Spy:
+    """oracle fns with the fitBeta / fitDisp arguments DESeq() hands down recorded in call order"""
+
+    def __init__(self, O):
+        self._O, self.calls = O, []
+
+    def __getattr__(self, k):
+        return getattr(self._O, k)
+
+    def fitBeta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu, **kw):
+        self.calls.append(("fitBeta", np.asarray(y).shape[0], np.asarray(x).shape[1], float(tol), int(maxit), float(minmu),
+                           float(kw.get("mu_floor", 0.0))))
+        return self._O.fitBeta(y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu, **kw)
+
+    def fitDisp(self, y, x, mu, *rest):
+        self.calls.append(("fitDisp", np.asarray(y).shape[0], float(np.asarray(mu).min())))
+        return self._O.fitDisp(y, x, mu, *rest)
+
+
+def test_minmu_is_carried_the_way_the_reference_carries_it(oracle):
+    """DESeq(minmu = v): estimateDispersions -> estimateDispersionsGeneEst floors the fitted means it hands to the
+    search at v (R/core.R:393, R/methods.R:552, R/core.R:763) while the IRLS of that fitNbinomGLMs call keeps its default
+    minmu = 0.5 (:755-757); nbinomWaldTest's fit clamps at v (:400, :1408); refitWithoutOutliers runs every step on
+    its defaults (0.5, betaTol 1e-8, maxit 100; :2509-2531)."""
+    x = simulate.design_batch_condition(48)                      # cells of 8: outlier replacement + refit; GLM mu (4 cells... p=4)
+    x = np.column_stack([x, (np.arange(48) % 5 == 0).astype(float)])          # more cells than columns: no linear mu
+    d = simulate.make_counts(200, x, seed=5, intercept_mean=1.0)   # low counts: fitted means below 0.5 exist
+    counts = d["counts"].copy()
+    counts[3, 7] = 50000                                           # a count outlier
+    spy = _Spy(oracle)
+    dds = core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], engine=HostEngine(spy))
+    core.DESeq(dds, minmu=1e-3, betaTol=1e-6, maxit=50, minReplicatesForReplace=4)
+    assert dds.mcols["replace"].sum() >= 1
+    n = dds.n
+    fb = [c for c in spy.calls if c[0] == "fitBeta"]
+    fd = [c for c in spy.calls if c[0] == "fitDisp"]
+    main = [c for c in fb if c[1] >= n - 1]
+    refit = [c for c in fb if c[1] < n - 1]
+    # gene-wise estimate: defaults inside the IRLS, the caller's minmu as the floor of mu-hat
+    assert main[0][3:] == (1e-8, 100, 0.5, 1e-3)
+    # the test's fit: the caller's settings
+    assert main[-1][3:6] == (1e-6, 50, 1e-3)
+    # the search saw means below 0.5 but not below the floor
+    assert 1e-3 <= min(c[2] for c in fd if c[1] >= n - 1) < 0.5
+    # the refit of the replaced rows: defaults everywhere
+    assert refit and all(c[3:6] == (1e-8, 100, 0.5) for c in refit)
+    assert all(c[6] in (0.0, 0.5) for c in refit)
+    assert min(c[2] for c in fd if c[1] < n - 1) >= 0.5
