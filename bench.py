@@ -318,7 +318,7 @@ def main():
     hostpath = hostpath_fused = None
     if world == 1 and not args.no_hostpath:
         hostpath = hostpath_ms(core, W, x, cfg, factors, reduced)
-        hostpath_fused = hostpath_fused_ms(W, x, cfg, reduced)
+        hostpath_fused = hostpath_fused_ms(W, x, cfg, reduced, factors)
 
     if rank == 0:
         per = {}
@@ -470,15 +470,17 @@ def hostpath_ms(core, W, x, cfg, factors, reduced):
                     "upload + kernels + download per call, pinned staging)"}
 
 
-def hostpath_fused_ms(W, x, cfg, reduced):
+def hostpath_fused_ms(W, x, cfg, reduced, factors=None):
     """PCIe-inclusive, ONE call: dsq_deseq (what r_shim.c binds as _DESeq2_mi355x_DESeq) -- counts
     up from pageable host memory once through pinned staging, the device-driven chain, the per-gene columns down
-    (the n x m assays stay on the device unless asked for; "with_assays" times the call that brings mu / H / cooks down).
-    None for the settings the entry point declines (betaPrior: C5)."""
+    (the n x m assays stay on the device unless asked for; "with_assays" times the call that brings mu / H / cooks down
+    into freshly allocated host matrices, as R's are; assays_GBps = their bytes / the extra time)."""
     from deseq2_amd import native
-    if cfg.get("betaPrior") or cfg.get("weights"):
-        return None
     kw = dict(test=cfg["test"], reduced=reduced, minmu=cfg.get("minmu", 0.5))
+    if cfg.get("weights"):
+        kw["weights"] = np.asfortranarray(W["w"])
+    if cfg.get("betaPrior"):
+        kw.update(betaPrior=True, factors=factors)
 
     counts_r = np.asfortranarray(W["counts"])      # column-major as R holds counts(dds): no layout copy inside the call
 
@@ -489,8 +491,10 @@ def hostpath_fused_ms(W, x, cfg, reduced):
     run(())
     dt = min(run(()), run(()))
     run(("mu", "H", "cooks"))
-    dta = run(("mu", "H", "cooks"))
+    dta = min(run(("mu", "H", "cooks")), run(("mu", "H", "cooks")))
+    abytes = 3.0 * W["n"] * counts_r.shape[1] * 8
     return {"ms": dt * 1e3, "genes_per_s": W["n"] / dt, "with_assays_ms": dta * 1e3,
+            "assays_bytes": abytes, "assays_GBps": (abytes / max(dta - dt, 1e-9)) / 1e9,
             "note": "full DESeq() through ONE dsq_deseq host-pointer call (upload counts once + device-driven chain + "
                     "per-gene columns down); with_assays also downloads mu / H / cooks (n x m f64 each)"}
 

@@ -196,6 +196,16 @@ class DsqDeseqHostArgs(C.Structure):
         ("expVarLogDisp", C.c_double), ("betaTol", C.c_double), ("minmu", C.c_double), ("maxit", C.c_int32),
         ("useQR", C.c_int32), ("disp_maxit", C.c_int32), ("useCR", C.c_int32), ("disp_grid", C.c_void_p),
         ("ngrid", C.c_int32),
+        ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32), ("coef_factor", C.c_void_p),
+        ("prior_coef_factor", C.c_void_p), ("prior_coef_src", C.c_void_p), ("betaPriorVar", C.c_void_p),
+    ]
+
+
+class DsqBetaPriorArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("p", C.c_int32), ("mle_beta", C.c_void_p), ("baseMean", C.c_void_p), ("dispFit", C.c_void_p),
+        ("allZero", C.c_void_p), ("coef_factor", C.c_void_p), ("expanded", C.c_int32), ("p_prior", C.c_int32),
+        ("prior_coef_factor", C.c_void_p), ("prior_coef_src", C.c_void_p), ("upperQuantile", C.c_double),
     ]
 
 
@@ -204,7 +214,8 @@ class DsqDeseqHostOut(C.Structure):
         "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
         "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
         "logLikeReduced", "maxCooks", "replace", "weightsFail", "mu", "H", "cooks", "replaceCounts")] + [
-        ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16)]
+        ("dispersionFunction", C.c_double * 4), ("status", C.c_int32 * 16), ("betaPriorVar", C.c_double * 24),
+        ("mle_beta", C.c_void_p)]
 
 
 DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS, DSQ_PH_FINISH, DSQ_PH_PRIOR = 1, 2, 4, 8, 16, 32
@@ -226,7 +237,7 @@ EXPORTED_SYMBOLS = [
     "dsq_fit_beta_rows", "dsq_fit_disp_rows", "dsq_fit_disp_grid_rows", "dsq_optim_rows",
     "dsq_intercept_fit", "dsq_intercept_fit_dev", "dsq_deseq_dev", "dsq_deseq_workspace_bytes",
     "dsq_profile_count", "dsq_profile_get",
-    "dsq_deseq", "dsq_weights_prep_dev", "dsq_xim_dev",
+    "dsq_deseq", "dsq_beta_prior_var", "dsq_weights_prep_dev", "dsq_xim_dev",
     "dsq_linear_mu", "dsq_linear_mu_dev", "dsq_cooks_distance", "dsq_cooks_distance_dev", "dsq_replace_outliers", "dsq_replace_outliers_dev",
 ]
 
@@ -289,6 +300,7 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dsq_xim_dev.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dsq_deseq.argtypes = [C.POINTER(DsqDeseqHostArgs), C.POINTER(DsqDeseqHostOut)]
+    L.dsq_beta_prior_var.argtypes = [C.POINTER(DsqBetaPriorArgs), C.c_void_p]
     L.dsq_deseq_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.dsq_deseq_workspace_bytes.restype = C.c_int64
     L.dsq_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]

@@ -659,7 +659,7 @@ def Hmisc_wtd_quantile(x, weights, prob, normwt=True, sorter=None):
     keep = ~(np.isnan(w) | (w == 0))
     x, w = x[keep], w[keep]
     if normwt:
-        w = w * x.size / w.sum()
+        w = w * x.size / np.cumsum(w)[-1]          # (every sum here is sequential: the order csrc/beta_prior.hip follows)
     o = np.argsort(x, kind="stable") if sorter is None else np.asarray(sorter(x))
     x, w = x[o], w[o]
     # the distinct values of the sorted vector and, per value, the sum of its weights in index order (what
@@ -670,12 +670,12 @@ def Hmisc_wtd_quantile(x, weights, prob, normwt=True, sorter=None):
     ux = x[head]
     inv = np.cumsum(head) - 1
     wts = np.bincount(inv, weights=w)
-    n = wts.sum()
+    cs = np.cumsum(wts)
+    n = cs[-1]
     order = 1 + (n - 1) * prob
     low = max(np.floor(order), 1.0)
     high = min(low + 1, n)
     frac = order % 1
-    cs = np.cumsum(wts)
 
     def stepq(q):                      # approx(cumsum(wts), x, method='constant', f=1, rule=2)
         i = np.searchsorted(cs, q, side="left")
@@ -685,8 +685,9 @@ def Hmisc_wtd_quantile(x, weights, prob, normwt=True, sorter=None):
 
 def matchWeightedUpperQuantileForVariance(x, weights, upperQuantile=0.05, sorter=None):
     """R/core.R:2416-2419"""
-    sdEst = Hmisc_wtd_quantile(np.abs(x), weights, 1 - upperQuantile, normwt=True, sorter=sorter) / sps.ndtri(1 - upperQuantile / 2)
-    return float(sdEst) ** 2
+    qn = 1.959963984540054 if upperQuantile == 0.05 else sps.ndtri(1 - upperQuantile / 2)       # qnorm(1 - 0.05 / 2)
+    sdEst = float(Hmisc_wtd_quantile(np.abs(x), weights, 1 - upperQuantile, normwt=True, sorter=sorter) / qn)
+    return sdEst * sdEst
 
 
 def matchUpperQuantileForVariance(x, upperQuantile=0.05):
@@ -735,7 +736,7 @@ def estimateBetaPriorVar(dds, mleBetaMatrix, names, betaPriorMethod="weighted", 
         for f in factors:
             mmset = {nm for nm in enames if nm.startswith(f)} | {f + "Cntrst"}
             vals = [pv[c] for c, nm in enumerate(names) if nm in mmset]
-            meanvar = float(np.mean(vals))
+            meanvar = float(np.cumsum(vals)[-1] / len(vals))
             for i, nm in enumerate(enames):
                 if nm.startswith(f) and nm != "Intercept":
                     out[i] = meanvar

@@ -119,7 +119,8 @@ static constexpr int WS_SLOTS_MAX = DSQ_WS_COUNT;
 static std::map<hipStream_t, std::vector<Slot>> g_pool[64];
 static std::mutex g_pool_mu;      // the maps themselves (worker threads of a multi-device call look their slots up concurrently)
 static thread_local hipStream_t g_ws_stream = nullptr;
-struct WsScope { explicit WsScope(hipStream_t s) { g_ws_stream = s; } };
+// (its destructor also waits for the first-touch threads of stage.hip: no entry point returns while they are at work)
+struct WsScope { explicit WsScope(hipStream_t s) { g_ws_stream = s; } ~WsScope() { stage_prefault_finish(); } };
 std::mutex &capi_mutex() { return g_mu; }
 void capi_latch_stream(hipStream_t s) { g_ws_stream = s; }
 
@@ -1256,6 +1257,10 @@ int dsq_fit_beta_rows(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, int64_t r
     std::vector<int32_t> labels;
     const int32_t *cells; int ncell;
     host_cells(a->x, a->m, a->p, a->cell_of, a->ncell, &labels, &cells, &ncell);
+    if (row_lo == 0) {          // the n x m results land in fresh pages: take the faults while the inputs go up (stage.hip)
+        stage_prefault(o->hat_diagonals, (size_t)a->n * a->m * 8);
+        stage_prefault(o->mu, (size_t)a->n * a->m * 8);
+    }
     return host_sharded((size_t)row_lo, (size_t)row_cnt, [&](size_t lo, size_t cnt, hipStream_t st) {
         return fit_beta_host_range(a, o, lo, cnt, st, cells, ncell);
     });
@@ -1416,6 +1421,7 @@ int dsq_linear_mu(const DsqPrefitArgs *a, double mu_floor, double *mu) {
     DsqPrefitArgs d = *a;
     void *v;
     int rc;
+    stage_prefault(mu, n * m * 8);
     if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
     if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
     if ((rc = ws_get(WS_H_VEC, 2 * m * p * 8, &v))) return rc;
@@ -1480,6 +1486,8 @@ int dsq_intercept_fit(const DsqInterceptArgs *a, const DsqInterceptOut *o) {
     DsqInterceptOut od = *o;
     void *v;
     int rc;
+    stage_prefault(o->mu, n * m * 8);
+    stage_prefault(o->hat, n * m * 8);
     if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
     if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
     if (a->useWeights) { if ((rc = up(WS_H_W, a->weights, n * m * 8, st, &v))) return rc; d.weights = (double *)v; }
@@ -1599,6 +1607,7 @@ int dsq_cooks_distance(const DsqCooksArgs *a, const DsqCooksOut *o) {
     DsqCooksOut od = *o;
     void *v;
     int rc;
+    stage_prefault(o->cooks, n * m * 8);
     if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
     if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
     if ((rc = up(WS_H_MU, a->mu, n * m * 8, st, &v))) return rc; d.mu = (double *)v;
@@ -1631,6 +1640,7 @@ int dsq_replace_outliers(const DsqReplaceArgs *a, const DsqReplaceOut *o) {
     DsqReplaceOut od = *o;
     void *v;
     int rc;
+    stage_prefault(o->newCounts, n * m * 4);
     if ((rc = up(WS_H_Y, a->y, n * m * (a->y_type == DSQ_Y_INT32 ? 4 : 8), st, &v))) return rc; d.y = v;
     if ((rc = up(WS_H_NF, a->nf, (a->nf_is_vector ? m : n * m) * 8, st, &v))) return rc; d.nf = (double *)v;
     if ((rc = up(WS_H_MU, a->cooks, n * m * 8, st, &v))) return rc; d.cooks = (double *)v;

@@ -31,6 +31,7 @@ namespace dsq {
 int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st);      // pipeline.hip
 int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f, int max_shards);   // capi.hip
 int capi_host_shards(size_t n);
+int beta_prior_var(const DsqBetaPriorArgs *a, double *out);                        // beta_prior.hip
 
 #define HD_HIP(expr)                                                                                     \
     do {                                                                                                 \
@@ -44,7 +45,7 @@ namespace {
 
 enum {   // device workspace slots of a range (grow-only, cached per (device, stream): a second call allocates nothing)
     HD_YR = DSQ_WS_HOSTDESEQ, HD_Y, HD_VEC, HD_MAT, HD_IVEC, HD_MUHAT, HD_MU, HD_H, HD_COOKS, HD_REPC, HD_STAT, HD_WORK,
-    HD_DESIGN, HD_TREND, HD_OUTR, HD_NFR, HD_NF, HD_WRAW, HD_WNORM, HD_WFLOOR, HD_END
+    HD_DESIGN, HD_TREND, HD_OUTR, HD_NFR, HD_NF, HD_WRAW, HD_WNORM, HD_WFLOOR, HD_MLE, HD_END
 };
 static_assert(HD_END <= DSQ_WS_COUNT, "workspace slots");
 
@@ -57,6 +58,8 @@ struct Facts {
     int ncell = 0, do_replace = 0, linearMu = 0, ncell_red = 0;
     std::vector<double> a, grid, lam, a_red;
     double xim = 0.0;
+    int pcol = 0;                      // columns of beta / betaSE / stat / pvalue: p, or p_prior with the beta prior
+    int prior_intercept = 0;
 };
 
 // A = X R^-1 by back substitution over the columns (linearModelMuNormalized, R/core.R:2455-2457)
@@ -126,6 +129,12 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
     }
     const double ln2 = 0.6931471805599453;
     f->lam.assign(p, 1e-6 / (ln2 * ln2));                                    // R/fitNbinomGLMs.R:73,162
+    f->pcol = (a->betaPrior && a->x_prior) ? a->p_prior : p;
+    if (a->betaPrior) {
+        const double *xp = a->x_prior ? a->x_prior : a->x;
+        f->prior_intercept = 1;
+        for (int j = 0; j < m; j++) if (xp[j] != 1.0) { f->prior_intercept = 0; break; }
+    }
     if (a->normalizationFactors) {
         f->xim = 0.0;       // (the chain takes mean(1 / colMeans(nf)) over the rows that are not all zero itself)
     } else {
@@ -139,7 +148,15 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
 struct Exchange {
     std::mutex mu;
     std::condition_variable cv;
-    int arrived[2] = {0, 0}, target = 1;
+    int arrived[3] = {0, 0, 0}, target = 1;
+    // betaPrior: the MLE coefficients / baseMean / dispFit / all-zero flags of ALL ranges (stage 2), the prior variance
+    // the first range through computes from them, its ridge on the natural-log scale
+    std::vector<double> mle, dfit;
+    std::vector<int32_t> allzero;
+    std::mutex prior_mu;
+    int prior_state = 0;               // 0 not yet computed, 1 done, < 0 failed (the DSQ_ERR_* code)
+    bool trend_ok = true;
+    std::vector<double> bpv, lam_prior;
     bool failed = false;
     std::vector<double> bm, dge;
     long n_refit = 0;                  // refitted rows over all ranges (stage 1)
@@ -168,6 +185,12 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
     if (a->x_reduced && (a->test != 1 || !a->q_reduced || !a->r_reduced || a->p_reduced < 1 || a->p_reduced >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with qr.Q / qr.R of its model matrix and 1 <= p_reduced < p");
+    if (a->betaPrior) {
+        if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: the Wald test only (R/core.R:1791: nbinomLRT has no beta prior)");
+        if (!a->coef_factor) return capi_fail(DSQ_ERR_ARG, "betaPrior: coef_factor (what each model-matrix column is) must be given");
+        if (a->x_prior && (a->p_prior < 1 || !a->prior_coef_factor)) return capi_fail(DSQ_ERR_ARG, "betaPrior on the expanded model matrix: p_prior / prior_coef_factor");
+        if (a->x_prior && a->p_prior > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: expanded model matrix with %d > %d columns", a->p_prior, DSQ_P_REG);
+    }
     if (a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "the number of samples and the number of model coefficients are equal");
     if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns", a->p, DSQ_P_REG);
     if (a->m - a->p <= 3)
@@ -232,9 +255,10 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     }
     // ---- design: x | q | a | r | grid | size factors, one small staging vector
     const size_t pr = a->x_reduced ? (size_t)a->p_reduced : 0;
+    const size_t pcol = (size_t)F.pcol, pxp = (a->betaPrior && a->x_prior) ? (size_t)a->p_prior : 0;
     const size_t off_x = 0, off_q = off_x + m * p, off_a = off_q + m * p, off_r = off_a + m * p, off_g = off_r + p * p,
                  off_sf = off_g + F.grid.size(), off_xr = off_sf + m, off_qr = off_xr + m * pr, off_ar = off_qr + m * pr,
-                 off_rr = off_ar + m * pr, dtot = off_rr + pr * pr;
+                 off_rr = off_ar + m * pr, off_xp = off_rr + pr * pr, dtot = off_xp + m * pxp;
     if ((rc = capi_ws_get(HD_DESIGN, dtot * 8, &v))) return rc;
     double *dd = (double *)v;
     {
@@ -248,13 +272,16 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
             memcpy(hb.data() + off_xr, a->x_reduced, m * pr * 8); memcpy(hb.data() + off_qr, a->q_reduced, m * pr * 8);
             memcpy(hb.data() + off_ar, F.a_red.data(), m * pr * 8); memcpy(hb.data() + off_rr, a->r_reduced, pr * pr * 8);
         }
+        if (pxp) memcpy(hb.data() + off_xp, a->x_prior, m * pxp * 8);
         HD_HIP(hipMemcpyAsync(dd, hb.data(), dtot * 8, hipMemcpyHostToDevice, st));      // (pageable: staged at once)
     }
     // ---- outputs
     if ((rc = capi_ws_get(HD_VEC, V_COUNT * cnt * 8, &v))) return rc;
     double *vec = (double *)v;
-    if ((rc = capi_ws_get(HD_MAT, 4 * p * cnt * 8, &v))) return rc;
+    if ((rc = capi_ws_get(HD_MAT, 4 * pcol * cnt * 8, &v))) return rc;
     double *mat = (double *)v;
+    double *mle = nullptr;
+    if (a->betaPrior) { if ((rc = capi_ws_get(HD_MLE, p * cnt * 8, &v))) return rc; mle = (double *)v; }
     if ((rc = capi_ws_get(HD_IVEC, I_COUNT * cnt * 4, &v))) return rc;
     int32_t *ivec = (int32_t *)v;
     double *mats[4];
@@ -263,7 +290,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     if ((rc = capi_ws_get(HD_REPC, cnt * (size_t)ld * 4, &v))) return rc;
     int32_t *repc = (int32_t *)v;
     const int nt = nshards > 1 ? (int)n : 0;
-    const int64_t wsb = dsq_deseq_workspace_bytes((int32_t)cnt, (int32_t)m, (int32_t)p, nt);
+    const int64_t wsb = dsq_deseq_workspace_bytes((int32_t)cnt, (int32_t)m, (int32_t)(pcol > p ? pcol : p), nt);
     if ((rc = capi_ws_get(HD_WORK, (size_t)wsb, &v))) return rc;
     void *work = v;
 
@@ -293,8 +320,15 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     od.dispFit = vec + V_DFIT * cnt; od.dispMAP = vec + V_DMAP * cnt; od.dispersion = vec + V_DISP * cnt;
     od.betaIter = vec + V_BITER * cnt; od.logLike = vec + V_LL * cnt; od.logLikeReduced = vec + V_LLR * cnt;
     od.maxCooks = vec + V_MAXCOOKS * cnt;
-    od.beta = mat; od.betaSE = mat + p * cnt;
-    od.stat = a->test == 0 ? mat + 2 * p * cnt : nullptr; od.pvalue = a->test == 0 ? mat + 3 * p * cnt : nullptr;
+    od.beta = mat; od.betaSE = mat + pcol * cnt;
+    od.stat = a->test == 0 ? mat + 2 * pcol * cnt : nullptr; od.pvalue = a->test == 0 ? mat + 3 * pcol * cnt : nullptr;
+    od.mle_beta = mle;
+    if (a->betaPrior) {
+        d.betaPrior = 1;
+        d.x_prior = pxp ? dd + off_xp : dd + off_x; d.p_prior = (int32_t)pcol;
+        d.prior_expanded = pxp ? 1 : 0;              // (the expanded matrix is rank deficient: start values of R/fitNbinomGLMs.R:146-155)
+        d.prior_intercept = F.prior_intercept;
+    }
     od.allZero = ivec + I_ALLZERO * cnt; od.dispGeneIter = ivec + I_DGITER * cnt; od.dispIter = ivec + I_DITER * cnt;
     od.dispOutlier = ivec + I_DOUTLIER * cnt; od.betaConv = ivec + I_BCONV * cnt; od.replace = ivec + I_REPLACE * cnt;
     od.optim_geneest = ivec + I_OPT1 * cnt; od.optim_test = ivec + I_OPT2 * cnt;
@@ -307,7 +341,53 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     od.status = status; od.scalars = scalars;
 
     // ---- the chain
-    if (nshards == 1) {
+    // betaPrior: between the MLE pass and the pass with the ridge every range hands its MLE coefficients (+ baseMean, dispFit,
+    // the all-zero flags) to the host, the first range through computes the prior variance over ALL rows (R/core.R:1601-1689,
+    // beta_prior.hip) -- DESeqParallel's exchange for this branch, R/parallel.R:34-48
+    auto prior_exchange = [&]() -> int {
+        HD_HIP(hipMemcpy2DAsync(X.mle.data() + lo, n * 8, mle, cnt * 8, cnt * 8, p, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipMemcpyAsync(X.bm.data() + lo, od.baseMean, cnt * 8, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipMemcpyAsync(X.dfit.data() + lo, od.dispFit, cnt * 8, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipMemcpyAsync(X.allzero.data() + lo, od.allZero, cnt * 4, hipMemcpyDeviceToHost, st));
+        int32_t hst[DSQ_ST_COUNT];
+        HD_HIP(hipMemcpyAsync(hst, status, sizeof hst, hipMemcpyDeviceToHost, st));
+        HD_HIP(hipStreamSynchronize(st));
+        if (shard == 0 && (hst[DSQ_ST_N_TREND] == 0 || hst[DSQ_ST_TREND_STATUS] != 0 || hst[DSQ_ST_N_ABOVE_MIN] == 0)) X.trend_ok = false;
+        if (!X.wait(2)) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
+        std::lock_guard<std::mutex> lk(X.prior_mu);
+        if (X.prior_state == 0) {
+            X.bpv.assign(pcol, 0.0);
+            int r = DSQ_OK;
+            if (!X.trend_ok) r = DSQ_ERR_FIT;                // (no dispersion trend: dsq_deseq reports it at the end)
+            else if (a->betaPriorVar) for (size_t c = 0; c < pcol; c++) X.bpv[c] = a->betaPriorVar[c];
+            else {
+                DsqBetaPriorArgs b;
+                memset(&b, 0, sizeof b);
+                b.n = (int32_t)n; b.p = (int32_t)p; b.mle_beta = X.mle.data(); b.baseMean = X.bm.data(); b.dispFit = X.dfit.data();
+                b.allZero = X.allzero.data(); b.coef_factor = a->coef_factor; b.expanded = pxp ? 1 : 0; b.p_prior = (int32_t)pcol;
+                b.prior_coef_factor = a->prior_coef_factor; b.prior_coef_src = a->prior_coef_src; b.upperQuantile = 0.05;
+                r = beta_prior_var(&b, X.bpv.data());
+            }
+            if (r == DSQ_OK)
+                for (size_t c = 0; c < pcol; c++)
+                    if (X.bpv[c] == 0.0) r = capi_fail(DSQ_ERR_FIT, "beta prior variances are equal to zero for some variables");
+            const double ln2 = 0.6931471805599453;
+            X.lam_prior.assign(pcol, 0.0);
+            for (size_t c = 0; c < pcol; c++) X.lam_prior[c] = (1.0 / X.bpv[c]) / (ln2 * ln2);      // R/fitNbinomGLMs.R:311,162
+            X.prior_state = (r == DSQ_OK) ? 1 : (r < 0 ? r : -r);
+        }
+        return X.prior_state == 1 ? DSQ_OK : -1;
+    };
+    bool prior_skipped = false;
+    if (nshards == 1 && a->betaPrior) {
+        d.phases = DSQ_PH_GENE_EST | DSQ_PH_TREND | DSQ_PH_MAP_TEST;
+        if ((rc = pipeline_run(&d, &od, st))) return rc;
+        if (prior_exchange() == DSQ_OK) {
+            d.lambda_prior = X.lam_prior.data();
+            d.phases = DSQ_PH_PRIOR | DSQ_PH_OUTLIERS;
+            if ((rc = pipeline_run(&d, &od, st))) return rc;
+        } else prior_skipped = true;
+    } else if (nshards == 1) {
         d.phases = DSQ_PH_GENE_EST | DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
         if ((rc = pipeline_run(&d, &od, st))) return rc;
     } else {
@@ -323,10 +403,20 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         HD_HIP(hipMemcpyAsync(tv, X.bm.data(), n * 8, hipMemcpyHostToDevice, st));
         HD_HIP(hipMemcpyAsync(tv + n, X.dge.data(), n * 8, hipMemcpyHostToDevice, st));
         d.trend_mean = tv; d.trend_disp = tv + n;
-        d.phases = DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
         d.defer_finish = 1;
-        if ((rc = pipeline_run(&d, &od, st))) return rc;
-        if (F.do_replace) {
+        if (a->betaPrior) {
+            d.phases = DSQ_PH_TREND | DSQ_PH_MAP_TEST;
+            if ((rc = pipeline_run(&d, &od, st))) return rc;
+            if (prior_exchange() == DSQ_OK) {
+                d.lambda_prior = X.lam_prior.data();
+                d.phases = DSQ_PH_PRIOR | DSQ_PH_OUTLIERS;
+                if ((rc = pipeline_run(&d, &od, st))) return rc;
+            } else prior_skipped = true;
+        } else {
+            d.phases = DSQ_PH_TREND | DSQ_PH_MAP_TEST | DSQ_PH_OUTLIERS;
+            if ((rc = pipeline_run(&d, &od, st))) return rc;
+        }
+        if (F.do_replace && !prior_skipped) {
             // refitWithoutOutliers' closing steps ask whether ANY row of the whole object was refitted (R/core.R:2496):
             // the ranges add up their counts, then each finishes its own rows
             int32_t mine = 0;
@@ -346,13 +436,13 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     // ---- per-gene columns down: three packed blocks, scattered into the caller's columns at this range's rows
     static thread_local std::vector<double> hv;
     static thread_local std::vector<int32_t> hi;
-    hv.resize((V_COUNT + 4 * p) * cnt + DSQ_SC_COUNT + DSQ_ST_COUNT);
+    hv.resize((V_COUNT + 4 * pcol) * cnt + DSQ_SC_COUNT + DSQ_ST_COUNT);
     hi.resize(I_COUNT * cnt);
-    double *hvec = hv.data(), *hmat = hvec + V_COUNT * cnt, *hsc = hmat + 4 * p * cnt;
+    double *hvec = hv.data(), *hmat = hvec + V_COUNT * cnt, *hsc = hmat + 4 * pcol * cnt;
     int32_t *hst = (int32_t *)(hsc + DSQ_SC_COUNT);
     HD_HIP(hipMemcpyAsync(hsc, scalars, DSQ_SC_COUNT * 8 + (DSQ_ST_COUNT + 4) * 4, hipMemcpyDeviceToHost, st));
     if ((rc = stage_d2h(hvec, vec, 1, V_COUNT * cnt * 8, 0, V_COUNT * cnt * 8, 1, st))) return rc;
-    if ((rc = stage_d2h(hmat, mat, 1, 4 * p * cnt * 8, 0, 4 * p * cnt * 8, 1, st))) return rc;
+    if ((rc = stage_d2h(hmat, mat, 1, 4 * pcol * cnt * 8, 0, 4 * pcol * cnt * 8, 1, st))) return rc;
     if ((rc = stage_d2h(hi.data(), ivec, 1, I_COUNT * cnt * 4, 0, I_COUNT * cnt * 4, 1, st))) return rc;
     HD_HIP(hipStreamSynchronize(st));
     if (hst[DSQ_ST_COUNT] != 0) return capi_fail(DSQ_ERR_VALUE, "count matrix holds negative, non-finite or non-integer values");
@@ -366,7 +456,9 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     double *const mcol[4] = {o->beta, o->betaSE, o->stat, o->pvalue};
     for (int k = 0; k < 4; k++)
         if (mcol[k] && (k < 2 || a->test == 0))
-            for (size_t c = 0; c < p; c++) memcpy(mcol[k] + c * n + lo, hmat + ((size_t)k * p + c) * cnt, cnt * 8);
+            for (size_t c = 0; c < pcol; c++) memcpy(mcol[k] + c * n + lo, hmat + ((size_t)k * pcol + c) * cnt, cnt * 8);
+    if (a->betaPrior && o->mle_beta)
+        for (size_t c = 0; c < p; c++) memcpy(o->mle_beta + c * n + lo, X.mle.data() + c * n + lo, cnt * 8);
     int32_t *const icol[6] = {o->allZero, o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv, o->replace};
     for (int k = 0; k < 6; k++) memcpy(icol[k] + lo, hi.data() + (size_t)k * cnt, cnt * 4);
     if (o->weightsFail) {
@@ -408,7 +500,11 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     design_facts(a, &F);
     if (a->normalizationFactors && F.do_replace)
         return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: a normalization-factor matrix together with the outlier refit (R/core.R:2440-2444 re-averages the factors over the refitted rows): pass minReplicatesForReplace = Inf");
+    PrefaultScope pf;               // the n x m assays land in fresh pages of the caller: fault them in while the chain runs
+    for (double *w : {o->mu, o->H, o->cooks}) stage_prefault(w, (size_t)a->n * a->m * 8);
+    stage_prefault(o->replaceCounts, (size_t)a->n * a->m * 4);
     Exchange X;
+    if (a->betaPrior) { X.mle.resize((size_t)a->n * a->p); X.dfit.resize(a->n); X.allzero.resize(a->n); X.bm.resize(a->n); }
     // a normalization-factor matrix: momentsDispEstimate averages it over ALL non-zero rows of the object, a sum that
     // gene ranges could only reproduce in another order -- one range
     const int S = a->normalizationFactors ? 1 : capi_host_shards((size_t)a->n);
@@ -422,6 +518,8 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
         return r;
     }, S);
     if (rc) return rc;
+    if (a->betaPrior && X.prior_state < 0 && X.trend_ok) return -X.prior_state;      // (beta_prior_var's own failure; its message is set)
+    if (a->betaPrior) for (int c = 0; c < F.pcol && c < 24; c++) o->betaPriorVar[c] = X.prior_state == 1 ? X.bpv[c] : NAN;
     // counters: per-range counts add up; the trend's (fitted by every range over the same gathered vectors) are range 0's
     memset(o->status, 0, sizeof o->status);
     for (int s = 0; s < S; s++)

@@ -268,6 +268,11 @@ void capi_prof_end(hipStream_t st);
 // when the host rows are complete.
 int stage_h2d(void *dev, const void *host, size_t e, size_t n_total, size_t lo, size_t cnt, size_t cols, hipStream_t st);
 int stage_d2h(void *host, const void *dev, size_t e, size_t n_total, size_t lo, size_t cnt, size_t cols, hipStream_t st);
+// first touch of a large result matrix in the caller's (fresh, pageable) memory on helper threads, ahead of the copy into
+// it -- announce the outputs when an entry point starts, wait before it returns (stage.hip)
+void stage_prefault(void *host, size_t bytes);
+void stage_prefault_finish();
+struct PrefaultScope { ~PrefaultScope() { stage_prefault_finish(); } };
 enum { DSQ_WS_PIPE = 40, DSQ_WS_PIPE_SCRATCH = 41, DSQ_WS_PIPE_META = 42, DSQ_WS_HOSTDESEQ = 48, DSQ_WS_COUNT = 72 };
 
 }  // namespace dsq

@@ -24,6 +24,9 @@
 namespace dsq {
 
 #define DSQ_DEV __device__ __forceinline__
+// the wave-uniform p x p algebra below uses nothing of the device: it also compiles for the host, where the probe of
+// tools/lu_probe.hip runs the SAME template as the reference for what the device computed
+#define DSQ_HD __host__ __device__ __forceinline__
 
 // ---- cross-lane exchange without LDS ------------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip per 32-bit half).  The butterfly
@@ -153,20 +156,23 @@ DSQ_DEV int next_gene(int *counter, int g, int stride, int lane) {
 // wave-uniform predicate -> scalar branch
 DSQ_DEV bool uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
 
-// widest LU<P> whose solve() swaps the right-hand side with select chains (see solve): P = 5, 6 with observation
-// weights came out wrong on the device in that form (fitDisp, round 2), so only the narrow widths keep it
+// widest LU<P> whose solve() swaps the right-hand side with select chains (form 1 below; see solve).  Round 2 saw two
+// select forms give wrong results on the device inside the kernels of that time (P = 5, 6 with observation weights;
+// P = 10 in the second-derivative kernel), so only the narrow widths use it.  tools/lu_probe.hip instantiates all three
+// forms at P = 4, 5, 6, 10 in the usage patterns of those kernels and compares them with the host build of this template.
 #ifndef DSQ_LU_SELECT_MAXP
 #define DSQ_LU_SELECT_MAXP 4
 #endif
+enum { LU_SWAP = 0, LU_SELECT = 1, LU_PAIRSEL = 2 };
 // ---- P x P LU with partial pivoting (first maximum wins), reciprocal pivots -----
-template <int P>
+template <int P, int FORM = (P <= DSQ_LU_SELECT_MAXP ? LU_SELECT : LU_SWAP)>
 struct LU {
     double a[P][P];
     double rdiag[P];
     int piv[P];
     int sign;
 
-    DSQ_DEV void factor() {
+    DSQ_HD void factor() {
         sign = 1;
 DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
@@ -199,18 +205,18 @@ DSQ_UNROLL_P
             }
         }
     }
-    DSQ_DEV double det() const {
+    DSQ_HD double det() const {
         double d = a[0][0];
 DSQ_UNROLL_P
         for (int i = 1; i < P; i++) d = d * a[i][i];
         return sign < 0 ? -d : d;
     }
-    DSQ_DEV void solve(double (&b)[P]) const {
+    DSQ_HD void solve(double (&b)[P]) const {
 DSQ_UNROLL_P
         for (int k = 0; k < P; k++) {
             int pr = piv[k];
             if (pr != k) {
-                if constexpr (P <= DSQ_LU_SELECT_MAXP) {
+                if constexpr (FORM == LU_SELECT) {
                     // b[k] <-> b[pr] as select chains: written as a conditional swap the compiler turns it into a
                     // dynamically indexed access, which moves b[] (a register array otherwise) into scratch memory
                     // (fit_disp<4>: 48 B/lane of scratch and ~90 scratch accesses per evaluation, 209 -> 177 VGPRs
@@ -224,6 +230,15 @@ DSQ_UNROLL_P
 DSQ_UNROLL_P
                     for (int i = k + 1; i < P; i++) b[i] = (i == pr) ? bk : b[i];
                     b[k] = picked;
+                } else if constexpr (FORM == LU_PAIRSEL) {
+                    // (the form LaneLU::solve uses at every width)
+DSQ_UNROLL_P
+                    for (int i = k + 1; i < P; i++) {
+                        const bool sw = (i == pr);
+                        const double bi = b[i], bk = b[k];
+                        b[i] = sw ? bk : bi;
+                        b[k] = sw ? bi : bk;
+                    }
                 } else {
 DSQ_UNROLL_P
                     for (int i = k + 1; i < P; i++) {
@@ -247,7 +262,7 @@ DSQ_UNROLL_P
             b[i] = t * rdiag[i];
         }
     }
-    DSQ_DEV void inverse(double (&inv)[P][P]) const {
+    DSQ_HD void inverse(double (&inv)[P][P]) const {
 DSQ_UNROLL_P
         for (int c = 0; c < P; c++) {
             double col[P];
@@ -389,7 +404,7 @@ DSQ_DEV double lane_trace_prod(const double (&a)[P], const double (&b)[P]) {
 }
 
 template <int P>
-DSQ_DEV void mat_mul(const double (&a)[P][P], const double (&b)[P][P], double (&c)[P][P]) {
+DSQ_HD void mat_mul(const double (&a)[P][P], const double (&b)[P][P], double (&c)[P][P]) {
 DSQ_UNROLL_P
     for (int i = 0; i < P; i++)
 DSQ_UNROLL_P
@@ -402,7 +417,7 @@ DSQ_UNROLL_P
 }
 
 template <int P>
-DSQ_DEV double trace_prod(const double (&a)[P][P], const double (&b)[P][P]) {
+DSQ_HD double trace_prod(const double (&a)[P][P], const double (&b)[P][P]) {
     double acc = 0.0;
 DSQ_UNROLL_P
     for (int i = 0; i < P; i++)
@@ -413,7 +428,7 @@ DSQ_UNROLL_P
 
 // trace(A B) for a SYMMETRIC B (wave-uniform matrices): the same sums as lane_trace_sym
 template <int P>
-DSQ_DEV double trace_sym(const double (&a)[P][P], const double (&b)[P][P]) {
+DSQ_HD double trace_sym(const double (&a)[P][P], const double (&b)[P][P]) {
     double tr = 0.0;
 DSQ_UNROLL_P
     for (int k = 0; k < P; k++) {

@@ -255,7 +255,7 @@ SEXP _DESeq2_mi355x_replace(SEXP ySEXP, SEXP nfSEXP, SEXP cooksSEXP, SEXP cutoff
  * minReplicatesForReplace, qf(.99, p, m - p) (R/core.R:2081),
  * trigamma((m - p) / 2) (:1196), betaTol, maxit, useQR, minmu, the dispersion searches' maxit, useCR, and which n x m
  * assays to bring back (a character-free bit mask: 1 mu, 2 H, 4 cooks, 8 replaceCounts).
- * Returns NULL when the library declines the analysis (DSQ_ERR_UNSUPPORTED: betaPrior-free chain only, p <= 10,
+ * Returns NULL when the library declines the analysis (DSQ_ERR_UNSUPPORTED: p <= 10 (also of the expanded matrix),
  * m - p > 3; DSQ_ERR_FIT: the parametric trend failed / no usable gene) -- the R caller then runs its unchanged code
  * path over the three classic routines; any other failure is an R error. ---------------------------------------- */
 static SEXP int_col(const int *v, int n, int type, int *np) {      /* -1 -> NA */
@@ -274,7 +274,13 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
                           SEXP qSEXP, SEXP rSEXP, SEXP testSEXP,
                           SEXP xRedSEXP, SEXP qRedSEXP, SEXP rRedSEXP, SEXP minReplicatesSEXP, SEXP cooksCutoffSEXP, SEXP expVarLogDispSEXP, SEXP betaTolSEXP,
                           SEXP maxitSEXP, SEXP useQRSEXP, SEXP minmuSEXP, SEXP dispMaxitSEXP, SEXP useCRSEXP,
-                          SEXP assaysSEXP) {
+                          SEXP assaysSEXP,
+                          /* nbinomWaldTest(betaPrior = TRUE): logical; the expanded model matrix or NULL (standard); integer
+                           * codes of the columns of the model matrix / of the expanded one (0 intercept, f level of factor f,
+                           * -1 other) and, for the -1 columns of the expanded one, the model-matrix column of the same name
+                           * (0-based); the user's betaPriorVar or NULL */
+                          SEXP betaPriorSEXP, SEXP xPriorSEXP, SEXP coefFactorSEXP, SEXP priorCoefFactorSEXP,
+                          SEXP priorCoefSrcSEXP, SEXP betaPriorVarSEXP) {
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
@@ -317,6 +323,31 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
         SEXP xr = as_real(xRedSEXP, &np), qr = as_real(qRedSEXP, &np), rr = as_real(rRedSEXP, &np);
         a.x_reduced = REAL(xr); a.q_reduced = REAL(qr); a.r_reduced = REAL(rr); a.p_reduced = pr;
     }
+    int pcol = p;
+    if (scalar_b(betaPriorSEXP)) {
+        a.betaPrior = 1;
+        need_length(coefFactorSEXP, p, "coefficient codes of the model matrix");
+        SEXP cf = PROTECT(Rf_coerceVector(coefFactorSEXP, INTSXP)); np++;
+        a.coef_factor = INTEGER(cf);
+        if (xPriorSEXP != R_NilValue) {
+            pcol = Rf_ncols(xPriorSEXP);
+            need_matrix(xPriorSEXP, m, pcol, "expanded model matrix");
+            need_length(priorCoefFactorSEXP, pcol, "coefficient codes of the expanded model matrix");
+            SEXP xp = as_real(xPriorSEXP, &np);
+            SEXP pcf = PROTECT(Rf_coerceVector(priorCoefFactorSEXP, INTSXP)); np++;
+            a.x_prior = REAL(xp); a.p_prior = pcol; a.prior_coef_factor = INTEGER(pcf);
+            if (priorCoefSrcSEXP != R_NilValue) {
+                need_length(priorCoefSrcSEXP, pcol, "source columns of the expanded model matrix");
+                SEXP pcs = PROTECT(Rf_coerceVector(priorCoefSrcSEXP, INTSXP)); np++;
+                a.prior_coef_src = INTEGER(pcs);
+            }
+        }
+        if (betaPriorVarSEXP != R_NilValue) {
+            need_length(betaPriorVarSEXP, pcol, "betaPriorVar");
+            SEXP bv = as_real(betaPriorVarSEXP, &np);
+            a.betaPriorVar = REAL(bv);
+        }
+    }
     a.minReplicatesForReplace = scalar_d(minReplicatesSEXP);
     a.cooksCutoff = scalar_d(cooksCutoffSEXP); a.expVarLogDisp = scalar_d(expVarLogDispSEXP);
     a.betaTol = scalar_d(betaTolSEXP); a.maxit = scalar_i(maxitSEXP); a.useQR = scalar_b(useQRSEXP);
@@ -325,10 +356,11 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     enum { BM, BV, DGE, DFIT, DMAP, DISP, BITER, LL, LLR, MAXC, NDBL };
     SEXP dv[NDBL];
     for (int k = 0; k < NDBL; k++) { dv[k] = PROTECT(Rf_allocVector(REALSXP, n)); np++; }
-    SEXP beta = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
-    SEXP se = PROTECT(Rf_allocMatrix(REALSXP, n, p)); np++;
-    SEXP stat = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
-    SEXP pval = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? p : 0)); np++;
+    SEXP beta = PROTECT(Rf_allocMatrix(REALSXP, n, pcol)); np++;
+    SEXP se = PROTECT(Rf_allocMatrix(REALSXP, n, pcol)); np++;
+    SEXP stat = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? pcol : 0)); np++;
+    SEXP pval = PROTECT(Rf_allocMatrix(REALSXP, n, wald ? pcol : 0)); np++;
+    SEXP mle = PROTECT(Rf_allocMatrix(REALSXP, n, a.betaPrior ? p : 0)); np++;
     int *iv = (int *)R_alloc((size_t)7 * n, sizeof(int));
     SEXP mu = R_NilValue, H = R_NilValue, ck = R_NilValue, rc = R_NilValue;
     if (want & 1) { mu = PROTECT(Rf_allocMatrix(REALSXP, n, m)); np++; }
@@ -347,22 +379,25 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     if (want & 2) o.H = REAL(H);
     if (want & 4) o.cooks = REAL(ck);
     if (want & 8) o.replaceCounts = INTEGER(rc);
+    if (a.betaPrior) o.mle_beta = REAL(mle);
     int status = dsq_deseq(&a, &o);
     if (status == DSQ_ERR_UNSUPPORTED || status == DSQ_ERR_FIT) { UNPROTECT(np); return R_NilValue; }
     chk(status);
     for (int k = 0; k < NDBL; k++) nan_to_na(dv[k]);
-    nan_to_na(beta); nan_to_na(se); nan_to_na(stat); nan_to_na(pval);
+    nan_to_na(beta); nan_to_na(se); nan_to_na(stat); nan_to_na(pval); nan_to_na(mle);
     SEXP fn = PROTECT(Rf_allocVector(REALSXP, 4)); np++;
     for (int k = 0; k < 4; k++) REAL(fn)[k] = o.dispersionFunction[k];
+    SEXP bpv = PROTECT(Rf_allocVector(REALSXP, a.betaPrior ? pcol : 0)); np++;
+    for (int k = 0; k < Rf_length(bpv); k++) REAL(bpv)[k] = o.betaPriorVar[k];
     const char *names[] = {"baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP",
                            "dispersion", "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv",
                            "betaIter", "logLike", "logLikeReduced", "maxCooks", "replace", "weightsFail", "mu", "H", "cooks",
-                           "replaceCounts", "dispersionFunction"};
+                           "replaceCounts", "dispersionFunction", "MLE_beta", "betaPriorVar"};
     SEXP vals[] = {dv[BM], dv[BV], int_col(o.allZero, n, LGLSXP, &np), dv[DGE], int_col(o.dispGeneIter, n, INTSXP, &np),
                    dv[DFIT], dv[DMAP], dv[DISP], int_col(o.dispIter, n, INTSXP, &np), int_col(o.dispOutlier, n, LGLSXP, &np),
                    beta, se, stat, pval, int_col(o.betaConv, n, LGLSXP, &np), dv[BITER], dv[LL], dv[LLR], dv[MAXC],
-                   int_col(o.replace, n, LGLSXP, &np), int_col(o.weightsFail, n, LGLSXP, &np), mu, H, ck, rc, fn};
-    SEXP out = named_list(26, names, vals);
+                   int_col(o.replace, n, LGLSXP, &np), int_col(o.weightsFail, n, LGLSXP, &np), mu, H, ck, rc, fn, mle, bpv};
+    SEXP out = named_list(28, names, vals);
     UNPROTECT(np);
     return out;
 }
@@ -374,7 +409,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
-    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 21},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 27},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

@@ -12,13 +12,21 @@
 #include "../../include/deseq2_mi355x.h"
 #include "dsq_internal.hpp"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23          /* Linux >= 5.14 */
+#endif
 
 namespace dsq {
 
@@ -99,6 +107,79 @@ class CopyPool {
     unsigned long long gen_ = 0;
 };
 
+// ---- first touch of the caller's result matrices, ahead of the copies ---------------------------------------------------
+// The n x m results go into memory R has just allocated (Rf_allocMatrix -> mmap): pages nobody has touched.  A copy into
+// them is bound by the page faults (zeroing + mapping, 4 KiB at a time), not by PCIe or memcpy: tools/d2h_probe.hip on an
+// MI355X box measured 15-23 ms per 200 MiB into fresh pages against 4.4-5 ms (45 GB/s) into touched ones -- round 3's
+// "mu / H / cooks come down at 10 GB/s".  MADV_POPULATE_WRITE faults a range in without changing its contents, a few
+// threads reach 25-35 GB/s, and it needs neither the device nor the data: an entry point announces its large outputs
+// when it starts (stage_prefault) and the faults are taken while the uploads and the kernels run.  stage_d2h announces
+// its own destination if nobody has (the copy then runs behind the populate threads).  stage_prefault_finish() waits for
+// the outstanding ranges: called before an entry point returns, so nothing touches the caller's memory afterwards.
+class Prefaulter {
+  public:
+    static Prefaulter &get() {
+        static Prefaulter *p = new Prefaulter();
+        return *p;
+    }
+    bool on() const { return nthreads_ > 0; }
+    void add(void *host, size_t bytes) {
+        if (!on() || bytes < ((size_t)4 << 20)) return;
+        const uintptr_t pg = (uintptr_t)page_;
+        uintptr_t a = (uintptr_t)host & ~(pg - 1), b = ((uintptr_t)host + bytes + pg - 1) & ~(pg - 1);
+        std::lock_guard<std::mutex> lk(m_);
+        for (const auto &r : ranges_) if (a >= r.first && b <= r.second) return;       // already announced
+        ranges_.push_back({a, b});
+        const uintptr_t piece = (uintptr_t)4 << 20;
+        for (uintptr_t q = a; q < b; q += piece) { tasks_.push_back({q, (b - q < piece) ? b - q : piece}); pending_++; }
+        cv_.notify_all();
+    }
+    void finish() {
+        if (!on()) return;
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        ranges_.clear();
+    }
+
+  private:
+    Prefaulter() {
+        page_ = sysconf(_SC_PAGESIZE);
+        if (page_ <= 0) page_ = 4096;
+        unsigned hw = std::thread::hardware_concurrency();
+        int t = env_int_("DSQ_PREFAULT_THREADS", hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 0));
+        if (env_int_("DSQ_PREFAULT", 1) == 0 || t < 0) t = 0;
+        // probe once: kernels before 5.14 answer EINVAL
+        if (t > 0) {
+            void *probe = mmap(nullptr, (size_t)page_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (probe == MAP_FAILED || madvise(probe, (size_t)page_, MADV_POPULATE_WRITE) != 0) t = 0;
+            if (probe != MAP_FAILED) munmap(probe, (size_t)page_);
+        }
+        nthreads_ = t;
+        for (int k = 0; k < t; k++) std::thread([this] { loop(); }).detach();
+    }
+    void loop() {
+        for (;;) {
+            std::pair<uintptr_t, uintptr_t> t;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !tasks_.empty(); });
+                t = tasks_.front();
+                tasks_.pop_front();
+            }
+            (void)madvise((void *)t.first, (size_t)t.second, MADV_POPULATE_WRITE);     // (a failure leaves the faults to the copy)
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    long page_ = 4096;
+    int nthreads_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<std::pair<uintptr_t, uintptr_t>> tasks_;
+    std::vector<std::pair<uintptr_t, uintptr_t>> ranges_;
+    size_t pending_ = 0;
+};
+
 // ---- three pinned chunks per (host thread, device) ------------------------------------------------------------------
 struct Stager {
     static constexpr int NB = 3;
@@ -110,7 +191,8 @@ struct Stager {
 static thread_local Stager g_stagers[64];
 
 static size_t chunk_bytes() {
-    static size_t c = (size_t)(env_int_("DSQ_STAGE_MB", 8) < 1 ? 1 : env_int_("DSQ_STAGE_MB", 8)) << 20;
+    // (16 MiB: tools/d2h_probe.hip, three chunks in flight, 8 copy threads -> 47 GB/s into touched pages; 8 MiB: 31)
+    static size_t c = (size_t)(env_int_("DSQ_STAGE_MB", 16) < 1 ? 1 : env_int_("DSQ_STAGE_MB", 16)) << 20;
     return c;
 }
 static bool staging_on() {
@@ -172,6 +254,16 @@ static void build_pieces(std::vector<Piece> *out, char *buf, const char *host, s
 
 }  // namespace
 
+static std::atomic<bool> g_prefault_live{false};      // (entry points that never announce anything never start the threads)
+void stage_prefault(void *host, size_t bytes) {
+    if (!host || bytes < ((size_t)4 << 20)) return;
+    g_prefault_live.store(true);
+    Prefaulter::get().add(host, bytes);
+}
+void stage_prefault_finish() {
+    if (g_prefault_live.load()) Prefaulter::get().finish();
+}
+
 // rows [lo, lo + cnt) of a column-major n_total x cols host matrix (elements of e bytes) -> the contiguous column-major
 // cnt x cols device matrix `dev`.  Asynchronous on `st` for the device side; the host source has been read when
 // the call returns.
@@ -217,6 +309,8 @@ int stage_d2h(void *host, const void *dev, size_t e, size_t n_total, size_t lo, 
     }
     Stager *s;
     if (int rc = stager_get(&s)) return rc;
+    // (the whole matrix the rows belong to: a no-op when the entry point has announced it)
+    stage_prefault((char *)host, (cnt == n_total) ? total : stride * cols);
     for (int b = 0; b < Stager::NB; b++)
         if (s->busy[b]) { ST_HIP(hipEventSynchronize(s->ev[b])); s->busy[b] = false; }
     const size_t seg_eff = (cnt == n_total) ? total : seg;

@@ -260,9 +260,39 @@ def optimRows(counts, x, nf, alpha, lam, weights, useWeights, beta_start, minmu=
     return {"beta": beta, "betaSE": se, "conv": conv.astype(bool), "mu": mu, "logLike": ll}
 
 
+def coef_factor_codes(factors, expanded=False):
+    """the column coding dsq_deseq takes for the beta prior: for model.matrix(~ f1 + f2 + ...) of the design `factors`
+    (ordered dict name -> integer level codes, 0 = reference level) 0 for the intercept and f >= 1 for a level
+    indicator of the f-th factor; `expanded` = the same for the expanded model matrix (R/expanded.R:1-18: every level)"""
+    codes = [0]
+    for f, (_, lv) in enumerate(factors.items(), start=1):
+        k = int(np.asarray(lv).max())
+        codes += [f] * (k + 1 if expanded else k)
+    return np.ascontiguousarray(codes, dtype=np.int32)
+
+
+def estimateBetaPriorVarHost(mle_beta, baseMean, dispFit, allZero, coef_factor, prior_coef_factor=None, prior_coef_src=None):
+    """dsq_beta_prior_var: estimateBetaPriorVar (R/core.R:1601-1689) on host arrays, no device work"""
+    mle = _fcol(mle_beta)
+    n, p = mle.shape
+    bm, df = np.ascontiguousarray(baseMean, np.float64), np.ascontiguousarray(dispFit, np.float64)
+    az = np.ascontiguousarray(np.asarray(allZero).astype(np.int32))
+    cf = np.ascontiguousarray(coef_factor, dtype=np.int32)
+    pcf = None if prior_coef_factor is None else np.ascontiguousarray(prior_coef_factor, dtype=np.int32)
+    pcs = None if prior_coef_src is None else np.ascontiguousarray(prior_coef_src, dtype=np.int32)
+    pp = p if pcf is None else pcf.size
+    out = np.zeros(pp)
+    args = L.DsqBetaPriorArgs(n=n, p=p, mle_beta=_ptr(mle), baseMean=_ptr(bm), dispFit=_ptr(df), allZero=_ptr(az),
+                              coef_factor=_ptr(cf), expanded=int(pcf is not None), p_prior=int(pp),
+                              prior_coef_factor=_ptr(pcf), prior_coef_src=_ptr(pcs), upperQuantile=0.05)
+    L.check(L.lib().dsq_beta_prior_var(C.byref(args), _ptr(out)))
+    return out
+
+
 def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationFactors=None, weights=None,
           minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
-          minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks")):
+          minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks"),
+          betaPrior=False, factors=None, modelMatrixType=None, betaPriorVar=None, coef_factor=None):
     """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
     in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
     design-only quantities the R caller computes with qr() / qf() / trigamma() come from numpy / scipy here.  Returns the
@@ -293,14 +323,38 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
         if not (red.shape[1] == 1 and (red == 1).all()):
             xr, p_red = red, red.shape[1]
             qr_, _, rr_ = design_qr(red)
+    # nbinomWaldTest(betaPrior = TRUE): the model matrix of the prior pass and what its columns are (R/core.R:1374-1380)
+    pcol, xe, cf, pcf = p, None, None, None
+    if betaPrior:
+        if not wald:
+            raise ValueError("betaPrior: the Wald test only")
+        mmt = modelMatrixType or ("expanded" if factors is not None else "standard")
+        if factors is not None:
+            cf = coef_factor_codes(factors)
+        else:
+            cf = np.ascontiguousarray(coef_factor if coef_factor is not None else [0] + [-1] * (p - 1), dtype=np.int32)
+        if cf.size != p:
+            raise ValueError("the design factors do not describe the %d columns of the model matrix" % p)
+        if mmt == "expanded":
+            if factors is None:
+                raise ValueError("an expanded model matrix needs the design factors")
+            from . import core
+            xe = _fcol(core.makeExpandedModelMatrix(factors)[0])
+            pcf = coef_factor_codes(factors, expanded=True)
+            pcol = xe.shape[1]
+    bpv_in = None if betaPriorVar is None else np.ascontiguousarray(betaPriorVar, dtype=np.float64)
+    if bpv_in is not None and bpv_in.size != pcol:
+        raise ValueError("betaPriorVar needs one value per column of the (expanded) model matrix")
     f64 = lambda *sh: np.full(sh, np.nan, order="F")                    # noqa: E731
     i32 = lambda: np.full(n, -1, dtype=np.int32)                         # noqa: E731
     d = {k: f64(n) for k in ("baseMean", "baseVar", "dispGeneEst", "dispFit", "dispMAP", "dispersion", "betaIter",
                              "logLike", "maxCooks")}
     d.update({k: i32() for k in ("allZero", "dispGeneIter", "dispIter", "dispOutlier", "betaConv", "replace", "weightsFail")})
-    d.update(beta=f64(n, p), betaSE=f64(n, p))
+    d.update(beta=f64(n, pcol), betaSE=f64(n, pcol))
+    if betaPrior:
+        d["mle_beta"] = f64(n, p)
     if wald:
-        d.update(stat=f64(n, p), pvalue=f64(n, p))
+        d.update(stat=f64(n, pcol), pvalue=f64(n, pcol))
     else:
         d["logLikeReduced"] = f64(n)
     for k in assays:
@@ -311,7 +365,9 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
         test=0 if wald else 1, x_reduced=_ptr(xr), q_reduced=_ptr(qr_), r_reduced=_ptr(rr_), p_reduced=int(p_red),
         minReplicatesForReplace=float(minReplicatesForReplace), cooksCutoff=cutoff,
         expVarLogDisp=evld, betaTol=float(betaTol), minmu=float(minmu), maxit=int(maxit), useQR=int(bool(useQR)),
-        disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size))
+        disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size),
+        betaPrior=int(bool(betaPrior)), x_prior=_ptr(xe), p_prior=int(pcol), coef_factor=_ptr(cf),
+        prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in))
     out = L.DsqDeseqHostOut(**{k: _ptr(v) for k, v in d.items()})
     L.check(L.lib().dsq_deseq(C.byref(args), C.byref(out)))
     res = {}
@@ -326,6 +382,8 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
                                  "varLogDispEsts": float(out.dispersionFunction[2]),
                                  "dispPriorVar": float(out.dispersionFunction[3])}
     res["status"] = {k: int(out.status[i]) for k, i in L.DSQ_ST.items()}
+    if betaPrior:
+        res["betaPriorVar"] = np.array(out.betaPriorVar[:pcol])
     res["cooksCutoff"] = cutoff
     res["df"] = p - (p_red if p_red else 1)
     return res

@@ -529,7 +529,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
- * Covers what the fused chain covers: parametric trend, betaPrior = FALSE, Wald or LRT (any nested reduced model), p <= 10,
+ * Covers what the fused chain covers: parametric trend, Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 10,
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
  * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),
@@ -560,6 +560,21 @@ typedef struct {
     int32_t disp_maxit, useCR;     /* estimateDispersions: 100, TRUE                                              */
     const double *disp_grid;       /* fitDispGridWrapper's seq(log(1e-8), log(max(10, m)), length = 20) (R/wrappers.R:70-72) */
     int32_t ngrid;                 /*   as the caller's own log() gives it; NULL / 0: computed here                */
+    /* nbinomWaldTest(betaPrior = TRUE) (R/core.R:1416-1432 -> fitGLMsWithPrior, R/fitNbinomGLMs.R:242-337), Wald only:
+     * the MLE pass on x, the all-gene prior variance (estimateBetaPriorVar, R/core.R:1601-1689: dsq_beta_prior_var
+     * below, run inside the call on the MLE coefficients of ALL gene ranges), then the pass with lambda = 1 /
+     * betaPriorVar on the standard model matrix (x_prior NULL) or on the expanded one (R/expanded.R:1-18).  beta,
+     * betaSE, stat and pvalue are then n x p_prior.  The refit of the replaced rows reuses the prior variance
+     * (R/core.R:2521-2527).                                                                                        */
+    int32_t betaPrior;
+    const double *x_prior;         /* expanded model matrix, m x p_prior column-major (same design cells as x), or NULL  */
+    int32_t p_prior;               /* columns of x_prior (ignored when x_prior is NULL: p)                         */
+    const int32_t *coef_factor;    /* p: what each column of x is -- 0 the intercept, f >= 1 an indicator of a level of
+                                      design factor f, -1 anything else (numeric covariate, interaction)            */
+    const int32_t *prior_coef_factor;  /* p_prior, the same for the columns of x_prior (expanded only)               */
+    const int32_t *prior_coef_src;     /* p_prior: for the -1 columns of x_prior the column of x with the same name   */
+    const double *betaPriorVar;    /* optional, p_prior values: the caller's prior variance (nbinomWaldTest's argument);
+                                      NULL = estimated                                                              */
 } DsqDeseqHostArgs;
 
 typedef struct {
@@ -582,9 +597,28 @@ typedef struct {
     /* dispersionFunction(dds): coefficients asymptDisp / extraPois, varLogDispEsts, dispPriorVar                  */
     double dispersionFunction[4];
     int32_t status[16];            /* DSQ_ST_*                                                                    */
+    /* betaPrior = TRUE: the prior variance used (attr(object, "betaPriorVar")) and, optionally, the n x p MLE
+     * coefficients (mcols MLE_*, log2 scale)                                                                      */
+    double betaPriorVar[24];
+    double *mle_beta;
 } DsqDeseqHostOut;
 
 int dsq_deseq(const DsqDeseqHostArgs *args, DsqDeseqHostOut *out);
+
+/* estimateBetaPriorVar (R/core.R:1601-1689, betaPriorMethod = "weighted", upperQuantile = 0.05) on HOST arrays: the
+ * n x p MLE coefficients (log2 scale, column-major), baseMean, dispFit, the all-zero flags of the rows; the column
+ * coding of DsqDeseqHostArgs.  No device work (an all-gene step on n-vectors like the dispersion trend; a stable radix
+ * sort and sequential sums).  betaPriorVar: p values, or p_prior for the expanded model matrix.                    */
+typedef struct {
+    int32_t n, p;
+    const double *mle_beta, *baseMean, *dispFit;
+    const int32_t *allZero;
+    const int32_t *coef_factor;
+    int32_t expanded, p_prior;
+    const int32_t *prior_coef_factor, *prior_coef_src;
+    double upperQuantile;
+} DsqBetaPriorArgs;
+int dsq_beta_prior_var(const DsqBetaPriorArgs *args, double *betaPriorVar);
 
 /* kernel timings of the calls since dsq_profile_enable(1): one entry per bracketed launch */
 int dsq_profile_count(void);

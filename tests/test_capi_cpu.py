@@ -99,3 +99,42 @@ def test_r_shim_is_valid_c_against_stub_r_headers():
                         "-I", os.path.join(root, "include"), os.path.join(root, "deseq2_amd", "csrc", "r_shim.c")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("case", ["standard_two_group", "standard_two_factors", "expanded_three_levels", "expanded_two_factors",
+                                  "ties_and_zero_rows"])
+def test_beta_prior_var_equals_the_host_mirror(case):
+    """dsq_beta_prior_var (csrc/beta_prior.hip: estimateBetaPriorVar of R/core.R:1601-1689 inside the library, pure host
+    code -- runs without a GPU) against core.estimateBetaPriorVar, the line-cited mirror: same stable order, same
+    sequential sums, so the same bits."""
+    from deseq2_amd import core, native
+    rng = np.random.Generator(np.random.PCG64(sum(map(ord, case))))
+    n = 3000
+    if case in ("standard_two_group",):
+        factors = {"condition": np.repeat([0, 1], 4)}
+    elif case in ("expanded_three_levels", "ties_and_zero_rows"):
+        factors = {"condition": np.repeat([0, 1, 2], 3)}
+    else:
+        factors = {"batch": np.tile([0, 1, 2], 4), "condition": np.repeat([0, 1, 2, 3], 3)}
+    x, names = core.standard_model_matrix(factors)
+    p = x.shape[1]
+    mle = rng.normal(0, 1.5, (n, p)) * rng.choice([1.0, 1.0, 1.0, 8.0], (n, 1))       # some |beta| >= 10
+    mle[:, 0] = rng.normal(5, 2, n)
+    bm = np.exp(rng.normal(3, 2, n))
+    dfit = 0.05 + 3.0 / bm
+    az = np.zeros(n, bool)
+    if case == "ties_and_zero_rows":
+        mle[::7, 1] = 0.25                                     # exact ties of |beta| ...
+        mle[1::7, 1] = -0.25                                   # ... across signs
+        mle[::11, 2] = np.nan                                  # rows without a coefficient
+        az[::13] = True
+    expanded = case.startswith("expanded") or case == "ties_and_zero_rows"
+    mmt = "expanded" if expanded else "standard"
+    view = type("V", (), {"mcols": {"baseMean": bm[~az], "dispFit": dfit[~az]}})()
+    ref, _ = core.estimateBetaPriorVar(view, mle[~az], names, modelMatrixType=mmt, factors=factors)
+    got = native.estimateBetaPriorVarHost(
+        mle, bm, dfit, az, native.coef_factor_codes(factors),
+        prior_coef_factor=native.coef_factor_codes(factors, expanded=True) if expanded else None)
+    assert got.shape == np.asarray(ref).shape
+    assert (got == np.asarray(ref)).all(), (got, ref)
+    assert got[0] == 1e6 and (got > 0).all()

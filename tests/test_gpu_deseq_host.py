@@ -60,7 +60,17 @@ def _cases():
     nf6 = np.exp(rng.normal(0, 0.2, d1["counts"].shape))
     c6 = d1["counts"].copy()
     c6[::41] = 0                 # all-zero rows: momentsDispEstimate averages the factors over the OTHER rows (objectNZ)
+    # nbinomWaldTest(betaPrior = TRUE): the prior variance is estimated INSIDE the one call (csrc/beta_prior.hip); expanded
+    # model matrix with weights (BASELINE configs[4]'s shape), a 5-level factor on the expanded and on the standard matrix
+    # with replaced outliers (the refit reuses the prior variance, R/core.R:2521-2527)
+    f2 = {"condition": x2[:, 1].astype(int)}
+    f3 = {"group": (np.arange(40) * 5) // 40}
+    c3s = _spike(d3["counts"], 12, 5)
     return {"bc_outliers": (c1, x1, d1["size_factors"], {}),
+            "bp_two_group_expanded_weights": (c2, x2, d2["size_factors"], {"weights": w5, "betaPrior": True, "factors": f2}),
+            "bp_factor5_expanded_outliers": (c3s, x3, d3["size_factors"], {"betaPrior": True, "factors": f3}),
+            "bp_factor5_standard_outliers": (c3s, x3, d3["size_factors"], {"betaPrior": True, "factors": f3,
+                                                                        "modelMatrixType": "standard"}),
             "two_group_weights": (c2, x2, d2["size_factors"], {"weights": w5}),
             "bc_nf_matrix": (c6, x1, None, {"normalizationFactors": nf6, "minReplicatesForReplace": np.inf}),
             "factor6_lrt_reduced2": (c4, x4, d4["size_factors"], {"test": "LRT", "reduced": red4, "minmu": 1e-6}),
@@ -75,7 +85,8 @@ CASES = _cases()
 def _host_entry(counts, x, sf, kw, assays=("mu", "H", "cooks")):
     return native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"), minmu=kw.get("minmu", 0.5),
                         normalizationFactors=kw.get("normalizationFactors"), weights=kw.get("weights"),
-                        minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=assays)
+                        minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=assays,
+                        betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"), modelMatrixType=kw.get("modelMatrixType"))
 
 
 def _dataset(counts, x, sf, kw, engine):
@@ -150,6 +161,11 @@ def test_host_entry_equals_fused_chain(E, name, shards):
         assert_same(res["replaceCounts"][nz], E.to_numpy(b.assays["replaceCounts"])[nz], name + ": replaceCounts")
     for k in ("N_NONZERO", "N_REPLACE", "N_REFIT", "N_OPTIM_GENEEST", "N_OPTIM_TEST", "N_GRID_GENEEST", "N_GRID_MAP"):
         assert res["status"][k] == b.attrs["status"][k], (name, k)
+    if kw.get("betaPrior"):
+        assert_same(res["betaPriorVar"], np.asarray(b.attrs["betaPriorVar"]), name + ": betaPriorVar")
+        live = ~np.asarray(b.mcols["allZero"], bool)
+        assert_same(_f(res["mle_beta"])[live], _f(b.mcols["MLE_beta"])[live], name + ": MLE_beta")
+        assert res["beta"].shape[1] == (x.shape[1] + 1 if kw.get("modelMatrixType") != "standard" else x.shape[1])
     if name == "two_group_optim_rows":
         assert res["status"]["N_OPTIM_TEST"] >= 1
     if name == "bc_outliers":
