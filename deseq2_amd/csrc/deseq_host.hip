@@ -18,7 +18,9 @@
 #include "dsq_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +34,10 @@ int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st);  
 int capi_host_sharded(size_t n, const std::function<int(size_t, size_t, hipStream_t, int, int)> &f, int max_shards);   // capi.hip
 int capi_host_shards(size_t n);
 int beta_prior_var(const DsqBetaPriorArgs *a, double *out);                        // beta_prior.hip
+
+// DSQ_TIMING=1: wall-clock marks of one dsq_deseq call on stderr (where does a PCIe-inclusive call spend its time)
+static bool timing_on() { static int on = getenv("DSQ_TIMING") ? atoi(getenv("DSQ_TIMING")) : 0; return on != 0; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define HD_HIP(expr)                                                                                     \
     do {                                                                                                 \
@@ -216,6 +222,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     const long ld = ((long)m + 7) & ~7L;
     int rc;
     void *v;
+    const double t_begin = now_ms();
     // ---- counts: R layout rows -> device -> gene-major int32
     const size_t ye = a->y_type == DSQ_Y_INT32 ? 4 : 8;
     if ((rc = capi_ws_get(HD_YR, cnt * m * ye, &v))) return rc;
@@ -433,6 +440,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         }
     }
 
+    const double t_enq = now_ms();
     // ---- per-gene columns down: three packed blocks, scattered into the caller's columns at this range's rows
     static thread_local std::vector<double> hv;
     static thread_local std::vector<int32_t> hi;
@@ -441,6 +449,9 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     double *hvec = hv.data(), *hmat = hvec + V_COUNT * cnt, *hsc = hmat + 4 * pcol * cnt;
     int32_t *hst = (int32_t *)(hsc + DSQ_SC_COUNT);
     HD_HIP(hipMemcpyAsync(hsc, scalars, DSQ_SC_COUNT * 8 + (DSQ_ST_COUNT + 4) * 4, hipMemcpyDeviceToHost, st));
+    // (the MLE coefficients as the chain leaves them: the refit has rewritten the rows it refitted, R/core.R:2533-2534)
+    if (a->betaPrior && o->mle_beta)
+        HD_HIP(hipMemcpy2DAsync(o->mle_beta + lo, n * 8, mle, cnt * 8, cnt * 8, p, hipMemcpyDeviceToHost, st));
     if ((rc = stage_d2h(hvec, vec, 1, V_COUNT * cnt * 8, 0, V_COUNT * cnt * 8, 1, st))) return rc;
     if ((rc = stage_d2h(hmat, mat, 1, 4 * pcol * cnt * 8, 0, 4 * pcol * cnt * 8, 1, st))) return rc;
     if ((rc = stage_d2h(hi.data(), ivec, 1, I_COUNT * cnt * 4, 0, I_COUNT * cnt * 4, 1, st))) return rc;
@@ -457,8 +468,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     for (int k = 0; k < 4; k++)
         if (mcol[k] && (k < 2 || a->test == 0))
             for (size_t c = 0; c < pcol; c++) memcpy(mcol[k] + c * n + lo, hmat + ((size_t)k * pcol + c) * cnt, cnt * 8);
-    if (a->betaPrior && o->mle_beta)
-        for (size_t c = 0; c < p; c++) memcpy(o->mle_beta + c * n + lo, X.mle.data() + c * n + lo, cnt * 8);
+
     int32_t *const icol[6] = {o->allZero, o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv, o->replace};
     for (int k = 0; k < 6; k++) memcpy(icol[k] + lo, hi.data() + (size_t)k * cnt, cnt * 4);
     if (o->weightsFail) {
@@ -469,6 +479,8 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     for (size_t i = 0; i < cnt; i++)
         if (!F.do_replace || (o->allZero[lo + i] && o->replace[lo + i] == 0)) o->replace[lo + i] = -1;
 
+    const double t_cols = now_ms();
+    double t_assay[3] = {0, 0, 0};
     // ---- assays on request: gene-major -> R layout on the device -> the caller's n x m matrix
     double *const want[3] = {o->mu, o->H, o->cooks};
     for (int k = 0; k < 3; k++) {
@@ -476,7 +488,12 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         if ((rc = capi_ws_get(HD_OUTR, cnt * m * 8, &v))) return rc;
         HD_HIP(launch_transpose_gm_to_r_f64(mats[k + 1], (double *)v, (int)cnt, (int)m, ld, st));
         if ((rc = stage_d2h(want[k], v, 8, n, lo, cnt, m, st))) return rc;
+        t_assay[k] = now_ms();
     }
+    if (timing_on())
+        fprintf(stderr, "[dsq_deseq range %d] upload+enqueue %.2f ms, chain done + columns down %.2f ms, assays %.2f / %.2f / %.2f ms\n", shard,
+                t_enq - t_begin, t_cols - t_enq, t_assay[0] ? t_assay[0] - t_cols : 0.0, t_assay[1] ? t_assay[1] - t_assay[0] : 0.0,
+                t_assay[2] ? t_assay[2] - t_assay[1] : 0.0);
     if (o->replaceCounts) {
         if ((rc = capi_ws_get(HD_OUTR, cnt * m * 8, &v))) return rc;
         HD_HIP(launch_transpose_gm_to_r_i32(repc, (int32_t *)v, (int)cnt, (int)m, ld, st));

@@ -67,15 +67,17 @@ double orc_exp(double x) {
 #define LG6 1.531383769920937332e-01
 #define LG7 1.479819860511658591e-01
 
+/* (round 4: polynomial and closing sum as fused multiply-adds -- the sequence of csrc/dsq_math.hpp: log_core) */
 static inline double log_core(double f, double dk, double c) {
     double hfsq = 0.5 * f * f;
     double s = f / (2.0 + f);
     double z = s * s;
     double w = z * z;
-    double t1 = w * (LG2 + w * (LG4 + w * LG6));
-    double t2 = z * (LG1 + w * (LG3 + w * (LG5 + w * LG7)));
+    double t1 = w * fma(w, fma(w, LG6, LG4), LG2);
+    double t2 = z * fma(w, fma(w, fma(w, LG7, LG5), LG3), LG1);
     double R = t2 + t1;
-    return s * (hfsq + R) + (dk * ORC_LN2_LO + c) - hfsq + f + dk * ORC_LN2_HI;
+    double u = fma(s, hfsq + R, fma(dk, ORC_LN2_LO, c));
+    return fma(dk, ORC_LN2_HI, (u - hfsq) + f);
 }
 
 double orc_log(double x) {
