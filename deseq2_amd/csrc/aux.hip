@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(256) loglike_kernel(LogLikeKernelParams kp) {
     const int nwork = DSQ_NWORK(kp);
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
         const int g = DSQ_GENE(kp, wi);
+        if (kp.skip && kp.skip[g]) continue;       // (rows another launch is fitting and writing at this moment: pipeline.hip)
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *mug = kp.mu + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;

@@ -107,6 +107,25 @@ void capi_prof_end(hipStream_t st) {
     if (g_prof_list.empty()) return;
     (void)hipEventRecord(g_prof_list.back().e1, st);
 }
+bool capi_prof_on() { return g_prof; }
+
+struct SideStream { hipStream_t s = nullptr; hipEvent_t f = nullptr, j = nullptr; };
+static std::map<std::pair<int, hipStream_t>, SideStream> g_side;      // (device, main stream) -> its side stream; under g_mu / the
+static std::mutex g_side_mu;                                          // worker threads of a sharded host call: own mutex
+int capi_side_stream(hipStream_t main, hipStream_t *side, hipEvent_t *fork_ev, hipEvent_t *join_ev) {
+    int dev = 0;
+    DSQ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream &e = g_side[{dev, main}];
+    if (!e.s) {
+        DSQ_HIP(hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking));
+        DSQ_HIP(hipEventCreateWithFlags(&e.f, hipEventDisableTiming));
+        DSQ_HIP(hipEventCreateWithFlags(&e.j, hipEventDisableTiming));
+    }
+    *side = e.s; *fork_ev = e.f; *join_ev = e.j;
+    return DSQ_OK;
+}
+
 static void prof_begin(hipStream_t st) { capi_prof_begin("call", 0, st); }
 static void prof_end(hipStream_t st) { capi_prof_end(st); }
 

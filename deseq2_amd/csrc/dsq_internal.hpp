@@ -40,6 +40,9 @@ struct DispKernelParams {
     const int32_t *rows;
     const int32_t *n_dev;
     int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
+    // long rows read through L2 (unstaged): the distinct-count buffer of every resident wave (2 m int32 each) in GLOBAL
+    // memory instead of LDS, so that LDS no longer caps the resident waves (set by the launch; nullptr: in LDS)
+    int32_t *dist_global;
 };
 
 struct BetaKernelParams {
@@ -104,6 +107,7 @@ struct LogLikeKernelParams {
     // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
     const int32_t *rows;
     const int32_t *n_dev;
+    const int32_t *skip;     // n flags or NULL: genes with a non-zero flag are left alone (neither read nor written)
 };
 
 struct InterceptKernelParams {
@@ -263,6 +267,10 @@ hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, 
 hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok);
 void capi_prof_begin(const char *name, int n, hipStream_t st);   // no-ops unless dsq_profile_enable(1)
 void capi_prof_end(hipStream_t st);
+bool capi_prof_on();
+// a second stream (with two events) next to `main` on the current device: the chain runs work that nothing downstream
+// waits for beside its serial tail (pipeline.hip); created once per (device, main stream), under the call lock
+int capi_side_stream(hipStream_t main, hipStream_t *side, hipEvent_t *fork_ev, hipEvent_t *join_ev);
 // stage.hip: pageable host memory <-> device through pinned chunks packed by a small thread pool; rows [lo, lo + cnt) of
 // a column-major n_total x cols host matrix <-> a contiguous column-major cnt x cols device matrix.  stage_d2h returns
 // when the host rows are complete.

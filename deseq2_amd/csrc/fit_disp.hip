@@ -895,7 +895,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 
     const double *xs = smem;
     const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
-    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
+    // (unstaged rows with the distinct-count buffer in global memory: no slab but the serial-Gram diagonals)
+    const size_t slab_d = (!STAGE && kp.dist_global) ? (serial_gram ? (size_t)3 * m : 0) : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
@@ -975,7 +976,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             }
             G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
-            dist = reinterpret_cast<int32_t *>(slab);
+            dist = kp.dist_global ? kp.dist_global + (size_t)(blockIdx.x * waves + wave) * 2 * (size_t)m
+                                  : reinterpret_cast<int32_t *>(slab);
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
@@ -1104,6 +1106,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 }
 
 // ---- launch ---------------------------------------------------------------------
+enum { DSQ_WS_DISP_DIST = 36 };       // two grow-only workspace slots (search / second-derivative launch) between the call slots and the chain's
 template <int P, bool USE_W, int MODE>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
@@ -1131,10 +1134,17 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
                                   disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
+    // unstaged rows without weights: the distinct-count buffer (2 m int32 per wave -- 16 KB at m = 2000, what held C4's
+    // fit_disp<10> at two waves per SIMD although it needs 112 registers) moves to global memory: it is written once per
+    // gene and its first nv entries are read once per evaluation, L2-resident either way (DSQ_DISP_GLOBAL_DV=0: in LDS)
+    static const bool global_dv_on = !(getenv("DSQ_DISP_GLOBAL_DV") && atoi(getenv("DSQ_DISP_GLOBAL_DV")) == 0);
+    const bool global_dv = !stage && !USE_W && global_dv_on && kp.m >= 512;
+    const size_t unstaged_lds = global_dv ? ((disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) + disp_arena_doubles(P, kp.ncell)) * sizeof(double)
+                                          : unstaged_wave;
     if (!stage)
-        while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
+        while (waves > 1 && (size_t)waves * unstaged_lds + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds, kp.ncell) * sizeof(double)
-                        : (size_t)waves * unstaged_wave) + cell_bytes;   // unstaged: distinct-count buffer + WIDE arena
+                        : (size_t)waves * unstaged_lds) + cell_bytes;   // unstaged: [distinct-count buffer +] WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
@@ -1156,6 +1166,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (kp.rows_few && grid > cus) grid = cus;        // a row list (stragglers, refits): its length lives on the device
     if (grid < 1) grid = 1;
+    if (global_dv) {
+        void *v = nullptr;
+        if (capi_ws_get(DSQ_WS_DISP_DIST + (MODE == 2 ? 1 : 0), (size_t)grid * waves * 2 * (size_t)kp.m * sizeof(int32_t), &v) != 0) return hipErrorOutOfMemory;
+        kq.dist_global = (int32_t *)v;
+    }
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -502,6 +503,10 @@ struct Pipe {
     // replaced rows runs every step on its DEFAULTS (refitWithoutOutliers passes none of them on, R/core.R:2509-2531)
     double t_tol, t_minmu, ge_floor;
     int t_maxit, t_useQR;
+    // the full-row nbinomLogLike of the test's fit on a SIDE stream (overlap below): set while it is in flight
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool overlap, forked;
     // host-side facts of the design cells
     int any3, maxcell, all_replaceable;
 };
@@ -813,6 +818,15 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
     return DSQ_OK;
 }
 
+// the side stream's work has to be finished before anything that rewrites what it reads or reads what it writes
+static int join_side(Pipe &P) {
+    if (!P.forked) return DSQ_OK;
+    P.forked = false;
+    PIPE_HIP(hipEventRecord(P.ev_join, P.side));
+    PIPE_HIP(hipStreamWaitEvent(P.st, P.ev_join, 0));
+    return DSQ_OK;
+}
+
 // nbinomWaldTest / nbinomLRT(reduced = ~1) on the rows `rw` (R/core.R:1403-1408, 1471, 1507; 1850-1878)
 static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat, int cnt_optim) {
     const DsqDeseqArgs *a = P.a;
@@ -826,14 +840,33 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     lk.n = P.n; lk.m = P.m; lk.ld = P.ld; lk.y = y; lk.mu = mu_out; lk.disp = o->dispersion;
     lk.weights = a->useWeights ? a->weights_norm : nullptr; lk.useWeights = a->useWeights ? 1 : 0;
     lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev;
-    capi_prof_begin(P.tag[0] ? "nbinom_loglike:refit" : "nbinom_loglike", P.n, P.st);
-    PIPE_HIP(launch_loglike(lk, P.st));
-    capi_prof_end(P.st);
     RuleParams b = rule_params(P, rw);
     b.beta = o->beta; b.betaSE = o->betaSE; b.stat = o->stat; b.pvalue = o->pvalue; b.wald = (a->test == 0) ? 1 : 0;
     b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
     b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
+    // OVERLAP (the main chain, when this call also runs the outlier phase): nothing on the way to the refit of the replaced
+    // rows reads the log likelihoods -- beta_post / the optim fallback / Cook's distances / replaceOutliers / the refit's
+    // own dispersion searches -- and that tail is latency, not throughput: a handful of rows, each one gene's serial search
+    // (~0.5 ms of a 12.8 ms step at C3 on an otherwise idle device).  So the full-row nbinomLogLike goes to a side stream
+    // behind beta_post and runs beside it.  It leaves the rows flagged for the optim fallback alone (`skip`): the fallback
+    // writes their logLike (and rewrites their fitted means) itself, R/fitNbinomGLMs.R:386,398-399.  What it may read
+    // half-updated -- the dispersion of a row the refit is re-estimating -- only feeds that row's logLike, which the
+    // refit's own test fit writes after the join (run(): join_side before the refit's test_fit).
+    const bool overlap = P.overlap && !P.tag[0];
+    if (!overlap) {
+        capi_prof_begin(P.tag[0] ? "nbinom_loglike:refit" : "nbinom_loglike", P.n, P.st);
+        PIPE_HIP(launch_loglike(lk, P.st));
+        capi_prof_end(P.st);
+    }
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    if (overlap) {
+        PIPE_HIP(hipEventRecord(P.ev_fork, P.st));
+        PIPE_HIP(hipStreamWaitEvent(P.side, P.ev_fork, 0));
+        lk.skip = o->optim_test;
+        PIPE_HIP(launch_loglike(lk, P.side));
+        lk.skip = nullptr;
+        P.forked = true;
+    }
     // rows for the optim fallback (R/fitNbinomGLMs.R:203-227): coefficients, standard errors, logLike (:398-399) and
     // fitted means (:386) of those rows in place, then betaConv and the Wald columns from them
     rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, o->beta, o->betaSE, o->logLike, mu_out);
@@ -983,7 +1016,15 @@ static Carve carve(int n, int p, int nt) {
     return c;
 }
 
+static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st, Pipe &P);
 static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
+    Pipe P;
+    memset(&P, 0, sizeof P);
+    const int rc = run_chain(a, o, st, P);
+    const int rj = join_side(P);             // (whatever path the chain left by: nothing stays in flight beside `st`)
+    return rc ? rc : rj;
+}
+static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st, Pipe &P) {
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
     if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_REG);
@@ -1016,10 +1057,15 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     int rc = capi_check_device();
     if (rc) return rc;
 
-    Pipe P;
-    memset(&P, 0, sizeof P);
     P.a = a; P.o = o; P.st = st; P.tag = "";
     P.t_tol = a->betaTol; P.t_maxit = a->betaMaxit; P.t_useQR = a->useQR; P.t_minmu = a->minmu; P.ge_floor = a->minmu;
+    {
+        // (see test_fit) only when the test's fit and the outlier phase are enqueued by this one call; the profiling passes
+        // time every launch on one stream; DSQ_OVERLAP=0 switches it off
+        static const bool env_on = !(getenv("DSQ_OVERLAP") && atoi(getenv("DSQ_OVERLAP")) == 0);
+        P.overlap = env_on && !capi_prof_on() && !a->betaPrior && (a->phases & DSQ_PH_MAP_TEST) && (a->phases & DSQ_PH_OUTLIERS);
+        if (P.overlap && capi_side_stream(st, &P.side, &P.ev_fork, &P.ev_join) != DSQ_OK) P.overlap = false;
+    }
     const int n = P.n = a->n, m = P.m = a->m, p = P.p = a->p;
     P.ld = a->ld;
     P.maxDisp = m > 10 ? (double)m : 10.0;
@@ -1213,6 +1259,7 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
             if (rc) return rc;
             rc = map_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID2R);
             if (rc) return rc;
+            if ((rc = join_side(P))) return rc;          // the full-row log likelihoods are down before the refit writes its rows'
             rc = test_fit(P, rf, o->replaceCounts, o->mu_hat, nullptr, CNT_OPT2R);
             if (rc) return rc;
             if (a->betaPrior) {
