@@ -609,5 +609,16 @@ hipError_t launch_loglike(const LogLikeKernelParams &kp, hipStream_t st) {
     else hipLaunchKernelGGL((loglike_kernel<false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
     return hipGetLastError();
 }
+// the same launch BESIDE other work (pipeline.hip: side stream): the grid-stride grid above fills every wave slot of the
+// device for the whole launch, so nothing of another stream would get in before it ends; three quarters of it leaves two
+// blocks per CU to the (small, latency-bound) launches it runs beside
+hipError_t launch_loglike_side(const LogLikeKernelParams &kp, hipStream_t st) {
+    int grid = aux_grid(kp.n);
+    const int cap = device_cu_count() * 6;
+    if (grid > cap) grid = cap;
+    if (kp.useWeights) hipLaunchKernelGGL((loglike_kernel<true>), dim3(grid), dim3(256), 0, st, kp);
+    else hipLaunchKernelGGL((loglike_kernel<false>), dim3(grid), dim3(256), 0, st, kp);
+    return hipGetLastError();
+}
 
 }  // namespace dsq

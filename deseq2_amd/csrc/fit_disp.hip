@@ -37,8 +37,9 @@ namespace dsq {
 #endif
 // ... and from DSQ_DISP_ROWPASS_MIN up the general (non-cell) pass accumulates one matrix row per sweep over the samples
 // (the K p(p+1)/2 running sums of a single sweep no longer fit in registers)
+#include "../../include/dsq_arith_spec.h"
 #ifndef DSQ_DISP_ROWPASS_MIN
-#define DSQ_DISP_ROWPASS_MIN 7
+#define DSQ_DISP_ROWPASS_MIN DSQ_SPEC_SERIAL_GRAM_MINP
 #endif
 typedef double DsqMat1[1][DSQ_P][DSQ_P];
 typedef double DsqMat2[2][DSQ_P][DSQ_P];
@@ -822,13 +823,20 @@ __host__ __device__ inline size_t disp_arena_doubles(int p, int ncell) {
 // 17.6 -> 15.7; but p = 7, m = 500: 5.6 -> 12.9 -- m serial steps on 28 of 64 lanes and 12 KB more LDS per wave lose to
 // seven sweeps: narrow designs take it for short rows only)
 #ifndef DSQ_DISP_SERIAL_MAXM
-#define DSQ_DISP_SERIAL_MAXM 1024
+#define DSQ_DISP_SERIAL_MAXM DSQ_SPEC_SERIAL_GRAM_MAXM
 #endif
 #ifndef DSQ_DISP_SERIAL_MAXM_NARROW
-#define DSQ_DISP_SERIAL_MAXM_NARROW 256
+#define DSQ_DISP_SERIAL_MAXM_NARROW DSQ_SPEC_SERIAL_GRAM_MAXM_NARROW
+#endif
+#ifndef DSQ_TUNING_BUILD
+// these thresholds choose a summation ORDER: the test suite's CPU checker reads the same header (include/dsq_arith_spec.h)
+static_assert(DSQ_DISP_ROWPASS_MIN == DSQ_SPEC_SERIAL_GRAM_MINP && DSQ_DISP_SERIAL_MAXM == DSQ_SPEC_SERIAL_GRAM_MAXM &&
+              DSQ_DISP_SERIAL_MAXM_NARROW == DSQ_SPEC_SERIAL_GRAM_MAXM_NARROW,
+              "a -D override of the serial-Gram thresholds changes the arithmetic spec: edit include/dsq_arith_spec.h (or build with -DDSQ_TUNING_BUILD and expect the parity tests to fail)");
 #endif
 __host__ __device__ inline bool disp_serial_gram(int p, int ncell, int m) {
-    return p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0 && m <= (p >= 10 ? DSQ_DISP_SERIAL_MAXM : DSQ_DISP_SERIAL_MAXM_NARROW);
+    return p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0 &&
+           m <= (p >= DSQ_SPEC_SERIAL_GRAM_WIDE_P ? DSQ_DISP_SERIAL_MAXM : DSQ_DISP_SERIAL_MAXM_NARROW);
 }
 template <bool USE_W>
 __host__ __device__ inline size_t disp_slab_doubles(int m, bool stage, bool serial) {
@@ -896,7 +904,10 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
     const double *xs = smem;
     const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
     // (unstaged rows with the distinct-count buffer in global memory: no slab but the serial-Gram diagonals)
-    const size_t slab_d = (!STAGE && kp.dist_global) ? (serial_gram ? (size_t)3 * m : 0) : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
+    // (... and, experiment DSQ_DISP_MU_LDS, the row of fitted means: kp.xlds == 2 in an unstaged launch)
+    const bool mu_lds = !STAGE && kp.dist_global && kp.xlds == 2;
+    const size_t slab_d = (!STAGE && kp.dist_global) ? ((mu_lds ? (size_t)m : 0) + (serial_gram ? (size_t)3 * m : 0))
+                                                     : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
@@ -978,7 +989,16 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
         } else {
             dist = kp.dist_global ? kp.dist_global + (size_t)(blockIdx.x * waves + wave) * 2 * (size_t)m
                                   : reinterpret_cast<int32_t *>(slab);
-            G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
+            const double *mu_src = mug;
+            if (mu_lds) {
+                // the fitted means of the gene (8 of the 12 bytes a sample costs per evaluation) stay in the wave's LDS slab,
+                // the counts keep coming through L2
+                wave_lds_sync();
+                for (int j = lane; j < m; j += 64) slab[j] = mug[j];
+                wave_lds_sync();
+                mu_src = slab;
+            }
+            G.r.y_ = yg; G.r.mu_ = mu_src; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
         {
@@ -1134,12 +1154,18 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
                                   disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
-    // unstaged rows without weights: the distinct-count buffer (2 m int32 per wave -- 16 KB at m = 2000, what held C4's
-    // fit_disp<10> at two waves per SIMD although it needs 112 registers) moves to global memory: it is written once per
-    // gene and its first nv entries are read once per evaluation, L2-resident either way (DSQ_DISP_GLOBAL_DV=0: in LDS)
-    static const bool global_dv_on = !(getenv("DSQ_DISP_GLOBAL_DV") && atoi(getenv("DSQ_DISP_GLOBAL_DV")) == 0);
+    // unstaged rows without weights: the distinct-count buffer (2 m int32 per wave -- 16 KB at m = 2000, what holds C4's
+    // fit_disp<10> at two waves per SIMD although it needs 112 registers) can move to global memory: it is written once per
+    // gene and its first nv entries are read once per evaluation, L2-resident either way.
+    // Measured at C4 (60 000 x 2000, p = 10; profiles/r04_c4_experiments.md): no gain from the extra resident waves --
+    // the knobs stay for tuning runs, the default is the LDS buffer.  DSQ_DISP_GLOBAL_DV=1: the buffer in global memory;
+    // DSQ_DISP_MU_LDS=1 (implies it): also keep the gene's fitted means in the wave's LDS slab (m doubles).
+    static const bool mu_lds_on = getenv("DSQ_DISP_MU_LDS") && atoi(getenv("DSQ_DISP_MU_LDS")) != 0;
+    static const bool global_dv_on = mu_lds_on || (getenv("DSQ_DISP_GLOBAL_DV") && atoi(getenv("DSQ_DISP_GLOBAL_DV")) != 0);
     const bool global_dv = !stage && !USE_W && global_dv_on && kp.m >= 512;
-    const size_t unstaged_lds = global_dv ? ((disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) + disp_arena_doubles(P, kp.ncell)) * sizeof(double)
+    const bool mu_lds = global_dv && mu_lds_on;
+    const size_t unstaged_lds = global_dv ? ((mu_lds ? (size_t)kp.m : 0) + (disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) +
+                                             disp_arena_doubles(P, kp.ncell)) * sizeof(double)
                                           : unstaged_wave;
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_lds + cell_bytes > budget) waves >>= 1;
@@ -1147,6 +1173,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
                         : (size_t)waves * unstaged_lds) + cell_bytes;   // unstaged: [distinct-count buffer +] WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
+    kq.dist_global = nullptr;      // (set below when the launch takes the global buffer: callers do not know the field)
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
     static thread_local int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
@@ -1170,6 +1197,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
         void *v = nullptr;
         if (capi_ws_get(DSQ_WS_DISP_DIST + (MODE == 2 ? 1 : 0), (size_t)grid * waves * 2 * (size_t)kp.m * sizeof(int32_t), &v) != 0) return hipErrorOutOfMemory;
         kq.dist_global = (int32_t *)v;
+        if (mu_lds) kq.xlds = 2;
     }
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);

@@ -818,6 +818,7 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
     return DSQ_OK;
 }
 
+hipError_t launch_loglike_side(const LogLikeKernelParams &kp, hipStream_t st);       // aux.hip
 // the side stream's work has to be finished before anything that rewrites what it reads or reads what it writes
 static int join_side(Pipe &P) {
     if (!P.forked) return DSQ_OK;
@@ -863,7 +864,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         PIPE_HIP(hipEventRecord(P.ev_fork, P.st));
         PIPE_HIP(hipStreamWaitEvent(P.side, P.ev_fork, 0));
         lk.skip = o->optim_test;
-        PIPE_HIP(launch_loglike(lk, P.side));
+        PIPE_HIP(launch_loglike_side(lk, P.side));
         lk.skip = nullptr;
         P.forked = true;
     }

@@ -40,7 +40,13 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     if kw.get("betaPrior"):
         # nbinomWaldTest(betaPrior = TRUE): the MLE pass, the all-gene prior variance (host), the pass with the ridge
         from . import parallel
-        if test != "Wald" or parallel.world_size() > 1 or _prior_design(dds, kw) is None:
+        if test != "Wald" or _prior_design(dds, kw) is None:
+            return False
+        # gene shards: R/parallel.R:34-40 takes the MLE coefficients for the prior variance from a fit WITHOUT the
+        # observation weights (estimateMLEForBetaPriorVar) -- not the chain's MLE pass: left to DESeqParallel
+        # (... and on that function's defaults: minmu 0.5, betaTol 1e-8, maxit 100, QR)
+        if parallel.world_size() > 1 and (dds.has_weights or kw.get("minmu", 0.5) != 0.5 or kw.get("betaTol", 1e-8) != 1e-8 or
+                                          kw.get("maxit", 100) != 100 or not kw.get("useQR", True)):
             return False
     if kw.get("useT") and test != "Wald":
         return False
@@ -327,18 +333,25 @@ class _Run:
 
 
 _DEVICE_REDUCE_OK = None      # the device all-reduce of N_REFIT: None = not yet checked against the host exchange
+_DEVICE_REDUCE_FOR = None     # ... and the communicator that verdict was reached on
 
 
 def _global_refit_count(run, comm_device, t):
     """refitWithoutOutliers' closing steps ask whether ANY row of the whole object was refitted (R/core.R:2496): the
     shards add up their counts.  With a device communicator (RCCL) the sum is an all-reduce of the one device counter,
-    enqueued behind the chain -- no host look at the device in the middle of the analysis; the FIRST call also runs the
-    host exchange and keeps the device route only if the two agree.  Ranks sharing a device (tests): through the host."""
-    global _DEVICE_REDUCE_OK
+    enqueued behind the chain -- no host look at the device in the middle of the analysis.  The route is decided ONCE per
+    communicator, by collectives every rank executes: the first call runs both exchanges and the ranks agree on whether
+    the device sum matched the host sum.  A collective that fails raises on the rank it fails on (no per-rank change of
+    route: the other ranks would be left waiting in a collective this one never joins).  Ranks sharing a device (tests):
+    through the host."""
+    global _DEVICE_REDUCE_OK, _DEVICE_REDUCE_FOR
     from . import parallel
-    if comm_device is not None and _DEVICE_REDUCE_OK is not False:
+    if comm_device is not None:
         import torch.distributed as dist
-        try:
+        key = (id(dist.distributed_c10d._get_default_group()), str(comm_device))
+        if _DEVICE_REDUCE_FOR != key:
+            _DEVICE_REDUCE_OK, _DEVICE_REDUCE_FOR = None, key
+        if _DEVICE_REDUCE_OK is not False:
             tot = run.status[L.DSQ_ST["N_REFIT"]: L.DSQ_ST["N_REFIT"] + 1].to(t.int64)
             dist.all_reduce(tot)
             dev_total = tot.clamp(max=2 ** 31 - 1).to(t.int32)
@@ -346,12 +359,9 @@ def _global_refit_count(run, comm_device, t):
                 st, _ = run.read_status()
                 host_total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
                 mine = int(dev_total.item()) == min(host_total, 2 ** 31 - 1)
-                # (every rank must take the same route from now on: the verdict is the ranks' common one)
                 _DEVICE_REDUCE_OK = all(parallel.allgather_sizes(int(mine), comm_device))
             if _DEVICE_REDUCE_OK:
                 return dev_total
-        except Exception:                                            # noqa: BLE001  (fall back to the host exchange)
-            _DEVICE_REDUCE_OK = False
     st, _ = run.read_status()
     total = sum(parallel.allgather_sizes(st["N_REFIT"], comm_device))
     return t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=run.E.device)
@@ -390,17 +400,31 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     early = None
     if run.prior is not None:
         # betaPrior: the MLE pass, then ONE extra look at the device -- estimateBetaPriorVar (R/core.R:1601-1689) is an
-        # all-gene weighted quantile of the MLE coefficients, host code on n x p values -- then the pass with the ridge
-        run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
+        # all-gene weighted quantile of the MLE coefficients, host code on n x p values -- then the pass with the ridge.
+        # Gene shards (R/parallel.R:30-48): the shards hand over their MLE coefficients, baseMean and dispFit and every
+        # rank computes the same prior variance over all rows.
+        if world == 1:
+            run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
+        else:
+            run.launch(L.DSQ_PH_GENE_EST)
+            trend = parallel.allgather_device_pairs(run.baseMean, run.dispGeneEst, max(sizes), comm_device, t)
+            run.args.defer_finish = 1
+            run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST, trend=trend)
         st0, sc0 = run.read_status()
-        if st0["N_NONZERO"] == 0:
+        nnz0 = st0["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st0["N_NONZERO"], comm_device))
+        if nnz0 == 0:
             raise ValueError("all genes have zero counts in every sample")
         if st0["N_TREND"] == 0 or st0["TREND_STATUS"] != 0 or st0["N_ABOVE_MIN"] == 0:
+            if world > 1:
+                return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                              minReplicatesForReplace=minReplicatesForReplace, **kw)
             return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
                               minReplicatesForReplace=minReplicatesForReplace, **kw)
         bpv = kw.get("betaPriorVar")
         if bpv is None:
             h = E._host(t.cat([run.mle, run.baseMean[None], run.dispFit[None], run.allZero[None].to(t.float64)])).numpy()
+            if world > 1:
+                h = np.stack([parallel._allgather_vec(np.ascontiguousarray(r), comm_device) for r in h])
             nzr = h[-1] == 0
             view = type("V", (), {"mcols": {"baseMean": h[dds.p][nzr], "dispFit": h[dds.p + 1][nzr]}})()
             def dev_sort(v):           # the (unique) stable order, sorted on the device: the host has nothing else to do

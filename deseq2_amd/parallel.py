@@ -163,12 +163,12 @@ class LocalGroup:
 def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_device=None,
                   minReplicatesForReplace=7, group=None, chunk=0, **kw):
     """`dds` is THIS worker's shard (a rank's, or one chunk of a rank's when `group` is given).
-    R/parallel.R:6-74 (betaPrior = FALSE branch)."""
-    if kw.get("betaPrior"):
-        raise NotImplementedError("DESeqParallel mirrors the betaPrior = FALSE branch of R/parallel.R (the global "
-                                  "beta prior variance of :30-52 is not exchanged)")
-    # round 1: gene-wise estimates on the shard                                 (:18-20)
-    core.estimateDispersionsGeneEst(dds)
+    R/parallel.R:6-74, both branches (betaPrior = TRUE: :30-48)."""
+    betaPrior = bool(kw.get("betaPrior"))
+    if betaPrior and test != "Wald":
+        raise ValueError("betaPrior: the Wald test only")
+    # round 1: gene-wise estimates on the shard                                 (:18-20; minmu is handed on, :19)
+    core.estimateDispersionsGeneEst(dds, minmu=kw.get("minmu", 0.5))
     # global steps on the gathered n-vectors                                    (:27-28)
     if group is not None:
         bm_all = group.allgather(chunk, dds.mcols["baseMean"])
@@ -187,8 +187,21 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
     dds.dispersionFunction = dict(fn)
     # round 2: MAP + test on the shard                                          (:54-66)
     core.estimateDispersionsMAP(dds, dispPriorVar=dispPriorVar)
+    if betaPrior and kw.get("betaPriorVar") is None:
+        # (:34-40) the MLE coefficients of every shard -- estimateMLEForBetaPriorVar (R/core.R:1693-1730): fitNbinomGLMs on
+        # its DEFAULTS and, as written there, without the observation weights -- then the beta prior variance over ALL
+        # rows (estimateBetaPriorVar on the recombined object)
+        gather = (lambda v: group.allgather(chunk, v)) if group is not None else (lambda v: _allgather_vec(v, comm_device))
+        factors = kw.get("factors")
+        mmt = kw.get("modelMatrixType") or ("expanded" if factors is not None else "standard")
+        names = core.standard_model_matrix(factors)[1] if factors is not None else ["Intercept"] + ["V%d" % i for i in range(1, dds.p)]
+        mle = np.asarray(core.fitNbinomGLMs(dds)["betaMatrix"], np.float64)
+        mle_all = np.column_stack([gather(np.ascontiguousarray(mle[:, c])) for c in range(mle.shape[1])])
+        view = type("V", (), {"mcols": {"baseMean": bm_all, "dispFit": gather(dds.mcols["dispFit"])}})()
+        bpv, _ = core.estimateBetaPriorVar(view, mle_all, names, modelMatrixType=mmt, factors=factors)
+        kw = dict(kw, betaPriorVar=bpv)
     if test == "Wald":
-        core.nbinomWaldTest(dds, **kw)
+        core.nbinomWaldTest(dds, **kw)                                          # (:42-46 / :54-60)
     else:
         core.nbinomLRT(dds, reduced, **kw)
     # outlier replacement + refit (R/core.R:419-426 after the parallel branch): per gene, so per shard;

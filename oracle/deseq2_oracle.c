@@ -47,6 +47,7 @@
  *     pivots, as LAPACK dgetf2; QR by unblocked Householder reflections as LAPACK
  *     dgeqr2/dlarfg (what qr_econ reaches for p < 32).
  */
+#include "../include/dsq_arith_spec.h"   /* where a sum's order depends on the shape: one definition with the kernels */
 #include "orc_nmath.h"
 #include <math.h>
 #include <stdlib.h>
@@ -273,7 +274,8 @@ static void cr_gram(const gene_t *g, const double *wd, double *B) {
      * these sums one matrix entry per lane, SERIALLY over the samples (csrc/fit_disp.hip: disp_serial_gram,
      * DispGene::pass) -- the order is part of the arithmetic spec, so the checker takes them serially under the same
      * condition */
-    const int serial_gram = g->serial || (g->p >= 7 && m <= (g->p >= 10 ? 1024 : 256));
+    const int serial_gram = g->serial || (g->p >= DSQ_SPEC_SERIAL_GRAM_MINP &&
+                                          m <= (g->p >= DSQ_SPEC_SERIAL_GRAM_WIDE_P ? DSQ_SPEC_SERIAL_GRAM_MAXM : DSQ_SPEC_SERIAL_GRAM_MAXM_NARROW));
     for (int a = 0; a < q; a++)
         for (int b = a; b < q; b++) {
             const double *xa = g->x + (long)m * g->keepcol[a];

@@ -4,6 +4,7 @@
   * DeviceEngine (HBM-resident, gene-major, torch glue for the O(n m) pre-steps) vs the
     oracle chain: the start values differ in the last bits (torch vs numpy QR), so the bar
     is north_star's: values within 1e-6 relative, flags equal."""
+import os
 import numpy as np
 import pytest
 
@@ -274,3 +275,86 @@ dist.destroy_process_group()
     if "SKIP" in r.stdout:
         pytest.skip("RCCL did not come up on this box: " + r.stdout.strip())
     assert "OK device route" in r.stdout, r.stdout + r.stderr
+
+
+def _fused_rank(rank, world, port, outdir, betaPrior):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deseq2_amd import core, fused, parallel, simulate
+    from deseq2_amd.engine import DeviceEngine
+    torch.cuda.set_device(0)                                       # (the test box has one GPU: the ranks share it)
+    E = DeviceEngine("cuda:0")
+    m = 48
+    x = simulate.design_factor(m, 3)                               # cells of 16: outlier replacement + refit on every shard
+    factors = {"group": (np.arange(m) * 3) // m}
+    d = simulate.make_counts(900, x, seed=41)
+    counts = d["counts"].copy()
+    rng = np.random.default_rng(2)
+    for r in rng.choice(counts.shape[0], 8, replace=False):
+        counts[r, rng.integers(m)] = int(counts[r].max() * 40 + 1000)
+    idx = parallel.shard_ranges(counts.shape[0], world)[rank]
+    dds = core.DESeqDataSet(counts[idx], x, sizeFactors=d["size_factors"], engine=E)
+    kw = dict(betaPrior=True, factors=factors) if betaPrior else {}
+    assert fused.supported(dds, **kw)
+    fused.DESeq(dds, comm_device=None, **kw)
+    assert dds.attrs.get("fused")
+    cols = ["dispGeneEst", "dispersion", "beta", "betaSE", "WaldStatistic", "WaldPvalue", "maxCooks", "replace"] + (["MLE_beta"] if betaPrior else [])
+    np.savez(os.path.join(outdir, "fr%d.npz" % rank), idx=idx, n_refit=dds.attrs["status"]["N_REFIT"],
+             bpv=np.asarray(dds.attrs.get("betaPriorVar", [0.0])), **{k: np.asarray(dds.mcols[k], np.float64) for k in cols})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("betaPrior", [False, True])
+def test_fused_chain_on_two_gene_shards_equals_the_serial_chain(tmp_path, betaPrior):
+    """the MULTI-RANK branch of the fused device chain itself (deseq2_amd/fused.py: the trend exchange, defer_finish, the
+    global count of refitted rows; with betaPrior the MLE exchange of R/parallel.R:34-40) as two processes over gloo --
+    against the one-process chain, every column bit for bit (tests/testthat/test_parallel.R:27-37)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_fused_rank, args=(2, port, str(tmp_path), betaPrior), nprocs=2, join=True)
+    m = 48
+    x = simulate.design_factor(m, 3)
+    factors = {"group": (np.arange(m) * 3) // m}
+    d = simulate.make_counts(900, x, seed=41)
+    counts = d["counts"].copy()
+    rng = np.random.default_rng(2)
+    for r in rng.choice(counts.shape[0], 8, replace=False):
+        counts[r, rng.integers(m)] = int(counts[r].max() * 40 + 1000)
+    serial = core.DESeqDataSet(counts, x, sizeFactors=d["size_factors"], engine=DeviceEngine("cuda:0"))
+    from deseq2_amd import fused
+    fused.DESeq(serial, **(dict(betaPrior=True, factors=factors) if betaPrior else {}))
+    parts = [np.load(os.path.join(str(tmp_path), "fr%d.npz" % r)) for r in range(2)]
+    assert sum(int(p["n_refit"]) for p in parts) == serial.attrs["status"]["N_REFIT"] >= 2
+    for k in parts[0].files:
+        if k in ("idx", "n_refit", "bpv"):
+            continue
+        got = np.concatenate([p[k] for p in parts])
+        assert_same(got, np.asarray(serial.mcols[k], np.float64), "2 shards vs serial: " + k)
+    if betaPrior:
+        assert_same(parts[0]["bpv"], np.asarray(serial.attrs["betaPriorVar"]), "betaPriorVar")
+        assert_same(parts[1]["bpv"], parts[0]["bpv"], "betaPriorVar, rank 1")
+
+
+def test_bench_two_ranks_over_rccl_when_two_devices_are_visible():
+    """one process per GPU over RCCL (what the driver's multi-GPU bench launches): only where the box has >= 2 devices"""
+    import json, os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: the N > 1 path runs with ranks sharing it (tests above)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--genes", "3000", "--no-cpu-baseline", "--no-hostpath", "--no-weak"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DSQ_BENCH_ONE_DEVICE", None)
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "RCCL unavailable" not in r2.stderr, r2.stderr[-2000:]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j2, j1 = json.loads(r2.stdout.strip().splitlines()[-1]), json.loads(r1.stdout.strip().splitlines()[-1])
+    assert j2["n_gpus"] == 2 and j2["result_digest"] == j1["result_digest"]

@@ -167,3 +167,45 @@ def test_cooperative_chunks_with_baton(oracle):
     got = parallel.concat_mcols(out, COLS)
     for kk in COLS:
         np.testing.assert_array_equal(got[kk], serial.mcols[kk], err_msg=kk)
+
+
+def _worker_bp(rank, world, port, n, m, seed, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    from oracle import oracle as O
+    x = simulate.design_factor(m, 3)
+    factors = {"group": (np.arange(m) * 3) // m}
+    d = simulate.make_counts(n, x, seed=seed)
+    idx = parallel.shard_ranges(d["counts"].shape[0], world)[rank]
+    dds = core.DESeqDataSet(d["counts"][idx], x, sizeFactors=d["size_factors"], engine=HostEngine(O))
+    parallel.DESeqParallel(dds, betaPrior=True, factors=factors)
+    np.savez(os.path.join(outdir, "bp%d.npz" % rank), idx=idx, bpv=dds.attrs["betaPriorVar"],
+             **{k: dds.mcols[k] for k in COLS + ["MLE_beta"]})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_shards_equal_serial_with_the_beta_prior(tmp_path, oracle):
+    """R/parallel.R:30-48: MAP + MLE coefficients per shard, estimateBetaPriorVar over all rows, the prior fit per shard"""
+    import torch.multiprocessing as mp
+    n, m, seed, world = 300, 12, 33, 2
+    mp.spawn(_worker_bp, args=(world, _free_port(), n, m, seed, str(tmp_path)), nprocs=world, join=True)
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_factor(m, 3)
+    factors = {"group": (np.arange(m) * 3) // m}
+    d = simulate.make_counts(n, x, seed=seed)
+    serial = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle)),
+                        betaPrior=True, factors=factors)
+    parts = [np.load(os.path.join(str(tmp_path), "bp%d.npz" % r)) for r in range(world)]
+    np.testing.assert_array_equal(parts[0]["bpv"], parts[1]["bpv"])
+    np.testing.assert_array_equal(parts[0]["bpv"], serial.attrs["betaPriorVar"])
+    assert serial.mcols["beta"].shape[1] == 4                     # expanded model matrix: intercept + 3 levels
+    for k in COLS + ["MLE_beta"]:
+        got = np.concatenate([p[k] for p in parts])
+        np.testing.assert_array_equal(got, serial.mcols[k], err_msg=k)
