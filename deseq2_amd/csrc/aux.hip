@@ -493,6 +493,25 @@ hipError_t launch_xim_rows(const double *nf, const int32_t *rows, const int32_t 
     hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);
     return hipGetLastError();
 }
+// ... and over the genes with want_a[g] != 0 and want_b[g] == 0, in GENE order whatever order a row list of them would
+// have (the refitted rows of refitWithoutOutliers: replace & !allZero -- their list is built with atomics, and the order
+// of these sums is part of the result)
+__global__ void __launch_bounds__(256) xim_flagged_kernel(const double *nf, int n, int m, long ld, const int32_t *want_a,
+                                                          const int32_t *want_b, double *colmean_recip) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    int cnt = 0;
+    for (int g = 0; g < n; g++)
+        if (want_a[g] != 0 && want_b[g] == 0) { s += nf[(size_t)g * ld + j]; cnt++; }
+    colmean_recip[j] = 1.0 / (s / (double)cnt);
+}
+hipError_t launch_xim_flagged(const double *nf, int n, int m, long ld, const int32_t *want_a, const int32_t *want_b, double *scratch_m,
+                              double *out, hipStream_t st) {
+    hipLaunchKernelGGL(xim_flagged_kernel, dim3((m + 255) / 256), dim3(256), 0, st, nf, n, m, ld, want_a, want_b, scratch_m);
+    hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);
+    return hipGetLastError();
+}
 hipError_t launch_xim(const double *nf, int n, int m, long ld, double *scratch_m, double *out, hipStream_t st) {
     hipLaunchKernelGGL(xim_kernel, dim3((m + 255) / 256), dim3(256), 0, st, nf, n, m, ld, scratch_m);
     hipLaunchKernelGGL(xim_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch_m, m, out);

@@ -515,8 +515,6 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     if ((rc = capi_check_device())) return rc;
     Facts F;
     design_facts(a, &F);
-    if (a->normalizationFactors && F.do_replace)
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: a normalization-factor matrix together with the outlier refit (R/core.R:2440-2444 re-averages the factors over the refitted rows): pass minReplicatesForReplace = Inf");
     PrefaultScope pf;               // the n x m assays land in fresh pages of the caller: fault them in while the chain runs
     for (double *w : {o->mu, o->H, o->cooks}) stage_prefault(w, (size_t)a->n * a->m * 8);
     stage_prefault(o->replaceCounts, (size_t)a->n * a->m * 4);

@@ -40,9 +40,6 @@ struct DispKernelParams {
     const int32_t *rows;
     const int32_t *n_dev;
     int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
-    // long rows read through L2 (unstaged): the distinct-count buffer of every resident wave (2 m int32 each) in GLOBAL
-    // memory instead of LDS, so that LDS no longer caps the resident waves (set by the launch; nullptr: in LDS)
-    int32_t *dist_global;
 };
 
 struct BetaKernelParams {

@@ -903,11 +903,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 
     const double *xs = smem;
     const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
-    // (unstaged rows with the distinct-count buffer in global memory: no slab but the serial-Gram diagonals)
-    // (... and, experiment DSQ_DISP_MU_LDS, the row of fitted means: kp.xlds == 2 in an unstaged launch)
-    const bool mu_lds = !STAGE && kp.dist_global && kp.xlds == 2;
-    const size_t slab_d = (!STAGE && kp.dist_global) ? ((mu_lds ? (size_t)m : 0) + (serial_gram ? (size_t)3 * m : 0))
-                                                     : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
+    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
@@ -987,18 +983,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             }
             G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
-            dist = kp.dist_global ? kp.dist_global + (size_t)(blockIdx.x * waves + wave) * 2 * (size_t)m
-                                  : reinterpret_cast<int32_t *>(slab);
-            const double *mu_src = mug;
-            if (mu_lds) {
-                // the fitted means of the gene (8 of the 12 bytes a sample costs per evaluation) stay in the wave's LDS slab,
-                // the counts keep coming through L2
-                wave_lds_sync();
-                for (int j = lane; j < m; j += 64) slab[j] = mug[j];
-                wave_lds_sync();
-                mu_src = slab;
-            }
-            G.r.y_ = yg; G.r.mu_ = mu_src; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
+            dist = reinterpret_cast<int32_t *>(slab);
+            G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
         {
@@ -1126,7 +1112,6 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 }
 
 // ---- launch ---------------------------------------------------------------------
-enum { DSQ_WS_DISP_DIST = 36 };       // two grow-only workspace slots (search / second-derivative launch) between the call slots and the chain's
 template <int P, bool USE_W, int MODE>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
@@ -1146,6 +1131,10 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
             int score = wpc * 100 + w * 2 + xl;
             if (score > best) { best = score; best_wpc = wpc; stage = true; waves = w; xlds = xl; }
         }
+    // (round 4, C4 = 60 000 x 2000, p = 10, profiles/r04_c4_experiments.md: moving the distinct-count buffer of the unstaged
+    //  rows to global memory frees 64 KB of LDS per block but not a single wave slot -- the occupancy query still answers two
+    //  blocks per CU, the <10, false, false, 0> kernel is bound by its registers -- 13.1 vs 13.1 ms; keeping the fitted means
+    //  of the gene in LDS on top of that, counts through L2: 12.7 ms.  Neither is in the tree.)
     // long rows: below 6 resident waves per CU the staged kernel loses to L2-resident rows at full occupancy
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
@@ -1154,26 +1143,12 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
                                   disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
-    // unstaged rows without weights: the distinct-count buffer (2 m int32 per wave -- 16 KB at m = 2000, what holds C4's
-    // fit_disp<10> at two waves per SIMD although it needs 112 registers) can move to global memory: it is written once per
-    // gene and its first nv entries are read once per evaluation, L2-resident either way.
-    // Measured at C4 (60 000 x 2000, p = 10; profiles/r04_c4_experiments.md): no gain from the extra resident waves --
-    // the knobs stay for tuning runs, the default is the LDS buffer.  DSQ_DISP_GLOBAL_DV=1: the buffer in global memory;
-    // DSQ_DISP_MU_LDS=1 (implies it): also keep the gene's fitted means in the wave's LDS slab (m doubles).
-    static const bool mu_lds_on = getenv("DSQ_DISP_MU_LDS") && atoi(getenv("DSQ_DISP_MU_LDS")) != 0;
-    static const bool global_dv_on = mu_lds_on || (getenv("DSQ_DISP_GLOBAL_DV") && atoi(getenv("DSQ_DISP_GLOBAL_DV")) != 0);
-    const bool global_dv = !stage && !USE_W && global_dv_on && kp.m >= 512;
-    const bool mu_lds = global_dv && mu_lds_on;
-    const size_t unstaged_lds = global_dv ? ((mu_lds ? (size_t)kp.m : 0) + (disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) +
-                                             disp_arena_doubles(P, kp.ncell)) * sizeof(double)
-                                          : unstaged_wave;
     if (!stage)
-        while (waves > 1 && (size_t)waves * unstaged_lds + cell_bytes > budget) waves >>= 1;
+        while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds, kp.ncell) * sizeof(double)
-                        : (size_t)waves * unstaged_lds) + cell_bytes;   // unstaged: [distinct-count buffer +] WIDE arena
+                        : (size_t)waves * unstaged_wave) + cell_bytes;   // unstaged: distinct-count buffer + WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
-    kq.dist_global = nullptr;      // (set below when the launch takes the global buffer: callers do not know the field)
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
     static thread_local int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
@@ -1193,12 +1168,6 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (kp.rows_few && grid > cus) grid = cus;        // a row list (stragglers, refits): its length lives on the device
     if (grid < 1) grid = 1;
-    if (global_dv) {
-        void *v = nullptr;
-        if (capi_ws_get(DSQ_WS_DISP_DIST + (MODE == 2 ? 1 : 0), (size_t)grid * waves * 2 * (size_t)kp.m * sizeof(int32_t), &v) != 0) return hipErrorOutOfMemory;
-        kq.dist_global = (int32_t *)v;
-        if (mu_lds) kq.xlds = 2;
-    }
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else

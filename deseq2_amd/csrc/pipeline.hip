@@ -484,6 +484,7 @@ struct Pipe {
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
     double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
+    double *xim_cur;               // ... the one the rule kernels read now: over the non-zero rows, or (refit) over the refitted rows
     double *xim_dev;               // normalization-factor matrix: mean(1 / colMeans(nf)) over the non-zero rows (one double
                                    // behind the lambda block of the caller's workspace: it persists between the phases)
     // nbinomLRT against a reduced model that is not ~1 / the beta-prior refit (never both: the prior is Wald only)
@@ -534,7 +535,7 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     const DsqDeseqOut *o = P.o;
     q.rw = rw; q.n = P.n; q.p = P.p;
     q.minDisp = a->minDisp; q.maxDisp = P.maxDisp; q.xim = a->xim; q.outlierSD = a->outlierSD;
-    q.xim_dev = a->nf_is_vector ? nullptr : P.xim_dev;
+    q.xim_dev = a->nf_is_vector ? nullptr : P.xim_cur;
     q.maxit = a->maxit; q.betaMaxit = P.t_maxit;
     q.baseMean = o->baseMean; q.baseVar = o->baseVar; q.roughDisp = P.roughDisp;
     q.alpha_init = P.alpha_init; q.la0 = P.la0;
@@ -819,6 +820,8 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
 }
 
 hipError_t launch_loglike_side(const LogLikeKernelParams &kp, hipStream_t st);       // aux.hip
+hipError_t launch_xim_flagged(const double *nf, int n, int m, long ld, const int32_t *want_a, const int32_t *want_b, double *scratch_m,
+                              double *out, hipStream_t st);
 // the side stream's work has to be finished before anything that rewrites what it reads or reads what it writes
 static int join_side(Pipe &P) {
     if (!P.forked) return DSQ_OK;
@@ -1085,7 +1088,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     P.last_lp = D + cv.o_llp; P.last_dlp = D + cv.o_ldlp; P.la_grid = D + cv.o_lagrid; P.log_dfit = D + cv.o_ldfit;
     P.la_init = D + cv.o_lainit; P.beta_nat = D + cv.o_bnat; P.beta_var = D + cv.o_bvar; P.beta_iter = D + cv.o_biter;
     P.cnum = D + cv.o_cnum; P.cden = D + cv.o_cden; P.dev = D + cv.o_dev;
-    P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax; P.xim_dev = P.lam + 3 * (size_t)pmax;
+    P.lam = D + cv.o_lam; P.contrast = P.lam + pmax; P.lam_prior = P.contrast + pmax; P.xim_dev = P.lam + 3 * (size_t)pmax; P.xim_cur = P.xim_dev;
     P.resbuf = D + cv.o_res; P.trend_mean_c = D + cv.o_tm; P.trend_disp_c = D + cv.o_td; P.robustDisp = D + cv.o_robust;
     P.iter = I + cv.i_iter; P.iter_accept = I + cv.i_itacc; P.grid_flag = I + cv.i_gflag; P.rows_nz = I + cv.i_nz;
     P.rows_grid = I + cv.i_grid; P.rows_rep = I + cv.i_rep; P.rows_refit = I + cv.i_refit; P.counters = o->status;
@@ -1256,6 +1259,15 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
             // assays mu / H keep the original fit as in R (the refit runs on a subset object, :2500-2531)
             P.tag = ":refit";
             P.t_tol = 1e-8; P.t_maxit = 100; P.t_useQR = 1; P.t_minmu = 0.5; P.ge_floor = 0.5;
+            if (!a->nf_is_vector) {
+                // momentsDispEstimate of the refitted subset averages the normalization factors over ITS rows
+                // (R/core.R:2440-2444 on objectSub, :2500-2509): the second scalar behind the lambda block
+                void *b;
+                rc = capi_ws_get(DSQ_WS_PIPE_META + 5, ((size_t)m + 8) * sizeof(double), &b);
+                if (rc) return rc;
+                PIPE_HIP(launch_xim_flagged(a->nf, n, m, P.ld, o->replace, o->allZero, (double *)b, P.xim_dev + 1, st));
+                P.xim_cur = P.xim_dev + 1;
+            }
             rc = gene_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID1R, CNT_OPT1R, o->optim_geneest);
             if (rc) return rc;
             rc = map_est(P, rf, o->replaceCounts, o->mu_hat, CNT_GRID2R);

@@ -30,11 +30,6 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     # NotImplementedError) are left to the call-by-call code, which reports them
     if dds.m - dds.p <= 3 or core._rank(dds.x) < dds.p:
         return False
-    # normalization-factor MATRIX + outlier replacement: momentsDispEstimate of the refitted subset recomputes
-    # mean(1 / colMeans(nf)) over the subset's rows (R/core.R:2440-2444 on objectSub); the chain carries one xim
-    if dds.sizeFactors is None and np.isfinite(kw.get("minReplicatesForReplace", 7)) and \
-            core.nOrMoreInCell(dds.x, kw.get("minReplicatesForReplace", 7)).any():
-        return False
     if kw.get("modelMatrix") is not None or not kw.get("useOptim", True):
         return False
     if kw.get("betaPrior"):

@@ -542,9 +542,9 @@ typedef struct {
     const double *x;               /* m x p model matrix, column-major, full rank                                 */
     const double *sizeFactors;     /* m, or NULL when normalizationFactors is given                               */
     const double *normalizationFactors;  /* n x m column-major (normalizationFactors(object)), or NULL.  With a matrix the
-                                      outlier refit is not available (its momentsDispEstimate re-averages the factors over
-                                      the refitted rows, R/core.R:2440-2444): pass minReplicatesForReplace = Inf or get
-                                      DSQ_ERR_UNSUPPORTED                                                            */
+                                      genes stay in ONE range (momentsDispEstimate averages the factors over all non-zero
+                                      rows -- and, in the outlier refit, over the refitted rows, R/core.R:2440-2444 --
+                                      sums a split could only reproduce in another order)                            */
     const double *weights;         /* n x m column-major (assays(object)[["weights"]]), or NULL                   */
     const double *q, *r;           /* qr.Q(qr(x)) (m x p) and qr.R(qr(x)) (p x p), column-major                   */
     const double *xrinv;           /* x %*% solve(R) (m x p), or NULL: computed here by back substitution         */

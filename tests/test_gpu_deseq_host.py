@@ -56,7 +56,7 @@ def _cases():
     w5 = rng.uniform(0.05, 1.0, c2.shape)
     w5[rng.uniform(size=c2.shape) < 0.03] = 0.0
     w5[17, x2[:, 1] == 1] = 0.0
-    # a normalization-factor matrix (no outlier refit with it: see include/deseq2_mi355x.h)
+    # a normalization-factor matrix
     nf6 = np.exp(rng.normal(0, 0.2, d1["counts"].shape))
     c6 = d1["counts"].copy()
     c6[::41] = 0                 # all-zero rows: momentsDispEstimate averages the factors over the OTHER rows (objectNZ)
@@ -73,6 +73,8 @@ def _cases():
                                                                         "modelMatrixType": "standard"}),
             "two_group_weights": (c2, x2, d2["size_factors"], {"weights": w5}),
             "bc_nf_matrix": (c6, x1, None, {"normalizationFactors": nf6, "minReplicatesForReplace": np.inf}),
+            # ... and with the outlier refit: momentsDispEstimate of the refitted subset re-averages the factors over ITS rows
+            "bc_nf_matrix_outliers": (_spike(c6, 8), x1, None, {"normalizationFactors": nf6}),
             "factor6_lrt_reduced2": (c4, x4, d4["size_factors"], {"test": "LRT", "reduced": red4, "minmu": 1e-6}),
             "two_group_optim_rows": (c2, x2, d2["size_factors"], {}),
             "factor5_lrt": (_spike(d3["counts"], 2, 4), x3, d3["size_factors"], {"test": "LRT"}),
