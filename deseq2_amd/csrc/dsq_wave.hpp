@@ -156,10 +156,13 @@ DSQ_DEV int next_gene(int *counter, int g, int stride, int lane) {
 // wave-uniform predicate -> scalar branch
 DSQ_DEV bool uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
 
-// widest LU<P> whose solve() swaps the right-hand side with select chains (form 1 below; see solve).  Round 2 saw two
-// select forms give wrong results on the device inside the kernels of that time (P = 5, 6 with observation weights;
-// P = 10 in the second-derivative kernel), so only the narrow widths use it.  tools/lu_probe.hip instantiates all three
-// forms at P = 4, 5, 6, 10 in the usage patterns of those kernels and compares them with the host build of this template.
+// widest LU<P> whose solve() swaps the right-hand side with select chains (LU_SELECT below; see solve).  The three forms
+// are equal -- tools/lu_probe.hip: bit for bit against the host build at P = 4, 5, 6, 10, on the device and under the
+// sanitizers.  Round 2 saw the select forms give wrong results inside ONE kernel of that time, fit_disp<6> with weights at
+// the 256-VGPR cap; round 4 reproduced it on that commit and traced it to the toolchain's SGPR spilling into VGPR lanes
+// (the same source is right with -mllvm -amdgpu-spill-sgpr-to-vgpr=false; profiles/r04_lu_solve.md).  So this is a
+// register-pressure choice, not a fence: the select chain where it removes scratch traffic (the narrow widths), the
+// conditional swap where the wave-uniform matrices already fill the register file.
 #ifndef DSQ_LU_SELECT_MAXP
 #define DSQ_LU_SELECT_MAXP 4
 #endif
@@ -220,9 +223,7 @@ DSQ_UNROLL_P
                     // b[k] <-> b[pr] as select chains: written as a conditional swap the compiler turns it into a
                     // dynamically indexed access, which moves b[] (a register array otherwise) into scratch memory
                     // (fit_disp<4>: 48 B/lane of scratch and ~90 scratch accesses per evaluation, 209 -> 177 VGPRs
-                    // without it).  Only for the narrow widths: at P = 10 the select form of the second-derivative
-                    // kernel came out WRONG on the device (last_d2lp off by orders of magnitude, everything else
-                    // unchanged), so the wider builds keep the conditional swap they have always been tested with.
+                    // without it).  Only for the narrow widths (see DSQ_LU_SELECT_MAXP above).
                     const double bk = b[k];
                     double picked = bk;
 DSQ_UNROLL_P

@@ -507,7 +507,8 @@ struct Pipe {
     // the full-row nbinomLogLike of the test's fit on a SIDE stream (overlap below): set while it is in flight
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
-    bool overlap, forked;
+    bool overlap, forked, ll_pending;
+    LogLikeKernelParams ll;        // the deferred full-row launch (test_fit -> run_chain)
     // host-side facts of the design cells
     int any3, maxcell, all_replaceable;
 };
@@ -831,6 +832,21 @@ static int join_side(Pipe &P) {
     return DSQ_OK;
 }
 
+// the deferred full-row nbinomLogLike: on the side stream (forked here) or on the chain's own stream
+static int launch_pending_ll(Pipe &P, bool beside) {
+    if (!P.ll_pending) return DSQ_OK;
+    P.ll_pending = false;
+    if (beside) {
+        PIPE_HIP(hipEventRecord(P.ev_fork, P.st));
+        PIPE_HIP(hipStreamWaitEvent(P.side, P.ev_fork, 0));
+        PIPE_HIP(launch_loglike_side(P.ll, P.side));
+        P.forked = true;
+    } else {
+        PIPE_HIP(launch_loglike(P.ll, P.st));
+    }
+    return DSQ_OK;
+}
+
 // nbinomWaldTest / nbinomLRT(reduced = ~1) on the rows `rw` (R/core.R:1403-1408, 1471, 1507; 1850-1878)
 static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, double *hat, int cnt_optim) {
     const DsqDeseqArgs *a = P.a;
@@ -850,9 +866,10 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
     // OVERLAP (the main chain, when this call also runs the outlier phase): nothing on the way to the refit of the replaced
     // rows reads the log likelihoods -- beta_post / the optim fallback / Cook's distances / replaceOutliers / the refit's
-    // own dispersion searches -- and that tail is latency, not throughput: a handful of rows, each one gene's serial search
-    // (~0.5 ms of a 12.8 ms step at C3 on an otherwise idle device).  So the full-row nbinomLogLike goes to a side stream
-    // behind beta_post and runs beside it.  It leaves the rows flagged for the optim fallback alone (`skip`): the fallback
+    // own dispersion searches -- and the refit is latency, not throughput: a handful of rows, each one gene's serial search
+    // (~0.45 ms of a 12.8 ms step at C3 on an otherwise idle device).  So the full-row nbinomLogLike is DEFERRED: run_chain
+    // launches it on a side stream when the refit starts (beside Cook's distances, another full-size launch, it would only
+    // share the device: measured).  It leaves the rows flagged for the optim fallback alone (`skip`): the fallback
     // writes their logLike (and rewrites their fitted means) itself, R/fitNbinomGLMs.R:386,398-399.  What it may read
     // half-updated -- the dispersion of a row the refit is re-estimating -- only feeds that row's logLike, which the
     // refit's own test fit writes after the join (run(): join_side before the refit's test_fit).
@@ -864,12 +881,10 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     }
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
     if (overlap) {
-        PIPE_HIP(hipEventRecord(P.ev_fork, P.st));
-        PIPE_HIP(hipStreamWaitEvent(P.side, P.ev_fork, 0));
-        lk.skip = o->optim_test;
-        PIPE_HIP(launch_loglike_side(lk, P.side));
-        lk.skip = nullptr;
-        P.forked = true;
+        // (launched by run_chain: beside the refit of the replaced rows when there is one, else right behind this fit)
+        P.ll = lk;
+        P.ll.skip = o->optim_test;
+        P.ll_pending = true;
     }
     // rows for the optim fallback (R/fitNbinomGLMs.R:203-227): coefficients, standard errors, logLike (:398-399) and
     // fitted means (:386) of those rows in place, then betaConv and the Wald columns from them
@@ -1025,8 +1040,9 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
     Pipe P;
     memset(&P, 0, sizeof P);
     const int rc = run_chain(a, o, st, P);
+    const int rl = rc ? DSQ_OK : launch_pending_ll(P, false);      // (no refit in this analysis: behind everything else)
     const int rj = join_side(P);             // (whatever path the chain left by: nothing stays in flight beside `st`)
-    return rc ? rc : rj;
+    return rc ? rc : (rl ? rl : rj);
 }
 static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st, Pipe &P) {
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
@@ -1257,6 +1273,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
             const Rows rf = {P.rows_refit, P.counters + CNT_REFIT, n};
             // the same chain on the replaced rows; their mu-hat and fitted means go to the (now dead) mu_hat matrix,
             // assays mu / H keep the original fit as in R (the refit runs on a subset object, :2500-2531)
+            if ((rc = launch_pending_ll(P, true))) return rc;      // the full-row log likelihoods, beside the refit
             P.tag = ":refit";
             P.t_tol = 1e-8; P.t_maxit = 100; P.t_useQR = 1; P.t_minmu = 0.5; P.ge_floor = 0.5;
             if (!a->nf_is_vector) {
