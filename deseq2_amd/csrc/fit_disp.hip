@@ -134,53 +134,16 @@ DSQ_UNROLL_P
             // CELL MODE: X' diag(wd) X = sum_c S_c x_c x_c', S_c = sum of wd over the kept samples of cell c (lane c keeps
             // S_c; a cell's sums are closed when the sweep leaves it), outer products added serially in cell order.
             // Per sample: K additions instead of K p(p+1)/2 multiply-adds; K C wave reductions instead of K p(p+1)/2.
+            // (round 4 tried DEFERRED closes -- the butterfly steps xor 1, 2, 4 when the sweep leaves a cell, the eight group
+            //  sums parked in one lane per group, the steps xor 8, 16, 32 once per evaluation for all cells together: the same
+            //  bits with ~ 200 of ~ 1 100 VALU instructions per evaluation gone on paper -- and measured it SLOWER: C3 2.95 ->
+            //  3.01 ms, C4 12.8 -> 13.8 ms; nine more spilled VGPRs and the scalar branches around the parked registers cost
+            //  more than the shuffles saved.  Not in the tree; profiles/r04_c4_experiments.md.)
             double Sl[K], acc[K];
             _Pragma("unroll")
             for (int k = 0; k < K; k++) { Sl[k] = 0.0; acc[k] = 0.0; }
             int cur = 0;
-            // DEFERRED CLOSES (round 4).  A cell's K sums are butterflies over the 64 per-lane partials: steps xor 1, 2, 4 stay
-            // inside a group of 8 lanes, steps xor 8, 16, 32 combine the 8 groups.  When the sweep leaves a cell only the first
-            // three steps are taken; the eight group sums are parked in ONE lane per group -- slot (cell % CPR) K + k of the 8
-            // lanes of a group, register cell / CPR -- and the last three steps run once per evaluation on the parked
-            // registers, for all cells at the same time (the partner lanes l ^ 8, 16, 32 hold the same slot).  The same
-            // additions on the same operands in the same order as a butterfly per cell, so the same bits; per evaluation
-            // C (6 + 3 K) + 9 NH instead of ~ 26 C K shuffle / add instructions (C3, K = 2: ~ 110 instead of ~ 310 of the
-            // ~ 1 100 VALU instructions of an evaluation).  For up to CPR NH cells; wider designs close cell by cell as before.
-            constexpr int CPR = 8 / K, NH = (P >= 7) ? 4 : 2;
-            const bool deferred = C <= CPR * NH;
-            double hold[NH];
-            _Pragma("unroll")
-            for (int r = 0; r < NH; r++) hold[r] = 0.0;
-            auto hold_put = [&](int q, bool mine, double v) {
-                _Pragma("unroll")
-                for (int r = 0; r < NH; r++)
-                    if (q == r) hold[r] = mine ? v : hold[r];        // (q is wave-uniform: a scalar branch)
-            };
             auto close_cell = [&]() {
-                if (deferred) {
-                    const int q = cur / CPR, sl = cur % CPR;
-                    if constexpr (K == 2) {
-                        // (the first step hands the odd lanes the second sum and the even lanes the first: wave_allreduce_pair)
-                        const bool odd = (lane & 1) != 0;
-                        const double keep = odd ? acc[1] : acc[0], send = odd ? acc[0] : acc[1];
-                        double v = keep + lane_xor1(send);
-                        v = v + lane_xor2(v);
-                        v = v + lane_xor4(v);
-                        hold_put(q, ((lane & 7) >> 1) == sl, v);
-                    } else {
-                        _Pragma("unroll")
-                        for (int k = 0; k < K; k++) {
-                            double v = acc[k];
-                            v = v + lane_xor1(v);
-                            v = v + lane_xor2(v);
-                            v = v + lane_xor4(v);
-                            hold_put(q, (lane & 7) == sl * K + k, v);
-                        }
-                    }
-                    _Pragma("unroll")
-                    for (int k = 0; k < K; k++) acc[k] = 0.0;
-                    return;
-                }
                 if constexpr (K == 2) {
                     double s0 = acc[0], s1 = acc[1];
                     wave_allreduce_pair(s0, s1, lane);          // same bits as two butterflies, ~half the instructions
@@ -259,27 +222,6 @@ DSQ_UNROLL_P
             }
             if (!useCR) return;
             close_cell();
-            if (deferred) {
-                _Pragma("unroll")
-                for (int r = 0; r < NH; r++)
-                    if (r * CPR < C) {
-                        double v = hold[r], a_, b_;
-                        v = v + lane_xor8(v);
-                        lane_pair16(v, a_, b_); v = a_ + b_;
-                        lane_pair32(v, a_, b_); v = a_ + b_;
-                        hold[r] = v;
-                    }
-            }
-            // S_c[k]: from the lane that keeps it (the parked slot, or lane c of Sl)
-            auto cell_sum = [&](int c, int k) -> double {
-                if (!deferred) return lane_read(Sl[k], c);
-                const int q = c / CPR, sl = (c % CPR) * K + k;
-                double out = 0.0;
-                _Pragma("unroll")
-                for (int r = 0; r < NH; r++)
-                    if (q == r) out = lane_read(hold[r], sl);
-                return out;
-            };
             if constexpr (LANE) {
                 // lane b builds column b: entry (i, b) = sum_c (x_c[i] x_c[b]) S_c, cells in order
                 const int bl = lane < P ? lane : 0;
@@ -290,7 +232,7 @@ DSQ_UNROLL_P
                 for (int c = 0; c < C; c++) {
                     double sc[K];
                     _Pragma("unroll")
-                    for (int k = 0; k < K; k++) sc[k] = cell_sum(c, k);
+                    for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
                     if (xxs) {
                         _Pragma("unroll")
                         for (int i = 0; i < P; i++) {
@@ -324,7 +266,7 @@ DSQ_UNROLL_P
                     const int j0 = sorted ? crep[c] : (cperm[cstart[c]] & 0x3ffffff);
                     double sc[K];
                     _Pragma("unroll")
-                    for (int k = 0; k < K; k++) sc[k] = cell_sum(c, k);
+                    for (int k = 0; k < K; k++) sc[k] = lane_read(Sl[k], c);
 DSQ_UNROLL_P
                     for (int a = 0; a < P; a++) {
                         const double xa = r.x(j0, a);
