@@ -352,7 +352,7 @@ def main():
         # passes of this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed under
         # profiles/ -- counters cannot be read from inside the process.
         traffic, valu, pmc_file = None, None, None
-        for cand in ("r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
+        for cand in ("r04_pmc_%s.json" % args.config, "r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
                      "r01_pmc.json" if args.config == "C3" else None):
             if cand and os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand

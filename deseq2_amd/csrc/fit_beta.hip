@@ -1384,7 +1384,11 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
                 int wpc = w * (int)(cu_lds / need);
                 if (wpc > 8) wpc = 8;
                 int score = wpc * 100 + w * 2 + xl;
-                if (wpc >= 4 && score > qbest) { qbest = score; qw = w; qx = xl; }
+                // (the wide builds: replay costs p^3 per row and IRLS step against p^2 with the rows stored -- at p = 24 even
+                //  two resident waves per CU win by an order of magnitude; DSQ_BETA_QRROWS_MINWPC overrides)
+                static const int min_wpc_env = getenv("DSQ_BETA_QRROWS_MINWPC") ? atoi(getenv("DSQ_BETA_QRROWS_MINWPC")) : 0;
+                const int min_wpc = min_wpc_env > 0 ? min_wpc_env : (P >= 16 ? 1 : 4);
+                if (wpc >= min_wpc && score > qbest) { qbest = score; qw = w; qx = xl; }
             }
         if (qbest >= 0) { qr = true; *stage = true; *waves = qw; *xlds = qx; }
     }
