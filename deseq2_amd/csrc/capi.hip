@@ -272,13 +272,20 @@ struct DispatchP<0> {
     static hipError_t optim(int, const OptimKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
 };
 
+// (wide designs: the caller passes the PADDED width, 16 or 24 -- the chain of pipeline.hip, dsq_optim_rows)
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok) {
+    if (p == DSQ_P_WIDE0) { *ok = true; return launch_fit_beta_p<DSQ_P_WIDE0>(kp, st); }
+    if (p == DSQ_P_WIDE) { *ok = true; return launch_fit_beta_p<DSQ_P_WIDE>(kp, st); }
     return DispatchP<DSQ_P_REG>::beta(p, kp, st, ok);
 }
 void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr) {
+    if (p == DSQ_P_WIDE0) { fit_beta_scratch_doubles<DSQ_P_WIDE0>(n, m, useW, slab, cscr); return; }
+    if (p == DSQ_P_WIDE) { fit_beta_scratch_doubles<DSQ_P_WIDE>(n, m, useW, slab, cscr); return; }
     DispatchP<DSQ_P_REG>::beta_scratch(p, n, m, useW, slab, cscr);
 }
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
+    if (p == DSQ_P_WIDE0) { *ok = true; return launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, grid); }
+    if (p == DSQ_P_WIDE) { *ok = true; return launch_fit_disp_p<DSQ_P_WIDE>(kp, st, grid); }
     return DispatchP<DSQ_P_REG>::disp(p, kp, st, grid, ok);
 }
 hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok) {

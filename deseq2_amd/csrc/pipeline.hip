@@ -469,6 +469,9 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
                              hipGetErrorString(e_));                                                     \
     } while (0)
 
+enum { DSQ_WS_PIPE_PADX = 38 };      // (a free slot between the call slots and the chain's: the padded design)
+static inline int kern_width(int p) { return p > DSQ_P_REG ? (p <= DSQ_P_WIDE0 ? DSQ_P_WIDE0 : DSQ_P_WIDE) : p; }
+
 struct Pipe {
     const DsqDeseqArgs *a;
     const DsqDeseqOut *o;
@@ -484,6 +487,12 @@ struct Pipe {
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
     double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
+    // WIDE designs (10 < p <= 24): the fit kernels run at the padded width pk = 16 / 24 on the design zero-padded to pk
+    // columns (ridge 1, start value 0, contrast 0 on the padding: the real coefficients keep their bits, csrc/capi.hip
+    // "wide designs"); the n x . work matrices have pk columns, the rule kernels and the results keep the true p
+    int pk;
+    const double *x_k;             // the design at the kernels' width (the caller's, or the padded copy)
+    unsigned padmask;
     double *xim_cur;               // ... the one the rule kernels read now: over the non-zero rows, or (refit) over the refitted rows
     double *xim_dev;               // normalization-factor matrix: mean(1 / colMeans(nf)) over the non-zero rows (one double
                                    // behind the lambda block of the caller's workspace: it persists between the phases)
@@ -566,7 +575,7 @@ static DesignSel design_of(const Pipe &P, int which) {
     if (which == DES_REDUCED) d = {a->x_red, P.red_binit, P.lam, a->p_red, P.red_cell_perm, P.red_cell_start, P.red_ncell};
     else if (which == DES_PRIOR) d = {a->x_prior, a->prior_expanded ? P.red_binit : P.beta_init, P.lam_prior, a->p_prior,
                                       P.cell_perm, P.cell_start, P.ncell};
-    else d = {a->x, P.beta_init, P.lam, P.p, P.cell_perm, P.cell_start, P.ncell};
+    else d = {P.x_k, P.beta_init, P.lam, P.pk, P.cell_perm, P.cell_start, P.ncell};
     return d;
 }
 
@@ -606,9 +615,9 @@ static int launch_fit_disp(Pipe &P, const Rows &rw, const int32_t *y, const doub
     const DsqDeseqArgs *a = P.a;
     DispKernelParams kp;
     memset(&kp, 0, sizeof kp);
-    kp.n = P.n; kp.m = P.m; kp.p = P.p; kp.ld = P.ld;
+    kp.n = P.n; kp.m = P.m; kp.p = P.pk; kp.ld = P.ld;
     kp.y = y; kp.mu_hat = mu; kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
-    kp.x = a->x;
+    kp.x = P.x_k; kp.padmask = P.padmask;
     kp.log_alpha_in = la_in; kp.prior_mean = prior_mean;
     kp.prior_sigmasq = 1.0;
     kp.prior_sigmasq_dev = usePrior ? P.o->scalars + DSQ_SC_DISP_PRIOR_VAR : nullptr;
@@ -629,7 +638,7 @@ static int launch_fit_disp(Pipe &P, const Rows &rw, const int32_t *y, const doub
     char nm[32];
     snprintf(nm, sizeof nm, "%s%s", name, P.tag);
     capi_prof_begin(nm, P.n, P.st);
-    PIPE_HIP(dispatch_fit_disp(P.p, kp, P.st, grid, &ok));
+    PIPE_HIP(dispatch_fit_disp(P.pk, kp, P.st, grid, &ok));
     capi_prof_end(P.st);
     if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no register kernel for p=%d", P.p);
     return DSQ_OK;
@@ -654,6 +663,18 @@ static int launch_prefit_rows(Pipe &P, const Rows &rw, const int32_t *y) {
     return DSQ_OK;
 }
 
+// the first p columns of two n x . work matrices -> the caller's n x p matrices, for the listed rows
+__global__ void copy_rows_cols_kernel(Rows rw, int n, int p, const double *src_a, const double *src_b, double *dst_a, double *dst_b) {
+    const int cnt = rows_count(rw);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const int g = rows_gene(rw, i);
+        for (int c = 0; c < p; c++) {
+            dst_a[(size_t)g + (size_t)n * c] = src_a[(size_t)g + (size_t)n * c];
+            dst_b[(size_t)g + (size_t)n * c] = src_b[(size_t)g + (size_t)n * c];
+        }
+    }
+}
+
 // fitNbinomGLMsOptim (R/fitNbinomGLMs.R:340-407) on the rows beta_post_kernel listed (their number lives on the device:
 // usually zero, the launch then finds nothing to do): start values from P.opt_start, coefficients / standard errors /
 // logLike / fitted means written at the rows' own positions
@@ -668,7 +689,11 @@ static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *
     kp.weights = a->useWeights ? weights : nullptr; kp.useWeights = a->useWeights ? 1 : 0;
     kp.x = ds.x; kp.alpha_hat = alpha; kp.lamnat = ds.lam; kp.beta_start = P.opt_start;
     kp.minmu = minmu; kp.mu_floor = mu_floor;
-    kp.beta = beta; kp.betaSE = betaSE; kp.conv = P.opt_conv; kp.mu_out = mu_out; kp.loglike = loglike;
+    // (a padded design: the kernel writes ds.p columns -- into the work matrices; the listed rows' true columns are copied
+    //  to the caller's n x p matrices behind the launch)
+    const bool via_work = ds.p != (which == DES_FULL ? P.p : ds.p) && beta != P.opt_beta;
+    kp.beta = via_work ? P.opt_beta : beta; kp.betaSE = via_work ? P.opt_se : betaSE;
+    kp.conv = P.opt_conv; kp.mu_out = mu_out; kp.loglike = loglike;
     kp.rows = P.rows_opt; kp.n_dev = P.counters + cnt_optim;
     bool ok = false;
     char nm[32];
@@ -677,6 +702,12 @@ static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *
     PIPE_HIP(dispatch_optim_rows(kp.p, kp, P.st, &ok));
     capi_prof_end(P.st);
     if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no optim kernel for p=%d", P.p);
+    if (via_work) {
+        const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
+        hipLaunchKernelGGL(copy_rows_cols_kernel, dim3(16), dim3(256), 0, P.st, orw, P.n, P.p, (const double *)P.opt_beta,
+                           (const double *)P.opt_se, beta, betaSE);
+        PIPE_HIP(hipGetLastError());
+    }
     return DSQ_OK;
 }
 
@@ -1047,7 +1078,9 @@ static int run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) {
 static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st, Pipe &P) {
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
-    if (a->p > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_REG);
+    if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_WIDE);
+    if (a->p > DSQ_P_REG && (a->betaPrior || (a->x_red && a->p_red > DSQ_P_REG)))
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: a design of %d > %d columns with a beta prior or a reduced model of more than %d columns", a->p, DSQ_P_REG, DSQ_P_REG);
     if (a->betaPrior) {
         if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: Wald test only (R/core.R:1787)");
         if (!a->x_prior || a->p_prior < 1 || !o->mle_beta) return capi_fail(DSQ_ERR_ARG, "betaPrior needs x_prior / p_prior / mle_beta");
@@ -1092,7 +1125,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     P.min_log_alpha = a->min_log_alpha;
     // ---- workspace carve (caller-owned: the row lists and counters persist between the phases of an analysis)
     const int nt_cap = a->n_trend > n ? a->n_trend : n;      // (n_trend is the capacity even in the phases without a trend)
-    const int pmax = (a->betaPrior && a->p_prior > p) ? a->p_prior : p;      // columns of the n x . work matrices
+    const int pk = P.pk = kern_width(p);
+    const int pmax = (a->betaPrior && a->p_prior > pk) ? a->p_prior : pk;    // columns of the n x . work matrices
     Carve cv = carve(n, pmax, nt_cap);
     if (!a->workspace || a->workspace_bytes < (int64_t)cv.bytes)
         return capi_fail(DSQ_ERR_ARG, "workspace of %lld bytes, dsq_deseq_workspace_bytes() asks for %zu",
@@ -1114,7 +1148,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     P.red_binit = D + cv.o_rbinit; P.red_beta = D + cv.o_rbeta; P.red_se = D + cv.o_rse;
     {
         size_t slab_d = 0, cscr_d = 0;
-        dispatch_beta_scratch(p, n, m, a->useWeights, &slab_d, &cscr_d);
+        dispatch_beta_scratch(pk, n, m, a->useWeights, &slab_d, &cscr_d);
         if (a->x_red || a->betaPrior) {
             size_t s2 = 0, c2 = 0;
             dispatch_beta_scratch(a->betaPrior ? a->p_prior : a->p_red, n, m, a->useWeights, &s2, &c2);
@@ -1129,13 +1163,27 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     // dynamic-scheduling counters of the fit launches of THIS call; the row-list counters of the phases it runs
     PIPE_HIP(hipMemsetAsync(P.work_counters, 0, 64 * sizeof(int32_t), st));
     {   // the ridge (R/fitNbinomGLMs.R:73,162) and the default contrast (R/wrappers.R:105-108)
-        static thread_local double host[3 * DSQ_P_REG + 8];   // (pageable copies are staged at once)
+        static thread_local double host[3 * DSQ_P_WIDE + 8];   // (pageable copies are staged at once)
         for (int c = 0; c < pmax; c++) {
-            host[c] = c < p ? a->lambda[c] : 0.0;
+            host[c] = c < p ? a->lambda[c] : (c < pk ? 1.0 : 0.0);          // (ridge 1 on the padding of a wide design)
             host[pmax + c] = (c == 0) ? 1.0 : 0.0;
             host[2 * pmax + c] = (a->betaPrior && a->lambda_prior && c < a->p_prior) ? a->lambda_prior[c] : 0.0;
         }
         PIPE_HIP(hipMemcpyAsync(P.lam, host, 3 * (size_t)pmax * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    P.x_k = a->x; P.padmask = 0;
+    if (pk > p) {
+        // the design zero-padded to the kernels' width; the padded columns of the start values (the moments kernel writes
+        // the true p columns) and of the optim start values are zero
+        void *b;
+        rc = capi_ws_get(DSQ_WS_PIPE_PADX, (size_t)m * pk * sizeof(double), &b);
+        if (rc) return rc;
+        PIPE_HIP(hipMemsetAsync(b, 0, (size_t)m * pk * sizeof(double), st));
+        PIPE_HIP(hipMemcpyAsync(b, a->x, (size_t)m * p * sizeof(double), hipMemcpyDeviceToDevice, st));
+        P.x_k = (const double *)b;
+        P.padmask = ((1u << pk) - 1u) & ~((1u << p) - 1u);
+        PIPE_HIP(hipMemsetAsync(P.beta_init + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
+        PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
     }
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
     if (a->cell_of && a->ncell > 0)
@@ -1323,7 +1371,7 @@ int pipeline_run(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st) { 
 extern "C" int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_trend) {
     (void)m;
     if (n < 1 || p < 1) return 0;
-    return (int64_t)dsq::carve(n, p, n_trend > n ? n_trend : n).bytes;
+    return (int64_t)dsq::carve(n, dsq::kern_width(p), n_trend > n ? n_trend : n).bytes;
 }
 
 extern "C" int dsq_deseq_dev(const DsqDeseqArgs *args, const DsqDeseqOut *out, void *stream) {

@@ -66,7 +66,18 @@ def _cases():
     f2 = {"condition": x2[:, 1].astype(int)}
     f3 = {"group": (np.arange(40) * 5) // 40}
     c3s = _spike(d3["counts"], 12, 5)
+    # WIDE designs (10 < p <= 24: the zero-padded kernel builds) inside the chain -- round 4
+    x7 = simulate.design_factor(48, 12)                              # p = 12 on the 16-column build, cells of 4: no replacement
+    d7 = simulate.make_counts(300, x7, seed=31)
+    x8 = simulate.design_factor(136, 17)                             # p = 17 on the 24-column build, cells of 8: refit
+    d8 = simulate.make_counts(260, x8, seed=32)
+    c8 = _spike(d8["counts"], 33, 5)
+    c8[5] = 0
+    c8[5, 60:62] = 3000                                              # a row for the optim fallback
     return {"bc_outliers": (c1, x1, d1["size_factors"], {}),
+            "wide12_wald": (d7["counts"], x7, d7["size_factors"], {}),
+            "wide12_lrt": (d7["counts"], x7, d7["size_factors"], {"test": "LRT"}),
+            "wide17_outliers_optim": (c8, x8, d8["size_factors"], {}),
             "bp_two_group_expanded_weights": (c2, x2, d2["size_factors"], {"weights": w5, "betaPrior": True, "factors": f2}),
             "bp_factor5_expanded_outliers": (c3s, x3, d3["size_factors"], {"betaPrior": True, "factors": f3}),
             "bp_factor5_standard_outliers": (c3s, x3, d3["size_factors"], {"betaPrior": True, "factors": f3,
