@@ -255,7 +255,7 @@ SEXP _DESeq2_mi355x_replace(SEXP ySEXP, SEXP nfSEXP, SEXP cooksSEXP, SEXP cutoff
  * minReplicatesForReplace, qf(.99, p, m - p) (R/core.R:2081),
  * trigamma((m - p) / 2) (:1196), betaTol, maxit, useQR, minmu, the dispersion searches' maxit, useCR, and which n x m
  * assays to bring back (a character-free bit mask: 1 mu, 2 H, 4 cooks, 8 replaceCounts).
- * Returns NULL when the library declines the analysis (DSQ_ERR_UNSUPPORTED: p <= 10 (also of the expanded matrix),
+ * Returns NULL when the library declines the analysis (DSQ_ERR_UNSUPPORTED: p <= 24 -- 10 < p only without beta prior / weights --,
  * m - p > 3; DSQ_ERR_FIT: the parametric trend failed / no usable gene) -- the R caller then runs its unchanged code
  * path over the three classic routines; any other failure is an R error. ---------------------------------------- */
 static SEXP int_col(const int *v, int n, int type, int *np) {      /* -1 -> NA */

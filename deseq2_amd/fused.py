@@ -26,7 +26,9 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     if dds.p > 24 or dds.m <= dds.p:
         return False
     # wide designs (10 < p <= 24, the zero-padded kernel builds): without a beta prior, reduced model of at most 10 columns
-    if dds.p > 10 and (kw.get("betaPrior") or (reduced is not None and np.ndim(reduced) == 2 and np.shape(reduced)[1] > 10)):
+    # (... and without observation weights: the rank tests of getAndCheckWeights run as a register kernel up to 10 columns)
+    if dds.p > 10 and (kw.get("betaPrior") or dds.has_weights or
+                       (reduced is not None and np.ndim(reduced) == 2 and np.shape(reduced)[1] > 10)):
         return False
     # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3
     # branch of estimateDispersionsPriorVar (seeded Monte-Carlo matching, R/core.R:1155-1190: not mirrored, core raises

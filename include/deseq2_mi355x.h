@@ -529,7 +529,8 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
- * Covers what the fused chain covers: parametric trend, Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 10,
+ * Covers what the fused chain covers: parametric trend, Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 24
+ * (10 < p: no beta prior, no observation weights, reduced model of at most 10 columns),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
  * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),
