@@ -3,8 +3,10 @@ chain of core.py on the same engine, random small analyses -- designs (factor, f
 continuous covariate the general kernels), samples per cell, size factors or a normalization-factor matrix, weights,
 spiked outliers, all-zero rows, Wald (useT, betaPrior) / LRT against ~1 or a nested reduced model -- every per-gene
 column, the assays and the trend bit for bit (tests/test_gpu_fused.py's comparison); where the one-call host entry
-covers the analysis (dsq_deseq: no betaPrior, no useT) it is run too, over a random number of in-library gene ranges,
-and compared with the fused chain column by column.
+covers the analysis (dsq_deseq: no useT) it is run too, over a random number of in-library gene ranges, and compared
+with the fused chain column by column.  Round 4: wide factor designs (11 ... 20 levels, the zero-padded kernel builds
+inside the chain), the beta prior THROUGH the host entry (prior variance estimated inside the library), a
+normalization-factor matrix together with the outlier refit, minmu != 0.5 on Wald analyses.
 
     python tests/gpu_fuzz_chain.py [first_seed] [n_seeds]
 """
@@ -29,7 +31,8 @@ def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
         os.environ["DSQ_HOST_SHARDS"] = str(shards)
         res = native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"),
                            normalizationFactors=nfm, weights=weights, minmu=kw.get("minmu", 0.5),
-                           minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=("mu", "cooks"))
+                           minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=("mu", "cooks"),
+                           betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"))
     finally:
         if old is None:
             os.environ.pop("DSQ_HOST_SHARDS", None)
@@ -47,6 +50,8 @@ def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
     else:
         assert_same(f(res["stat"]), f(b.mcols["WaldStatistic"]), tag + " host entry: Wald statistic")
         assert_same(f(res["pvalue"]), f(b.mcols["WaldPvalue"]), tag + " host entry: Wald p-value")
+    if kw.get("betaPrior"):
+        assert_same(res["betaPriorVar"], np.asarray(b.attrs["betaPriorVar"]), tag + " host entry: betaPriorVar")
     nz = ~np.asarray(b.mcols["allZero"], bool) | (np.nan_to_num(f(b.mcols.get("replace", np.zeros(b.n)))) == 1)
     E = b.engine
     for k in ("mu", "cooks"):
@@ -56,8 +61,12 @@ def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
 
 def one(E, seed):
     rng = np.random.default_rng(70000 + seed)
-    kind = int(rng.integers(4))
-    if kind == 0:
+    kind = int(rng.integers(5))
+    if kind == 4:
+        levels = int(rng.integers(11, 21))                       # wide: p = 11 ... 20
+        m = levels * int(rng.integers(2, 9))
+        x = simulate.design_factor(m, levels)
+    elif kind == 0:
         m = int(rng.integers(3, 9)) * 2
         x = simulate.design_two_group(m)
     elif kind == 1:
@@ -80,19 +89,21 @@ def one(E, seed):
     if rng.uniform() < 0.3:
         counts[:: int(rng.integers(17, 60))] = 0
     weights = None
-    if rng.uniform() < 0.3:
+    if rng.uniform() < 0.3 and kind != 4:
         weights = rng.uniform(0.05, 1.0, counts.shape)
         weights[rng.uniform(size=counts.shape) < 0.02] = 0.0
     kw = {}
     p = x.shape[1]
     u = rng.uniform()
     if u < 0.3:
-        q = 1 if (p == 1 or rng.uniform() < 0.5) else int(rng.integers(1, p))
+        q = 1 if (p == 1 or rng.uniform() < 0.5) else int(rng.integers(1, min(p, 11)))
         kw.update(test="LRT", reduced=np.ones((m, 1)) if q == 1 else np.ascontiguousarray(x[:, :q]))
         if q > 1 and rng.uniform() < 0.5:
             kw["minmu"] = 1e-6                                   # R/core.R:1856-1868 (glmGamPoi-style floor)
     elif u < 0.45:
         kw.update(useT=True)
+        if rng.uniform() < 0.3:
+            kw["minmu"] = float(rng.choice([1e-6, 0.1, 2.0]))
     elif u < 0.6 and kind in (0, 2):
         # betaPrior on the expanded model matrix of a one-factor design (R/core.R:1374-1380)
         lev = (x[:, 1:] @ np.arange(1, p)).astype(int) if p > 1 else np.zeros(m, int)
@@ -100,7 +111,8 @@ def one(E, seed):
     nfm = None
     if rng.uniform() < 0.15 and not kw.get("betaPrior"):
         nfm = np.exp(rng.normal(0, 0.2, counts.shape)) * d["size_factors"][None, :]
-        kw["minReplicatesForReplace"] = np.inf                  # (a factor matrix + the outlier refit is left to core)
+        if rng.uniform() < 0.4:
+            kw["minReplicatesForReplace"] = np.inf
     sfv = None if nfm is not None else d["size_factors"]
     tag = "seed %d: kind=%d n=%d m=%d p=%d weights=%d nf=%d %s%s%s" % (
         seed, kind, counts.shape[0], m, p, weights is not None, nfm is not None, kw.get("test", "Wald"),
@@ -119,7 +131,7 @@ def one(E, seed):
     if not b.attrs.get("fused"):           # (a failed parametric trend hands the analysis to core.DESeq)
         return tag + " SKIP not fused"
     _compare(a, b, tag)
-    if not kw.get("betaPrior") and not kw.get("useT"):
+    if not kw.get("useT"):
         _host_entry_check(b, counts, x, sfv, nfm, weights, kw, rng, tag)
         tag += " +host"
     return tag
