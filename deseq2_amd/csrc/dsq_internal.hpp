@@ -40,6 +40,9 @@ struct DispKernelParams {
     const int32_t *rows;
     const int32_t *n_dev;
     int rows_few;            // the list is expected to be short (stragglers, refits): a one-block-per-CU grid is enough
+    // unstaged rows (long rows read through L2), no weights: the distinct-count buffers of the resident waves (2 m int32
+    // each) in GLOBAL memory -- set by the launch (fit_disp.hip); the kernel instantiation decides at compile time
+    int32_t *dist_global;
 };
 
 struct BetaKernelParams {

@@ -896,8 +896,19 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
 // evaluated at the log_alpha the MODE-0 launch stored (same stream).  The second derivative needs
 // three p x p matrices at once; keeping it out of the search kernel saves that kernel's registers, and
 // callers that never read last_d2lp (DESeq() itself does not) skip the launch.
+// Long rows (the unstaged search / grid instantiation without weights) keep their distinct-count buffer in global memory
+// (disp_global_dv below), so LDS no longer caps their resident waves, and get a register budget for three waves per SIMD
+// where the staged instantiations of the same width take two: measured together at C4 (60 000 x 2000, p = 10), fit_disp
+// 12.73 -> 12.27 ms (four waves: 12.20; the buffer in global memory at two waves: 13.1 -- either change alone is a loss or
+// nothing, profiles/r04_c4_experiments.md).  Same arithmetic, same bits.
+#ifndef DSQ_DISP_MINW_LONG
+#define DSQ_DISP_MINW_LONG (DSQ_P <= 10 ? 3 : 1)
+#endif
+template <bool USE_W, bool STAGE, int MODE>
+__host__ __device__ constexpr bool disp_global_dv() { return !STAGE && !USE_W && MODE != 2; }
+
 template <int P, bool USE_W, bool STAGE, int MODE>
-__global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernelParams kp) {
+__global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? DSQ_DISP_MINW_LONG : DSQ_DISP_MINW)) fit_disp_kernel(DispKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -908,7 +919,8 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 
     const double *xs = smem;
     const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
-    const size_t slab_d = disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
+    const size_t slab_d = disp_global_dv<USE_W, STAGE, MODE>() ? (serial_gram ? (size_t)3 * m : 0)
+                                                               : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
     double *arena = smem + xoff + (size_t)waves * slab_d + (size_t)wave * disp_arena_doubles(P, kp.ncell);
@@ -988,7 +1000,9 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
             }
             G.r.y_ = ys; G.r.mu_ = ms; G.r.w_ = USE_W ? ws : nullptr; G.r.x_ = xs; G.r.m = m;
         } else {
-            dist = reinterpret_cast<int32_t *>(slab);
+            if constexpr (disp_global_dv<USE_W, STAGE, MODE>())
+                dist = kp.dist_global + (size_t)(blockIdx.x * waves + wave) * 2 * (size_t)m;      // this wave's slot
+            else dist = reinterpret_cast<int32_t *>(slab);
             G.r.y_ = yg; G.r.mu_ = mug; G.r.w_ = wg; G.r.x_ = kp.x; G.r.m = m;
         }
         G.m = m; G.lane = lane;
@@ -1117,6 +1131,7 @@ __global__ void __launch_bounds__(256, DSQ_DISP_MINW) fit_disp_kernel(DispKernel
 }
 
 // ---- launch ---------------------------------------------------------------------
+enum { DSQ_WS_DISP_DIST = 36 };       // a grow-only workspace slot between the call slots and the chain's
 template <int P, bool USE_W, int MODE>
 static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const Tuning &tu = tuning();
@@ -1136,10 +1151,6 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
             int score = wpc * 100 + w * 2 + xl;
             if (score > best) { best = score; best_wpc = wpc; stage = true; waves = w; xlds = xl; }
         }
-    // (round 4, C4 = 60 000 x 2000, p = 10, profiles/r04_c4_experiments.md: moving the distinct-count buffer of the unstaged
-    //  rows to global memory frees 64 KB of LDS per block but not a single wave slot -- the occupancy query still answers two
-    //  blocks per CU, the <10, false, false, 0> kernel is bound by its registers -- 13.1 vs 13.1 ms; keeping the fitted means
-    //  of the gene in LDS on top of that, counts through L2: 12.7 ms.  Neither is in the tree.)
     // long rows: below 6 resident waves per CU the staged kernel loses to L2-resident rows at full occupancy
     // (measured, p = 4: m = 1250 8.4 vs 7.6 ms, m = 2000 12.1 vs 7.7 ms; m = 800 4.4 vs 4.8 ms)
     if (stage && best_wpc < 6 && tu.disp_stage < 0) { stage = false; waves = wmax; }
@@ -1148,12 +1159,16 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
                                   disp_arena_doubles(P, kp.ncell)) * sizeof(double);
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
+    const bool gdv = !stage && disp_global_dv<USE_W, false, MODE>();
+    const size_t unstaged_lds = gdv ? ((disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) + disp_arena_doubles(P, kp.ncell)) * sizeof(double)
+                                    : unstaged_wave;
     if (!stage)
-        while (waves > 1 && (size_t)waves * unstaged_wave + cell_bytes > budget) waves >>= 1;
+        while (waves > 1 && (size_t)waves * unstaged_lds + cell_bytes > budget) waves >>= 1;
     size_t lds = (stage ? disp_lds_doubles<USE_W>(kp.m, P, waves, xlds, kp.ncell) * sizeof(double)
-                        : (size_t)waves * unstaged_wave) + cell_bytes;   // unstaged: distinct-count buffer + WIDE arena
+                        : (size_t)waves * unstaged_lds) + cell_bytes;   // unstaged: [distinct-count buffer +] WIDE arena
     DispKernelParams kq = kp;
     kq.xlds = xlds;
+    kq.dist_global = nullptr;
     if (kq.work_counter && MODE == 2) kq.work_counter += 1;   // the d2 pass has its own counter
     const void *fn = stage ? (const void *)fit_disp_kernel<P, USE_W, true, MODE> : (const void *)fit_disp_kernel<P, USE_W, false, MODE>;
     static thread_local int bpc_cache[2][8];      // [stage][waves]: the occupancy query costs ~1 ms, ask once
@@ -1173,6 +1188,11 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     int grid = blocks_needed < cus * bpc ? blocks_needed : cus * bpc;
     if (kp.rows_few && grid > cus) grid = cus;        // a row list (stragglers, refits): its length lives on the device
     if (grid < 1) grid = 1;
+    if (gdv) {
+        void *v = nullptr;       // one slot of 2 m int32 per resident wave, grow-only workspace of the (device, stream)
+        if (capi_ws_get(DSQ_WS_DISP_DIST, (size_t)grid * waves * 2 * (size_t)kp.m * sizeof(int32_t), &v) != 0) return hipErrorOutOfMemory;
+        kq.dist_global = (int32_t *)v;
+    }
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else
