@@ -533,6 +533,33 @@ def _mad(v):
     return 1.4826 * np.median(np.abs(v - med))
 
 
+def trimmed_mean_fit(dge, minDisp=1e-8, trim=0.001):
+    """fitType = "mean" (R/core.R:894-899): mean(dispGeneEst[dispGeneEst > 10 minDisp], na.rm = TRUE, trim = 0.001).
+    base::mean.default keeps the order statistics floor(N trim) + 1 ... N - floor(N trim) and takes their long-double
+    mean with a correction pass -- to double precision the correctly rounded mean.  The specification shared with the
+    chain's kernel (csrc/pipeline.hip: trend_mean_kernel): every kept value as the integer floor(x 2^128), the exact
+    integer sum, the quotient rounded once to nearest-even -- Python integers here."""
+    import math
+    with np.errstate(invalid="ignore"):
+        v = np.sort(dge[dge > 10 * minDisp])
+    k = int(np.floor(v.size * trim))
+    kept = v[k: v.size - k]
+    fr, ex = np.frexp(kept)
+    M = np.ldexp(fr, 53).astype(np.int64)
+    S = 0
+    for mnt, sh in zip(M.tolist(), (ex.astype(np.int64) - 53 + 128).tolist()):
+        S += (mnt << sh) if sh >= 0 else (mnt >> -sh)
+    Q, rem = divmod(S, int(kept.size))
+    h = Q.bit_length() - 1
+    if h <= 52:
+        return math.ldexp(float(Q), -128)
+    shift = h - 52
+    mant, rest, half = Q >> shift, Q & ((1 << shift) - 1), 1 << (shift - 1)
+    if rest > half or (rest == half and (rem != 0 or (mant & 1))):
+        mant += 1
+    return math.ldexp(float(mant), shift - 128)
+
+
 def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None):
     """R/core.R:864-939 + `dispersionFunction<-` (R/methods.R:142-190)"""
     E = engine if engine is not None else dds.engine
@@ -547,10 +574,7 @@ def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None)
         except RuntimeError:
             fitType = "mean"       # the reference falls back to locfit (not available here)
     if fitType == "mean":
-        useForMean = dge > 10 * minDisp
-        v = np.sort(dge[useForMean])
-        k = int(np.floor(v.size * 0.001))
-        fn = ("mean", float(v[k: v.size - k].mean()))                                  # mean(trim = 0.001)
+        fn = ("mean", trimmed_mean_fit(dge, minDisp))                                  # mean(trim = 0.001)
     if fn[0] == "parametric":
         dispFit = fn[1][0] + fn[1][1] / bm
     else:

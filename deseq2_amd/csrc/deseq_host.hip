@@ -189,6 +189,7 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (!a->sizeFactors == !a->normalizationFactors) return capi_fail(DSQ_ERR_ARG, "exactly one of sizeFactors / normalizationFactors must be given");
     if (a->y_type != DSQ_Y_INT32 && a->y_type != DSQ_Y_FLOAT64) return capi_fail(DSQ_ERR_ARG, "unknown y_type %d", a->y_type);
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
+    if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
     if (a->x_reduced && (a->test != 1 || !a->q_reduced || !a->r_reduced || a->p_reduced < 1 || a->p_reduced >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with qr.Q / qr.R of its model matrix and 1 <= p_reduced < p");
     if (a->betaPrior) {
@@ -316,7 +317,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     d.betaMaxit = a->maxit;
     d.disp_grid = dd + off_g; d.ngrid = (int32_t)F.grid.size(); d.expVarLogDisp = a->expVarLogDisp;
     d.n_trend = nt; d.lambda = F.lam.data(); d.min_log_alpha = std::log(1e-8 / 10.0);
-    d.workspace = work; d.workspace_bytes = wsb; d.test = a->test;
+    d.workspace = work; d.workspace_bytes = wsb; d.test = a->test; d.fitType = a->fitType;
     d.cell_of = F.cells.data(); d.ncell = F.ncell; d.replaceable = F.replaceable.data();
     d.cooksCutoff = a->cooksCutoff; d.trim = 0.2; d.do_replace = F.do_replace;
     if (pr) {
@@ -545,11 +546,11 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     o->status[DSQ_ST_N_TREND] = X.status[DSQ_ST_N_TREND];
     o->status[DSQ_ST_TREND_STATUS] = X.status[DSQ_ST_TREND_STATUS];
     o->status[DSQ_ST_N_ABOVE_MIN] = X.status[DSQ_ST_N_ABOVE_MIN];
-    for (int k = 0; k < 4; k++) o->dispersionFunction[k] = X.scalars[k];
+    for (int k = 0; k < DSQ_SC_COUNT; k++) o->dispersionFunction[k] = X.scalars[k];
     if (o->status[DSQ_ST_N_NONZERO] == 0) return capi_fail(DSQ_ERR_FIT, "all genes have zero counts in every sample");
     if (o->status[DSQ_ST_N_TREND] == 0)
         return capi_fail(DSQ_ERR_FIT, "all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value");
     if (o->status[DSQ_ST_TREND_STATUS] != 0 || o->status[DSQ_ST_N_ABOVE_MIN] == 0)
-        return capi_fail(DSQ_ERR_FIT, "the parametric dispersion trend did not fit (status %d): use the call-by-call routines with fitType = 'local' / 'mean' (R/core.R:885-893)", o->status[DSQ_ST_TREND_STATUS]);
+        return capi_fail(DSQ_ERR_FIT, "the parametric dispersion trend did not fit (status %d): fitType = DSQ_FIT_PARAMETRIC_OR_MEAN / DSQ_FIT_MEAN, or 'local' through the call-by-call routines (R/core.R:885-893)", o->status[DSQ_ST_TREND_STATUS]);
     return DSQ_OK;
 }

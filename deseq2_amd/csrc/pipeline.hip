@@ -217,6 +217,124 @@ __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, con
     }
 }
 
+// ---- fitType = "mean" (R/core.R:894-899): mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001) ----------------
+// R: the values between the floor(N trim)-th order statistics from either end, then a long-double mean with a
+// correction pass -- to double precision the correctly rounded mean.  Here: the two order statistics by radix selection
+// (exact), the sum of the kept values as a 192-bit integer in units of 2^-128 (exact for every value >= 2^-75, and
+// independent of the order of the additions: a deterministic result without a specified order), the quotient by long
+// division, rounded once to nearest-even.  The mirror (core.py, Python integers) and the oracle restate exactly this.
+struct U192 { uint64_t w[3]; };
+DSQ_DEV void u192_add(U192 &a, const U192 &b) {
+    uint64_t c = 0;
+    for (int k = 0; k < 3; k++) {
+        const uint64_t s = a.w[k] + b.w[k];
+        const uint64_t c1 = s < a.w[k];
+        const uint64_t t = s + c;
+        c = c1 | (uint64_t)(t < s);
+        a.w[k] = t;
+    }
+}
+DSQ_DEV U192 u192_fixed(double x) {           // floor(x 2^128), 0 < x < 2^62 finite
+    const uint64_t u = d2bits(x);
+    int E = (int)((u >> 52) & 0x7ff);
+    uint64_t M = u & ((1ull << 52) - 1ull);
+    if (E) M |= 1ull << 52; else E = 1;
+    const int sh = E - 1075 + 128;
+    U192 r = {{0, 0, 0}};
+    if (sh >= 0) {
+        const int w = sh >> 6, b = sh & 63;
+        if (w < 3) { r.w[w] = M << b; if (b && w + 1 < 3) r.w[w + 1] = M >> (64 - b); }
+    } else if (-sh < 64) r.w[0] = M >> (-sh);
+    return r;
+}
+DSQ_DEV U192 u192_times(double x, unsigned long c) {      // c copies of x (ties at the two cut points)
+    U192 r = {{0, 0, 0}}, v = u192_fixed(x);
+    for (; c; c >>= 1) { if (c & 1ul) u192_add(r, v); U192 d = v; u192_add(v, d); }
+    return r;
+}
+DSQ_DEV double u192_mean(const U192 &S, uint64_t cnt) {   // RN-even(S / cnt) 2^-128 (cnt < 2^32)
+    uint32_t q[6];
+    uint64_t rem = 0;
+    for (int k = 5; k >= 0; k--) {
+        const uint64_t limb = (S.w[k >> 1] >> ((k & 1) * 32)) & 0xffffffffull;
+        const uint64_t cur = (rem << 32) | limb;
+        q[k] = (uint32_t)(cur / cnt);
+        rem = cur % cnt;
+    }
+    int h = -1;
+    for (int k = 5; k >= 0 && h < 0; k--) if (q[k]) h = k * 32 + 31 - __builtin_clz(q[k]);
+    if (h < 0) return 0.0;
+    auto bit_range = [&](int lo, int len) {                // bits [lo, lo + len) of the quotient, len <= 53
+        uint64_t v = 0;
+        for (int b = len - 1; b >= 0; b--) { const int i = lo + b; v = (v << 1) | ((q[i >> 5] >> (i & 31)) & 1u); }
+        return v;
+    };
+    if (h <= 52) return (double)bit_range(0, h + 1) * bits2d((uint64_t)(1023 - 128) << 52);       // (means below 2^-75: truncated)
+    const int shift = h - 52;
+    uint64_t mant = bit_range(shift, 53);
+    const bool half = (q[(shift - 1) >> 5] >> ((shift - 1) & 31)) & 1u;
+    bool below = rem != 0;
+    for (int i = 0; i < shift - 1 && !below; i++) below = (q[i >> 5] >> (i & 31)) & 1u;
+    if (half && (below || (mant & 1ull))) mant++;
+    return (double)mant * bits2d((uint64_t)(1023 + shift - 128) << 52);
+}
+
+// mode DSQ_FIT_MEAN: always; DSQ_FIT_PARAMETRIC_OR_MEAN: only when the parametric trend did not fit.  The trend then is
+// the constant: COEF0 = the mean, COEF1 = 0 (dispFit = COEF0 + COEF1 / baseMean is that constant, exactly).
+__global__ void __launch_bounds__(1024) trend_mean_kernel(const double *disp, int n, double minDisp, int mode, double *scalars,
+                                                          int32_t *status) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long bc[2];
+    __shared__ unsigned long long cnts[5];
+    __shared__ U192 part[1024];
+    if (mode == DSQ_FIT_PARAMETRIC_OR_MEAN && status[DSQ_ST_TREND_STATUS] == 0) return;
+    const double inf = __builtin_inf(), thr = 10.0 * minDisp;
+    auto val = [&](int i) { const double d = disp[i]; return (d > thr) ? d : inf; };       // (NaN: not kept, as na.rm)
+    if (threadIdx.x < 5) cnts[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c += val(i) != inf;
+    atomicAdd(&cnts[0], c);
+    __syncthreads();
+    const long N = (long)cnts[0];
+    if (N == 0) {                                           // (cannot happen behind N_TREND > 0; kept a failure)
+        if (threadIdx.x == 0) status[DSQ_ST_TREND_STATUS] = 3;
+        return;
+    }
+    const long k = (long)__builtin_floor((double)N * 0.001);
+    const double a = block_select(n, k, val, hist, bc);
+    const double b = block_select(n, N - 1 - k, val, hist, bc);
+    U192 acc = {{0, 0, 0}};
+    unsigned long long la = 0, ca = 0, lb = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = val(i);
+        if (v == inf) continue;
+        la += v < a; ca += v == a; lb += v < b;
+        if (v > a && v < b) { const U192 f = u192_fixed(v); u192_add(acc, f); }
+    }
+    atomicAdd(&cnts[1], la); atomicAdd(&cnts[2], ca); atomicAdd(&cnts[3], lb);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) u192_add(part[threadIdx.x], part[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double mean = a;
+        if (a != b) {                                       // sorted positions k .. N-1-k: the copies of a and of b inside
+            U192 S = part[0];
+            const U192 ta = u192_times(a, (unsigned long)(cnts[1] + cnts[2] - (unsigned long long)k));
+            const U192 tb = u192_times(b, (unsigned long)((unsigned long long)(N - k) - cnts[3]));
+            u192_add(S, ta); u192_add(S, tb);
+            mean = u192_mean(S, (uint64_t)(N - 2 * k));
+        }
+        scalars[DSQ_SC_COEF0] = mean;
+        scalars[DSQ_SC_COEF1] = 0.0;
+        status[DSQ_ST_TREND_STATUS] = 0;
+        scalars[DSQ_SC_FIT_USED] = (double)DSQ_FIT_MEAN;
+    }
+}
+
 // ---- per-gene rules ----------------------------------------------------------------------------------------------
 struct RuleParams {
     Rows rw;
@@ -1097,6 +1215,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
+    if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
     if (a->x_red && (a->test != 1 || !a->q_red || !a->a_red || !a->r_red || a->p_red < 1 || a->p_red >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with its QR factors and 1 <= p_red < p");
     if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
@@ -1249,8 +1368,12 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         rc = capi_ws_get(DSQ_WS_PIPE_META, trend_fit_workspace_bytes() + 64, &tws);
         if (rc) return rc;
         capi_prof_begin("trend_fit", nt, st);
-        PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
-                                      o->status + DSQ_ST_TREND_STATUS, tws, st));
+        PIPE_HIP(hipMemsetAsync(o->scalars + DSQ_SC_FIT_USED, 0, sizeof(double), st));               // 0.0 = DSQ_FIT_PARAMETRIC
+        if (a->fitType != DSQ_FIT_MEAN)
+            PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
+                                          o->status + DSQ_ST_TREND_STATUS, tws, st));
+        if (a->fitType != DSQ_FIT_PARAMETRIC)                // R/core.R:894-899 over the same vector, uncompacted
+            hipLaunchKernelGGL(trend_mean_kernel, dim3(1), dim3(1024), 0, st, td, nt, a->minDisp, (int)a->fitType, o->scalars, o->status);
         capi_prof_end(st);
         capi_prof_begin("prior_var", nt, st);
         hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,

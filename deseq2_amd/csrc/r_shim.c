@@ -280,7 +280,10 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
                            * -1 other) and, for the -1 columns of the expanded one, the model-matrix column of the same name
                            * (0-based); the user's betaPriorVar or NULL */
                           SEXP betaPriorSEXP, SEXP xPriorSEXP, SEXP coefFactorSEXP, SEXP priorCoefFactorSEXP,
-                          SEXP priorCoefSrcSEXP, SEXP betaPriorVarSEXP) {
+                          SEXP priorCoefSrcSEXP, SEXP betaPriorVarSEXP,
+                          /* estimateDispersionsFit's fitType as DSQ_FIT_*: 0 "parametric" (a trend that does not fit returns
+                           * NULL and the caller takes the reference's route to locfit, R/core.R:885-893), 1 "mean" */
+                          SEXP fitTypeSEXP) {
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
@@ -352,6 +355,7 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     a.cooksCutoff = scalar_d(cooksCutoffSEXP); a.expVarLogDisp = scalar_d(expVarLogDispSEXP);
     a.betaTol = scalar_d(betaTolSEXP); a.maxit = scalar_i(maxitSEXP); a.useQR = scalar_b(useQRSEXP);
     a.minmu = scalar_d(minmuSEXP); a.disp_maxit = scalar_i(dispMaxitSEXP); a.useCR = scalar_b(useCRSEXP);
+    a.fitType = scalar_i(fitTypeSEXP);
     /* double columns straight into fresh R vectors; integer columns through scratch (NA_integer_ / NA for -1) */
     enum { BM, BV, DGE, DFIT, DMAP, DISP, BITER, LL, LLR, MAXC, NDBL };
     SEXP dv[NDBL];
@@ -385,8 +389,9 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     chk(status);
     for (int k = 0; k < NDBL; k++) nan_to_na(dv[k]);
     nan_to_na(beta); nan_to_na(se); nan_to_na(stat); nan_to_na(pval); nan_to_na(mle);
-    SEXP fn = PROTECT(Rf_allocVector(REALSXP, 4)); np++;
-    for (int k = 0; k < 4; k++) REAL(fn)[k] = o.dispersionFunction[k];
+    /* asymptDisp, extraPois (the mean, 0 when fitType "mean" was used: [4] says which), varLogDispEsts, dispPriorVar */
+    SEXP fn = PROTECT(Rf_allocVector(REALSXP, 5)); np++;
+    for (int k = 0; k < 5; k++) REAL(fn)[k] = o.dispersionFunction[k];                  /* DSQ_SC_COEF0 .. DSQ_SC_FIT_USED */
     SEXP bpv = PROTECT(Rf_allocVector(REALSXP, a.betaPrior ? pcol : 0)); np++;
     for (int k = 0; k < Rf_length(bpv); k++) REAL(bpv)[k] = o.betaPriorVar[k];
     const char *names[] = {"baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP",
@@ -409,7 +414,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
-    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 27},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 28},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

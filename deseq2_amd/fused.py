@@ -7,7 +7,7 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 24 (p > 10: no beta prior, reduced model of at most 10 columns), fitType = "parametric", test = "Wald" (also with betaPrior = TRUE on the standard or
+Supported: DeviceEngine, p <= 24 (p > 10: no beta prior, reduced model of at most 10 columns), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
 the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
@@ -21,7 +21,7 @@ from . import core
 
 def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     E = dds.engine
-    if getattr(E, "name", "") != "device" or fitType != "parametric":
+    if getattr(E, "name", "") != "device" or fitType not in ("parametric", "mean"):
         return False
     if dds.p > 24 or dds.m <= dds.p:
         return False
@@ -391,6 +391,9 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         assert len(sizes) == world and sizes[parallel.rank()] == n, "shard_sizes: one entry per rank, this rank's = n"
         n_all = int(max(sizes)) * world
     run = _Run(dds, test, minReplicatesForReplace, n_all if world > 1 else 0, kw, reduced=reduced)
+    # estimateDispersionsFit (R/core.R:864-939): "mean" on the device; a parametric trend that does not fit is replaced
+    # by the mean there as well (core.estimateDispersionsFit's substitute for the reference's locfit fallback)
+    run.args.fitType = L.DSQ_FIT["mean" if fitType == "mean" else "parametric_or_mean"]
 
     # Everything is enqueued without a host decision: the rows a rule sends on -- fitDispGrid stragglers, rows for the
     # optim fallback (R/fitNbinomGLMs.R:203-227), replaced-outlier rows -- are row-listed launches whose lengths live
@@ -476,8 +479,11 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
                                           minReplicatesForReplace=minReplicatesForReplace, **kw)
         return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
                           minReplicatesForReplace=minReplicatesForReplace, **kw)
-    fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
-          "dispPriorVar": float(sc[3])}
+    if sc[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]:
+        fn = {"fitType": "mean", "coefficients": float(sc[0]), "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
+    else:
+        fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
+              "dispPriorVar": float(sc[3])}
     allZero = hi[0].astype(bool)
     # rows that were all zero from the start carry NA in every column; a row that only BECAME all zero when its outlier
     # was replaced (newAllZero, R/core.R:2492) keeps its "intermediate" columns and gets NA in the "results" columns

@@ -292,13 +292,17 @@ def estimateBetaPriorVarHost(mle_beta, baseMean, dispFit, allZero, coef_factor, 
 def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationFactors=None, weights=None,
           minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
           minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks"),
-          betaPrior=False, factors=None, modelMatrixType=None, betaPriorVar=None, coef_factor=None):
+          betaPrior=False, factors=None, modelMatrixType=None, betaPriorVar=None, coef_factor=None,
+          fitType="parametric"):
     """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
     in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
     design-only quantities the R caller computes with qr() / qf() / trigamma() come from numpy / scipy here.  Returns the
     per-gene columns (NA = NaN; integer columns as float64 with NaN), the requested n x m assays, the dispersion
-    function and the status counters."""
+    function and the status counters.  fitType: "parametric" (a trend that does not fit is an error, DSQ_ERR_FIT: the R
+    caller then takes the reference's route to locfit), "mean", or "parametric_or_mean" (the mean substituted on the device)."""
     from scipy import special as sps
+    if fitType not in L.DSQ_FIT:
+        raise ValueError("fitType should be one of %s" % sorted(L.DSQ_FIT))
     from scipy.stats import f as fdist
     y, ytype = _counts(counts)
     x = _fcol(x)
@@ -367,7 +371,7 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
         expVarLogDisp=evld, betaTol=float(betaTol), minmu=float(minmu), maxit=int(maxit), useQR=int(bool(useQR)),
         disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size),
         betaPrior=int(bool(betaPrior)), x_prior=_ptr(xe), p_prior=int(pcol), coef_factor=_ptr(cf),
-        prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in))
+        prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in), fitType=L.DSQ_FIT[fitType])
     out = L.DsqDeseqHostOut(**{k: _ptr(v) for k, v in d.items()})
     L.check(L.lib().dsq_deseq(C.byref(args), C.byref(out)))
     res = {}
@@ -378,10 +382,12 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
             res[k] = f
         else:
             res[k] = v
-    res["dispersionFunction"] = {"fitType": "parametric", "coefficients": np.array(out.dispersionFunction[0:2]),
+    res["status"] = {k: int(out.status[i]) for k, i in L.DSQ_ST.items()}
+    mean_used = out.dispersionFunction[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]
+    res["dispersionFunction"] = {"fitType": "mean" if mean_used else "parametric",
+                                 "coefficients": float(out.dispersionFunction[0]) if mean_used else np.array(out.dispersionFunction[0:2]),
                                  "varLogDispEsts": float(out.dispersionFunction[2]),
                                  "dispPriorVar": float(out.dispersionFunction[3])}
-    res["status"] = {k: int(out.status[i]) for k, i in L.DSQ_ST.items()}
     if betaPrior:
         res["betaPriorVar"] = np.array(out.betaPriorVar[:pcol])
     res["cooksCutoff"] = cutoff

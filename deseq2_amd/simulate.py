@@ -51,3 +51,16 @@ def make_counts(n, x, seed=1, intercept_mean=4.0, intercept_sd=2.0, size_factors
         keep = counts.sum(axis=1) > 0
         counts, beta, alpha = counts[keep], beta[keep], alpha[keep]
     return {"counts": counts, "size_factors": sf, "beta": beta, "alpha": alpha, "x": x}
+
+
+def make_counts_trend_fails(n, x, seed=1):
+    """counts whose dispersion GROWS with the mean: disp ~ asymptDisp + extraPois / mean cannot capture it and
+    parametricDispersionFit stops with "parametric dispersion fit failed" (R/core.R:2177-2178) -- the case the reference
+    answers with fitType = "local" (:885-893)"""
+    rng = np.random.default_rng(seed)
+    mean = np.exp(rng.uniform(np.log(20), np.log(3000), n))
+    alpha = 0.01 + 0.0004 * mean
+    lfc = np.column_stack([np.zeros(n)] + [rng.normal(0, .5, n) for _ in range(x.shape[1] - 1)])
+    mu = mean[:, None] * 2.0 ** (lfc @ x.T)
+    size = 1 / alpha
+    return rng.negative_binomial(np.broadcast_to(size[:, None], mu.shape), size[:, None] / (size[:, None] + mu)).astype(np.int32)

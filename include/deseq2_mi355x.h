@@ -414,7 +414,7 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
  * L-BFGS-B rows of fitNbinomGLMsOptim) are only FLAGGED (optim_* outputs): the caller re-does them through the
  * per-call entry points.  Phases (bit mask), each asynchronous on `stream`:
  *   DSQ_PH_GENE_EST   counts -> baseMean .. dispGeneEst, mu-hat
- *   DSQ_PH_TREND      parametric trend + prior variance over (trend_mean, trend_disp) [n_trend on the device] or,
+ *   DSQ_PH_TREND      dispersion trend (fitType: parametric / mean) + prior variance over (trend_mean, trend_disp) [n_trend on the device] or,
  *                     when those are NULL, over this call's own genes (multi-GPU: the gathered vectors)
  *   DSQ_PH_MAP_TEST   dispFit, MAP dispersions, final GLM fit [+ the reduced-model fit], Wald statistics / logLik pair
  *   DSQ_PH_OUTLIERS   Cook's distances, replaceOutliers, refit of the replaced rows, maxCooks
@@ -436,8 +436,17 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
 enum { DSQ_ST_N_NONZERO = 0, DSQ_ST_N_GRID_GENEEST, DSQ_ST_N_TREND, DSQ_ST_TREND_STATUS, DSQ_ST_N_ABOVE_MIN,
        DSQ_ST_N_GRID_MAP, DSQ_ST_N_OPTIM_GENEEST, DSQ_ST_N_OPTIM_TEST, DSQ_ST_N_REPLACE, DSQ_ST_N_REFIT,
        DSQ_ST_N_GRID_GENEEST_REFIT, DSQ_ST_N_GRID_MAP_REFIT, DSQ_ST_N_OPTIM_GENEEST_REFIT, DSQ_ST_N_OPTIM_TEST_REFIT,
-       DSQ_ST_COUNT = 16 };
-enum { DSQ_SC_COEF0 = 0, DSQ_SC_COEF1, DSQ_SC_VAR_LOG_DISP, DSQ_SC_DISP_PRIOR_VAR, DSQ_SC_COUNT = 8 };
+       DSQ_ST_COUNT = 16 };        /* (14, 15: counters of the chain's own) */
+/* estimateDispersionsFit's fitType (R/core.R:864-939).  "local" needs locfit (an R package, not in the reference's
+ * tree): a caller that wants the reference's automatic substitution asks for DSQ_FIT_PARAMETRIC, gets DSQ_ERR_FIT when
+ * the trend does not fit and takes its own route; DSQ_FIT_PARAMETRIC_OR_MEAN substitutes the mean on the device.   */
+#define DSQ_FIT_PARAMETRIC          0
+#define DSQ_FIT_MEAN                1    /* mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001), R/core.R:894-899 */
+#define DSQ_FIT_PARAMETRIC_OR_MEAN  2
+enum { DSQ_SC_COEF0 = 0, DSQ_SC_COEF1, DSQ_SC_VAR_LOG_DISP, DSQ_SC_DISP_PRIOR_VAR,
+       DSQ_SC_FIT_USED,            /* the trend the analysis ended up with: DSQ_FIT_PARAMETRIC (0.0) or DSQ_FIT_MEAN (1.0:
+                                      COEF0 is the mean, COEF1 zero)                                               */
+       DSQ_SC_COUNT = 8 };
 
 typedef struct {
     int32_t n, m, p;
@@ -492,6 +501,7 @@ typedef struct {
     const double *x_prior;         /* device, m x p_prior column-major                                           */
     int32_t p_prior, prior_expanded, prior_intercept;   /* expanded: rank-deficient start values; first column all ones */
     const double *lambda_prior;    /* HOST, p_prior: 1 / betaPriorVar / log(2)^2; read by DSQ_PH_PRIOR / _OUTLIERS */
+    int32_t fitType;               /* DSQ_FIT_*: read by DSQ_PH_TREND                                             */
 } DsqDeseqArgs;
 
 typedef struct {
@@ -529,7 +539,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
- * Covers what the fused chain covers: parametric trend, Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 24
+ * Covers what the fused chain covers: parametric trend or fitType "mean", Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 24
  * (10 < p: no beta prior, no observation weights, reduced model of at most 10 columns),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
@@ -576,6 +586,8 @@ typedef struct {
     const int32_t *prior_coef_src;     /* p_prior: for the -1 columns of x_prior the column of x with the same name   */
     const double *betaPriorVar;    /* optional, p_prior values: the caller's prior variance (nbinomWaldTest's argument);
                                       NULL = estimated                                                              */
+    int32_t fitType;               /* DSQ_FIT_PARAMETRIC (0, the default of DESeq()), DSQ_FIT_MEAN, DSQ_FIT_PARAMETRIC_OR_MEAN;
+                                      dispersionFunction[DSQ_SC_FIT_USED] says which trend the results carry          */
 } DsqDeseqHostArgs;
 
 typedef struct {
@@ -595,8 +607,9 @@ typedef struct {
     /* assays, n x m column-major, each optional (NULL = stays on the device)                                      */
     double *mu, *H, *cooks;
     int32_t *replaceCounts;
-    /* dispersionFunction(dds): coefficients asymptDisp / extraPois, varLogDispEsts, dispPriorVar                  */
-    double dispersionFunction[4];
+    /* dispersionFunction(dds), indexed by DSQ_SC_*: coefficients asymptDisp / extraPois (fitType "mean": the mean, 0),
+     * varLogDispEsts, dispPriorVar, the fit type used                                                             */
+    double dispersionFunction[8];
     int32_t status[16];            /* DSQ_ST_*                                                                    */
     /* betaPrior = TRUE: the prior variance used (attr(object, "betaPriorVar")) and, optionally, the n x p MLE
      * coefficients (mcols MLE_*, log2 scale)                                                                      */

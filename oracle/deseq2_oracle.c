@@ -1327,6 +1327,68 @@ int orc_intercept_fit(int n, int m, const double *y, const double *nf, const dou
     return 0;
 }
 
+/* ==================================================== fitType = "mean" ==
+ * R/core.R:894-899: mean(dispGeneEst[dispGeneEst > 10 minDisp], na.rm = TRUE, trim = 0.001).  base::mean.default drops
+ * floor(N trim) order statistics from either end and hands the rest to a long-double mean with a correction pass: to
+ * double precision the correctly rounded mean of the kept values.  The shared specification of kernel, mirror and this
+ * restatement: every kept value as the integer floor(x 2^128) (exact from 2^-75 up), the integers added exactly, the
+ * quotient by the count rounded ONCE to nearest-even -- no order of summation to specify.  Means below 2^-75 (no
+ * dispersion estimate is: minDisp = 1e-8) are the truncated quotient.  Returns the number of kept values (0: none).  */
+static int cmp_double(const void *a, const void *b) {
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+long orc_trimmed_mean_fit(long n, const double *disps, double minDisp, double *mean_out) {
+    double *v = malloc((n > 0 ? n : 1) * sizeof(double));
+    long N = 0;
+    for (long i = 0; i < n; i++) if (disps[i] > 10.0 * minDisp) v[N++] = disps[i];       /* (NaN: dropped, na.rm) */
+    *mean_out = NAN;
+    if (N == 0) { free(v); return 0; }
+    qsort(v, N, sizeof(double), cmp_double);
+    const long k = (long)floor((double)N * 0.001);
+    const long lo = k, hi = N - k;                       /* kept: v[lo .. hi) */
+    const long cnt = hi - lo;
+    /* sum of floor(x 2^128): the low 64 bits and the part above them accumulated apart (no carries to propagate) */
+    unsigned __int128 low = 0, high = 0;
+    for (long i = lo; i < hi; i++) {
+        int e;
+        const double fr = frexp(v[i], &e);               /* x = fr 2^e, fr in [0.5, 1) */
+        const unsigned long long M = (unsigned long long)ldexp(fr, 53);       /* 53-bit integer */
+        const int sh = e - 53 + 128;                     /* floor(x 2^128) = M 2^sh */
+        if (sh >= 64) high += (unsigned __int128)M << (sh - 64);
+        else if (sh >= 0) { high += (unsigned __int128)(sh ? M >> (64 - sh) : 0); low += (unsigned long long)(M << sh); }
+        else if (-sh < 64) low += M >> (-sh);
+    }
+    high += low >> 64;
+    const unsigned long long low64 = (unsigned long long)low;
+    /* (high 2^64 + low64) / cnt by two-limb long division */
+    const unsigned __int128 qh = high / (unsigned long)cnt, r1 = high % (unsigned long)cnt;
+    const unsigned __int128 t = (r1 << 64) | low64;
+    const unsigned long long ql = (unsigned long long)(t / (unsigned long)cnt);
+    const int inexact = (t % (unsigned long)cnt) != 0;
+    /* the quotient's 53 leading bits, round to nearest, ties to even */
+    int h = -1;
+    for (int b = 127; b >= 0 && h < 0; b--) if ((qh >> b) & 1) h = b + 64;
+    for (int b = 63; b >= 0 && h < 0; b--) if ((ql >> b) & 1) h = b;
+    if (h < 0) { *mean_out = 0.0; free(v); return cnt; }
+#define QBIT(i) ((i) >= 64 ? (int)((qh >> ((i) - 64)) & 1) : (int)((ql >> (i)) & 1))
+    double mean;
+    if (h <= 52) mean = ldexp((double)ql, -128);
+    else {
+        const int shift = h - 52;
+        unsigned long long mant = 0;
+        for (int b = 52; b >= 0; b--) mant = (mant << 1) | (unsigned)QBIT(shift + b);
+        int below = inexact;
+        for (int i = 0; i < shift - 1 && !below; i++) below = QBIT(i);
+        if (QBIT(shift - 1) && (below || (mant & 1))) mant++;
+        mean = ldexp((double)mant, shift - 128);
+    }
+#undef QBIT
+    *mean_out = mean;
+    free(v);
+    return cnt;
+}
+
 /* ==================================================== parametricDispersionFit ==
  * R/core.R:2166-2190: disps ~ asymptDisp + extraPois / means by stats::glm(family =
  * Gamma(link = "identity"), start = coefs) inside the outlier-filter loop.  glm.fit's IRLS is

@@ -239,6 +239,17 @@ def parametricDispersionFit(means, disps):
     return coefs
 
 
+def trimmedMeanFit(disps, minDisp=1e-8):
+    """fitType = "mean", R/core.R:894-899: the trimmed mean of the gene-wise estimates above 10 minDisp"""
+    disps = np.ascontiguousarray(disps, dtype=np.float64)
+    out = ctypes.c_double(0.0)
+    lib().orc_trimmed_mean_fit.restype = ctypes.c_long
+    kept = lib().orc_trimmed_mean_fit(ctypes.c_long(disps.size), _p(disps), ctypes.c_double(float(minDisp)), ctypes.byref(out))
+    if kept == 0:
+        raise RuntimeError("no gene-wise dispersion estimate above 10 minDisp")
+    return float(out.value)
+
+
 def cell_index(x):
     """cells of identical model-matrix rows (nOrMoreInCell, R/core.R:2366-2371): cell id per sample"""
     _, inv = np.unique(np.asarray(x, np.float64), axis=0, return_inverse=True)

@@ -6,7 +6,8 @@ column, the assays and the trend bit for bit (tests/test_gpu_fused.py's comparis
 covers the analysis (dsq_deseq: no useT) it is run too, over a random number of in-library gene ranges, and compared
 with the fused chain column by column.  Round 4: wide factor designs (11 ... 20 levels, the zero-padded kernel builds
 inside the chain), the beta prior THROUGH the host entry (prior variance estimated inside the library), a
-normalization-factor matrix together with the outlier refit, minmu != 0.5 on Wald analyses.
+normalization-factor matrix together with the outlier refit, minmu != 0.5 on Wald analyses, fitType = "mean" (and the mean
+substituted on the device where the parametric trend does not fit).
 
     python tests/gpu_fuzz_chain.py [first_seed] [n_seeds]
 """
@@ -32,7 +33,8 @@ def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
         res = native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"),
                            normalizationFactors=nfm, weights=weights, minmu=kw.get("minmu", 0.5),
                            minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=("mu", "cooks"),
-                           betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"))
+                           betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"),
+                           fitType="mean" if kw.get("fitType") == "mean" else "parametric_or_mean")
     finally:
         if old is None:
             os.environ.pop("DSQ_HOST_SHARDS", None)
@@ -108,6 +110,8 @@ def one(E, seed):
         # betaPrior on the expanded model matrix of a one-factor design (R/core.R:1374-1380)
         lev = (x[:, 1:] @ np.arange(1, p)).astype(int) if p > 1 else np.zeros(m, int)
         kw.update(betaPrior=True, factors={"condition": lev})
+    if rng.uniform() < 0.15:
+        kw["fitType"] = "mean"                                   # R/core.R:894-899 on the device
     nfm = None
     if rng.uniform() < 0.15 and not kw.get("betaPrior"):
         nfm = np.exp(rng.normal(0, 0.2, counts.shape)) * d["size_factors"][None, :]
@@ -116,7 +120,8 @@ def one(E, seed):
     sfv = None if nfm is not None else d["size_factors"]
     tag = "seed %d: kind=%d n=%d m=%d p=%d weights=%d nf=%d %s%s%s" % (
         seed, kind, counts.shape[0], m, p, weights is not None, nfm is not None, kw.get("test", "Wald"),
-        " reduced=%d" % kw["reduced"].shape[1] if "reduced" in kw else "", " useT" if kw.get("useT") else " betaPrior" if kw.get("betaPrior") else "")
+        " reduced=%d" % kw["reduced"].shape[1] if "reduced" in kw else "", (" useT" if kw.get("useT") else " betaPrior" if kw.get("betaPrior") else "")
+        + (" fitType=mean" if kw.get("fitType") else ""))
     a = core.DESeqDataSet(counts, x, sizeFactors=sfv, normalizationFactors=nfm, weights=weights, engine=E)
     try:
         core.DESeq(a, **kw)

@@ -74,7 +74,13 @@ def _cases():
     c8 = _spike(d8["counts"], 33, 5)
     c8[5] = 0
     c8[5, 60:62] = 3000                                              # a row for the optim fallback
+    # estimateDispersionsFit: fitType = "mean" asked for, and an analysis whose parametric trend does not fit (the mean
+    # substituted on the device: DSQ_FIT_PARAMETRIC_OR_MEAN, what core.estimateDispersionsFit does in the reference's
+    # locfit branch) -- round 4
+    c9 = simulate.make_counts_trend_fails(420, x2, seed=5)
     return {"bc_outliers": (c1, x1, d1["size_factors"], {}),
+            "bc_outliers_fit_mean": (c1, x1, d1["size_factors"], {"fitType": "mean"}),
+            "two_group_trend_fails": (c9, x2, np.ones(12), {"host_fitType": "parametric_or_mean"}),
             "wide12_wald": (d7["counts"], x7, d7["size_factors"], {}),
             "wide12_lrt": (d7["counts"], x7, d7["size_factors"], {"test": "LRT"}),
             "wide17_outliers_optim": (c8, x8, d8["size_factors"], {}),
@@ -99,7 +105,8 @@ def _host_entry(counts, x, sf, kw, assays=("mu", "H", "cooks")):
     return native.DESeq(counts, x, sf, test=kw.get("test", "Wald"), reduced=kw.get("reduced"), minmu=kw.get("minmu", 0.5),
                         normalizationFactors=kw.get("normalizationFactors"), weights=kw.get("weights"),
                         minReplicatesForReplace=kw.get("minReplicatesForReplace", 7), assays=assays,
-                        betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"), modelMatrixType=kw.get("modelMatrixType"))
+                        betaPrior=kw.get("betaPrior", False), factors=kw.get("factors"), modelMatrixType=kw.get("modelMatrixType"),
+                        fitType=kw.get("host_fitType", kw.get("fitType", "parametric")))
 
 
 def _dataset(counts, x, sf, kw, engine):
@@ -108,7 +115,7 @@ def _dataset(counts, x, sf, kw, engine):
 
 
 def _chain_kw(kw, x):
-    kw = {k: v for k, v in kw.items() if k not in ("weights", "normalizationFactors")}
+    kw = {k: v for k, v in kw.items() if k not in ("weights", "normalizationFactors", "host_fitType")}
     if kw.get("test") == "LRT" and "reduced" not in kw:
         kw["reduced"] = np.ones((x.shape[0], 1))
     return kw
@@ -212,8 +219,10 @@ def test_host_entry_equals_oracle_chain(oracle, name):
     res = _host_entry(counts, x, sf, kw, assays=())
     o = _oracle_chain(oracle, counts, x, sf, kw)
     _against_oracle(_mcols_of(res, test), o, name, test)
-    co, cf = o.dispersionFunction["coefficients"], res["dispersionFunction"]["coefficients"]
-    assert co[0] == cf[0] and co[1] == cf[1]
+    assert o.dispersionFunction["fitType"] == res["dispersionFunction"]["fitType"]
+    assert_same(np.asarray(o.dispersionFunction["coefficients"]), np.asarray(res["dispersionFunction"]["coefficients"]), name + ": trend")
+    if "fit_mean" in name or "trend_fails" in name:
+        assert res["dispersionFunction"]["fitType"] == "mean"
     assert o.dispersionFunction["dispPriorVar"] == res["dispersionFunction"]["dispPriorVar"]
 
 
@@ -228,6 +237,16 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     assert b.attrs.get("fused")
     o = _oracle_chain(oracle, counts, x, sf, kw)
     _against_oracle(b.mcols, o, name, test)
+
+
+def test_a_parametric_trend_that_does_not_fit_is_reported():
+    """fitType = "parametric" (DSQ_FIT_PARAMETRIC): the library does not substitute anything -- DSQ_ERR_FIT, and the R caller
+    takes the reference's own route (locfit, R/core.R:885-893)"""
+    counts, x, sf, _ = CASES["two_group_trend_fails"]
+    with pytest.raises(Exception, match="did not fit"):
+        native.DESeq(counts, x, sf, assays=())
+    with pytest.raises(ValueError, match="fitType"):
+        native.DESeq(counts, x, sf, assays=(), fitType="local")
 
 
 def test_a_gene_range_of_all_zero_rows_is_legal():

@@ -172,6 +172,34 @@ def test_wald_t_distribution_pvalues(E):
     assert not np.allclose(b.mcols["WaldPvalue"], 2 * norm.sf(np.abs(b.mcols["WaldStatistic"])), rtol=1e-3)
 
 
+@pytest.mark.parametrize("case", ["mean_asked_for", "mean_with_ties_and_outliers", "parametric_fails", "parametric_fails_lrt"])
+def test_fit_type_mean_on_the_device(E, case):
+    """estimateDispersionsFit(fitType = "mean") (R/core.R:894-899) inside the chain -- the trimmed mean by selection and an
+    exact integer sum (trend_mean_kernel) against the mirror's Python integers -- and the analysis whose parametric trend
+    does not fit (:885-893): the mean substituted on the device, no bounce to the call-by-call chain."""
+    x = simulate.design_batch_condition(48) if "outliers" in case else simulate.design_two_group(12)
+    kw = {}
+    if case.startswith("mean"):
+        d = simulate.make_counts(900, x, seed=31)
+        counts, sf = d["counts"], d["size_factors"]
+        kw["fitType"] = "mean"
+        if "ties" in case:
+            counts = _spike_outliers(counts, np.random.default_rng(2))
+            counts[100:400] = counts[100]                    # 300 equal rows: equal estimates at the cut points' side
+    else:
+        counts, sf = simulate.make_counts_trend_fails(500, x, seed=5), np.ones(12)
+        if case.endswith("lrt"):
+            kw.update(test="LRT", reduced=np.ones((12, 1)))
+    a, b = _both(E, counts, x, sf, **kw)
+    assert a.dispersionFunction["fitType"] == b.dispersionFunction["fitType"] == "mean"
+    _compare(a, b, case)
+    if "outliers" not in case:         # (the refit re-estimates the replaced rows: their dispGeneEst is no longer the trend's input)
+        dge = np.asarray(b.mcols["dispGeneEst"], float)
+        assert b.dispersionFunction["coefficients"] == core.trimmed_mean_fit(dge[~np.isnan(dge)])
+    fit = np.asarray(b.mcols["dispFit"], float)
+    assert (fit[~np.isnan(fit)] == b.dispersionFunction["coefficients"]).all()
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)

@@ -467,3 +467,38 @@ def test_minmu_is_carried_the_way_the_reference_carries_it(oracle):
     assert refit and all(c[3:6] == (1e-8, 100, 0.5) for c in refit)
     assert all(c[6] in (0.0, 0.5) for c in refit)
     assert min(c[2] for c in fd if c[1] < n - 1) >= 0.5
+
+
+def test_trimmed_mean_fit_is_the_correctly_rounded_mean_of_the_kept_values():
+    """fitType = "mean" (R/core.R:894-899): mean(dispGeneEst[dispGeneEst > 10 minDisp], na.rm = TRUE, trim = 0.001).  The
+    oracle's C restatement, core.py's Python-integer mirror and exact rational arithmetic agree bit for bit (the shared
+    specification has no order of summation); base::mean.default's long-double two-pass mean -- restated with numpy's
+    80-bit long double -- gives the same double up to the last bit."""
+    from fractions import Fraction
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    equal_to_r = 0
+    for trial in range(40):
+        n = int(rng.integers(5, 6000))
+        d = np.exp(rng.normal(-3, 2, n))
+        if trial % 3 == 0:
+            d[rng.integers(0, n, n // 3)] = d[0]               # ties, also across the cut points
+        if trial % 4 == 0:
+            d[rng.integers(0, n, n // 10)] = np.nan            # all-zero rows
+        if trial % 5 == 0:
+            d[rng.integers(0, n, n // 10)] = 1e-8              # at the floor: not used
+        a, b = O.trimmedMeanFit(d), core.trimmed_mean_fit(d)
+        v = np.sort(d[d > 1e-7])
+        k = int(np.floor(v.size * 0.001))
+        kept = v[k: v.size - k]
+        exact = float(sum(Fraction(x) for x in kept.tolist()) / kept.size)
+        assert a == b == exact, (trial, a, b, exact)
+        ld = np.asarray(kept, np.longdouble)                   # mean.default -> .Internal(mean(x)): summary.c real_mean
+        s = ld.sum() / kept.size
+        s = s + (ld - s).sum() / kept.size
+        assert abs(float(s) - a) <= np.spacing(a)
+        equal_to_r += float(s) == a
+    assert equal_to_r >= 38
+    # all kept values equal; a single value
+    assert O.trimmedMeanFit(np.full(3000, 0.25)) == core.trimmed_mean_fit(np.full(3000, 0.25)) == 0.25
+    assert O.trimmedMeanFit(np.array([0.3, np.nan, 1e-9])) == core.trimmed_mean_fit(np.array([0.3, np.nan, 1e-9])) == 0.3
