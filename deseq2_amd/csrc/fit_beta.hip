@@ -72,8 +72,9 @@ __host__ __device__ inline size_t beta_arena_doubles(int p) { return p >= DSQ_BE
 template <int P, bool WITH_RHS, class FW>
 DSQ_DEV void beta_gram_wide(const double *xs, int m, int lane, FW &&wz, double (&G)[P][P], double *rhs) {
     constexpr int RB = 2;
-    _Pragma("unroll")
-    for (int a0 = 0; a0 < P; a0 += RB) {
+    static_assert(P % RB == 0, "the wide builds have an even number of columns");
+    static_for<P / RB>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a0 = decltype(ac)::value * RB;
         double acc[RB][P], racc[RB];
         _Pragma("unroll")
         for (int i = 0; i < RB; i++) {
@@ -94,17 +95,33 @@ DSQ_DEV void beta_gram_wide(const double *xs, int m, int lane, FW &&wz, double (
                 if constexpr (WITH_RHS) racc[i] += xr[a0 + i] * zw;
             }
         }
-        _Pragma("unroll")
-        for (int i = 0; i < RB; i++) {
+        // the sums of this pass reduced together (wave_allreduce_many: the bits of one wave_allreduce each)
+        constexpr int NR = RB * (P - a0) - RB * (RB - 1) / 2 + (WITH_RHS ? RB : 0);
+        double red[NR];
+        {
+            int q = 0;
             _Pragma("unroll")
-            for (int b = a0 + i; b < P; b++) {
-                double v = wave_allreduce(acc[i][b]);
-                G[a0 + i][b] = v;
-                G[b][a0 + i] = v;
+            for (int i = 0; i < RB; i++) {
+                _Pragma("unroll")
+                for (int b = a0 + i; b < P; b++) red[q++] = acc[i][b];
+                if constexpr (WITH_RHS) red[q++] = racc[i];
             }
-            if constexpr (WITH_RHS) rhs[a0 + i] = wave_allreduce(racc[i]);
         }
-    }
+        wave_allreduce_many(red, lane);
+        {
+            int q = 0;
+            _Pragma("unroll")
+            for (int i = 0; i < RB; i++) {
+                _Pragma("unroll")
+                for (int b = a0 + i; b < P; b++) {
+                    const double v = red[q++];
+                    G[a0 + i][b] = v;
+                    G[b][a0 + i] = v;
+                }
+                if constexpr (WITH_RHS) rhs[a0 + i] = red[q++];
+            }
+        }
+    });
 }
 
 // per-sample state a wave keeps across passes: sqrt(w); mu and sqrt(w)*z sharing one slot (mu is
@@ -161,11 +178,31 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
 #ifndef DSQ_BETA_QRROWS_MIN
 #define DSQ_BETA_QRROWS_MIN DSQ_BETA_WIDE_MIN
 #endif
-__host__ __device__ static inline size_t beta_qr_doubles(int m, int p) { return (size_t)(m + p) * (p + 1) + (size_t)p * p + p; }
+// QRM = 2 (round 4; m + p <= 64 DSQ_BETA_QRREG_TRIPS, from DSQ_BETA_QRREG_MIN columns): the same rows in REGISTERS -- row
+// i of the least squares is trip i / 64 of lane i % 64, (p + 1) doubles each -- so a Householder stage is register
+// arithmetic plus its round of wave reductions, no LDS traffic, and the wave's LDS shrinks to the slabs plus R and gamma
+// (p = 10, m = 200: 29 KB -> 11 KB; five resident waves per CU -> eight, the register budget of two per SIMD).  The
+// per-lane sums run over the trips in the order of the lane-strided loop: the same operations on the same values.
+#ifndef DSQ_BETA_QRREG_MIN
+#define DSQ_BETA_QRREG_MIN 7
+#endif
+#ifndef DSQ_BETA_QRREG_TRIPS
+#define DSQ_BETA_QRREG_TRIPS (DSQ_P <= 12 ? 4 : 5)     /* two waves per SIMD: 4 (p + 1) doubles of rows; one: 5 (p + 1) */
+#endif
+#ifndef DSQ_BETA_QRREG_MINW
+/* (p = 7, 8, 9 -- the builds whose p x p work sits in registers -- at one wave per SIMD: 1.98 / 2.20 / 3.43 ms against
+   2.51 / 2.24 / 3.56 at two, 20 000 x 200, tools/r04u.sh) */
+#define DSQ_BETA_QRREG_MINW (DSQ_P <= 9 ? 1 : DSQ_P <= 12 ? 2 : 1)
+#endif
+// per wave: QRM 1 the (m + p) x (p + 1) rows, R, gamma; QRM 2 R and gamma only
+__host__ __device__ static inline size_t beta_qr_doubles(int m, int p, int qrm = 1) {
+    return (qrm == 1 ? (size_t)(m + p) * (p + 1) : 0) + (size_t)p * p + p;
+}
 
-template <int P, bool USE_W, bool STAGE, bool QRROWS>
-__global__ void __launch_bounds__(256, (QRROWS ? 2 : DSQ_BETA_MINW)) fit_beta_kernel(BetaKernelParams kp) {
-    static_assert(!QRROWS || STAGE, "stored rows need the staged layout");
+template <int P, bool USE_W, bool STAGE, int QRM>
+__global__ void __launch_bounds__(256, (QRM == 1 ? 2 : QRM == 2 ? DSQ_BETA_QRREG_MINW : DSQ_BETA_MINW)) fit_beta_kernel(BetaKernelParams kp) {
+    constexpr bool QRROWS = QRM == 1;
+    static_assert(QRM == 0 || STAGE, "stored rows need the staged layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -204,6 +241,12 @@ __global__ void __launch_bounds__(256, (QRROWS ? 2 : DSQ_BETA_MINW)) fit_beta_ke
         qR = qa + (size_t)M * (P + 1);
         qg = qR + P * P;
     }
+    if constexpr (QRM == 2) {
+        qR = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(P) +
+             (size_t)wave * beta_qr_doubles(m, P, 2);
+        qg = qR + P * P;
+    }
+    (void)qa;
 
     DSQ_BWORK(DsqVecP, lambda);
     DSQ_BWORK(DsqVecP, contrast);
@@ -263,6 +306,103 @@ DSQ_UNROLL_P
             for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
             if (abl & 2) {
                 // (ablated: no least-squares solve)
+            } else if (QRM == 2 && kp.useQR) {
+                if constexpr (QRM == 2) {
+                constexpr int T = DSQ_BETA_QRREG_TRIPS;
+                double ar[T][P + 1];
+                // pass A: row i = lane + 64 t of [sqrt(w) X ; sqrt(ridge) | sqrt(w) z] into registers
+                _Pragma("unroll")
+                for (int t = 0; t < T; t++) {
+                    const int i = lane + 64 * t;
+                    _Pragma("unroll")
+                    for (int c = 0; c <= P; c++) ar[t][c] = 0.0;
+                    if (uniform(64 * t < M)) {
+                        if (i < m) {
+                            const double mu = mu_s[i];
+                            const double sw = __builtin_sqrt(wvec(i, mu));
+                            const double z = lg_s[i] + ((double)yg[i] - mu) / mu;
+                            sw_s[i] = sw;
+                            _Pragma("unroll")
+                            for (int c = 0; c < P; c++) ar[t][c] = xs[c * m + i] * sw;
+                            ar[t][P] = z * sw;
+                        } else if (i < M) {
+                            _Pragma("unroll")
+                            for (int c = 0; c < P; c++) ar[t][c] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
+                        }
+                    }
+                }
+                // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
+                double tprev[P + 1];
+                double scal_prev = 0.0;
+                _Pragma("unroll")
+                for (int j = 0; j <= P; j++) tprev[j] = 0.0;
+                static_for<P>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    double acc[P + 1];
+                    _Pragma("unroll")
+                    for (int j = 0; j <= P; j++) acc[j] = 0.0;
+                    _Pragma("unroll")
+                    for (int t = 0; t < T; t++) {
+                        const int i = lane + 64 * t;
+                        if (uniform(64 * t < M)) {
+                            if (i >= k && i < M) {                 // (rows below k are finished rows of R)
+                                if (k > 0) {
+                                    const double v = ar[t][k - 1] * scal_prev;
+                                    _Pragma("unroll")
+                                    for (int j = k; j <= P; j++) ar[t][j] = __builtin_fma(v, tprev[j], ar[t][j]);
+                                }
+                                if (i > k) {
+                                    _Pragma("unroll")
+                                    for (int j = k; j < P; j++) acc[j] += ar[t][k] * ar[t][j];
+                                    acc[P] += ar[t][k] * ar[t][P];
+                                }
+                            }
+                        }
+                    }
+                    double prow[P + 1];
+                    _Pragma("unroll")
+                    for (int j = 0; j <= P; j++) prow[j] = 0.0;
+                    {
+                        double red[P + 1 - k];
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) red[j - k] = acc[j];
+                        wave_allreduce_many(red, lane);
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) acc[j] = red[j - k];
+                    }
+                    _Pragma("unroll")
+                    for (int j = k; j <= P; j++) prow[j] = lane_read(ar[0][j], k);      // row k: trip 0 of lane k
+                    const double alpha_k = prow[k];
+                    double tau, scal, bet;
+                    if (acc[k] == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                    else {
+                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acc[k]), alpha_k);
+                        tau = (bet - alpha_k) / bet;
+                        scal = 1.0 / (alpha_k - bet);
+                    }
+                    scal_prev = scal;
+                    _Pragma("unroll")
+                    for (int j = k + 1; j <= P; j++) {
+                        const double wj = prow[j] + scal * acc[j];
+                        tprev[j] = -tau * wj;
+                    }
+                    if (lane == 0) {
+                        qR[k * P + k] = bet;
+                        _Pragma("unroll")
+                        for (int j = k + 1; j < P; j++) qR[k * P + j] = prow[j] + tprev[j];
+                        qg[k] = prow[P] + tprev[P];
+                    }
+                });
+                wave_lds_sync();
+DSQ_UNROLL_Q
+                for (int i = P - 1; i >= 0; i--) {
+                    double tt = qg[i];
+DSQ_UNROLL_Q
+                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[i * P + j], beta[j], tt);
+                    beta[i] = tt / qR[i * P + i];
+                }
+                wave_lds_sync();
+                }
             } else if (QRROWS && kp.useQR) {
                 if constexpr (QRROWS) {
                 // pass A: the rows of the least squares into LDS (column c of row i at qa[c M + i]; column P = sqrt(w) z)
@@ -286,13 +426,13 @@ DSQ_UNROLL_Q
                 double scal_prev = 0.0;
 DSQ_UNROLL_Q
                 for (int j = 0; j <= P; j++) tprev[j] = 0.0;
-DSQ_UNROLL_Q
-                for (int k = 0; k < P; k++) {
+                static_for<P>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
                     double acc[P + 1], prow[P + 1];
 DSQ_UNROLL_Q
                     for (int j = 0; j <= P; j++) { acc[j] = 0.0; prow[j] = 0.0; }
                     for (int i = lane; i < M; i += 64) {
-                        if (i < k) continue;                       // finished rows of R
+                        if (i < k) continue;                       // finished rows of R (k < 64: only in the first trip)
                         double a[P + 1];
 DSQ_UNROLL_Q
                         for (int j = (k > 0 ? k - 1 : 0); j <= P; j++) a[j] = qa[(size_t)j * M + i];
@@ -313,8 +453,14 @@ DSQ_UNROLL_Q
                             for (int j = k; j <= P; j++) prow[j] = a[j];
                         }
                     }
-DSQ_UNROLL_Q
-                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);
+                    {
+                        double red[P + 1 - k];
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) red[j - k] = acc[j];
+                        wave_allreduce_many(red, lane);
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) acc[j] = red[j - k];
+                    }
 DSQ_UNROLL_Q
                     for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
                     const double alpha_k = prow[k];
@@ -337,7 +483,7 @@ DSQ_UNROLL_Q
                         for (int j = k + 1; j < P; j++) qR[k * P + j] = prow[j] + tprev[j];
                         qg[k] = prow[P] + tprev[P];
                     }
-                }
+                });
                 wave_lds_sync();
 DSQ_UNROLL_Q
                 for (int i = P - 1; i >= 0; i--) {
@@ -348,7 +494,7 @@ DSQ_UNROLL_Q
                 }
                 wave_lds_sync();
                 }
-            } else if (!QRROWS && kp.useQR) {
+            } else if (QRM == 0 && kp.useQR) {
                 // pass A                                                       (:336-353)
                 if (!(abl & 1))
                 for (int j = lane; j < m; j += 64) {
@@ -363,8 +509,8 @@ DSQ_UNROLL_Q
                 DSQ_BWORK(DsqMatP1, tS);
                 DSQ_BWORK(DsqMatP, Rm);
                 DSQ_BWORK(DsqVecP, gamma);
-DSQ_UNROLL_Q
-                for (int k = 0; k < P; k++) {
+                static_for<P>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
                     double acc[P + 1];
 DSQ_UNROLL_Q
                     for (int j = 0; j <= P; j++) acc[j] = 0.0;
@@ -404,8 +550,14 @@ DSQ_UNROLL_Q
                         }
                     }
                     // reductions S_kj, j = k..P, and the pivot row from lane k
-DSQ_UNROLL_Q
-                    for (int j = k; j <= P; j++) acc[j] = wave_allreduce(acc[j]);    // independent chains: interleaved
+                    {                                           // reductions S_kj, j = k..P, together
+                        double red[P + 1 - k];
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) red[j - k] = acc[j];
+                        wave_allreduce_many(red, lane);
+                        _Pragma("unroll")
+                        for (int j = k; j <= P; j++) acc[j] = red[j - k];
+                    }
 DSQ_UNROLL_Q
                     for (int j = k; j <= P; j++) prow[j] = lane_read(prow[j], k);
                     double alpha_k = prow[k];
@@ -426,7 +578,7 @@ DSQ_UNROLL_Q
 DSQ_UNROLL_Q
                     for (int j = k + 1; j < P; j++) Rm[k][j] = prow[j] + tS[k][j];
                     gamma[k] = prow[P] + tS[k][P];
-                }
+                });
 DSQ_UNROLL_Q
                 for (int i = P - 1; i >= 0; i--) {
                     double tt = gamma[i];
@@ -470,7 +622,7 @@ DSQ_UNROLL_P
                             acc[N + a] += xr[a] * (z * wv);
                         }
                     }
-                    wave_allreduce_n(acc);
+                    wave_allreduce_many(acc, lane);
                     LU<P> lu;
                     int idx = 0;
 DSQ_UNROLL_P
@@ -491,7 +643,7 @@ DSQ_UNROLL_P
             int toolarge = 0;
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
-            if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0) && !QRROWS; break; }   // (:357-360)
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; mu_lost = (kp.useQR != 0) && QRM == 0; break; }   // (:357-360)
             if (!(abl & 4)) update_mu();
             double dacc = 0.0;                                                            // (:365-373)
             if (!(abl & 8))
@@ -530,7 +682,13 @@ DSQ_UNROLL_P
         DSQ_BWORK(DsqMatP, G);
         DSQ_BWORK(DsqMatP, Gi);
         if constexpr (P >= DSQ_WIDE_MIN) {
-            for (int j = lane; j < m; j += 64) sw_s[j] = __builtin_sqrt(wvec(j, mu_s[j]));
+            // (a wave-uniform trip count: the exit of a lane-dependent loop is where the toolchain re-materialised the
+            //  constants of the LAST sqrt of this block under an empty exec mask -- profiles/r04_exec_remat.md,
+            //  tools/exec_lint.py)
+            for (int j0 = 0; j0 < m; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < m) sw_s[j] = __builtin_sqrt(wvec(j, mu_s[j]));
+            }
             beta_gram_wide<P, false>(xs, m, lane, [&](int j, double &wv, double &zw) { wv = wvec(j, mu_s[j]); zw = 0.0; },
                                      G, nullptr);
         } else {
@@ -549,7 +707,7 @@ DSQ_UNROLL_P
 DSQ_UNROLL_P
                     for (int b = a; b < P; b++) gacc[idx++] += xr[a] * (xr[b] * wv);
             }
-            wave_allreduce_n(gacc);
+            wave_allreduce_many(gacc, lane);
             int idx = 0;
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)
@@ -1232,7 +1390,7 @@ DSQ_UNROLL_P
                         acc[N + a] += xr[a] * rv;
                     }
                 }
-                wave_allreduce_n(acc);
+                wave_allreduce_many(acc, lane);
                 int idx = 0;
 DSQ_UNROLL_P
                 for (int a = 0; a < P; a++)
@@ -1358,14 +1516,14 @@ hipError_t launch_optim_p<DSQ_P>(const OptimKernelParams &kp, hipStream_t st) {
 // ---- launch ---------------------------------------------------------------------
 // Geometry: W waves (genes) per block share the LDS copy of X; the grid is persistent
 // (blocks-per-CU x CUs, grid-stride over genes) so the per-wave scratch slabs stay L2-resident.
-static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds, bool qrrows = false) {
+static inline size_t beta_lds_doubles(int m, int p, int waves, int xlds, int qrm = 0) {
     return (xlds ? (size_t)p * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(p) +
-           (qrrows ? (size_t)waves * beta_qr_doubles(m, p) : 0);
+           (qrm ? (size_t)waves * beta_qr_doubles(m, p, qrm) : 0);
 }
 
 template <int P>
 static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int *xlds, int *grid, size_t *lds,
-                          bool want_qrrows = false, bool *qrrows = nullptr) {
+                          bool want_qrrows = false, int *qrmode = nullptr) {
     const Tuning &tu = tuning();
     // Pick (waves per block, X in LDS?) maximising resident waves per CU: 160 KiB of LDS per CU, and
     // the register budget of these kernels admits 2 waves per SIMD = 8 per CU.  Ties: bigger blocks
@@ -1376,11 +1534,28 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     *stage = false; *waves = wmax; *xlds = 0;
     // stored-row QR: taken when its LDS leaves at least 4 waves on a CU (the replay kernel runs 4 at p >= 7)
     bool qr = false;
-    if (want_qrrows && P >= DSQ_BETA_QRROWS_MIN && tu.beta_stage != 0) {
+    int qrm = 0;
+    // rows in registers (QRM 2): whenever the least squares has at most 64 T rows -- the LDS then admits the register budget's
+    // resident waves at every width
+    static const int qrreg_env = getenv("DSQ_BETA_QRREG") ? atoi(getenv("DSQ_BETA_QRREG")) : 1;
+    if (want_qrrows && qrreg_env && P >= DSQ_BETA_QRREG_MIN && m + P <= 64 * DSQ_BETA_QRREG_TRIPS && tu.beta_stage != 0) {
         int qbest = -1, qw = 0, qx = 0;
         for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
             for (int w = wmax; w >= 1; w >>= 1) {
-                size_t need = beta_lds_doubles(m, P, w, xl, true) * sizeof(double);
+                size_t need = beta_lds_doubles(m, P, w, xl, 2) * sizeof(double);
+                if (need > budget) continue;
+                int wpc = w * (int)(cu_lds / need);
+                if (wpc > 4 * DSQ_BETA_QRREG_MINW) wpc = 4 * DSQ_BETA_QRREG_MINW;
+                int score = wpc * 100 + w * 2 + xl;
+                if (score > qbest) { qbest = score; qw = w; qx = xl; }
+            }
+        if (qbest >= 0) { qr = true; qrm = 2; *stage = true; *waves = qw; *xlds = qx; }
+    }
+    if (!qr && want_qrrows && P >= DSQ_BETA_QRROWS_MIN && tu.beta_stage != 0) {
+        int qbest = -1, qw = 0, qx = 0;
+        for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
+            for (int w = wmax; w >= 1; w >>= 1) {
+                size_t need = beta_lds_doubles(m, P, w, xl, 1) * sizeof(double);
                 if (need > budget) continue;
                 int wpc = w * (int)(cu_lds / need);
                 if (wpc > 8) wpc = 8;
@@ -1391,9 +1566,9 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
                 const int min_wpc = min_wpc_env > 0 ? min_wpc_env : (P >= 16 ? 1 : 4);
                 if (wpc >= min_wpc && score > qbest) { qbest = score; qw = w; qx = xl; }
             }
-        if (qbest >= 0) { qr = true; *stage = true; *waves = qw; *xlds = qx; }
+        if (qbest >= 0) { qr = true; qrm = 1; *stage = true; *waves = qw; *xlds = qx; }
     }
-    if (qrrows) *qrrows = qr;
+    if (qrmode) *qrmode = qrm;
     if (!qr)
     for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
         for (int w = wmax; w >= 1; w >>= 1) {
@@ -1411,23 +1586,25 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     if (!*stage) *xlds = 0;
     if (!*stage)
         while (*waves > 1 && (size_t)*waves * beta_arena_doubles(P) * sizeof(double) > budget) *waves >>= 1;
-    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds, qr) * sizeof(double)
+    *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds, qrm) * sizeof(double)
                   : (size_t)*waves * beta_arena_doubles(P) * sizeof(double);     // unstaged: only the WIDE arena
-    static thread_local int bpc_cache[3][2][8];   // [stage + stored rows][useW][waves]: the occupancy query costs ~1 ms, ask once
-    static thread_local size_t lds_cache[3][2][8];
+    static thread_local int bpc_cache[4][2][8];   // [stage + stored rows][useW][waves]: the occupancy query costs ~1 ms, ask once
+    static thread_local size_t lds_cache[4][2][8];
     DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
-    const int ci = qr ? 2 : (*stage ? 1 : 0);
+    const int ci = qr ? 1 + qrm : (*stage ? 1 : 0);
     if (lds_cache[ci][useW][*waves] != *lds) { bpc_cache[ci][useW][*waves] = 0; lds_cache[ci][useW][*waves] = *lds; }
     int bpc = bpc_cache[ci][useW][*waves];
-    const void *fn = qr ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRROWS_MIN)>
-                                : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRROWS_MIN)>)
-                  : *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true, false> : (const void *)fit_beta_kernel<P, false, true, false>)
-                           : (useW ? (const void *)fit_beta_kernel<P, true, false, false> : (const void *)fit_beta_kernel<P, false, false, false>);
+    const void *fn = qrm == 2 ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRREG_MIN ? 2 : 0)>
+                                      : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRREG_MIN ? 2 : 0)>)
+                  : qr ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRROWS_MIN ? 1 : 0)>
+                               : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRROWS_MIN ? 1 : 0)>)
+                  : *stage ? (useW ? (const void *)fit_beta_kernel<P, true, true, 0> : (const void *)fit_beta_kernel<P, false, true, 0>)
+                           : (useW ? (const void *)fit_beta_kernel<P, true, false, 0> : (const void *)fit_beta_kernel<P, false, false, 0>);
     if (bpc == 0) {
         if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * *waves, *lds) != hipSuccess || bpc < 1) bpc = 1;
         bpc_cache[ci][useW][*waves] = bpc;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d stored-rows=%d xlds=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, (int)qr, *xlds, *lds, bpc);
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta<P=%d> waves=%d stage=%d stored-rows=%d xlds=%d lds=%zu occupancy-api blocks/CU=%d\n", P, *waves, (int)*stage, qrm, *xlds, *lds, bpc);
     }
     if (tu.beta_bpc > 0) bpc = tu.beta_bpc;
     const int cus = device_cu_count();
@@ -1457,28 +1634,33 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
     int waves, grid, xlds;
     bool stage;
     size_t lds;
-    bool qr = false;
+    int qr = 0;
     beta_geometry<DSQ_P>(kp0.n, kp0.m, kp0.useWeights != 0, &waves, &stage, &xlds, &grid, &lds,
                          kp0.useQR != 0 && kp0.maxit > 0, &qr);
     BetaKernelParams kp = kp0;
     kp.xlds = xlds;
     if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();   // a row list: its length lives on the device
-    constexpr bool kQr = (DSQ_P >= DSQ_BETA_QRROWS_MIN);
-    if (qr) {
+    constexpr int kQr = (DSQ_P >= DSQ_BETA_QRROWS_MIN) ? 1 : 0, kQreg = (DSQ_P >= DSQ_BETA_QRREG_MIN) ? 2 : 0;
+    if (qr == 2) {
+        if (kp.useWeights)
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, kQreg>), dim3(grid), dim3(64 * waves), lds, st, kp);
+        else
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, kQreg>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    } else if (qr == 1) {
         if (kp.useWeights)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, kQr>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, kQr>), dim3(grid), dim3(64 * waves), lds, st, kp);
     } else if (stage) {
         if (kp.useWeights)
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, 0>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, 0>), dim3(grid), dim3(64 * waves), lds, st, kp);
     } else {
         if (kp.useWeights)
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, false, 0>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else
-            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, false, 0>), dim3(grid), dim3(64 * waves), lds, st, kp);
     }
     return hipGetLastError();
 }

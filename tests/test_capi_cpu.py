@@ -138,3 +138,19 @@ def test_beta_prior_var_equals_the_host_mirror(case):
     assert got.shape == np.asarray(ref).shape
     assert (got == np.asarray(ref)).all(), (got, ref)
     assert got[0] == 1e6 and (got > 0).all()
+
+
+def test_shipped_library_passes_the_exec_lint():
+    """profiles/r04_exec_remat.md: the toolchain can re-materialise a constant above the exec restore of a join block (it
+    did, in two kernels of round 4: sqrt() returned its argument).  tools/exec_lint.py looks for that pattern in the
+    disassembly of every gfx950 code object of the library that ships."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lint = os.path.join(root, "tools", "exec_lint.py")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    from deseq2_amd import _lib
+    r = subprocess.run([sys.executable, lint, _lib.SO_PATH], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 suspicious" in r.stdout

@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Static check of the COMPILER'S OUTPUT for a miscompile met in round 4 (profiles/r04_exec_remat.md): under register
+pressure the allocator re-materialises a constant (v_mov_b32 vN, 0x260 ...) at the HEAD of a join block, ABOVE the
+`s_or_b64 exec, exec, s[a:b]` that re-activates the lanes.  The move then runs under the mask of the region that just
+ended -- empty after a loop -- and every lane reads garbage from vN afterwards (there: the class mask of an inlined
+sqrt, which then returned its argument).  Nothing in the source can provoke or prevent it, so the build is checked:
+
+    python tools/exec_lint.py deseq2_amd/libdeseq2_mi355x.so      # the shipped library: every gfx950 code object in it
+    python tools/exec_lint.py file.s                               # hipcc -S --cuda-device-only output
+
+Reports every constant move into a vector register that sits between the head of a block where lanes come back together
+(the target of a forward skip on an empty mask, the fall-through of a loop latch; in -S output: any label) and the exec
+restore that leads the block.  Exit status 1 when anything is found."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+SCALAR_OK = ("s_mov", "s_movk", "s_brev", "s_nop", "s_waitcnt", "v_readlane", "v_readfirstlane", "s_getpc", "s_add_u32",
+             "s_addc_u32")
+
+
+# a constant put into a vector register: what the allocator re-materialises instead of keeping or spilling it
+CONST_MOVE = re.compile(r"^(v_mov_b32_e32|v_mov_b64_e32|v_bfrev_b32_e32|v_accvgpr_write_b32)\s+\S+,\s*(-?0x[0-9a-fA-F]+|-?\d+(\.\d+)?)\s*(<.*)?$")
+
+
+def scan(blocks):
+    """blocks: iterable of (kernel, [instruction text ...]) with each list starting at a block head"""
+    hits = []
+    for kernel, where, ins in blocks:
+        pending = []
+        for w, t in zip(where, ins):
+            op = t.split()[0]
+            if op == "s_or_b64" and re.match(r"s_or_b64\s+exec,\s*exec,", t):
+                hits += [(kernel, pw, pt) for pw, pt in pending]
+                break
+            if CONST_MOVE.match(t):
+                pending.append((w, t))
+            elif not op.startswith(SCALAR_OK):
+                break
+    return hits
+
+
+def blocks_of_asm(path):
+    kernel, cur, where = None, None, None
+    for ln, line in enumerate(open(path, errors="replace"), 1):
+        t = line.strip()
+        if not t or t.startswith((";", "//")):
+            continue
+        mk = re.match(r"^([A-Za-z_][\w$.]*):", t)
+        if mk and not t.startswith("."):
+            kernel = mk.group(1)
+        if re.match(r"^\.LBB\d+_\d+:", t) or (mk and not t.startswith(".")):
+            if cur:
+                yield kernel, where, cur
+            cur, where = [], []
+            continue
+        if t.startswith(".") or cur is None:
+            continue
+        cur.append(t); where.append("%s:%d" % (path, ln))
+    if cur:
+        yield kernel, where, cur
+
+
+def blocks_of_disassembly(text, tag):
+    funcs = re.split(r"\n(?=[0-9a-f]{16} <)", text)
+    for f in funcs:
+        m = re.match(r"([0-9a-f]{16}) <([^>]+)>:", f)
+        if not m:
+            continue
+        base, kernel = int(m.group(1), 16), m.group(2)
+        ins = []
+        for line in f.splitlines()[1:]:
+            mm = re.match(r"\s+(\S.*?)\s+// ([0-9A-F]{12}):[^<]*(<[^>]+>)?", line)
+            if mm:
+                ins.append((int(mm.group(2), 16), mm.group(1) + (" " + mm.group(3) if mm.group(3) else "")))
+        # heads where the lanes of a region come back together: the target of a forward skip on an empty mask
+        # (s_cbranch_execz) and the fall-through of a loop's latch (a backward s_cbranch_execnz)
+        targets = set()
+        for k, (a, t) in enumerate(ins):
+            if t.startswith(("s_cbranch_execz", "s_cbranch_execnz")):
+                mt = re.search(r"<[^>]+\+0x([0-9a-f]+)>", t)
+                if not mt:
+                    continue
+                tg = base + int(mt.group(1), 16)
+                if tg > a:
+                    targets.add(tg)
+                elif k + 1 < len(ins):
+                    targets.add(ins[k + 1][0])
+        idx = {a: i for i, (a, _) in enumerate(ins)}
+        for tg in sorted(targets):
+            if tg in idx:
+                i = idx[tg]
+                chunk = ins[i: i + 24]
+                yield kernel, ["%s %s+0x%x" % (tag, kernel[:60], a - base) for a, _ in chunk], [re.sub(r"\s*<[^>]+>$", "", t) for _, t in chunk]
+
+
+def lint_library(so):
+    hits = []
+    tmp = tempfile.mkdtemp(prefix="dsq_lint_")
+    try:
+        lib = os.path.join(tmp, "lib.so")
+        shutil.copy(so, lib)
+        subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+        for f in objs:
+            text = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            hits += scan(blocks_of_disassembly(text, f.split(".")[2] if f.count(".") > 2 else f))
+        return hits, len(objs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main(argv):
+    bad = 0
+    for p in argv:
+        if p.endswith(".so") or p.endswith(".o"):
+            hits, n = lint_library(p)
+            print("exec_lint: %s: %d gfx950 code objects" % (p, n))
+        else:
+            hits = scan(blocks_of_asm(p))
+        for kernel, w, t in hits:
+            bad += 1
+            print("%s: %s\n    in %s" % (w, t, kernel))
+    print("exec_lint: %d suspicious instruction(s)" % bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
