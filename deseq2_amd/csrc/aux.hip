@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
             a2[0] += cn;
             a2[1] += yy;
         });
-        wave_allreduce_n(a2);
+        wave_allreduce_many(a2, lane);
         const double mean = a2[0] / (double)m;
         double av = 0.0;
         sweep_batched<kAuxBatch>(m, lane, load_row, [&](int, int b) {
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
                 tu[P + c] += ly * qv;
             }
         });
-        wave_allreduce_n(tu);
+        wave_allreduce_many(tu, lane);
         double ae = 0.0;
         sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
             double yn = (double)yb[b] / nb[b];
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, d
                 for (int c = 0; c < P; c++) tu[c] += yn * kp.q[(size_t)c * m + j];
             });
         }
-        wave_allreduce_n(tu);
+        wave_allreduce_many(tu, lane);
         double *mg = mu_out + (size_t)g * kp.ld;
         for (int j = lane; j < m; j += 64) {
             double v = tu[0] * kp.a[j];
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) intercept_fit_kernel(InterceptKernelParam
             if constexpr (USE_W) { double w = wg[j]; cn = w * cn; s[1] += w; }
             s[0] += cn;
         }
-        wave_allreduce_n(s);
+        wave_allreduce_many(s, lane);
         const double mean = s[0] / (USE_W ? s[1] : (double)m);
         const double b = dlog(mean);
         const double eb = dexp(b);

@@ -1464,7 +1464,7 @@ DSQ_UNROLL_P
                 if constexpr (USE_W) d = wg[j] * d;
                 lacc += d;
             }
-            wave_allreduce_n(gacc);
+            wave_allreduce_many(gacc, lane);
             int idx = 0;
 DSQ_UNROLL_P
             for (int a = 0; a < P; a++)

@@ -381,15 +381,25 @@ DSQ_UNROLL_P
                         }
                     }
                 }
-                _Pragma("unroll")
-                for (int b = 0; b < P; b++) {
-                    if (b < a0) continue;                         // (wave-uniform) the lower triangle is the mirror
+                {
+                    // the K p sums of the row reduced together (wave_allreduce_many: the bits of one butterfly each, a
+                    // quarter of the instructions; the entries left of the diagonal come along and are not stored)
+                    double red[K * P];
                     _Pragma("unroll")
-                    for (int k = 0; k < K; k++) {
-                        const double v = wave_allreduce(acc[k][b]);
-                        if (lane == 0) {
-                            arena[(k * P + a0) * P + b] = v;
-                            arena[(k * P + b) * P + a0] = v;
+                    for (int b = 0; b < P; b++)
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) red[b * K + k] = acc[k][b];
+                    wave_allreduce_many(red, lane);
+                    _Pragma("unroll")
+                    for (int b = 0; b < P; b++) {
+                        if (b < a0) continue;                     // (wave-uniform) the lower triangle is the mirror
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) {
+                            const double v = red[b * K + k];
+                            if (lane == 0) {
+                                arena[(k * P + a0) * P + b] = v;
+                                arena[(k * P + b) * P + a0] = v;
+                            }
                         }
                     }
                 }
@@ -440,7 +450,7 @@ DSQ_UNROLL_P
                         }
                 }
             }
-            wave_allreduce_n(acc);
+            wave_allreduce_many(acc, lane);
             if constexpr (LANE) {
                 // the reduced entries are wave-uniform: lane b picks column b
                 _Pragma("unroll")
