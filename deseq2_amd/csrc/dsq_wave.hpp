@@ -192,6 +192,30 @@ DSQ_DEV void wave_allreduce_many(double (&v)[N], int lane) {
     }
 }
 
+// ... of N values that are +0.0 outside lanes [0, nlive) (wave_allreduce_low's case): the four DPP steps merged as above,
+// the cross-row steps done only when live lanes sit beyond the first row(s); the totals are read from the first row,
+// whose 16 lanes hold them whatever nlive is.
+template <int N>
+DSQ_DEV void wave_allreduce_many_low(double (&v)[N], int lane, int nlive) {
+    if constexpr (N == 1) { v[0] = lane_read(wave_allreduce_low(v[0], nlive), 0); }
+    else {
+        constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+        double r1[N1], r2[N2], r3[N3], r4[N4];
+        wave_merge_level<N, 1>(v, r1, lane);
+        wave_merge_level<N1, 2>(r1, r2, lane);
+        wave_merge_level<N2, 4>(r2, r3, lane);
+        wave_merge_level<N3, 8>(r3, r4, lane);
+        _Pragma("unroll")
+        for (int i = 0; i < N4; i++) {
+            double a, b;
+            if (nlive > 16) { lane_pair16(r4[i], a, b); r4[i] = a + b; } else r4[i] = r4[i] + 0.0;
+            if (nlive > 32) { lane_pair32(r4[i], a, b); r4[i] = a + b; } else r4[i] = r4[i] + 0.0;
+        }
+        _Pragma("unroll")
+        for (int j = 0; j < N; j++) v[j] = lane_read(r4[j >> 4], j & 15);
+    }
+}
+
 DSQ_DEV double wave_bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
 

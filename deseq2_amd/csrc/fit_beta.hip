@@ -999,15 +999,26 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     a[k] = v;
                 }
                 if (lane < C) b = (sS > 0.0) ? Tl / sS : 0.0;
-#pragma unroll
-                for (int k = 0; k < P; k++) {
+                static_for<P>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
                     double acc[P + 1];
                     const bool below = (lane > k) && (lane < Mrows);
 #pragma unroll
                     for (int j = k; j < P; j++) acc[j] = below ? a[k] * a[j] : 0.0;
                     acc[P] = below ? a[k] * b : 0.0;
+#ifdef DSQ_BETA_CELL_SINGLE_REDUCTIONS
 #pragma unroll
                     for (int j = k; j <= P; j++) acc[j] = wave_allreduce_low(acc[j], Mrows);   // (only rows < Mrows use them)
+#else
+                    {                                           // the p + 1 - k sums of the stage together (dsq_wave.hpp)
+                        double red[P + 1 - k];
+#pragma unroll
+                        for (int j = k; j <= P; j++) red[j - k] = acc[j];
+                        wave_allreduce_many_low(red, lane, Mrows);
+#pragma unroll
+                        for (int j = k; j <= P; j++) acc[j] = red[j - k];
+                    }
+#endif
                     double prow[P + 1];
 #pragma unroll
                     for (int j = k; j < P; j++) prow[j] = lane_read(a[j], k);
@@ -1034,7 +1045,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                         b = b + tvec[P];
                         a[k] = bet;
                     }
-                }
+                });
 #pragma unroll
                 for (int i = P - 1; i >= 0; i--) {
                     double tt = lane_read(b, i);

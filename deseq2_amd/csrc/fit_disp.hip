@@ -578,8 +578,9 @@ DSQ_UNROLL_P
                 if (q0 == 0) lg_an1 = lane_read(lg, 0);
                 if (live) accv += (double)dc[q - 1] * (lg - lg_an1);
             }
-            const double sv = wave_allreduce(accv);
-            ll_part = sv + wave_allreduce(acc);
+            double sv = accv, sa = acc;
+            wave_allreduce_pair(sv, sa, lane);              // (the bits of two butterflies)
+            ll_part = sv + sa;
         }
         double prior_part = 0.0;
         if (usePrior) {
@@ -649,8 +650,10 @@ DSQ_UNROLL_P
         }
         double ll_part, ll_dpart;
         if constexpr (USE_W) {
-            ll_part = wave_allreduce(acc);
-            ll_dpart = an2 * wave_allreduce(acc2);
+            double s1 = acc, s2 = acc2;
+            wave_allreduce_pair(s1, s2, lane);
+            ll_part = s1;
+            ll_dpart = an2 * s2;
         } else {
             double accv = 0.0, accv2 = 0.0;
 #ifdef DSQ_ABLATE_BUILD
@@ -668,9 +671,16 @@ DSQ_UNROLL_P
                     accv2 += c * (dg_an1 - dg);
                 }
             }
+#ifdef DSQ_DISP_SINGLE_REDUCTIONS
             double sv = wave_allreduce(accv), sv2 = wave_allreduce(accv2);
             ll_part = sv + wave_allreduce(acc);
             ll_dpart = an2 * (sv2 + wave_allreduce(acc2));
+#else
+            double red[4] = {accv, accv2, acc, acc2};      // the four sums of an evaluation reduced together: the bits of four
+            wave_allreduce_many(red, lane);                 // butterflies (dsq_wave.hpp), less than half their instructions
+            ll_part = red[0] + red[2];
+            ll_dpart = an2 * (red[1] + red[3]);
+#endif
         }
         double prior_part = 0.0, prior_dpart = 0.0;
         if (usePrior) {
@@ -731,8 +741,9 @@ DSQ_UNROLL_P
                 if (q0 == 0) dg_an1 = lane_read(dg, 0);
                 if (live) accv += (double)dc[q - 1] * (dg_an1 - dg);
             }
-            double sv = wave_allreduce(accv);
-            ll_sum = sv + wave_allreduce(acc);
+            double sv = accv, sa = acc;
+            wave_allreduce_pair(sv, sa, lane);
+            ll_sum = sv + sa;
         }
         double ll_part = an2 * ll_sum;
         double prior_part = 0.0;
