@@ -175,7 +175,7 @@ class DsqDeseqArgs(C.Structure):
         ("cell_of_red", C.c_void_p), ("ncell_red", C.c_int32), ("defer_finish", C.c_int32),
         ("n_refit_global", C.c_void_p), ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32),
         ("prior_expanded", C.c_int32), ("prior_intercept", C.c_int32), ("lambda_prior", C.c_void_p),
-        ("fitType", C.c_int32),
+        ("fitType", C.c_int32), ("dispFit_in", C.c_void_p), ("trend_fit_in", C.c_void_p),
     ]
 
 
@@ -199,7 +199,7 @@ class DsqDeseqHostArgs(C.Structure):
         ("ngrid", C.c_int32),
         ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32), ("coef_factor", C.c_void_p),
         ("prior_coef_factor", C.c_void_p), ("prior_coef_src", C.c_void_p), ("betaPriorVar", C.c_void_p),
-        ("fitType", C.c_int32),
+        ("fitType", C.c_int32), ("dispFit", C.c_void_p), ("geneEstOnly", C.c_int32),
     ]
 
 
@@ -226,7 +226,7 @@ DSQ_ST = {k: i for i, k in enumerate((
     "N_OPTIM_TEST", "N_REPLACE", "N_REFIT", "N_GRID_GENEEST_REFIT", "N_GRID_MAP_REFIT", "N_OPTIM_GENEEST_REFIT",
     "N_OPTIM_TEST_REFIT"))}
 DSQ_SC_FIT_USED = 4
-DSQ_FIT = {"parametric": 0, "mean": 1, "parametric_or_mean": 2}
+DSQ_FIT = {"parametric": 0, "mean": 1, "parametric_or_mean": 2, "given": 3}
 DSQ_ST_COUNT, DSQ_SC_COUNT = 16, 8
 
 # every symbol include/deseq2_mi355x.h declares (tests check the .so exports all of them)

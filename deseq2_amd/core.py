@@ -575,8 +575,16 @@ def estimateDispersionsFit(dds, fitType="parametric", minDisp=1e-8, engine=None)
             fitType = "mean"       # the reference falls back to locfit (not available here)
     if fitType == "mean":
         fn = ("mean", trimmed_mean_fit(dge, minDisp))                                  # mean(trim = 0.001)
+    if callable(fitType):
+        # the caller's trend, a function of the normalized mean: what R reaches with fitType = "local" (locfit, :889-893:
+        # `dispFunction <- localDispersionFit(means[useForFit], disps[useForFit], minDisp)`) or `dispersionFunction(dds) <- f`
+        # (R/methods.R:142-190); it is given the vectors of the genes that enter the fit, returns the function of the mean
+        fn = ("custom", fitType(bm[useForFit], dge[useForFit]))
     if fn[0] == "parametric":
         dispFit = fn[1][0] + fn[1][1] / bm
+    elif fn[0] == "custom":
+        with np.errstate(invalid="ignore", divide="ignore"):
+            dispFit = np.asarray(fn[1](bm), dtype=np.float64)
     else:
         dispFit = np.full(bm.shape, fn[1])
     dds.mcols["dispFit"] = dispFit
@@ -937,6 +945,8 @@ def _dispersion_function(dds, baseMean):
     fn = dds.dispersionFunction
     if fn["fitType"] == "parametric":
         return fn["coefficients"][0] + fn["coefficients"][1] / baseMean
+    if fn["fitType"] == "custom":
+        return np.asarray(fn["coefficients"](baseMean), dtype=np.float64)
     return np.full(baseMean.shape, fn["coefficients"])
 
 

@@ -117,7 +117,7 @@ static void design_facts(const DsqDeseqHostArgs *a, Facts *f) {
     f->replaceable.assign(m, 0);
     if (std::isfinite(a->minReplicatesForReplace))
         for (int j = 0; j < m; j++)
-            if ((double)size[f->cells[j]] >= a->minReplicatesForReplace) { f->replaceable[j] = 1; f->do_replace = 1; }
+            if (!a->dispFit && (double)size[f->cells[j]] >= a->minReplicatesForReplace) { f->replaceable[j] = 1; f->do_replace = 1; }
     f->linearMu = (f->ncell == p && !a->weights) ? 1 : 0;                   // R/core.R:735-742
     if (a->xrinv) f->a.assign(a->xrinv, a->xrinv + (size_t)m * p);
     else x_rinv(a->x, a->r, m, p, &f->a);
@@ -190,6 +190,7 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (a->y_type != DSQ_Y_INT32 && a->y_type != DSQ_Y_FLOAT64) return capi_fail(DSQ_ERR_ARG, "unknown y_type %d", a->y_type);
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
     if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
+    if (a->geneEstOnly && a->dispFit) return capi_fail(DSQ_ERR_ARG, "geneEstOnly and dispFit are the two calls of one analysis");
     if (a->x_reduced && (a->test != 1 || !a->q_reduced || !a->r_reduced || a->p_reduced < 1 || a->p_reduced >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with qr.Q / qr.R of its model matrix and 1 <= p_reduced < p");
     if (a->betaPrior) {
@@ -319,7 +320,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     d.n_trend = nt; d.lambda = F.lam.data(); d.min_log_alpha = std::log(1e-8 / 10.0);
     d.workspace = work; d.workspace_bytes = wsb; d.test = a->test; d.fitType = a->fitType;
     d.cell_of = F.cells.data(); d.ncell = F.ncell; d.replaceable = F.replaceable.data();
-    d.cooksCutoff = a->cooksCutoff; d.trim = 0.2; d.do_replace = F.do_replace;
+    d.cooksCutoff = a->cooksCutoff; d.trim = 0.2; d.do_replace = F.do_replace;      // (dispFit given: Facts leaves it 0)
     if (pr) {
         d.x_red = dd + off_xr; d.q_red = dd + off_qr; d.a_red = dd + off_ar; d.r_red = dd + off_rr; d.p_red = (int32_t)pr;
         d.cell_of_red = F.cells_red.data(); d.ncell_red = F.ncell_red;
@@ -389,7 +390,24 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         return X.prior_state == 1 ? DSQ_OK : -1;
     };
     bool prior_skipped = false;
-    if (nshards == 1 && a->betaPrior) {
+    if (a->dispFit) {
+        // the caller's trend: this range's values beside the gathered vectors (behind them: all n, for the residuals)
+        if ((rc = capi_ws_get(HD_TREND, 3 * n * 8, &v))) return rc;
+        double *tv = (double *)v;
+        HD_HIP(hipMemcpyAsync(tv + 2 * n, a->dispFit, n * 8, hipMemcpyHostToDevice, st));
+        d.dispFit_in = tv + 2 * n + lo;
+        d.trend_fit_in = tv + 2 * n;
+    }
+    if (a->geneEstOnly) {
+        // estimateDispersionsGeneEst alone (the caller fits its own trend next): every other column NA
+        HD_HIP(hipMemsetAsync(vec, 0xFF, V_COUNT * cnt * 8, st));
+        HD_HIP(hipMemsetAsync(mat, 0xFF, 4 * pcol * cnt * 8, st));
+        HD_HIP(hipMemsetAsync(ivec, 0xFF, I_COUNT * cnt * 4, st));
+        HD_HIP(hipMemsetAsync(scalars, 0xFF, DSQ_SC_COUNT * 8, st));
+        HD_HIP(hipMemsetAsync(status, 0, DSQ_ST_COUNT * 4, st));
+        d.phases = DSQ_PH_GENE_EST;
+        if ((rc = pipeline_run(&d, &od, st))) return rc;
+    } else if (nshards == 1 && a->betaPrior) {
         d.phases = DSQ_PH_GENE_EST | DSQ_PH_TREND | DSQ_PH_MAP_TEST;
         if ((rc = pipeline_run(&d, &od, st))) return rc;
         if (prior_exchange() == DSQ_OK) {
@@ -408,7 +426,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
         HD_HIP(hipMemcpyAsync(X.dge.data() + lo, od.dispGeneEst, cnt * 8, hipMemcpyDeviceToHost, st));
         HD_HIP(hipStreamSynchronize(st));
         if (!X.wait(0)) return capi_fail(DSQ_ERR_DEVICE, "another gene range of this call failed");
-        if ((rc = capi_ws_get(HD_TREND, 2 * n * 8, &v))) return rc;
+        if ((rc = capi_ws_get(HD_TREND, 3 * n * 8, &v))) return rc;
         double *tv = (double *)v;
         HD_HIP(hipMemcpyAsync(tv, X.bm.data(), n * 8, hipMemcpyHostToDevice, st));
         HD_HIP(hipMemcpyAsync(tv + n, X.dge.data(), n * 8, hipMemcpyHostToDevice, st));
@@ -487,7 +505,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     // ---- assays on request: gene-major -> R layout on the device -> the caller's n x m matrix
     double *const want[3] = {o->mu, o->H, o->cooks};
     for (int k = 0; k < 3; k++) {
-        if (!want[k]) continue;
+        if (!want[k] || a->geneEstOnly) continue;        // (geneEstOnly: no test has run, nothing to bring down)
         if ((rc = capi_ws_get(HD_OUTR, cnt * m * 8, &v))) return rc;
         HD_HIP(launch_transpose_gm_to_r_f64(mats[k + 1], (double *)v, (int)cnt, (int)m, ld, st));
         if ((rc = stage_d2h(want[k], v, 8, n, lo, cnt, m, st))) return rc;
@@ -548,6 +566,7 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     o->status[DSQ_ST_N_ABOVE_MIN] = X.status[DSQ_ST_N_ABOVE_MIN];
     for (int k = 0; k < DSQ_SC_COUNT; k++) o->dispersionFunction[k] = X.scalars[k];
     if (o->status[DSQ_ST_N_NONZERO] == 0) return capi_fail(DSQ_ERR_FIT, "all genes have zero counts in every sample");
+    if (a->geneEstOnly) return DSQ_OK;
     if (o->status[DSQ_ST_N_TREND] == 0)
         return capi_fail(DSQ_ERR_FIT, "all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value");
     if (o->status[DSQ_ST_TREND_STATUS] != 0 || o->status[DSQ_ST_N_ABOVE_MIN] == 0)

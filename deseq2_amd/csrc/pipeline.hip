@@ -170,7 +170,7 @@ DSQ_DEV double block_median(int n, long k, F &&value, unsigned *hist, unsigned l
 
 __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, const double *disp, int n, double minDisp,
                                                          double expVarLogDisp, int m_gt_p, double *resbuf,
-                                                         double *scalars, int32_t *status) {
+                                                         double *scalars, int32_t *status, const double *fit_in) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long bc[2];
     __shared__ int kshared;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, con
         bool above = d >= minDisp * 100.0;                       // aboveMinDisp, R/core.R:897 / :1137
         double r = inf;
         if (above) {
-            double fit = c0 + c1 / mean[i];
+            double fit = fit_in ? fit_in[i] : c0 + c1 / mean[i];       // (fit_in: the caller's trend, DSQ_FIT_GIVEN)
             r = dlog(d) - dlog(fit);
             c++;
         }
@@ -335,6 +335,12 @@ __global__ void __launch_bounds__(1024) trend_mean_kernel(const double *disp, in
     }
 }
 
+__global__ void trend_given_kernel(double *scalars, int32_t *status) {
+    scalars[DSQ_SC_COEF0] = dnan(); scalars[DSQ_SC_COEF1] = dnan();
+    scalars[DSQ_SC_FIT_USED] = (double)DSQ_FIT_GIVEN;
+    status[DSQ_ST_TREND_STATUS] = 0;
+}
+
 // ---- per-gene rules ----------------------------------------------------------------------------------------------
 struct RuleParams {
     Rows rw;
@@ -354,6 +360,7 @@ struct RuleParams {
     int32_t *grid_flag, *grid_rows, *grid_count;
     const double *scalars;
     double *dispFit, *log_dfit, *la_init, *dispMAP, *dispersion;
+    const double *dispFit_in;      // DSQ_FIT_GIVEN: the caller's trend values, per gene
     int32_t *dispIter, *dispOutlier;
     // GLM fit
     const double *beta_nat, *beta_var, *beta_iter, *logLike;
@@ -413,7 +420,7 @@ __global__ void map_init_kernel(RuleParams q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows_count(q.rw)) return;
     const int g = rows_gene(q.rw, i);
-    const double fit = q.scalars[DSQ_SC_COEF0] + q.scalars[DSQ_SC_COEF1] / q.baseMean[g];
+    const double fit = q.dispFit_in ? q.dispFit_in[g] : q.scalars[DSQ_SC_COEF0] + q.scalars[DSQ_SC_COEF1] / q.baseMean[g];
     const double d = q.dge[g];
     double init = (d > 0.1 * fit) ? d : fit;
     if (init != init) init = fit;
@@ -671,6 +678,7 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
     q.dge = o->dispGeneEst; q.dispGeneIter = o->dispGeneIter;
     q.grid_flag = P.grid_flag; q.grid_rows = P.rows_grid;
     q.scalars = o->scalars;
+    q.dispFit_in = a->dispFit_in;
     q.dispFit = o->dispFit; q.log_dfit = P.log_dfit; q.la_init = P.la_init; q.dispMAP = o->dispMAP;
     q.dispersion = o->dispersion; q.dispIter = o->dispIter; q.dispOutlier = o->dispOutlier;
     q.beta_nat = P.beta_nat; q.beta_var = P.beta_var; q.beta_iter = P.beta_iter;
@@ -1216,6 +1224,9 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
     if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
+    if (a->dispFit_in && a->trend_mean && !a->trend_fit_in) return capi_fail(DSQ_ERR_ARG, "dispFit_in with gathered trend vectors needs trend_fit_in");
+    if (a->dispFit_in && (a->phases & DSQ_PH_OUTLIERS) && a->do_replace)
+        return capi_fail(DSQ_ERR_ARG, "dispFit_in: the refit of replaced rows needs the trend at their NEW means -- run with do_replace = 0 and refit in the caller");
     if (a->x_red && (a->test != 1 || !a->q_red || !a->a_red || !a->r_red || a->p_red < 1 || a->p_red >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with its QR factors and 1 <= p_red < p");
     if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
@@ -1369,15 +1380,21 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (rc) return rc;
         capi_prof_begin("trend_fit", nt, st);
         PIPE_HIP(hipMemsetAsync(o->scalars + DSQ_SC_FIT_USED, 0, sizeof(double), st));               // 0.0 = DSQ_FIT_PARAMETRIC
-        if (a->fitType != DSQ_FIT_MEAN)
-            PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
-                                          o->status + DSQ_ST_TREND_STATUS, tws, st));
-        if (a->fitType != DSQ_FIT_PARAMETRIC)                // R/core.R:894-899 over the same vector, uncompacted
-            hipLaunchKernelGGL(trend_mean_kernel, dim3(1), dim3(1024), 0, st, td, nt, a->minDisp, (int)a->fitType, o->scalars, o->status);
+        if (a->dispFit_in) {
+            // the caller's trend (fitType "local" evaluated by R, dispersionFunction<-): nothing to fit; the coefficients are NA
+            hipLaunchKernelGGL(trend_given_kernel, dim3(1), dim3(1), 0, st, o->scalars, o->status);
+        } else {
+            if (a->fitType != DSQ_FIT_MEAN)
+                PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
+                                              o->status + DSQ_ST_TREND_STATUS, tws, st));
+            if (a->fitType != DSQ_FIT_PARAMETRIC)            // R/core.R:894-899 over the same vector, uncompacted
+                hipLaunchKernelGGL(trend_mean_kernel, dim3(1), dim3(1024), 0, st, td, nt, a->minDisp, (int)a->fitType, o->scalars, o->status);
+        }
         capi_prof_end(st);
         capi_prof_begin("prior_var", nt, st);
         hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
-                           (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status);
+                           (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status,
+                           a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr);
         capi_prof_end(st);
         PIPE_HIP(hipGetLastError());
     }

@@ -283,7 +283,10 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
                           SEXP priorCoefSrcSEXP, SEXP betaPriorVarSEXP,
                           /* estimateDispersionsFit's fitType as DSQ_FIT_*: 0 "parametric" (a trend that does not fit returns
                            * NULL and the caller takes the reference's route to locfit, R/core.R:885-893), 1 "mean" */
-                          SEXP fitTypeSEXP) {
+                          SEXP fitTypeSEXP,
+                          /* a trend R fits itself (fitType = "local", dispersionFunction<-): geneEstOnly TRUE = stop after
+                           * estimateDispersionsGeneEst; dispFit = the trend at res$baseMean (or NULL), see dsq_deseq */
+                          SEXP dispFitSEXP, SEXP geneEstOnlySEXP) {
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
@@ -356,6 +359,12 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     a.betaTol = scalar_d(betaTolSEXP); a.maxit = scalar_i(maxitSEXP); a.useQR = scalar_b(useQRSEXP);
     a.minmu = scalar_d(minmuSEXP); a.disp_maxit = scalar_i(dispMaxitSEXP); a.useCR = scalar_b(useCRSEXP);
     a.fitType = scalar_i(fitTypeSEXP);
+    a.geneEstOnly = scalar_b(geneEstOnlySEXP);
+    if (dispFitSEXP != R_NilValue) {
+        need_length(dispFitSEXP, n, "dispFit");
+        SEXP df = as_real(dispFitSEXP, &np);
+        a.dispFit = REAL(df);
+    }
     /* double columns straight into fresh R vectors; integer columns through scratch (NA_integer_ / NA for -1) */
     enum { BM, BV, DGE, DFIT, DMAP, DISP, BITER, LL, LLR, MAXC, NDBL };
     SEXP dv[NDBL];
@@ -414,7 +423,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
-    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 28},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 30},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

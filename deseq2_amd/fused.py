@@ -21,7 +21,9 @@ from . import core
 
 def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     E = dds.engine
-    if getattr(E, "name", "") != "device" or fitType not in ("parametric", "mean"):
+    if getattr(E, "name", "") != "device" or not (fitType in ("parametric", "mean") or callable(fitType)):
+        return False
+    if callable(fitType) and kw.get("betaPrior"):
         return False
     if dds.p > 24 or dds.m <= dds.p:
         return False
@@ -394,6 +396,27 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     # estimateDispersionsFit (R/core.R:864-939): "mean" on the device; a parametric trend that does not fit is replaced
     # by the mean there as well (core.estimateDispersionsFit's substitute for the reference's locfit fallback)
     run.args.fitType = L.DSQ_FIT["mean" if fitType == "mean" else "parametric_or_mean"]
+    custom = None
+    if callable(fitType):
+        # the caller's trend (core.estimateDispersionsFit: what R has after fitType = "local" or dispersionFunction<-):
+        # the gene-wise estimates come up, the function is evaluated on the host, its values go down as dispFit_in.  The
+        # refit of replaced rows would need the function at their new means: such analyses (and gene shards) go call by call.
+        if run.do_replace or world > 1:
+            if world > 1:
+                return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+            return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
+                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+        run.launch(L.DSQ_PH_GENE_EST)
+        hb = E._host(t.stack([run.baseMean, run.dispGeneEst])).numpy()
+        with np.errstate(invalid="ignore"):
+            use = hb[1] > 100 * 1e-8
+        if not use.any():
+            raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
+        custom = fitType(hb[0][use], hb[1][use])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            run._fit_in = t.as_tensor(np.ascontiguousarray(custom(hb[0]), dtype=np.float64), device=E.device)
+        run.args.dispFit_in = _ptr(run._fit_in)
 
     # Everything is enqueued without a host decision: the rows a rule sends on -- fitDispGrid stragglers, rows for the
     # optim fallback (R/fitNbinomGLMs.R:203-227), replaced-outlier rows -- are row-listed launches whose lengths live
@@ -440,6 +463,8 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.lam_prior = np.ascontiguousarray((1.0 / bpv) / np.log(2) ** 2)                 # R/fitNbinomGLMs.R:311,162
         run.args.lambda_prior = run.lam_prior.ctypes.data_as(C.c_void_p)
         run.launch(L.DSQ_PH_PRIOR | L.DSQ_PH_OUTLIERS)
+    elif custom is not None:
+        run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     elif world == 1 and test == "LRT" and E.record is None and dds.n >= 4096:
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
         early_host, early_done = run.early_loglike()
@@ -479,7 +504,9 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
                                           minReplicatesForReplace=minReplicatesForReplace, **kw)
         return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
                           minReplicatesForReplace=minReplicatesForReplace, **kw)
-    if sc[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]:
+    if custom is not None:
+        fn = {"fitType": "custom", "coefficients": custom, "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
+    elif sc[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]:
         fn = {"fitType": "mean", "coefficients": float(sc[0]), "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
     else:
         fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),

@@ -293,13 +293,16 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
           minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
           minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks"),
           betaPrior=False, factors=None, modelMatrixType=None, betaPriorVar=None, coef_factor=None,
-          fitType="parametric"):
+          fitType="parametric", dispFit=None, geneEstOnly=False):
     """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
     in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
     design-only quantities the R caller computes with qr() / qf() / trigamma() come from numpy / scipy here.  Returns the
     per-gene columns (NA = NaN; integer columns as float64 with NaN), the requested n x m assays, the dispersion
     function and the status counters.  fitType: "parametric" (a trend that does not fit is an error, DSQ_ERR_FIT: the R
-    caller then takes the reference's route to locfit), "mean", or "parametric_or_mean" (the mean substituted on the device)."""
+    caller then takes the reference's route to locfit), "mean", or "parametric_or_mean" (the mean substituted on the device).
+    A trend the library does not fit (fitType = "local", dispersionFunction<-): geneEstOnly = True returns after
+    estimateDispersionsGeneEst; the caller evaluates its trend at res["baseMean"] and calls again with dispFit = those values
+    (count outliers are then flagged but not replaced: the refit is the caller's, R/core.R:2484-2563)."""
     from scipy import special as sps
     if fitType not in L.DSQ_FIT:
         raise ValueError("fitType should be one of %s" % sorted(L.DSQ_FIT))
@@ -346,6 +349,9 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
             xe = _fcol(core.makeExpandedModelMatrix(factors)[0])
             pcf = coef_factor_codes(factors, expanded=True)
             pcol = xe.shape[1]
+    fit_in = None if dispFit is None else np.ascontiguousarray(dispFit, dtype=np.float64)
+    if fit_in is not None and fit_in.shape != (n,):
+        raise ValueError("dispFit needs one value per gene")
     bpv_in = None if betaPriorVar is None else np.ascontiguousarray(betaPriorVar, dtype=np.float64)
     if bpv_in is not None and bpv_in.size != pcol:
         raise ValueError("betaPriorVar needs one value per column of the (expanded) model matrix")
@@ -371,7 +377,8 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
         expVarLogDisp=evld, betaTol=float(betaTol), minmu=float(minmu), maxit=int(maxit), useQR=int(bool(useQR)),
         disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size),
         betaPrior=int(bool(betaPrior)), x_prior=_ptr(xe), p_prior=int(pcol), coef_factor=_ptr(cf),
-        prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in), fitType=L.DSQ_FIT[fitType])
+        prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in), fitType=L.DSQ_FIT[fitType],
+        dispFit=_ptr(fit_in), geneEstOnly=int(bool(geneEstOnly)))
     out = L.DsqDeseqHostOut(**{k: _ptr(v) for k, v in d.items()})
     L.check(L.lib().dsq_deseq(C.byref(args), C.byref(out)))
     res = {}
@@ -384,7 +391,8 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
             res[k] = v
     res["status"] = {k: int(out.status[i]) for k, i in L.DSQ_ST.items()}
     mean_used = out.dispersionFunction[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]
-    res["dispersionFunction"] = {"fitType": "mean" if mean_used else "parametric",
+    given = out.dispersionFunction[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["given"]
+    res["dispersionFunction"] = {"fitType": "given" if given else "mean" if mean_used else "parametric",
                                  "coefficients": float(out.dispersionFunction[0]) if mean_used else np.array(out.dispersionFunction[0:2]),
                                  "varLogDispEsts": float(out.dispersionFunction[2]),
                                  "dispPriorVar": float(out.dispersionFunction[3])}

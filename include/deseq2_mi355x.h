@@ -443,6 +443,7 @@ enum { DSQ_ST_N_NONZERO = 0, DSQ_ST_N_GRID_GENEEST, DSQ_ST_N_TREND, DSQ_ST_TREND
 #define DSQ_FIT_PARAMETRIC          0
 #define DSQ_FIT_MEAN                1    /* mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001), R/core.R:894-899 */
 #define DSQ_FIT_PARAMETRIC_OR_MEAN  2
+#define DSQ_FIT_GIVEN               3    /* (reported in DSQ_SC_FIT_USED only) the caller's trend values: dispFit_in        */
 enum { DSQ_SC_COEF0 = 0, DSQ_SC_COEF1, DSQ_SC_VAR_LOG_DISP, DSQ_SC_DISP_PRIOR_VAR,
        DSQ_SC_FIT_USED,            /* the trend the analysis ended up with: DSQ_FIT_PARAMETRIC (0.0) or DSQ_FIT_MEAN (1.0:
                                       COEF0 is the mean, COEF1 zero)                                               */
@@ -502,6 +503,13 @@ typedef struct {
     int32_t p_prior, prior_expanded, prior_intercept;   /* expanded: rank-deficient start values; first column all ones */
     const double *lambda_prior;    /* HOST, p_prior: 1 / betaPriorVar / log(2)^2; read by DSQ_PH_PRIOR / _OUTLIERS */
     int32_t fitType;               /* DSQ_FIT_*: read by DSQ_PH_TREND                                             */
+    /* the caller's dispersion trend -- what R has after fitType = "local" (locfit, R/core.R:889-893) or
+     * `dispersionFunction(dds) <- f` (R/methods.R:142-190) --, evaluated by the caller at the baseMean of every gene (the
+     * DSQ_PH_GENE_EST phase gives baseMean and dispGeneEst): device, n values.  DSQ_PH_TREND then fits nothing and takes
+     * varLogDispEsts / the prior variance from the residuals against it (against trend_fit_in, n_trend values aligned with
+     * trend_mean / trend_disp, when those are given); DSQ_PH_MAP_TEST takes dispFit from it.  The refit of replaced rows
+     * needs the trend at means the caller has not seen: do_replace must be 0 (the caller refits, R/core.R:2484-2563).  */
+    const double *dispFit_in, *trend_fit_in;
 } DsqDeseqArgs;
 
 typedef struct {
@@ -539,7 +547,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
- * Covers what the fused chain covers: parametric trend or fitType "mean", Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 24
+ * Covers what the fused chain covers: parametric trend, fitType "mean" or the caller's own trend (geneEstOnly / dispFit), Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 24
  * (10 < p: no beta prior, no observation weights, reduced model of at most 10 columns),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
@@ -588,6 +596,14 @@ typedef struct {
                                       NULL = estimated                                                              */
     int32_t fitType;               /* DSQ_FIT_PARAMETRIC (0, the default of DESeq()), DSQ_FIT_MEAN, DSQ_FIT_PARAMETRIC_OR_MEAN;
                                       dispersionFunction[DSQ_SC_FIT_USED] says which trend the results carry          */
+    /* a trend the library does not fit -- fitType = "local" (locfit: R code, R/core.R:889-893) or `dispersionFunction<-`
+     * (R/methods.R:142-190) -- in two calls: geneEstOnly = 1 runs estimateDispersionsGeneEst only (baseMean, baseVar,
+     * allZero, dispGeneEst, dispGeneIter come back; every other column NA); the caller fits its trend and calls again with
+     * dispFit = its values at baseMean (host, n; rows that are all zero: anything).  Count outliers are then flagged by
+     * Cook's distance as always, but NOT replaced: the refit needs the trend at the new means of the replaced rows, so the
+     * caller runs refitWithoutOutliers itself on the (few) rows concerned (R/core.R:2484-2563, unchanged code).        */
+    const double *dispFit;
+    int32_t geneEstOnly;
 } DsqDeseqHostArgs;
 
 typedef struct {

@@ -239,6 +239,48 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     _against_oracle(b.mcols, o, name, test)
 
 
+@pytest.mark.parametrize("shards", [0, 3])
+def test_the_callers_trend_in_two_host_calls(E, shards):
+    """what the R patch does for fitType = "local" (INTEGRATION.md section 4): dsq_deseq(geneEstOnly) -> the caller's trend at
+    baseMean -> dsq_deseq(dispFit = ...) -- against the fused chain with the same function; every other column of the first
+    call is NA; count outliers are flagged (Cook's distances) but not replaced"""
+    from tests.test_gpu_fused import _smooth_trend
+    counts, x, sf, _ = CASES["bc_outliers"]                    # cells of 8: replaceable samples, were the refit the library's
+    old = os.environ.get("DSQ_HOST_SHARDS")
+    try:
+        if shards:
+            os.environ["DSQ_HOST_SHARDS"] = str(shards)
+        first = native.DESeq(counts, x, sf, assays=(), geneEstOnly=True)
+        bm, dge = first["baseMean"], first["dispGeneEst"]
+        assert np.isnan(first["dispFit"]).all() and np.isnan(first["dispersion"]).all() and np.isnan(first["beta"]).all()
+        use = dge > 1e-6
+        f = _smooth_trend(bm[use], dge[use])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            fit = f(bm)
+        res = native.DESeq(counts, x, sf, assays=("mu", "cooks"), dispFit=fit)
+    finally:
+        if old is None:
+            os.environ.pop("DSQ_HOST_SHARDS", None)
+        else:
+            os.environ["DSQ_HOST_SHARDS"] = old
+    assert res["dispersionFunction"]["fitType"] == "given" and np.isnan(res["replace"]).all()
+    b = _dataset(counts, x, sf, {}, E)
+    fused.DESeq(b, fitType=_smooth_trend, minReplicatesForReplace=np.inf)
+    assert b.attrs.get("fused")
+    assert_same(_f(first["baseMean"]), _f(b.mcols["baseMean"]), "first call: baseMean")
+    assert_same(_f(first["dispGeneEst"]), _f(b.mcols["dispGeneEst"]), "first call: dispGeneEst")
+    mc = _mcols_of(res, "Wald")
+    for k in sorted(mc):
+        if k in b.mcols:
+            assert_same(_f(mc[k]), _f(b.mcols[k]), "second call (%d ranges): %s" % (shards, k))
+    assert res["dispersionFunction"]["varLogDispEsts"] == b.dispersionFunction["varLogDispEsts"]
+    assert res["dispersionFunction"]["dispPriorVar"] == b.dispersionFunction["dispPriorVar"]
+    nz = ~np.asarray(b.mcols["allZero"], bool)
+    for k in ("mu", "cooks"):
+        assert_same(res[k][nz], E.to_numpy(b.assays[k])[nz], "second call: assays$" + k)
+    assert (res["maxCooks"][nz] > res["cooksCutoff"]).any()     # the outliers are there for the caller's refitWithoutOutliers
+
+
 def test_a_parametric_trend_that_does_not_fit_is_reported():
     """fitType = "parametric" (DSQ_FIT_PARAMETRIC): the library does not substitute anything -- DSQ_ERR_FIT, and the R caller
     takes the reference's own route (locfit, R/core.R:885-893)"""

@@ -200,6 +200,56 @@ def test_fit_type_mean_on_the_device(E, case):
     assert (fit[~np.isnan(fit)] == b.dispersionFunction["coefficients"]).all()
 
 
+def _smooth_trend(means, disps):
+    """a stand-in for localDispersionFit (locfit is R code): a running median of the log dispersions over the log means,
+    returned as a function of the mean -- what matters to the chain is only that it is NOT of the parametric form"""
+    o = np.argsort(means)
+    lx, ly = np.log(means[o]), np.log(disps[o])
+    k = max(5, lx.size // 25)
+    knots = np.array([np.median(lx[i: i + k]) for i in range(0, lx.size - k + 1, k)])
+    vals = np.array([np.median(ly[i: i + k]) for i in range(0, lx.size - k + 1, k)])
+    return lambda q: np.exp(np.interp(np.log(q), knots, vals))
+
+
+@pytest.mark.parametrize("case", ["wald", "lrt", "weights"])
+def test_the_callers_trend_inside_the_chain(E, case):
+    """a dispersion trend the library does not fit (fitType = "local": locfit, R/core.R:889-893; dispersionFunction<-,
+    R/methods.R:142-190): gene-wise estimates up, the caller's function on the host, its values down as dispFit_in -- the
+    prior variance from the residuals against them, the MAP search around them -- against the call-by-call chain with the
+    same function.  No sample is replaceable here (the refit needs the function at new means: fused.DESeq hands such an
+    analysis to core.DESeq, checked at the end)."""
+    x = simulate.design_two_group(12)
+    d = simulate.make_counts(700, x, seed=41)
+    counts = d["counts"].copy()
+    counts[::61] = 0
+    kw = dict(fitType=_smooth_trend)
+    w = None
+    if case == "lrt":
+        kw.update(test="LRT", reduced=np.ones((12, 1)))
+    if case == "weights":
+        w = np.random.default_rng(3).uniform(0.2, 1.0, counts.shape)
+    a, b = _both(E, counts, x, d["size_factors"], weights=w, **kw)
+    assert a.dispersionFunction["fitType"] == b.dispersionFunction["fitType"] == "custom"
+    for k in [k for k in a.mcols if k != "rowsForOptim"]:
+        assert_same(np.asarray(a.mcols[k], np.float64), np.asarray(b.mcols[k], np.float64), "%s: mcols$%s" % (case, k))
+    assert a.dispersionFunction["varLogDispEsts"] == b.dispersionFunction["varLogDispEsts"]
+    assert a.dispersionFunction["dispPriorVar"] == b.dispersionFunction["dispPriorVar"]
+    fit = np.asarray(b.mcols["dispFit"], float)
+    bm = np.asarray(b.mcols["baseMean"], float)
+    live = ~np.isnan(fit)
+    assert_same(fit[live], b.dispersionFunction["coefficients"](bm[live]), "dispFit = the function at baseMean")
+    for k in ("mu", "H", "cooks"):
+        ha, hb = E.to_numpy(a.assays[k]), E.to_numpy(b.assays[k])
+        nz = a.attrs.get("nz_rows")
+        assert_same(ha, hb[nz] if nz is not None else hb, "%s: assays$%s" % (case, k))
+    # with replaceable samples the analysis goes call by call
+    x2 = simulate.design_two_group(16)
+    d2 = simulate.make_counts(200, x2, seed=42)
+    c = core.DESeqDataSet(d2["counts"], x2, sizeFactors=d2["size_factors"], engine=E)
+    fused.DESeq(c, fitType=_smooth_trend)
+    assert not c.attrs.get("fused") and c.dispersionFunction["fitType"] == "custom"
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)
