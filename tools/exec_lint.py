@@ -66,49 +66,71 @@ def blocks_of_asm(path):
 
 
 def blocks_of_disassembly(text, tag):
-    funcs = re.split(r"\n(?=[0-9a-f]{16} <)", text)
-    for f in funcs:
-        m = re.match(r"([0-9a-f]{16}) <([^>]+)>:", f)
-        if not m:
-            continue
-        base, kernel = int(m.group(1), 16), m.group(2)
-        ins = []
-        for line in f.splitlines()[1:]:
-            mm = re.match(r"\s+(\S.*?)\s+// ([0-9A-F]{12}):[^<]*(<[^>]+>)?", line)
-            if mm:
-                ins.append((int(mm.group(2), 16), mm.group(1) + (" " + mm.group(3) if mm.group(3) else "")))
-        # heads where the lanes of a region come back together: the target of a forward skip on an empty mask
-        # (s_cbranch_execz) and the fall-through of a loop's latch (a backward s_cbranch_execnz)
-        targets = set()
-        for k, (a, t) in enumerate(ins):
-            if t.startswith(("s_cbranch_execz", "s_cbranch_execnz")):
-                mt = re.search(r"<[^>]+\+0x([0-9a-f]+)>", t)
+    """heads where the lanes of a region come back together -- the target of a forward skip on an empty mask
+    (s_cbranch_execz), the fall-through of a loop's latch (a backward s_cbranch_execnz) -- with the instructions behind them"""
+    kernel, base, ins, addr = None, 0, [], []
+
+    def flush():
+        if kernel is None or not ins:
+            return
+        idx = {a: i for i, a in enumerate(addr)}
+        heads = set()
+        for k, t in enumerate(ins):
+            if t.startswith("s_cbranch_exec"):
+                mt = re.search(r"\+0x([0-9a-f]+)>", t)
                 if not mt:
                     continue
                 tg = base + int(mt.group(1), 16)
-                if tg > a:
-                    targets.add(tg)
+                if tg > addr[k]:
+                    heads.add(tg)
                 elif k + 1 < len(ins):
-                    targets.add(ins[k + 1][0])
-        idx = {a: i for i, (a, _) in enumerate(ins)}
-        for tg in sorted(targets):
-            if tg in idx:
-                i = idx[tg]
-                chunk = ins[i: i + 24]
-                yield kernel, ["%s %s+0x%x" % (tag, kernel[:60], a - base) for a, _ in chunk], [re.sub(r"\s*<[^>]+>$", "", t) for _, t in chunk]
+                    heads.add(addr[k + 1])
+        for tg in sorted(heads):
+            i = idx.get(tg)
+            if i is not None:
+                chunk = range(i, min(i + 24, len(ins)))
+                yield kernel, ["%s %s+0x%x" % (tag, kernel[:60], addr[j] - base) for j in chunk], [re.sub(r"\s*<[^>]+>$", "", ins[j]) for j in chunk]
+
+    for line in text.split("\n"):
+        c = line.find("// ")
+        if c < 0:
+            if line[:1] in "0123456789abcdef" and line.endswith(">:"):
+                yield from flush()
+                m = re.match(r"([0-9a-f]{16}) <([^>]+)>:", line)
+                kernel, base, ins, addr = (m.group(2), int(m.group(1), 16), [], []) if m else (None, 0, [], [])
+            continue
+        t = line[:c].strip()
+        rest = line[c + 3:]
+        try:
+            a = int(rest[:12], 16)
+        except ValueError:
+            continue
+        if t.startswith("s_cbranch_exec"):
+            lt = rest.find("<")
+            if lt >= 0:
+                t += " " + rest[lt:]
+        ins.append(t); addr.append(a)
+    yield from flush()
+
+
+def _lint_object(path):
+    text = subprocess.run([OBJDUMP, "-d", path], check=True, capture_output=True, text=True).stdout
+    f = os.path.basename(path)
+    return scan(blocks_of_disassembly(text, f.split(".")[2] if f.count(".") > 2 else f))
 
 
 def lint_library(so):
+    import multiprocessing
     hits = []
     tmp = tempfile.mkdtemp(prefix="dsq_lint_")
     try:
         lib = os.path.join(tmp, "lib.so")
         shutil.copy(so, lib)
         subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
-        for f in objs:
-            text = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
-            hits += scan(blocks_of_disassembly(text, f.split(".")[2] if f.count(".") > 2 else f))
+        objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f)
+        with multiprocessing.Pool(min(8, max(1, os.cpu_count() or 1))) as pool:
+            for h in pool.map(_lint_object, objs):
+                hits += h
         return hits, len(objs)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
