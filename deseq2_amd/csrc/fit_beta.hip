@@ -193,6 +193,11 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
 /* (p = 7, 8, 9 -- the builds whose p x p work sits in registers -- at one wave per SIMD: 1.98 / 2.20 / 3.43 ms against
    2.51 / 2.24 / 3.56 at two, 20 000 x 200, tools/r04u.sh) */
 #define DSQ_BETA_QRREG_MINW (DSQ_P <= 9 ? 1 : DSQ_P <= 12 ? 2 : 1)
+// QRM = 3: the same with twice the trips (m + p <= 512 at p <= 10) at one wave per SIMD -- the rows of a 500-sample
+// analysis with continuous covariates (p = 7..9: instead of the replay; p = 10: instead of the rows in LDS)
+#ifndef DSQ_BETA_QRREG2_MAXP
+#define DSQ_BETA_QRREG2_MAXP 10
+#endif
 #endif
 // per wave: QRM 1 the (m + p) x (p + 1) rows, R, gamma; QRM 2 R and gamma only
 __host__ __device__ static inline size_t beta_qr_doubles(int m, int p, int qrm = 1) {
@@ -200,8 +205,9 @@ __host__ __device__ static inline size_t beta_qr_doubles(int m, int p, int qrm =
 }
 
 template <int P, bool USE_W, bool STAGE, int QRM>
-__global__ void __launch_bounds__(256, (QRM == 1 ? 2 : QRM == 2 ? DSQ_BETA_QRREG_MINW : DSQ_BETA_MINW)) fit_beta_kernel(BetaKernelParams kp) {
+__global__ void __launch_bounds__(256, (QRM == 1 ? 2 : QRM == 2 ? DSQ_BETA_QRREG_MINW : QRM == 3 ? 1 : DSQ_BETA_MINW)) fit_beta_kernel(BetaKernelParams kp) {
     constexpr bool QRROWS = QRM == 1;
+    constexpr bool QRREG = QRM == 2 || QRM == 3;
     static_assert(QRM == 0 || STAGE, "stored rows need the staged layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(256, (QRM == 1 ? 2 : QRM == 2 ? DSQ_BETA_QRREG
         qR = qa + (size_t)M * (P + 1);
         qg = qR + P * P;
     }
-    if constexpr (QRM == 2) {
+    if constexpr (QRREG) {
         qR = smem + (kp.xlds ? (size_t)P * m : 0) + (size_t)waves * m * kSlabVecs + (size_t)waves * beta_arena_doubles(P) +
              (size_t)wave * beta_qr_doubles(m, P, 2);
         qg = qR + P * P;
@@ -306,9 +312,9 @@ DSQ_UNROLL_P
             for (int c = 0; c < P; c++) beta_prev[c] = beta[c];
             if (abl & 2) {
                 // (ablated: no least-squares solve)
-            } else if (QRM == 2 && kp.useQR) {
-                if constexpr (QRM == 2) {
-                constexpr int T = DSQ_BETA_QRREG_TRIPS;
+            } else if (QRREG && kp.useQR) {
+                if constexpr (QRREG) {
+                constexpr int T = (QRM == 3 ? 2 : 1) * DSQ_BETA_QRREG_TRIPS;
                 double ar[T][P + 1];
                 // pass A: row i = lane + 64 t of [sqrt(w) X ; sqrt(ridge) | sqrt(w) z] into registers
                 _Pragma("unroll")
@@ -1549,18 +1555,20 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
     // rows in registers (QRM 2): whenever the least squares has at most 64 T rows -- the LDS then admits the register budget's
     // resident waves at every width
     static const int qrreg_env = getenv("DSQ_BETA_QRREG") ? atoi(getenv("DSQ_BETA_QRREG")) : 1;
-    if (want_qrrows && qrreg_env && P >= DSQ_BETA_QRREG_MIN && m + P <= 64 * DSQ_BETA_QRREG_TRIPS && tu.beta_stage != 0) {
+    const int reg_trips = m + P <= 64 * DSQ_BETA_QRREG_TRIPS ? 1 : (P <= DSQ_BETA_QRREG2_MAXP && qrreg_env != 2 && m + P <= 128 * DSQ_BETA_QRREG_TRIPS) ? 2 : 0;
+    if (want_qrrows && qrreg_env && P >= DSQ_BETA_QRREG_MIN && reg_trips && tu.beta_stage != 0) {
+        const int regw = reg_trips == 2 ? 1 : DSQ_BETA_QRREG_MINW;
         int qbest = -1, qw = 0, qx = 0;
         for (int xl = tu.beta_xlds ? 1 : 0; xl >= 0; xl--)
             for (int w = wmax; w >= 1; w >>= 1) {
                 size_t need = beta_lds_doubles(m, P, w, xl, 2) * sizeof(double);
                 if (need > budget) continue;
                 int wpc = w * (int)(cu_lds / need);
-                if (wpc > 4 * DSQ_BETA_QRREG_MINW) wpc = 4 * DSQ_BETA_QRREG_MINW;
+                if (wpc > 4 * regw) wpc = 4 * regw;
                 int score = wpc * 100 + w * 2 + xl;
                 if (score > qbest) { qbest = score; qw = w; qx = xl; }
             }
-        if (qbest >= 0) { qr = true; qrm = 2; *stage = true; *waves = qw; *xlds = qx; }
+        if (qbest >= 0) { qr = true; qrm = 1 + reg_trips; *stage = true; *waves = qw; *xlds = qx; }
     }
     if (!qr && want_qrrows && P >= DSQ_BETA_QRROWS_MIN && tu.beta_stage != 0) {
         int qbest = -1, qw = 0, qx = 0;
@@ -1599,13 +1607,15 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
         while (*waves > 1 && (size_t)*waves * beta_arena_doubles(P) * sizeof(double) > budget) *waves >>= 1;
     *lds = *stage ? beta_lds_doubles(m, P, *waves, *xlds, qrm) * sizeof(double)
                   : (size_t)*waves * beta_arena_doubles(P) * sizeof(double);     // unstaged: only the WIDE arena
-    static thread_local int bpc_cache[4][2][8];   // [stage + stored rows][useW][waves]: the occupancy query costs ~1 ms, ask once
-    static thread_local size_t lds_cache[4][2][8];
+    static thread_local int bpc_cache[5][2][8];   // [stage + stored rows][useW][waves]: the occupancy query costs ~1 ms, ask once
+    static thread_local size_t lds_cache[5][2][8];
     DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
     const int ci = qr ? 1 + qrm : (*stage ? 1 : 0);
     if (lds_cache[ci][useW][*waves] != *lds) { bpc_cache[ci][useW][*waves] = 0; lds_cache[ci][useW][*waves] = *lds; }
     int bpc = bpc_cache[ci][useW][*waves];
-    const void *fn = qrm == 2 ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRREG_MIN ? 2 : 0)>
+    constexpr int kQreg2 = (P >= DSQ_BETA_QRREG_MIN && P <= DSQ_BETA_QRREG2_MAXP) ? 3 : 0;
+    const void *fn = qrm == 3 ? (useW ? (const void *)fit_beta_kernel<P, true, true, kQreg2> : (const void *)fit_beta_kernel<P, false, true, kQreg2>)
+                  : qrm == 2 ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRREG_MIN ? 2 : 0)>
                                       : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRREG_MIN ? 2 : 0)>)
                   : qr ? (useW ? (const void *)fit_beta_kernel<P, true, true, (P >= DSQ_BETA_QRROWS_MIN ? 1 : 0)>
                                : (const void *)fit_beta_kernel<P, false, true, (P >= DSQ_BETA_QRROWS_MIN ? 1 : 0)>)
@@ -1652,7 +1662,13 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
     kp.xlds = xlds;
     if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();   // a row list: its length lives on the device
     constexpr int kQr = (DSQ_P >= DSQ_BETA_QRROWS_MIN) ? 1 : 0, kQreg = (DSQ_P >= DSQ_BETA_QRREG_MIN) ? 2 : 0;
-    if (qr == 2) {
+    constexpr int kQreg2 = (DSQ_P >= DSQ_BETA_QRREG_MIN && DSQ_P <= DSQ_BETA_QRREG2_MAXP) ? 3 : 0;
+    if (qr == 3) {
+        if (kp.useWeights)
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, kQreg2>), dim3(grid), dim3(64 * waves), lds, st, kp);
+        else
+            hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, false, true, kQreg2>), dim3(grid), dim3(64 * waves), lds, st, kp);
+    } else if (qr == 2) {
         if (kp.useWeights)
             hipLaunchKernelGGL((fit_beta_kernel<DSQ_P, true, true, kQreg>), dim3(grid), dim3(64 * waves), lds, st, kp);
         else

@@ -87,7 +87,9 @@ def test_wide_chain_with_optim_rows_matches_oracle(oracle):
 @pytest.mark.parametrize("p,m,useW,useQR", [
     (10, 200, False, True), (10, 500, True, True), (10, 130, False, False),       # stored-row QR (LDS) from p = 10
     (9, 250, False, True), (9, 300, True, True), (7, 256, False, True), (7, 257, False, True),   # serial Gram up to m = 256 below p = 10
-    (16, 120, False, True), (16, 400, True, True), (24, 100, False, True), (24, 260, False, True), (12, 1100, False, True)])
+    (16, 120, False, True), (16, 400, True, True), (24, 100, False, True), (24, 260, False, True), (12, 1100, False, True),
+    # round 4: rows in registers, four trips (m + p <= 256) / eight trips (<= 512, p <= 10) and the first shapes beyond
+    (8, 248, True, True), (8, 440, False, True), (10, 502, False, True), (10, 503, False, True), (16, 304, False, True), (16, 305, True, True)])
 def test_general_path_kernels_match_oracle(oracle, p, m, useW, useQR):
     """designs with a CONTINUOUS covariate (one design cell per sample) at the widths where round 3 changed the general
     kernels: fitBeta's stored-row Householder QR (rows of the least squares in LDS, p >= 10; the replay where they do
