@@ -176,6 +176,7 @@ class DsqDeseqArgs(C.Structure):
         ("n_refit_global", C.c_void_p), ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32),
         ("prior_expanded", C.c_int32), ("prior_intercept", C.c_int32), ("lambda_prior", C.c_void_p),
         ("fitType", C.c_int32), ("dispFit_in", C.c_void_p), ("trend_fit_in", C.c_void_p),
+        ("dispPriorVar_in", C.c_double),
     ]
 
 
@@ -200,6 +201,7 @@ class DsqDeseqHostArgs(C.Structure):
         ("betaPrior", C.c_int32), ("x_prior", C.c_void_p), ("p_prior", C.c_int32), ("coef_factor", C.c_void_p),
         ("prior_coef_factor", C.c_void_p), ("prior_coef_src", C.c_void_p), ("betaPriorVar", C.c_void_p),
         ("fitType", C.c_int32), ("dispFit", C.c_void_p), ("geneEstOnly", C.c_int32),
+        ("dispPriorVar", C.c_double),
     ]
 
 

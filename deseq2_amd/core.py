@@ -651,11 +651,13 @@ def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, ka
     return dds
 
 
-def estimateDispersions(dds, fitType="parametric", maxit=100, **kw):
-    """R/methods.R:500-563 (maxit is handed to both dispersion searches, :520,:546)"""
+def estimateDispersions(dds, fitType="parametric", maxit=100, dispPriorVar=None, **kw):
+    """R/methods.R:500-563 (maxit is handed to both dispersion searches, :520,:546).  dispPriorVar: the argument of
+    estimateDispersionsMAP (R/core.R:989-994) for callers that run the three steps themselves -- the way an analysis with
+    residual df <= 3 gets its prior variance (R's estimate there needs R's RNG, :1155-1190)."""
     estimateDispersionsGeneEst(dds, maxit=maxit, **kw)
     estimateDispersionsFit(dds, fitType=fitType)
-    estimateDispersionsMAP(dds, maxit=maxit)
+    estimateDispersionsMAP(dds, maxit=maxit, dispPriorVar=dispPriorVar)
     return dds
 
 
@@ -1048,7 +1050,8 @@ def cooksOutlier(dds, cooksCutoff=None):
 
 
 def _DESeqNZ(dds, test, fitType, reduced, minReplicatesForReplace, disp_maxit=100, **kw):
-    estimateDispersions(dds, fitType=fitType, maxit=disp_maxit, minmu=kw.get("minmu", 0.5))      # R/core.R:393
+    dpv = kw.pop("dispPriorVar", None)      # (not an argument of R's DESeq(): of estimateDispersionsMAP, R/core.R:989-994)
+    estimateDispersions(dds, fitType=fitType, maxit=disp_maxit, minmu=kw.get("minmu", 0.5), dispPriorVar=dpv)      # R/core.R:393
     if test == "Wald":
         nbinomWaldTest(dds, **kw)
     elif test == "LRT":

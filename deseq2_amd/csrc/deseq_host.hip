@@ -203,8 +203,8 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns", a->p, DSQ_P_WIDE);
     if (a->p > DSQ_P_REG && (a->betaPrior || a->weights || (a->x_reduced && a->p_reduced > DSQ_P_REG)))
         return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns together with a beta prior, observation weights or a reduced model of more than %d columns", a->p, DSQ_P_REG, DSQ_P_REG);
-    if (a->m - a->p <= 3)
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is not available", a->m - a->p);
+    if (a->m - a->p <= 3 && !a->geneEstOnly && !(a->dispPriorVar > 0.0))
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is the caller's -- geneEstOnly, then dispPriorVar", a->m - a->p);
     if (!(a->cooksCutoff > 0.0) || !(a->expVarLogDisp > 0.0)) return capi_fail(DSQ_ERR_ARG, "cooksCutoff = qf(.99, p, m - p) and expVarLogDisp = trigamma((m - p) / 2) must be given");
     if (a->maxit < 1 || a->disp_maxit < 1 || !(a->betaTol > 0.0) || !(a->minmu > 0.0)) return capi_fail(DSQ_ERR_ARG, "betaTol / maxit / minmu / disp_maxit");
     if (!(a->minReplicatesForReplace >= 3.0)) return capi_fail(DSQ_ERR_ARG, "at least 3 replicates are necessary in order to indentify a sample as a count outlier");
@@ -319,6 +319,7 @@ static int deseq_range(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o, const Fact
     d.disp_grid = dd + off_g; d.ngrid = (int32_t)F.grid.size(); d.expVarLogDisp = a->expVarLogDisp;
     d.n_trend = nt; d.lambda = F.lam.data(); d.min_log_alpha = std::log(1e-8 / 10.0);
     d.workspace = work; d.workspace_bytes = wsb; d.test = a->test; d.fitType = a->fitType;
+    d.dispPriorVar_in = a->dispPriorVar > 0.0 ? a->dispPriorVar : 0.0;
     d.cell_of = F.cells.data(); d.ncell = F.ncell; d.replaceable = F.replaceable.data();
     d.cooksCutoff = a->cooksCutoff; d.trim = 0.2; d.do_replace = F.do_replace;      // (dispFit given: Facts leaves it 0)
     if (pr) {

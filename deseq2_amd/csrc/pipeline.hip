@@ -170,7 +170,8 @@ DSQ_DEV double block_median(int n, long k, F &&value, unsigned *hist, unsigned l
 
 __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, const double *disp, int n, double minDisp,
                                                          double expVarLogDisp, int m_gt_p, double *resbuf,
-                                                         double *scalars, int32_t *status, const double *fit_in) {
+                                                         double *scalars, int32_t *status, const double *fit_in,
+                                                         double pv_in) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long bc[2];
     __shared__ int kshared;
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, con
             const double t = v - expVarLogDisp;
             pv = (0.25 > t) ? 0.25 : t;                           // max(varLogDispEsts - expVarLogDisp, 0.25), :1200
         }
+        if (pv_in > 0.0) pv = pv_in;                              // estimateDispersionsMAP(dispPriorVar = x), :989-994
         scalars[DSQ_SC_DISP_PRIOR_VAR] = pv;
     }
 }
@@ -1217,8 +1219,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (a->ld < a->m) return capi_fail(DSQ_ERR_ARG, "ld < m");
     // estimateDispersionsPriorVar's branch for 1..3 residual degrees of freedom matches a seeded Monte-Carlo sample
     // (R/core.R:1155-1190, R's RNG + loess): not reproducible here, so the prior variance is not computed at all
-    if ((a->phases & DSQ_PH_TREND) && a->m - a->p <= 3)
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is not available", a->m - a->p);
+    if ((a->phases & DSQ_PH_TREND) && a->m - a->p <= 3 && !(a->dispPriorVar_in > 0.0))
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is the caller's (dispPriorVar_in)", a->m - a->p);
     if (!a->y || !a->nf || !a->x || !a->q || !a->a || !a->r || !a->disp_grid || a->ngrid < 2 || !a->lambda) return capi_fail(DSQ_ERR_ARG, "NULL input");
     if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
@@ -1394,7 +1396,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         capi_prof_begin("prior_var", nt, st);
         hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
                            (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status,
-                           a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr);
+                           a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr,
+                           a->dispPriorVar_in);
         capi_prof_end(st);
         PIPE_HIP(hipGetLastError());
     }

@@ -286,7 +286,9 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
                           SEXP fitTypeSEXP,
                           /* a trend R fits itself (fitType = "local", dispersionFunction<-): geneEstOnly TRUE = stop after
                            * estimateDispersionsGeneEst; dispFit = the trend at res$baseMean (or NULL), see dsq_deseq */
-                          SEXP dispFitSEXP, SEXP geneEstOnlySEXP) {
+                          SEXP dispFitSEXP, SEXP geneEstOnlySEXP,
+                          /* estimateDispersionsMAP(dispPriorVar = x) or NULL (estimated; m - p <= 3: required) */
+                          SEXP dispPriorVarSEXP) {
     int np = 0;
     R_CheckUserInterrupt();
     int n = Rf_nrows(countsSEXP), m = Rf_ncols(countsSEXP), p = Rf_ncols(xSEXP);
@@ -360,6 +362,7 @@ SEXP _DESeq2_mi355x_DESeq(SEXP countsSEXP, SEXP xSEXP, SEXP sizeFactorsSEXP, SEX
     a.minmu = scalar_d(minmuSEXP); a.disp_maxit = scalar_i(dispMaxitSEXP); a.useCR = scalar_b(useCRSEXP);
     a.fitType = scalar_i(fitTypeSEXP);
     a.geneEstOnly = scalar_b(geneEstOnlySEXP);
+    if (dispPriorVarSEXP != R_NilValue) a.dispPriorVar = scalar_d(dispPriorVarSEXP);
     if (dispFitSEXP != R_NilValue) {
         need_length(dispFitSEXP, n, "dispFit");
         SEXP df = as_real(dispFitSEXP, &np);
@@ -423,7 +426,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_DESeq2_mi355x_nbinomLogLike", (DL_FUNC)&_DESeq2_mi355x_nbinomLogLike, 5},
     {"_DESeq2_mi355x_cooks", (DL_FUNC)&_DESeq2_mi355x_cooks, 6},
     {"_DESeq2_mi355x_replace", (DL_FUNC)&_DESeq2_mi355x_replace, 6},
-    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 30},
+    {"_DESeq2_mi355x_DESeq", (DL_FUNC)&_DESeq2_mi355x_DESeq, 31},
     {NULL, NULL, 0}};
 
 void R_init_DESeq2(DllInfo *dll) {

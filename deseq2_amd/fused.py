@@ -35,7 +35,8 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3
     # branch of estimateDispersionsPriorVar (seeded Monte-Carlo matching, R/core.R:1155-1190: not mirrored, core raises
     # NotImplementedError) are left to the call-by-call code, which reports them
-    if dds.m - dds.p <= 3 or core._rank(dds.x) < dds.p:
+    # ... unless the caller brings the prior variance (estimateDispersionsMAP(dispPriorVar = x), R/core.R:989-994)
+    if (dds.m - dds.p <= 3 and not kw.get("dispPriorVar")) or dds.m <= dds.p or core._rank(dds.x) < dds.p:
         return False
     if kw.get("modelMatrix") is not None or not kw.get("useOptim", True):
         return False
@@ -53,7 +54,7 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
     if kw.get("useT") and test != "Wald":
         return False
     if set(kw) - {"betaPrior", "betaPriorVar", "modelMatrixType", "factors", "modelMatrix", "useT", "df", "useOptim", "betaTol",
-                  "maxit", "useQR", "minmu", "disp_maxit", "minReplicatesForReplace"}:
+                  "maxit", "useQR", "minmu", "disp_maxit", "minReplicatesForReplace", "dispPriorVar"}:
         return False
     if test == "LRT":
         # reduced = ~1 takes the closed form (R/fitNbinomGLMs.R:99-137); any other reduced model matrix is fitted by the
@@ -396,6 +397,8 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     # estimateDispersionsFit (R/core.R:864-939): "mean" on the device; a parametric trend that does not fit is replaced
     # by the mean there as well (core.estimateDispersionsFit's substitute for the reference's locfit fallback)
     run.args.fitType = L.DSQ_FIT["mean" if fitType == "mean" else "parametric_or_mean"]
+    if kw.get("dispPriorVar"):
+        run.args.dispPriorVar_in = float(kw["dispPriorVar"])
     custom = None
     if callable(fitType):
         # the caller's trend (core.estimateDispersionsFit: what R has after fitType = "local" or dispersionFunction<-):

@@ -293,7 +293,7 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
           minReplicatesForReplace=7, betaTol=1e-8, maxit=100, useQR=True,
           minmu=0.5, disp_maxit=100, useCR=True, assays=("mu", "H", "cooks"),
           betaPrior=False, factors=None, modelMatrixType=None, betaPriorVar=None, coef_factor=None,
-          fitType="parametric", dispFit=None, geneEstOnly=False):
+          fitType="parametric", dispFit=None, geneEstOnly=False, dispPriorVar=None):
     """dsq_deseq: DESeq() behind ONE host-pointer call (what r_shim.c binds as _DESeq2_mi355x_DESeq; the R-side glue is
     in INTEGRATION.md).  counts: n x m integer matrix in R orientation; x: m x p model matrix; sizeFactors: m.  The three
     design-only quantities the R caller computes with qr() / qf() / trigamma() come from numpy / scipy here.  Returns the
@@ -302,7 +302,9 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
     caller then takes the reference's route to locfit), "mean", or "parametric_or_mean" (the mean substituted on the device).
     A trend the library does not fit (fitType = "local", dispersionFunction<-): geneEstOnly = True returns after
     estimateDispersionsGeneEst; the caller evaluates its trend at res["baseMean"] and calls again with dispFit = those values
-    (count outliers are then flagged but not replaced: the refit is the caller's, R/core.R:2484-2563)."""
+    (count outliers are then flagged but not replaced: the refit is the caller's, R/core.R:2484-2563).  dispPriorVar: the
+    argument of estimateDispersionsMAP (R/core.R:989-994); required for m - p <= 3, where R's own estimate is a seeded
+    Monte-Carlo match (:1155-1190) the library leaves to the caller."""
     from scipy import special as sps
     if fitType not in L.DSQ_FIT:
         raise ValueError("fitType should be one of %s" % sorted(L.DSQ_FIT))
@@ -378,7 +380,8 @@ def DESeq(counts, x, sizeFactors=None, test="Wald", reduced=None, normalizationF
         disp_maxit=int(disp_maxit), useCR=int(bool(useCR)), disp_grid=_ptr(grid), ngrid=int(grid.size),
         betaPrior=int(bool(betaPrior)), x_prior=_ptr(xe), p_prior=int(pcol), coef_factor=_ptr(cf),
         prior_coef_factor=_ptr(pcf), prior_coef_src=None, betaPriorVar=_ptr(bpv_in), fitType=L.DSQ_FIT[fitType],
-        dispFit=_ptr(fit_in), geneEstOnly=int(bool(geneEstOnly)))
+        dispFit=_ptr(fit_in), geneEstOnly=int(bool(geneEstOnly)),
+        dispPriorVar=0.0 if dispPriorVar is None else float(dispPriorVar))
     out = L.DsqDeseqHostOut(**{k: _ptr(v) for k, v in d.items()})
     L.check(L.lib().dsq_deseq(C.byref(args), C.byref(out)))
     res = {}

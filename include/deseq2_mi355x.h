@@ -510,6 +510,10 @@ typedef struct {
      * trend_mean / trend_disp, when those are given); DSQ_PH_MAP_TEST takes dispFit from it.  The refit of replaced rows
      * needs the trend at means the caller has not seen: do_replace must be 0 (the caller refits, R/core.R:2484-2563).  */
     const double *dispFit_in, *trend_fit_in;
+    /* estimateDispersionsMAP(dispPriorVar = x) (R/core.R:970,989-994): > 0 = the caller's prior variance, taken instead of
+     * the estimate (varLogDispEsts is still computed: the dispOutlier rule reads it).  The way residual df <= 3 runs on the
+     * chain: R's estimate there is a seeded Monte-Carlo match (R/core.R:1155-1190, R's RNG + loess), the caller's job.   */
+    double dispPriorVar_in;
 } DsqDeseqArgs;
 
 typedef struct {
@@ -604,6 +608,9 @@ typedef struct {
      * caller runs refitWithoutOutliers itself on the (few) rows concerned (R/core.R:2484-2563, unchanged code).        */
     const double *dispFit;
     int32_t geneEstOnly;
+    double dispPriorVar;           /* > 0: estimateDispersionsMAP(dispPriorVar = x), R/core.R:989-994 -- required when m - p <= 3
+                                      (R's estimate there is a seeded Monte-Carlo match over the residuals of the trend,
+                                      R/core.R:1155-1190: after the geneEstOnly call the caller has what it needs)       */
 } DsqDeseqHostArgs;
 
 typedef struct {

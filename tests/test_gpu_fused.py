@@ -250,6 +250,31 @@ def test_the_callers_trend_inside_the_chain(E, case):
     assert not c.attrs.get("fused") and c.dispersionFunction["fitType"] == "custom"
 
 
+@pytest.mark.parametrize("m", [4, 5])
+def test_residual_df_of_at_most_three_with_the_callers_prior_variance(E, m):
+    """m - p <= 3 (two against two, three against two): R's estimateDispersionsPriorVar is a seeded Monte-Carlo match there
+    (R/core.R:1155-1190, R's RNG and loess) -- the caller's job; with estimateDispersionsMAP's dispPriorVar argument
+    (:989-994) the analysis runs on the chain, against the call-by-call chain and through the host entry"""
+    from deseq2_amd import native
+    x = simulate.design_two_group(m) if m % 2 == 0 else np.column_stack([np.ones(m), (np.arange(m) >= 3).astype(float)])
+    d = simulate.make_counts(600, x, seed=51, intercept_mean=6.0)
+    dds = core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E)
+    assert not fused.supported(dds)                               # without the prior variance: left to the caller
+    with pytest.raises(NotImplementedError):
+        core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=E))
+    a, b = _both(E, d["counts"], x, d["size_factors"], dispPriorVar=0.7)
+    assert a.dispersionFunction["dispPriorVar"] == b.dispersionFunction["dispPriorVar"] == 0.7
+    _compare(a, b, "df = %d" % (m - 2))
+    with pytest.raises(Exception, match="residual degrees of freedom"):
+        native.DESeq(d["counts"], x, d["size_factors"], assays=())
+    first = native.DESeq(d["counts"], x, d["size_factors"], assays=(), geneEstOnly=True)
+    assert_same(np.asarray(first["dispGeneEst"], float), np.asarray(b.mcols["dispGeneEst"], float), "geneEstOnly: dispGeneEst")
+    res = native.DESeq(d["counts"], x, d["size_factors"], assays=(), dispPriorVar=0.7)
+    for k, kb in (("dispMAP", "dispMAP"), ("dispersion", "dispersion"), ("beta", "beta"), ("stat", "WaldStatistic"), ("maxCooks", "maxCooks")):
+        assert_same(np.asarray(res[k], float), np.asarray(b.mcols[kb], float), "host entry: " + k)
+    assert res["dispersionFunction"]["dispPriorVar"] == 0.7
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)
