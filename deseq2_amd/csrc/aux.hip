@@ -275,9 +275,7 @@ __device__ __forceinline__ void grid_barrier(TrendWs *ws) {
 template <int K>
 __device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], TrendWs *ws, int &parity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (one value at a time: the interleaved form keeps 2 K extra registers live, and a 1024-thread block has 128 per lane)
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = wave_allreduce(v[k]);
+    wave_allreduce_many(v, lane);         // (the bits of K butterflies, dsq_wave.hpp)
     __syncthreads();                      // previous use of `red` is complete
     if (lane == 0) {
 #pragma unroll
@@ -291,17 +289,23 @@ __device__ __forceinline__ void grid_sum(double (&v)[K], double (*red)[8], Trend
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     grid_barrier(ws);
+    // the block sums of every workgroup, added in workgroup order: thread k takes sum k -- its 16 loads in flight together
+    // (round 4: every thread used to fetch all K x 16 values itself, two at a time: ~ 60 dependent L2 round trips per pass)
+    // -- and hands the total to the block through LDS
+    if (threadIdx.x < K) {
+        double t[kTrendBlocks];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        double tot = 0.0;
-#pragma unroll 2
-        for (int b = 0; b < kTrendBlocks; b++) {       // (not unrolled further: K x 16 loads in flight would spill)
-            double t = __longlong_as_double((long long)__hip_atomic_load(&ws->sums[parity][b][k], __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_AGENT));
-            tot = (b == 0) ? t : tot + t;
-        }
-        v[k] = tot;
+        for (int b = 0; b < kTrendBlocks; b++)
+            t[b] = __longlong_as_double((long long)__hip_atomic_load(&ws->sums[parity][b][threadIdx.x], __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT));
+        double tot = t[0];
+#pragma unroll
+        for (int b = 1; b < kTrendBlocks; b++) tot = tot + t[b];
+        red[0][threadIdx.x] = tot;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = red[0][k];
     parity ^= 1;
 }
 
