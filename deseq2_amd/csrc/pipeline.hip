@@ -222,6 +222,162 @@ __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, con
     }
 }
 
+// ---- the same on SIXTEEN workgroups (round 4): the one-workgroup kernel above spends 0.24 ms on 50 000 genes -- its thirteen
+// selection passes and the two logarithms per gene all on one CU -- and every rank of a gene-sharded run pays it on the
+// gathered vectors.  Here each workgroup histograms its slice, the histograms meet in a global table (one per pass, zeroed
+// by the launch), a grid barrier, and every workgroup scans the table itself: the selected order statistics are exact, so
+// nothing changes in the results.  The workgroups must be co-resident: 16 x 1024 threads on a 256-CU device.
+static constexpr int kSelBlocks = 16;
+struct SelWs {
+    unsigned int count, gen;
+    unsigned int pad[14];
+    unsigned long long cnt[8];
+    unsigned long long inv_min[8];       // ~key of the smallest value above a median candidate (atomicMax; zero = none)
+    unsigned int ghist[16][2048];
+};
+size_t prior_var_workspace_bytes() { return sizeof(SelWs); }
+
+DSQ_DEV void sel_barrier(SelWs *ws) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned g = __hip_atomic_load(&ws->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        unsigned arrived = atomicAdd(&ws->count, 1u);
+        if (arrived == (unsigned)kSelBlocks - 1u) {
+            atomicExch(&ws->count, 0u);
+            __threadfence();
+            atomicAdd(&ws->gen, 1u);
+        } else {
+            while (__hip_atomic_load(&ws->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(2);
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+template <class F>
+DSQ_DEV double grid_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc, SelWs *ws, int &phase) {
+    uint64_t prefix = 0, mask = 0;
+    int shift = 64;
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
+    while (shift > 0) {
+        const int bits = shift >= 11 + 9 ? 11 : shift;         // 64 = 5 x 11 + 9
+        shift -= bits;
+        const unsigned nb = 1u << bits;
+        for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (long i = first; i < n; i += stride) {
+            uint64_t k = key_of(value((int)i));
+            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & (nb - 1u)], 1u);
+        }
+        __syncthreads();
+        unsigned *gh = ws->ghist[phase];
+        for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) { const unsigned h = hist[b]; if (h) atomicAdd(&gh[b], h); }
+        sel_barrier(ws);
+        for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = __hip_atomic_load(&gh[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            long r = rank;
+            int found = -1;
+            for (unsigned b0 = 0; b0 < nb && found < 0; b0 += 64) {
+                const unsigned h = hist[b0 + threadIdx.x];
+                unsigned incl = h;
+                for (int o = 1; o < 64; o <<= 1) {
+                    unsigned v = __shfl_up(incl, o, 64);
+                    if ((int)threadIdx.x >= o) incl += v;
+                }
+                const unsigned tot = __shfl(incl, 63, 64);
+                if (r < (long)tot) {
+                    const unsigned long long m = __ballot((long)incl > r);
+                    const int l = __ffsll((long long)m) - 1;
+                    const unsigned before = __shfl(incl, l, 64) - __shfl(h, l, 64);
+                    found = (int)b0 + l;
+                    r -= (long)before;
+                } else {
+                    r -= (long)tot;
+                }
+            }
+            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; }
+        }
+        __syncthreads();
+        prefix |= (uint64_t)bc[0] << shift;
+        mask |= (uint64_t)(nb - 1u) << shift;
+        rank = (long)bc[1];
+        __syncthreads();
+        phase++;
+    }
+    return double_of(prefix);
+}
+
+template <class F>
+DSQ_DEV double grid_median(int n, long k, F &&value, unsigned *hist, unsigned long long *bc, SelWs *ws, int &phase, int slot) {
+    const double a = grid_select(n, (k - 1) / 2, value, hist, bc, ws, phase);
+    if (k & 1) return a;
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
+    unsigned long long le = 0, inv = 0;
+    for (long i = first; i < n; i += stride) {
+        const double v = value((int)i);
+        if (v <= a) le++;
+        else { const unsigned long long kv = ~key_of(v); if (kv > inv) inv = kv; }
+    }
+    if (le) atomicAdd(&ws->cnt[slot], le);
+    if (inv) atomicMax(&ws->inv_min[slot], inv);
+    sel_barrier(ws);
+    const unsigned long long tot = __hip_atomic_load(&ws->cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long iv = __hip_atomic_load(&ws->inv_min[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double b = ((long)tot > k / 2) ? a : double_of(~iv);
+    return (a + b) * 0.5;
+}
+
+__global__ void __launch_bounds__(1024) prior_var_grid_kernel(const double *mean, const double *disp, int n, double minDisp,
+                                                              double expVarLogDisp, int m_gt_p, double *resbuf, double *scalars,
+                                                              int32_t *status, const double *fit_in, double pv_in, SelWs *ws) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long bc[2];
+    const double inf = __builtin_inf();
+    const double c0 = scalars[DSQ_SC_COEF0], c1 = scalars[DSQ_SC_COEF1];
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
+    unsigned long long c = 0;
+    for (long i = first; i < n; i += stride) {
+        const double d = disp[i];
+        const bool above = d >= minDisp * 100.0;                 // aboveMinDisp, R/core.R:897 / :1137
+        double r = inf;
+        if (above) {
+            const double fit = fit_in ? fit_in[i] : c0 + c1 / mean[i];
+            r = dlog(d) - dlog(fit);
+            c++;
+        }
+        resbuf[i] = r;                                           // (read back by this thread only)
+    }
+    if (c) atomicAdd(&ws->cnt[7], c);
+    sel_barrier(ws);
+    const long k = (long)__hip_atomic_load(&ws->cnt[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (writer) status[DSQ_ST_N_ABOVE_MIN] = (int32_t)k;
+    if (k == 0) {
+        if (writer) { scalars[DSQ_SC_VAR_LOG_DISP] = dnan(); scalars[DSQ_SC_DISP_PRIOR_VAR] = dnan(); }
+        return;
+    }
+    int phase = 0;
+    const double med = grid_median(n, k, [&](int i) { return resbuf[i]; }, hist, bc, ws, phase, 0);
+    const double med2 = grid_median(n, k, [&](int i) {
+        const double r = resbuf[i];
+        return (r == inf) ? inf : __builtin_fabs(r - med);
+    }, hist, bc, ws, phase, 1);
+    if (writer) {
+        const double mad = 1.4826 * med2;
+        const double v = mad * mad;
+        scalars[DSQ_SC_VAR_LOG_DISP] = v;
+        double pv = v;
+        if (m_gt_p) {
+            const double t = v - expVarLogDisp;
+            pv = (0.25 > t) ? 0.25 : t;                           // max(varLogDispEsts - expVarLogDisp, 0.25), :1200
+        }
+        if (pv_in > 0.0) pv = pv_in;                              // estimateDispersionsMAP(dispPriorVar = x), :989-994
+        scalars[DSQ_SC_DISP_PRIOR_VAR] = pv;
+    }
+}
+
 // ---- fitType = "mean" (R/core.R:894-899): mean(dispGeneEst[dispGeneEst > 10 minDisp], trim = 0.001) ----------------
 // R: the values between the floor(N trim)-th order statistics from either end, then a long-double mean with a
 // correction pass -- to double precision the correctly rounded mean.  Here: the two order statistics by radix selection
@@ -599,7 +755,7 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
                              hipGetErrorString(e_));                                                     \
     } while (0)
 
-enum { DSQ_WS_PIPE_PADX = 38 };      // (a free slot between the call slots and the chain's: the padded design)
+enum { DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };      // (a free slot between the call slots and the chain's: the padded design)
 static inline int kern_width(int p) { return p > DSQ_P_REG ? (p <= DSQ_P_WIDE0 ? DSQ_P_WIDE0 : DSQ_P_WIDE) : p; }
 
 struct Pipe {
@@ -1397,10 +1553,21 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         }
         capi_prof_end(st);
         capi_prof_begin("prior_var", nt, st);
-        hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
-                           (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status,
-                           a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr,
-                           a->dispPriorVar_in);
+        {
+            const double *fin = a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr;
+            static const int one_block = getenv("DSQ_PRIOR_VAR_ONE_BLOCK") ? atoi(getenv("DSQ_PRIOR_VAR_ONE_BLOCK")) : 0;
+            if (one_block || nt < 16384)          // (6 250 genes: 0.116 ms on one workgroup, 0.146 on sixteen; 50 000: 0.243 / 0.124)
+                hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
+                                   (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status, fin, a->dispPriorVar_in);
+            else {
+                void *sws;
+                rc = capi_ws_get(DSQ_WS_PIPE_SEL, prior_var_workspace_bytes() + 64, &sws);
+                if (rc) return rc;
+                PIPE_HIP(hipMemsetAsync(sws, 0, prior_var_workspace_bytes(), st));
+                hipLaunchKernelGGL(prior_var_grid_kernel, dim3(kSelBlocks), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
+                                   (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status, fin, a->dispPriorVar_in, (SelWs *)sws);
+            }
+        }
         capi_prof_end(st);
         PIPE_HIP(hipGetLastError());
     }
