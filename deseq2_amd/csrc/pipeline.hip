@@ -45,40 +45,54 @@ __global__ void __launch_bounds__(1024) compact_kernel(int mode, int n, int32_t 
                                                        const double *mean_in, const double *disp_in, double thresh,
                                                        int32_t *rows_out, double *mean_out, double *disp_out,
                                                        int32_t *count_out) {
-    // tiles of 1024 consecutive elements (coalesced), kept elements ranked by wave ballots + a 16-entry prefix
-    __shared__ int wcnt[16];
+    // tiles of 1024 consecutive elements (coalesced), kept elements ranked by wave ballots + a 16-entry prefix per tile;
+    // FOUR tiles per round (round 4: one tile per round was 49 rounds of "load, three barriers" at 50 000 genes -- 66 us of
+    // latency, twice per analysis; the loads of a round are now in flight together and the barriers are shared)
+    constexpr int NT = 4;
+    __shared__ int wcnt[NT][16];
     __shared__ int base_s;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) base_s = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + t;
-        bool keep = false;
-        if (i < n) {
-            if (mode == 0) {
-                int z = allZero[i] | (force_zero ? force_zero[i] : 0);
-                if (force_zero) allZero[i] = z ? 1 : 0;
-                keep = !z;
-            } else {
-                keep = disp_in[i] > thresh;
+    for (int i0 = 0; i0 < n; i0 += NT * 1024) {
+        bool keep[NT];
+        double mv[NT], dv[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            const int i = i0 + q * 1024 + t;
+            keep[q] = false; mv[q] = 0.0; dv[q] = 0.0;
+            if (i < n) {
+                if (mode == 0) {
+                    int z = allZero[i] | (force_zero ? force_zero[i] : 0);
+                    if (force_zero) allZero[i] = z ? 1 : 0;
+                    keep[q] = !z;
+                } else {
+                    dv[q] = disp_in[i]; mv[q] = mean_in[i];
+                    keep[q] = dv[q] > thresh;
+                }
             }
         }
-        const unsigned long long mask = __ballot(keep);
-        if (lane == 0) wcnt[wave] = __popcll(mask);
+        unsigned long long mask[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            mask[q] = __ballot(keep[q]);
+            if (lane == 0) wcnt[q][wave] = __popcll(mask[q]);
+        }
         __syncthreads();
         int off = base_s;
-        for (int w = 0; w < wave; w++) off += wcnt[w];
-        off += __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) {
-            if (mode == 0) rows_out[off] = i;
-            else { mean_out[off] = mean_in[i]; disp_out[off] = disp_in[i]; }
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            int mine = off;
+            for (int w = 0; w < 16; w++) { const int c = wcnt[q][w]; if (w < wave) mine += c; off += c; }
+            mine += __popcll(mask[q] & ((1ull << lane) - 1ull));
+            if (keep[q]) {
+                const int i = i0 + q * 1024 + t;
+                if (mode == 0) rows_out[mine] = i;
+                else { mean_out[mine] = mv[q]; disp_out[mine] = dv[q]; }
+            }
         }
         __syncthreads();
-        if (t == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; w++) tot += wcnt[w];
-            base_s += tot;
-        }
+        if (t == 0) base_s = off;               // (every thread has computed the same running total)
         __syncthreads();
     }
     if (t == 0) *count_out = base_s;
