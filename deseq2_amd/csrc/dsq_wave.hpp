@@ -125,22 +125,6 @@ DSQ_DEV double wave_allreduce_low(double v, int nlive) {
     return v;
 }
 
-template <int N>
-DSQ_DEV void wave_allreduce_n(double (&v)[N]) {
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor1(v[i]);
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor2(v[i]);
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor4(v[i]);
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) v[i] = v[i] + lane_xor8(v[i]);
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) { double a, b; lane_pair16(v[i], a, b); v[i] = a + b; }
-DSQ_UNROLL_P
-    for (int i = 0; i < N; i++) { double a, b; lane_pair32(v[i], a, b); v[i] = a + b; }
-}
-
 // compile-time loop index (a stage whose reductions have a width that depends on the stage)
 template <class F, int... K>
 DSQ_DEV void static_for_impl(F &&f, std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }
