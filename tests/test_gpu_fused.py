@@ -275,6 +275,25 @@ def test_residual_df_of_at_most_three_with_the_callers_prior_variance(E, m):
     assert res["dispersionFunction"]["dispPriorVar"] == 0.7
 
 
+def test_all_gene_kernels_above_their_size_thresholds(E):
+    """20 000 genes: the prior variance of the trend runs on sixteen workgroups from 16 384 genes (prior_var_grid_kernel:
+    per-pass histograms in a global table, grid barriers), the ordered compactions take several rounds of four tiles --
+    against the call-by-call chain, whose MAD and row lists come from other code (engine.mad, host masks): trend
+    coefficients, varLogDispEsts, dispPriorVar and every per-gene column bit for bit"""
+    x = simulate.design_two_group(12)
+    d = simulate.make_counts(20000, x, seed=61, drop_all_zero=False)
+    counts = d["counts"].copy()
+    counts[::13] = 0                                        # all-zero rows inside every tile of the compaction
+    a, b = _both(E, counts, x, d["size_factors"])
+    assert b.n >= 16384 and int(np.asarray(b.mcols["allZero"], bool).sum()) > 1500
+    _compare(a, b, "20 000 genes")
+    # ... and the caller's-trend form of the same kernel (residuals against given values)
+    a2, b2 = _both(E, counts, x, d["size_factors"], fitType=_smooth_trend)
+    assert a2.dispersionFunction["varLogDispEsts"] == b2.dispersionFunction["varLogDispEsts"]
+    assert a2.dispersionFunction["dispPriorVar"] == b2.dispersionFunction["dispPriorVar"]
+    assert_same(np.asarray(a2.mcols["dispersion"], float), np.asarray(b2.mcols["dispersion"], float), "custom trend, 20 000 genes")
+
+
 def test_unsupported_settings_fall_back(E):
     x = simulate.design_two_group(12)
     d = simulate.make_counts(200, x, seed=11)
