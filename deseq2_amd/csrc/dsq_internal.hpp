@@ -75,6 +75,8 @@ struct BetaKernelParams {
     // cell-collapsed kernel; cell_perm = samples grouped by cell (ascending inside a cell), cell_start = ncell + 1 offsets
     const int32_t *cell_perm, *cell_start;
     int ncell;
+    double *kconst_out;     // n values or NULL: K' of the row -- the mu-independent part of sum [wts] log NB(y; 1/alpha, mu) on
+                            // the closed split (dsq_math.hpp) -- for the nbinomLogLike launch that follows this fit
 };
 
 struct PrefitKernelParams {
@@ -108,6 +110,8 @@ struct LogLikeKernelParams {
     const int32_t *rows;
     const int32_t *n_dev;
     const int32_t *skip;     // n flags or NULL: genes with a non-zero flag are left alone (neither read nor written)
+    const double *kconst;    // n values or NULL: the mu-independent part of each row's sum, from the fitBeta launch that
+                             // fitted the row with the SAME dispersions / weights (BetaKernelParams.kconst_out); NULL: computed here
 };
 
 struct InterceptKernelParams {
@@ -126,6 +130,7 @@ struct InterceptKernelParams {
     // genes 0 .. n-1); n stays the capacity / leading dimension of the n-vectors and n x p matrices
     const int32_t *rows;
     const int32_t *n_dev;
+    const double *kconst;    // as LogLikeKernelParams.kconst (the full model's fit has the same counts, dispersions, weights)
 };
 
 struct OptimKernelParams {

@@ -533,4 +533,36 @@ DSQ_DEV double dnbinom_mu_log(double x, double size, double mu) {
     return dnbinom_mu_log(x, size, mu, st_size, lg_size);
 }
 
+// ---- the closed split of log NB(y; size = 1/alpha, mu) ---------------------------------------
+// On the saddle-point form of dnbinom_mu the two bd0 terms are -n [log1p(alpha mu) - log1p(alpha y)] - y [log y - log mu]
+// (n = y + size), so   log f = K' + y log mu - n log1p(alpha mu),   K' = [saddle-point constants] + n log1p(alpha y) - y log y
+// independent of mu (0 for y = 0).  fitBeta's deviance has used it since round 2 (with lg = log(mu / nf), the y log nf
+// in its constants); nbinomLogLike takes it since round 4 (aux.hip) -- the sum over a row is K' once per gene (fitBeta's
+// constants pass hands it over) plus one sweep with two logarithms per sample, instead of R's dnbinom_mu sample by sample.
+// `fast`: alpha and size positive and finite; a sample outside the split (a count below 1e-10 size ...) keeps the full form.
+DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
+    const double n = y + size;
+    const bool gen = (y > 0.0) && dfinite(y) && !(y < 1e-10 * size) && (n != size) && dfinite(n);
+    return fast && (y == 0.0 || gen);
+}
+DSQ_DEV bool nb_split_fast(double alpha, double size) { return (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0); }
+// y != 0 inside the split: K' = base + t  (fitBeta: K = base + (t + y log nf))
+DSQ_DEV void nb_split_const(double y, double alpha, double size, double st_size, double &base, double &t) {
+    // log(size/(size+y)) = -L, log1p(-size/n) = log y - log size - L, L = log1p(alpha y)
+    const double n = y + size;
+    const double L = dlog1p(alpha * y), ly = dlog(y);
+    const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
+    base = -L + (c0 - 0.5 * (kLn2Pi + ly - L));
+    t = n * L - y * ly;
+}
+// the mu-dependent part (the whole log density for a sample outside the split)
+DSQ_DEV double nb_split_var(double y, double size, double alpha, double mu, bool fast) {
+    if (cell_dev_closed(y, size, fast)) {
+        const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
+        const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
+        return (y == 0.0) ? -(size * l1p) : y * dlog(mu) - (y + size) * l1p;
+    }
+    return dnbinom_mu_log(y, size, mu);
+}
+
 }  // namespace dsq

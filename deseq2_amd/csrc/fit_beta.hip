@@ -138,35 +138,35 @@ static constexpr int kSlabVecs = 3;      // sqrt(w) | mu (or sqrt(w) z) | log(mu
 // count below 1e-10 size): the full dnbinom_mu, kept out of line so that its registers do not count against the sweep's
 __device__ __noinline__ static double nb_offbranch(double y, double size, double mu) { return dnbinom_mu_log(y, size, mu); }
 
-// 0: log NB(y; size, mu) = K_j + y lg - (y + size) log1p(alpha mu)  (zero counts and the general branch of dnbinom_mu)
-DSQ_DEV bool cell_dev_closed(double y, double size, bool fast) {
-    const double n = y + size;
-    const bool gen = (y > 0.0) && dfinite(y) && !(y < 1e-10 * size) && (n != size) && dfinite(n);
-    return fast && (y == 0.0 || gen);
-}
-
+// (cell_dev_closed / nb_split_const: dsq_math.hpp)
 // K = sum_j [wts_j] K_j, the mu-independent part of the IRLS deviance, samples in their natural order:
-// K_j = [saddle-point constants of dnbinom_mu, logarithms folded] + n log1p(alpha y) - y log y + y log nf_j  (0 for y = 0)
+// K_j = [saddle-point constants of dnbinom_mu, logarithms folded] + n log1p(alpha y) - y log y + y log nf_j  (0 for y = 0);
+// kprime (optional): the same without the y log nf_j -- what nbinomLogLike adds to its own sweep (aux.hip)
 template <bool USE_W>
 DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double *wg, int m, int lane, double alpha,
-                              double size, bool fast, const double *lnf = nullptr) {
+                              double size, bool fast, const double *lnf = nullptr, double *kprime = nullptr) {
+    if (kprime) *kprime = 0.0;
     if (!fast) return 0.0;
     const double st_size = dstirlerr(size);
-    double kacc = 0.0;
+    double kacc = 0.0, pacc = 0.0;
     for (int j = lane; j < m; j += 64) {
         const double y = (double)yg[j];
-        double kj = 0.0;
+        double kj = 0.0, pj = 0.0;
         if (y != 0.0 && cell_dev_closed(y, size, fast)) {
-            // log(size/(size+y)) = -L, log1p(-size/n) = log y - log size - L, L = log1p(alpha y)
-            const double n = y + size;
-            const double L = dlog1p(alpha * y), ly = dlog(y);
-            const double c0 = dstirlerr(n) - st_size - dstirlerr(n - size);
+            double base, t;
+            nb_split_const(y, alpha, size, st_size, base, t);
             // (lnf: log nf_j from the block's table when the factors are the size-factor vector -- the same function of
             // the same value, evaluated once per block instead of once per gene)
-            kj = -L + (c0 - 0.5 * (kLn2Pi + ly - L)) + ((n * L - y * ly) + y * (lnf ? lnf[j] : dlog(nfg[j])));
+            kj = base + (t + y * (lnf ? lnf[j] : dlog(nfg[j])));
+            pj = base + t;
         }
-        if constexpr (USE_W) kacc += wg[j] * kj;
-        else kacc += kj;
+        if constexpr (USE_W) { kacc += wg[j] * kj; pacc += wg[j] * pj; }
+        else { kacc += kj; pacc += pj; }
+    }
+    if (kprime) {
+        wave_allreduce_pair(kacc, pacc, lane);         // (the bits of two butterflies)
+        *kprime = pacc;
+        return kacc;
     }
     return wave_allreduce(kacc);
 }
@@ -296,8 +296,9 @@ DSQ_UNROLL_P
         // dev = -2 (K + D): the mu-independent part of the NB log densities once per gene, one logarithm per sample and
         // iteration for the rest (the closed split of the cell kernel below)
         const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
-        double K = 0.0;
-        if (kp.maxit > 0 && !(abl & 16)) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast);
+        double K = 0.0, Kp = 0.0;
+        if (kp.maxit > 0 && !(abl & 16)) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr);
+        if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
         DSQ_BWORK(DsqVecP, beta_prev);   // beta the current mu slot was computed from
@@ -891,7 +892,9 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         double K = 0.0, dev = 0.0;
         // the mu-independent part of the log densities, once per gene (samples in their natural order):
         // K_j = [saddle-point constants] + n log1p(alpha y) - y log y + y log nf_j,  n = y + size;  0 for y = 0
-        if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, lnf_s);
+        double Kp = 0.0;
+        if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, lnf_s, kp.kconst_out ? &Kp : nullptr);
+        if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
         // one sweep over the samples at the current beta: positions k = lane, lane + 64, ... of the cell-sorted
         // sequence (full trips); the sums of a cell are closed when the sweep leaves it.  Deviance term of a sample:
         // y lg - (y + size) log1p(alpha mu), lg = log(mu / nf) -- one logarithm (of the rounded 1 + alpha mu, plus

@@ -783,6 +783,7 @@ struct Pipe {
     double *roughDisp, *beta_init, *alpha_init, *la0, *la_out, *last_change, *initial_lp, *initial_dlp, *last_lp, *last_dlp;
     double *la_grid, *log_dfit, *la_init, *beta_nat, *beta_var, *beta_iter, *cnum, *cden, *dev, *lam, *contrast, *resbuf;
     double *trend_mean_c, *trend_disp_c, *robustDisp, *scratch, *cscratch;
+    double *kconst;              // n: K' of each row from its last fitBeta launch (-> LogLikeKernelParams.kconst)
     double *opt_start, *opt_beta, *opt_se, *opt_ll;
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
@@ -896,6 +897,7 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.beta_mat = P.beta_nat; kp.beta_var_mat = P.beta_var; kp.iter = P.beta_iter;
     kp.contrast_num = P.cnum; kp.contrast_denom = P.cden; kp.deviance = P.dev;
     kp.hat_diagonals = hat; kp.mu_out = mu_out;
+    kp.kconst_out = P.kconst;            // K' of the rows this launch fits: the nbinomLogLike launch behind it reads it
     kp.scratch = P.scratch; kp.cscratch = P.cscratch;
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
@@ -1129,7 +1131,7 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
     memset(&lk, 0, sizeof lk);
     lk.n = P.n; lk.m = P.m; lk.ld = P.ld; lk.y = y; lk.mu = P.red_mu; lk.disp = o->dispersion;
     lk.weights = a->useWeights ? a->weights_norm : nullptr; lk.useWeights = a->useWeights ? 1 : 0;
-    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev;
+    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev; lk.kconst = P.kconst;
     capi_prof_begin(P.tag[0] ? "nbinom_loglike:refit" : "nbinom_loglike", P.n, P.st);
     PIPE_HIP(launch_loglike(lk, P.st));
     capi_prof_end(P.st);
@@ -1191,7 +1193,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     memset(&lk, 0, sizeof lk);
     lk.n = P.n; lk.m = P.m; lk.ld = P.ld; lk.y = y; lk.mu = mu_out; lk.disp = o->dispersion;
     lk.weights = a->useWeights ? a->weights_norm : nullptr; lk.useWeights = a->useWeights ? 1 : 0;
-    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev;
+    lk.loglike = o->logLike; lk.rows = rw.rows; lk.n_dev = rw.n_dev; lk.kconst = P.kconst;
     RuleParams b = rule_params(P, rw);
     b.beta = o->beta; b.betaSE = o->betaSE; b.stat = o->stat; b.pvalue = o->pvalue; b.wald = (a->test == 0) ? 1 : 0;
     b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
@@ -1266,6 +1268,7 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         ik.weights = a->useWeights ? a->weights_norm : nullptr; ik.useWeights = a->useWeights ? 1 : 0;
         ik.alpha = o->dispersion; ik.beta_log2 = P.cnum; ik.betaSE = P.cden;      // not read by nbinomLRT
         ik.loglike = o->logLikeReduced; ik.rows = rw.rows; ik.n_dev = rw.n_dev;
+        ik.kconst = P.kconst;            // (the full model's fit of the same rows: same counts, dispersions, weights)
         capi_prof_begin("intercept_fit", P.n, P.st);
         PIPE_HIP(launch_intercept_fit(ik, P.st));
         capi_prof_end(P.st);
@@ -1339,7 +1342,7 @@ static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 struct Carve {
     size_t o_rough, o_binit, o_ainit, o_la0, o_laout, o_lchg, o_ilp, o_idlp, o_llp, o_ldlp, o_lagrid, o_ldfit, o_lainit,
-        o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, o_ostart, o_obeta, o_ose, o_oll, o_rbinit, o_rbeta, o_rse, dbl;
+        o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, o_ostart, o_obeta, o_ose, o_oll, o_rbinit, o_rbeta, o_rse, o_kc, dbl;
     size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, i_opt, i_oconv, ints;
     size_t bytes;
 };
@@ -1356,6 +1359,7 @@ static Carve carve(int n, int p, int nt) {
     c.o_res = takeD(ntd); c.o_tm = takeD(ntd); c.o_td = takeD(ntd); c.o_robust = takeD(nd);
     c.o_ostart = takeD(np_); c.o_obeta = takeD(np_); c.o_ose = takeD(np_); c.o_oll = takeD(nd);
     c.o_rbinit = takeD(np_); c.o_rbeta = takeD(np_); c.o_rse = takeD(np_);
+    c.o_kc = takeD(nd);
     c.dbl = d;
     size_t i = 0;
     auto takeI = [&](size_t k) { size_t off = i; i += align8(k); return off; };
@@ -1451,6 +1455,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     P.opt_start = D + cv.o_ostart; P.opt_beta = D + cv.o_obeta; P.opt_se = D + cv.o_ose; P.opt_ll = D + cv.o_oll;
     P.rows_opt = I + cv.i_opt; P.opt_conv = I + cv.i_oconv;
     P.red_binit = D + cv.o_rbinit; P.red_beta = D + cv.o_rbeta; P.red_se = D + cv.o_rse;
+    P.kconst = D + cv.o_kc;
     {
         size_t slab_d = 0, cscr_d = 0;
         dispatch_beta_scratch(pk, n, m, a->useWeights, &slab_d, &cscr_d);

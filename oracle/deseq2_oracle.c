@@ -1156,18 +1156,41 @@ int orc_optim_rows(int n, int m, int p, const double *y, const double *x, const 
  * R/core.R:2208-2217: rowSums([weights *] dnbinom(counts, mu = mu, size = 1/disp, log = TRUE)).
  * (called from R/fitNbinomGLMs.R:182 and, per model, from nbinomLRT R/core.R:1850-1877)
  * dnbinom(.., mu=) is nmath's dnbinom_mu, the same function fitBeta's deviance uses. */
+/* Round 4: evaluated on the closed split of the density that fitBeta's deviance uses (fit_beta_gene_cells above):
+ *   log f_j = K'_j + y_j log mu_j - (y_j + size) log1p(alpha mu_j),
+ *   K'_j = [saddle-point constants, logarithms folded] + n log1p(alpha y) - y log y   (0 for y = 0; the K_j of the
+ *   deviance without its y log nf_j -- the likelihood is given mu, not nf),
+ * a sample outside the split (cell_dev_class != 0) keeps dnbinom_mu.  The row's value is K' + D: two sums over the samples
+ * in their natural order, added once.  Against R's sample-by-sample dnbinom_mu the split's terms cancel four to five
+ * digits (error ~ 4e-12 on a log likelihood of -430, against 5e-13: mpmath); the engine pays a third of the instructions. */
 int orc_nbinom_loglike(int n, int m, const double *y, const double *mu, const double *disp,
                        const double *weights, int useWeights, double *loglike, int sum_mode) {
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) {
-        wsum_t s; wsum_init(&s, sum_mode);
-        double size = 1.0 / disp[i];
+        const double alpha = disp[i], size = 1.0 / alpha;
+        const int fast = (alpha > 0.0) && isfinite(alpha) && isfinite(size) && (size > 0.0);
+        const double st_size = fast ? orc_stirlerr(size) : 0.0;
+        wsum_t sk, sd; wsum_init(&sk, sum_mode); wsum_init(&sd, sum_mode);
         for (int j = 0; j < m; j++) {
-            double d = orc_dnbinom_mu_log(y[i + (long)n * j], size, mu[i + (long)n * j]);
-            if (useWeights) d = weights[i + (long)n * j] * d;
-            wsum_add(&s, j, d);
+            const double yy = y[i + (long)n * j], mm = mu[i + (long)n * j];
+            const double w = useWeights ? weights[i + (long)n * j] : 1.0;
+            const int cls = cell_dev_class(yy, size, fast);
+            double kj = 0.0, d;
+            if (cls == 0) {
+                if (yy != 0.0) {
+                    const double nn = yy + size;
+                    const double L = orc_log1p(alpha * yy), ly = orc_log(yy);
+                    const double c0 = orc_stirlerr(nn) - st_size - orc_stirlerr(nn - size);
+                    kj = (-L + (c0 - 0.5 * (1.837877066409345483560659472811 /* ln 2 pi */ + ly - L))) + (nn * L - yy * ly);
+                }
+                const double am = alpha * mm, opm = 1.0 + am, rcp = 1.0 / opm;
+                const double l1p = orc_log(opm) + (am - (opm - 1.0)) * rcp;
+                d = (yy == 0.0) ? -(size * l1p) : yy * orc_log(mm) - (yy + size) * l1p;
+            } else d = orc_dnbinom_mu_log(yy, size, mm);
+            if (fast) wsum_add(&sk, j, useWeights ? w * kj : kj);
+            wsum_add(&sd, j, useWeights ? w * d : d);
         }
-        loglike[i] = wsum_total(&s);
+        loglike[i] = (fast ? wsum_total(&sk) : 0.0) + wsum_total(&sd);
     }
     return 0;
 }
