@@ -148,8 +148,10 @@ __global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, d
 // row's sum, samples in their natural order -- plus one sweep with two logarithms per sample.  The fitBeta launch that
 // fitted the row hands K' over (kconst; same counts, dispersions, weights: its constants pass computes it beside its own);
 // without it the constants pass runs here.  Round 4: R's dnbinom_mu sample by sample cost 8.2 k instructions per gene for
-// this one pass; the split's terms lose four to five digits to cancellation where bd0 loses none -- |error| ~ 4e-12 on a
-// log likelihood of -430 against 5e-13 (mpmath), ten orders below the budget of the LRT statistic.
+// this one pass.  Against 40-digit arithmetic the split's terms lose four to five digits to cancellation where bd0 loses
+// none (|error| ~ 4e-12 on a log likelihood of -430 against 5e-13); at the dispersion floor (size 1e8) dnbinom_mu's own
+// log1p(-x/n) loses nine and the split none -- there the two differ by R's error, ~ 6e-10 per sample, a term of (y, size)
+// that cancels in an LRT statistic (tests/test_loglike_cpu.py).
 template <bool USE_W>
 DSQ_DEV double loglike_constants(const int32_t *yg, const double *wg, int m, int lane, double alpha, double size, bool fast) {
     if (!fast) return 0.0;

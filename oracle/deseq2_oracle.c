@@ -1161,8 +1161,10 @@ int orc_optim_rows(int n, int m, int p, const double *y, const double *x, const 
  *   K'_j = [saddle-point constants, logarithms folded] + n log1p(alpha y) - y log y   (0 for y = 0; the K_j of the
  *   deviance without its y log nf_j -- the likelihood is given mu, not nf),
  * a sample outside the split (cell_dev_class != 0) keeps dnbinom_mu.  The row's value is K' + D: two sums over the samples
- * in their natural order, added once.  Against R's sample-by-sample dnbinom_mu the split's terms cancel four to five
- * digits (error ~ 4e-12 on a log likelihood of -430, against 5e-13: mpmath); the engine pays a third of the instructions. */
+ * in their natural order, added once.  Against 40-digit arithmetic the split's terms cancel four to five digits where
+ * dnbinom_mu's bd0 loses none (error ~ 4e-12 on a log likelihood of -430 against 5e-13); at the dispersion floor (size 1e8)
+ * dnbinom_mu's log1p(-x/n) loses nine (~ 6e-10 per sample, a term of (y, size): the same in every model of a gene) and
+ * the split none -- tests/test_loglike_cpu.py pins all three.  The engine pays a third of the instructions. */
 int orc_nbinom_loglike(int n, int m, const double *y, const double *mu, const double *disp,
                        const double *weights, int useWeights, double *loglike, int sum_mode) {
 #pragma omp parallel for schedule(static)
