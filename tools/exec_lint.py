@@ -10,7 +10,8 @@ sqrt, which then returned its argument).  Nothing in the source can provoke or p
 
 Reports every constant move into a vector register that sits between the head of a block where lanes come back together
 (the target of a forward skip on an empty mask, the fall-through of a loop latch; in -S output: any label) and the exec
-restore that leads the block.  Exit status 1 when anything is found."""
+restore that leads the block -- and, at the fall-through of a loop latch, where the mask is EMPTY, every vector write of
+any kind (disassembly only).  Exit status 1 when anything is found."""
 import os
 import re
 import shutil
@@ -19,8 +20,8 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-SCALAR_OK = ("s_mov", "s_movk", "s_brev", "s_nop", "s_waitcnt", "v_readlane", "v_readfirstlane", "s_getpc", "s_add_u32",
-             "s_addc_u32")
+SCALAR_OK = ("s_mov", "s_movk", "s_brev", "s_nop", "s_waitcnt", "v_readlane", "v_readfirstlane", "v_writelane", "s_getpc",
+             "s_add_u32", "s_addc_u32")
 
 
 # a constant put into a vector register: what the allocator re-materialises instead of keeping or spilling it
@@ -39,6 +40,9 @@ def scan(blocks):
                 break
             if CONST_MOVE.match(t):
                 pending.append((w, t))
+            elif kernel.endswith("[loop exit]") and op.startswith("v_") and not op.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_cmp")):
+                pending.append((w, t))        # at a loop exit the mask is empty: ANY vector write in front of the restore is lost
+                                              # (v_writelane / v_readlane -- SGPR spills -- do not look at the mask)
             elif not op.startswith(SCALAR_OK):
                 break
     return hits
@@ -74,7 +78,7 @@ def blocks_of_disassembly(text, tag):
         if kernel is None or not ins:
             return
         idx = {a: i for i, a in enumerate(addr)}
-        heads = set()
+        heads = {}
         for k, t in enumerate(ins):
             if t.startswith("s_cbranch_exec"):
                 mt = re.search(r"\+0x([0-9a-f]+)>", t)
@@ -82,14 +86,16 @@ def blocks_of_disassembly(text, tag):
                     continue
                 tg = base + int(mt.group(1), 16)
                 if tg > addr[k]:
-                    heads.add(tg)
-                elif k + 1 < len(ins):
-                    heads.add(addr[k + 1])
+                    heads.setdefault(tg, "join")
+                elif k + 1 < len(ins) and t.startswith("s_cbranch_execnz"):
+                    heads[addr[k + 1]] = "exit"       # the fall-through of a loop latch: reached with an EMPTY mask
         for tg in sorted(heads):
             i = idx.get(tg)
             if i is not None:
                 chunk = range(i, min(i + 24, len(ins)))
-                yield kernel, ["%s %s+0x%x" % (tag, kernel[:60], addr[j] - base) for j in chunk], [re.sub(r"\s*<[^>]+>$", "", ins[j]) for j in chunk]
+                yield (kernel + ("  [loop exit]" if heads[tg] == "exit" else ""),
+                       ["%s %s+0x%x" % (tag, kernel[:60], addr[j] - base) for j in chunk],
+                       [re.sub(r"\s*<[^>]+>$", "", ins[j]) for j in chunk])
 
     for line in text.split("\n"):
         c = line.find("// ")
