@@ -962,7 +962,8 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
     # the refit runs estimateDispersionsGeneEst / MAP and nbinomWaldTest / nbinomLRT on their DEFAULTS: DESeq()'s betaTol,
     # maxit, useQR, minmu, useT, df are not handed on (:2509-2531) -- refitted rows carry normal-distribution p-values
     # even in a useT analysis
-    kw = {}
+    # ... but the caller's model matrix IS (modelMatrix = modelMatrix in all three calls of the refit, :2509-2527)
+    kw = {k: v for k, v in kw.items() if k == "modelMatrix" and v is not None}
     replaceOutliers(dds, minReplicates=minReplicatesForReplace)
     if "replace" not in dds.mcols:
         if count_all is not None:
@@ -986,7 +987,7 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
     if refitReplace.size > 0:                                                         # :2496
         keep = ~whole.mcols["allZero"]
         sub = whole if keep.all() else dds.subset(refitReplace, dds.assays["replaceCounts"])
-        estimateDispersionsGeneEst(sub, maxit=disp_maxit)                             # :2509
+        estimateDispersionsGeneEst(sub, maxit=disp_maxit, **kw)                       # :2509
         sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
         estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"], maxit=disp_maxit)   # :2518-2519
         if test == "Wald":
@@ -994,7 +995,7 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
                 dds.attrs["betaPriorVar"] if dds.attrs.get("betaPrior", False) else None),
                 modelMatrixType=dds.attrs.get("modelMatrixType"), factors=dds.attrs.get("factors"), **kw)
         else:
-            nbinomLRT(sub, reduced, **kw)
+            nbinomLRT(sub, reduced)         # (full / reduced are the matrices themselves in this mirror)
         for k, v in sub.mcols.items():                                                # :2533-2534
             if k not in dds.mcols or k == "rowsForOptim" or np.shape(v)[:1] != (sub.n,):
                 continue

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dsq_isa.hpp"
 
 namespace dsq {
 
@@ -36,6 +37,10 @@ DSQ_DEV double dexp(double x) {
     if (x != x) return x;
     if (x > 709.782712893384) return kInf;
     if (x < -745.1332191019412) return 0.0;
+#if DSQ_ISA_CORES
+    double kf;
+    const double y = isa_exp_core(x, kf);        // dsq_isa.hpp: the same operations, coefficients from the scalar cache
+#else
     double kf = __builtin_rint(x * kInvLn2);
     double hi = __builtin_fma(-kf, kLn2Hi, x);
     double lo = kf * kLn2Lo;
@@ -57,6 +62,7 @@ DSQ_DEV double dexp(double x) {
     double t = __builtin_fma(r2, p, r);
     t = t + rerr;
     double y = 1.0 + t;
+#endif
     int k = (int)kf;
     int k1 = k >> 1;
     int k2 = k - k1;
@@ -104,6 +110,9 @@ constexpr double kLg7 = 1.479819860511658591e-01;
 // (round 4: ~10 of its ~45 instructions; every fma drops one rounding of the mul + add pair it replaces, so the error
 // bound of the original form -- below 1 ulp -- still holds; the CPU checker of the test suite runs the same sequence)
 DSQ_DEV double log_core(double f, double dk, double c) {
+#if DSQ_ISA_CORES
+    return isa_log_core<true>(f, dk, c);         // dsq_isa.hpp: the same operations, coefficients from the scalar cache
+#else
     double hfsq = 0.5 * f * f;
     double s = ddiv_n(f, 2.0 + f);      // 2 + f in [1.7, 2.42], f = 0 or |f| >= 2^-53: nothing to scale
     double z = s * s;
@@ -113,6 +122,15 @@ DSQ_DEV double log_core(double f, double dk, double c) {
     double R = t2 + t1;
     double u = __builtin_fma(s, hfsq + R, __builtin_fma(dk, kLn2Lo, c));
     return __builtin_fma(dk, kLn2Hi, (u - hfsq) + f);
+#endif
+}
+// c = +0.0 (the plain logarithm)
+DSQ_DEV double log_core0(double f, double dk) {
+#if DSQ_ISA_CORES
+    return isa_log_core<false>(f, dk, 0.0);
+#else
+    return log_core(f, dk, 0.0);
+#endif
 }
 
 // general version: NaN / negative / zero / subnormal / +inf handled
@@ -128,7 +146,7 @@ DSQ_DEV double dlog_full(double x) {
     k += (int)(ix >> 52) - 0x3ff;
     ix = (ix & 0x000fffffffffffffULL) + ((uint64_t)0x3fe6a09eu << 32);
     double f = bits2d(ix) - 1.0;
-    return log_core(f, (double)k, 0.0);
+    return log_core0(f, (double)k);
 }
 
 // positive normal finite argument: same bits as dlog_full, no special-case tests
@@ -138,7 +156,7 @@ DSQ_DEV double dlog_pn(double x) {
     int k = (int)(ix >> 52) - 0x3ff;
     ix = (ix & 0x000fffffffffffffULL) + ((uint64_t)0x3fe6a09eu << 32);
     double f = bits2d(ix) - 1.0;
-    return log_core(f, (double)k, 0.0);
+    return log_core0(f, (double)k);
 }
 
 // The special cases almost never occur in the kernels; test them once per wave (a scalar
@@ -155,7 +173,7 @@ DSQ_DEV double dlog1p(double x) {
     if (x == -1.0) return -kInf;
     if (x == kInf) return x;
     if (__builtin_fabs(x) < 1.1102230246251565e-16) return x;
-    if (x > -0.2928932188134524 && x < 0.41421356237309503) return log_core(x, 0.0, 0.0);
+    if (x > -0.2928932188134524 && x < 0.41421356237309503) return log_core0(x, 0.0);
     double u = 1.0 + x;
     uint64_t iu = d2bits(u);
     iu += (uint64_t)(0x3ff00000u - 0x3fe6a09eu) << 32;
@@ -185,6 +203,9 @@ DSQ_DEV double dlgamma(double x) {
     double lx = dlog(xs);
     double rx = 1.0 / xs;
     double r2 = rx * rx;
+#if DSQ_ISA_CORES
+    double c = isa_stirling_lgamma(r2);
+#else
     double c = -3617.0 / 122400.0;
     c = __builtin_fma(c, r2, 1.0 / 156.0);
     c = __builtin_fma(c, r2, -691.0 / 360360.0);
@@ -193,6 +214,7 @@ DSQ_DEV double dlgamma(double x) {
     c = __builtin_fma(c, r2, 1.0 / 1260.0);
     c = __builtin_fma(c, r2, -1.0 / 360.0);
     c = __builtin_fma(c, r2, 1.0 / 12.0);
+#endif
     double cor = c * rx;
     double res = kLnSqrt2Pi + (xs - 0.5) * lx - xs + cor;
     if (__any(shifted)) {
@@ -217,6 +239,9 @@ DSQ_DEV double ddigamma(double x) {
     double lx = dlog(xs);
     double rx = 1.0 / xs;
     double r2 = rx * rx;
+#if DSQ_ISA_CORES
+    double c = isa_stirling_digamma(r2);
+#else
     double c = -3617.0 / 8160.0;
     c = __builtin_fma(c, r2, 1.0 / 12.0);
     c = __builtin_fma(c, r2, -691.0 / 32760.0);
@@ -225,6 +250,7 @@ DSQ_DEV double ddigamma(double x) {
     c = __builtin_fma(c, r2, 1.0 / 252.0);
     c = __builtin_fma(c, r2, -1.0 / 120.0);
     c = __builtin_fma(c, r2, 1.0 / 12.0);
+#endif
     double res = (lx - 0.5 * rx) - c * r2;
     if (shifted) res = res - num / den;
     return res;
@@ -250,6 +276,12 @@ DSQ_DEV void dlgamma_digamma(double x, double &lg, double &dg) {
     double lx = dlog(xs);
     double rx = 1.0 / xs;
     double r2 = rx * rx;
+#if DSQ_ISA_CORES
+    double c, d;
+    isa_stirling_pair(r2, c, d);                 // dsq_isa.hpp: both sums, the same operations
+    double cor = c * rx;
+    double res = kLnSqrt2Pi + (xs - 0.5) * lx - xs + cor;
+#else
     double c = -3617.0 / 122400.0;
     c = __builtin_fma(c, r2, 1.0 / 156.0);
     c = __builtin_fma(c, r2, -691.0 / 360360.0);
@@ -268,6 +300,7 @@ DSQ_DEV void dlgamma_digamma(double x, double &lg, double &dg) {
     d = __builtin_fma(d, r2, 1.0 / 252.0);
     d = __builtin_fma(d, r2, -1.0 / 120.0);
     d = __builtin_fma(d, r2, 1.0 / 12.0);
+#endif
     double dres = (lx - 0.5 * rx) - d * r2;
     if (__any(shifted)) {
         double lp = dlog(prod);
@@ -293,6 +326,9 @@ DSQ_DEV double dtrigamma(double x) {
     }
     double rx = 1.0 / xs;
     double r2 = rx * rx;
+#if DSQ_ISA_CORES
+    double c = isa_stirling_trigamma(r2);
+#else
     double c = -3617.0 / 510.0;
     c = __builtin_fma(c, r2, 7.0 / 6.0);
     c = __builtin_fma(c, r2, -691.0 / 2730.0);
@@ -301,6 +337,7 @@ DSQ_DEV double dtrigamma(double x) {
     c = __builtin_fma(c, r2, 1.0 / 42.0);
     c = __builtin_fma(c, r2, -1.0 / 30.0);
     c = __builtin_fma(c, r2, 1.0 / 6.0);
+#endif
     double res = rx + r2 * (0.5 + rx * c);
     if (shifted) res = res + num / den;
     return res;

@@ -1402,6 +1402,9 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (a->trend_mean && (!a->trend_disp || a->n_trend < 1)) return capi_fail(DSQ_ERR_ARG, "trend vectors");
     if (a->useWeights && (!a->weights_raw || !a->weights_norm || !a->weights_floor)) return capi_fail(DSQ_ERR_ARG, "useWeights without weights");
     if (a->test != 0 && a->test != 1) return capi_fail(DSQ_ERR_ARG, "test must be 0 (Wald) or 1 (LRT)");
+    // the chain's nbinomLogLike reads K' (the mu-independent part of the row's log density) from the fitBeta launch in
+    // front of it, and that launch forms K' inside its IRLS set-up: a chain without IRLS iterations has no K'
+    if (a->betaMaxit < 1) return capi_fail(DSQ_ERR_ARG, "dsq_deseq_dev: betaMaxit must be >= 1 (DESeq() itself runs maxit = 100)");
     if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
     if (a->dispFit_in && a->trend_mean && !a->trend_fit_in) return capi_fail(DSQ_ERR_ARG, "dispFit_in with gathered trend vectors needs trend_fit_in");
     if (a->dispFit_in && (a->phases & DSQ_PH_OUTLIERS) && a->do_replace)

@@ -182,9 +182,8 @@ def DESeqParallel(dds, test="Wald", fitType="parametric", reduced=None, comm_dev
     # bring the global dispersion function back to the shard
     fn = glob.dispersionFunction
     bm = dds.mcols["baseMean"]
-    dds.mcols["dispFit"] = (fn["coefficients"][0] + fn["coefficients"][1] / bm
-                            if fn["fitType"] == "parametric" else np.full(bm.shape, fn["coefficients"]))
     dds.dispersionFunction = dict(fn)
+    dds.mcols["dispFit"] = core._dispersion_function(dds, bm)      # parametric / mean / a caller's function ('custom')
     # round 2: MAP + test on the shard                                          (:54-66)
     core.estimateDispersionsMAP(dds, dispPriorVar=dispPriorVar)
     if betaPrior and kw.get("betaPriorVar") is None:

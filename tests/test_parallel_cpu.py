@@ -209,3 +209,49 @@ def test_two_shards_equal_serial_with_the_beta_prior(tmp_path, oracle):
     for k in COLS + ["MLE_beta"]:
         got = np.concatenate([p[k] for p in parts])
         np.testing.assert_array_equal(got, serial.mcols[k], err_msg=k)
+
+
+# ---- a caller's trend function (fitType = callable, the 'custom' dispersion function) ------------------
+def _loglinear_trend(means, disps):
+    """a stand-in for R's fitType = "local": least squares of log disp on log mean, returned as a function of the mean"""
+    ok = (disps > 1e-6) & (means > 0)
+    b, a = np.polyfit(np.log(means[ok]), np.log(disps[ok]), 1)
+    return lambda bm: np.exp(a + b * np.log(bm))
+
+
+def _worker_custom(rank, world, port, n, m, seed, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    from oracle import oracle as O
+    x = simulate.design_two_group(m)
+    d = simulate.make_counts(n, x, seed=seed)
+    idx = parallel.shard_ranges(d["counts"].shape[0], world)[rank]
+    dds = core.DESeqDataSet(d["counts"][idx], x, sizeFactors=d["size_factors"], engine=HostEngine(O))
+    parallel.DESeqParallel(dds, fitType=_loglinear_trend)
+    assert dds.dispersionFunction["fitType"] == "custom"
+    np.savez(os.path.join(outdir, "cu%d.npz" % rank), idx=idx, **{k: dds.mcols[k] for k in COLS})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_shards_with_a_callers_trend_function(tmp_path, oracle):
+    """DESeqParallel with fitType = a function: the shard evaluates the global function on its own means (it used to
+    build an object array out of the function and fail in estimateDispersionsMAP)"""
+    import torch.multiprocessing as mp
+    n, m, seed, world = 300, 12, 37, 2
+    mp.spawn(_worker_custom, args=(world, _free_port(), n, m, seed, str(tmp_path)), nprocs=world, join=True)
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_two_group(m)
+    d = simulate.make_counts(n, x, seed=seed)
+    serial = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=d["size_factors"], engine=HostEngine(oracle)),
+                        fitType=_loglinear_trend)
+    parts = [np.load(os.path.join(str(tmp_path), "cu%d.npz" % r)) for r in range(world)]
+    for k in COLS:
+        got = np.concatenate([p[k] for p in parts])
+        np.testing.assert_array_equal(got, serial.mcols[k], err_msg=k)
