@@ -111,6 +111,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic workload (SURVEY 8d: seeds 1..3)")
+    ap.add_argument("--size-factors", choices=("lognormal", "unit"), default="lognormal",
+                    help="s_j ~ logN(0, 0.25^2) (SURVEY 8d's second variant: the harder half, the headline since round 5) or s_j = 1")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N = 1: skip the short extra timed regions on the other workload variants (s_j = 1, seeds 2 and 3)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of a 256-row sample of the step's own result")
     ap.add_argument("--genes", type=int, default=0, help="override the config's gene count (tuning runs)")
     ap.add_argument("--samples", type=int, default=0, help="override the config's sample count (tuning runs)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second (weak-scaling) timed region")
@@ -183,9 +189,13 @@ def main():
         reduced = np.column_stack([np.ones(m), (np.arange(m) >= m // 2).astype(np.float64)])
     E = DeviceEngine(dev)
 
-    def workload(seed, lo_hi=None):
+    def workload(seed, lo_hi=None, sf_mode=None):
         """synthetic counts (+ weights) of this config, resident in HBM in R layout; lo_hi = this rank's shard"""
-        d = simulate.make_counts(n_req, x, seed=seed, intercept_mean=cfg.get("intercept_mean", 4.0))
+        sf_in = None
+        if (sf_mode or args.size_factors) == "lognormal":
+            # SURVEY 8d: s_j ~ logN(0, 0.25^2), its own stream so that the per-gene draws are those of the s_j = 1 variant
+            sf_in = np.exp(np.random.Generator(np.random.PCG64(1000 + seed)).normal(0.0, 0.25, m))
+        d = simulate.make_counts(n_req, x, seed=seed, intercept_mean=cfg.get("intercept_mean", 4.0), size_factors=sf_in)
         counts = d["counts"]
         w = make_weights(counts.shape[0], m, seed + 77) if use_w else None
         n_all = counts.shape[0]
@@ -287,7 +297,7 @@ def main():
         return dt, n_total, dds, stats
 
     # ---- headline: STRONG scaling, the config's genes in total -----------------------------------------------
-    W = workload(1, shard if world > 1 else None)
+    W = workload(args.seed, shard if world > 1 else None)
     n = W["n"]
     step = make_step(W)
 
@@ -306,10 +316,35 @@ def main():
     mc = parallel.concat_mcols(dds, [k for k in ("betaIter", "dispIter", "dispGeneIter") if k in dds[0].mcols])
     digest = result_digest(dds[0], world, comm_dev, parallel)
 
+    # parity where the driver can see it: a fixed 256-row sample of THIS step's result against the CPU oracle (the checker,
+    # after the timed region, never the thing measured)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            parity = parity_sample(dds[0], W, x, cfg, factors, reduced, rows=256)
+        except Exception as e:                                       # noqa: BLE001
+            parity = {"error": repr(e)}
+
+    # the other halves of the spec'd workload, short timed regions of the same step: s_j = 1 and seeds 2, 3
+    variants = None
+    if world == 1 and not args.no_variants and not args.genes and not args.samples:
+        variants = []
+        keep_steps, keep_warm = args.steps, args.warmup
+        args.steps, args.warmup = max(3, min(5, keep_steps)), 1
+        for vseed, vmode in ((args.seed, "unit" if args.size_factors == "lognormal" else "lognormal"),
+                             (args.seed + 1, args.size_factors), (args.seed + 2, args.size_factors)):
+            Wv = workload(vseed, None, vmode)
+            dtv, ntv, ddv, _ = timed(make_step(Wv), Wv["n"])
+            variants.append({"seed": vseed, "size_factors": vmode, "genes": ntv, "steps": args.steps,
+                             "ms_per_step": dtv / args.steps * 1e3, "value": ntv * args.steps / dtv,
+                             "result_digest": result_digest(ddv[0], world, comm_dev, parallel)})
+            Wv = ddv = None
+        args.steps, args.warmup = keep_steps, keep_warm
+
     weak = None
     if world > 1 and not args.no_weak:
         dds = step = None
-        W2 = workload(1 + rank)
+        W2 = workload(args.seed + rank)
         dtw, ntw, _, _ = timed(make_step(W2), W2["n"])
         weak = {"value": ntw * args.steps / dtw, "unit": "genes/s", "ms_per_step": dtw / args.steps * 1e3,
                 "genes_per_gpu": W2["n"], "genes_total": ntw}
@@ -351,8 +386,8 @@ def main():
         # HBM bytes / VALU instructions per launch from the PMC counters: collected in separate rocprofv3 --pmc
         # passes of this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed under
         # profiles/ -- counters cannot be read from inside the process.
-        traffic, valu, pmc_file = None, None, None
-        for cand in ("r04_pmc_%s.json" % args.config, "r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
+        traffic, valu, f64, pmc_file = None, None, None, None
+        for cand in ("r05_pmc_%s.json" % args.config, "r04_pmc_%s.json" % args.config, "r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
                      "r01_pmc.json" if args.config == "C3" else None):
             if cand and os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
@@ -369,6 +404,17 @@ def main():
             valu = {"kernel": dom, "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
                     "frac": ach / peak, "valu_instructions_per_launch": insts,
                     "note": "SQ_INSTS_VALU from profiles/%s (same workload), launch time measured live" % pmc_file}
+            if pmc[dom].get("f64_flops_per_launch"):
+                # the bound that is real for this path: f64 vector flops of the dominant kernel -- the PMC pass's
+                # SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave-instructions x 64 lanes (fma = 2) -- over the launch time
+                # measured live, against the f64 vector peak = CUs x 4 SIMDs x 16 lanes x 2 flop x clock (78.6 TF at 2.4 GHz)
+                flops = pmc[dom]["f64_flops_per_launch"] * scale
+                peak_f = prop.multi_processor_count * 4 * 16 * 2 * clock_hz
+                f64 = {"kernel": dom, "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_f / 1e12, "unit": "TFLOP/s",
+                       "frac": flops / (avg_ms * 1e-3) / peak_f, "flops_per_launch": flops,
+                       "f64_arith_frac_of_valu_instructions": pmc[dom].get("f64_arith_frac_of_valu"),
+                       "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 from profiles/%s (same workload; lanes masked off "
+                               "count as flops: an upper bound), launch time measured live" % pmc_file}
         except (OSError, KeyError, TypeError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -405,11 +451,16 @@ def main():
                        "chain": "fused device-driven (dsq_deseq_dev)" if fused_used else "call-by-call (core.py)"},
             "roofline": roofline,
             "valu_roofline": valu,
+            "f64_roofline": f64,
             "kernels": kern,
             "kernels_outlier_refit": kern_refit,
             "mean_iterations": {k: float(np.nanmean(v)) for k, v in mc.items()},
             "result_digest": digest,
+            "parity": parity,
+            "workload": {"seed": args.seed, "size_factors": args.size_factors},
         }
+        if variants is not None:
+            out["variants"] = variants
         if weak is not None:
             out["weak"] = weak
         if hostpath is not None:
@@ -425,6 +476,58 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_sample(dds, W, x, cfg, factors, reduced, rows=256):
+    """A fixed sample of the rows of the step's OWN result, re-fitted by the CPU oracle (oracle/, the checker): the gene-wise
+    dispersion search, the MAP search under the run's trend and prior variance, and the final IRLS + test -- every per-gene
+    step of the chain (the all-gene steps, trend and prior variance, are taken from the run: they are not per-gene).  Rows
+    whose counts the outlier step replaced are left out of the sample (their columns come from the refit on the replaced
+    counts).  iter_equal: fraction of sampled rows whose three iteration counts are all equal; max_rel: largest relative
+    difference over the float columns (0.0 = bit-identical)."""
+    from deseq2_amd import core
+    from deseq2_amd.engine import HostEngine
+    from oracle import oracle as O
+    mc = dds.mcols
+    n = W["counts"].shape[0]
+    ok = ~np.asarray(mc["allZero"], bool)
+    if "replace" in mc:
+        ok &= ~(np.nan_to_num(np.asarray(mc["replace"], np.float64)) != 0)
+    cand = np.where(ok)[0]
+    pick = np.sort(np.random.Generator(np.random.PCG64(20260926)).choice(cand, min(rows, cand.size), replace=False))
+    w = None if W["w"] is None else W["w"][pick]
+    o = core.DESeqDataSet(W["counts"][pick], x, sizeFactors=W["sf"], weights=w, engine=HostEngine(O))
+    minmu = cfg.get("minmu", 0.5)
+    core.estimateDispersionsGeneEst(o, minmu=minmu)
+    fn = dict(dds.dispersionFunction)
+    o.dispersionFunction = fn
+    o.mcols["dispFit"] = np.asarray(mc["dispFit"])[pick]
+    core.estimateDispersionsMAP(o, dispPriorVar=fn["dispPriorVar"])
+    if cfg["test"] == "Wald":
+        kw = dict(minmu=minmu)
+        if cfg.get("betaPrior"):
+            kw.update(betaPrior=True, factors=factors, betaPriorVar=dds.attrs["betaPriorVar"])
+        core.nbinomWaldTest(o, **kw)
+        fcols = ["baseMean", "dispGeneEst", "dispMAP", "dispersion", "beta", "betaSE", "WaldStatistic"]
+    else:
+        core.nbinomLRT(o, reduced, minmu=minmu)
+        fcols = ["baseMean", "dispGeneEst", "dispMAP", "dispersion", "beta", "betaSE", "LRTStatistic"]
+    icols = ["dispGeneIter", "dispIter", "betaIter"]
+    eq = np.ones(pick.size, bool)
+    for k in icols:
+        eq &= np.asarray(o.mcols[k], np.float64) == np.asarray(mc[k], np.float64)[pick]
+    max_rel, worst = 0.0, None
+    for k in fcols:
+        a, b = np.asarray(mc[k], np.float64)[pick], np.asarray(o.mcols[k], np.float64)
+        both = np.isfinite(a) & np.isfinite(b)
+        assert (np.isfinite(a) == np.isfinite(b)).all(), "NA pattern of %s differs" % k
+        if both.any():
+            r = float(np.max(np.abs(a[both] - b[both]) / np.maximum(np.abs(b[both]), 1e-300)))
+            if r > max_rel:
+                max_rel, worst = r, k
+    return {"rows": int(pick.size), "of_genes": int(n), "iter_equal": float(eq.mean()), "max_rel": max_rel, "worst_column": worst,
+            "columns": fcols + icols, "checker": "oracle/ (CPU restatement, pinned to the compiled reference by tests/test_oracle_vs_reference.py)",
+            "tolerance_north_star": 1e-6}
 
 
 def result_digest(dds, world, comm_dev, parallel):

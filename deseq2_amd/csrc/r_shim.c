@@ -16,6 +16,7 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 #include <R_ext/Utils.h>
+#include <stdlib.h>
 #include <string.h>
 #include "deseq2_mi355x.h"
 
@@ -43,6 +44,8 @@ static void need_length(SEXP s, int n, const char *what) {
 /* genes per library call: between two calls R_CheckUserInterrupt() runs (the reference polls every 100 genes,
  * src/DESeq2.cpp:195,320,493; a range here is ~50 ms of GPU work) */
 static int rows_per_call(int n, int m) {
+    const char *e = getenv("DSQ_SHIM_ROWS");              /* (tests: force several ranges on a small matrix) */
+    if (e && atoi(e) > 0) return atoi(e) > n ? n : atoi(e);
     double r = 2.5e7 / (double)(m > 0 ? m : 1);
     if (r < 4096.0) r = 4096.0;
     return r > (double)n ? n : (int)r;

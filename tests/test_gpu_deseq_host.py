@@ -239,6 +239,28 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     _against_oracle(b.mcols, o, name, test)
 
 
+@pytest.mark.parametrize("name", ["bc_outliers", "factor6_lrt_reduced2", "bp_factor5_expanded_outliers"])
+def test_host_entry_in_eight_ranges(E, name):
+    """dsq_deseq with the genes cut into EIGHT ranges inside the library (DSQ_HOST_SHARDS=8: the multi-device walk of the
+    host entry -- per-range chains, the trend over the gathered vectors, the global refit count -- on one device):
+    identical to the single-range call, column by column"""
+    counts, x, sf, kw = CASES[name]
+    one = _host_entry(counts, x, sf, kw, assays=("mu", "cooks"))
+    old = os.environ.get("DSQ_HOST_SHARDS")
+    try:
+        os.environ["DSQ_HOST_SHARDS"] = "8"
+        eight = _host_entry(counts, x, sf, kw, assays=("mu", "cooks"))
+    finally:
+        if old is None:
+            os.environ.pop("DSQ_HOST_SHARDS", None)
+        else:
+            os.environ["DSQ_HOST_SHARDS"] = old
+    for k in sorted(one):
+        if isinstance(one[k], np.ndarray):
+            assert_same(_f(eight[k]), _f(one[k]), "%s in 8 ranges: %s" % (name, k))
+    assert eight["dispersionFunction"]["dispPriorVar"] == one["dispersionFunction"]["dispPriorVar"]
+
+
 @pytest.mark.parametrize("shards", [0, 3])
 def test_the_callers_trend_in_two_host_calls(E, shards):
     """what the R patch does for fitType = "local" (INTEGRATION.md section 4): dsq_deseq(geneEstOnly) -> the caller's trend at

@@ -227,6 +227,30 @@ def test_bench_spawns_its_own_ranks():
     assert j2["result_digest"] == j1["result_digest"]          # sharded == serial, every per-gene result column
 
 
+def test_bench_eight_ranks_on_one_device_equal_serial():
+    """the N = 8 path of bench.py (what the driver launches for SCALE): eight ranks (all on cuda:0 here, the n-vector
+    exchanges over gloo), shards cut as R/parallel.R:10 -- the digest over every per-gene result column equals the serial
+    run's (tests/testthat/test_parallel.R:27-37 at 8 workers), and the parity block reports the oracle's bits"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSQ_BENCH_ONE_DEVICE="1")
+    common = ["--steps", "1", "--warmup", "0", "--genes", "4100", "--no-cpu-baseline", "--no-hostpath", "--no-weak"]
+    r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"] + common, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    j8 = json.loads(r8.stdout.strip().splitlines()[-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert j8["n_gpus"] == 8 and j8["config"]["genes_total"] == j1["config"]["genes_total"]
+    assert abs(j8["config"]["genes_this_gpu"] * 8 - j8["config"]["genes_total"]) < 8
+    assert j8["config"]["chain"].startswith("fused")
+    assert j8["result_digest"] == j1["result_digest"]
+    for j in (j1, j8):
+        assert j["parity"]["iter_equal"] == 1.0 and j["parity"]["max_rel"] == 0.0, j["parity"]
+
+
 def test_global_refit_count_over_rccl_single_rank():
     """fused._global_refit_count with a DEVICE communicator (RCCL, backend "nccl"): the device all-reduce of the N_REFIT
     counter, its one-time check against the host exchange and the ranks' consensus -- exercised on a 1-rank group (the

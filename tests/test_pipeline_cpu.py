@@ -502,3 +502,24 @@ def test_trimmed_mean_fit_is_the_correctly_rounded_mean_of_the_kept_values():
     # all kept values equal; a single value
     assert O.trimmedMeanFit(np.full(3000, 0.25)) == core.trimmed_mean_fit(np.full(3000, 0.25)) == 0.25
     assert O.trimmedMeanFit(np.array([0.3, np.nan, 1e-9])) == core.trimmed_mean_fit(np.array([0.3, np.nan, 1e-9])) == 0.3
+
+
+def test_bench_parity_sample_on_the_oracle_chain(oracle):
+    """bench.py's "parity" block (a sample of the step's own result re-fitted per gene by the oracle under the run's trend and
+    prior variance) run on a result the oracle chain itself produced: every sampled row identical, iterations equal; and
+    a perturbed result is reported as such"""
+    import bench
+    from deseq2_amd import core, simulate
+    from deseq2_amd.engine import HostEngine
+    x = simulate.design_batch_condition(18)
+    sf = np.exp(np.random.Generator(np.random.PCG64(5)).normal(0, 0.25, 18))
+    d = simulate.make_counts(500, x, seed=3, size_factors=sf)
+    dds = core.DESeq(core.DESeqDataSet(d["counts"], x, sizeFactors=sf, engine=HostEngine(oracle)))
+    W = {"counts": d["counts"], "sf": sf, "w": None}
+    cfg = {"test": "Wald"}
+    par = bench.parity_sample(dds, W, x, cfg, None, None, rows=64)
+    assert par["rows"] == 64 and par["iter_equal"] == 1.0 and par["max_rel"] == 0.0, par
+    dds.mcols["beta"] = dds.mcols["beta"] * (1 + 1e-9)
+    dds.mcols["dispIter"] = dds.mcols["dispIter"] + 1
+    par = bench.parity_sample(dds, W, x, cfg, None, None, rows=64)
+    assert par["iter_equal"] == 0.0 and 0.5e-9 < par["max_rel"] < 2e-9 and par["worst_column"] == "beta", par

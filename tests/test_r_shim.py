@@ -150,16 +150,21 @@ def test_fitDisp_and_fitDispGrid_through_the_shim():
 
 
 @pytest.mark.gpu
-def test_ranges_between_interrupt_polls_cover_every_row():
-    """the shim cuts a large call into ranges and polls R_CheckUserInterrupt between them (the reference polls every 100
-    genes, src/DESeq2.cpp:195): a 9 000 x 6 call runs as three ranges and equals the one-range result"""
+def test_ranges_between_interrupt_polls_cover_every_row(monkeypatch):
+    """the shim cuts a large call into ranges (about 2.5e7 matrix entries each) and polls R_CheckUserInterrupt between them
+    (the reference polls every 100 genes, src/DESeq2.cpp:195): with the range length forced down to 1 000 rows a
+    2 600-row call runs as three ranges and equals the one-range result"""
     from deseq2_amd import native
     L = rmock.lib()
     L.rmock_reset()
-    d = make_case(9000, 6, "two_group", seed=21)
+    d = make_case(2600, 6, "two_group", seed=21)
+    n = d["counts"].shape[0]
+    assert 2000 < n <= 2600
     args, lam = _beta_args(d)
+    monkeypatch.setenv("DSQ_SHIM_ROWS", "1000")
     got = rmock.dotCall("_DESeq2_fitBeta", *args)
-    assert L.rmock_interrupt_polls() >= 4          # entry + three ranges of <= 4096 rows
+    assert L.rmock_interrupt_polls() == 4          # entry + three ranges
+    monkeypatch.delenv("DSQ_SHIM_ROWS")
     ref = native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, 0.0], d["beta_init"], lam, d["weights"], False,
                          1e-8, 100, True, 0.5)
     for k in ("beta_mat", "iter", "deviance", "hat_diagonals"):
@@ -198,6 +203,7 @@ def test_DESeq_through_the_shim(test):
     d = make_case(600, 16, "two_group", seed=13)
     counts = d["counts"].copy()
     counts[5] = 0                                   # an all-zero row: NA in the integer / logical columns
+    n = counts.shape[0]
     x = d["x"]
     m, p = x.shape
     sf = np.exp(np.random.Generator(np.random.PCG64(4)).normal(0, 0.2, m))
@@ -216,7 +222,7 @@ def test_DESeq_through_the_shim(test):
     assert names[:4] == ["baseMean", "baseVar", "allZero", "dispGeneEst"] and len(names) == 28
     types = {n: rmock.rtype(L.rmock_elt(out, i)) for i, n in enumerate(names)}
     assert types["allZero"] == rmock.LGLSXP and types["dispIter"] == rmock.INTSXP and types["betaConv"] == rmock.LGLSXP
-    assert got["H"] is None and got["replaceCounts"] is None and got["mu"].shape == (600, m)
+    assert got["H"] is None and got["replaceCounts"] is None and got["mu"].shape == (n, m)
     na_int = np.iinfo(np.int32).min
     assert got["dispIter"][5] == na_int and got["betaConv"][5] == na_int and got["allZero"][5] == 1
     assert L.rmock_is_na_real(float(got["dispersion"][5])) == 1          # NA_real_, not a plain NaN
@@ -229,9 +235,9 @@ def test_DESeq_through_the_shim(test):
         _same(g, ref[k], k)
     if test == "Wald":
         np.testing.assert_allclose(got["stat"], ref["stat"], rtol=1e-8, equal_nan=True)
-        assert got["stat"].shape == (600, p) and got["logLikeReduced"].shape == (600,)
+        assert got["stat"].shape == (n, p) and got["logLikeReduced"].shape == (n,)
     else:
-        assert got["stat"].shape == (600, 0)
+        assert got["stat"].shape == (n, 0)
         np.testing.assert_allclose(got["logLikeReduced"], ref["logLikeReduced"], rtol=1e-9, equal_nan=True)
     np.testing.assert_allclose(got["mu"], ref["mu"], rtol=1e-9)
     assert got["dispersionFunction"].shape == (5,)

@@ -5,7 +5,7 @@
 #   tests[:PYTEST_ARGS]        pytest -m gpu (extra args after ':' , e.g. tests:tests/test_gpu_fused.py)
 #   bench:CFG[:ARGS...]        python bench.py --config CFG ARGS (':'-separated; without CPU baseline / hostpath unless +cpu / +host)
 #   stats:CFG                  rocprofv3 --kernel-trace --stats of bench.py --config CFG (5 steps), summarised to <TAG>/stats_CFG.md
-#   pmc:CFG                    three separate rocprofv3 --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE) -> <TAG>/pmc_CFG.json
+#   pmc:CFG                    five separate rocprofv3 --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE, the f64 op mix, int / cvt / smem) -> <TAG>/pmc_CFG.json
 #   py:SCRIPT[:ARGS...]        python SCRIPT ARGS
 #   sh:SCRIPT[:ARGS...]        bash SCRIPT ARGS
 #   env:NAME=VALUE             export for the following steps (DSQ_* tuning knobs)
@@ -50,15 +50,17 @@ PY
     pmc)
       cfg=${F[1]}
       k=0
-      for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+      for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" \
+                 "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM"; do
         k=$((k+1)); d=$O/pmc${k}_$cfg; rm -rf "$d"
         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$d" -o p -- python "$R/bench.py" --config "$cfg" --steps 2 --warmup 1 --no-cpu-baseline --no-hostpath > "$O/pmc${k}_$cfg.log" 2>&1)
       done
       P1=$(dirname "$(find "$O/pmc1_$cfg" -name p_counter_collection.csv | head -1)"); P2=$(dirname "$(find "$O/pmc2_$cfg" -name p_counter_collection.csv | head -1)"); P3=$(dirname "$(find "$O/pmc3_$cfg" -name p_counter_collection.csv | head -1)")
+      export DSQ_PMC_EXTRA="$(dirname "$(find "$O/pmc4_$cfg" -name p_counter_collection.csv | head -1)"):$(dirname "$(find "$O/pmc5_$cfg" -name p_counter_collection.csv | head -1)")"
       NG=$(python -c "import bench; print(bench.CONFIGS['$cfg']['genes'])")
       python tools/pmc_summary.py "$P2" "$P3" "$P1" "$O/pmc_$cfg.json" "$NG" "rocprofv3 --pmc passes (SQ_*, FETCH_SIZE, WRITE_SIZE separately) of bench.py --config $cfg --steps 2 --warmup 1, state $TAG; means over the FULL-SIZE launches of each kernel (dispatches joined with the kernel trace of the same pass; a launch counts when it ran for >= half of the kernel's longest launch); FETCH_SIZE x2 (gfx950 note) + WRITE_SIZE; tools/gpu_job.sh pmc:$cfg" > "$O/pmc_$cfg.log" 2>&1
       echo "[gpu_job] pmc $cfg rc=$?"; tail -3 "$O/pmc_$cfg.log"
-      rm -rf "$O/pmc1_$cfg" "$O/pmc2_$cfg" "$O/pmc3_$cfg";;
+      rm -rf "$O/pmc1_$cfg" "$O/pmc2_$cfg" "$O/pmc3_$cfg" "$O/pmc4_$cfg" "$O/pmc5_$cfg";;
     sh)
       name=$(basename "${F[1]}" .sh)
       timeout 900 bash "${F[1]}" "${F[@]:2}" > "$O/$name.log" 2>&1; echo "[gpu_job] sh ${F[1]} rc=$?"; tail -20 "$O/$name.log";;

@@ -32,6 +32,15 @@ def main(fetch_dir, write_dir, sq_dir, out):
     kt["k"] = kt["Kernel_Name"].str.extract(r"dsq::(\w+?)_kernel")
     kt["ms"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e6
     kt = kt[kt["ms"] >= 0.5 * kt.groupby("k")["ms"].transform("max")]
+    # further SQ passes (the f64 operation mix: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; int / cvt / smem): directories in
+    # DSQ_PMC_EXTRA, ':'-separated; their columns join the SQ table
+    import os
+    for d in [e for e in os.environ.get("DSQ_PMC_EXTRA", "").split(":") if e and e != "."]:
+        try:
+            x = load(d)
+            s = s.join(x[[c for c in x.columns if c not in s.columns]], how="left")
+        except (OSError, KeyError, ValueError) as e:
+            print("pmc_summary: extra pass %s skipped: %r" % (d, e))
     res = {}
     for k in s.index:
         r = {"fetch_bytes_per_launch": float(f.loc[k, "FETCH_SIZE"]) * 1024 * 2 if k in f.index else None,
@@ -45,6 +54,13 @@ def main(fetch_dir, write_dir, sq_dir, out):
         # SQ_* cycle counters are in quad-cycles summed over SIMDs
         if "SQ_ACTIVE_INST_VALU" in r and "SQ_WAVE_CYCLES" in r and r["SQ_WAVE_CYCLES"]:
             r["valu_active_frac_of_wave_cycles"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"]
+        # the dynamic f64 mix: wave-instructions by class; flops = (add + mul + 2 fma) x 64 lanes (an upper bound: masked
+        # lanes count); "useful" share of the VALU issue slots
+        if all(("SQ_INSTS_VALU_%s_F64" % c) in r for c in ("ADD", "MUL", "FMA", "TRANS")) and r.get("SQ_INSTS_VALU"):
+            a, mu_, fm, tr = (r["SQ_INSTS_VALU_%s_F64" % c] for c in ("ADD", "MUL", "FMA", "TRANS"))
+            r["f64_arith_insts_per_launch"] = a + mu_ + fm + tr
+            r["f64_arith_frac_of_valu"] = (a + mu_ + fm + tr) / r["SQ_INSTS_VALU"]
+            r["f64_flops_per_launch"] = 64.0 * (a + mu_ + 2.0 * fm + tr)
         res[k] = r
     if "fit_beta_cell" in res and "fit_beta" not in res:
         res["fit_beta"] = dict(res["fit_beta_cell"])       # factor designs run the cell-collapsed fitBeta kernel
