@@ -584,30 +584,9 @@ static hipError_t launch_prefit_p(const PrefitKernelParams &kp, hipStream_t st) 
 hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok) {
     *ok = true;
     switch (kp.p) {
-    case 1: return launch_prefit_p<1>(kp, st);
-    case 2: return launch_prefit_p<2>(kp, st);
-    case 3: return launch_prefit_p<3>(kp, st);
-    case 4: return launch_prefit_p<4>(kp, st);
-    case 5: return launch_prefit_p<5>(kp, st);
-    case 6: return launch_prefit_p<6>(kp, st);
-    case 7: return launch_prefit_p<7>(kp, st);
-    case 8: return launch_prefit_p<8>(kp, st);
-    case 9: return launch_prefit_p<9>(kp, st);
-    case 10: return launch_prefit_p<10>(kp, st);
-    case 11: return launch_prefit_p<11>(kp, st);
-    case 12: return launch_prefit_p<12>(kp, st);
-    case 13: return launch_prefit_p<13>(kp, st);
-    case 14: return launch_prefit_p<14>(kp, st);
-    case 15: return launch_prefit_p<15>(kp, st);
-    case 16: return launch_prefit_p<16>(kp, st);
-    case 17: return launch_prefit_p<17>(kp, st);
-    case 18: return launch_prefit_p<18>(kp, st);
-    case 19: return launch_prefit_p<19>(kp, st);
-    case 20: return launch_prefit_p<20>(kp, st);
-    case 21: return launch_prefit_p<21>(kp, st);
-    case 22: return launch_prefit_p<22>(kp, st);
-    case 23: return launch_prefit_p<23>(kp, st);
-    case 24: return launch_prefit_p<24>(kp, st);
+#define DSQ_X(W) case W: return launch_prefit_p<W>(kp, st);
+    DSQ_P_EACH(DSQ_X)
+#undef DSQ_X
     default: *ok = false; return hipSuccess;
     }
 }
@@ -621,30 +600,9 @@ static hipError_t launch_linear_mu_p(const PrefitKernelParams &kp, double mu_flo
 hipError_t launch_linear_mu(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st, bool *ok) {
     *ok = true;
     switch (kp.p) {
-    case 1: return launch_linear_mu_p<1>(kp, mu_floor, mu, st);
-    case 2: return launch_linear_mu_p<2>(kp, mu_floor, mu, st);
-    case 3: return launch_linear_mu_p<3>(kp, mu_floor, mu, st);
-    case 4: return launch_linear_mu_p<4>(kp, mu_floor, mu, st);
-    case 5: return launch_linear_mu_p<5>(kp, mu_floor, mu, st);
-    case 6: return launch_linear_mu_p<6>(kp, mu_floor, mu, st);
-    case 7: return launch_linear_mu_p<7>(kp, mu_floor, mu, st);
-    case 8: return launch_linear_mu_p<8>(kp, mu_floor, mu, st);
-    case 9: return launch_linear_mu_p<9>(kp, mu_floor, mu, st);
-    case 10: return launch_linear_mu_p<10>(kp, mu_floor, mu, st);
-    case 11: return launch_linear_mu_p<11>(kp, mu_floor, mu, st);
-    case 12: return launch_linear_mu_p<12>(kp, mu_floor, mu, st);
-    case 13: return launch_linear_mu_p<13>(kp, mu_floor, mu, st);
-    case 14: return launch_linear_mu_p<14>(kp, mu_floor, mu, st);
-    case 15: return launch_linear_mu_p<15>(kp, mu_floor, mu, st);
-    case 16: return launch_linear_mu_p<16>(kp, mu_floor, mu, st);
-    case 17: return launch_linear_mu_p<17>(kp, mu_floor, mu, st);
-    case 18: return launch_linear_mu_p<18>(kp, mu_floor, mu, st);
-    case 19: return launch_linear_mu_p<19>(kp, mu_floor, mu, st);
-    case 20: return launch_linear_mu_p<20>(kp, mu_floor, mu, st);
-    case 21: return launch_linear_mu_p<21>(kp, mu_floor, mu, st);
-    case 22: return launch_linear_mu_p<22>(kp, mu_floor, mu, st);
-    case 23: return launch_linear_mu_p<23>(kp, mu_floor, mu, st);
-    case 24: return launch_linear_mu_p<24>(kp, mu_floor, mu, st);
+#define DSQ_X(W) case W: return launch_linear_mu_p<W>(kp, mu_floor, mu, st);
+    DSQ_P_EACH(DSQ_X)
+#undef DSQ_X
     default: *ok = false; return hipSuccess;
     }
 }

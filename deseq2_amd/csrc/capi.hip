@@ -272,26 +272,30 @@ struct DispatchP<0> {
     static hipError_t optim(int, const OptimKernelParams &, hipStream_t, bool *ok) { *ok = false; return hipSuccess; }
 };
 
-// (wide designs: the caller passes the PADDED width, 16 or 24 -- the chain of pipeline.hip, dsq_optim_rows)
+// (wide designs: the caller passes the PADDED width, one of DSQ_WIDE_LIST -- the chain of pipeline.hip, dsq_optim_rows)
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok) {
-    if (p == DSQ_P_WIDE0) { *ok = true; return launch_fit_beta_p<DSQ_P_WIDE0>(kp, st); }
-    if (p == DSQ_P_WIDE) { *ok = true; return launch_fit_beta_p<DSQ_P_WIDE>(kp, st); }
+#define DSQ_X(W) if (p == W) { *ok = true; return launch_fit_beta_p<W>(kp, st); }
+    DSQ_WIDE_LIST(DSQ_X)
+#undef DSQ_X
     return DispatchP<DSQ_P_REG>::beta(p, kp, st, ok);
 }
 void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr) {
-    if (p == DSQ_P_WIDE0) { fit_beta_scratch_doubles<DSQ_P_WIDE0>(n, m, useW, slab, cscr); return; }
-    if (p == DSQ_P_WIDE) { fit_beta_scratch_doubles<DSQ_P_WIDE>(n, m, useW, slab, cscr); return; }
+#define DSQ_X(W) if (p == W) { fit_beta_scratch_doubles<W>(n, m, useW, slab, cscr); return; }
+    DSQ_WIDE_LIST(DSQ_X)
+#undef DSQ_X
     DispatchP<DSQ_P_REG>::beta_scratch(p, n, m, useW, slab, cscr);
 }
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
-    if (p == DSQ_P_WIDE0) { *ok = true; return launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, grid); }
-    if (p == DSQ_P_WIDE) { *ok = true; return launch_fit_disp_p<DSQ_P_WIDE>(kp, st, grid); }
+#define DSQ_X(W) if (p == W) { *ok = true; return launch_fit_disp_p<W>(kp, st, grid); }
+    DSQ_WIDE_LIST(DSQ_X)
+#undef DSQ_X
     return DispatchP<DSQ_P_REG>::disp(p, kp, st, grid, ok);
 }
 hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok) {
     // (wide designs: the caller passes the padded width, dsq_optim_rows)
-    if (p == DSQ_P_WIDE0) { *ok = true; return launch_optim_p<DSQ_P_WIDE0>(kp, st); }
-    if (p == DSQ_P_WIDE) { *ok = true; return launch_optim_p<DSQ_P_WIDE>(kp, st); }
+#define DSQ_X(W) if (p == W) { *ok = true; return launch_optim_p<W>(kp, st); }
+    DSQ_WIDE_LIST(DSQ_X)
+#undef DSQ_X
     return DispatchP<DSQ_P_REG>::optim(p, kp, st, ok);
 }
 
@@ -300,7 +304,7 @@ hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t s
 // Gram / QR / LU arithmetic of the real coefficients sees only extra exact zeros (x + 0 = x, 0 * y = 0), so their
 // results keep their bits (tests/test_gpu_wide.py compares with the oracle run at the true p).
 static inline bool is_wide(int p) { return p > DSQ_P_REG && p <= DSQ_P_WIDE; }
-static inline int wide_width(int p) { return p <= DSQ_P_WIDE0 ? DSQ_P_WIDE0 : DSQ_P_WIDE; }   // padded width for a wide p
+static inline int wide_width(int p) { return dsq_wide_width(p); }   // padded width for a wide p
 
 static int wide_pad_matrix(int slot, const double *src, size_t rows, int p, hipStream_t st, double **out) {
     // column-major rows x p  ->  rows x wide_width(p), new columns zero
@@ -314,12 +318,12 @@ static int wide_pad_matrix(int slot, const double *src, size_t rows, int p, hipS
     return DSQ_OK;
 }
 
-static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const double **xout, unsigned *padmask) {
+static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const double **xout, unsigned long long *padmask) {
     double *b;
     int rc = wide_pad_matrix(WS_PAD_X, x, (size_t)m, p, st, &b);
     if (rc) return rc;
     *xout = b;
-    *padmask = ((1u << wide_width(p)) - 1u) & ~((1u << p) - 1u);
+    *padmask = ((1ull << wide_width(p)) - 1ull) & ~((1ull << p) - 1ull);
     return DSQ_OK;
 }
 
@@ -423,7 +427,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     const int pk = wide ? wide_width(a->p) : a->p;       // the kernel's design width
     double *wide_out = nullptr;
     if (wide) {
-        unsigned padmask;
+        unsigned long long padmask;
         rc = wide_pad_x(a->m, a->p, a->x, st, &kp.x, &padmask); if (rc) return rc;
         static thread_local double ones[DSQ_P_WIDE];
         for (int c = 0; c < DSQ_P_WIDE; c++) ones[c] = 1.0;
@@ -461,9 +465,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         }
     }
     size_t slab_d = 0, cscr_d = 0;
-    if (wide && pk == DSQ_P_WIDE0) fit_beta_scratch_doubles<DSQ_P_WIDE0>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
-    else if (wide) fit_beta_scratch_doubles<DSQ_P_WIDE>(a->n, a->m, a->useWeights, &slab_d, &cscr_d);
-    else DispatchP<DSQ_P_REG>::beta_scratch(a->p, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
+    dispatch_beta_scratch(pk, a->n, a->m, a->useWeights, &slab_d, &cscr_d);
     {
         void *b; rc = ws_get(WS_SCRATCH, (slab_d + cscr_d) * sizeof(double) + 64, &b); if (rc) return rc;
         kp.scratch = (double *)b;
@@ -471,12 +473,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
     }
     bool ok = false;
     prof_begin(st);
-    if (wide) {
-        ok = true;
-        if (pk == DSQ_P_WIDE0) DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE0>(kp, st));
-        else DSQ_HIP(launch_fit_beta_p<DSQ_P_WIDE>(kp, st));
-    }
-    else DSQ_HIP(DispatchP<DSQ_P_REG>::beta(a->p, kp, st, &ok));
+    DSQ_HIP(dispatch_fit_beta(pk, kp, st, &ok));
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     if (wide) {     // the real coefficients are the leading columns of the padded n x 16 results
@@ -570,12 +567,7 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     kp.last_lp = o->last_lp; kp.last_dlp = o->last_dlp; kp.last_d2lp = o->last_d2lp;
     bool ok = false;
     prof_begin(st);
-    if (is_wide(a->p)) {
-        ok = true;
-        if (kp.p == DSQ_P_WIDE0) DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, false));
-        else DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, false));
-    }
-    else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, false, &ok));
+    DSQ_HIP(dispatch_fit_disp(kp.p, kp, st, false, &ok));       // (kp.p: the padded width for a wide design)
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);
@@ -598,12 +590,7 @@ static int fit_disp_grid_dev_locked(const DsqFitDispGridArgs *a, const DsqFitDis
     rc = work_counter(st, &kp.work_counter); if (rc) return rc;
     bool ok = false;
     prof_begin(st);
-    if (is_wide(a->p)) {
-        ok = true;
-        if (kp.p == DSQ_P_WIDE0) DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE0>(kp, st, true));
-        else DSQ_HIP(launch_fit_disp_p<DSQ_P_WIDE>(kp, st, true));
-    }
-    else DSQ_HIP(DispatchP<DSQ_P_REG>::disp(a->p, kp, st, true, &ok));
+    DSQ_HIP(dispatch_fit_disp(kp.p, kp, st, true, &ok));       // (kp.p: the padded width for a wide design)
     prof_end(st);
     if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
     return finish_ycheck(ycheck, st);

@@ -30,7 +30,7 @@ struct DispKernelParams {
     int ablate, force_iters; // profiling only
     int xlds;                // 1: X staged in LDS, 0: read through L1/L2
     int *work_counter;       // zeroed int: waves draw their next gene from it (nullptr: static grid-stride)
-    unsigned padmask;        // WIDE kernels: bit c set = design column c is zero padding
+    unsigned long long padmask;   // WIDE kernels: bit c set = design column c is zero padding
     const double *prior_sigmasq_dev;   // non-null: the prior variance is read from the device (fused pipeline)
     // design cells (see BetaKernelParams): ncell > 0 -> the Cox-Reid matrices are assembled from per-cell sums
     const int32_t *cell_perm, *cell_start;
@@ -213,11 +213,19 @@ hipError_t launch_xim_rows(const double *nf, const int32_t *rows, const int32_t 
 // Register-resident kernels exist for 1 <= p <= DSQ_P_REG (one translation unit per p,
 // explicit specialisations in fit_disp.hip / fit_beta.hip compiled with -DDSQ_P=p).
 #define DSQ_P_REG 10
-// 11 <= p <= DSQ_P_WIDE run on two more translation units (-DDSQ_P=16 and 24: loops not unrolled, p x p state in
-// scratch memory) over designs zero-padded to 16 or 24 columns: a padded column gets ridge 1 and a unit diagonal in
+// 11 <= p <= DSQ_P_WIDE run on the translation units of DSQ_WIDE_LIST (-DDSQ_P=16, 24, ...: loops not unrolled, p x p state in
+// scratch memory) over designs zero-padded to the next listed width: a padded column gets ridge 1 and a unit diagonal in
 // the Cox-Reid matrix, which leaves every quantity of the real coefficients unchanged (capi.hip, "wide designs").
+// (round 5: 32 and 48 added -- `~ patient + treatment` with up to 47 patients, factors of up to 48 levels; a 64-column
+//  build compiles for half an hour and is left out: p > 48 is refused)
 #define DSQ_P_WIDE0 16
-#define DSQ_P_WIDE 24
+#define DSQ_WIDE_LIST(X) X(16) X(24) X(32) X(48)
+#define DSQ_P_WIDE 48
+static inline int dsq_wide_width(int p) { return p <= 16 ? 16 : p <= 24 ? 24 : p <= 32 ? 32 : 48; }   // padded width of a wide p
+// every design width 1 .. DSQ_P_WIDE (the small per-width kernels of aux.hip: pre-fit moments, linear mu)
+#define DSQ_P_EACH(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) \
+    X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) \
+    X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48)
 #define DSQ_CMAX 32       // most design cells the cell-collapsed paths take
 #define DSQ_DISP_CELL_MINP 4   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);

@@ -10,7 +10,7 @@
 
 // The per-width kernels (one translation unit per design width, -DDSQ_P=p, p <= 10) want every p-loop of the
 // wave-uniform algebra fully unrolled so that the p x p state stays in registers.  The WIDE translation units
-// (-DDSQ_P=16 and 24, serving 11 <= p <= 24 on zero-padded designs) keep the loops of the general fitBeta kernel rolled,
+// (-DDSQ_P=16, 24, 32, 48, serving 11 <= p <= 48 on zero-padded designs) keep the loops of the general fitBeta kernel rolled,
 // with its work arrays in an LDS arena; everything built on LaneLU is unrolled at every width (2 p registers per matrix).
 #ifndef DSQ_WIDE_MIN
 #define DSQ_WIDE_MIN 11

@@ -12,7 +12,7 @@
 //   * the p x p algebra (LU with partial pivoting, determinant, inverse, traces): wave-uniform registers up to p = 3,
 //     one matrix column per lane (LaneLU, dsq_wave.hpp) from p = 4.
 // The Armijo line search itself is wave-uniform scalar control flow.
-// design widths from DSQ_DISP_WIDE_MIN up are served by two zero-padded builds (p = 16, 24)
+// design widths from DSQ_DISP_WIDE_MIN up are served by the zero-padded builds of DSQ_WIDE_LIST (p = 16, 24, 32, 48)
 #ifndef DSQ_DISP_WIDE_MIN
 #define DSQ_DISP_WIDE_MIN 11
 #endif
@@ -59,8 +59,8 @@ struct DispGene {
     int m, lane;
     double prior_mean, prior_sigmasq, thr;
     bool usePrior, useCR;
-    unsigned dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
-    unsigned padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
+    unsigned long long dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
+    unsigned long long padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
     // every fitted mean of the gene lies in [0, 1e140): with alpha in [e^-30, e^10] (the search's clamp, :215-224) and
     // on the dispersion grid, 1 + mu alpha is then a normal number far from the ends of the exponent range and its
@@ -114,7 +114,7 @@ DSQ_UNROLL_P
                     bool any = false;
                     for (int j = lane; j < m; j += 64)
                         if (keep_row(j) && __builtin_fabs(r.x(j, c)) > 0.0) any = true;
-                    if (!__any(any)) dropmask |= (1u << c);
+                    if (!__any(any)) dropmask |= (1ull << c);
                 }
             }
         }
@@ -143,19 +143,33 @@ DSQ_UNROLL_P
             _Pragma("unroll")
             for (int k = 0; k < K; k++) { Sl[k] = 0.0; acc[k] = 0.0; }
             int cur = 0;
+            // PARKED CLOSES (round 5).  A cell's sum is the butterfly over the 64 per-lane partials (steps xor 1, 2, 4, 8,
+            // 16, 32).  When the sweep leaves a cell only the steps inside a group of eight lanes run (xor 1, 2, 4; two
+            // sums share them as in wave_allreduce_pair) and the eight group sums are parked in the wave's LDS arena,
+            // [cell][k][group]; after the sweep lane 8 g + c picks up group g of cell c and the steps xor 8, 16, 32 run ONCE
+            // for eight cells at a time -- lane c ends with S_c, where the Gram build reads it.  The same additions on the
+            // same operands in the same order per cell (the bits of wave_allreduce), 16 VALU instructions per close
+            // instead of ~ 50; the parked state lives in 24 doubles of LDS per cell, not in registers (round 4's
+            // register-parked variant lost to its spills, profiles/r04_c4_experiments.md).
+            double *park = arena;
+            const int pgrp = lane >> 3;
             auto close_cell = [&]() {
-                if constexpr (K == 2) {
-                    double s0 = acc[0], s1 = acc[1];
-                    wave_allreduce_pair(s0, s1, lane);          // same bits as two butterflies, ~half the instructions
-                    if (lane == cur) { Sl[0] = s0; Sl[1] = s1; }
+                if constexpr (K >= 2) {
+                    const bool odd = (lane & 1) != 0;
+                    const double keep = odd ? acc[1] : acc[0], send = odd ? acc[0] : acc[1];
+                    double v = keep + lane_xor1(send);
+                    v = v + lane_xor2(v);
+                    v = v + lane_xor4(v);
+                    if ((lane & 6) == 0) park[(cur * 3 + (lane & 1)) * 8 + pgrp] = v;      // lanes 8 g (k = 0) and 8 g + 1 (k = 1)
                     acc[0] = 0.0; acc[1] = 0.0;
-                } else {
-                    _Pragma("unroll")
-                    for (int k = 0; k < K; k++) {
-                        const double v = wave_allreduce(acc[k]);
-                        if (lane == cur) Sl[k] = v;
-                        acc[k] = 0.0;
-                    }
+                }
+                if constexpr (K == 1 || K == 3) {
+                    double v = acc[K - 1];
+                    v = v + lane_xor1(v);
+                    v = v + lane_xor2(v);
+                    v = v + lane_xor4(v);
+                    if ((lane & 7) == 0) park[(cur * 3 + (K - 1)) * 8 + pgrp] = v;
+                    acc[K - 1] = 0.0;
                 }
             };
             const int tail_lane = (m - 1) & 63;
@@ -222,6 +236,21 @@ DSQ_UNROLL_P
             }
             if (!useCR) return;
             close_cell();
+            wave_lds_sync();
+            for (int r8 = 0; r8 < C; r8 += 8) {               // eight cells per round: lane 8 g + j <- group g of cell r8 + j
+                const int c = r8 + (lane & 7);
+                const int cc = c < C ? c : C - 1;             // (lanes past the last cell: a valid slot, their result is not read)
+                _Pragma("unroll")
+                for (int k = 0; k < K; k++) {
+                    double v = park[(cc * 3 + k) * 8 + pgrp];
+                    v = v + lane_xor8(v);
+                    double x_, y_;
+                    lane_pair16(v, x_, y_); v = x_ + y_;
+                    lane_pair32(v, x_, y_); v = x_ + y_;
+                    Sl[k] = (lane >= r8 && lane < r8 + 8) ? v : Sl[k];
+                }
+            }
+            wave_lds_sync();                                  // (the next evaluation parks into the same slots)
             if constexpr (LANE) {
                 // lane b builds column b: entry (i, b) = sum_c (x_c[i] x_c[b]) S_c, cells in order
                 const int bl = lane < P ? lane : 0;
@@ -253,7 +282,7 @@ DSQ_UNROLL_P
                 if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++)
-                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                        if (lane == i && ((dropmask >> i) & 1ull)) B[0][i] = 1.0;
                 }
             } else {
 DSQ_UNROLL_P
@@ -287,7 +316,7 @@ DSQ_UNROLL_P
                 if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
 DSQ_UNROLL_P
                     for (int c = 0; c < P; c++)
-                        if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+                        if (dropmask & (1ull << c)) B[0][c][c] = 1.0;
                 }
             }
             return;
@@ -321,7 +350,7 @@ DSQ_UNROLL_P
                     int a = 0, rem = e < NE ? e : 0;
                     while (rem >= P - a) { rem -= P - a; a++; }
                     const int b = a + rem;
-                    const bool live = e < NE && !(((dropmask >> a) | (dropmask >> b)) & 1u);
+                    const bool live = e < NE && !(((dropmask >> a) | (dropmask >> b)) & 1ull);
                     double acc[K];
                     _Pragma("unroll")
                     for (int k = 0; k < K; k++) acc[k] = 0.0;
@@ -350,7 +379,7 @@ DSQ_UNROLL_P
                 if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++)
-                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                        if (lane == i && ((dropmask >> i) & 1ull)) B[0][i] = 1.0;
                 }
                 return;
             }
@@ -362,7 +391,7 @@ DSQ_UNROLL_P
             // takes its column.
             bool first = true;
             for (int a0 = 0; a0 < P; a0++) {
-                if ((dropmask >> a0) & 1u) continue;              // a dropped / padding column: exact zeros, left out
+                if ((dropmask >> a0) & 1ull) continue;              // a dropped / padding column: exact zeros, left out
                 double acc[K][P];
                 _Pragma("unroll")
                 for (int k = 0; k < K; k++)
@@ -417,14 +446,14 @@ DSQ_UNROLL_P
             for (int k = 0; k < K; k++)
                 _Pragma("unroll")
                 for (int i = 0; i < P; i++) {
-                    const bool dropped = (((dropmask >> i) | (dropmask >> bl)) & 1u) != 0;
+                    const bool dropped = (((dropmask >> i) | (dropmask >> bl)) & 1ull) != 0;
                     B[k][i] = dropped ? 0.0 : arena[(k * P + i) * P + bl];
                 }
             wave_lds_sync();
             if constexpr (USE_W || (P >= DSQ_WIDE_MIN)) {
                 _Pragma("unroll")
                 for (int i = 0; i < P; i++)
-                    if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                    if (lane == i && ((dropmask >> i) & 1ull)) B[0][i] = 1.0;
             }
             return;
         } else {
@@ -469,7 +498,7 @@ DSQ_UNROLL_P
                 if constexpr (USE_W) {
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++)
-                        if (lane == i && ((dropmask >> i) & 1u)) B[0][i] = 1.0;
+                        if (lane == i && ((dropmask >> i) & 1ull)) B[0][i] = 1.0;
                 }
             } else {
 DSQ_UNROLL_P
@@ -489,7 +518,7 @@ DSQ_UNROLL_P
         if constexpr (!LANE && USE_W) {
 DSQ_UNROLL_P
             for (int c = 0; c < P; c++)
-                if (dropmask & (1u << c)) B[0][c][c] = 1.0;
+                if (dropmask & (1ull << c)) B[0][c][c] = 1.0;
         }
     }
 
@@ -836,10 +865,11 @@ DSQ_UNROLL_P
 //   unstaged "slab": the distinct-count buffer only (2 m int32, unweighted only); the row itself is re-read through L2
 // lane-column builds: per-wave LDS arena through which the general-mode pass hands the reduced Cox-Reid rows to the
 // lanes (3 p p doubles: the second-derivative kernel has three matrices)
-// (only the general-mode pass uses it: with design cells the sums are per cell and the arena is not carved -- at
-// p = 10, m = 2000 its 9.6 KiB per block were what kept a second block off the CU)
+// (with design cells the sums are per cell and the arena holds only the parked group sums of the cell closes, 192 bytes
+// per cell -- at p = 10, m = 2000 the 9.6 KiB of a general-mode arena per block were what kept a second block off the CU)
 __host__ __device__ inline size_t disp_arena_doubles(int p, int ncell) {
-    return (p >= DSQ_DISP_ROWPASS_MIN && ncell <= 0) ? (size_t)3 * p * p : 0;
+    if (ncell > 0) return (size_t)24 * ncell;          // cell mode: the parked group sums, [cell][3][8] (DispGene::pass)
+    return (p >= DSQ_DISP_ROWPASS_MIN) ? (size_t)3 * p * p : 0;
 }
 
 // general mode (no design cells) from DSQ_DISP_ROWPASS_MIN columns up, rows of at most DSQ_DISP_SERIAL_MAXM samples:

@@ -726,6 +726,26 @@ __global__ void na_rows_kernel(NaRowsParams q) {
     q.betaConv[g] = -1;
 }
 
+// the n x m assays of the rows that were never fitted (all-zero counts, or weights that leave a degenerate design): NA, as
+// buildMatrixWithNARows leaves them in R -- the kernels skip those rows, so without this they keep whatever the buffer
+// held (found by the 8-range host-entry test of round 5: two calls returned different garbage there)
+__global__ void __launch_bounds__(256) na_assay_rows_kernel(int n, int m, long ld, const int32_t *allZero, double *a0, double *a1) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;            // one gene per lane for the flag ...
+    unsigned long long todo = __ballot(g < n && allZero[g] != 0);
+    const int base = g - lane;
+    const double nan = dnan();
+    while (todo) {                                                  // ... the (few) flagged rows of the wave written by all lanes
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const size_t row = (size_t)(base + l) * ld;
+        for (int j = lane; j < m; j += 64) {
+            if (a0) a0[row + j] = nan;
+            if (a1) a1[row + j] = nan;
+        }
+    }
+}
+
 // maxCooks after the refit (R/core.R:2538-2546): NA everywhere when every sample is replaceable, else the row
 // maximum of the ORIGINAL Cook's distances over the samples in cells of >= 3, replaceable samples zeroed
 __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld, const double *cooks, const int32_t *use,
@@ -770,7 +790,7 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
     } while (0)
 
 enum { DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };      // (a free slot between the call slots and the chain's: the padded design)
-static inline int kern_width(int p) { return p > DSQ_P_REG ? (p <= DSQ_P_WIDE0 ? DSQ_P_WIDE0 : DSQ_P_WIDE) : p; }
+static inline int kern_width(int p) { return p > DSQ_P_REG ? dsq_wide_width(p) : p; }
 
 struct Pipe {
     const DsqDeseqArgs *a;
@@ -788,12 +808,12 @@ struct Pipe {
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
     double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
-    // WIDE designs (10 < p <= 24): the fit kernels run at the padded width pk = 16 / 24 on the design zero-padded to pk
+    // WIDE designs (10 < p <= 48): the fit kernels run at the padded width pk = 16 / 24 / 32 / 48 on the design zero-padded to pk
     // columns (ridge 1, start value 0, contrast 0 on the padding: the real coefficients keep their bits, csrc/capi.hip
     // "wide designs"); the n x . work matrices have pk columns, the rule kernels and the results keep the true p
     int pk;
     const double *x_k;             // the design at the kernels' width (the caller's, or the padded copy)
-    unsigned padmask;
+    unsigned long long padmask;
     double *xim_cur;               // ... the one the rule kernels read now: over the non-zero rows, or (refit) over the refitted rows
     double *xim_dev;               // normalization-factor matrix: mean(1 / colMeans(nf)) over the non-zero rows (one double
                                    // behind the lambda block of the caller's workspace: it persists between the phases)
@@ -1494,7 +1514,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         PIPE_HIP(hipMemsetAsync(b, 0, (size_t)m * pk * sizeof(double), st));
         PIPE_HIP(hipMemcpyAsync(b, a->x, (size_t)m * p * sizeof(double), hipMemcpyDeviceToDevice, st));
         P.x_k = (const double *)b;
-        P.padmask = ((1u << pk) - 1u) & ~((1u << p) - 1u);
+        P.padmask = ((1ull << pk) - 1ull) & ~((1ull << p) - 1ull);
         PIPE_HIP(hipMemsetAsync(P.beta_init + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
         PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
     }
@@ -1602,6 +1622,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (rc) return rc;
         rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
         if (rc) return rc;
+        hipLaunchKernelGGL(na_assay_rows_kernel, ew_grid(n), dim3(256), 0, st, n, m, P.ld, (const int32_t *)o->allZero, o->mu, o->H);
     }
     // ================================================================ betaPrior: the pass with lambda = 1 / betaPriorVar
     if ((a->phases & DSQ_PH_PRIOR) && a->betaPrior) {
@@ -1631,6 +1652,9 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         PIPE_HIP(launch_cooks(ck, st, &ok));
         capi_prof_end(st);
         if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "m=%d samples: a gene row plus its sort buffer exceeds the 160 KiB LDS", m);
+        // (before the replacement: allZero still says which rows had no fit -- a row that only BECOMES all zero keeps its assays)
+        hipLaunchKernelGGL(na_assay_rows_kernel, ew_grid(n), dim3(256), 0, st, n, m, P.ld, (const int32_t *)o->allZero, o->cooks,
+                           (double *)nullptr);
         if (a->do_replace) {
             ReplaceKernelParams rk;
             memset(&rk, 0, sizeof rk);

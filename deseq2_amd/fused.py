@@ -7,7 +7,7 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 24 (p > 10: no beta prior, reduced model of at most 10 columns), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
+Supported: DeviceEngine, p <= 48 (p > 10: no beta prior, reduced model of at most 10 columns), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
 the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
@@ -25,9 +25,9 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
         return False
     if callable(fitType) and kw.get("betaPrior"):
         return False
-    if dds.p > 24 or dds.m <= dds.p:
+    if dds.p > L.DSQ_MAX_P or dds.m <= dds.p:
         return False
-    # wide designs (10 < p <= 24, the zero-padded kernel builds): without a beta prior, reduced model of at most 10 columns
+    # wide designs (10 < p <= 48, the zero-padded kernel builds): without a beta prior, reduced model of at most 10 columns
     # (... and without observation weights: the rank tests of getAndCheckWeights run as a register kernel up to 10 columns)
     if dds.p > 10 and (kw.get("betaPrior") or dds.has_weights or
                        (reduced is not None and np.ndim(reduced) == 2 and np.shape(reduced)[1] > 10)):

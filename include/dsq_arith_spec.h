@@ -13,4 +13,7 @@
 #define DSQ_SPEC_SERIAL_GRAM_MAXM_NARROW 256
 #define DSQ_SPEC_SERIAL_GRAM_WIDE_P 10
 #define DSQ_SPEC_SERIAL_GRAM_MAXM 1024
+/* fitBeta's cell-collapsed least squares (one row per design cell + p ridge rows, one row per lane) serves designs of at
+ * most this many columns; wider factor designs take the general per-sample sums (round 5: the 32- and 48-column builds) */
+#define DSQ_SPEC_BETA_CELL_MAXP 24
 #endif

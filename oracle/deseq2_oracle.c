@@ -173,7 +173,7 @@ static double trace_sym(int q, const double *a, const double *b) {
 /* which designs take the cell-collapsed paths (the engine's rule): fitBeta at every width, the Cox-Reid
  * matrices of fitDisp from 4 columns up (below that the per-sample accumulation of the p(p+1)/2 <= 6 entries is
  * cheaper than the per-cell passes) */
-#define ORC_BETA_CELL_MAXP 24
+#define ORC_BETA_CELL_MAXP DSQ_SPEC_BETA_CELL_MAXP
 #define ORC_DISP_CELL_MINP 4
 static int design_cells(int m, int p, const double *x, int cmax, int *perm, int *start, double *xc);
 

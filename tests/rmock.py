@@ -16,6 +16,10 @@ def lib():
     global _lib
     if _lib is None:
         subprocess.check_call(["make", "-C", HERE, "-s"])
+        # the product library first, the way deseq2_amd/_lib.py loads it (torch's bundled HIP runtime before anything else
+        # pulls in a second one): the shim library then binds to that same instance
+        from deseq2_amd import _lib
+        _lib.lib()
         L = C.CDLL(SO)
         P, I, LG = C.c_void_p, C.c_int, C.c_long
         for name, res, args in [("rmock_new", P, [I, I, I, P]), ("rmock_nil", P, []), ("rmock_type", I, [P]),

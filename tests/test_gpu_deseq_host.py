@@ -342,8 +342,8 @@ def test_host_entry_argument_errors():
     with pytest.raises(L.DsqError, match="residual degrees of freedom"):
         native.DESeq(counts[:, :4], simulate.design_two_group(4), sf[:4])
     with pytest.raises(L.DsqError, match="design columns"):
-        native.DESeq(np.ones((5, 40), dtype=np.int32), np.column_stack([np.ones(40)] + [np.cos(np.arange(40.0) * k) for k in range(1, 26)]),
-                     np.ones(40))
+        native.DESeq(np.ones((5, 60), dtype=np.int32), np.column_stack([np.ones(60)] + [np.cos(np.arange(60.0) * k) for k in range(1, 49)]),
+                     np.ones(60))                                   # 49 columns: beyond the widest (48-column) build
     with pytest.raises(L.DsqError, match="zero counts"):
         native.DESeq(np.zeros((20, 12), dtype=np.int32), x, sf)
     bad = counts.astype(np.float64)

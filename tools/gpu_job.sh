@@ -24,11 +24,11 @@ for step in "$@"; do
     tests)
       timeout 900 python -m pytest ${F[1]:-tests} -m gpu --maxfail=10 -q > "$O/tests.log" 2>&1; echo "[gpu_job] tests rc=$? $(tail -1 "$O/tests.log")";;
     bench)
-      cfg=${F[1]}; extra=(); cpu=--no-cpu-baseline; host=--no-hostpath; name=$cfg
+      cfg=${F[1]}; extra=(); cpu=--no-cpu-baseline; host=--no-hostpath; var=--no-variants; name=$cfg
       for a in "${F[@]:2}"; do
-        case $a in +cpu) cpu=;; +host) host=;; name=*) name=${a#name=};; *) extra+=("$a");; esac
+        case $a in +cpu) cpu=;; +host) host=;; +var) var=;; name=*) name=${a#name=};; *) extra+=("$a");; esac
       done
-      timeout 900 python bench.py --config "$cfg" $cpu $host "${extra[@]}" > "$O/bench_$name.json" 2> "$O/bench_$name.err"
+      timeout 900 python bench.py --config "$cfg" $cpu $host $var "${extra[@]}" > "$O/bench_$name.json" 2> "$O/bench_$name.err"
       echo "[gpu_job] bench $name rc=$?"
       python - "$O/bench_$name.json" <<'PY'
 import json,sys
@@ -36,14 +36,14 @@ try:
     j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     print("   ", j["config"]["name"], "gpus", j["n_gpus"], "genes/s", round(j["value"]), "ms/step", round(j["ms_per_step"],3), "roofline", round(j["roofline"]["frac"],5),
           {k:round(v["avg_ms"],3) for k,v in j["kernels"].items()}, "hostpath", j.get("hostpath_ms"), "fused-host", j.get("hostpath_fused_ms"),
-          (j.get("hostpath_fused") or {}).get("with_assays_ms"), "cpu", (j.get("cpu_baseline") or {}).get("value"), "chain", j["config"]["chain"][:6], j["result_digest"][:12])
+          (j.get("hostpath_fused") or {}).get("with_assays_ms"), "cpu", (j.get("cpu_baseline") or {}).get("value"), "chain", j["config"]["chain"][:6], j["result_digest"][:12], "parity", j.get("parity"), "variants", [(v["seed"], v["size_factors"], round(v["ms_per_step"], 3)) for v in (j.get("variants") or [])])
 except Exception as e:
     print("    FAILED", e)
 PY
       ;;
     stats)
       cfg=${F[1]}; d=$O/prof_$cfg; rm -rf "$d"
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$d" -o trace -- python "$R/bench.py" --config "$cfg" --steps 5 --warmup 2 --no-cpu-baseline --no-hostpath > "$O/stats_$cfg.log" 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$d" -o trace -- python "$R/bench.py" --config "$cfg" --steps 5 --warmup 2 --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/stats_$cfg.log" 2>&1)
       python tools/timeline.py "$(find "$d" -name '*.db' | head -1)" > "$O/timeline_$cfg.txt" 2>&1
       python profiles/summarize_rocpd.py "$(find "$d" -name '*.db' | head -1)" > "$O/stats_$cfg.md" 2>> "$O/stats_$cfg.log"; echo "[gpu_job] stats $cfg rc=$?"; head -25 "$O/stats_$cfg.md"
       rm -rf "$d";;
@@ -53,7 +53,7 @@ PY
       for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" \
                  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM"; do
         k=$((k+1)); d=$O/pmc${k}_$cfg; rm -rf "$d"
-        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$d" -o p -- python "$R/bench.py" --config "$cfg" --steps 2 --warmup 1 --no-cpu-baseline --no-hostpath > "$O/pmc${k}_$cfg.log" 2>&1)
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$d" -o p -- python "$R/bench.py" --config "$cfg" --steps 2 --warmup 1 --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/pmc${k}_$cfg.log" 2>&1)
       done
       P1=$(dirname "$(find "$O/pmc1_$cfg" -name p_counter_collection.csv | head -1)"); P2=$(dirname "$(find "$O/pmc2_$cfg" -name p_counter_collection.csv | head -1)"); P3=$(dirname "$(find "$O/pmc3_$cfg" -name p_counter_collection.csv | head -1)")
       export DSQ_PMC_EXTRA="$(dirname "$(find "$O/pmc4_$cfg" -name p_counter_collection.csv | head -1)"):$(dirname "$(find "$O/pmc5_$cfg" -name p_counter_collection.csv | head -1)")"
