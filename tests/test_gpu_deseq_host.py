@@ -239,6 +239,29 @@ def test_fused_chain_equals_oracle_chain_directly(E, oracle, name):
     _against_oracle(b.mcols, o, name, test)
 
 
+def test_fused_chain_equals_oracle_chain_on_9000_genes(E, oracle):
+    """an analysis with three times as many genes as the fit kernels keep resident waves (3 072), so
+    that every persistent wave fits several genes in a row: ~ batch + condition on 48 samples (cells of 8: count outliers
+    are replaced and their rows refitted), log-normal size factors, spiked counts and all-zero rows -- fused.DESeq() on the device against
+    core.DESeq() over HostEngine(oracle), every column bit for bit; and the one-call host entry on the same analysis"""
+    x = simulate.design_batch_condition(48)
+    sf = np.exp(np.random.Generator(np.random.PCG64(90)).normal(0, 0.25, 48))
+    d = simulate.make_counts(9000, x, seed=91, size_factors=sf)
+    counts = _spike(d["counts"], 40, 4)
+    counts[::997] = 0
+    assert counts.shape[0] > 8192
+    b = _dataset(counts, x, sf, {}, E)
+    fused.DESeq(b)
+    assert b.attrs.get("fused")
+    o = _oracle_chain(oracle, counts, x, sf, {})
+    _against_oracle(b.mcols, o, "9000 genes", "Wald")
+    res = _host_entry(counts, x, sf, {}, assays=())
+    mc = _mcols_of(res, "Wald")
+    for k in sorted(mc):
+        if k in b.mcols:
+            assert_same(_f(mc[k]), _f(b.mcols[k]), "9000 genes, host entry: " + k)
+
+
 @pytest.mark.parametrize("name", ["bc_outliers", "factor6_lrt_reduced2", "bp_factor5_expanded_outliers"])
 def test_host_entry_in_eight_ranges(E, name):
     """dsq_deseq with the genes cut into EIGHT ranges inside the library (DSQ_HOST_SHARDS=8: the multi-device walk of the

@@ -37,6 +37,22 @@ def test_hip_vs_compiled_reference_live(n, m, design, kw):
     compare(run_all(native, d), run_all(reference, d), d, "live %dx%d" % (n, m))
 
 
+@pytest.mark.skipif(not _have_ref(), reason="oracle/_ref/libdeseq2_ref.so not present")
+def test_hip_vs_compiled_reference_beyond_the_resident_waves():
+    """9 000 genes x 100 samples, ~ batch + condition: three times the 3 072 wave slots the persistent fit kernels keep
+    resident, so every wave fits several genes in a row under the reference's eye.  Against the
+    libm-double build of the reference's src/DESeq2.cpp (10 s of CPU; the binary128 build would take minutes): fitBeta$iter
+    equal on every gene, fitDisp iterations equal outside <= 1 % ulp-level ties, values within 1e-6 / 1e-7."""
+    from oracle import reference
+    reference.use_fast(True)
+    try:
+        d = _case(9000, 100, "batch_condition", seed=9100)
+        st = compare(run_all(native, d), run_all(reference, d), d, "live 9000x100 (libm-double reference build)", scale=10)
+    finally:
+        reference.use_fast(False)
+    assert st["fitBeta"]["iter_mismatch"] == 0 and st["fitDispGrid"]["same"] >= 0.99
+
+
 @pytest.mark.parametrize("name", SHAPE_NAMES)
 def test_hip_reproduces_reference_at_baseline_shapes(name):
     """BASELINE.json configs C2..C5 at full shape (C3: 1000 x 500 p=4; C4: 200 x 2000, 10-level factor, QR; C5:

@@ -128,32 +128,34 @@ MIN_GRID_SAME = 0.95
 HEAD = 32          # rows of the n x m hat matrix kept in tests/golden/reference_shapes.npz
 
 
-def _fit_beta_compare(gb, rb, name, fn):
+def _fit_beta_compare(gb, rb, name, fn, scale=1.0):
     np.testing.assert_array_equal(gb["iter"], rb["iter"], err_msg="%s %s$iter" % (name, fn))
     conv = rb["iter"] < 100
     assert conv.mean() > 0.8
     for k in ("beta_mat", "beta_var_mat", "contrast_num", "contrast_denom"):
-        _close(gb[k][conv], rb[k][conv], "%s %s$%s" % (name, fn, k), rtol=1e-7, atol=1e-12)
+        _close(gb[k][conv], rb[k][conv], "%s %s$%s" % (name, fn, k), rtol=1e-7 * scale, atol=1e-12)
     hr = np.asarray(rb["hat_diagonals"])
     hg = np.asarray(gb["hat_diagonals"])[: hr.shape[0]]               # shape goldens keep the first HEAD rows
     c = conv[: hr.shape[0]]
-    _close(hg[c], hr[c], "%s %s$hat_diagonals" % (name, fn), rtol=1e-8, atol=1e-14)
+    _close(hg[c], hr[c], "%s %s$hat_diagonals" % (name, fn), rtol=1e-8 * scale, atol=1e-14)
     # dnbinom_mu: R's algorithm (restated by the oracle) approximates for x < 1e-10 size; the stand-in is exact
-    _close(gb["deviance"][conv], rb["deviance"][conv], "%s %s$deviance" % (name, fn), rtol=1e-8)
+    _close(gb["deviance"][conv], rb["deviance"][conv], "%s %s$deviance" % (name, fn), rtol=1e-8 * scale)
     return {"n": int(conv.size), "iter_mismatch": 0, "converged": float(conv.mean())}
 
 
-def compare(got, ref, d, name, min_well=None, min_grid=None):
-    """asserts the budgets and returns the measured rates (profiles/r02_parity.md is printed from them)"""
+def compare(got, ref, d, name, min_well=None, min_grid=None, scale=1.0):
+    """asserts the budgets and returns the measured rates (profiles/r02_parity.md is printed from them).  scale: multiplier of
+    the VALUE tolerances -- 1 against the binary128 build of the reference, 10 against its libm-double build (whose own
+    special functions carry ~1e-8 relative on the deviance); the iteration counts are held equal either way"""
     alpha0 = d["alpha_init"]
     tiny = d["counts"].shape[1] <= 12          # m <= 12: up to a sixth of the synthetic genes sit at the floor
     if min_well is None:
         min_well = 0.8 if tiny else 0.95
     if min_grid is None:
         min_grid = 0.85 if tiny else MIN_GRID_SAME
-    stats = {"fitBeta": _fit_beta_compare(got["fitBeta"], ref["fitBeta"], name, "fitBeta")}
+    stats = {"fitBeta": _fit_beta_compare(got["fitBeta"], ref["fitBeta"], name, "fitBeta", scale)}
     if "fitBetaPrior" in ref:
-        stats["fitBetaPrior"] = _fit_beta_compare(got["fitBetaPrior"], ref["fitBetaPrior"], name, "fitBetaPrior")
+        stats["fitBetaPrior"] = _fit_beta_compare(got["fitBetaPrior"], ref["fitBetaPrior"], name, "fitBetaPrior", scale)
     # ---- fitDisp: strict on the well-conditioned genes
     for fn in ("fitDispMLE", "fitDispMAP"):
         g, r = got[fn], ref[fn]
@@ -176,7 +178,7 @@ def compare(got, ref, d, name, min_well=None, min_grid=None):
             np.testing.assert_array_equal(g[k][well_strict], r[k][well_strict], err_msg="%s %s$%s" % (name, fn, k))
         for k in ("log_alpha", "initial_lp", "last_lp"):
             _close(g[k][well_strict], r[k][well_strict], "%s %s$%s" % (name, fn, k),
-                   rtol=1e-7 if k == "log_alpha" else 1e-8, atol=1e-9)
+                   rtol=(1e-7 if k == "log_alpha" else 1e-8) * scale, atol=1e-9)
             # a tie gene stops one (tiny) step earlier or later: its optimum agrees to the search's own tolerance
             _close(g[k][tie], r[k][tie], "%s %s$%s (ties)" % (name, fn, k), rtol=1e-6, atol=1e-9)
         _close(g["initial_dlp"][well], r["initial_dlp"][well], "%s %s$initial_dlp" % (name, fn), rtol=1e-6, atol=1e-5)
