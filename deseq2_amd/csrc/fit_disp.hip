@@ -643,7 +643,7 @@ DSQ_UNROLL_P
 #else
                     const double rr = rcp1(opm);
 #endif
-                    if (useCR) {
+                    {   // (also without the Cox-Reid term, where nothing reads them: three multiplications instead of four selects)
                         const double w0 = mu * rr;
                         wd[0] = w0;
                         wd[1] = -(w0 * w0);
