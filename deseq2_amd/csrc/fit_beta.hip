@@ -154,13 +154,13 @@ static constexpr int kIrlsTab = 256;
 template <bool USE_W>
 DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double *wg, int m, int lane, double alpha,
                               double size, bool fast, const double *lnf = nullptr, double *kprime = nullptr,
-                              double *scr = nullptr) {
+                              double *scr = nullptr, int T = kIrlsTab) {
+    // T: counts below it go through the table (64, 128 or 256: scr holds T / 2 + 2 T doubles)
     if (kprime) *kprime = 0.0;
     if (!fast) return 0.0;
     const double st_size = dstirlerr(size);
     double *tab = nullptr;
     if (scr) {
-        constexpr int T = kIrlsTab;
         int32_t *flag = reinterpret_cast<int32_t *>(scr);            // T int32: presence flags, then the list of counts present
         tab = scr + T / 2;                                           // T x (base, t)
         wave_lds_sync();
@@ -171,13 +171,13 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
             if (yi > 0 && yi < T) flag[yi] = 1;
         }
         wave_lds_sync();
-        int pres[T / 64];
+        int pres[kIrlsTab / 64];
         _Pragma("unroll")
-        for (int t = 0; t < T / 64; t++) pres[t] = flag[64 * t + lane];
+        for (int t = 0; t < kIrlsTab / 64; t++) pres[t] = (64 * t < T) ? flag[64 * t + lane] : 0;
         wave_lds_sync();
         int nv = 0;
         _Pragma("unroll")
-        for (int t = 0; t < T / 64; t++) {
+        for (int t = 0; t < kIrlsTab / 64; t++) {
             const unsigned long long mask = __ballot(pres[t] != 0);
             const int rank = nv + __popcll(mask & ((1ull << lane) - 1ull));
             if (pres[t] != 0) flag[rank] = 64 * t + lane;
@@ -200,7 +200,7 @@ DSQ_DEV double irls_constants(const int32_t *yg, const double *nfg, const double
         double kj = 0.0, pj = 0.0;
         if (y != 0.0 && cell_dev_closed(y, size, fast)) {
             double base = 0.0, t = 0.0;
-            const bool direct = !(tab && yi < kIrlsTab);
+            const bool direct = !(tab && yi < T);
             if (!direct) { base = tab[2 * yi]; t = tab[2 * yi + 1]; }
             if (__any(direct)) {                                      // (wave-uniform: a trip of small counts skips the evaluation)
                 if (direct) nb_split_const(y, alpha, size, st_size, base, t);
@@ -347,7 +347,14 @@ DSQ_UNROLL_P
         // iteration for the rest (the closed split of the cell kernel below)
         const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
         double K = 0.0, Kp = 0.0;
-        if (kp.maxit > 0 && !(abl & 16)) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr);
+        // (staged rows: the sqrt(w) slot of the wave's slab -- m doubles, first written inside the iterations -- lends the pass
+        //  its flags and table: 2.5 T doubles, T = 256 from 640 samples, 128 from 320, 64 from 160)
+        {
+            const int tabT = m >= 640 ? 256 : m >= 320 ? 128 : m >= 160 ? 64 : 0;
+            double *scr = (STAGE && tabT > 0) ? sw_s : nullptr;
+            if (kp.maxit > 0 && !(abl & 16))
+                K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr, scr, tabT > 0 ? tabT : kIrlsTab);
+        }
         if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
         double dev = 0.0, dev_old = 0.0;
         double it = 0.0;
