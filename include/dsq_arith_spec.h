@@ -14,6 +14,7 @@
 #define DSQ_SPEC_SERIAL_GRAM_WIDE_P 10
 #define DSQ_SPEC_SERIAL_GRAM_MAXM 1024
 /* fitBeta's cell-collapsed least squares (one row per design cell + p ridge rows, one row per lane) serves designs of at
- * most this many columns; wider factor designs take the general per-sample sums (round 5: the 32- and 48-column builds) */
-#define DSQ_SPEC_BETA_CELL_MAXP 24
+ * most this many columns (cells + padded columns <= 64 lanes); wider designs take the general per-sample sums (round 5: the
+ * 48-column build; a 40-level factor, a paired design with more than 32 cells) */
+#define DSQ_SPEC_BETA_CELL_MAXP 32
 #endif

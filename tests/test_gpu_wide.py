@@ -207,8 +207,9 @@ def test_paired_designs_beyond_24_columns(oracle, patients, useW):
 
 @pytest.mark.parametrize("levels,m", [(28, 112), (32, 128), (40, 160), (48, 192)])
 def test_factors_of_up_to_48_levels(oracle, levels, m):
-    """a 40-level factor (and the edges of the 32- and 48-column builds): cells of four samples; up to 32 levels the
-    cell-collapsed fitDisp runs (fitBeta's collapsed least squares needs cells + p <= 64 rows: the general kernel here)"""
+    """a 40-level factor (and the edges of the 32- and 48-column builds): cells of four samples; up to 32 levels both
+    routines run cell-collapsed (fitBeta's collapsed least squares: 32 cells + 32 columns = the 64 lanes of a wave; the
+    shared spec, include/dsq_arith_spec.h, says so to kernels and oracle alike), beyond that the general kernels"""
     d = make_case(80, m, ("factor", levels), seed=levels + m, sf_random=True)
     _native_triplet_vs_oracle(oracle, d["counts"], d["x"], d["size_factors"], "factor %d" % levels)
 
