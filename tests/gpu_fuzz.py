@@ -1,5 +1,5 @@
 """GPU fuzz (run by hand on a GPU box, not collected by pytest): the three native routines, HIP library vs the CPU
-checker, on random shapes / designs (factor designs with few cells, continuous covariates, mixed; p up to 24) /
+checker, on random shapes / designs (factor designs with few cells, continuous covariates, mixed; p up to 40) /
 weights / ridge / QR / prior settings.  Every output is compared bit for bit, as in tests/test_gpu_edge.py.
 
     python tests/gpu_fuzz.py [first_seed] [n_seeds]
@@ -22,16 +22,16 @@ DISP_KEYS = ("log_alpha", "iter", "iter_accept", "last_change", "initial_lp", "i
 def design(rng, m):
     kind = rng.integers(3)
     if kind == 0:                                  # factor design(s): few cells
-        levels = int(rng.integers(2, 25))
+        levels = int(rng.integers(2, 25)) if rng.uniform() < 0.8 else int(rng.integers(25, 41))      # (round 5: the 32- / 48-column builds)
         levels = min(levels, max(2, m // 2))
         f = np.arange(m) % levels
         rng.shuffle(f)
         x = np.column_stack([np.ones(m)] + [(f == l).astype(float) for l in range(1, levels)])
-        if rng.uniform() < 0.4 and x.shape[1] <= 22:
+        if rng.uniform() < 0.4 and x.shape[1] <= 46:
             g = (rng.uniform(size=m) < 0.5).astype(float)
             x = np.column_stack([x, g])
     else:
-        p = int(rng.integers(1, 25 if kind == 1 else 11))
+        p = int(rng.integers(1, (25 if rng.uniform() < 0.85 else 34) if kind == 1 else 11))
         p = min(p, m - 1)
         cols = [np.ones(m)]
         for c in range(p - 1):

@@ -9,7 +9,8 @@ target of a backward branch to the branch) of at least --min instructions, inner
   f64      v_*_f64 arithmetic (add / mul / fma / fmac / rcp / rndne / ldexp / div_* ...), not compares or conversions
   mov      v_mov_b32 / v_mov_b64 / accvgpr moves (without DPP)
   cnd      v_cndmask
-  lane     v_readlane / v_writelane / v_readfirstlane (SGPR spills and lane broadcasts)
+  lane     v_readlane / v_writelane / v_readfirstlane (SGPR spills and lane broadcasts; the last three columns split them:
+           a v_readlane whose source VGPR is the target of a v_writelane somewhere in the kernel is an SGPR-spill reload)
   dpp      DPP moves and v_permlane*_swap (cross-lane butterflies)
   smem     s_load_* (the coefficient fetches of dsq_isa.hpp among them)
 The dynamic counterpart is the SQ_INSTS_VALU_*_F64 pass of tools/gpu_job.sh pmc (profiles/r05_pmc_*.json)."""
@@ -56,9 +57,25 @@ def classify(op, text):
 COLS = ["all", "VALU", "f64", "mov", "cnd", "lane", "dpp", "cmp", "cvt", "valu_other", "salu", "smem", "lds", "vmem"]
 
 
-def tally(ins):
+def spill_vgprs(ins):
+    """VGPRs that hold spilled SGPRs: the destinations of v_writelane"""
+    out = set()
+    for t in ins:
+        if t.startswith("v_writelane_b32"):
+            m = re.match(r"v_writelane_b32\s+(v\d+)", t)
+            if m:
+                out.add(m.group(1))
+    return out
+
+
+def tally(ins, spill=frozenset()):
     c = collections.Counter()
     for t in ins:
+        if t.startswith("v_readlane_b32"):
+            m = re.match(r"v_readlane_b32\s+\S+,\s*(v\d+)", t)
+            c["readlane_spill" if (m and m.group(1) in spill) else "readlane_bcast"] += 1
+        elif t.startswith("v_writelane_b32"):
+            c["writelane"] += 1
         op = t.split()[0]
         k = classify(op, t)
         c[k] += 1
@@ -158,14 +175,15 @@ def main():
                 print("## `%s`\n" % dm[name])
                 print("vgpr %s, sgpr %s, spilled vgpr %s, spilled sgpr %s, scratch %s B/lane, static LDS %s B\n" %
                       (m["vgpr"], m["sgpr"], m["vspill"], m["sspill"], m["scratch"], m["lds"]))
-                print("| region | " + " | ".join(COLS) + " | v_fmac_f64 | v_mov_b64 v,v |")
-                print("|---|" + "---|" * (len(COLS) + 2))
-                rows = [("whole kernel", tally(ins))]
+                print("| region | " + " | ".join(COLS) + " | v_fmac_f64 | v_mov_b64 v,v | readlane: SGPR reload | readlane: broadcast | writelane |")
+                print("|---|" + "---|" * (len(COLS) + 5))
+                sp = spill_vgprs(ins)
+                rows = [("whole kernel", tally(ins, sp))]
                 for lo, hi in regions(ins, addr):
                     if hi - lo + 1 >= a.min:
-                        rows.append(("loop +0x%x..+0x%x" % (addr[lo] - base, addr[hi] - base), tally(ins[lo:hi + 1])))
+                        rows.append(("loop +0x%x..+0x%x" % (addr[lo] - base, addr[hi] - base), tally(ins[lo:hi + 1], sp)))
                 for label, c in rows:
-                    print("| %s | " % label + " | ".join(str(c[k]) for k in COLS) + " | %d | %d |" % (c["fmac"], c["mov64vv"]))
+                    print("| %s | " % label + " | ".join(str(c[k]) for k in COLS) + " | %d | %d | %d | %d | %d |" % (c["fmac"], c["mov64vv"], c["readlane_spill"], c["readlane_bcast"], c["writelane"]))
                 print()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
