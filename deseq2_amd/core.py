@@ -751,6 +751,9 @@ def estimateBetaPriorVar(dds, mleBetaMatrix, names, betaPriorMethod="weighted", 
     pv = np.empty(beta.shape[1])
     for c in range(beta.shape[1]):
         xcol = beta[:, c]
+        if beta.shape[0] == 1:                                         # a one-gene object: (betaMatrix)^2, :1647,1662
+            pv[c] = float(xcol[0]) ** 2
+            continue
         use = np.abs(xcol) < 10
         if use.sum() == 0:
             pv[c] = 1e6

@@ -126,6 +126,11 @@ int beta_prior_var(const DsqBetaPriorArgs *a, double *out) {
             if (cols[c].j < 0 && a->coef_factor[cols[c].i] == 0) { pv[c] = 1e6; continue; }      // the intercept (:1669-1671)
             x.clear(); w.clear();
             const double *bi = a->mle_beta + (size_t)n * cols[c].i, *bj = cols[c].j >= 0 ? a->mle_beta + (size_t)n * cols[c].j : nullptr;
+            if (rows.size() == 1) {                               // a one-gene object: (betaMatrix)^2 (R/core.R:1647,1662)
+                const double v = bj ? bi[rows[0]] - bj[rows[0]] : bi[rows[0]];
+                pv[c] = v * v;
+                continue;
+            }
             for (size_t k = 0; k < rows.size(); k++) {
                 const double v = bj ? bi[rows[k]] - bj[rows[k]] : bi[rows[k]];
                 const double av = std::fabs(v);

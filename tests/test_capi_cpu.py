@@ -141,6 +141,20 @@ def test_beta_prior_var_equals_the_host_mirror(case):
     assert got[0] == 1e6 and (got > 0).all()
 
 
+def test_beta_prior_var_of_a_one_gene_object():
+    """nrow(betaMatrix) == 1 (R/core.R:1647,1662): the prior variances are the squared coefficients themselves (the
+    intercept still 1e6, :1669-1671) -- library and mirror alike"""
+    from deseq2_amd import core, native
+    factors = {"condition": np.repeat([0, 1], 4)}
+    x, names = core.standard_model_matrix(factors)
+    mle = np.array([[5.0, -1.75], [np.nan, np.nan]])
+    bm, dfit, az = np.array([30.0, 0.0]), np.array([0.2, 0.2]), np.array([False, True])       # the second row is all zero
+    view = type("V", (), {"mcols": {"baseMean": bm[~az], "dispFit": dfit[~az]}})()
+    ref, _ = core.estimateBetaPriorVar(view, mle[~az], names, modelMatrixType="standard", factors=factors)
+    got = native.estimateBetaPriorVarHost(mle, bm, dfit, az, native.coef_factor_codes(factors))
+    assert list(ref) == [1e6, 1.75 ** 2] and list(got) == [1e6, 1.75 ** 2]
+
+
 def test_shipped_library_passes_the_exec_lint():
     """profiles/r04_exec_remat.md: the toolchain can re-materialise a constant above the exec restore of a join block (it
     did, in two kernels of round 4: sqrt() returned its argument).  tools/exec_lint.py looks for that pattern in the
