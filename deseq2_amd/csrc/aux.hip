@@ -21,8 +21,16 @@ static inline int aux_grid_fwd(int n) {
     return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
 }
 
-template <int P, bool USE_W>
+// TILED (round 5; long rows): the passes over Q and over A = X R^-1 read p doubles per SAMPLE of design-only data -- 160 KB per
+// gene at m = 2000, p = 10, every gene again through L2 (C4: 19 GB per launch, 2.3 ms for a kernel with 0.3 ms of arithmetic).
+// The four waves of a block walk the samples in lockstep tiles of kTileS samples whose Q / A columns they stage ONCE in LDS
+// for their four genes.  A lane still adds its samples j = lane, lane + 64, ... in increasing order: the same sums.
+static constexpr int kTileS = 256;
+__host__ __device__ static inline bool aux_tiled(int m, int p) { return (size_t)m * p >= 8192 && p <= 24; }   // (tile <= 48 KB)
+
+template <int P, bool USE_W, bool TILED>
 __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];       // TILED: P x kTileS doubles
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -33,8 +41,13 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
 #pragma unroll
         for (int k = 0; k < P; k++) rr[c][k] = kp.r[c + P * k];
     const int nwork = DSQ_NWORK(kp);
-    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
-        const int g = DSQ_GENE(kp, wi);
+    // (TILED: every wave of the block runs the same number of rounds -- the block barriers of the tile loops -- and a wave
+    //  past the end of the work list goes through them idle)
+    for (int wbase = blockIdx.x * waves; wbase < nwork; wbase += gridDim.x * waves) {
+        const int wi = wbase + wave;
+        const bool active = wi < nwork;
+        if (!TILED && !active) break;
+        const int g = DSQ_GENE(kp, active ? wi : nwork - 1);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
@@ -66,6 +79,57 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
         double tu[2 * P];
 #pragma unroll
         for (int c = 0; c < 2 * P; c++) tu[c] = 0.0;
+        double ae = 0.0;
+        if constexpr (TILED) {
+            static_assert(kTileS == 64 * kAuxBatch, "one tile = one batch of trips");
+            auto stage = [&](const double *src, int t0) {
+                __syncthreads();                                          // (the previous tile has been consumed)
+                const int ts = (m - t0) < kTileS ? (m - t0) : kTileS;
+                for (int idx = threadIdx.x; idx < P * kTileS; idx += blockDim.x) {
+                    const int c = idx / kTileS, jj = idx - c * kTileS;
+                    if (jj < ts) tile[idx] = src[(size_t)c * m + t0 + jj];
+                }
+                __syncthreads();
+            };
+            for (int t0 = 0; t0 < m; t0 += kTileS) {
+                stage(kp.q, t0);
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) { const int j = t0 + 64 * b + lane; if (j < m) { yb[b] = yg[j]; nb[b] = nfg[j]; } }
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) {
+                    const int j = t0 + 64 * b + lane;
+                    if (j < m) {
+                        double yn = (double)yb[b] / nb[b];
+                        double ly = dlog(yn + 0.1);
+#pragma unroll
+                        for (int c = 0; c < P; c++) {
+                            double qv = tile[c * kTileS + 64 * b + lane];
+                            tu[c] += yn * qv;
+                            tu[P + c] += ly * qv;
+                        }
+                    }
+                }
+            }
+            wave_allreduce_many(tu, lane);
+            for (int t0 = 0; t0 < m; t0 += kTileS) {
+                stage(kp.a, t0);
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) { const int j = t0 + 64 * b + lane; if (j < m) { yb[b] = yg[j]; nb[b] = nfg[j]; } }
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) {
+                    const int j = t0 + 64 * b + lane;
+                    if (j < m) {
+                        double yn = (double)yb[b] / nb[b];
+                        double mu = tu[0] * tile[64 * b + lane];
+#pragma unroll
+                        for (int c = 1; c < P; c++) mu = __builtin_fma(tu[c], tile[c * kTileS + 64 * b + lane], mu);
+                        mu = __builtin_fmax(1.0, mu);
+                        double d = yn - mu;
+                        ae += (d * d - mu) / (mu * mu);
+                    }
+                }
+            }
+        } else {
         sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
             double yn = (double)yb[b] / nb[b];
             double ly = dlog(yn + 0.1);
@@ -77,7 +141,6 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
             }
         });
         wave_allreduce_many(tu, lane);
-        double ae = 0.0;
         sweep_batched<kAuxBatch>(m, lane, [&](int j, int b) { yb[b] = yg[j]; nb[b] = nfg[j]; }, [&](int j, int b) {
             double yn = (double)yb[b] / nb[b];
             double mu = tu[0] * kp.a[j];
@@ -87,6 +150,7 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
             double d = yn - mu;
             ae += (d * d - mu) / (mu * mu);
         });
+        }
         ae = wave_allreduce(ae);
         double b[P];
 #pragma unroll
@@ -96,7 +160,7 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
             for (int k = c + 1; k < P; k++) v = __builtin_fma(-rr[c][k], b[k], v);
             b[c] = v / rr[c][c];
         }
-        if (lane == 0) {
+        if (lane == 0 && active) {
             kp.baseMean[g] = mean;
             kp.baseVar[g] = av / (double)(m - 1);
             kp.allZero[g] = (a2[1] == 0.0) ? 1 : 0;
@@ -108,20 +172,69 @@ __global__ void __launch_bounds__(256) prefit_kernel(PrefitKernelParams kp) {
 }
 
 // linearModelMuNormalized (R/core.R:2454-2471): mu = nf * ((yn Q)(X R^-1)'), optionally floored (:763)
-template <int P>
+template <int P, bool TILED>
 __global__ void __launch_bounds__(256) linear_mu_kernel(PrefitKernelParams kp, double mu_floor, double *mu_out) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];       // TILED: P x kTileS doubles (see prefit_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int m = kp.m;
     const int nwork = DSQ_NWORK(kp);
-    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi += gridDim.x * waves) {
-        const int g = DSQ_GENE(kp, wi);
+    for (int wbase = blockIdx.x * waves; wbase < nwork; wbase += gridDim.x * waves) {
+        const int wi = wbase + wave;
+        const bool active = wi < nwork;
+        if (!TILED && !active) break;
+        const int g = DSQ_GENE(kp, active ? wi : nwork - 1);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
         double tu[P];
 #pragma unroll
         for (int c = 0; c < P; c++) tu[c] = 0.0;
+        if constexpr (TILED) {
+            auto stage = [&](const double *src, int t0) {
+                __syncthreads();
+                const int ts = (m - t0) < kTileS ? (m - t0) : kTileS;
+                for (int idx = threadIdx.x; idx < P * kTileS; idx += blockDim.x) {
+                    const int c = idx / kTileS, jj = idx - c * kTileS;
+                    if (jj < ts) tile[idx] = src[(size_t)c * m + t0 + jj];
+                }
+                __syncthreads();
+            };
+            int32_t yb[kAuxBatch];
+            double nb[kAuxBatch];
+            for (int t0 = 0; t0 < m; t0 += kTileS) {
+                stage(kp.q, t0);
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) { const int j = t0 + 64 * b + lane; if (j < m) { yb[b] = yg[j]; nb[b] = nfg[j]; } }
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) {
+                    const int j = t0 + 64 * b + lane;
+                    if (j < m) {
+                        double yn = (double)yb[b] / nb[b];
+#pragma unroll
+                        for (int c = 0; c < P; c++) tu[c] += yn * tile[c * kTileS + 64 * b + lane];
+                    }
+                }
+            }
+            wave_allreduce_many(tu, lane);
+            double *mg = mu_out + (size_t)g * kp.ld;
+            for (int t0 = 0; t0 < m; t0 += kTileS) {
+                stage(kp.a, t0);
+                _Pragma("unroll")
+                for (int b = 0; b < kAuxBatch; b++) {
+                    const int j = t0 + 64 * b + lane;
+                    if (j < m && active) {
+                        double v = tu[0] * tile[64 * b + lane];
+#pragma unroll
+                        for (int c = 1; c < P; c++) v = __builtin_fma(tu[c], tile[c * kTileS + 64 * b + lane], v);
+                        v = v * nfg[j];
+                        if (mu_floor > 0.0) v = __builtin_fmax(v, mu_floor);
+                        mg[j] = v;
+                    }
+                }
+            }
+            continue;
+        }
         {
             int32_t yb[kAuxBatch];
             double nb[kAuxBatch];
@@ -576,8 +689,16 @@ static inline int aux_grid(int n) {
 
 template <int P>
 static hipError_t launch_prefit_p(const PrefitKernelParams &kp, hipStream_t st) {
-    if (kp.useWeights) hipLaunchKernelGGL((prefit_kernel<P, true>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
-    else hipLaunchKernelGGL((prefit_kernel<P, false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    if constexpr (P <= 24) {
+        if (aux_tiled(kp.m, P)) {
+            const size_t lds = (size_t)P * kTileS * sizeof(double);
+            if (kp.useWeights) hipLaunchKernelGGL((prefit_kernel<P, true, true>), dim3(aux_grid(kp.n)), dim3(256), lds, st, kp);
+            else hipLaunchKernelGGL((prefit_kernel<P, false, true>), dim3(aux_grid(kp.n)), dim3(256), lds, st, kp);
+            return hipGetLastError();
+        }
+    }
+    if (kp.useWeights) hipLaunchKernelGGL((prefit_kernel<P, true, false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
+    else hipLaunchKernelGGL((prefit_kernel<P, false, false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp);
     return hipGetLastError();
 }
 
@@ -593,7 +714,13 @@ hipError_t launch_prefit(const PrefitKernelParams &kp, hipStream_t st, bool *ok)
 
 template <int P>
 static hipError_t launch_linear_mu_p(const PrefitKernelParams &kp, double mu_floor, double *mu, hipStream_t st) {
-    hipLaunchKernelGGL((linear_mu_kernel<P>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp, mu_floor, mu);
+    if constexpr (P <= 24) {
+        if (aux_tiled(kp.m, P)) {
+            hipLaunchKernelGGL((linear_mu_kernel<P, true>), dim3(aux_grid(kp.n)), dim3(256), (size_t)P * kTileS * sizeof(double), st, kp, mu_floor, mu);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((linear_mu_kernel<P, false>), dim3(aux_grid(kp.n)), dim3(256), 0, st, kp, mu_floor, mu);
     return hipGetLastError();
 }
 

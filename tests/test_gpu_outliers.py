@@ -131,7 +131,8 @@ def test_chain_lrt_with_outliers_identical_to_oracle(oracle):
         assert_same(a.mcols[k], b.mcols[k], "DESeq(LRT, outliers)$" + k)
 
 
-@pytest.mark.parametrize("n,m,kind", [(300, 6, "two"), (200, 24, "bc"), (100, 500, "bc"), (50, 130, "f10")])
+@pytest.mark.parametrize("n,m,kind", [(300, 6, "two"), (200, 24, "bc"), (100, 500, "bc"), (50, 130, "f10"),
+                                      (61, 900, "f10"), (130, 2000, "f10"), (33, 2100, "bc")])      # long rows: tiles shared through LDS
 def test_linear_mu_vs_oracle(oracle, n, m, kind):
     """linearModelMuNormalized (R/core.R:2454-2471) kernel, host ABI and device ABI, bit for bit"""
     x = _design(kind, m)

@@ -182,7 +182,11 @@ def test_double_counts_and_bad_counts():
 
 
 @pytest.mark.parametrize("n,m,design,useW", [(400, 100, "two_group", False), (300, 500, "batch_condition", True),
-                                              (100, 130, ("factor", 10), False), (200, 7, "two_group", False)])
+                                              (100, 130, ("factor", 10), False), (200, 7, "two_group", False),
+                                              # long rows (m p >= 8192): the waves of a block share the Q / A tiles through LDS
+                                              # (round 5); 61 genes: a last block with idle waves; ragged last tile
+                                              (61, 900, ("factor", 10), False), (59, 700, ("factor", 12), True),
+                                              (130, 2000, ("factor", 10), False), (33, 2100, "batch_condition", False)])
 def test_prefit_moments_matches_oracle(oracle, n, m, design, useW):
     """extension: baseMean/baseVar/allZero, roughDispEstimate, IRLS start values"""
     from deseq2_amd import native
