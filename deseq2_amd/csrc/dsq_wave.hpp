@@ -55,6 +55,14 @@ DSQ_DEV double lane_xor4(double v) {                               // row_shl:4 
     h2 = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xF, 0xA, false);
     return __hiloint2double(h2, l2);
 }
+// lane l <- lane l + N of the same row of sixteen (N = 1 .. 15; lanes whose source lies outside the row keep their own value)
+template <int N>
+DSQ_DEV double dpp_row_shl(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 typedef unsigned dsq_u2 __attribute__((ext_vector_type(2)));
 // (self, partner) across rows: swap(v, v) leaves [row0,row0,row2,row2] and [row1,row1,row3,row3]
 DSQ_DEV void lane_pair16(double v, double &a, double &b) {
@@ -592,8 +600,42 @@ DSQ_DEV void wave_merge_regs(T (&v)[R], int lane) { sort_level_regs<T, R>(v, lan
 // Sort the gene's m counts (bitonic network in the wave's LDS slice buf), keep the first of every run and its length.
 // buf: 2 m int32 -- sorted values in [0, n2), n2 = pow2 >= m (<= 2m); on return the distinct values (ascending) are
 // buf[0..nv), their multiplicities buf[m..m+nv); returns nv.  yfun(k) = count of sample k as int32.
+// hist (round 5; buf in LDS): when every count of the row is below m, a HISTOGRAM replaces the sort -- buf[m + y] counts the
+// samples with count y (LDS atomic adds), then one ordered compaction over y = 0 .. m-1 leaves the same ascending distinct
+// values and multiplicities the sort + run-length pass produce (~ 160 instead of ~ 1 300 VALU instructions at m = 500; the
+// compaction writes slot rank <= y behind its own reads).  A row with a count >= m takes the sort as before.
+// hist_lds: m int32 of wave-private LDS for the histogram when buf itself is not in LDS (long rows: their distinct-count
+// buffer lives in global memory); nullptr: the histogram sits in buf[m .. 2 m).
 template <class F>
-DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun) {
+DSQ_DEV int wave_distinct_counts(int32_t *buf, int m, int lane, F &&yfun, bool hist = false, int32_t *hist_lds = nullptr) {
+    if (hist) {
+        int32_t *h = hist_lds ? hist_lds : buf + m;
+        wave_lds_sync();
+        for (int t = lane; t < m; t += 64) h[t] = 0;
+        wave_lds_sync();
+        bool big = false;
+        for (int k = lane; k < m; k += 64) {
+            const int32_t y = yfun(k);
+            if (y >= 0 && y < m) atomicAdd(&h[y], 1);
+            else big = true;
+        }
+        wave_lds_sync();
+        if (!__any(big)) {
+            int base = 0;
+            for (int v0 = 0; v0 < m; v0 += 64) {
+                const int v = v0 + lane;
+                const int32_t c = v < m ? h[v] : 0;
+                const bool head = c > 0;
+                const unsigned long long mask = __ballot(head);
+                const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
+                wave_lds_sync();                              // every lane has read before any lane writes
+                if (head) { buf[rank] = v; buf[m + rank] = c; }
+                base += __popcll(mask);
+                wave_lds_sync();
+            }
+            return base;
+        }
+    }
     int n2 = 2;
     while (n2 < m) n2 <<= 1;
     wave_lds_sync();

@@ -74,6 +74,8 @@ struct DispGene {
     // per DISTINCT count (often a handful) instead of once per sample
     const int32_t *dv, *dc;
     int nv;
+    bool hist_ok;       // the histogram form of wave_distinct_counts may run: the buffer sits in LDS, or hist_lds is given
+    int32_t *hist_lds;  // long rows (the buffer in global memory): m int32 of the wave's LDS for the histogram
     // design cells (block-shared LDS): cperm[k] = sample | cell << 26 at position k of the cell-sorted sequence, cell
     // offsets; C = 0 -> general per-sample Gram
     const int32_t *cperm, *cstart;
@@ -94,7 +96,9 @@ struct DispGene {
 #ifdef DSQ_ABLATE_BUILD
         if (ablate & 16) { dv = buf; dc = buf + m; nv = 0; return; }
 #endif
-        nv = wave_distinct_counts(buf, m, lane, [&](int k) { return (int32_t)r.y(k); });
+        // (the histogram form only in the builds of p >= 4: compiled into the p = 2, 3 kernels it cost them 5 % at m = 100
+        //  even when not taken -- registers)
+        nv = wave_distinct_counts(buf, m, lane, [&](int k) { return (int32_t)r.y(k); }, (P >= 4) && hist_ok, hist_lds);
         dv = buf; dc = buf + m;
     }
     DSQ_DEV static void lds_sync() { wave_lds_sync(); }
@@ -258,6 +262,36 @@ DSQ_UNROLL_P
                 for (int k = 0; k < K; k++)
                     _Pragma("unroll")
                     for (int i = 0; i < P; i++) B[k][i] = 0.0;
+                if constexpr (P == 4) {
+                    if (xxs) {
+                        // ENTRY PER LANE (round 5): lane e = 4 i + b accumulates entry (i, b) of all K matrices over the cells
+                        // -- one table read and K multiply-adds per cell instead of P of each -- then lane b picks up its
+                        // column: entry (i, b) sits four i lanes to the right in the same row of sixteen (DPP row_shl).  The
+                        // same products added in the same cell order.
+                        double E[K];
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) E[k] = 0.0;
+                        const int el = lane & 15;
+                        for (int c = 0; c < C; c++) {
+                            const double xx = xxs[c * 16 + el];
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) E[k] = E[k] + xx * lane_read(Sl[k], c);
+                        }
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) {
+                            B[k][0] = E[k];
+                            B[k][1] = dpp_row_shl<4>(E[k]);
+                            B[k][2] = dpp_row_shl<8>(E[k]);
+                            B[k][3] = dpp_row_shl<12>(E[k]);
+                        }
+                        if constexpr (USE_W) {
+                            _Pragma("unroll")
+                            for (int i = 0; i < P; i++)
+                                if (lane == i && ((dropmask >> i) & 1ull)) B[0][i] = 1.0;
+                        }
+                        return;
+                    }
+                }
                 for (int c = 0; c < C; c++) {
                     double sc[K];
                     _Pragma("unroll")
@@ -957,6 +991,10 @@ __host__ __device__ inline size_t disp_lds_doubles(int m, int p, int waves, int 
 #endif
 template <bool USE_W, bool STAGE, int MODE>
 __host__ __device__ constexpr bool disp_global_dv() { return !STAGE && !USE_W && MODE != 2; }
+// ... whose histogram of the counts (wave_distinct_counts, round 5) still fits in LDS: m int32 per wave, up to 2 560 samples
+// (C4: 8 KB per wave, three blocks of four waves per CU as before); the sort of a 2 000-sample row in 32 registers per lane
+// was ~ 10 % of fit_disp<10>
+__host__ __device__ inline size_t disp_hist_doubles(int p, int m) { return (p >= 4 && m >= 256 && m <= 2560) ? ((size_t)m + 1) / 2 : 0; }
 
 template <int P, bool USE_W, bool STAGE, int MODE>
 __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? DSQ_DISP_MINW_LONG : DSQ_DISP_MINW)) fit_disp_kernel(DispKernelParams kp) {
@@ -970,7 +1008,7 @@ __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? D
 
     const double *xs = smem;
     const bool serial_gram = disp_serial_gram(P, kp.ncell, m);
-    const size_t slab_d = disp_global_dv<USE_W, STAGE, MODE>() ? (serial_gram ? (size_t)3 * m : 0)
+    const size_t slab_d = disp_global_dv<USE_W, STAGE, MODE>() ? disp_hist_doubles(P, m) + (serial_gram ? (size_t)3 * m : 0)
                                                                : disp_slab_doubles<USE_W>(m, STAGE, serial_gram);
     const size_t xoff = (STAGE && kp.xlds) ? (size_t)P * m : 0;
     double *slab = smem + xoff + (size_t)wave * slab_d;
@@ -1077,6 +1115,10 @@ __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? D
         G.wdbuf = serial_gram ? slab + slab_d - (size_t)3 * m : nullptr;
         G.C = C; G.cperm = cperm_s; G.cstart = cstart_s;
         G.sorted = sorted; G.cid = cid_s; G.crep = crep_s; G.xxs = xx_s; G.xcs = xc_s;
+        // (the histogram pays from ~ 256 samples: below, the register sort is a few hundred instructions and a row with one
+        //  large count would pay both -- measured at m = 100: fit_disp 0.387 -> 0.406 ms with it)
+        G.hist_lds = (disp_global_dv<USE_W, STAGE, MODE>() && disp_hist_doubles(P, m) > 0) ? reinterpret_cast<int32_t *>(slab) : nullptr;
+        G.hist_ok = (!disp_global_dv<USE_W, STAGE, MODE>() || G.hist_lds != nullptr) && m >= 256;
         G.build_distinct(dist);
         G.setup_cr();
 
@@ -1211,7 +1253,7 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
     const size_t cell_bytes = (disp_cell_doubles(kp.m, kp.ncell, disp_sorted<USE_W>(stage, kp.ncell)) + disp_xx_doubles(P, kp.ncell) +
                                disp_xc_doubles(P, kp.ncell)) * sizeof(double);
     const bool gdv = !stage && disp_global_dv<USE_W, false, MODE>();
-    const size_t unstaged_lds = gdv ? ((disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) + disp_arena_doubles(P, kp.ncell)) * sizeof(double)
+    const size_t unstaged_lds = gdv ? (disp_hist_doubles(P, kp.m) + (disp_serial_gram(P, kp.ncell, kp.m) ? (size_t)3 * kp.m : 0) + disp_arena_doubles(P, kp.ncell)) * sizeof(double)
                                     : unstaged_wave;
     if (!stage)
         while (waves > 1 && (size_t)waves * unstaged_lds + cell_bytes > budget) waves >>= 1;
