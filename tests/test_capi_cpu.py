@@ -169,3 +169,32 @@ def test_shipped_library_passes_the_exec_lint():
     r = subprocess.run([sys.executable, lint, _lib.SO_PATH], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "0 suspicious" in r.stdout
+
+
+def test_exec_lint_flags_the_round_4_pattern_and_not_a_masked_body():
+    """the lint on three synthetic disassemblies: (a) round 4's defect -- constants of the next statement written at the
+    fall-through of a lane-dependent loop latch, above the exec restore; (b) a constant at the target of a forward
+    s_cbranch_execz, above the restore; (c) the body of a masked region entered through a forward s_cbranch_execnz (the
+    weighted fit_disp<4>'s `pivot = 1.0` of a dropped column): legitimate, not reported."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("exec_lint", os.path.join(root, "tools", "exec_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+
+    def dis(rows, base=0x1000):
+        out = ["%016x <k>:" % base]
+        for i, r in enumerate(rows):
+            out.append("\t%-60s// %012X: 00000000%s" % (r[0], base + 4 * i, "" if len(r) < 2 else " <k+0x%x>" % (4 * r[1])))
+        return "\n".join(out)
+
+    a = dis([("v_add_f64 v[0:1], v[0:1], v[2:3]",), ("s_andn2_b64 exec, exec, s[2:3]",), ("s_cbranch_execnz 65533", 0),
+             ("s_mov_b32 s80, 0",), ("v_mov_b32_e32 v116, 0x260",), ("s_or_b64 exec, exec, s[0:1]",), ("s_endpgm",)])
+    b = dis([("s_and_saveexec_b64 s[8:9], vcc",), ("s_cbranch_execz 2", 3), ("v_add_f64 v[0:1], v[0:1], v[2:3]",),
+             ("v_mov_b64_e32 v[4:5], 1.0",), ("s_or_b64 exec, exec, s[8:9]",), ("s_endpgm",)])
+    c = dis([("s_and_saveexec_b64 s[8:9], s[0:1]",), ("s_cbranch_execnz 1", 3), ("s_branch 1", 4),
+             ("v_mov_b64_e32 v[60:61], 1.0",), ("s_or_b64 exec, exec, s[8:9]",), ("s_endpgm",)])
+    hits = [[t for _, _, t in lint.scan(lint.blocks_of_disassembly(x, "t"))] for x in (a, b, c)]
+    assert hits[0] == ["v_mov_b32_e32 v116, 0x260"], hits
+    assert hits[1] == ["v_mov_b64_e32 v[4:5], 1.0"], hits
+    assert hits[2] == [], hits

@@ -9,7 +9,8 @@ sqrt, which then returned its argument).  Nothing in the source can provoke or p
     python tools/exec_lint.py file.s                               # hipcc -S --cuda-device-only output
 
 Reports every constant move into a vector register that sits between the head of a block where lanes come back together
-(the target of a forward skip on an empty mask, the fall-through of a loop latch; in -S output: any label) and the exec
+(the target of a forward skip on an empty mask -- s_cbranch_execz, not the forward s_cbranch_execnz that enters the
+body of a masked region --, the fall-through of a loop latch; in -S output: any label) and the exec
 restore that leads the block -- and, at the fall-through of a loop latch, where the mask is EMPTY, every vector write of
 any kind (disassembly only).  Exit status 1 when anything is found."""
 import os
@@ -86,7 +87,11 @@ def blocks_of_disassembly(text, tag):
                     continue
                 tg = base + int(mt.group(1), 16)
                 if tg > addr[k]:
-                    heads.setdefault(tg, "join")
+                    if t.startswith("s_cbranch_execz"):
+                        heads.setdefault(tg, "join")
+                    # a forward s_cbranch_execnz enters the BODY of a masked region (`s_and_saveexec; s_cbranch_execnz
+                    # body; s_branch join; body: v_mov ..; join: s_or exec`): writes there are the region's own, under
+                    # its own non-empty mask -- e.g. the `pivot = 1.0` of a dropped column in the weighted fit_disp<4>
                 elif k + 1 < len(ins) and t.startswith("s_cbranch_execnz"):
                     heads[addr[k + 1]] = "exit"       # the fall-through of a loop latch: reached with an EMPTY mask
         for tg in sorted(heads):
