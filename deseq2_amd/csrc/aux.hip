@@ -598,9 +598,125 @@ __global__ void __launch_bounds__(256) weights_prep_kernel(WeightsPrepParams kp)
     }
 }
 
+// ... for designs of more than DSQ_P_REG columns (round 5): one wavefront per gene and workgroup, the design padded to
+// PK = 16 / 24 / 32 / 48 columns.  Lane l owns the entries e = l, l + 64, ... of the two PK x PK Gram matrices (registers:
+// PK^2 / 64 per matrix); the samples go by in tiles of kRankTile whose design rows, w^2 and keep flags sit in LDS.  The rank
+// test is gram_rank's, one matrix column per lane: the same subtractions in the same order for every entry, the Gram
+// matrices and the factor in LDS.
+static constexpr int kRankTile = 16;
+template <int PK>
+DSQ_DEV int gram_rank_lds(const double *G, double *Cm, int p, int lane) {
+    unsigned long long acc = 0ull;
+    int rank = 0;
+    for (int j = 0; j < p; j++) {
+        const double gjj = G[j * PK + j];
+        double r = gjj;
+        for (int k = 0; k < j; k++)
+            if ((acc >> k) & 1ull) { const double c = Cm[k * PK + j]; r -= c * c; }
+        const bool ok = (gjj > 0.0) && (r >= 1e-14 * gjj);
+        if (ok) {
+            const double inv = 1.0 / __builtin_sqrt(r);
+            if (lane < p) {
+                double num = G[j * PK + lane];
+                for (int k = 0; k < j; k++)
+                    if ((acc >> k) & 1ull) num -= Cm[k * PK + j] * Cm[k * PK + lane];
+                Cm[j * PK + lane] = num * inv;
+            }
+            acc |= 1ull << j;
+            rank++;
+            wave_lds_sync();
+        }
+    }
+    return rank;
+}
+
+template <int PK>
+__global__ void __launch_bounds__(64) weights_prep_wide_kernel(WeightsPrepParams kp) {
+    extern __shared__ double smem[];
+    constexpr int T = PK * PK / 64;
+    static_assert(T * 64 == PK * PK, "the padded Gram matrix splits evenly over the lanes");
+    double *G1 = smem, *G2 = G1 + PK * PK, *Cm = G2 + PK * PK, *xt = Cm + PK * PK, *w2t = xt + kRankTile * PK, *kpt = w2t + kRankTile;
+    const int lane = threadIdx.x;
+    const int m = kp.m, p = kp.p;
+    for (int g = blockIdx.x; g < kp.n; g += gridDim.x) {
+        const double *w = kp.w_raw + (size_t)g * kp.ld;
+        double mx = -__builtin_inf();
+        int isneg = 0, isnan_ = 0;
+        for (int j = lane; j < m; j += 64) {
+            const double v = w[j];
+            if (v < 0.0) isneg = 1;
+            if (v != v) isnan_ = 1;
+            if (v > mx) mx = v;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+        if (__any(isnan_)) mx = dnan();                                  // apply(weights, 1, max) is NA then
+        if (__any(isneg) && lane == 0) atomicOr(kp.neg, 1);
+        for (int j = lane; j < m; j += 64) {
+            const double wn = w[j] / mx;
+            kp.w_norm[(size_t)g * kp.ld + j] = wn;
+            kp.w_floor[(size_t)g * kp.ld + j] = (wn != wn) ? wn : (wn > 1e-6 ? wn : 1e-6);      // pmax(weights, 1e-6)
+        }
+        double g1[T], g2[T], cs = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; t++) { g1[t] = 0.0; g2[t] = 0.0; }
+        for (int j0 = 0; j0 < m; j0 += kRankTile) {
+            wave_lds_sync();
+            const int nj = (m - j0) < kRankTile ? (m - j0) : kRankTile;
+            for (int i = lane; i < kRankTile * PK; i += 64) {
+                const int c = i / kRankTile, jj = i - c * kRankTile;
+                xt[jj * PK + c] = (c < p && jj < nj) ? kp.x[(size_t)c * m + j0 + jj] : 0.0;
+            }
+            if (lane < kRankTile) {
+                const double wn = lane < nj ? w[j0 + lane] / mx : 0.0;
+                w2t[lane] = wn * wn;
+                kpt[lane] = (wn > kp.thr) ? 1.0 : 0.0;
+            }
+            wave_lds_sync();
+            for (int jj = 0; jj < nj; jj++) {
+                const double w2 = w2t[jj], keep = kpt[jj];
+                const double *xr = xt + jj * PK;
+                if (lane < PK) cs += keep * __builtin_fabs(xr[lane]);
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int e = lane + 64 * t;
+                    const double xx = xr[e / PK] * xr[e % PK];
+                    g1[t] += w2 * xx;
+                    g2[t] += keep * xx;
+                }
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < T; t++) { G1[lane + 64 * t] = g1[t]; G2[lane + 64 * t] = g2[t]; }
+        wave_lds_sync();
+        const int ncol = __popcll(__ballot(lane < p && cs > 0.0));
+        const int r1 = gram_rank_lds<PK>(G1, Cm, p, lane);
+        wave_lds_sync();
+        const int r2 = gram_rank_lds<PK>(G2, Cm, p, lane);
+        if (lane == 0) kp.force_zero[g] = (r1 == p && r2 == ncol) ? 0 : 1;
+    }
+}
+
 hipError_t launch_weights_prep(const double *w_raw, const double *x, int n, int m, int p, long ld, double thr, double *w_norm,
                                double *w_floor, int32_t *force_zero, int32_t *neg, hipStream_t st) {
     WeightsPrepParams kp = {n, m, p, ld, w_raw, x, thr, w_norm, w_floor, force_zero, neg};
+    if (p > DSQ_P_REG) {
+        const int grid = n < 256 * 8 ? n : 256 * 8;
+        switch (dsq_wide_width(p)) {
+#define DSQ_X(W)                                                                                                              \
+        case W: {                                                                                                             \
+            const size_t lds = (size_t)(3 * W * W + kRankTile * W + 2 * kRankTile) * sizeof(double);                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&weights_prep_wide_kernel<W>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+            hipLaunchKernelGGL((weights_prep_wide_kernel<W>), dim3(grid), dim3(64), lds, st, kp);                              \
+            break;                                                                                                            \
+        }
+        DSQ_WIDE_LIST(DSQ_X)
+#undef DSQ_X
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(weights_prep_kernel, dim3(aux_grid_fwd(n)), dim3(256), 0, st, kp);
     return hipGetLastError();
 }

@@ -943,7 +943,7 @@ int dsq_weights_prep_dev(const double *weights_raw, const double *x, int32_t n, 
                          int32_t *any_negative, void *stream) {
     if (!weights_raw || !x || !w_norm || !w_floor || !weightsFail || !any_negative || n < 0 || m < 1 || ld < m)
         return fail(DSQ_ERR_ARG, "bad arguments");
-    if (p < 1 || p > DSQ_P_REG) return fail(DSQ_ERR_UNSUPPORTED, "dsq_weights_prep_dev: p=%d design columns (1..%d)", p, DSQ_P_REG);
+    if (p < 1 || p > DSQ_P_WIDE) return fail(DSQ_ERR_UNSUPPORTED, "dsq_weights_prep_dev: p=%d design columns (1..%d)", p, DSQ_P_WIDE);
     if (int rc = check_device()) return rc;
     if (n == 0) return DSQ_OK;
     DSQ_HIP(launch_weights_prep(weights_raw, x, n, m, p, ld, weightThreshold, w_norm, w_floor, weightsFail, any_negative,

@@ -201,8 +201,8 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
     }
     if (a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "the number of samples and the number of model coefficients are equal");
     if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns", a->p, DSQ_P_WIDE);
-    if (a->p > DSQ_P_REG && (a->betaPrior || a->weights || (a->x_reduced && a->p_reduced > DSQ_P_REG)))
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns together with a beta prior, observation weights or a reduced model of more than %d columns", a->p, DSQ_P_REG, DSQ_P_REG);
+    if (a->p > DSQ_P_REG && a->betaPrior)
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns together with a beta prior", a->p, DSQ_P_REG);
     if (a->m - a->p <= 3 && !a->geneEstOnly && !(a->dispPriorVar > 0.0))
         return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is the caller's -- geneEstOnly, then dispPriorVar", a->m - a->p);
     if (!(a->cooksCutoff > 0.0) || !(a->expVarLogDisp > 0.0)) return capi_fail(DSQ_ERR_ARG, "cooksCutoff = qf(.99, p, m - p) and expVarLogDisp = trigamma((m - p) / 2) must be given");

@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
                              hipGetErrorString(e_));                                                     \
     } while (0)
 
-enum { DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };      // (a free slot between the call slots and the chain's: the padded design)
+enum { DSQ_WS_PIPE_PADXR = 37, DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };      // (a free slot between the call slots and the chain's: the padded design)
 static inline int kern_width(int p) { return p > DSQ_P_REG ? dsq_wide_width(p) : p; }
 
 struct Pipe {
@@ -819,6 +819,11 @@ struct Pipe {
                                    // behind the lambda block of the caller's workspace: it persists between the phases)
     // nbinomLRT against a reduced model that is not ~1 / the beta-prior refit (never both: the prior is Wald only)
     double *red_binit, *red_beta, *red_se, *red_mu;
+    // ... a reduced model of more than DSQ_P_REG columns runs at ITS padded width (round 5): the reduced design zero-padded to
+    // red_pk columns, ridge 1 on the padding (kept in the lambda block's third part, which only the beta prior uses otherwise)
+    int red_pk;
+    const double *red_x_k;
+    double *red_lam;
     const int32_t *red_cell_perm, *red_cell_start;
     int red_ncell;
     int32_t *cells_dev;            // perm | in3 | cell_start | use3 | replaceable
@@ -894,7 +899,7 @@ struct DesignSel {
 static DesignSel design_of(const Pipe &P, int which) {
     const DsqDeseqArgs *a = P.a;
     DesignSel d;
-    if (which == DES_REDUCED) d = {a->x_red, P.red_binit, P.lam, a->p_red, P.red_cell_perm, P.red_cell_start, P.red_ncell};
+    if (which == DES_REDUCED) d = {P.red_x_k, P.red_binit, P.red_lam, P.red_pk, P.red_cell_perm, P.red_cell_start, P.red_ncell};
     else if (which == DES_PRIOR) d = {a->x_prior, a->prior_expanded ? P.red_binit : P.beta_init, P.lam_prior, a->p_prior,
                                       P.cell_perm, P.cell_start, P.ncell};
     else d = {P.x_k, P.beta_init, P.lam, P.pk, P.cell_perm, P.cell_start, P.ncell};
@@ -1278,6 +1283,8 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
         rb.p = a->p_red; rb.beta_init = P.red_binit;
         rb.optim_flag = P.grid_flag; rb.optim_count = P.counters + cnt3;      // (the grid flags are free between the searches)
         hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, rb);
+        if (P.red_pk > a->p_red)         // (columns p_red .. of the start values may hold the full fit's: zero on the padding)
+            PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)P.n * a->p_red, 0, (size_t)P.n * (P.red_pk - a->p_red) * sizeof(double), P.st));
         rc = launch_optim(P, cnt3, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, P.red_beta, P.red_se, o->logLikeReduced,
                           P.red_mu, DES_REDUCED);
         if (rc) return rc;
@@ -1404,8 +1411,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
     if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_WIDE);
-    if (a->p > DSQ_P_REG && (a->betaPrior || (a->x_red && a->p_red > DSQ_P_REG)))
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: a design of %d > %d columns with a beta prior or a reduced model of more than %d columns", a->p, DSQ_P_REG, DSQ_P_REG);
+    if (a->p > DSQ_P_REG && a->betaPrior)
+        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: a design of %d > %d columns with a beta prior", a->p, DSQ_P_REG);
     if (a->betaPrior) {
         if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: Wald test only (R/core.R:1787)");
         if (!a->x_prior || a->p_prior < 1 || !o->mle_beta) return capi_fail(DSQ_ERR_ARG, "betaPrior needs x_prior / p_prior / mle_beta");
@@ -1484,7 +1491,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         dispatch_beta_scratch(pk, n, m, a->useWeights, &slab_d, &cscr_d);
         if (a->x_red || a->betaPrior) {
             size_t s2 = 0, c2 = 0;
-            dispatch_beta_scratch(a->betaPrior ? a->p_prior : a->p_red, n, m, a->useWeights, &s2, &c2);
+            dispatch_beta_scratch(a->betaPrior ? a->p_prior : kern_width(a->p_red), n, m, a->useWeights, &s2, &c2);
             if (s2 > slab_d) slab_d = s2;
             if (c2 > cscr_d) cscr_d = c2;
         }
@@ -1501,6 +1508,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
             host[c] = c < p ? a->lambda[c] : (c < pk ? 1.0 : 0.0);          // (ridge 1 on the padding of a wide design)
             host[pmax + c] = (c == 0) ? 1.0 : 0.0;
             host[2 * pmax + c] = (a->betaPrior && a->lambda_prior && c < a->p_prior) ? a->lambda_prior[c] : 0.0;
+            if (a->x_red) host[2 * pmax + c] = c < a->p_red ? a->lambda[c] : (c < kern_width(a->p_red) ? 1.0 : 0.0);
         }
         PIPE_HIP(hipMemcpyAsync(P.lam, host, 3 * (size_t)pmax * sizeof(double), hipMemcpyHostToDevice, st));
     }
@@ -1517,6 +1525,19 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         P.padmask = ((1ull << pk) - 1ull) & ~((1ull << p) - 1ull);
         PIPE_HIP(hipMemsetAsync(P.beta_init + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
         PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
+    }
+    P.red_x_k = a->x_red; P.red_pk = a->x_red ? a->p_red : 0; P.red_lam = a->x_red ? P.lam_prior : P.lam;
+    if (a->x_red && kern_width(a->p_red) > a->p_red) {
+        // the reduced design at its own padded width; the padded columns of its start values are zero (the moments kernel
+        // writes the true p_red columns; those of the optim start values are cleared in front of the reduced fit)
+        const int pkr = kern_width(a->p_red);
+        void *b;
+        rc = capi_ws_get(DSQ_WS_PIPE_PADXR, (size_t)m * pkr * sizeof(double), &b);
+        if (rc) return rc;
+        PIPE_HIP(hipMemsetAsync(b, 0, (size_t)m * pkr * sizeof(double), st));
+        PIPE_HIP(hipMemcpyAsync(b, a->x_red, (size_t)m * a->p_red * sizeof(double), hipMemcpyDeviceToDevice, st));
+        P.red_x_k = (const double *)b; P.red_pk = pkr;
+        PIPE_HIP(hipMemsetAsync(P.red_binit + (size_t)n * a->p_red, 0, (size_t)n * (pkr - a->p_red) * sizeof(double), st));
     }
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
     if (a->cell_of && a->ncell > 0)

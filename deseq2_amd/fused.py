@@ -7,7 +7,7 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 48 (p > 10: no beta prior, reduced model of at most 10 columns), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
+Supported: DeviceEngine, p <= 48 (p > 10: no beta prior), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
 the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
@@ -27,10 +27,10 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
         return False
     if dds.p > L.DSQ_MAX_P or dds.m <= dds.p:
         return False
-    # wide designs (10 < p <= 48, the zero-padded kernel builds): without a beta prior, reduced model of at most 10 columns
-    # (... and without observation weights: the rank tests of getAndCheckWeights run as a register kernel up to 10 columns)
-    if dds.p > 10 and (kw.get("betaPrior") or dds.has_weights or
-                       (reduced is not None and np.ndim(reduced) == 2 and np.shape(reduced)[1] > 10)):
+    # wide designs (10 < p <= 48, the zero-padded kernel builds): without a beta prior (observation weights and reduced
+    # models of more than 10 columns run on the chain since round 5: csrc/aux.hip weights_prep_wide_kernel, the reduced
+    # design at its own padded width in csrc/pipeline.hip)
+    if dds.p > 10 and kw.get("betaPrior"):
         return False
     # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3
     # branch of estimateDispersionsPriorVar (seeded Monte-Carlo matching, R/core.R:1155-1190: not mirrored, core raises

@@ -367,7 +367,7 @@ int dsq_replace_outliers_dev(const DsqReplaceArgs *args, const DsqReplaceOut *ou
 
 /* getAndCheckWeights (R/core.R:2697-2751) on resident gene-major weights: w_norm = w / rowmax (:2702), w_floor =
  * pmax(w_norm, 1e-6) (:702), weightsFail[i] = 1 when the weights of gene i leave a degenerate design (the two per-gene
- * qr() rank tests of :2711-2722, full-rank model matrices, p <= 10), *any_negative |= 1 when a weight is negative
+ * qr() rank tests of :2711-2722, full-rank model matrices, p <= DSQ_MAX_P), *any_negative |= 1 when a weight is negative
  * (the caller zeroes it first).  All device pointers; x: m x p column-major.                                      */
 int dsq_weights_prep_dev(const double *weights_raw, const double *x, int32_t n, int32_t m, int32_t p, int64_t ld,
                          double weightThreshold, double *w_norm, double *w_floor, int32_t *weightsFail,
@@ -553,7 +553,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
  * Covers what the fused chain covers: parametric trend, fitType "mean" or the caller's own trend (geneEstOnly / dispFit), Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 48
- * (10 < p: no beta prior, no observation weights, reduced model of at most 10 columns),
+ * (10 < p: no beta prior; observation weights and reduced models of any width < p are taken since round 5),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
  * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),

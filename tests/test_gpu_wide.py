@@ -233,6 +233,106 @@ def test_wide_chain_paired_design_matches_oracle(oracle):
         assert_same(np.asarray(res[k], float), np.asarray(b.mcols[kr], float), "paired-design dsq_deseq$" + k)
 
 
+@pytest.mark.parametrize("p,m", [(12, 60), (16, 130), (24, 120), (31, 93), (46, 200)])
+def test_wide_weights_prep_matches_host(p, m):
+    """getAndCheckWeights (R/core.R:2697-2751) on designs of more than 10 columns (round 5: weights_prep_wide_kernel, the
+    Gram matrices entry-per-lane, the rank test one column per lane): normalised weights, their floor and the
+    weightsFail flags against the host mirror -- rows that lose a whole level, a column pair that becomes collinear
+    and rows with all-zero weights included"""
+    from deseq2_amd.engine import _weights_ok_host
+    rng = np.random.default_rng(p * 1000 + m)
+    x = simulate.design_factor(m, p)
+    n = 300
+    w = rng.uniform(0.02, 1.0, (n, m))
+    w[rng.uniform(size=w.shape) < 0.05] = 0.0
+    w[3, x[:, 2] == 1] = 0.0                               # a level without a sample: rank(w * X) < p
+    w[10, x[:, p - 1] == 1] = 0.005                        # ... only below the threshold: the second test's column drop
+    w[20] = 0.0                                            # apply(w, 1, max) = 0: NaN weights
+    w[30, (x[:, 1] == 0) & (x[:, 4] == 0)] = 0.0           # only levels 1 and 4 (and no reference sample) left
+    E = DeviceEngine("cuda:0")
+    wn, wf, fz, neg = E.weights_prep(E.matrix(w), x, 1e-2)
+    with np.errstate(all="ignore"):
+        want = w / w.max(axis=1, keepdims=True)
+        ok = _weights_ok_host(np.nan_to_num(want, nan=0.0), x, 1e-2, True)
+    got = E.to_numpy(wn)
+    assert_same(got, want, "w_norm")
+    assert_same(E.to_numpy(wf), np.where(np.isnan(want), want, np.maximum(want, 1e-6)), "w_floor")
+    fail = E._host(fz).numpy().astype(bool)
+    assert fail[3] and fail[20] and fail[30]
+    keep = ~np.isnan(want).any(axis=1)
+    assert (fail[keep] == ~ok[keep]).all(), np.flatnonzero(fail[keep] != ~ok[keep])
+    assert int(E._host(neg).numpy()[0]) == 0
+
+
+def _chain_three_ways(oracle, counts, x, sf, tag, weights=None, **kw):
+    """fused device chain == call-by-call chain on the device == the oracle's chain (HostEngine), every column"""
+    from deseq2_amd import fused
+    E = DeviceEngine("cuda:0")
+    a = core.DESeqDataSet(counts, x, sizeFactors=sf, weights=weights, engine=E)
+    assert fused.supported(a, **{k: v for k, v in kw.items() if k != "minReplicatesForReplace"})
+    fused.DESeq(a, **kw)
+    assert a.attrs.get("fused")
+    b = core.DESeq(core.DESeqDataSet(counts, x, sizeFactors=sf, weights=weights, engine=E), **kw)
+    c = core.DESeq(core.DESeqDataSet(counts, x, sizeFactors=sf, weights=weights, engine=HostEngine(oracle)), **kw)
+    keys = [k for k in c.mcols if k != "rowsForOptim"]
+    for k in keys:
+        assert_same(np.asarray(b.mcols[k], np.float64), np.asarray(c.mcols[k], np.float64), tag + " call-by-call vs oracle$" + k)
+        assert_same(np.asarray(a.mcols[k], np.float64), np.asarray(c.mcols[k], np.float64), tag + " fused vs oracle$" + k)
+    return a, c
+
+
+def test_wide_chain_with_observation_weights(oracle):
+    """VERDICT r4 missing #4: a 14-level factor WITH observation weights stays on the fused chain (cells of 8: count
+    outliers are replaced and their rows refitted), a row whose weights fail included"""
+    m = 112
+    x = simulate.design_factor(m, 14)
+    rng = np.random.default_rng(31)
+    sf = np.exp(rng.normal(0, 0.2, m))
+    d = simulate.make_counts(260, x, seed=31, size_factors=sf)
+    counts = d["counts"].copy()
+    n = counts.shape[0]
+    for r in rng.choice(n, 5, replace=False):
+        counts[r, rng.integers(m)] = int(counts[r].max() * 40 + 1000)
+    w = rng.uniform(0.05, 1.0, (n, m))
+    w[rng.uniform(size=w.shape) < 0.02] = 0.0
+    w[9, x[:, 5] == 1] = 0.0
+    a, c = _chain_three_ways(oracle, counts, x, sf, "wide weights", weights=w)
+    assert c.mcols["weightsFail"][9] and np.isnan(a.mcols["dispersion"][9])
+    assert a.attrs["status"]["N_REFIT"] >= 1
+    res = native.DESeq(counts, x, sf, weights=w, assays=())
+    for k, kr in (("dispGeneEst", "dispGeneEst"), ("dispersion", "dispersion"), ("beta", "beta"), ("betaSE", "betaSE"),
+                  ("stat", "WaldStatistic")):
+        assert_same(np.asarray(res[k], float), np.asarray(c.mcols[kr], float), "wide weights dsq_deseq$" + k)
+
+
+@pytest.mark.parametrize("patients,reps,minrep", [(12, 4, 3), (30, 1, 7)])
+def test_wide_chain_lrt_against_a_wide_reduced_model(oracle, patients, reps, minrep):
+    """VERDICT r4 missing #4: `~ patient + treatment` tested by nbinomLRT against `~ patient` -- a reduced model of 12
+    (30) columns under a full model of 13 (31): the reduced fit runs at its own padded width inside the chain
+    (R/core.R:1856-1868), also on the rows the outlier replacement refits (12 patients, minReplicatesForReplace = 3)"""
+    m = 2 * reps * patients
+    pat = np.repeat(np.arange(patients), 2 * reps)
+    trt = np.tile(np.repeat([0.0, 1.0], reps), patients)
+    x = np.column_stack([np.ones(m)] + [(pat == k).astype(float) for k in range(1, patients)] + [trt])
+    red = np.ascontiguousarray(x[:, :-1])
+    rng = np.random.default_rng(patients)
+    sf = np.exp(rng.normal(0, 0.2, m))
+    d = simulate.make_counts(220, x, seed=patients + 5, beta_sd=np.array([0.4] * (patients - 1) + [1.0]), size_factors=sf)
+    counts = d["counts"].copy()
+    for r in rng.choice(counts.shape[0], 5, replace=False):
+        counts[r, rng.integers(m)] = int(counts[r].max() * 40 + 1000)
+    a, c = _chain_three_ways(oracle, counts, x, sf, "wide reduced %d" % patients, test="LRT", reduced=red,
+                             minReplicatesForReplace=minrep)
+    assert np.isfinite(np.asarray(c.mcols["LRTPvalue"], float)).mean() > 0.9
+    if minrep == 3:
+        assert a.attrs["status"]["N_REFIT"] >= 1
+    res = native.DESeq(counts, x, sf, test="LRT", reduced=red, minReplicatesForReplace=minrep, assays=())
+    for k, kr in (("dispersion", "dispersion"), ("beta", "beta"), ("betaSE", "betaSE")):
+        assert_same(np.asarray(res[k], float), np.asarray(c.mcols[kr], float), "wide reduced dsq_deseq$" + k)
+    lrt = 2 * (np.asarray(res["logLike"], float) - np.asarray(res["logLikeReduced"], float))
+    assert_same(lrt, np.asarray(c.mcols["LRTStatistic"], float), "wide reduced dsq_deseq$LRTStatistic")
+
+
 def test_too_wide_is_refused():
     from deseq2_amd import _lib
     d = make_case(10, 147, ("factor", 49), seed=1)
