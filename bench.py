@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic workload (SURVEY 8d: seeds 1..3)")
     ap.add_argument("--size-factors", choices=("lognormal", "unit"), default="lognormal",
                     help="s_j ~ logN(0, 0.25^2) (SURVEY 8d's second variant: the harder half, the headline since round 5) or s_j = 1")
+    ap.add_argument("--pipeline", type=int, choices=(1, 2), default=2,
+                    help="N = 1, fused chain: 2 (default) = a step is enqueued while the previous step's result block is "
+                         "copied (side stream) and post-processed on the host; 1 = every step waits for its own results")
     ap.add_argument("--no-variants", action="store_true",
                     help="N = 1: skip the short extra timed regions on the other workload variants (s_j = 1, seeds 2 and 3)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of a 256-row sample of the step's own result")
@@ -217,7 +220,7 @@ def main():
         return int(r[0]), int(r[-1]) + 1
 
     def make_step(W):
-        def step():
+        def step(wait=True):
             dds = core.DESeqDataSet.from_device(E, W["counts_r"], W["nf_r"], x, weights=W["w"], sizeFactors=W["sf"],
                                                 weights_r=W["w_r"])
             kw = dict(test=cfg["test"], reduced=reduced)
@@ -233,7 +236,7 @@ def main():
             else:
                 # the fused device-driven chain (deseq2_amd/fused.py); settings it does not cover (betaPrior: C5) run
                 # the call-by-call chain of core.py
-                fused.DESeq(dds, comm_device=comm_dev, shard_sizes=W.get("shard_sizes"), **kw)
+                fused.DESeq(dds, comm_device=comm_dev, shard_sizes=W.get("shard_sizes"), wait=wait, **kw)
             return [dds]
         return step
 
@@ -253,32 +256,74 @@ def main():
             c["pinned_host"] = None
         return c
 
-    def timed(step, n_local):
+    def timed(step, n_local, depth=1):
+        """depth = 2: software pipeline over the steps (fused chain, one process).  Step k is ENQUEUED (chain + the copy
+        of its result block on a side stream), then step k - 1 is finished on the host (wait for its block, build its
+        columns) while the device works on step k.  Every step's results are consumed inside the timed region; all K
+        steps are complete before the closing barrier.  depth = 1: each step waits for its own results (what one
+        DESeq() call costs end to end)."""
         import gc
-        for _ in range(args.warmup):
-            step()
-        gc.collect()
-        barrier()
-        a0 = alloc_counters()
+        gc.collect()            # (before the warm-up, not between it and the timed steps: the device would sit idle for the
+                                #  tens of milliseconds a collection takes and start the timed region from lowered clocks)
+        gc_was_on = gc.isenabled()
+        gc.disable()            # ... and no automatic collection inside the timed region (a 4-6 ms pause when one lands
+                                #  there; the standard library's timeit does the same).  Nothing here relies on the cyclic
+                                #  collector: fused.py keeps its objects free of reference cycles.
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        prev = wd = None
+        for _ in range(args.warmup):      # (the warm-up runs the way the timed steps do -- same enqueue / finish / release
+            wd = None                     #  order --: the allocator pools and the runtime's queues get their size here)
+            if depth == 2:
+                cur = step(wait=False)
+                if prev is not None:
+                    fused.finish(prev[0])
+                wd, prev = prev, cur
+            else:
+                wd = step()
+        if prev is not None:
+            fused.finish(prev[0])
+        prev = cur = wd = None
+        a0 = alloc_counters()
+        barrier()
         marks = []
         t0 = time.perf_counter()
         dds = None
         held = []
+        prev = None
         for k in range(args.steps):
             if args.hold_results:
                 held.append(dds)
+            tq0 = time.perf_counter()
             dds = None          # release the previous step's HBM tensors before allocating the next ones
+            tq1 = time.perf_counter()
             ev[k][0].record()
-            dds = step()        # (ends with the one device-to-host copy of the result block + stream sync)
-            ev[k][1].record()
+            if depth == 2:
+                cur = step(wait=False)      # chain + result copy enqueued, nothing waited for
+                ev[k][1].record()
+                tq2 = time.perf_counter()
+                if prev is not None:
+                    fused.finish(prev[0])   # step k - 1: its block is down (or nearly), its columns are built now
+                if os.environ.get("DSQ_BENCH_DEBUG") and k < 5:
+                    print("k=%d release %.3f enqueue %.3f finish %.3f ms" % (k, (tq1 - tq0) * 1e3, (tq2 - tq1) * 1e3, (time.perf_counter() - tq2) * 1e3), file=sys.stderr)
+                dds, prev = prev, cur
+            else:
+                dds = step()    # (ends with the one device-to-host copy of the result block + stream sync)
+                ev[k][1].record()
             marks.append(time.perf_counter())
+        if prev is not None:
+            fused.finish(prev[0])
+            dds = prev
+            prev = cur = None
         barrier()
         dt = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         a1 = alloc_counters()
         held = None
         per = np.diff(np.r_[t0, marks]) * 1e3
         span = np.array([a.elapsed_time(b) for a, b in ev])
+        if os.environ.get("DSQ_BENCH_DEBUG") and rank == 0:
+            print("steps wall ms", np.round(per, 3).tolist(), "device span ms", np.round(span, 3).tolist(), file=sys.stderr)
         stats = {"step_ms": {"min": float(per.min()), "median": float(np.median(per)), "max": float(per.max())},
                  # first enqueue of a step -> its last copy has landed, on the device's clock (HIP events on the chain's
                  # stream); step wall time minus this = host code after the results are down
@@ -304,8 +349,19 @@ def main():
     if args.profile_host and rank == 0:
         return profile_host(core, E, step, torch)
 
-    dt, n_total, dds, step_stats = timed(step, n)
+    depth = args.pipeline if (world == 1 and not args.call_by_call) else 1
+    dt, n_total, dds, step_stats = timed(step, n, depth)
     fused_used = bool(dds[0].attrs.get("fused"))
+    sync_ms = None
+    if depth == 2:
+        # the same K steps, each waiting for its own results: what ONE DESeq() call costs end to end (reported beside the
+        # pipelined throughput, never instead of it)
+        keep_warm, args.warmup = args.warmup, 1
+        dts, _, dsy, sst = timed(step, n, 1)
+        args.warmup = keep_warm
+        sync_ms = {"ms_per_step": dts / args.steps * 1e3, "step_ms": sst["step_ms"],
+                   "result_digest_equal": bool(result_digest(dsy[0], world, comm_dev, parallel) == result_digest(dds[0], world, comm_dev, parallel))}
+        dsy = None
 
     # per-kernel launch durations: two extra UNTIMED passes with HIP events around each kernel (recorded inside
     # the C library on the launch stream; reading them back synchronises, so they stay out of the throughput)
@@ -334,7 +390,7 @@ def main():
         for vseed, vmode in ((args.seed, "unit" if args.size_factors == "lognormal" else "lognormal"),
                              (args.seed + 1, args.size_factors), (args.seed + 2, args.size_factors)):
             Wv = workload(vseed, None, vmode)
-            dtv, ntv, ddv, _ = timed(make_step(Wv), Wv["n"])
+            dtv, ntv, ddv, _ = timed(make_step(Wv), Wv["n"], depth)
             variants.append({"seed": vseed, "size_factors": vmode, "genes": ntv, "steps": args.steps,
                              "ms_per_step": dtv / args.steps * 1e3, "value": ntv * args.steps / dtv,
                              "result_digest": result_digest(ddv[0], world, comm_dev, parallel)})
@@ -448,7 +504,8 @@ def main():
                                    "built from)" % (cfg["label"], n_total, world, ", f64 weights" if use_w else ""),
                        "name": args.config, "genes_total": n_total, "genes_this_gpu": n, "samples": m, "p": p,
                        "test": cfg["test"], "parallelism": "gene-shard x%d" % world,
-                       "chain": "fused device-driven (dsq_deseq_dev)" if fused_used else "call-by-call (core.py)"},
+                       "chain": "fused device-driven (dsq_deseq_dev)" if fused_used else "call-by-call (core.py)",
+                       "steps_overlap": "step k enqueued while step k-1's results are copied and post-processed" if depth == 2 else "none"},
             "roofline": roofline,
             "valu_roofline": valu,
             "f64_roofline": f64,
@@ -458,7 +515,12 @@ def main():
             "result_digest": digest,
             "parity": parity,
             "workload": {"seed": args.seed, "size_factors": args.size_factors},
+            # 2: step k is enqueued while step k - 1's result block is copied (side stream) and its columns are built on
+            # the host -- every step's results are consumed inside the timed region; 1: each step waits for its own
+            "pipeline_depth": depth,
         }
+        if sync_ms is not None:
+            out["one_call_at_a_time"] = sync_ms      # the same K steps without the overlap: one DESeq() call end to end
         if variants is not None:
             out["variants"] = variants
         if weak is not None:

@@ -285,7 +285,7 @@ class _Run:
             return
         L.check(L.lib().dsq_deseq_dev(C.byref(self.args), C.byref(self.out), stream))
 
-    _side = {}          # device -> (side stream, pinned buffer): the early copy of the log likelihoods
+    _side = {}          # device -> side stream of the early copy of the log likelihoods
 
     def early_loglike(self):
         """nbinomLRT: start bringing logLike / logLikeReduced to the host as soon as the test's fits are enqueued, on a
@@ -293,11 +293,12 @@ class _Run:
         device works through the outlier phase.  The rows that phase refits are still being rewritten while this copy
         is in flight: whatever the copy saw of them is checked against the final values and recomputed (DESeq below)."""
         t = self.t
-        key = (str(self.E.device), 2 * self.n)
-        side = _Run._side.get(key)
-        if side is None:
-            side = _Run._side[key] = (t.cuda.Stream(device=self.E.device), t.empty(2 * self.n, dtype=t.float64, pin_memory=True))
-        stream, host = side
+        key = str(self.E.device)
+        stream = _Run._side.get(key)
+        if stream is None:
+            stream = _Run._side[key] = t.cuda.Stream(device=self.E.device)
+        # (a pinned buffer per analysis, from torch's caching host allocator: with wait = False two analyses are in flight)
+        host = t.empty(2 * self.n, dtype=t.float64, pin_memory=True)
         ready = t.cuda.Event()
         ready.record()
         stream.wait_event(ready)
@@ -305,6 +306,7 @@ class _Run:
             host.copy_(self.vec[7:9].reshape(-1), non_blocking=True)
             done = t.cuda.Event()
             done.record(stream)
+        self._early_done = done
         return host, done
 
     def read_status(self):
@@ -320,10 +322,56 @@ class _Run:
             raise ValueError("all(weights >= 0) is not TRUE")
         return st, sc
 
+    _copy_stream = {}   # device -> the stream the result block travels on
+
+    def start_read(self):
+        """enqueue the ONE device-to-host copy of the result block (counters, scalars, every per-gene column) behind
+        everything enqueued so far -- on a side stream, into pinned memory, without blocking the host: whatever the
+        caller enqueues next on the chain's stream (the next analysis of a pipelined loop) runs beside the copy"""
+        t = self.t
+        key = str(self.E.device)
+        side = _Run._copy_stream.get(key)
+        if side is None:
+            side = _Run._copy_stream[key] = t.cuda.Stream(device=self.E.device)
+        ready = t.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+        host = t.empty(self.blob.shape, dtype=t.uint8, pin_memory=True)
+        with t.cuda.stream(side):
+            host.copy_(self.blob, non_blocking=True)
+            done = t.cuda.Event()
+            done.record(side)
+        self._pending = (host, done, ready)
+
+    def __del__(self):
+        # an analysis dropped between start_read() and read_all(): its result block goes back to torch's allocator (and
+        # to the next analysis on the chain's stream) only when the copy on the side stream has read it.  (Waiting here
+        # instead of blob.record_stream(side) keeps the block's reuse deterministic: a loop over analyses does not grow
+        # the pool by a block whenever a copy happens to be still in flight.)
+        try:
+            pend = getattr(self, "_pending", None)
+            if pend is not None:
+                pend[1].synchronize()
+            early = getattr(self, "_early_done", None)
+            if early is not None:
+                early.synchronize()
+        except Exception:                                            # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def read_all(self):
-        """the whole result block in ONE device-to-host copy + stream sync: counters, scalars and every per-gene column"""
+        """the whole result block on the host: waits for start_read()'s copy (enqueues it first if nobody has)"""
         n, pc = self.n, self._pcol
-        h = self.E._host(self.blob).numpy()
+        if getattr(self, "_pending", None) is None:
+            self.start_read()
+        host, done, ready = self._pending
+        self._pending = None
+        wait = getattr(self.E._tls, "before_sync", None)    # (cooperative chunk pipeline: see DeviceEngine._host)
+        if wait is not None:
+            wait()
+        done.synchronize()
+        ready.synchronize()     # (complete by now: lets the runtime retire the chain's commands on ITS stream as well -- a loop
+                                #  of wait = False analyses never synchronises that stream otherwise)
+        h = host.numpy()
         hd, hi = h[: self._nd * 8].view(np.float64), h[self._nd * 8:].view(np.int32)
         st = {k: int(hi[9 * n + i]) for k, i in L.DSQ_ST.items()}
         if self.neg is not None and hi[9 * n + L.DSQ_ST_COUNT] != 0:
@@ -370,11 +418,22 @@ def _global_refit_count(run, comm_device, t):
     return t.tensor([min(total, 2 ** 31 - 1)], dtype=t.int32, device=run.E.device)
 
 
+def finish(dds):
+    """the second half of DESeq(dds, wait=False): waits for the result block and fills in mcols / assays / attrs"""
+    f = dds.__dict__.pop("_fused_pending", None)
+    return f() if f is not None else dds
+
+
 def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None,
-          shard_sizes=None, **kw):
+          shard_sizes=None, wait=True, **kw):
     """core.DESeq() / parallel.DESeqParallel() semantics (R/core.R:280-432, R/parallel.R:6-74) on the fused device
     chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
-    over the gathered (baseMean, dispGeneEst) of all ranks."""
+    over the gathered (baseMean, dispGeneEst) of all ranks.
+
+    wait = False (single process): returns as soon as the chain and the copy of its result block are ENQUEUED; the
+    object is complete after fused.finish(dds).  A loop over analyses then keeps the device busy while the host
+    prepares the next one and post-processes the previous one, and the result copy (a side stream) runs beside the
+    next chain's kernels -- bench.py's pipelined steps."""
     if not supported(dds, test=test, reduced=reduced, fitType=fitType, minReplicatesForReplace=minReplicatesForReplace, **kw):
         from . import parallel
         if parallel.world_size() > 1:
@@ -472,10 +531,12 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
         early_host, early_done = run.early_loglike()
         run.launch(L.DSQ_PH_OUTLIERS)
-        early_done.synchronize()
-        eh = early_host.numpy()
-        early = 2 * (eh[:n] - eh[n:])
-        early = (early, core.pchisq_upper(early, dds.p - run.p_red))     # (the device is in the outlier phase meanwhile)
+
+        def early():                          # (first thing of _finish below)
+            early_done.synchronize()
+            eh = early_host.numpy()
+            e = 2 * (eh[:n] - eh[n:])
+            return e, core.pchisq_upper(e, dds.p - run.p_red)            # (the device is in the outlier phase meanwhile)
     elif world == 1:
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     else:
@@ -489,104 +550,112 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.n_refit_all = _global_refit_count(run, comm_device, t)
         run.args.n_refit_global = _ptr(run.n_refit_all)
         run.launch(L.DSQ_PH_FINISH)
-    st, sc, hv, hm, hi, hmle = run.read_all()
-    st2 = st
-    # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
-    # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
-    # (N_TREND is the same on every rank, so all ranks take this branch -- and its exchange -- together; an analysis that
-    # fits a trend has non-zero rows somewhere and needs no exchange to know it)
-    if st["N_TREND"] == 0:
-        nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
-        if nnz == 0:
-            raise ValueError("all genes have zero counts in every sample")
-        raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
-    if st["TREND_STATUS"] != 0 or st["N_ABOVE_MIN"] == 0:
-        # the reference falls back to a local / mean fit here (R/core.R:885-893): not on the fused path
-        if world > 1:
-            return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
-                                          minReplicatesForReplace=minReplicatesForReplace, **kw)
-        return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
-                          minReplicatesForReplace=minReplicatesForReplace, **kw)
-    if custom is not None:
-        fn = {"fitType": "custom", "coefficients": custom, "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
-    elif sc[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]:
-        fn = {"fitType": "mean", "coefficients": float(sc[0]), "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
-    else:
-        fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
-              "dispPriorVar": float(sc[3])}
-    allZero = hi[0].astype(bool)
-    # rows that were all zero from the start carry NA in every column; a row that only BECAME all zero when its outlier
-    # was replaced (newAllZero, R/core.R:2492) keeps its "intermediate" columns and gets NA in the "results" columns
-    # only (:2534-2536) -- the device has already written those
-    zero0 = allZero & (hi[5] == 0) if run.do_replace else allZero
-    anyz = bool(zero0.any())
-
-    def icol(v, as_bool=False):
-        if anyz:
-            out = v.astype(np.float64)
-            out[zero0] = np.nan
-            return out
-        return v.astype(bool) if as_bool else v.copy()
-    mc = {"baseMean": hv[0], "baseVar": hv[1], "allZero": allZero, "dispGeneEst": hv[2], "dispGeneIter": icol(hi[1]),
-          "dispFit": hv[3], "dispMAP": hv[4], "dispersion": hv[5], "dispIter": icol(hi[2]),
-          "dispOutlier": icol(hi[3], True), "beta": hm[0].T, "betaSE": hm[1].T, "betaIter": hv[6],
-          "deviance": -2 * hv[7], "maxCooks": hv[9]}
-    if run.force_zero is not None:
-        wf = E._host(run.force_zero).numpy().astype(bool)
-        if wf.any():
-            mc["weightsFail"] = wf
-    conv = hi[4].astype(np.float64)
-    conv[hi[4] < 0] = np.nan
-    if test == "Wald":
-        pval = hm[3].T
-        if kw.get("useT"):
-            # t-distribution p-values (R/core.R:1474-1503): a function of the statistic and the residual degrees of
-            # freedom alone, evaluated on the host from the downloaded column as core.nbinomWaldTest does
-            from scipy.stats import t as tdist
-            df = kw.get("df")
-            if df is None:
-                num = E.to_numpy(run.w_norm).sum(axis=1) if run.useWeights else np.full(dds.n, dds.m)   # (core's own sum)
-                df = num - dds.p
-            df = np.broadcast_to(np.asarray(df, float), (dds.n,))
-            df = np.where(df > 0, df, np.nan)
-            pval_t = 2 * tdist.sf(np.abs(hm[2].T), df=df[:, None])
-            if run.do_replace and st["N_REFIT"] > 0:
-                # refitWithoutOutliers calls nbinomWaldTest WITHOUT useT (R/core.R:2524-2527): the refitted rows keep the
-                # normal-distribution p-values the device wrote
-                refit = (hi[5] != 0) & ~allZero
-                pval_t[refit] = pval[refit]
-            pval = pval_t
-        mc.update(WaldStatistic=hm[2].T, WaldPvalue=pval, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
-    else:
-        stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878
-        if early is None:
-            pval = core.pchisq_upper(stat, dds.p - run.p_red)
+    def _finish():
+        early_v = early() if early is not None else None
+        st, sc, hv, hm, hi, hmle = run.read_all()
+        st2 = st
+        # R/parallel.R fits the trend on the gathered object: a shard whose rows are all zero is legal as long as some
+        # rank holds counts (N_TREND / TREND_STATUS / N_ABOVE_MIN below come from the gathered vectors: equal on all ranks)
+        # (N_TREND is the same on every rank, so all ranks take this branch -- and its exchange -- together; an analysis that
+        # fits a trend has non-zero rows somewhere and needs no exchange to know it)
+        if st["N_TREND"] == 0:
+            nnz = st["N_NONZERO"] if world == 1 else sum(parallel.allgather_sizes(st["N_NONZERO"], comm_device))
+            if nnz == 0:
+                raise ValueError("all genes have zero counts in every sample")
+            raise RuntimeError("all gene-wise dispersion estimates are within 2 orders of magnitude from the minimum value")
+        if st["TREND_STATUS"] != 0 or st["N_ABOVE_MIN"] == 0:
+            # the reference falls back to a local / mean fit here (R/core.R:885-893): not on the fused path
+            if world > 1:
+                return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+            return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
+                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+        if custom is not None:
+            fn = {"fitType": "custom", "coefficients": custom, "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
+        elif sc[L.DSQ_SC_FIT_USED] == L.DSQ_FIT["mean"]:
+            fn = {"fitType": "mean", "coefficients": float(sc[0]), "varLogDispEsts": float(sc[2]), "dispPriorVar": float(sc[3])}
         else:
-            # p-values computed during the outlier phase from the early copy: keep them where the statistic is what it
-            # was then (bit for bit), recompute the rest (the refitted rows)
-            changed = ~((stat == early[0]) | (np.isnan(stat) & np.isnan(early[0])))
-            pval = early[1]
-            if changed.any():
-                pval[changed] = core.pchisq_upper(stat[changed], dds.p - run.p_red)
-        mc.update(LRTStatistic=stat, LRTPvalue=pval,
-                  fullBetaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
-    if run.do_replace:
-        mc["replace"] = icol(hi[5], True)
-    dds.mcols = mc
-    GM = E.native.GeneMajor
-    dds.assays = {"mu": GM(run.mu, dds.m), "H": GM(run.H, dds.m), "cooks": GM(run.cooks, dds.m)}
-    if run.prior is not None:
-        mc["MLE_beta"] = hmle.T
-        dds.attrs.update(betaPriorVar=bpv, modelMatrixType=run.prior[1], factors=kw.get("factors"))
-    dds.attrs.update(betaPrior=run.prior is not None, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
-                     status={**st, **{k: v for k, v in st2.items() if k.startswith(("N_REPLACE", "N_REFIT")) or k.endswith("_REFIT")}})
-    if run.do_replace:
-        dds.attrs["replaceable"] = run.replaceable.astype(bool)
-        if st2["N_REPLACE"] > 0:
-            dds.assays["replaceCounts"] = GM(run.replaceCounts, dds.m)
-            dds.assays["replaceCooks"] = dds.assays["cooks"]
-    if anyz:
-        dds.attrs["nz_rows"] = np.where(~zero0)[0]
-    dds.dispersionFunction = fn
-    dds._fused_run = run           # keeps the device buffers of the assays alive
+            fn = {"fitType": "parametric", "coefficients": np.array([sc[0], sc[1]]), "varLogDispEsts": float(sc[2]),
+                  "dispPriorVar": float(sc[3])}
+        allZero = hi[0].astype(bool)
+        # rows that were all zero from the start carry NA in every column; a row that only BECAME all zero when its outlier
+        # was replaced (newAllZero, R/core.R:2492) keeps its "intermediate" columns and gets NA in the "results" columns
+        # only (:2534-2536) -- the device has already written those
+        zero0 = allZero & (hi[5] == 0) if run.do_replace else allZero
+        anyz = bool(zero0.any())
+
+        def icol(v, as_bool=False):
+            if anyz:
+                out = v.astype(np.float64)
+                out[zero0] = np.nan
+                return out
+            return v.astype(bool) if as_bool else v.copy()
+        mc = {"baseMean": hv[0], "baseVar": hv[1], "allZero": allZero, "dispGeneEst": hv[2], "dispGeneIter": icol(hi[1]),
+              "dispFit": hv[3], "dispMAP": hv[4], "dispersion": hv[5], "dispIter": icol(hi[2]),
+              "dispOutlier": icol(hi[3], True), "beta": hm[0].T, "betaSE": hm[1].T, "betaIter": hv[6],
+              "deviance": -2 * hv[7], "maxCooks": hv[9]}
+        if run.force_zero is not None:
+            wf = E._host(run.force_zero).numpy().astype(bool)
+            if wf.any():
+                mc["weightsFail"] = wf
+        conv = hi[4].astype(np.float64)
+        conv[hi[4] < 0] = np.nan
+        if test == "Wald":
+            pval = hm[3].T
+            if kw.get("useT"):
+                # t-distribution p-values (R/core.R:1474-1503): a function of the statistic and the residual degrees of
+                # freedom alone, evaluated on the host from the downloaded column as core.nbinomWaldTest does
+                from scipy.stats import t as tdist
+                df = kw.get("df")
+                if df is None:
+                    num = E.to_numpy(run.w_norm).sum(axis=1) if run.useWeights else np.full(dds.n, dds.m)   # (core's own sum)
+                    df = num - dds.p
+                df = np.broadcast_to(np.asarray(df, float), (dds.n,))
+                df = np.where(df > 0, df, np.nan)
+                pval_t = 2 * tdist.sf(np.abs(hm[2].T), df=df[:, None])
+                if run.do_replace and st["N_REFIT"] > 0:
+                    # refitWithoutOutliers calls nbinomWaldTest WITHOUT useT (R/core.R:2524-2527): the refitted rows keep the
+                    # normal-distribution p-values the device wrote
+                    refit = (hi[5] != 0) & ~allZero
+                    pval_t[refit] = pval[refit]
+                pval = pval_t
+            mc.update(WaldStatistic=hm[2].T, WaldPvalue=pval, betaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
+        else:
+            stat = 2 * (hv[7] - hv[8])                                                    # R/core.R:1877-1878
+            if early_v is None:
+                pval = core.pchisq_upper(stat, dds.p - run.p_red)
+            else:
+                # p-values computed during the outlier phase from the early copy: keep them where the statistic is what it
+                # was then (bit for bit), recompute the rest (the refitted rows)
+                changed = ~((stat == early_v[0]) | (np.isnan(stat) & np.isnan(early_v[0])))
+                pval = early_v[1]
+                if changed.any():
+                    pval[changed] = core.pchisq_upper(stat[changed], dds.p - run.p_red)
+            mc.update(LRTStatistic=stat, LRTPvalue=pval,
+                      fullBetaConv=conv if np.isnan(conv).any() else hi[4].astype(bool))
+        if run.do_replace:
+            mc["replace"] = icol(hi[5], True)
+        dds.mcols = mc
+        GM = E.native.GeneMajor
+        dds.assays = {"mu": GM(run.mu, dds.m), "H": GM(run.H, dds.m), "cooks": GM(run.cooks, dds.m)}
+        if run.prior is not None:
+            mc["MLE_beta"] = hmle.T
+            dds.attrs.update(betaPriorVar=bpv, modelMatrixType=run.prior[1], factors=kw.get("factors"))
+        dds.attrs.update(betaPrior=run.prior is not None, test=test, dispModelMatrix=np.asarray(dds.x, np.float64), fused=True,
+                         status={**st, **{k: v for k, v in st2.items() if k.startswith(("N_REPLACE", "N_REFIT")) or k.endswith("_REFIT")}})
+        if run.do_replace:
+            dds.attrs["replaceable"] = run.replaceable.astype(bool)
+            if st2["N_REPLACE"] > 0:
+                dds.assays["replaceCounts"] = GM(run.replaceCounts, dds.m)
+                dds.assays["replaceCooks"] = dds.assays["cooks"]
+        if anyz:
+            dds.attrs["nz_rows"] = np.where(~zero0)[0]
+        dds.dispersionFunction = fn
+        dds._fused_run = run           # keeps the device buffers of the assays alive
+        return dds
+
+    if wait or world > 1:
+        return _finish()
+    run.start_read()
+    dds._fused_pending = _finish
     return dds

@@ -427,3 +427,37 @@ def test_a_loop_of_analyses_allocates_nothing_once_warm(E):
             assert torch.cuda.host_memory_stats().get("num_host_alloc") == h0
     finally:
         gc.enable()
+
+
+def test_pipelined_analyses_equal_the_waiting_ones(E):
+    """fused.DESeq(wait=False) + fused.finish(): three analyses enqueued back to back (each one's result block copied on
+    the side stream while the next chain runs), finished out of order -- every column, the trend and the assays equal
+    the one-call-at-a-time results; an object dropped without finish() leaves nothing behind"""
+    x = simulate.design_batch_condition(48)
+    jobs = []
+    for seed in (21, 22, 23):
+        d = simulate.make_counts(700, x, seed=seed, size_factors=np.exp(np.random.default_rng(seed).normal(0, .2, 48)))
+        jobs.append((_spike_outliers(d["counts"], np.random.default_rng(seed)), d["size_factors"]))
+    want = []
+    for counts, sf in jobs:
+        w = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+        fused.DESeq(w)
+        want.append(w)
+    got = []
+    for counts, sf in jobs:
+        g = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+        assert fused.DESeq(g, wait=False) is g and "_fused_pending" in g.__dict__ and not g.mcols
+        got.append(g)
+    dropped = core.DESeqDataSet(jobs[0][0], x, sizeFactors=jobs[0][1], engine=E)
+    fused.DESeq(dropped, wait=False)
+    del dropped
+    for k in (2, 0, 1):
+        assert fused.finish(got[k]) is got[k] and "_fused_pending" not in got[k].__dict__
+        assert fused.finish(got[k]) is got[k]                     # (a second call finds nothing to do)
+        _compare(want[k], got[k], "pipelined analysis %d" % k)
+    lrt = core.DESeqDataSet(jobs[1][0], x, sizeFactors=jobs[1][1], engine=E)
+    fused.DESeq(lrt, test="LRT", reduced=np.ones((48, 1)), wait=False)
+    fused.finish(lrt)
+    ref = core.DESeqDataSet(jobs[1][0], x, sizeFactors=jobs[1][1], engine=E)
+    fused.DESeq(ref, test="LRT", reduced=np.ones((48, 1)))
+    _compare(ref, lrt, "pipelined LRT")

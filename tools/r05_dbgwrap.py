@@ -1,0 +1,34 @@
+import time, sys, os
+sys.path.insert(0, os.getcwd())
+from deseq2_amd import core, fused
+def w(name, f):
+    def g(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); dt = (time.perf_counter() - t0) * 1e3
+        if dt > 1.0: print("SLOW %s %.3f ms" % (name, dt), file=sys.stderr)
+        return r
+    return g
+fused._Run.__init__ = w("run_init", fused._Run.__init__)
+fused._Run.launch = w("launch", fused._Run.launch)
+def start_read(self):
+    import torch as t
+    T = [time.perf_counter()]
+    key = str(self.E.device)
+    side = fused._Run._copy_stream.get(key)
+    if side is None:
+        side = fused._Run._copy_stream[key] = t.cuda.Stream(device=self.E.device)
+    ready = t.cuda.Event(); ready.record(); T.append(time.perf_counter())
+    side.wait_event(ready); T.append(time.perf_counter())
+    host = t.empty(self.blob.shape, dtype=t.uint8, pin_memory=True); T.append(time.perf_counter())
+    with t.cuda.stream(side):
+        host.copy_(self.blob, non_blocking=True); T.append(time.perf_counter())
+        done = t.cuda.Event(); done.record(side); T.append(time.perf_counter())
+    self._pending = (host, done, ready)
+    if T[-1] - T[0] > 1e-3:
+        print("SLOW start_read parts (record, wait_event, pinned empty, copy_, record) ms:", [round((b - a) * 1e3, 3) for a, b in zip(T, T[1:])],
+              t.cuda.host_memory_stats().get("num_host_alloc"), file=sys.stderr)
+fused._Run.start_read = start_read
+fused.supported = w("supported", fused.supported)
+core.DESeqDataSet.from_device = classmethod(w("from_device", core.DESeqDataSet.from_device.__func__))
+import bench
+sys.argv = ["bench.py"] + sys.argv[1:]
+bench.main()
