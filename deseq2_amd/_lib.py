@@ -223,6 +223,7 @@ class DsqDeseqHostOut(C.Structure):
 
 
 DSQ_PH_GENE_EST, DSQ_PH_TREND, DSQ_PH_MAP_TEST, DSQ_PH_OUTLIERS, DSQ_PH_FINISH, DSQ_PH_PRIOR = 1, 2, 4, 8, 16, 32
+DSQ_PH_OUTLIERS_DETECT, DSQ_PH_OUTLIERS_REFIT = 64, 128
 DSQ_ST = {k: i for i, k in enumerate((
     "N_NONZERO", "N_GRID_GENEEST", "N_TREND", "TREND_STATUS", "N_ABOVE_MIN", "N_GRID_MAP", "N_OPTIM_GENEEST",
     "N_OPTIM_TEST", "N_REPLACE", "N_REFIT", "N_GRID_GENEEST_REFIT", "N_GRID_MAP_REFIT", "N_OPTIM_GENEEST_REFIT",

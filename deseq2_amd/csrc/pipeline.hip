@@ -1418,7 +1418,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (!a->x_prior || a->p_prior < 1 || !o->mle_beta) return capi_fail(DSQ_ERR_ARG, "betaPrior needs x_prior / p_prior / mle_beta");
         if (a->p_prior > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d columns in the prior pass > %d", a->p_prior, DSQ_P_REG);
         if ((a->phases & DSQ_PH_PRIOR) && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "DSQ_PH_PRIOR needs lambda_prior");
-        if ((a->phases & DSQ_PH_OUTLIERS) && a->do_replace && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "betaPrior: the outlier refit needs lambda_prior");
+        if ((a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_REFIT)) && a->do_replace && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "betaPrior: the outlier refit needs lambda_prior");
     }
     if (a->ld < a->m) return capi_fail(DSQ_ERR_ARG, "ld < m");
     // estimateDispersionsPriorVar's branch for 1..3 residual degrees of freedom matches a seeded Monte-Carlo sample
@@ -1435,7 +1435,9 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (a->fitType < DSQ_FIT_PARAMETRIC || a->fitType > DSQ_FIT_PARAMETRIC_OR_MEAN) return capi_fail(DSQ_ERR_ARG, "fitType must be one of DSQ_FIT_*");
     if (a->dispFit_in && a->trend_mean && !a->trend_fit_in) return capi_fail(DSQ_ERR_ARG, "dispFit_in with gathered trend vectors needs trend_fit_in");
     if (a->dispFit_in && (a->phases & DSQ_PH_OUTLIERS) && a->do_replace)
-        return capi_fail(DSQ_ERR_ARG, "dispFit_in: the refit of replaced rows needs the trend at their NEW means -- run with do_replace = 0 and refit in the caller");
+        return capi_fail(DSQ_ERR_ARG, "dispFit_in: the refit of replaced rows needs the trend at their NEW means -- split the phase (DSQ_PH_OUTLIERS_DETECT, update dispFit_in at the replaced rows, DSQ_PH_OUTLIERS_REFIT) or run with do_replace = 0");
+    if ((a->phases & DSQ_PH_OUTLIERS) && (a->phases & (DSQ_PH_OUTLIERS_DETECT | DSQ_PH_OUTLIERS_REFIT)))
+        return capi_fail(DSQ_ERR_ARG, "DSQ_PH_OUTLIERS is both halves: do not combine it with DSQ_PH_OUTLIERS_DETECT / _REFIT");
     if (a->x_red && (a->test != 1 || !a->q_red || !a->a_red || !a->r_red || a->p_red < 1 || a->p_red >= a->p))
         return capi_fail(DSQ_ERR_ARG, "reduced model: LRT only, with its QR factors and 1 <= p_red < p");
     if (!o->baseMean || !o->baseVar || !o->allZero || !o->dispGeneEst || !o->dispGeneIter || !o->dispFit || !o->dispMAP ||
@@ -1445,7 +1447,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         return capi_fail(DSQ_ERR_ARG, "NULL output");
     if (a->test == 0 && (!o->stat || !o->pvalue)) return capi_fail(DSQ_ERR_ARG, "Wald test needs stat / pvalue outputs");
     if (a->test == 1 && !o->logLikeReduced) return capi_fail(DSQ_ERR_ARG, "LRT needs logLikeReduced");
-    if ((a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_FINISH)) && (!a->cell_of || !a->replaceable || a->ncell < 1)) return capi_fail(DSQ_ERR_ARG, "outlier phase needs cell_of / replaceable");
+    if ((a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_DETECT | DSQ_PH_OUTLIERS_REFIT | DSQ_PH_FINISH)) && (!a->cell_of || !a->replaceable || a->ncell < 1)) return capi_fail(DSQ_ERR_ARG, "outlier phase needs cell_of / replaceable");
     int rc = capi_check_device();
     if (rc) return rc;
 
@@ -1652,12 +1654,17 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (rc) return rc;
     }
     // ================================================================ count outliers
-    if (a->phases & DSQ_PH_OUTLIERS) {
+    // (one call: DSQ_PH_OUTLIERS; a caller with its own dispersion trend splits it -- DSQ_PH_OUTLIERS_DETECT up to the moments
+    //  of the replaced rows, then, with dispFit_in updated at those rows' new means, DSQ_PH_OUTLIERS_REFIT)
+    const bool ph_detect = (a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_DETECT)) != 0;
+    const bool ph_refit = (a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_REFIT)) != 0;
+    if (ph_detect || ph_refit) {
         OutlierMeta M;
         rc = outlier_meta(a, m, st, &M);
         if (rc) return rc;
         int32_t *dperm = M.dperm, *din3 = M.din3, *drepl = M.drepl, *dstart = M.dstart;
         const int any3 = M.any3, maxcell = M.maxcell;
+      if (ph_detect) {
         PIPE_HIP(hipMemsetAsync(P.counters + CNT_REP, 0, (CNT_N - CNT_REP) * sizeof(int32_t), st));      // REP .. OPT3R
 
         CooksKernelParams ck;
@@ -1698,6 +1705,10 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
             if (rc) return rc;
             hipLaunchKernelGGL(list_kernel, ew_grid(n), dim3(256), 0, st, rep, (const int32_t *)o->allZero, 0, P.rows_refit,
                                P.counters + CNT_REFIT);
+        }
+      }
+        if (ph_refit && a->do_replace) {
+            const Rows rep = {P.rows_rep, P.counters + CNT_REP, n};
             const Rows rf = {P.rows_refit, P.counters + CNT_REFIT, n};
             // the same chain on the replaced rows; their mu-hat and fitted means go to the (now dead) mu_hat matrix,
             // assays mu / H keep the original fit as in R (the refit runs on a subset object, :2500-2531)

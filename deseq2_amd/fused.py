@@ -462,13 +462,11 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     if callable(fitType):
         # the caller's trend (core.estimateDispersionsFit: what R has after fitType = "local" or dispersionFunction<-):
         # the gene-wise estimates come up, the function is evaluated on the host, its values go down as dispFit_in.  The
-        # refit of replaced rows would need the function at their new means: such analyses (and gene shards) go call by call.
-        if run.do_replace or world > 1:
-            if world > 1:
-                return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
-                                              minReplicatesForReplace=minReplicatesForReplace, **kw)
-            return core.DESeq(dds, test=test, fitType=fitType, reduced=reduced,
-                              minReplicatesForReplace=minReplicatesForReplace, **kw)
+        # refit of replaced rows needs the function at their NEW means (R/core.R:2512): the outlier phase then runs in its two
+        # halves with one more look at the device in between (below).  Gene shards go call by call.
+        if world > 1:
+            return parallel.DESeqParallel(dds, test=test, fitType=fitType, reduced=reduced, comm_device=comm_device,
+                                          minReplicatesForReplace=minReplicatesForReplace, **kw)
         run.launch(L.DSQ_PH_GENE_EST)
         hb = E._host(t.stack([run.baseMean, run.dispGeneEst])).numpy()
         with np.errstate(invalid="ignore"):
@@ -525,6 +523,15 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.lam_prior = np.ascontiguousarray((1.0 / bpv) / np.log(2) ** 2)                 # R/fitNbinomGLMs.R:311,162
         run.args.lambda_prior = run.lam_prior.ctypes.data_as(C.c_void_p)
         run.launch(L.DSQ_PH_PRIOR | L.DSQ_PH_OUTLIERS)
+    elif custom is not None and run.do_replace:
+        run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS_DETECT)
+        h2 = E._host(t.stack([run.baseMean, run.replace.to(t.float64), run.allZero.to(t.float64)])).numpy()
+        rows = np.flatnonzero((h2[1] != 0) & (h2[2] == 0))                # refitReplace, R/core.R:2496-2498
+        if rows.size:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                vals = np.ascontiguousarray(custom(h2[0][rows]), dtype=np.float64)
+            run._fit_in[t.as_tensor(rows, device=E.device)] = t.as_tensor(vals, device=E.device)
+        run.launch(L.DSQ_PH_OUTLIERS_REFIT)
     elif custom is not None:
         run.launch(L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     elif world == 1 and test == "LRT" and E.record is None and dds.n >= 4096:

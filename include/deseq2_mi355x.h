@@ -425,6 +425,13 @@ int dsq_test_math(int op, const double *a, const double *b, const double *c, dou
 #define DSQ_PH_TREND    2
 #define DSQ_PH_MAP_TEST 4
 #define DSQ_PH_OUTLIERS 8
+/* DSQ_PH_OUTLIERS in two calls, for a caller that brings its own dispersion trend (dispFit_in) AND wants the replaced rows
+ * refitted on the chain (refitWithoutOutliers evaluates dispersionFunction(object) at the NEW means, R/core.R:2512):
+ *   DSQ_PH_OUTLIERS_DETECT  Cook's distances, replaceOutliers, baseMean / baseVar / allZero of the replaced rows (:2488-2491)
+ *   -- the caller reads `replace`, `allZero`, `baseMean`, writes its trend at the rows with replace = 1, allZero = 0 into dispFit_in --
+ *   DSQ_PH_OUTLIERS_REFIT   the refit of those rows and the closing steps (:2496-2546)                                   */
+#define DSQ_PH_OUTLIERS_DETECT 64
+#define DSQ_PH_OUTLIERS_REFIT 128
 #define DSQ_PH_PRIOR    32   /* betaPrior = TRUE: the second pass of fitGLMsWithPrior (R/fitNbinomGLMs.R:311-325) with
                                 lambda_prior = 1 / betaPriorVar; DSQ_PH_MAP_TEST has run the MLE pass (:256-260) and the
                                 caller has turned mle_beta into the prior variance (estimateBetaPriorVar, R/core.R:1601-1689:
@@ -509,7 +516,8 @@ typedef struct {
      * DSQ_PH_GENE_EST phase gives baseMean and dispGeneEst): device, n values.  DSQ_PH_TREND then fits nothing and takes
      * varLogDispEsts / the prior variance from the residuals against it (against trend_fit_in, n_trend values aligned with
      * trend_mean / trend_disp, when those are given); DSQ_PH_MAP_TEST takes dispFit from it.  The refit of replaced rows
-     * needs the trend at means the caller has not seen: do_replace must be 0 (the caller refits, R/core.R:2484-2563).  */
+     * needs the trend at means the caller has not seen: either do_replace = 0 (the caller refits, R/core.R:2484-2563) or the
+     * outlier phase in its two halves, DSQ_PH_OUTLIERS_DETECT / _REFIT above.                                          */
     const double *dispFit_in, *trend_fit_in;
     /* estimateDispersionsMAP(dispPriorVar = x) (R/core.R:970,989-994): > 0 = the caller's prior variance, taken instead of
      * the estimate (varLogDispEsts is still computed: the dispOutlier rule reads it).  The way residual df <= 3 runs on the

@@ -216,8 +216,8 @@ def test_the_callers_trend_inside_the_chain(E, case):
     """a dispersion trend the library does not fit (fitType = "local": locfit, R/core.R:889-893; dispersionFunction<-,
     R/methods.R:142-190): gene-wise estimates up, the caller's function on the host, its values down as dispFit_in -- the
     prior variance from the residuals against them, the MAP search around them -- against the call-by-call chain with the
-    same function.  No sample is replaceable here (the refit needs the function at new means: fused.DESeq hands such an
-    analysis to core.DESeq, checked at the end)."""
+    same function.  No sample is replaceable in the first analysis; the second one replaces count outliers and refits
+    their rows (the function is asked again, at the new means)."""
     x = simulate.design_two_group(12)
     d = simulate.make_counts(700, x, seed=41)
     counts = d["counts"].copy()
@@ -242,12 +242,22 @@ def test_the_callers_trend_inside_the_chain(E, case):
         ha, hb = E.to_numpy(a.assays[k]), E.to_numpy(b.assays[k])
         nz = a.attrs.get("nz_rows")
         assert_same(ha, hb[nz] if nz is not None else hb, "%s: assays$%s" % (case, k))
-    # with replaceable samples the analysis goes call by call
+    # with replaceable samples (round 5): the outlier phase in its two halves -- DSQ_PH_OUTLIERS_DETECT, the function at the NEW
+    # means of the replaced rows (R/core.R:2512), DSQ_PH_OUTLIERS_REFIT -- against the call-by-call chain
     x2 = simulate.design_two_group(16)
-    d2 = simulate.make_counts(200, x2, seed=42)
-    c = core.DESeqDataSet(d2["counts"], x2, sizeFactors=d2["size_factors"], engine=E)
-    fused.DESeq(c, fitType=_smooth_trend)
-    assert not c.attrs.get("fused") and c.dispersionFunction["fitType"] == "custom"
+    d2 = simulate.make_counts(500, x2, seed=42)
+    c2 = _spike_outliers(d2["counts"], np.random.default_rng(8), k=6)
+    kw2 = dict(kw)
+    if case == "lrt":
+        kw2.update(reduced=np.ones((16, 1)))
+    w2 = None if w is None else np.random.default_rng(4).uniform(0.2, 1.0, c2.shape)
+    a3, b3 = _both(E, c2, x2, d2["size_factors"], weights=w2, **kw2)
+    assert b3.attrs["status"]["N_REFIT"] >= 1 and b3.dispersionFunction["fitType"] == "custom"
+    for k in [k for k in a3.mcols if k != "rowsForOptim"]:
+        assert_same(np.asarray(a3.mcols[k], np.float64), np.asarray(b3.mcols[k], np.float64), "%s + refit: mcols$%s" % (case, k))
+    rf = np.asarray(b3.mcols["replace"], float) == 1
+    fit3, bm3 = np.asarray(b3.mcols["dispFit"], float), np.asarray(b3.mcols["baseMean"], float)
+    assert_same(fit3[rf], b3.dispersionFunction["coefficients"](bm3[rf]), "dispFit of the refitted rows = the function at their new means")
 
 
 @pytest.mark.parametrize("m", [4, 5])
