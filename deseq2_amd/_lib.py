@@ -218,7 +218,7 @@ class DsqDeseqHostOut(C.Structure):
         "baseMean", "baseVar", "allZero", "dispGeneEst", "dispGeneIter", "dispFit", "dispMAP", "dispersion",
         "dispIter", "dispOutlier", "beta", "betaSE", "stat", "pvalue", "betaConv", "betaIter", "logLike",
         "logLikeReduced", "maxCooks", "replace", "weightsFail", "mu", "H", "cooks", "replaceCounts")] + [
-        ("dispersionFunction", C.c_double * 8), ("status", C.c_int32 * 16), ("betaPriorVar", C.c_double * 24),
+        ("dispersionFunction", C.c_double * 8), ("status", C.c_int32 * 16), ("betaPriorVar", C.c_double * DSQ_MAX_P),
         ("mle_beta", C.c_void_p)]
 
 

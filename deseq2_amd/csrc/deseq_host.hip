@@ -197,12 +197,10 @@ static int check_args(const DsqDeseqHostArgs *a, const DsqDeseqHostOut *o) {
         if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: the Wald test only (R/core.R:1791: nbinomLRT has no beta prior)");
         if (!a->coef_factor) return capi_fail(DSQ_ERR_ARG, "betaPrior: coef_factor (what each model-matrix column is) must be given");
         if (a->x_prior && (a->p_prior < 1 || !a->prior_coef_factor)) return capi_fail(DSQ_ERR_ARG, "betaPrior on the expanded model matrix: p_prior / prior_coef_factor");
-        if (a->x_prior && a->p_prior > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: expanded model matrix with %d > %d columns", a->p_prior, DSQ_P_REG);
+        if (a->x_prior && a->p_prior > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: expanded model matrix with %d > %d columns", a->p_prior, DSQ_P_WIDE);
     }
     if (a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "the number of samples and the number of model coefficients are equal");
     if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns", a->p, DSQ_P_WIDE);
-    if (a->p > DSQ_P_REG && a->betaPrior)
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: p=%d > %d design columns together with a beta prior", a->p, DSQ_P_REG);
     if (a->m - a->p <= 3 && !a->geneEstOnly && !(a->dispPriorVar > 0.0))
         return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq: %d residual degrees of freedom: the prior variance of R/core.R:1155-1190 (seeded Monte-Carlo matching) is the caller's -- geneEstOnly, then dispPriorVar", a->m - a->p);
     if (!(a->cooksCutoff > 0.0) || !(a->expVarLogDisp > 0.0)) return capi_fail(DSQ_ERR_ARG, "cooksCutoff = qf(.99, p, m - p) and expVarLogDisp = trigamma((m - p) / 2) must be given");
@@ -556,7 +554,7 @@ extern "C" int dsq_deseq(const DsqDeseqHostArgs *a, DsqDeseqHostOut *o) {
     }, S);
     if (rc) return rc;
     if (a->betaPrior && X.prior_state < 0 && X.trend_ok) return -X.prior_state;      // (beta_prior_var's own failure; its message is set)
-    if (a->betaPrior) for (int c = 0; c < F.pcol && c < 24; c++) o->betaPriorVar[c] = X.prior_state == 1 ? X.bpv[c] : NAN;
+    if (a->betaPrior) for (int c = 0; c < F.pcol && c < DSQ_MAX_P; c++) o->betaPriorVar[c] = X.prior_state == 1 ? X.bpv[c] : NAN;
     // counters: per-range counts add up; the trend's (fitted by every range over the same gathered vectors) are range 0's
     memset(o->status, 0, sizeof o->status);
     for (int s = 0; s < S; s++)

@@ -824,6 +824,9 @@ struct Pipe {
     int red_pk;
     const double *red_x_k;
     double *red_lam;
+    // ... and so does the (expanded) design of the beta-prior pass: pri_pk columns, the padded copy pri_x_k
+    int pri_pk;
+    const double *pri_x_k;
     const int32_t *red_cell_perm, *red_cell_start;
     int red_ncell;
     int32_t *cells_dev;            // perm | in3 | cell_start | use3 | replaceable
@@ -892,17 +895,18 @@ static RuleParams rule_params(const Pipe &P, const Rows &rw) {
 enum { DES_FULL = 0, DES_REDUCED = 1, DES_PRIOR = 2 };
 struct DesignSel {
     const double *x, *beta_init, *lam;
-    int p;
+    int p;                         // the width the kernels run at (the padded one for a wide design)
     const int32_t *cperm, *cstart;
     int ncell;
+    int p_true;                    // the design's own number of columns
 };
 static DesignSel design_of(const Pipe &P, int which) {
     const DsqDeseqArgs *a = P.a;
     DesignSel d;
-    if (which == DES_REDUCED) d = {P.red_x_k, P.red_binit, P.red_lam, P.red_pk, P.red_cell_perm, P.red_cell_start, P.red_ncell};
-    else if (which == DES_PRIOR) d = {a->x_prior, a->prior_expanded ? P.red_binit : P.beta_init, P.lam_prior, a->p_prior,
-                                      P.cell_perm, P.cell_start, P.ncell};
-    else d = {P.x_k, P.beta_init, P.lam, P.pk, P.cell_perm, P.cell_start, P.ncell};
+    if (which == DES_REDUCED) d = {P.red_x_k, P.red_binit, P.red_lam, P.red_pk, P.red_cell_perm, P.red_cell_start, P.red_ncell, a->p_red};
+    else if (which == DES_PRIOR) d = {P.pri_x_k, a->prior_expanded ? P.red_binit : P.beta_init, P.lam_prior, P.pri_pk,
+                                      P.cell_perm, P.cell_start, P.ncell, a->p_prior};
+    else d = {P.x_k, P.beta_init, P.lam, P.pk, P.cell_perm, P.cell_start, P.ncell, P.p};
     return d;
 }
 
@@ -1019,7 +1023,7 @@ static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *
     kp.minmu = minmu; kp.mu_floor = mu_floor;
     // (a padded design: the kernel writes ds.p columns -- into the work matrices; the listed rows' true columns are copied
     //  to the caller's n x p matrices behind the launch)
-    const bool via_work = ds.p != (which == DES_FULL ? P.p : ds.p) && beta != P.opt_beta;
+    const bool via_work = ds.p != ds.p_true && which != DES_REDUCED && beta != P.opt_beta;     // (the reduced fit's coefficients are work matrices already)
     kp.beta = via_work ? P.opt_beta : beta; kp.betaSE = via_work ? P.opt_se : betaSE;
     kp.conv = P.opt_conv; kp.mu_out = mu_out; kp.loglike = loglike;
     kp.rows = P.rows_opt; kp.n_dev = P.counters + cnt_optim;
@@ -1032,7 +1036,7 @@ static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *
     if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: no optim kernel for p=%d", P.p);
     if (via_work) {
         const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
-        hipLaunchKernelGGL(copy_rows_cols_kernel, dim3(16), dim3(256), 0, P.st, orw, P.n, P.p, (const double *)P.opt_beta,
+        hipLaunchKernelGGL(copy_rows_cols_kernel, dim3(16), dim3(256), 0, P.st, orw, P.n, ds.p_true, (const double *)P.opt_beta,
                            (const double *)P.opt_se, beta, betaSE);
         PIPE_HIP(hipGetLastError());
     }
@@ -1148,6 +1152,8 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
         if (!ok) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: prefit p=1");
         hipLaunchKernelGGL(prior_start_kernel, ew_grid(P.n), dim3(256), 0, P.st, rw, P.n, a->p_prior, a->prior_intercept,
                            (const double *)P.cnum, P.red_binit);
+        if (P.pri_pk > a->p_prior)        // (start values 0 on the padding of a wide expanded design)
+            PIPE_HIP(hipMemsetAsync(P.red_binit + (size_t)P.n * a->p_prior, 0, (size_t)P.n * (P.pri_pk - a->p_prior) * sizeof(double), P.st));
     }
     rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, P.red_mu, 0.0, nullptr, P.t_tol, P.t_maxit, P.t_useQR,
                          P.t_minmu, "fit_beta_prior", DES_PRIOR);
@@ -1162,17 +1168,19 @@ static int prior_fit(Pipe &P, const Rows &rw, const int32_t *y, int cnt_optim) {
     capi_prof_end(P.st);
     const DesignSel ds = design_of(P, DES_PRIOR);
     RuleParams b = rule_params(P, rw);
-    b.p = ds.p; b.beta_init = ds.beta_init;
+    b.p = ds.p_true; b.beta_init = ds.beta_init;
     b.beta = o->beta; b.betaSE = o->betaSE; b.stat = o->stat; b.pvalue = o->pvalue; b.wald = 1;
     b.betaConv = o->betaConv; b.betaIter_out = o->betaIter;
     b.optim_flag = o->optim_test; b.optim_count = P.counters + cnt_optim;
     hipLaunchKernelGGL(beta_post_kernel, ew_grid(P.n), dim3(256), 0, P.st, b);
+    if (P.pri_pk > ds.p_true)             // (columns p_prior .. of the optim start values may hold another fit's: zero on the padding)
+        PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)P.n * ds.p_true, 0, (size_t)P.n * (P.pri_pk - ds.p_true) * sizeof(double), P.st));
     rc = launch_optim(P, cnt_optim, y, o->dispersion, a->weights_norm, P.t_minmu, 0.0, o->beta, o->betaSE, o->logLike, P.red_mu,
                       DES_PRIOR);
     if (rc) return rc;
     const Rows orw = {P.rows_opt, P.counters + cnt_optim, P.n};
     RuleParams ob = rule_params(P, orw);
-    ob.p = ds.p;
+    ob.p = ds.p_true;
     ob.beta = o->beta; ob.betaSE = o->betaSE; ob.stat = o->stat; ob.pvalue = o->pvalue; ob.wald = 1; ob.betaConv = o->betaConv;
     hipLaunchKernelGGL(optim_post_kernel, dim3(16), dim3(256), 0, P.st, ob);
     PIPE_HIP(hipGetLastError());
@@ -1411,12 +1419,10 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     if (!a || !o) return capi_fail(DSQ_ERR_ARG, "NULL args/out");
     if (a->n < 1 || a->m < 2 || a->p < 1 || a->m <= a->p) return capi_fail(DSQ_ERR_ARG, "bad dimensions n=%d m=%d p=%d", a->n, a->m, a->p);
     if (a->p > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: p=%d > %d design columns", a->p, DSQ_P_WIDE);
-    if (a->p > DSQ_P_REG && a->betaPrior)
-        return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: a design of %d > %d columns with a beta prior", a->p, DSQ_P_REG);
     if (a->betaPrior) {
         if (a->test != 0) return capi_fail(DSQ_ERR_ARG, "betaPrior: Wald test only (R/core.R:1787)");
         if (!a->x_prior || a->p_prior < 1 || !o->mle_beta) return capi_fail(DSQ_ERR_ARG, "betaPrior needs x_prior / p_prior / mle_beta");
-        if (a->p_prior > DSQ_P_REG) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d columns in the prior pass > %d", a->p_prior, DSQ_P_REG);
+        if (a->p_prior > DSQ_P_WIDE) return capi_fail(DSQ_ERR_UNSUPPORTED, "dsq_deseq_dev: %d columns in the prior pass > %d", a->p_prior, DSQ_P_WIDE);
         if ((a->phases & DSQ_PH_PRIOR) && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "DSQ_PH_PRIOR needs lambda_prior");
         if ((a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_REFIT)) && a->do_replace && !a->lambda_prior) return capi_fail(DSQ_ERR_ARG, "betaPrior: the outlier refit needs lambda_prior");
     }
@@ -1467,7 +1473,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     // ---- workspace carve (caller-owned: the row lists and counters persist between the phases of an analysis)
     const int nt_cap = a->n_trend > n ? a->n_trend : n;      // (n_trend is the capacity even in the phases without a trend)
     const int pk = P.pk = kern_width(p);
-    const int pmax = (a->betaPrior && a->p_prior > pk) ? a->p_prior : pk;    // columns of the n x . work matrices
+    const int pkp = a->betaPrior ? kern_width(a->p_prior) : 0;
+    const int pmax = pkp > pk ? pkp : pk;                                     // columns of the n x . work matrices
     Carve cv = carve(n, pmax, nt_cap);
     if (!a->workspace || a->workspace_bytes < (int64_t)cv.bytes)
         return capi_fail(DSQ_ERR_ARG, "workspace of %lld bytes, dsq_deseq_workspace_bytes() asks for %zu",
@@ -1493,7 +1500,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         dispatch_beta_scratch(pk, n, m, a->useWeights, &slab_d, &cscr_d);
         if (a->x_red || a->betaPrior) {
             size_t s2 = 0, c2 = 0;
-            dispatch_beta_scratch(a->betaPrior ? a->p_prior : kern_width(a->p_red), n, m, a->useWeights, &s2, &c2);
+            dispatch_beta_scratch(a->betaPrior ? pkp : kern_width(a->p_red), n, m, a->useWeights, &s2, &c2);
             if (s2 > slab_d) slab_d = s2;
             if (c2 > cscr_d) cscr_d = c2;
         }
@@ -1509,7 +1516,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         for (int c = 0; c < pmax; c++) {
             host[c] = c < p ? a->lambda[c] : (c < pk ? 1.0 : 0.0);          // (ridge 1 on the padding of a wide design)
             host[pmax + c] = (c == 0) ? 1.0 : 0.0;
-            host[2 * pmax + c] = (a->betaPrior && a->lambda_prior && c < a->p_prior) ? a->lambda_prior[c] : 0.0;
+            host[2 * pmax + c] = (a->betaPrior && a->lambda_prior) ? (c < a->p_prior ? a->lambda_prior[c] : (c < pkp ? 1.0 : 0.0)) : 0.0;
             if (a->x_red) host[2 * pmax + c] = c < a->p_red ? a->lambda[c] : (c < kern_width(a->p_red) ? 1.0 : 0.0);
         }
         PIPE_HIP(hipMemcpyAsync(P.lam, host, 3 * (size_t)pmax * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1540,6 +1547,15 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         PIPE_HIP(hipMemcpyAsync(b, a->x_red, (size_t)m * a->p_red * sizeof(double), hipMemcpyDeviceToDevice, st));
         P.red_x_k = (const double *)b; P.red_pk = pkr;
         PIPE_HIP(hipMemsetAsync(P.red_binit + (size_t)n * a->p_red, 0, (size_t)n * (pkr - a->p_red) * sizeof(double), st));
+    }
+    P.pri_x_k = a->x_prior; P.pri_pk = a->betaPrior ? a->p_prior : 0;
+    if (a->betaPrior && pkp > a->p_prior) {
+        void *b;
+        rc = capi_ws_get(DSQ_WS_PIPE_PADXR, (size_t)m * pkp * sizeof(double), &b);      // (never beside a reduced model: Wald only)
+        if (rc) return rc;
+        PIPE_HIP(hipMemsetAsync(b, 0, (size_t)m * pkp * sizeof(double), st));
+        PIPE_HIP(hipMemcpyAsync(b, a->x_prior, (size_t)m * a->p_prior * sizeof(double), hipMemcpyDeviceToDevice, st));
+        P.pri_x_k = (const double *)b; P.pri_pk = pkp;
     }
     const Rows nz = {P.rows_nz, P.counters + CNT_NZ, n};
     if (a->cell_of && a->ncell > 0)

@@ -7,7 +7,7 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 48 (p > 10: no beta prior), fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
+Supported: DeviceEngine, p <= 48, fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
 the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
@@ -27,11 +27,9 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
         return False
     if dds.p > L.DSQ_MAX_P or dds.m <= dds.p:
         return False
-    # wide designs (10 < p <= 48, the zero-padded kernel builds): without a beta prior (observation weights and reduced
-    # models of more than 10 columns run on the chain since round 5: csrc/aux.hip weights_prep_wide_kernel, the reduced
-    # design at its own padded width in csrc/pipeline.hip)
-    if dds.p > 10 and kw.get("betaPrior"):
-        return False
+    # (wide designs, 10 < p <= 48 on the zero-padded kernel builds, take everything the narrow ones do since round 5:
+    #  observation weights -- csrc/aux.hip weights_prep_wide_kernel --, reduced models and beta-prior passes of more than 10
+    #  columns, each design at its own padded width in csrc/pipeline.hip)
     # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3
     # branch of estimateDispersionsPriorVar (seeded Monte-Carlo matching, R/core.R:1155-1190: not mirrored, core raises
     # NotImplementedError) are left to the call-by-call code, which reports them
@@ -71,7 +69,7 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
 
 def _prior_design(dds, kw):
     """(model matrix of the beta-prior pass, its type, coefficient names) -- R/core.R:1374-1380, R/fitNbinomGLMs.R:311-325 --
-    or None when the chain does not take it (more than 10 columns; cells that differ from the design's)"""
+    or None when the chain does not take it (more than DSQ_MAX_P columns; cells that differ from the design's)"""
     factors = kw.get("factors")
     mmt = kw.get("modelMatrixType") or ("expanded" if factors is not None else "standard")
     if mmt == "expanded":
@@ -82,7 +80,7 @@ def _prior_design(dds, kw):
         xe = dds.x
     names = core.standard_model_matrix(factors)[1] if factors is not None else ["Intercept"] + ["V%d" % i for i in range(1, dds.p)]
     xe = np.ascontiguousarray(xe, dtype=np.float64)
-    if xe.shape[0] != dds.m or xe.shape[1] > 10 or len(names) != dds.p:
+    if xe.shape[0] != dds.m or xe.shape[1] > L.DSQ_MAX_P or len(names) != dds.p:
         return None
     ca, cb = core._cells(dds.x)[0], core._cells(xe)[0]
     if len(set(zip(ca.tolist(), cb.tolist()))) != len(set(ca.tolist())) or len(set(cb.tolist())) != len(set(ca.tolist())):

@@ -561,7 +561,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
  * Covers what the fused chain covers: parametric trend, fitType "mean" or the caller's own trend (geneEstOnly / dispFit), Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 48
- * (10 < p: no beta prior; observation weights and reduced models of any width < p are taken since round 5),
+ * (wide designs, 10 < p, included: observation weights, reduced models of any width < p and the beta-prior pass since round 5),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions
  * for are passed in: qr.Q / qr.R of the model matrix (R/fitNbinomGLMs.R:139-143), qf(.99, p, m - p) (R/core.R:2081),
@@ -645,7 +645,7 @@ typedef struct {
     int32_t status[16];            /* DSQ_ST_*                                                                    */
     /* betaPrior = TRUE: the prior variance used (attr(object, "betaPriorVar")) and, optionally, the n x p MLE
      * coefficients (mcols MLE_*, log2 scale)                                                                      */
-    double betaPriorVar[24];
+    double betaPriorVar[DSQ_MAX_P];
     double *mle_beta;
 } DsqDeseqHostOut;
 

@@ -7,7 +7,9 @@ covers the analysis (dsq_deseq: no useT) it is run too, over a random number of 
 with the fused chain column by column.  Round 4: wide factor designs (11 ... 20 levels, the zero-padded kernel builds
 inside the chain), the beta prior THROUGH the host entry (prior variance estimated inside the library), a
 normalization-factor matrix together with the outlier refit, minmu != 0.5 on Wald analyses, fitType = "mean" (and the mean
-substituted on the device where the parametric trend does not fit).
+substituted on the device where the parametric trend does not fit).  Round 5: wide designs to 36 levels and paired designs
+(~ patient + treatment) WITH weights and reduced models of any width below p on the chain, the caller's trend function with
+count outliers (the outlier phase in its two halves), and analyses enqueued with wait = False and finished later.
 
     python tests/gpu_fuzz_chain.py [first_seed] [n_seeds]
 """
@@ -21,7 +23,7 @@ import torch  # noqa: F401,E402
 from deseq2_amd import core, fused, native, simulate  # noqa: E402
 from deseq2_amd.engine import DeviceEngine  # noqa: E402
 from tests.helpers import assert_same  # noqa: E402
-from tests.test_gpu_fused import _compare, _spike_outliers  # noqa: E402
+from tests.test_gpu_fused import _compare, _smooth_trend, _spike_outliers  # noqa: E402
 
 
 def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
@@ -63,9 +65,16 @@ def _host_entry_check(b, counts, x, sf, nfm, weights, kw, rng, tag):
 
 def one(E, seed):
     rng = np.random.default_rng(70000 + seed)
-    kind = int(rng.integers(5))
-    if kind == 4:
-        levels = int(rng.integers(11, 21))                       # wide: p = 11 ... 20
+    kind = int(rng.integers(6))
+    if kind == 5:
+        patients = int(rng.integers(5, 25))                      # ~ patient + treatment: p = 6 ... 25, 2 * patients cells
+        reps = int(rng.integers(1, 4))
+        m = 2 * reps * patients
+        pat = np.repeat(np.arange(patients), 2 * reps)
+        x = np.column_stack([np.ones(m)] + [(pat == k).astype(float) for k in range(1, patients)] +
+                            [np.tile(np.repeat([0.0, 1.0], reps), patients)])
+    elif kind == 4:
+        levels = int(rng.integers(11, 37))                       # wide: p = 11 ... 36
         m = levels * int(rng.integers(2, 9))
         x = simulate.design_factor(m, levels)
     elif kind == 0:
@@ -91,14 +100,14 @@ def one(E, seed):
     if rng.uniform() < 0.3:
         counts[:: int(rng.integers(17, 60))] = 0
     weights = None
-    if rng.uniform() < 0.3 and kind != 4:
+    if rng.uniform() < 0.3:                                      # (round 5: on wide designs too)
         weights = rng.uniform(0.05, 1.0, counts.shape)
         weights[rng.uniform(size=counts.shape) < 0.02] = 0.0
     kw = {}
     p = x.shape[1]
     u = rng.uniform()
     if u < 0.3:
-        q = 1 if (p == 1 or rng.uniform() < 0.5) else int(rng.integers(1, min(p, 11)))
+        q = 1 if (p == 1 or rng.uniform() < 0.4) else (p - 1 if rng.uniform() < 0.4 else int(rng.integers(1, p)))   # (round 5: any width < p)
         kw.update(test="LRT", reduced=np.ones((m, 1)) if q == 1 else np.ascontiguousarray(x[:, :q]))
         if q > 1 and rng.uniform() < 0.5:
             kw["minmu"] = 1e-6                                   # R/core.R:1856-1868 (glmGamPoi-style floor)
@@ -106,12 +115,15 @@ def one(E, seed):
         kw.update(useT=True)
         if rng.uniform() < 0.3:
             kw["minmu"] = float(rng.choice([1e-6, 0.1, 2.0]))
-    elif u < 0.6 and kind in (0, 2):
+    elif u < 0.6 and kind in (0, 2, 4):                           # (round 5: wide factors too -- the prior pass at its padded width)
         # betaPrior on the expanded model matrix of a one-factor design (R/core.R:1374-1380)
         lev = (x[:, 1:] @ np.arange(1, p)).astype(int) if p > 1 else np.zeros(m, int)
         kw.update(betaPrior=True, factors={"condition": lev})
-    if rng.uniform() < 0.15:
+    u2 = rng.uniform()
+    if u2 < 0.15:
         kw["fitType"] = "mean"                                   # R/core.R:894-899 on the device
+    elif u2 < 0.27 and not kw.get("betaPrior"):
+        kw["fitType"] = _smooth_trend                            # the caller's trend; with replaceable samples the outlier phase in two halves
     nfm = None
     if rng.uniform() < 0.15 and not kw.get("betaPrior"):
         nfm = np.exp(rng.normal(0, 0.2, counts.shape)) * d["size_factors"][None, :]
@@ -121,7 +133,7 @@ def one(E, seed):
     tag = "seed %d: kind=%d n=%d m=%d p=%d weights=%d nf=%d %s%s%s" % (
         seed, kind, counts.shape[0], m, p, weights is not None, nfm is not None, kw.get("test", "Wald"),
         " reduced=%d" % kw["reduced"].shape[1] if "reduced" in kw else "", (" useT" if kw.get("useT") else " betaPrior" if kw.get("betaPrior") else "")
-        + (" fitType=mean" if kw.get("fitType") else ""))
+        + (" fitType=custom" if callable(kw.get("fitType")) else " fitType=mean" if kw.get("fitType") else ""))
     a = core.DESeqDataSet(counts, x, sizeFactors=sfv, normalizationFactors=nfm, weights=weights, engine=E)
     try:
         core.DESeq(a, **kw)
@@ -132,11 +144,31 @@ def one(E, seed):
             return tag + " SKIP NA guard"
         raise
     b = core.DESeqDataSet(counts, x, sizeFactors=sfv, normalizationFactors=nfm, weights=weights, engine=E)
-    fused.DESeq(b, **kw)
+    if rng.uniform() < 0.4:                                      # enqueue now, finish later (another analysis in between)
+        try:
+            fused.DESeq(b, wait=False, **kw)
+            other = core.DESeqDataSet(counts[: max(8, counts.shape[0] // 3)], x, sizeFactors=sfv,
+                                      normalizationFactors=None if nfm is None else nfm[: max(8, counts.shape[0] // 3)],
+                                      weights=None if weights is None else weights[: max(8, counts.shape[0] // 3)], engine=E)
+            try:
+                fused.DESeq(other, wait=False, **kw)
+            except Exception:                                    # noqa: BLE001  (the third of the rows may be degenerate)
+                other = None
+            fused.finish(b)
+            if other is not None:
+                try:
+                    fused.finish(other)
+                except Exception:                                # noqa: BLE001
+                    pass
+            tag += " pipelined"
+        except Exception:
+            raise
+    else:
+        fused.DESeq(b, **kw)
     if not b.attrs.get("fused"):           # (a failed parametric trend hands the analysis to core.DESeq)
         return tag + " SKIP not fused"
     _compare(a, b, tag)
-    if not kw.get("useT"):
+    if not kw.get("useT") and not callable(kw.get("fitType")):
         _host_entry_check(b, counts, x, sfv, nfm, weights, kw, rng, tag)
         tag += " +host"
     return tag

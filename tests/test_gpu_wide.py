@@ -333,6 +333,39 @@ def test_wide_chain_lrt_against_a_wide_reduced_model(oracle, patients, reps, min
     assert_same(lrt, np.asarray(c.mcols["LRTStatistic"], float), "wide reduced dsq_deseq$LRTStatistic")
 
 
+@pytest.mark.parametrize("levels,mode", [(12, "expanded"), (14, "standard"), (10, "expanded"), (20, "expanded_weights")])
+def test_wide_chain_with_beta_prior(oracle, levels, mode):
+    """nbinomWaldTest(betaPrior = TRUE) on factors of 10 ... 20 levels (R/core.R:1416-1432, R/fitNbinomGLMs.R:242-337): the
+    expanded model matrix has levels + 1 columns (10 levels: 11 -- the first one beyond the register kernels), the prior
+    pass runs at ITS padded width on the chain; fused == call-by-call == oracle chain, and the one-call host entry with
+    the prior variance estimated inside the library"""
+    m = levels * 8                                          # cells of 8: outliers are replaced, their rows refitted
+    factors = {"condition": np.repeat(np.arange(levels), 8)}
+    x, _ = core.standard_model_matrix(factors)
+    assert x.shape[1] == levels
+    rng = np.random.default_rng(levels)
+    sf = np.exp(rng.normal(0, 0.2, m))
+    d = simulate.make_counts(240, x, seed=levels + 3, size_factors=sf)
+    counts = d["counts"].copy()
+    for r in rng.choice(counts.shape[0], 5, replace=False):
+        counts[r, rng.integers(m)] = int(counts[r].max() * 40 + 1000)
+    w = None
+    if mode == "expanded_weights":
+        w = rng.uniform(0.05, 1.0, counts.shape)
+        w[rng.uniform(size=w.shape) < 0.02] = 0.0
+    kw = dict(betaPrior=True, factors=factors)
+    if mode == "standard":
+        kw["modelMatrixType"] = "standard"
+    a, c = _chain_three_ways(oracle, counts, x, sf, "wide betaPrior %d %s" % (levels, mode), weights=w, **kw)
+    assert np.asarray(a.mcols["beta"]).shape[1] == (levels if mode == "standard" else levels + 1)
+    assert_same(np.asarray(a.attrs["betaPriorVar"]), np.asarray(c.attrs["betaPriorVar"]), "betaPriorVar")
+    assert a.attrs["status"]["N_REFIT"] >= 1 or w is not None
+    res = native.DESeq(counts, x, sf, weights=w, assays=(), betaPrior=True, factors=factors, modelMatrixType=kw.get("modelMatrixType"))
+    assert_same(res["betaPriorVar"], np.asarray(c.attrs["betaPriorVar"]), "dsq_deseq: betaPriorVar")
+    for k, kr in (("dispersion", "dispersion"), ("beta", "beta"), ("betaSE", "betaSE"), ("stat", "WaldStatistic"), ("mle_beta", "MLE_beta")):
+        assert_same(np.asarray(res[k], float), np.asarray(c.mcols[kr], float), "wide betaPrior dsq_deseq$" + k)
+
+
 def test_too_wide_is_refused():
     from deseq2_amd import _lib
     d = make_case(10, 147, ("factor", 49), seed=1)

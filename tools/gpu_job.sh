@@ -4,7 +4,8 @@
 # Outputs under gpurun_out/<TAG>/ (merged back); summaries worth keeping are copied to profiles/ by hand.
 #   tests[:PYTEST_ARGS]        pytest -m gpu (extra args after ':' , e.g. tests:tests/test_gpu_fused.py)
 #   bench:CFG[:ARGS...]        python bench.py --config CFG ARGS (':'-separated; without CPU baseline / hostpath unless +cpu / +host)
-#   stats:CFG                  rocprofv3 --kernel-trace --stats of bench.py --config CFG (5 steps), summarised to <TAG>/stats_CFG.md
+#   stats:CFG[:DEPTH]          rocprofv3 --kernel-trace --stats of bench.py --config CFG (5 steps, --pipeline DEPTH, default 1: one step
+#                              at a time, so that the timeline reads step by step), summarised to <TAG>/stats_CFG.md
 #   pmc:CFG                    five separate rocprofv3 --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE, the f64 op mix, int / cvt / smem) -> <TAG>/pmc_CFG.json
 #   py:SCRIPT[:ARGS...]        python SCRIPT ARGS
 #   sh:SCRIPT[:ARGS...]        bash SCRIPT ARGS
@@ -43,7 +44,7 @@ PY
       ;;
     stats)
       cfg=${F[1]}; d=$O/prof_$cfg; rm -rf "$d"
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$d" -o trace -- python "$R/bench.py" --config "$cfg" --steps 5 --warmup 2 --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/stats_$cfg.log" 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$d" -o trace -- python "$R/bench.py" --config "$cfg" --steps 5 --warmup 2 --pipeline ${F[2]:-1} --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/stats_$cfg.log" 2>&1)
       python tools/timeline.py "$(find "$d" -name '*.db' | head -1)" > "$O/timeline_$cfg.txt" 2>&1
       python profiles/summarize_rocpd.py "$(find "$d" -name '*.db' | head -1)" > "$O/stats_$cfg.md" 2>> "$O/stats_$cfg.log"; echo "[gpu_job] stats $cfg rc=$?"; head -25 "$O/stats_$cfg.md"
       rm -rf "$d";;
@@ -53,7 +54,7 @@ PY
       for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" \
                  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM"; do
         k=$((k+1)); d=$O/pmc${k}_$cfg; rm -rf "$d"
-        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$d" -o p -- python "$R/bench.py" --config "$cfg" --steps 2 --warmup 1 --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/pmc${k}_$cfg.log" 2>&1)
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$d" -o p -- python "$R/bench.py" --config "$cfg" --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-hostpath --no-variants --no-parity > "$O/pmc${k}_$cfg.log" 2>&1)
       done
       P1=$(dirname "$(find "$O/pmc1_$cfg" -name p_counter_collection.csv | head -1)"); P2=$(dirname "$(find "$O/pmc2_$cfg" -name p_counter_collection.csv | head -1)"); P3=$(dirname "$(find "$O/pmc3_$cfg" -name p_counter_collection.csv | head -1)")
       export DSQ_PMC_EXTRA="$(dirname "$(find "$O/pmc4_$cfg" -name p_counter_collection.csv | head -1)"):$(dirname "$(find "$O/pmc5_$cfg" -name p_counter_collection.csv | head -1)")"
