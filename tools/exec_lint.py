@@ -102,7 +102,8 @@ def blocks_of_disassembly(text, tag):
                        ["%s %s+0x%x" % (tag, kernel[:60], addr[j] - base) for j in chunk],
                        [re.sub(r"\s*<[^>]+>$", "", ins[j]) for j in chunk])
 
-    for line in text.split("\n"):
+    for line in (text.split("\n") if isinstance(text, str) else text):
+        line = line.rstrip("\n")
         c = line.find("// ")
         if c < 0:
             if line[:1] in "0123456789abcdef" and line.endswith(">:"):
@@ -125,9 +126,13 @@ def blocks_of_disassembly(text, tag):
 
 
 def _lint_object(path):
-    text = subprocess.run([OBJDUMP, "-d", path], check=True, capture_output=True, text=True).stdout
+    # (streamed: the disassembly of the widest builds runs to gigabytes of text)
     f = os.path.basename(path)
-    return scan(blocks_of_disassembly(text, f.split(".")[2] if f.count(".") > 2 else f))
+    with subprocess.Popen([OBJDUMP, "-d", path], stdout=subprocess.PIPE, text=True, bufsize=1 << 20) as proc:
+        hits = scan(blocks_of_disassembly(proc.stdout, f.split(".")[2] if f.count(".") > 2 else f))
+        if proc.wait() != 0:
+            raise RuntimeError("llvm-objdump failed on " + path)
+    return hits
 
 
 def lint_library(so):
@@ -138,10 +143,11 @@ def lint_library(so):
         lib = os.path.join(tmp, "lib.so")
         shutil.copy(so, lib)
         subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f)
-        with multiprocessing.Pool(min(8, max(1, os.cpu_count() or 1))) as pool:
-            for h in pool.map(_lint_object, objs):
-                hits += h
+        objs = sorted((os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f), key=os.path.getsize, reverse=True)
+        with multiprocessing.Pool(min(32, max(1, os.cpu_count() or 1))) as pool:
+            for h in pool.imap_unordered(_lint_object, objs, chunksize=1):      # (largest first, one at a time: the widest
+                hits += h                                                       #  builds take ten times the narrow ones)
+        hits.sort()
         return hits, len(objs)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
