@@ -331,8 +331,10 @@ class _Run:
         side = _Run._copy_stream.get(key)
         if side is None:
             side = _Run._copy_stream[key] = t.cuda.Stream(device=self.E.device)
-        ready = t.cuda.Event()
-        ready.record()
+        ready = getattr(self, "_ready", None)
+        if ready is None:
+            ready = t.cuda.Event()
+            ready.record()
         side.wait_event(ready)
         host = t.empty(self.blob.shape, dtype=t.uint8, pin_memory=True)
         with t.cuda.stream(side):
@@ -340,6 +342,15 @@ class _Run:
             done = t.cuda.Event()
             done.record(side)
         self._pending = (host, done, ready)
+
+    def mark_ready(self):
+        """wait = False: the point of the chain's stream behind which the result block is complete.  The copy itself is
+        enqueued by read_all() -- at that time, in a loop of analyses, this point has usually been passed, so the side stream
+        never holds more than one copy, and none that waits (measured: with the copy of analysis k enqueued behind a
+        pending event while that of k - 1 had not run, hipMemcpyAsync once blocked for 5 ms -- a whole step at the small
+        configurations)."""
+        self._ready = self.t.cuda.Event()
+        self._ready.record()
 
     def __del__(self):
         # an analysis dropped between start_read() and read_all(): its result block goes back to torch's allocator (and
@@ -661,6 +672,6 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
 
     if wait or world > 1:
         return _finish()
-    run.start_read()
+    run.mark_ready()
     dds._fused_pending = _finish
     return dds
