@@ -25,6 +25,11 @@ dispersion trend, as in DESeqParallel.  Headline = STRONG scaling (the config's 
 quotes it: "50k x 500 x p=4 ... gene-sharded across 8 GPUs"); the same run also times WEAK scaling (the
 config's genes per GPU) and reports it under "weak".
 
+N = 1 on the fused chain: the K steps are pipelined two deep (--pipeline 2, the default) -- step k is enqueued, then
+step k - 1 is finished on the host (its result block waited for, its columns built) while the device runs step k; every
+step's results are consumed inside the timed region and all K steps are complete before the closing barrier.  The same
+steps one call at a time are timed right after ("one_call_at_a_time"); --pipeline 1 makes that the headline.
+
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline accounting.
 """
 import argparse

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timeline of one bench step (default: the last TIMED one) in a rocprofv3 rocpd database: every kernel in start order with its duration and
+"""Timeline of one bench step (default: the last but one TIMED step, so that what follows it is another timed step) in a rocprofv3 rocpd database: every kernel in start order with its duration and
 the idle gap before it.  usage: python tools/timeline.py x_results.db [n_steps_in_trace]"""
 import sqlite3
 import sys
@@ -10,7 +10,7 @@ def main(path):
     rows = cur.execute("select name, start, end, grid_x from kernels order by start").fetchall()
     # a step starts with the int32 R-layout -> gene-major conversion of the counts
     starts = [i for i, r in enumerate(rows) if "r_to_gm_kernel<int" in r[0]]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -3     # bench.py: warmup + K timed steps, then 2 passes with events
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else -4     # bench.py: warmup + K timed steps, then 2 passes with events
     lo = starts[which]
     hi = starts[which + 1] if which + 1 < 0 else len(rows)
     seg = rows[lo:hi]
