@@ -474,3 +474,30 @@ def test_pipelined_analyses_equal_the_waiting_ones(E):
     ref = core.DESeqDataSet(jobs[1][0], x, sizeFactors=jobs[1][1], engine=E)
     fused.DESeq(ref, test="LRT", reduced=np.ones((48, 1)))
     _compare(ref, lrt, "pipelined LRT")
+
+
+def test_pipelined_analyses_of_different_designs(E):
+    """three analyses with DIFFERENT designs (p = 4 / 6 / 2, other cells, other sample counts) enqueued back to back before
+    any is finished: each chain's small host-side tables (ridge, design cells, outlier metadata) must have left the host
+    by the time the call returns -- the next call overwrites them -- and the library's device scratch is shared
+    stream-ordered; results equal the one-call-at-a-time ones"""
+    designs = [simulate.design_batch_condition(48), simulate.design_factor(42, 6), simulate.design_two_group(16),
+               np.column_stack([simulate.design_batch_condition(36), np.random.default_rng(1).normal(size=36)])]
+    jobs = []
+    for i, x in enumerate(designs):
+        d = simulate.make_counts(400 + 150 * i, x, seed=90 + i, size_factors=np.exp(np.random.default_rng(i).normal(0, .2, x.shape[0])))
+        jobs.append((_spike_outliers(d["counts"], np.random.default_rng(i), k=4), x, d["size_factors"]))
+    want = []
+    for counts, x, sf in jobs:
+        w = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+        fused.DESeq(w)
+        want.append(w)
+    for _ in range(2):
+        got = []
+        for counts, x, sf in jobs:
+            g = core.DESeqDataSet(counts, x, sizeFactors=sf, engine=E)
+            fused.DESeq(g, wait=False)
+            got.append(g)
+        for k in range(len(jobs)):
+            fused.finish(got[k])
+            _compare(want[k], got[k], "pipelined, design %d" % k)
