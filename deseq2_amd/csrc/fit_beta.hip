@@ -994,7 +994,12 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     double rw = rcp;
                     if constexpr (USE_W) rw = wt * rcp;
                     wv = mu * rw;
-                    const double lg = (raw >= minmu) ? eta : dlog(mu / nf);
+                    // lg = (raw >= minmu) ? eta : log(mu / nf).  Floored means are rare: written as a select the compiler
+                    // evaluates the division and the logarithm for every sample (a quarter of the sweep's instructions);
+                    // behind a wave-uniform test they run only in a trip that holds a floored (or NaN) mean -- same values
+                    const bool floored = !(raw >= minmu);
+                    double lg = eta;
+                    if (__any(floored)) lg = floored ? dlog(mu / nf) : eta;
                     wz = wv * lg + rw * (y - mu);       // w z, with w / mu = [wts] / (1 + alpha mu): no second division
                     if (with_dev) {
                         double t;
