@@ -922,7 +922,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
     // the ridge rows of the collapsed least squares: lane C + k holds sqrt(lambda_k) in column k
     const double sqrt_lam_lane = (lane >= C && lane < Mrows) ? __builtin_sqrt(kp.lambda[lane - C]) : 0.0;
     const double large = 30.0;
-    const double minmu = kp.minmu;
+    // (its own SGPR pair: read as a sub-register of the 16-dword kernel-argument tuple, the allocator spilled the TUPLE and
+    //  reloaded all sixteen registers in front of every use inside the sweep -- 32 v_readlane per trip for one operand)
+    double minmu_ = kp.minmu;
+    asm volatile("" : "+v"(minmu_));
+    const double minmu = minmu_;
 
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
         const int g = DSQ_GENE(kp, wi);
