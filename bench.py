@@ -593,7 +593,7 @@ def parity_sample(dds, W, x, cfg, factors, reduced, rows=256):
             if r > max_rel:
                 max_rel, worst = r, k
     return {"rows": int(pick.size), "of_genes": int(n), "iter_equal": float(eq.mean()), "max_rel": max_rel, "worst_column": worst,
-            "columns": fcols + icols, "checker": "oracle/ (CPU restatement, pinned to the compiled reference by tests/test_oracle_vs_reference.py)",
+            "columns": fcols + icols, "checker": "oracle/ (CPU restatement; pinned by the reference tests' known answers, tests/test_oracle_properties.py)",
             "tolerance_north_star": 1e-6}
 
 
@@ -712,71 +712,10 @@ def profile_host(core, E, step, torch):
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
-class _ReferenceFns:
-    """fns module for HostEngine: the three native routines from the REFERENCE's own src/DESeq2.cpp
-    (oracle/_ref/libdeseq2_ref_fast.so: compiled against the stand-in headers of oracle/shim/, special
-    functions in plain double), everything the reference does in R around them from the C oracle.
-    pool = a multiprocessing pool: the three routines then run on contiguous gene ranges in `workers` processes
-    (the split of R/parallel.R:10 -- what DESeq(parallel = TRUE, BPPARAM = MulticoreParam(workers)) does)."""
-
-    def __init__(self, R, O, pool=None, workers=1):
-        self.R, self.O, self.pool, self.workers = R, O, pool, workers
-        for name in ("prefitMoments", "nbinomLogLike", "parametricDispersionFit", "cooksDistance", "replaceOutliers",
-                     "design_qr", "linearMu", "unary", "interceptFit", "optimRows"):
-            if hasattr(O, name):
-                setattr(self, name, getattr(O, name))
-
-    def _split(self, fname, rowargs, args):
-        """run R.<fname> over row chunks; rowargs = indices of the arguments that are per-gene (n x ., n)"""
-        if self.pool is None:
-            return getattr(self.R, fname)(*args)
-        n = np.asarray(args[0]).shape[0]
-        from deseq2_amd.parallel import shard_ranges
-        jobs = []
-        for r in shard_ranges(n, min(self.workers, max(1, n))):
-            if r.size == 0:
-                continue
-            a = list(args)
-            for i in rowargs:
-                v = np.asarray(a[i])
-                if v.ndim >= 1 and v.shape[0] == n:
-                    a[i] = v[r]
-            jobs.append((fname, a))
-        parts = self.pool.map(_ref_call, jobs)
-        return {k: np.concatenate([q[k] for q in parts], axis=0) for k in parts[0]}
-
-    def fitBeta(self, y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol, maxit, useQR, minmu,
-                want_mu=False, mu_floor=0.0, want_hat=True):
-        alpha_hat = np.broadcast_to(np.asarray(alpha_hat, float), (np.asarray(y).shape[0],))
-        r = self._split("fitBeta", (0, 2, 3, 5, 7), (y, x, nf, alpha_hat, contrast, beta_mat, lam, w, useWeights, tol,
-                                                      maxit, useQR, minmu))
-        if want_mu:
-            r["mu"] = self.O.fittedMu(x, nf, r["beta_mat"], mu_floor)
-        return r
-
-    def fitDisp(self, y, x, mu, la, pm, *rest):
-        n = np.asarray(y).shape[0]
-        la = np.broadcast_to(np.asarray(la, float), (n,))
-        pm = np.broadcast_to(np.asarray(pm, float), (n,))
-        return self._split("fitDisp", (0, 2, 3, 4, 11), (y, x, mu, la, pm) + tuple(rest))
-
-    def fitDispGrid(self, y, x, mu, grid, pm, *rest):
-        pm = np.broadcast_to(np.asarray(pm, float), (np.asarray(y).shape[0],))
-        return self._split("fitDispGrid", (0, 2, 4, 7), (y, x, mu, grid, pm) + tuple(rest))
-
-
-def _ref_call(job):
-    from oracle import reference as R
-    R.use_fast(True)
-    fname, a = job
-    return getattr(R, fname)(*a)
-
-
 def cpu_baseline(counts, sf, x, k, cfg, weights, factors, reduced):
     """CPU baseline on the first k genes of the same workload through the same host code, on the GPU box's host
-    cores: 1 thread (what the reference is) AND all cores (gene ranges on worker processes, the reference's
-    parallel = TRUE).  kind "reference" = the reference's own C++ source for fitBeta / fitDisp / fitDispGrid (when
-    the prebuilt oracle/_ref library is present), else kind "port" = the C oracle."""
+    cores: 1 thread (what the reference is) AND all cores (OpenMP over genes).  kind "port" = the C oracle: the reference's
+    src/DESeq2.cpp needs R, Rcpp and RcppArmadillo, which this image does not have, so it is not built here."""
     from deseq2_amd import core
     from deseq2_amd.engine import HostEngine
     from oracle import oracle as O
@@ -812,35 +751,8 @@ def cpu_baseline(counts, sf, x, k, cfg, weights, factors, reduced):
            "sample": "%s over the C oracle, %.1f s" % (what, dt_port),
            "all_cores": {"value": sub_all.shape[0] / dt_port_all, "cores": ncores, "kind": "port",
                          "sample": "first %d genes, OpenMP over genes, %.1f s" % (sub_all.shape[0], dt_port_all)}}
-    try:
-        from oracle import reference as R
-        R.use_fast(True)
-        O.set_threads(1)
-        dt_ref = run(_ReferenceFns(R, O))
-        out = {"value": sub.shape[0] / dt_ref, "unit": "genes/s", "cores": 1, "kind": "reference",
-               "sample": "%s; fitBeta/fitDisp/fitDispGrid = the reference's src/DESeq2.cpp compiled against stand-in "
-                         "Rcpp/Armadillo headers (libm special functions), the R-side steps in C, %.1f s" % (what, dt_ref),
-               "port_value": sub.shape[0] / dt_port, "port_all_cores": out["all_cores"]}
-        if ncores > 1:
-            import multiprocessing as mp
-            O.set_threads(ncores)
-            with mp.get_context("fork").Pool(ncores) as pool:
-                pool.map(_ref_call, [("fitDispGrid", _tiny_grid_job(x))] * ncores)      # workers load the library
-                dt_all = run(_ReferenceFns(R, O, pool, ncores), big=True)
-            out["all_cores"] = {"value": sub_all.shape[0] / dt_all, "cores": ncores, "kind": "reference",
-                                "sample": "first %d genes; the three native routines on %d worker processes over "
-                                          "contiguous gene ranges (R/parallel.R:10), R-side steps OpenMP, %.1f s"
-                                          % (sub_all.shape[0], ncores, dt_all)}
-    except (OSError, ImportError):
-        pass
     O.set_threads(1)
     return out
-
-
-def _tiny_grid_job(x):
-    m = x.shape[0]
-    y = np.ones((1, m))
-    return (y, x, y + 1.0, np.linspace(-2.0, 1.0, 3), np.zeros(1), 1.0, False, y, False, 1e-2, True)
 
 
 if __name__ == "__main__":

@@ -12,24 +12,27 @@
  * Same control flow, same counters, same break conditions, same clamps.  Each block
  * cites the reference lines it follows.
  *
- * PARITY STATUS: PINNED against the reference's own source.  The real package build is not
- * possible here (no R, Rcpp, RcppArmadillo), but src/DESeq2.cpp itself compiles unchanged
- * against the stand-in headers of oracle/shim/ (oracle/Makefile target `ref` ->
- * oracle/_ref/libdeseq2_ref.so, git-ignored, never a copy of the source).  Its outputs on
- * seeded inputs are committed as tests/golden/reference_golden.npz; tests/
- * test_oracle_vs_reference.py requires this oracle to reproduce them -- iteration and accept
- * counts equal, values within 1e-8 -- and repeats the comparison live on larger cases when the
- * .so is present.  What the stand-ins supply underneath the reference's control flow is dense
- * LU/QR and binary128 special functions, NOT LAPACK / R's nmath, so agreement is to rounding,
- * not to the bit; where the reference's formulas are themselves rounding noise (alpha ~ 1e-8:
- * dlog_posterior scales digamma differences by alpha^-2, DESeq2.cpp:90-96) only the
- * implementation-independent facts are asserted.  Also pinned by: the reference's
- * known-answer tests (tests/testthat/test_results.R:9,43-50; test_optim.R:30-39), the
- * cross-implementation properties its tests assert (test_betaFitting.R, test_dispersions.R,
- * test_QR.R, test_weights.R) re-run with scipy/mpmath, and mpmath accuracy tests of every
- * scalar primitive (tests/test_oracle_*.py).  The R-side callers restated later in this file
- * (moments, trend fit, Cook's distance, replaceOutliers) have no compiled counterpart (they
- * are R code); they are checked against independent numpy statements of the R lines cited.
+ * PARITY STATUS: PINNED by the reference's own tests; the reference itself is UNBUILDABLE here.
+ * src/DESeq2.cpp includes RcppArmadillo.h, R.h, Rmath.h and R_ext/Utils.h (:16,23-25): R, Rcpp,
+ * RcppArmadillo and Armadillo are external libraries this image lacks, no R runs here, and a build
+ * against stand-ins for them would not be the reference -- none is made, and no output of real R
+ * is in the tree.  What pins this file:
+ *   (1) the reference's known-answer tests (tests/testthat/test_results.R:9,43-50;
+ *       test_optim.R:30-39) and the cross-implementation properties its tests assert
+ *       (test_betaFitting.R:2-47, test_dispersions.R:35-111, test_QR.R, test_weights.R:9-19)
+ *       re-run with scipy / mpmath as the independent side -- tests/test_oracle_properties.py
+ *       (SURVEY.md 8c lists them; the R tests' own seeds are R-RNG specific);
+ *   (2) mpmath accuracy tests of every scalar primitive restated from R's nmath
+ *       (tests/golden/nmath_golden.json, tests/test_oracle_math.py);
+ *   (3) an independently written numpy restatement of the three routines over real LAPACK and
+ *       scipy's special functions (oracle/lapack_oracle.py): iteration and accept counts equal
+ *       outside ulp-level Armijo ties, values within 1e-7 / 1e-8 (tests/test_oracle_vs_lapack.py).
+ * NOT pinned: iteration counts against a run of real R (the reference's tests assert none but
+ * betaIter == 100 in test_optim.R:35); where the reference's formulas are themselves rounding
+ * noise (alpha ~ 1e-8: dlog_posterior scales digamma differences by alpha^-2, DESeq2.cpp:90-96)
+ * only the implementation-independent facts are asserted.  The R-side callers restated later in
+ * this file (moments, trend fit, Cook's distance, replaceOutliers) are R code in the reference;
+ * they are checked against independent numpy statements of the R lines cited.
  *
  * ARITHMETIC SPEC (what "the same result" means for the GPU):
  *   - all arithmetic IEEE binary64, no FMA contraction, fma() only where written;

@@ -2,17 +2,16 @@
 
 There the reference's dlog_posterior multiplies a cancelling digamma sum by alpha^-2 = 1e16
 (src/DESeq2.cpp:90-96): the number of line-search steps is rounding noise of whichever lgamma / digamma sits
-underneath -- the reference compiled with libm-double special functions disagrees with the SAME source compiled
-with exact ones on > 90 % of such genes (profiles/r03_parity.md).  So the iteration count of a floor gene cannot
-be pinned; what R's callers can SEE can, and that is what this module extracts and compares:
+underneath -- two correct implementations with different special functions (the C oracle's nmath restatement and
+scipy's cephes under oracle/lapack_oracle.py) disagree on most such genes.  So the iteration count of a floor gene
+cannot be pinned; what R's callers can SEE can, and that is what this module extracts and compares:
 
   fitBeta$iter                                                   (R/fitNbinomGLMs.R:191)
   dispGeneEst after the noIncrease rule and the [minDisp, maxDisp] clamp  (R/core.R:785, 826-830, 848)
   dispGeneEstConv = iter < maxit & iter != 1, refitDisp          (R/core.R:832-835)
   MAP dispConv = iter < maxit and the clamped dispMAP            (R/core.R:1048, 1100-1101)
 
-Shared by tests/test_floor_regime.py (CPU: oracle), tests/test_gpu_reference.py (HIP path),
-tests/golden/make_reference_floor.py (the compiled reference's stored outputs) and tools/parity_report.py.
+Shared by tests/test_floor_regime.py (CPU: oracle) and tests/test_gpu_vs_lapack.py (HIP path).
 """
 import numpy as np
 
@@ -73,8 +72,8 @@ def visible_chain(F, d, minDisp=1e-8, maxit=100):
 
 def rates(a, b):
     """agreement of two implementations on what R sees"""
-    # the regime: start OR end in the noise region (measured: the two builds of the reference itself disagree on step
-    # counts up to final dispersions of ~5e-6, profiles/r03_parity.md)
+    # the regime: start OR end in the noise region (step counts of two correct implementations differ up to final
+    # dispersions of ~5e-6)
     fl = (b["alpha_init"] <= NOISE) | (a["dispGeneEst"] <= NOISE) | (b["dispGeneEst"] <= NOISE)
     rel = np.abs(a["dispGeneEst"] - b["dispGeneEst"]) / np.maximum(np.abs(b["dispGeneEst"]), 1e-300)
     return dict(n=int(fl.size), floor_start=int((b["alpha_init"] <= 1e-8).sum()), floor=int(fl.sum()),
@@ -91,7 +90,7 @@ def rates(a, b):
 
 
 def assert_visible_parity(got, ref, name):
-    """the budgets (measured: profiles/r03_parity.md; the reference's own libm build sits at the same rates)"""
+    """the budgets"""
     s = rates(got, ref)
     assert s["floor_start"] >= 0.25 * s["n"], "%s: only %d of %d genes start at the floor" % (name, s["floor_start"], s["n"])
     assert s["beta_iter_mismatch"] == 0, "%s: fitBeta$iter differs on %d genes" % (name, s["beta_iter_mismatch"])
@@ -106,9 +105,3 @@ def assert_visible_parity(got, ref, name):
     # away from the floor the strict claim holds: iteration counts equal (bar ulp-level ties, <= 1 %)
     assert s["iter_equal_rest"] >= 0.99, "%s: fitDisp$iter equal on %.3f of the genes above the floor" % (name, s["iter_equal_rest"])
     return s
-
-
-def load_floor_golden(path, seed, which="ref"):
-    z = np.load(path)
-    pre = "%s/seed%d/" % (which, seed)
-    return {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}

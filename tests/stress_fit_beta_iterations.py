@@ -1,5 +1,5 @@
 """Stress check (run by hand, not collected by pytest): fitBeta iteration counts of the restatement (cell path, closed
-deviance split) against the reference's own src/DESeq2.cpp (oracle/_ref, libm build) on many genes, including the
+deviance split) against the LAPACK restatement (oracle/lapack_oracle.py) on many genes, including the
 corners where the deviance split could lose accuracy -- dispersions at the 1e-8 floor, counts of 1e5, size factors
 far from 1.  Prints the number of genes whose iteration count differs.
 
@@ -17,8 +17,7 @@ from tests.helpers import make_case           # noqa: E402
 
 def one(job):
     n, m, design, seed, imean, alpha_mode, sfr = job
-    from oracle import oracle, reference
-    reference.use_fast(True)
+    from oracle import oracle, lapack_oracle as reference
     cont = isinstance(design, tuple) and design[0] == "continuous"
     d = make_case(n, m, design[1] if cont else design, seed=seed, sf_random=sfr, intercept_mean=imean)
     if cont:
