@@ -124,7 +124,10 @@ def main():
                          "copied (side stream) and post-processed on the host; 1 = every step waits for its own results")
     ap.add_argument("--no-variants", action="store_true",
                     help="N = 1: skip the short extra timed regions on the other workload variants (s_j = 1, seeds 2 and 3)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of a 256-row sample of the step's own result")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1, default config: skip the short timed regions of the other BASELINE configs (C2, C4, C5), "
+                         "each in its own process, reported under \"configs\"")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of a 2048-row sample (+ the replaced rows) of the step's own result")
     ap.add_argument("--genes", type=int, default=0, help="override the config's gene count (tuning runs)")
     ap.add_argument("--samples", type=int, default=0, help="override the config's sample count (tuning runs)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second (weak-scaling) timed region")
@@ -377,12 +380,12 @@ def main():
     mc = parallel.concat_mcols(dds, [k for k in ("betaIter", "dispIter", "dispGeneIter") if k in dds[0].mcols])
     digest = result_digest(dds[0], world, comm_dev, parallel)
 
-    # parity where the driver can see it: a fixed 256-row sample of THIS step's result against the CPU oracle (the checker,
+    # parity where the driver can see it: a fixed 2048-row sample (+ every replaced row) of THIS step's result against the CPU oracle (the checker,
     # after the timed region, never the thing measured)
     parity = None
     if rank == 0 and not args.no_parity:
         try:
-            parity = parity_sample(dds[0], W, x, cfg, factors, reduced, rows=256)
+            parity = parity_sample(dds[0], W, x, cfg, factors, reduced, rows=2048)
         except Exception as e:                                       # noqa: BLE001
             parity = {"error": repr(e)}
 
@@ -447,14 +450,21 @@ def main():
         # HBM bytes / VALU instructions per launch from the PMC counters: collected in separate rocprofv3 --pmc
         # passes of this same command (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) and committed under
         # profiles/ -- counters cannot be read from inside the process.
-        traffic, valu, f64, pmc_file = None, None, None, None
-        for cand in ("r05_pmc_%s.json" % args.config, "r04_pmc_%s.json" % args.config, "r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
+        traffic, valu, f64, pmc_file, pmc_ok = None, None, None, None, None
+        lib_sha = library_sha256()
+        for cand in ("r06_pmc_%s.json" % args.config, "r05_pmc_%s.json" % args.config, "r04_pmc_%s.json" % args.config, "r03_pmc_%s.json" % args.config, "r02_pmc_%s.json" % args.config,
                      "r01_pmc.json" if args.config == "C3" else None):
             if cand and os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
                 break
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            # the counters were collected in separate rocprofv3 passes: they describe THIS run only if they were taken on
+            # the library that was just timed (tools/pmc_summary.py records its sha256); otherwise the counter-derived
+            # figures are withheld
+            pmc_ok = pmc.get("_library_sha256") == lib_sha
+            if not pmc_ok:
+                raise ValueError("PMC file of another library build")
             scale = nfull / pmc.get("_genes_per_launch", cfg["genes"])
             traffic = pmc[dom]["hbm_bytes_per_launch"] * scale
             insts = pmc[dom]["SQ_INSTS_VALU"] * scale
@@ -514,6 +524,7 @@ def main():
             "roofline": roofline,
             "valu_roofline": valu,
             "f64_roofline": f64,
+            "pmc_file": pmc_file, "pmc_matches_library": pmc_ok, "library_sha256": lib_sha,
             "kernels": kern,
             "kernels_outlier_refit": kern_refit,
             "mean_iterations": {k: float(np.nanmean(v)) for k, v in mc.items()},
@@ -536,6 +547,8 @@ def main():
         if hostpath_fused is not None:
             out["hostpath_fused_ms"] = hostpath_fused["ms"]
             out["hostpath_fused"] = hostpath_fused
+        if world == 1 and args.config == "C3" and not args.no_configs and not args.genes and not args.samples and not args.call_by_call:
+            out["configs"] = other_configs(out, args)
         if world == 1 and not args.no_cpu_baseline:
             k = args.cpu_sample_genes or {"C2": 8192, "C3": 4096, "C4": 768, "C4R": 768, "C5": 6144}[args.config]
             out["cpu_baseline"] = cpu_baseline(W["counts"], W["sf"], x, k, cfg, W["w"], factors, reduced)
@@ -545,56 +558,122 @@ def main():
         dist.destroy_process_group()
 
 
-def parity_sample(dds, W, x, cfg, factors, reduced, rows=256):
+def parity_sample(dds, W, x, cfg, factors, reduced, rows=2048):
     """A fixed sample of the rows of the step's OWN result, re-fitted by the CPU oracle (oracle/, the checker): the gene-wise
     dispersion search, the MAP search under the run's trend and prior variance, and the final IRLS + test -- every per-gene
     step of the chain (the all-gene steps, trend and prior variance, are taken from the run: they are not per-gene).  Rows
-    whose counts the outlier step replaced are left out of the sample (their columns come from the refit on the replaced
-    counts).  iter_equal: fraction of sampled rows whose three iteration counts are all equal; max_rel: largest relative
-    difference over the float columns (0.0 = bit-identical)."""
+    whose counts the outlier step replaced are IN the sample (every one of them, beside the random rows): they are re-fitted
+    on the run's replaced counts with the defaults refitWithoutOutliers uses (R/core.R:2509-2531), the trend taken at
+    their new means as the run did.  iter_equal: fraction of sampled rows whose three iteration counts are all equal;
+    max_rel: largest relative difference over the float columns (0.0 = bit-identical)."""
+    import torch
     from deseq2_amd import core
     from deseq2_amd.engine import HostEngine
     from oracle import oracle as O
+    O.set_threads(os.cpu_count() or 1)
     mc = dds.mcols
     n = W["counts"].shape[0]
     ok = ~np.asarray(mc["allZero"], bool)
+    rep = np.zeros(n, bool)
     if "replace" in mc:
-        ok &= ~(np.nan_to_num(np.asarray(mc["replace"], np.float64)) != 0)
-    cand = np.where(ok)[0]
+        rep = (np.nan_to_num(np.asarray(mc["replace"], np.float64)) != 0) & ok
+    cand = np.where(ok & ~rep)[0]
     pick = np.sort(np.random.Generator(np.random.PCG64(20260926)).choice(cand, min(rows, cand.size), replace=False))
-    w = None if W["w"] is None else W["w"][pick]
-    o = core.DESeqDataSet(W["counts"][pick], x, sizeFactors=W["sf"], weights=w, engine=HostEngine(O))
-    minmu = cfg.get("minmu", 0.5)
-    core.estimateDispersionsGeneEst(o, minmu=minmu)
+    rep_rows = np.where(rep)[0]
     fn = dict(dds.dispersionFunction)
-    o.dispersionFunction = fn
-    o.mcols["dispFit"] = np.asarray(mc["dispFit"])[pick]
-    core.estimateDispersionsMAP(o, dispPriorVar=fn["dispPriorVar"])
-    if cfg["test"] == "Wald":
-        kw = dict(minmu=minmu)
-        if cfg.get("betaPrior"):
-            kw.update(betaPrior=True, factors=factors, betaPriorVar=dds.attrs["betaPriorVar"])
-        core.nbinomWaldTest(o, **kw)
-        fcols = ["baseMean", "dispGeneEst", "dispMAP", "dispersion", "beta", "betaSE", "WaldStatistic"]
-    else:
-        core.nbinomLRT(o, reduced, minmu=minmu)
-        fcols = ["baseMean", "dispGeneEst", "dispMAP", "dispersion", "beta", "betaSE", "LRTStatistic"]
+    wald = cfg["test"] == "Wald"
+    fcols = ["baseMean", "dispGeneEst", "dispMAP", "dispersion", "beta", "betaSE", "WaldStatistic" if wald else "LRTStatistic"]
     icols = ["dispGeneIter", "dispIter", "betaIter"]
-    eq = np.ones(pick.size, bool)
-    for k in icols:
-        eq &= np.asarray(o.mcols[k], np.float64) == np.asarray(mc[k], np.float64)[pick]
-    max_rel, worst = 0.0, None
-    for k in fcols:
-        a, b = np.asarray(mc[k], np.float64)[pick], np.asarray(o.mcols[k], np.float64)
-        both = np.isfinite(a) & np.isfinite(b)
-        assert (np.isfinite(a) == np.isfinite(b)).all(), "NA pattern of %s differs" % k
-        if both.any():
-            r = float(np.max(np.abs(a[both] - b[both]) / np.maximum(np.abs(b[both]), 1e-300)))
-            if r > max_rel:
-                max_rel, worst = r, k
-    return {"rows": int(pick.size), "of_genes": int(n), "iter_equal": float(eq.mean()), "max_rel": max_rel, "worst_column": worst,
-            "columns": fcols + icols, "checker": "oracle/ (CPU restatement; pinned by the reference tests' known answers, tests/test_oracle_properties.py)",
-            "tolerance_north_star": 1e-6}
+
+    def refit(idx, counts, minmu, refit_defaults):
+        w = None if W["w"] is None else W["w"][idx]
+        o = core.DESeqDataSet(counts, x, sizeFactors=W["sf"], weights=w, engine=HostEngine(O))
+        core.estimateDispersionsGeneEst(o, minmu=minmu)
+        o.dispersionFunction = fn
+        o.mcols["dispFit"] = np.asarray(mc["dispFit"])[idx]
+        core.estimateDispersionsMAP(o, dispPriorVar=fn["dispPriorVar"])
+        if wald:
+            kw = {} if refit_defaults else dict(minmu=minmu)
+            if cfg.get("betaPrior"):
+                kw.update(betaPrior=True, factors=factors, betaPriorVar=dds.attrs["betaPriorVar"])
+            core.nbinomWaldTest(o, **kw)
+        else:
+            core.nbinomLRT(o, reduced, **({} if refit_defaults else dict(minmu=minmu)))
+        return o
+
+    def compare(o, idx):
+        eq = np.ones(idx.size, bool)
+        for k in icols:
+            eq &= np.asarray(o.mcols[k], np.float64) == np.asarray(mc[k], np.float64)[idx]
+        max_rel, worst = 0.0, None
+        for k in fcols:
+            a, b = np.asarray(mc[k], np.float64)[idx], np.asarray(o.mcols[k], np.float64)
+            both = np.isfinite(a) & np.isfinite(b)
+            assert (np.isfinite(a) == np.isfinite(b)).all(), "NA pattern of %s differs" % k
+            if both.any():
+                r = float(np.max(np.abs(a[both] - b[both]) / np.maximum(np.abs(b[both]), 1e-300)))
+                if r > max_rel:
+                    max_rel, worst = r, k
+        return eq, max_rel, worst
+
+    eq, max_rel, worst = compare(refit(pick, W["counts"][pick], cfg.get("minmu", 0.5), False), pick)
+    out = {"rows": int(pick.size), "of_genes": int(n)}
+    if rep_rows.size:
+        rc = dds.assays["replaceCounts"].view()[torch.as_tensor(rep_rows, device=dds.assays["replaceCounts"].t.device)]
+        eq_r, mr_r, worst_r = compare(refit(rep_rows, rc.cpu().numpy().astype(np.int32), 0.5, True), rep_rows)
+        out.update(rows=int(pick.size + rep_rows.size), replaced_rows=int(rep_rows.size), replaced_iter_equal=float(eq_r.mean()),
+                   replaced_max_rel=mr_r)
+        eq = np.r_[eq, eq_r]
+        if mr_r > max_rel:
+            max_rel, worst = mr_r, worst_r
+    else:
+        out["replaced_rows"] = 0
+    O.set_threads(1)
+    out.update({"iter_equal": float(eq.mean()), "max_rel": max_rel, "worst_column": worst, "columns": fcols + icols,
+                "checker": "oracle/ (CPU restatement; pinned by the reference tests' known answers, tests/test_oracle_properties.py)",
+                "tolerance_north_star": 1e-6})
+    return out
+
+
+def _config_row(j):
+    r = j.get("roofline") or {}
+    return {"name": j["config"]["name"], "workload": j["metric"], "genes": j["config"]["genes_total"], "samples": j["config"]["samples"],
+            "p": j["config"]["p"], "test": j["config"]["test"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
+            "one_call_at_a_time_ms": (j.get("one_call_at_a_time") or {}).get("ms_per_step"),
+            "genes_per_s": j["value"], "parity": j.get("parity"), "result_digest": j["result_digest"],
+            "dominant_kernel": r.get("kernel"), "dominant_kernel_ms": r.get("avg_launch_ms"), "hbm_frac": r.get("frac"),
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in (j.get("kernels") or {}).items() if v["avg_ms"] >= 0.05}}
+
+
+def other_configs(out, args):
+    """The other BASELINE configs where the driver sees them: C2, C4 and C5 (C3 is this line itself), each a short timed
+    region (4 steps, 1 warm-up) of the same bench in its OWN process -- the device is released in between -- with the same
+    2048-row oracle check.  A config that fails is reported with its error, never dropped."""
+    rows = [_config_row(out)]
+    for name in ("C2", "C4", "C5"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+               "--no-hostpath", "--no-variants", "--no-configs", "--seed", str(args.seed), "--size-factors", args.size_factors,
+               "--pipeline", str(args.pipeline)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                rows.append({"name": name, "error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-300:])})
+                continue
+            rows.append(_config_row(json.loads(line[-1])))
+        except Exception as e:                                       # noqa: BLE001
+            rows.append({"name": name, "error": repr(e)})
+    return rows
+
+
+def library_sha256():
+    import hashlib
+    from deseq2_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.SO_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def result_digest(dds, world, comm_dev, parallel):

@@ -67,6 +67,14 @@ def main(fetch_dir, write_dir, sq_dir, out):
     if len(sys.argv) > 5:
         res["_genes_per_launch"] = int(sys.argv[5])
         res["_note"] = sys.argv[6] if len(sys.argv) > 6 else ""
+    # which build of the library the passes ran on: bench.py uses the counters only for a library with this digest
+    import hashlib
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deseq2_amd", "libdeseq2_mi355x.so")
+    h = hashlib.sha256()
+    with open(so, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 22), b""):
+            h.update(blk)
+    res["_library_sha256"] = h.hexdigest()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
