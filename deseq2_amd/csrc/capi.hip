@@ -133,7 +133,11 @@ static void prof_end(hipStream_t st) { capi_prof_end(st); }
 // Keyed by (device, stream): calls issued on different streams (e.g. the chunks of a pipelined DESeq(),
 // deseq2_amd/parallel.py) must not share scratch, counters or staging buffers while both are in flight.
 // The stream of the current API call is latched at entry (WsScope, under g_mu).
-struct Slot { void *p = nullptr; size_t bytes = 0; };
+struct Slot {
+    void *p = nullptr; size_t bytes = 0;
+    std::vector<unsigned char> table;      // capi_upload_table: the bytes the slot holds (uploaded to `table_p`)
+    void *table_p = nullptr;
+};
 static constexpr int WS_SLOTS_MAX = DSQ_WS_COUNT;
 static std::map<hipStream_t, std::vector<Slot>> g_pool[64];
 static std::mutex g_pool_mu;      // the maps themselves (worker threads of a multi-device call look their slots up concurrently)
@@ -154,6 +158,7 @@ static int ws_get(int slot, size_t bytes, void **out) {
     plk.unlock();
     if (s.bytes < bytes) {
         if (s.p) { DSQ_HIP(hipDeviceSynchronize()); DSQ_HIP(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+        s.table_p = nullptr;               // (a new allocation may land on the old address: its bytes are not the table's)
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&s.p, want);
         if (e != hipSuccess) { s.p = nullptr; return fail(DSQ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
@@ -170,8 +175,54 @@ enum {  // workspace slots
     WS_H_Y, WS_H_X, WS_H_NF, WS_H_W, WS_H_MU, WS_H_VEC, WS_H_OUTMAT, WS_H_OUTMAT2, WS_H_OUTVEC,
     WS_COUNT
 };
-static_assert(WS_COUNT <= DSQ_WS_PIPE, "pipeline workspace slots follow the call slots");
+static_assert(WS_COUNT <= DSQ_WS_PIPE_PADXR, "pipeline workspace slots follow the call slots");
 int capi_ws_get(int slot, size_t bytes, void **out) { return ws_get(slot, bytes, out); }
+
+// Small host tables of an ASYNCHRONOUS call (the chain: design cells, outlier metadata).  Two things the plain
+// hipMemcpyAsync from a thread_local pageable buffer did not give: (1) the source may be rewritten as soon as this
+// returns -- the bytes travel through a ring of PINNED buffers, each fenced by an event recorded behind its copy (a
+// buffer is reused only when its copy has run), so nothing depends on how the runtime stages pageable copies; (2) the
+// tables of a design are the same analysis after analysis: a slot that already holds these bytes is not uploaded again
+// (one memcmp of a few KiB instead of a copy command in front of every chain).
+namespace {
+struct PinBuf { void *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+constexpr int kPinRing = 8;
+PinBuf g_pin[kPinRing];
+int g_pin_next = 0;
+std::mutex g_pin_mu;
+}
+int capi_upload_table(int slot, const void *src, size_t bytes, hipStream_t st, void **dev_out) {
+    void *v;
+    int rc = ws_get(slot, bytes, &v);
+    if (rc) return rc;
+    *dev_out = v;
+    int dev = 0;
+    DSQ_HIP(hipGetDevice(&dev));
+    Slot *sl;
+    {
+        std::unique_lock<std::mutex> plk(g_pool_mu);
+        sl = &g_pool[dev][g_ws_stream][slot];
+    }
+    if (sl->table_p == v && sl->table.size() == bytes && memcmp(sl->table.data(), src, bytes) == 0) return DSQ_OK;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    PinBuf &b = g_pin[g_pin_next];
+    g_pin_next = (g_pin_next + 1) % kPinRing;
+    if (b.used) DSQ_HIP(hipEventSynchronize(b.done));              // (eight uploads ago: long done)
+    if (b.cap < bytes) {
+        if (b.h) DSQ_HIP(hipHostFree(b.h));
+        b.h = nullptr; b.cap = 0;
+        DSQ_HIP(hipHostMalloc(&b.h, bytes + bytes / 2 + 256, hipHostMallocDefault));
+        b.cap = bytes + bytes / 2 + 256;
+    }
+    if (!b.done) DSQ_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    memcpy(b.h, src, bytes);
+    DSQ_HIP(hipMemcpyAsync(v, b.h, bytes, hipMemcpyHostToDevice, st));
+    DSQ_HIP(hipEventRecord(b.done, st));
+    b.used = true;
+    sl->table.assign((const unsigned char *)src, (const unsigned char *)src + bytes);
+    sl->table_p = v;
+    return DSQ_OK;
+}
 
 static inline long round_ld(int m) { return ((long)m + 7) & ~7L; }
 
@@ -354,8 +405,7 @@ int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, co
     std::vector<int> fill(start, start + C);
     for (int j = 0; j < m; j++) perm[fill[cell[j]]++] = j;
     void *v;
-    if (ws_get(slot, buf.size() * sizeof(int32_t), &v)) return 0;
-    if (hipMemcpyAsync(v, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    if (capi_upload_table(slot, buf.data(), buf.size() * sizeof(int32_t), st, &v)) return 0;
     *start_dev = (const int32_t *)v;
     *perm_dev = (const int32_t *)v + C + 1;
     return C;

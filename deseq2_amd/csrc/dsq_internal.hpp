@@ -268,6 +268,7 @@ int device_cu_count();
 
 // ---- shared by capi.hip and pipeline.hip (the fused DESeq() chain) ------------------------------------------
 int capi_fail(int code, const char *fmt, ...);
+int capi_upload_table(int slot, const void *src, size_t bytes, hipStream_t st, void **dev_out);   // small host table -> slot (pinned ring, skipped when unchanged)
 int capi_ws_get(int slot, size_t bytes, void **out);             // grow-only workspace of the current (device, stream)
 int capi_check_device();
 int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, const int32_t **perm_dev,
@@ -294,6 +295,9 @@ int stage_d2h(void *host, const void *dev, size_t e, size_t n_total, size_t lo, 
 void stage_prefault(void *host, size_t bytes);
 void stage_prefault_finish();
 struct PrefaultScope { ~PrefaultScope() { stage_prefault_finish(); } };
+// (three slots between the call slots of capi.hip and the chain's: the padded reduced / prior design, the padded design, the
+//  prior-variance selection workspace)
+enum { DSQ_WS_PIPE_PADXR = 37, DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };
 enum { DSQ_WS_PIPE = 40, DSQ_WS_PIPE_SCRATCH = 41, DSQ_WS_PIPE_META = 42, DSQ_WS_HOSTDESEQ = 48, DSQ_WS_COUNT = 72 };
 
 }  // namespace dsq

@@ -780,6 +780,61 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
     }
 }
 
+// ---- longest-expected-first order of a full-size fit launch ---------------------------------------------------------
+// The persistent fit kernels hand out genes in list order through a counter.  With many genes per wave slot the order does
+// not matter (measured at 50 000 genes: 2 %); at one rank's share of an 8-GPU run (6 250 genes on 3 072 wave slots, two genes
+// per slot) a launch ends when the last slot has worked off its two genes, and two slow genes that meet in one slot set the
+// time: fit_beta 0.30 ms against 0.16 ms for an eighth of the 50 000-gene launch.  The second fit of a gene costs about what
+// its first one did (the test's IRLS after the gene-wise IRLS: same counts, nearly the same dispersion), so the rows are
+// listed by DESCENDING iteration count of the first fit: the slow genes start first, the quick ones fill the gaps
+// (longest-processing-time-first).  A counting sort by one workgroup; the order inside a bin is whatever the atomics give --
+// every gene's results are written at its own position and no kernel couples two genes, so the order changes no bit.
+__global__ void __launch_bounds__(1024) lpt_order_kernel(Rows rw, const int32_t *key_i, const double *key_d, int32_t *out) {
+    __shared__ int hist[128], cursor[128];
+    const int cnt = rows_count(rw);
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto key_of = [&](int g) {
+        double kd = key_i ? (double)key_i[g] : key_d[g];
+        if (!(kd >= 0.0)) kd = 127.0;             // (NaN: an aborted fit -- treat as long)
+        return kd > 127.0 ? 127 : (int)kd;
+    };
+    for (int i = threadIdx.x; i < cnt; i += 1024) atomicAdd(&hist[key_of(rows_gene(rw, i))], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 127; k >= 0; k--) { cursor[k] = acc; acc += hist[k]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 1024) {
+        const int g = rows_gene(rw, i);
+        out[atomicAdd(&cursor[key_of(g)], 1)] = g;
+    }
+}
+
+// ---- the fills in front of a call's first kernel, as ONE launch ----------------------------------------------------
+// A chain used to open with a dozen memset / copy commands (the NA patterns of the result columns, the status block, the
+// dynamic-scheduling counters, the ridge / contrast block): ~ 5 us of dependent dispatch each -- 0.11 ms of a 2.7 ms step
+// at one rank's share of C3.  The segments (4-byte aligned, word patterns) and the small block (by value) ride in the
+// kernel's arguments: no host buffer is read after the launch returns.
+struct InitSeg { uint32_t *p; uint32_t words; uint32_t val; };
+struct InitParams {
+    int nseg;
+    InitSeg seg[24];
+    double *blk_dst;
+    int nblk;
+    double blk[3 * DSQ_P_WIDE + 8];
+};
+__global__ void __launch_bounds__(256) chain_init_kernel(InitParams q) {
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int s = 0; s < q.nseg; s++) {
+        uint32_t *p = q.seg[s].p;
+        const uint32_t v = q.seg[s].val, w = q.seg[s].words;
+        for (uint32_t i = tid; i < w; i += nth) p[i] = v;
+    }
+    if (tid < (unsigned)q.nblk) q.blk_dst[tid] = q.blk[tid];
+}
+
 // ---- orchestration -----------------------------------------------------------------------------------------------
 #define PIPE_HIP(expr)                                                                                   \
     do {                                                                                                 \
@@ -789,7 +844,6 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
                              hipGetErrorString(e_));                                                     \
     } while (0)
 
-enum { DSQ_WS_PIPE_PADXR = 37, DSQ_WS_PIPE_PADX = 38, DSQ_WS_PIPE_SEL = 39 };      // (a free slot between the call slots and the chain's: the padded design)
 static inline int kern_width(int p) { return p > DSQ_P_REG ? dsq_wide_width(p) : p; }
 
 struct Pipe {
@@ -807,6 +861,7 @@ struct Pipe {
     double *opt_start, *opt_beta, *opt_se, *opt_ll;
     int32_t *iter, *iter_accept, *grid_flag, *rows_nz, *rows_grid, *rows_rep, *rows_refit, *counters, *work_counters;
     int32_t *rows_opt, *opt_conv;
+    int32_t *rows_lpt;             // the non-zero rows in longest-expected-first order (lpt_order_kernel)
     double *lam_prior;             // betaPrior: 1 / betaPriorVar on the natural-log scale (device copy of a->lambda_prior)
     // WIDE designs (10 < p <= 48): the fit kernels run at the padded width pk = 16 / 24 / 32 / 48 on the design zero-padded to pk
     // columns (ridge 1, start value 0, contrast 0 on the padding: the real coefficients keep their bits, csrc/capi.hip
@@ -929,7 +984,7 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.kconst_out = P.kconst;            // K' of the rows this launch fits: the nbinomLogLike launch behind it reads it
     kp.scratch = P.scratch; kp.cscratch = P.cscratch;
     kp.work_counter = next_work_counter(P);
-    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
+    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz && rw.rows != P.rows_lpt) ? 1 : 0;
     kp.cell_perm = ds.cperm; kp.cell_start = ds.cstart; kp.ncell = ds.ncell;
     bool ok = false;
     char nm[32];
@@ -957,7 +1012,7 @@ static int launch_fit_disp(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.weightThreshold = a->weightThreshold; kp.maxit = a->maxit;
     kp.usePrior = usePrior ? 1 : 0; kp.useCR = useCR ? 1 : 0;
     kp.work_counter = next_work_counter(P);
-    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz) ? 1 : 0;
+    kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz && rw.rows != P.rows_lpt) ? 1 : 0;
     if (P.p >= tuning().disp_cell_minp) { kp.cell_perm = P.cell_perm; kp.cell_start = P.cell_start; kp.ncell = P.ncell; }
     if (grid) {
         kp.grid = a->disp_grid; kp.ngrid = a->ngrid; kp.log_alpha = P.la_grid;
@@ -1088,11 +1143,23 @@ static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, i
     return DSQ_OK;
 }
 
+// the rows of a full-size launch in longest-expected-first order (see lpt_order_kernel); DSQ_LPT=0 switches it off
+static Rows lpt_rows(Pipe &P, const Rows &rw, const int32_t *key_i, const double *key_d) {
+    // only where it pays: below ~ 5 genes per resident wave slot (measured, C3 shapes: 6 250 genes fit_beta 0.305 -> 0.256 ms;
+    // 50 000 genes: the launch gains 0.03 ms and the one-workgroup sort in front of it costs 0.1)
+    static const bool on = !(getenv("DSQ_LPT") && atoi(getenv("DSQ_LPT")) == 0);
+    if (!on || rw.rows != P.rows_nz || P.n > 16384) return rw;
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, P.st, rw, key_i, key_d, P.rows_lpt);
+    return Rows{P.rows_lpt, rw.n_dev, rw.n};
+}
+
 // estimateDispersionsMAP (R/core.R:943-1131) on the rows `rw`
 static int map_est(Pipe &P, const Rows &rw, const int32_t *y, const double *mu_hat, int cnt_grid) {
     const DsqDeseqArgs *a = P.a;
     RuleParams q = rule_params(P, rw);
     hipLaunchKernelGGL(map_init_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
+    // (no longest-first order here: the gene-wise search's iteration count does not predict the MAP search's -- other start
+    //  value, the prior --; measured at 6 250 genes: 0.435 ms either way)
     int rc = launch_fit_disp(P, rw, y, mu_hat, P.la_init, P.log_dfit, true, a->weights_norm, a->useCR != 0, false, "fit_disp");
     if (rc) return rc;
     q.grid_count = P.counters + cnt_grid;
@@ -1219,8 +1286,9 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     const DsqDeseqArgs *a = P.a;
     const DsqDeseqOut *o = P.o;
     if (a->betaPrior) return mle_fit(P, rw, y, mu_out, hat);         // (the prior fit follows once lambda is known)
-    int rc = launch_fit_beta(P, rw, y, o->dispersion, a->weights_norm, mu_out, 0.0, hat, P.t_tol, P.t_maxit, P.t_useQR,
-                             P.t_minmu, "fit_beta");
+    // (P.beta_iter: the iteration counts of the gene-wise estimate's IRLS on the same rows, when that fit ran)
+    int rc = launch_fit_beta(P, a->linearMu ? rw : lpt_rows(P, rw, nullptr, P.beta_iter), y, o->dispersion, a->weights_norm, mu_out, 0.0, hat,
+                             P.t_tol, P.t_maxit, P.t_useQR, P.t_minmu, "fit_beta");
     if (rc) return rc;
     LogLikeKernelParams lk;
     memset(&lk, 0, sizeof lk);
@@ -1319,7 +1387,7 @@ struct OutlierMeta {
     int maxcell, any3, all_rep;
 };
 static int outlier_meta(const DsqDeseqArgs *a, int m, hipStream_t st, OutlierMeta *M) {
-    static thread_local std::vector<int32_t> meta;   // (staged by the copy below)
+    static thread_local std::vector<int32_t> meta;   // (capi_upload_table takes its own copy)
     meta.assign((size_t)4 * m + a->ncell + 1, 0);
     int32_t *perm = meta.data(), *in3 = perm + m, *repl = in3 + m, *use3 = repl + m, *start = use3 + m;
     for (int j = 0; j < m; j++) {
@@ -1345,9 +1413,8 @@ static int outlier_meta(const DsqDeseqArgs *a, int m, hipStream_t st, OutlierMet
         if (!repl[j]) all_rep = 0;
     }
     void *mv;
-    int rc = capi_ws_get(DSQ_WS_PIPE_META + 1, meta.size() * sizeof(int32_t) + 64, &mv);
+    int rc = capi_upload_table(DSQ_WS_PIPE_META + 1, meta.data(), meta.size() * sizeof(int32_t), st, &mv);
     if (rc) return rc;
-    PIPE_HIP(hipMemcpyAsync(mv, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     M->dperm = (int32_t *)mv; M->din3 = M->dperm + m; M->drepl = M->din3 + m; M->duse3 = M->drepl + m; M->dstart = M->duse3 + m;
     M->maxcell = maxcell; M->any3 = any3; M->all_rep = all_rep;
     return DSQ_OK;
@@ -1378,7 +1445,7 @@ static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 struct Carve {
     size_t o_rough, o_binit, o_ainit, o_la0, o_laout, o_lchg, o_ilp, o_idlp, o_llp, o_ldlp, o_lagrid, o_ldfit, o_lainit,
         o_bnat, o_bvar, o_biter, o_cnum, o_cden, o_dev, o_lam, o_res, o_tm, o_td, o_robust, o_ostart, o_obeta, o_ose, o_oll, o_rbinit, o_rbeta, o_rse, o_kc, dbl;
-    size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, i_opt, i_oconv, ints;
+    size_t i_iter, i_itacc, i_gflag, i_nz, i_grid, i_rep, i_refit, i_cnt, i_wc, i_opt, i_oconv, i_lpt, ints;
     size_t bytes;
 };
 
@@ -1401,6 +1468,7 @@ static Carve carve(int n, int p, int nt) {
     c.i_iter = takeI(nd); c.i_itacc = takeI(nd); c.i_gflag = takeI(nd); c.i_nz = takeI(nd); c.i_grid = takeI(nd);
     c.i_rep = takeI(nd); c.i_refit = takeI(nd); c.i_cnt = takeI(16); c.i_wc = takeI(64);
     c.i_opt = takeI(nd); c.i_oconv = takeI(nd);
+    c.i_lpt = takeI(nd);
     c.ints = i;
     c.bytes = d * sizeof(double) + i * sizeof(int32_t) + 256;
     return c;
@@ -1493,6 +1561,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     P.work_counters = I + cv.i_wc;
     P.opt_start = D + cv.o_ostart; P.opt_beta = D + cv.o_obeta; P.opt_se = D + cv.o_ose; P.opt_ll = D + cv.o_oll;
     P.rows_opt = I + cv.i_opt; P.opt_conv = I + cv.i_oconv;
+    P.rows_lpt = I + cv.i_lpt;
     P.red_binit = D + cv.o_rbinit; P.red_beta = D + cv.o_rbeta; P.red_se = D + cv.o_rse;
     P.kconst = D + cv.o_kc;
     {
@@ -1509,17 +1578,56 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (rc) return rc;
         P.scratch = (double *)b; P.cscratch = (double *)b + slab_d;
     }
-    // dynamic-scheduling counters of the fit launches of THIS call; the row-list counters of the phases it runs
-    PIPE_HIP(hipMemsetAsync(P.work_counters, 0, 64 * sizeof(int32_t), st));
-    {   // the ridge (R/fitNbinomGLMs.R:73,162) and the default contrast (R/wrappers.R:105-108)
-        static thread_local double host[3 * DSQ_P_WIDE + 8];   // (pageable copies are staged at once)
-        for (int c = 0; c < pmax; c++) {
-            host[c] = c < p ? a->lambda[c] : (c < pk ? 1.0 : 0.0);          // (ridge 1 on the padding of a wide design)
-            host[pmax + c] = (c == 0) ? 1.0 : 0.0;
-            host[2 * pmax + c] = (a->betaPrior && a->lambda_prior) ? (c < a->p_prior ? a->lambda_prior[c] : (c < pkp ? 1.0 : 0.0)) : 0.0;
-            if (a->x_red) host[2 * pmax + c] = c < a->p_red ? a->lambda[c] : (c < kern_width(a->p_red) ? 1.0 : 0.0);
+    // ONE launch for every fill this call needs in front of its first kernel (chain_init_kernel): the dynamic-scheduling
+    // counters of the fit launches of THIS call, the ridge (R/fitNbinomGLMs.R:73,162) / default contrast (R/wrappers.R:105-108)
+    // / prior block, and -- gene-wise phase -- the NA patterns of the result columns and the status block
+    static thread_local InitParams ip;
+    ip.nseg = 0; ip.nblk = 0;
+    auto fill_words = [&](void *p_, size_t bytes, uint32_t val) {
+        if (!p_ || !bytes) return;
+        // neighbouring regions with the same pattern are one segment
+        if (ip.nseg && ip.seg[ip.nseg - 1].val == val && (char *)ip.seg[ip.nseg - 1].p + 4 * (size_t)ip.seg[ip.nseg - 1].words == (char *)p_ &&
+            (size_t)ip.seg[ip.nseg - 1].words + bytes / 4 < 0xFFFFFFFFull) { ip.seg[ip.nseg - 1].words += (uint32_t)(bytes / 4); return; }
+        ip.seg[ip.nseg++] = {(uint32_t *)p_, (uint32_t)(bytes / 4), val};
+    };
+    fill_words(P.work_counters, 64 * sizeof(int32_t), 0u);
+    for (int c = 0; c < pmax; c++) {
+        ip.blk[c] = c < p ? a->lambda[c] : (c < pk ? 1.0 : 0.0);          // (ridge 1 on the padding of a wide design)
+        ip.blk[pmax + c] = (c == 0) ? 1.0 : 0.0;
+        ip.blk[2 * pmax + c] = (a->betaPrior && a->lambda_prior) ? (c < a->p_prior ? a->lambda_prior[c] : (c < pkp ? 1.0 : 0.0)) : 0.0;
+        if (a->x_red) ip.blk[2 * pmax + c] = c < a->p_red ? a->lambda[c] : (c < kern_width(a->p_red) ? 1.0 : 0.0);
+    }
+    ip.blk_dst = P.lam; ip.nblk = 3 * pmax;
+    const bool with_gene_est = (a->phases & DSQ_PH_GENE_EST) != 0;
+    if (with_gene_est) {
+        // results of rows that turn out all-zero stay NA: 0xFF bytes are a NaN / -1.  The outputs of a caller usually sit
+        // side by side (packed blocks): sorted by address, neighbours with the same pattern merge
+        struct Fill { char *p; size_t bytes; uint32_t val; };
+        std::vector<Fill> fills;
+        auto fill = [&](void *p_, size_t bytes, uint32_t val) { if (p_ && bytes) fills.push_back({(char *)p_, bytes, val}); };
+        fill(o->status, DSQ_ST_COUNT * sizeof(int32_t), 0u);
+        for (double *v : {o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter, o->logLike, o->maxCooks, o->logLikeReduced})
+            fill(v, (size_t)n * sizeof(double), 0xFFFFFFFFu);
+        for (double *v : {o->beta, o->betaSE, o->stat, o->pvalue})
+            fill(v, (size_t)n * (a->betaPrior ? a->p_prior : p) * sizeof(double), 0xFFFFFFFFu);
+        if (a->betaPrior) fill(o->mle_beta, (size_t)n * p * sizeof(double), 0xFFFFFFFFu);
+        for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv}) fill(v, (size_t)n * sizeof(int32_t), 0xFFFFFFFFu);
+        for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag}) fill(v, (size_t)n * sizeof(int32_t), 0u);
+        std::sort(fills.begin(), fills.end(), [](const Fill &x, const Fill &y) { return x.p < y.p; });
+        for (const Fill &f : fills) {
+            if (ip.nseg >= 23) return capi_fail(DSQ_ERR_ARG, "dsq_deseq_dev: the result columns lie in more than 23 separate regions");
+            fill_words(f.p, f.bytes, f.val);
         }
-        PIPE_HIP(hipMemcpyAsync(P.lam, host, 3 * (size_t)pmax * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (a->phases & DSQ_PH_TREND) fill_words(o->scalars + DSQ_SC_FIT_USED, sizeof(double), 0u);     // 0.0 = DSQ_FIT_PARAMETRIC
+    {
+        size_t words = 0;
+        for (int sgi = 0; sgi < ip.nseg; sgi++) words += ip.seg[sgi].words;
+        unsigned blocks = (unsigned)((words + 256 * 8 - 1) / (256 * 8));
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(chain_init_kernel, dim3(blocks), dim3(256), 0, st, ip);
+        PIPE_HIP(hipGetLastError());
     }
     P.x_k = a->x; P.padmask = 0;
     if (pk > p) {
@@ -1571,26 +1679,6 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
 
     // ================================================================ gene-wise estimates
     if (a->phases & DSQ_PH_GENE_EST) {
-        // results of rows that turn out all-zero stay NA: 0xFF bytes are a NaN / -1.  The outputs of a caller usually sit
-        // side by side (packed blocks): neighbouring regions with the same fill byte are set by ONE memset
-        struct Fill { char *p; size_t bytes; int val; };
-        std::vector<Fill> fills;
-        auto fill = [&](void *p_, size_t bytes, int val) { if (p_ && bytes) fills.push_back({(char *)p_, bytes, val}); };
-        fill(o->status, DSQ_ST_COUNT * sizeof(int32_t), 0);
-        for (double *v : {o->dispGeneEst, o->dispFit, o->dispMAP, o->dispersion, o->betaIter, o->logLike, o->maxCooks, o->logLikeReduced})
-            fill(v, (size_t)n * sizeof(double), 0xFF);
-        for (double *v : {o->beta, o->betaSE, o->stat, o->pvalue})
-            fill(v, (size_t)n * (a->betaPrior ? a->p_prior : p) * sizeof(double), 0xFF);
-        if (a->betaPrior) fill(o->mle_beta, (size_t)n * p * sizeof(double), 0xFF);
-        for (int32_t *v : {o->dispGeneIter, o->dispIter, o->dispOutlier, o->betaConv}) fill(v, (size_t)n * sizeof(int32_t), 0xFF);
-        for (int32_t *v : {o->replace, o->optim_geneest, o->optim_test, P.grid_flag}) fill(v, (size_t)n * sizeof(int32_t), 0);
-        std::sort(fills.begin(), fills.end(), [](const Fill &x, const Fill &y) { return x.p < y.p; });
-        for (size_t i = 0; i < fills.size();) {
-            size_t j = i + 1, bytes = fills[i].bytes;
-            while (j < fills.size() && fills[j].val == fills[i].val && fills[j].p == fills[i].p + bytes) bytes += fills[j++].bytes;
-            PIPE_HIP(hipMemsetAsync(fills[i].p, fills[i].val, bytes, st));
-            i = j;
-        }
         const Rows all = {nullptr, nullptr, n};
         rc = launch_prefit_rows(P, all, a->y);                                   // getBaseMeansAndVariances + moments
         if (rc) return rc;
@@ -1613,7 +1701,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         const double *tm = a->trend_mean ? a->trend_mean : o->baseMean;
         const double *td = a->trend_mean ? a->trend_disp : o->dispGeneEst;
         const int nt = a->trend_mean ? a->n_trend : n;
-        PIPE_HIP(hipMemsetAsync(P.counters + CNT_TREND, 0, sizeof(int32_t), st));
+        if (!with_gene_est) PIPE_HIP(hipMemsetAsync(P.counters + CNT_TREND, 0, sizeof(int32_t), st));      // (else: the status fill)
         hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, 1, nt, (int32_t *)nullptr, (const int32_t *)nullptr,
                            tm, td, 100.0 * a->minDisp, (int32_t *)nullptr, P.trend_mean_c, P.trend_disp_c,
                            P.counters + CNT_TREND);
@@ -1621,7 +1709,6 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         rc = capi_ws_get(DSQ_WS_PIPE_META, trend_fit_workspace_bytes() + 64, &tws);
         if (rc) return rc;
         capi_prof_begin("trend_fit", nt, st);
-        PIPE_HIP(hipMemsetAsync(o->scalars + DSQ_SC_FIT_USED, 0, sizeof(double), st));               // 0.0 = DSQ_FIT_PARAMETRIC
         if (a->dispFit_in) {
             // the caller's trend (fitType "local" evaluated by R, dispersionFunction<-): nothing to fit; the coefficients are NA
             hipLaunchKernelGGL(trend_given_kernel, dim3(1), dim3(1), 0, st, o->scalars, o->status);
@@ -1654,9 +1741,11 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
     }
     // ================================================================ MAP dispersions + test
     if (a->phases & DSQ_PH_MAP_TEST) {
-        PIPE_HIP(hipMemsetAsync(P.counters + CNT_GRID2, 0, sizeof(int32_t), st));
-        PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT2, 0, sizeof(int32_t), st));
-        PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT3, 0, sizeof(int32_t), st));
+        if (!with_gene_est) {            // (else still zero from the status fill: nothing in between counts into them)
+            PIPE_HIP(hipMemsetAsync(P.counters + CNT_GRID2, 0, sizeof(int32_t), st));
+            PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT2, 0, sizeof(int32_t), st));
+            PIPE_HIP(hipMemsetAsync(P.counters + CNT_OPT3, 0, sizeof(int32_t), st));
+        }
         rc = map_est(P, nz, a->y, o->mu_hat, CNT_GRID2);
         if (rc) return rc;
         rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
