@@ -288,16 +288,19 @@ def main():
                 wd, prev = prev, cur
             else:
                 wd = step()
-        if prev is not None:
-            fused.finish(prev[0])
-        prev = cur = wd = None
+        # depth 2: the pipeline is NOT drained between the warm-up and the timed steps -- the last warm-up analysis stays in
+        # flight (its chain is complete at the barrier below, its host half is the first thing the timed region does, an
+        # extra it pays for) and the one before it stays alive until the first timed step releases it, as every later
+        # step does.  Draining here handed the caching allocator a different free list than the steady state's: one
+        # hipMalloc inside every timed region, whatever the number of warm-up steps (round 5's
+        # driver_allocs_in_timed_region.device = 1), and a first timed step that finished nothing (step_ms.min 0.45 ms).
+        dds = wd
+        cur = wd = None
         a0 = alloc_counters()
         barrier()
         marks = []
         t0 = time.perf_counter()
-        dds = None
         held = []
-        prev = None
         for k in range(args.steps):
             if args.hold_results:
                 held.append(dds)
@@ -550,7 +553,7 @@ def main():
         if world == 1 and args.config == "C3" and not args.no_configs and not args.genes and not args.samples and not args.call_by_call:
             out["configs"] = other_configs(out, args)
         if world == 1 and not args.no_cpu_baseline:
-            k = args.cpu_sample_genes or {"C2": 8192, "C3": 4096, "C4": 768, "C4R": 768, "C5": 6144}[args.config]
+            k = args.cpu_sample_genes or {"C2": 20000, "C3": 16384, "C4": 2048, "C4R": 2048, "C5": 16384}[args.config]   # (10-30 s of one core)
             out["cpu_baseline"] = cpu_baseline(W["counts"], W["sf"], x, k, cfg, W["w"], factors, reduced)
         print(json.dumps(out))
     if world > 1:
@@ -647,11 +650,11 @@ def _config_row(j):
 
 def other_configs(out, args):
     """The other BASELINE configs where the driver sees them: C2, C4 and C5 (C3 is this line itself), each a short timed
-    region (4 steps, 1 warm-up) of the same bench in its OWN process -- the device is released in between -- with the same
+    region (5 steps, 3 warm-up steps) of the same bench in its OWN process -- the device is released in between -- with the same
     2048-row oracle check.  A config that fails is reported with its error, never dropped."""
     rows = [_config_row(out)]
     for name in ("C2", "C4", "C5"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "5", "--warmup", "3", "--no-cpu-baseline",
                "--no-hostpath", "--no-variants", "--no-configs", "--seed", str(args.seed), "--size-factors", args.size_factors,
                "--pipeline", str(args.pipeline)]
         try:
@@ -809,12 +812,12 @@ def cpu_baseline(counts, sf, x, k, cfg, weights, factors, reduced):
     if cfg.get("minmu"):
         kw.update(minmu=cfg["minmu"])
 
-    # the all-core legs take a larger sample (8 x): with a few thousand genes on a few hundred workers the time is the
+    # the all-core legs take a larger sample (4 x, up to the whole matrix): with a few thousand genes on a few hundred workers the time is the
     # worker start-up, not the fits
-    sub_all = counts[: 8 * k]
+    sub_all = counts[: 4 * k]
     keep_all = sub_all.sum(axis=1) > 0
     sub_all = sub_all[keep_all]
-    w_all = None if weights is None else weights[: 8 * k][keep_all]
+    w_all = None if weights is None else weights[: 4 * k][keep_all]
 
     def run(fns, big=False):
         yy, ww = (sub_all, w_all) if big else (sub, w)

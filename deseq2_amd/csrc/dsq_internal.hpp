@@ -275,6 +275,9 @@ int capi_upload_cells(const int32_t *labels, int m, int slot, hipStream_t st, co
                       const int32_t **start_dev);
 std::mutex &capi_mutex();                                        // the library's call lock
 void capi_latch_stream(hipStream_t s);                           // workspace key of the current call (under the lock)
+// the rolled kernel of the wide designs without design cells (fit_beta_wide.hip): any kp.p in 11 .. 64
+hipError_t launch_fit_beta_rolled(const BetaKernelParams &kp, hipStream_t st);
+void fit_beta_rolled_scratch_doubles(int n, int m, int p, int useW, size_t *slab, size_t *cscr);
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok);
 void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr);
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok);

@@ -1,0 +1,556 @@
+// fit_beta_wide.hip -- fitBeta (src/DESeq2.cpp:283-465) for designs of 11 .. 64 columns that do not collapse to design
+// cells (paired designs such as ~ patient + treatment, many continuous covariates): ONE kernel for every width, all
+// loops over the design columns ROLLED, one wavefront per gene.
+//
+// Why another kernel: the per-width general kernel (fit_beta.hip) is compiled once per padded width (16, 24, 32, 48) with
+// its Householder stages fully unrolled; at those widths its wave-uniform p x p state sits in an LDS arena of 5 p^2 + 12 p
+// doubles (41 KB at p = 32, 92 KB at p = 48) next to the stored rows -- one or two waves per CU --, the two widest builds
+// compile for minutes at -O1, and a paired design of 31 columns cost 259 ms per 20 000 genes (profiles/r05_wide.txt).
+// Here the reflected rows [sqrt(w) X ; sqrt(ridge) | sqrt(w) z] and the p x p matrices of the post-loop block live in a
+// per-wave slab of GLOBAL memory (coalesced: lane l owns rows l, l + 64, ... of a column-major matrix, or column l of a
+// row-major p x p matrix), the LDS holds only a handful of p-vectors, and the register footprint is that of a chunk of
+// eight column sums: the occupancy is the register file's, whatever p is.
+//
+// THE ARITHMETIC IS THAT OF fit_beta_kernel (stored-row Householder QR in LAPACK dgeqr2 order, Gram sums in wave order,
+// LU with partial pivoting / first maximum / reciprocal pivots, the closed split of the deviance): the same operations on
+// the same values in the same order, so the results keep the oracle's bits (tests/test_gpu_wide.py).  What changes is
+// the loop nest: a sum over the samples is still 64 per-lane partials over the trips in order + the xor butterfly, but the
+// sums of a Householder stage are taken eight columns at a time (each sum's additions do not depend on its neighbours').
+#include "dsq_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include "dsq_math.hpp"
+#include "dsq_wave.hpp"
+#include "fit_beta_common.hpp"
+
+namespace dsq {
+
+// per-wave slab in global memory (doubles): the four per-sample vectors, then the larger of
+//   IRLS      the (m + p) x (p + 1) rows (column c of row i at qa[c M + i]) and R (p x p)
+//   post-loop G, LU (then T), Gi, Sigma (p x p each, row-major)
+__host__ __device__ static inline size_t wide_slab_doubles(int m, int p) {
+    const size_t M = (size_t)m + p;
+    const size_t irls = M * (p + 1) + (size_t)p * p, post = (size_t)4 * p * p;
+    return (size_t)4 * m + (irls > post ? irls : post) + 8;
+}
+// per-wave LDS (doubles): lambda, contrast, beta, beta_prev, gamma, rdiag, rhs / rr (p each), tprev, accs (p + 1 each), piv (p ints)
+__host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_t)10 * p + 16; }
+
+// orders every lane's earlier slab stores before the loads that follow (cross-lane exchange through the wave's slab)
+template <bool BIG_LDS>
+DSQ_DEV void wave_slab_sync_t() {
+    if constexpr (BIG_LDS) wave_lds_sync();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+constexpr int kChunk = 8;     // column sums reduced together (wave_allreduce_many: the bits of one butterfly each)
+template <int V> struct IntTag { static constexpr int value = V; };
+
+// BIG_LDS: the wave's slab (rows, matrices, per-sample vectors) in LDS instead of global memory -- taken when at least one
+// wave per SIMD pair still fits the CU's 160 KB (see wide_geometry): a Householder stage is a chain of dependent round
+// trips through the slab (rows -> column sums -> pivot row -> reflector), ~ 100 ns each in LDS against 1-3 us through L2 /
+// the infinity cache; in global memory the only cover is occupancy (128 registers: four waves per SIMD).
+template <bool USE_W, bool BIG_LDS>
+__global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel(BetaKernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int m = kp.m, P = kp.p;
+    const int M = m + P;
+    const int nwork = DSQ_NWORK(kp);
+    if (blockIdx.x * waves >= nwork) return;
+
+    auto wave_slab_sync = [] { wave_slab_sync_t<BIG_LDS>(); };
+    const double *xs = kp.x;
+    double *lv = smem + (size_t)wave * wide_lds_doubles(P);
+    double *lambda = lv, *contrast = lv + P, *beta = lv + 2 * P, *beta_prev = lv + 3 * P, *gamma = lv + 4 * P, *rdiag = lv + 5 * P,
+           *rhs = lv + 6 * P, *tprev = lv + 7 * P, *accs = lv + 8 * P + 1;
+    int *piv = reinterpret_cast<int *>(lv + 9 * P + 2);
+    double *slab;
+    if constexpr (BIG_LDS) slab = smem + (size_t)waves * wide_lds_doubles(P) + (size_t)wave * wide_slab_doubles(m, P);
+    else slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * wide_slab_doubles(m, P);
+    double *mu_s = slab, *lg_s = slab + m, *sw_s = slab + 2 * (size_t)m, *w_s = slab + 3 * (size_t)m;
+    double *big = slab + 4 * (size_t)m;
+    double *qa = big, *qR = big + (size_t)M * (P + 1);                         // IRLS
+    double *G = big, *LUm = big + (size_t)P * P, *Gi = big + 2 * (size_t)P * P, *Sg = big + 3 * (size_t)P * P;   // post-loop
+    double *Tm = LUm;                                                         // (LU is dead once Gi exists)
+
+    for (int c = lane; c < P; c += 64) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
+    wave_lds_sync();
+    const double large = 30.0;
+
+    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+        const int g = DSQ_GENE(kp, wi);
+        const int32_t *yg = kp.y + (size_t)g * kp.ld;
+        const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
+        const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+        const double alpha = kp.alpha_hat[g];
+        const double size = 1.0 / alpha;
+
+        wave_lds_sync();
+        for (int c = lane; c < P; c += 64) { const double b = kp.beta_init[(size_t)g + (size_t)kp.n * c]; beta[c] = b; beta_prev[c] = b; }
+        wave_lds_sync();
+
+        // mu_hat = nfrow % exp(x * beta_hat), clamped at minmu            (:324-327, :361-364)
+        auto update_mu = [&]() {
+            for (int j = lane; j < m; j += 64) {
+                double eta = xs[j] * beta[0];
+                for (int c = 1; c < P; c++) eta = __builtin_fma(xs[(size_t)c * m + j], beta[c], eta);
+                const double mu = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
+                mu_s[j] = mu;
+                lg_s[j] = dlog(mu / nfg[j]);
+            }
+        };
+        auto wvec = [&](int j, double mu) -> double {                       // (:336-342, :390-396, :430-436)
+            if constexpr (USE_W) return (wg[j] * mu) / (1.0 + alpha * mu);
+            else return mu / (1.0 + alpha * mu);
+        };
+        // G[a][b] = sum_j x_ja (x_jb w_j), b >= a, mirrored; with_rhs: rhs[a] = sum_j x_ja zw_j (zw_j in sw_s): wave order
+        auto gram = [&](double *Gm, bool with_rhs) {
+            // R column sums of row a (columns b0 .. b0 + R - 1) in one pass over the samples; R is a compile-time constant so
+            // that the pass is straight-line code (the tail of a row takes the instantiation of its length)
+            auto gram_chunk = [&](int a, int b0, auto rtag) __attribute__((always_inline)) {
+                constexpr int R = decltype(rtag)::value;
+                double acc[R];
+                _Pragma("unroll")
+                for (int u = 0; u < R; u++) acc[u] = 0.0;
+                const double *xa_p = xs + (size_t)a * m, *xb_p = xs + (size_t)b0 * m;
+                for (int j = lane; j < m; j += 64) {
+                    const double wv = w_s[j], xa = xa_p[j];
+                    _Pragma("unroll")
+                    for (int u = 0; u < R; u++) acc[u] += xa * (xb_p[(size_t)u * m + j] * wv);
+                }
+                wave_allreduce_many(acc, lane);
+                if (lane == 0) {
+                    _Pragma("unroll")
+                    for (int u = 0; u < R; u++) { Gm[(size_t)a * P + b0 + u] = acc[u]; Gm[(size_t)(b0 + u) * P + a] = acc[u]; }
+                }
+            };
+            for (int a = 0; a < P; a++) {
+                int b0 = a;
+                for (; b0 + kChunk <= P; b0 += kChunk) gram_chunk(a, b0, IntTag<kChunk>{});
+                switch (P - b0) {
+                    case 1: gram_chunk(a, b0, IntTag<1>{}); break;
+                    case 2: gram_chunk(a, b0, IntTag<2>{}); break;
+                    case 3: gram_chunk(a, b0, IntTag<3>{}); break;
+                    case 4: gram_chunk(a, b0, IntTag<4>{}); break;
+                    case 5: gram_chunk(a, b0, IntTag<5>{}); break;
+                    case 6: gram_chunk(a, b0, IntTag<6>{}); break;
+                    case 7: gram_chunk(a, b0, IntTag<7>{}); break;
+                    default: break;
+                }
+                if (with_rhs) {
+                    double racc = 0.0;
+                    for (int j = lane; j < m; j += 64) racc += xs[(size_t)a * m + j] * sw_s[j];
+                    racc = wave_allreduce(racc);
+                    if (lane == 0) rhs[a] = racc;
+                }
+            }
+            wave_slab_sync();
+            wave_lds_sync();
+        };
+        // LU with partial pivoting of the row-major P x P matrix A in the slab (lane j owns column j), LU<P>::factor's
+        // operations: first maximum wins, rows swapped in every column, reciprocal pivots, fma(-l, u, a)
+        auto lu_factor = [&](double *A) {
+            for (int k = 0; k < P; k++) {
+                int pr = k;
+                double best = __builtin_fabs(A[(size_t)k * P + k]);
+                for (int i = k + 1; i < P; i++) {
+                    const double v = __builtin_fabs(A[(size_t)i * P + k]);
+                    if (v > best) { best = v; pr = i; }
+                }
+                if (lane == 0) piv[k] = pr;
+                if (pr != k) {
+                    for (int j = lane; j < P; j += 64) {
+                        const double t = A[(size_t)k * P + j];
+                        A[(size_t)k * P + j] = A[(size_t)pr * P + j];
+                        A[(size_t)pr * P + j] = t;
+                    }
+                    wave_slab_sync();
+                }
+                const double rinv = 1.0 / A[(size_t)k * P + k];
+                if (lane == 0) rdiag[k] = rinv;
+                const double akj = lane < P ? A[(size_t)k * P + lane] : 0.0;
+                for (int i = k + 1; i < P; i++) {
+                    // (every lane loads A[i][k] in the instruction BEFORE lane k's store to it: a wave's memory operations
+                    //  issue in program order, no fence needed inside the loop)
+                    const double l = A[(size_t)i * P + k] * rinv;
+                    if (lane == k) A[(size_t)i * P + k] = l;
+                    else if (lane > k && lane < P) A[(size_t)i * P + lane] = __builtin_fma(-l, akj, A[(size_t)i * P + lane]);
+                }
+                wave_slab_sync();
+            }
+            wave_lds_sync();
+        };
+        // LU<P>::solve on ONE right-hand side in LDS (every lane computes the same values)
+        auto lu_solve_vec = [&](const double *A, double *b) {
+            for (int k = 0; k < P; k++) {
+                const int pr = piv[k];
+                if (pr != k) {
+                    wave_lds_sync();
+                    const double t = b[k], u = b[pr];
+                    wave_lds_sync();
+                    if (lane == 0) { b[k] = u; b[pr] = t; }
+                    wave_lds_sync();
+                }
+            }
+            for (int i = 0; i < P; i++) {
+                double t = b[i];
+                for (int j = 0; j < i; j++) t = __builtin_fma(-A[(size_t)i * P + j], b[j], t);
+                wave_lds_sync();
+                if (lane == 0) b[i] = t;
+                wave_lds_sync();
+            }
+            for (int i = P - 1; i >= 0; i--) {
+                double t = b[i];
+                for (int j = i + 1; j < P; j++) t = __builtin_fma(-A[(size_t)i * P + j], b[j], t);
+                wave_lds_sync();
+                if (lane == 0) b[i] = t * rdiag[i];
+                wave_lds_sync();
+            }
+        };
+
+        update_mu();
+        const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
+        double K = 0.0, Kp = 0.0;
+        if (kp.maxit > 0) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr);
+        if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
+        double dev = 0.0, dev_old = 0.0;
+        double it = 0.0;
+        for (int t = 0; t < kp.maxit; t++) {
+            it += 1.0;
+            wave_lds_sync();
+            for (int c = lane; c < P; c += 64) beta_prev[c] = beta[c];
+            wave_lds_sync();
+            if (kp.useQR) {
+                // pass A: the rows of the least squares (column P = sqrt(w) z)                              (:336-353)
+                for (int i = lane; i < M; i += 64) {
+                    if (i < m) {
+                        const double mu = mu_s[i];
+                        const double sw = __builtin_sqrt(wvec(i, mu));
+                        const double z = lg_s[i] + ((double)yg[i] - mu) / mu;
+                        sw_s[i] = sw;
+                        for (int c = 0; c < P; c++) qa[(size_t)c * M + i] = xs[(size_t)c * m + i] * sw;
+                        qa[(size_t)P * M + i] = z * sw;
+                    } else {
+                        for (int c = 0; c < P; c++) qa[(size_t)c * M + i] = (i - m == c) ? __builtin_sqrt(lambda[c]) : 0.0;
+                        qa[(size_t)P * M + i] = 0.0;
+                    }
+                }
+                // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
+                double scal_prev = 0.0;
+                for (int k = 0; k < P; k++) {
+                    // columns j0 .. j0 + R - 1 of the rows from k down: apply reflection k - 1, take the sums with column k.
+                    // FIRST: the chunk starts at column k itself (its updated values are the multiplier of every sum of the
+                    // stage; the later chunks read them back).  R and FIRST are compile-time: straight-line passes.
+                    const int i0 = lane + 64 * (k / 64);                 // (trips whose rows are all finished rows of R: skipped)
+                    auto stage_chunk = [&](int j0, auto rtag, auto ftag) __attribute__((always_inline)) {
+                        constexpr int R = decltype(rtag)::value;
+                        constexpr bool FIRST = decltype(ftag)::value != 0;
+                        double acc[R];
+                        _Pragma("unroll")
+                        for (int u = 0; u < R; u++) acc[u] = 0.0;
+                        double *colp = qa + (size_t)j0 * M;
+                        const double *prevp = qa + (size_t)(k > 0 ? k - 1 : 0) * M, *kp_ = qa + (size_t)k * M;
+                        for (int i = i0; i < M; i += 64) {
+                            if (i < k) continue;                          // finished rows of R (first live trip only)
+                            const double v = k > 0 ? prevp[i] * scal_prev : 0.0;
+                            double ak = FIRST ? 0.0 : kp_[i];
+                            _Pragma("unroll")
+                            for (int u = 0; u < R; u++) {
+                                double a = colp[(size_t)u * M + i];
+                                if (k > 0) { a = __builtin_fma(v, tprev[j0 + u], a); colp[(size_t)u * M + i] = a; }
+                                if (FIRST && u == 0) ak = a;
+                                if (i > k) acc[u] += ak * a;
+                            }
+                        }
+                        wave_allreduce_many(acc, lane);
+                        if (lane == 0) {
+                            _Pragma("unroll")
+                            for (int u = 0; u < R; u++) accs[j0 + u] = acc[u];
+                        }
+                    };
+                    auto stage_tail = [&](int j0, int r, auto ftag) __attribute__((always_inline)) {
+                        switch (r) {
+                            case 1: stage_chunk(j0, IntTag<1>{}, ftag); break;
+                            case 2: stage_chunk(j0, IntTag<2>{}, ftag); break;
+                            case 3: stage_chunk(j0, IntTag<3>{}, ftag); break;
+                            case 4: stage_chunk(j0, IntTag<4>{}, ftag); break;
+                            case 5: stage_chunk(j0, IntTag<5>{}, ftag); break;
+                            case 6: stage_chunk(j0, IntTag<6>{}, ftag); break;
+                            case 7: stage_chunk(j0, IntTag<7>{}, ftag); break;
+                            default: break;
+                        }
+                    };
+                    {
+                        int j0 = k;
+                        const int ncol = P + 1 - k;                       // columns k .. P
+                        if (ncol >= kChunk) { stage_chunk(j0, IntTag<kChunk>{}, IntTag<1>{}); j0 += kChunk; }
+                        else { stage_tail(j0, ncol, IntTag<1>{}); j0 = P + 1; }
+                        for (; j0 + kChunk <= P + 1; j0 += kChunk) stage_chunk(j0, IntTag<kChunk>{}, IntTag<0>{});
+                        if (j0 <= P) stage_tail(j0, P + 1 - j0, IntTag<0>{});
+                    }
+                    wave_slab_sync();
+                    wave_lds_sync();
+                    const double alpha_k = qa[(size_t)k * M + k];
+                    const double acck = accs[k];
+                    double tau, scal, bet;
+                    if (acck == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                    else {
+                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acck), alpha_k);
+                        tau = (bet - alpha_k) / bet;
+                        scal = 1.0 / (alpha_k - bet);
+                    }
+                    scal_prev = scal;
+                    wave_lds_sync();
+                    for (int j = k + 1 + lane; j <= P; j += 64) {
+                        const double prow = qa[(size_t)j * M + k];
+                        const double wj = prow + scal * accs[j];
+                        const double tp = -tau * wj;
+                        tprev[j] = tp;
+                        if (j < P) qR[(size_t)k * P + j] = prow + tp;
+                        else gamma[k] = prow + tp;
+                    }
+                    if (lane == 0) qR[(size_t)k * P + k] = bet;
+                    wave_lds_sync();
+                }
+                wave_slab_sync();
+                for (int i = P - 1; i >= 0; i--) {
+                    double tt = gamma[i];
+                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[(size_t)i * P + j], beta[j], tt);
+                    const double bi = tt / qR[(size_t)i * P + i];
+                    wave_lds_sync();
+                    if (lane == 0) beta[i] = bi;
+                    wave_lds_sync();
+                }
+            } else {
+                // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))            (:398)
+                for (int j = lane; j < m; j += 64) {
+                    const double mu = mu_s[j];
+                    const double wv = wvec(j, mu);
+                    const double z = lg_s[j] + ((double)yg[j] - mu) / mu;
+                    w_s[j] = wv;
+                    sw_s[j] = z * wv;
+                }
+                gram(G, true);
+                for (int a = lane; a < P; a += 64) G[(size_t)a * P + a] = G[(size_t)a * P + a] + lambda[a];
+                wave_slab_sync();
+                lu_factor(G);
+                lu_solve_vec(G, rhs);
+                wave_lds_sync();
+                for (int a = lane; a < P; a += 64) beta[a] = rhs[a];
+                wave_lds_sync();
+            }
+            int toolarge = 0;
+            for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                   // (:357-360)
+            update_mu();
+            double dacc = 0.0;                                                            // (:365-373)
+            for (int j = lane; j < m; j += 64) {
+                const double y = (double)yg[j], mu = mu_s[j];
+                double tj;
+                if (cell_dev_closed(y, size, fast)) {
+                    const double am = alpha * mu, opm = 1.0 + am, rcp = 1.0 / opm;
+                    const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
+                    tj = y * lg_s[j] - (y + size) * l1p;
+                } else tj = nb_offbranch(y, size, mu);
+                if constexpr (USE_W) dacc += wg[j] * tj;
+                else dacc += tj;
+            }
+            dev = -2.0 * (K + wave_allreduce(dacc));
+            const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
+            if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }        // (:375-378)
+            if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
+            else
+            if (uniform((t > 0) && (conv_test < kp.tol))) break;                          // (:379-381)
+            dev_old = dev;
+        }
+
+        // ---- post-loop block (:427-455) ------------------------------------------------
+        wave_slab_sync();
+        for (int j = lane; j < m; j += 64) {
+            const double wv = wvec(j, mu_s[j]);
+            w_s[j] = wv;
+            sw_s[j] = __builtin_sqrt(wv);
+        }
+        gram(G, false);
+        for (int i = 0; i < P; i++)
+            for (int j = lane; j < P; j += 64) {
+                double v = G[(size_t)i * P + j];
+                if (i == j) v = v + lambda[i];
+                LUm[(size_t)i * P + j] = v;
+            }
+        wave_slab_sync();
+        lu_factor(LUm);
+        // Gi = inverse: lane c owns right-hand side e_c (LU<P>::inverse = P solves)
+        if (lane < P) {
+            const int c = lane;
+            for (int i = 0; i < P; i++) Gi[(size_t)i * P + c] = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < P; k++) {
+                const int pr = piv[k];
+                if (pr != k) { const double t = Gi[(size_t)k * P + c]; Gi[(size_t)k * P + c] = Gi[(size_t)pr * P + c]; Gi[(size_t)pr * P + c] = t; }
+            }
+            for (int i = 0; i < P; i++) {
+                double t = Gi[(size_t)i * P + c];
+                for (int j = 0; j < i; j++) t = __builtin_fma(-LUm[(size_t)i * P + j], Gi[(size_t)j * P + c], t);
+                Gi[(size_t)i * P + c] = t;
+            }
+            for (int i = P - 1; i >= 0; i--) {
+                double t = Gi[(size_t)i * P + c];
+                for (int j = i + 1; j < P; j++) t = __builtin_fma(-LUm[(size_t)i * P + j], Gi[(size_t)j * P + c], t);
+                Gi[(size_t)i * P + c] = t * rdiag[i];
+            }
+        }
+        wave_slab_sync();
+        // hat diagonal, loop order of :443-449; fitted means (extension)
+        if (kp.hat_diagonals || kp.mu_out) {
+            for (int j = lane; j < m; j += 64) {
+                if (kp.hat_diagonals) {
+                    const double sw = sw_s[j];
+                    double h = 0.0;
+                    for (int i1 = 0; i1 < P; i1++) {
+                        const double xw1 = xs[(size_t)i1 * m + j] * sw;
+                        for (int i2 = 0; i2 < P; i2++) {
+                            const double xw2 = xs[(size_t)i2 * m + j] * sw;
+                            h += xw1 * (xw2 * Gi[(size_t)i2 * P + i1]);
+                        }
+                    }
+                    kp.hat_diagonals[(size_t)g * kp.ld + j] = h;
+                }
+                if (kp.mu_out) {
+                    double eta = xs[j] * beta[0];
+                    for (int c = 1; c < P; c++) eta = __builtin_fma(xs[(size_t)c * m + j], beta[c], eta);
+                    double v = nfg[j] * dexp(eta);
+                    if (kp.mu_floor > 0.0) v = __builtin_fmax(v, kp.mu_floor);
+                    kp.mu_out[(size_t)g * kp.ld + j] = v;
+                }
+            }
+        }
+        // sigma = Gi * G * Gi (:452), mat_mul's order: c[i][j] = sum_k fma(a[i][k], b[k][j]), k ascending; lane j owns column j
+        if (lane < P) {
+            const int j = lane;
+            for (int i = 0; i < P; i++) {
+                double acc = 0.0;
+                for (int k = 0; k < P; k++) acc = __builtin_fma(Gi[(size_t)i * P + k], G[(size_t)k * P + j], acc);
+                Tm[(size_t)i * P + j] = acc;
+            }
+        }
+        wave_slab_sync();
+        if (lane < P) {
+            const int j = lane;
+            for (int i = 0; i < P; i++) {
+                double acc = 0.0;
+                for (int k = 0; k < P; k++) acc = __builtin_fma(Tm[(size_t)i * P + k], Gi[(size_t)k * P + j], acc);
+                Sg[(size_t)i * P + j] = acc;
+            }
+        }
+        wave_slab_sync();
+        double cn = 0.0;
+        for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
+        wave_lds_sync();
+        if (lane < P) {
+            double rr = 0.0;
+            for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[(size_t)a * P + lane], rr);
+            rhs[lane] = rr;
+        }
+        wave_lds_sync();
+        double cd = 0.0;
+        for (int b = 0; b < P; b++) cd = __builtin_fma(rhs[b], contrast[b], cd);
+        for (int c = lane; c < P; c += 64) {
+            kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
+            kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[(size_t)c * P + c];
+        }
+        if (lane == 0) {
+            kp.iter[g] = it;
+            kp.deviance[g] = dev;
+            kp.contrast_num[g] = cn;
+            kp.contrast_denom[g] = __builtin_sqrt(cd);
+        }
+        wave_slab_sync();
+    }
+}
+
+// ---- launch ---------------------------------------------------------------------------------------------------------
+// LDS mode when a wave's slab fits the CU at least twice (two resident waves per CU); else the slabs live in global memory:
+// persistent grid, four waves per workgroup, as many workgroups as the registers admit -- but no more resident waves than
+// keep the slabs of all of them inside DSQ_WIDE_SLAB_MB (default 192) of memory: the stages stream a wave's rows once per
+// column chunk, and slabs that fit the 256 MB infinity cache together are served from there instead of from HBM
+struct WideGeom { int grid, waves; size_t lds; bool big_lds; };
+static WideGeom wide_geometry(int n, int m, int p, bool useW) {
+    WideGeom g;
+    const size_t cu_lds = 160 * 1024;
+    const size_t vec_b = wide_lds_doubles(p) * sizeof(double), slab_b = wide_slab_doubles(m, p) * sizeof(double);
+    static const int force = getenv("DSQ_WIDE_LDS") ? atoi(getenv("DSQ_WIDE_LDS")) : -1;       // 0: never, 1: whenever it fits once
+    const int fit = (int)(cu_lds / (vec_b + slab_b));              // waves per CU with their slabs in LDS
+    g.big_lds = force == 0 ? false : (force == 1 ? fit >= 1 : fit >= 2);
+    const int cus = device_cu_count();
+    if (g.big_lds) {
+        g.waves = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;                 // per workgroup
+        g.lds = (size_t)g.waves * (vec_b + slab_b);
+        const int bpc = (int)(cu_lds / g.lds);
+        const void *fn = useW ? (const void *)fit_beta_rolled_kernel<true, true> : (const void *)fit_beta_rolled_kernel<false, true>;
+        static thread_local size_t attr_set[2];
+        if (g.lds > 64 * 1024 && attr_set[useW] < g.lds) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cu_lds);
+            attr_set[useW] = cu_lds;
+        }
+        long need = ((long)n + g.waves - 1) / g.waves, cap = (long)cus * (bpc < 1 ? 1 : bpc);
+        g.grid = (int)(need < cap ? need : cap);
+        if (g.grid < 1) g.grid = 1;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in LDS, %d waves/block, lds=%zu, %d blocks/CU\n", p, m, g.waves, g.lds, bpc);
+        return g;
+    }
+    g.waves = 4;
+    g.lds = (size_t)g.waves * vec_b;
+    static thread_local int bpc_cache[2];
+    static thread_local size_t lds_cache[2];
+    DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
+    if (lds_cache[useW] != g.lds) { bpc_cache[useW] = 0; lds_cache[useW] = g.lds; }
+    int bpc = bpc_cache[useW];
+    if (bpc == 0) {
+        const void *fn = useW ? (const void *)fit_beta_rolled_kernel<true, false> : (const void *)fit_beta_rolled_kernel<false, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * g.waves, g.lds) != hipSuccess || bpc < 1) bpc = 1;
+        bpc_cache[useW] = bpc;
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in global memory, lds=%zu occupancy-api blocks/CU=%d\n", p, m, g.lds, bpc);
+    }
+    static const int slab_mb = getenv("DSQ_WIDE_SLAB_MB") ? atoi(getenv("DSQ_WIDE_SLAB_MB")) : 192;
+    long cap = (long)cus * bpc;
+    const size_t per_block = (size_t)g.waves * slab_b;
+    const long fitb = (long)(((size_t)slab_mb << 20) / per_block);
+    if (cap > fitb) cap = fitb < cus ? cus : fitb;              // (never below one workgroup per CU)
+    const long need = ((long)n + g.waves - 1) / g.waves;
+    long gr = need < cap ? need : cap;
+    if (gr < 1) gr = 1;
+    g.grid = (int)gr;
+    return g;
+}
+
+void fit_beta_rolled_scratch_doubles(int n, int m, int p, int useW, size_t *slab, size_t *cscr) {
+    const WideGeom g = wide_geometry(n, m, p, useW != 0);
+    *slab = g.big_lds ? 0 : (size_t)g.grid * g.waves * wide_slab_doubles(m, p);
+    *cscr = 0;
+}
+
+hipError_t launch_fit_beta_rolled(const BetaKernelParams &kp0, hipStream_t st) {
+    const WideGeom g = wide_geometry(kp0.n, kp0.m, kp0.p, kp0.useWeights != 0);
+    BetaKernelParams kp = kp0;
+    kp.xlds = 0;
+    int grid = g.grid;
+    // (a row list: its length lives on the device; the scratch was sized for the full grid, a smaller one uses its head)
+    if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();
+    if (g.big_lds) {
+        if (kp.useWeights) hipLaunchKernelGGL((fit_beta_rolled_kernel<true, true>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
+        else hipLaunchKernelGGL((fit_beta_rolled_kernel<false, true>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
+    } else {
+        if (kp.useWeights) hipLaunchKernelGGL((fit_beta_rolled_kernel<true, false>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
+        else hipLaunchKernelGGL((fit_beta_rolled_kernel<false, false>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dsq
