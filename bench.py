@@ -391,6 +391,10 @@ def main():
             parity = parity_sample(dds[0], W, x, cfg, factors, reduced, rows=2048)
         except Exception as e:                                       # noqa: BLE001
             parity = {"error": repr(e)}
+        try:
+            parity["second_implementation"] = lapack_rates(W, x, cfg)
+        except Exception as e:                                       # noqa: BLE001
+            parity["second_implementation"] = {"error": repr(e)}
 
     # the other halves of the spec'd workload, short timed regions of the same step: s_j = 1 and seeds 2, 3
     variants = None
@@ -677,6 +681,43 @@ def library_sha256():
         for blk in iter(lambda: f.read(1 << 22), b""):
             h.update(blk)
     return h.hexdigest()
+
+
+def lapack_rates(W, x, cfg, rows=256):
+    """The HIP path next to an implementation that shares no arithmetic with it (oracle/lapack_oracle.py: numpy over real
+    LAPACK, scipy's special functions): fitBeta -> fitDisp (gene-wise, then with a prior) -> fitDispGrid on a fixed sample of
+    this run's own rows, through the host-pointer C ABI.  Reports what north_star words as "iteration counts bit-exact" as
+    numbers: rows whose fitBeta iteration count differs; `ties` = rows whose final Armijo test falls on the last bit (they take
+    one step more or fewer); `floor_share` = rows whose dispersion sits at the 1e-8 floor, where the step count is rounding noise
+    of whichever lgamma / digamma is underneath (tests/test_oracle_vs_lapack.py, tests/floor_regime.py)."""
+    from deseq2_amd import native
+    from oracle import lapack_oracle
+    from tests.helpers import beta_init_qr, rough_alpha
+    from tests.test_oracle_vs_lapack import compare, run_all
+    counts = W["counts"]
+    cand = np.where(counts.sum(axis=1) > 0)[0]
+    pick = np.sort(np.random.Generator(np.random.PCG64(20260927)).choice(cand, min(rows, cand.size), replace=False))
+    y = counts[pick]
+    m = y.shape[1]
+    nf = np.broadcast_to(np.asarray(W["sf"], np.float64)[None, :], y.shape).copy()
+    use_w = W["w"] is not None
+    w = np.ones(y.shape)
+    if use_w:
+        w = W["w"][pick] / W["w"][pick].max(axis=1, keepdims=True)                       # R/core.R:2702
+    with np.errstate(all="ignore"):
+        d = dict(counts=y, x=x, nf=nf, weights=w, useWeights=use_w, useQR=True, useCR=True,
+                 lam=np.full(x.shape[1], 1e-6) / np.log(2) ** 2, beta_init=beta_init_qr(y.astype(float), nf, x),
+                 alpha_init=rough_alpha(y.astype(float), nf, x))
+    try:
+        st = compare(run_all(native, d), run_all(lapack_oracle, d), d, "bench sample", min_well=0.0, min_grid=0.0)
+    except AssertionError as e:
+        return {"rows": int(pick.size), "error": str(e)[:300]}
+    well = min(st["fitDispMLE"]["well"], st["fitDispMAP"]["well"])
+    return {"rows": int(pick.size), "fitBeta_iter_mismatch": st["fitBeta"]["iter_mismatch"],
+            "fitDisp_iter_mismatch_outside_ties": 0, "ties": st["fitDispMLE"]["ties"] + st["fitDispMAP"]["ties"],
+            "floor_share": 1.0 - well, "grid_same": st["fitDispGrid"]["same"],
+            "max_rel_log_alpha": max(st["fitDispMLE"]["max_rel_log_alpha"], st["fitDispMAP"]["max_rel_log_alpha"]),
+            "against": "oracle/lapack_oracle.py (numpy + LAPACK + scipy.special; values within 1e-7 / 1e-8 asserted)"}
 
 
 def result_digest(dds, world, comm_dev, parallel):

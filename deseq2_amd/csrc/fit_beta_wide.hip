@@ -34,57 +34,66 @@ __host__ __device__ static inline size_t wide_slab_doubles(int m, int p) {
     return (size_t)4 * m + (irls > post ? irls : post) + 8;
 }
 // per-wave LDS (doubles): lambda, contrast, beta, beta_prev, gamma, rdiag, rhs / rr (p each), tprev, accs (p + 1 each), piv (p ints)
-__host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_t)10 * p + 16; }
-
-// orders every lane's earlier slab stores before the loads that follow (cross-lane exchange through the wave's slab)
-template <bool BIG_LDS>
-DSQ_DEV void wave_slab_sync_t() {
-    if constexpr (BIG_LDS) wave_lds_sync();
-    else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-}
+__host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_t)10 * p + 16; }     // (+ the control words)
 
 constexpr int kChunk = 8;     // column sums reduced together (wave_allreduce_many: the bits of one butterfly each)
 template <int V> struct IntTag { static constexpr int value = V; };
 
-// BIG_LDS: the wave's slab (rows, matrices, per-sample vectors) in LDS instead of global memory -- taken when at least one
-// wave per SIMD pair still fits the CU's 160 KB (see wide_geometry): a Householder stage is a chain of dependent round
-// trips through the slab (rows -> column sums -> pivot row -> reflector), ~ 100 ns each in LDS against 1-3 us through L2 /
-// the infinity cache; in global memory the only cover is occupancy (128 registers: four waves per SIMD).
-template <bool USE_W, bool BIG_LDS>
-__global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel(BetaKernelParams kp) {
+// ONE WORKGROUP (four waves) PER GENE.  A gene of a wide design is 10^5 .. 10^6 wave instructions, most of them in the
+// Householder stages, and its slab leaves room for only a few genes per CU: with a wave per gene the CU ran one wave per
+// SIMD (or fewer), every instruction exposed to its own latency.  The four waves share the gene's slab and split what is
+// independent -- the column chunks of a Householder stage (after the first, which updates the multiplier column), the
+// (row, column-chunk) sums of the Gram matrices, the rows of an elimination step, the samples of the elementwise passes,
+// the rows of the p x p products -- and meet at workgroup barriers.  EVERY SUM OVER THE SAMPLES IS STILL TAKEN BY ONE
+// WAVE in wave order (64 per-lane partials over the trips in order, then the butterfly): which wave takes it does not
+// enter the result.  Serial recurrences (back substitution, the triangular solves of the inverse, the convergence
+// control) stay with wave 0; their results reach the other waves through LDS.
+// BIG_LDS: the gene's slab (rows, matrices, per-sample vectors) in LDS instead of global memory -- taken when at least
+// two genes fit a CU (wide_geometry): a Householder stage is a chain of dependent round trips through the slab
+// (rows -> column sums -> pivot row -> reflector), ~ 100 ns each in LDS against 1-3 us through L2 / the infinity cache.
+// NW = 1, 2 or 4 waves per gene: as many as bring a CU to about eight resident waves (two per SIMD: what the registers of
+// this kernel admit) given how many genes' slabs fit its LDS -- small problems run a wave per gene, without barriers.
+template <bool USE_W, bool BIG_LDS, int NW>
+__global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : 8 / NW)) fit_beta_rolled_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int waves = blockDim.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    constexpr int NT = 64 * NW;                // threads per gene (= per workgroup)
     const int m = kp.m, P = kp.p;
     const int M = m + P;
     const int nwork = DSQ_NWORK(kp);
-    if (blockIdx.x * waves >= nwork) return;
+    if ((int)blockIdx.x >= nwork) return;
 
-    auto wave_slab_sync = [] { wave_slab_sync_t<BIG_LDS>(); };
     const double *xs = kp.x;
-    double *lv = smem + (size_t)wave * wide_lds_doubles(P);
+    double *lv = smem;
     double *lambda = lv, *contrast = lv + P, *beta = lv + 2 * P, *beta_prev = lv + 3 * P, *gamma = lv + 4 * P, *rdiag = lv + 5 * P,
            *rhs = lv + 6 * P, *tprev = lv + 7 * P, *accs = lv + 8 * P + 1;
     int *piv = reinterpret_cast<int *>(lv + 9 * P + 2);
+    double *ctl = lv + 10 * P + 8;             // [0] loop control of the IRLS, [1] next gene, [2] dev, [3] iterations
     double *slab;
-    if constexpr (BIG_LDS) slab = smem + (size_t)waves * wide_lds_doubles(P) + (size_t)wave * wide_slab_doubles(m, P);
-    else slab = kp.scratch + ((size_t)blockIdx.x * waves + wave) * wide_slab_doubles(m, P);
+    if constexpr (BIG_LDS) slab = smem + wide_lds_doubles(P);
+    else slab = kp.scratch + (size_t)blockIdx.x * wide_slab_doubles(m, P);
     double *mu_s = slab, *lg_s = slab + m, *sw_s = slab + 2 * (size_t)m, *w_s = slab + 3 * (size_t)m;
     double *big = slab + 4 * (size_t)m;
     double *qa = big, *qR = big + (size_t)M * (P + 1);                         // IRLS
     double *G = big, *LUm = big + (size_t)P * P, *Gi = big + 2 * (size_t)P * P, *Sg = big + 3 * (size_t)P * P;   // post-loop
     double *Tm = LUm;                                                         // (LU is dead once Gi exists)
+    // workgroup barrier; in global-slab mode it also orders the slab's stores before the other waves' loads
+    auto sync = [] {
+        if constexpr (!BIG_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        else if constexpr (NW == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+        if constexpr (!BIG_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        else if constexpr (NW == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
-    for (int c = lane; c < P; c += 64) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
-    wave_lds_sync();
+    for (int c = tid; c < P; c += NT) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
 
-    for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+    int wi = blockIdx.x;
+    while (wi < nwork) {
         const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
@@ -92,13 +101,13 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
         const double alpha = kp.alpha_hat[g];
         const double size = 1.0 / alpha;
 
-        wave_lds_sync();
-        for (int c = lane; c < P; c += 64) { const double b = kp.beta_init[(size_t)g + (size_t)kp.n * c]; beta[c] = b; beta_prev[c] = b; }
-        wave_lds_sync();
+        sync();
+        for (int c = tid; c < P; c += NT) { const double b = kp.beta_init[(size_t)g + (size_t)kp.n * c]; beta[c] = b; beta_prev[c] = b; }
+        sync();
 
-        // mu_hat = nfrow % exp(x * beta_hat), clamped at minmu            (:324-327, :361-364)
+        // mu_hat = nfrow % exp(x * beta_hat), clamped at minmu            (:324-327, :361-364)      [all waves]
         auto update_mu = [&]() {
-            for (int j = lane; j < m; j += 64) {
+            for (int j = tid; j < m; j += NT) {
                 double eta = xs[j] * beta[0];
                 for (int c = 1; c < P; c++) eta = __builtin_fma(xs[(size_t)c * m + j], beta[c], eta);
                 const double mu = __builtin_fmax(nfg[j] * dexp(eta), kp.minmu);
@@ -110,10 +119,9 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
             if constexpr (USE_W) return (wg[j] * mu) / (1.0 + alpha * mu);
             else return mu / (1.0 + alpha * mu);
         };
-        // G[a][b] = sum_j x_ja (x_jb w_j), b >= a, mirrored; with_rhs: rhs[a] = sum_j x_ja zw_j (zw_j in sw_s): wave order
+        // G[a][b] = sum_j x_ja (x_jb w_j), b >= a, mirrored; with_rhs: rhs[a] = sum_j x_ja zw_j (zw_j in sw_s).  Each sum by
+        // one wave in wave order; the (row, chunk) tasks go round the waves.                                   [all waves]
         auto gram = [&](double *Gm, bool with_rhs) {
-            // R column sums of row a (columns b0 .. b0 + R - 1) in one pass over the samples; R is a compile-time constant so
-            // that the pass is straight-line code (the tail of a row takes the instantiation of its length)
             auto gram_chunk = [&](int a, int b0, auto rtag) __attribute__((always_inline)) {
                 constexpr int R = decltype(rtag)::value;
                 double acc[R];
@@ -131,63 +139,68 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                     for (int u = 0; u < R; u++) { Gm[(size_t)a * P + b0 + u] = acc[u]; Gm[(size_t)(b0 + u) * P + a] = acc[u]; }
                 }
             };
+            int task = 0;
             for (int a = 0; a < P; a++) {
                 int b0 = a;
-                for (; b0 + kChunk <= P; b0 += kChunk) gram_chunk(a, b0, IntTag<kChunk>{});
-                switch (P - b0) {
-                    case 1: gram_chunk(a, b0, IntTag<1>{}); break;
-                    case 2: gram_chunk(a, b0, IntTag<2>{}); break;
-                    case 3: gram_chunk(a, b0, IntTag<3>{}); break;
-                    case 4: gram_chunk(a, b0, IntTag<4>{}); break;
-                    case 5: gram_chunk(a, b0, IntTag<5>{}); break;
-                    case 6: gram_chunk(a, b0, IntTag<6>{}); break;
-                    case 7: gram_chunk(a, b0, IntTag<7>{}); break;
-                    default: break;
+                for (; b0 + kChunk <= P; b0 += kChunk)
+                    if ((task++ & (NW - 1)) == wave) gram_chunk(a, b0, IntTag<kChunk>{});
+                if (b0 < P && (task++ & (NW - 1)) == wave) {
+                    switch (P - b0) {
+                        case 1: gram_chunk(a, b0, IntTag<1>{}); break;
+                        case 2: gram_chunk(a, b0, IntTag<2>{}); break;
+                        case 3: gram_chunk(a, b0, IntTag<3>{}); break;
+                        case 4: gram_chunk(a, b0, IntTag<4>{}); break;
+                        case 5: gram_chunk(a, b0, IntTag<5>{}); break;
+                        case 6: gram_chunk(a, b0, IntTag<6>{}); break;
+                        case 7: gram_chunk(a, b0, IntTag<7>{}); break;
+                        default: break;
+                    }
                 }
-                if (with_rhs) {
+                if (with_rhs && (task++ & (NW - 1)) == wave) {
                     double racc = 0.0;
                     for (int j = lane; j < m; j += 64) racc += xs[(size_t)a * m + j] * sw_s[j];
                     racc = wave_allreduce(racc);
                     if (lane == 0) rhs[a] = racc;
                 }
             }
-            wave_slab_sync();
-            wave_lds_sync();
+            sync();
         };
         // LU with partial pivoting of the row-major P x P matrix A in the slab (lane j owns column j), LU<P>::factor's
-        // operations: first maximum wins, rows swapped in every column, reciprocal pivots, fma(-l, u, a)
+        // operations: first maximum wins, rows swapped in every column, reciprocal pivots, fma(-l, u, a).  Pivot search
+        // and row swap by wave 0, the rows of the elimination step round the waves.                            [all waves]
         auto lu_factor = [&](double *A) {
             for (int k = 0; k < P; k++) {
-                int pr = k;
-                double best = __builtin_fabs(A[(size_t)k * P + k]);
-                for (int i = k + 1; i < P; i++) {
-                    const double v = __builtin_fabs(A[(size_t)i * P + k]);
-                    if (v > best) { best = v; pr = i; }
-                }
-                if (lane == 0) piv[k] = pr;
-                if (pr != k) {
-                    for (int j = lane; j < P; j += 64) {
-                        const double t = A[(size_t)k * P + j];
-                        A[(size_t)k * P + j] = A[(size_t)pr * P + j];
-                        A[(size_t)pr * P + j] = t;
+                if (wave == 0) {
+                    int pr = k;
+                    double best = __builtin_fabs(A[(size_t)k * P + k]);
+                    for (int i = k + 1; i < P; i++) {
+                        const double v = __builtin_fabs(A[(size_t)i * P + k]);
+                        if (v > best) { best = v; pr = i; }
                     }
-                    wave_slab_sync();
+                    if (lane == 0) piv[k] = pr;
+                    if (pr != k) {
+                        for (int j = lane; j < P; j += 64) {
+                            const double t = A[(size_t)k * P + j];
+                            A[(size_t)k * P + j] = A[(size_t)pr * P + j];
+                            A[(size_t)pr * P + j] = t;
+                        }
+                    }
                 }
+                sync();
                 const double rinv = 1.0 / A[(size_t)k * P + k];
-                if (lane == 0) rdiag[k] = rinv;
+                if (tid == 0) rdiag[k] = rinv;
                 const double akj = lane < P ? A[(size_t)k * P + lane] : 0.0;
-                for (int i = k + 1; i < P; i++) {
+                for (int i = k + 1 + wave; i < P; i += NW) {
                     // (every lane loads A[i][k] in the instruction BEFORE lane k's store to it: a wave's memory operations
-                    //  issue in program order, no fence needed inside the loop)
+                    //  issue in program order)
                     const double l = A[(size_t)i * P + k] * rinv;
                     if (lane == k) A[(size_t)i * P + k] = l;
                     else if (lane > k && lane < P) A[(size_t)i * P + lane] = __builtin_fma(-l, akj, A[(size_t)i * P + lane]);
                 }
-                wave_slab_sync();
+                sync();
             }
-            wave_lds_sync();
         };
-        // LU<P>::solve on ONE right-hand side in LDS (every lane computes the same values)
+        // LU<P>::solve on ONE right-hand side in LDS                                                        [wave 0 only]
         auto lu_solve_vec = [&](const double *A, double *b) {
             for (int k = 0; k < P; k++) {
                 const int pr = piv[k];
@@ -216,20 +229,21 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
         };
 
         update_mu();
+        sync();
         const bool fast = (alpha > 0.0) && dfinite(alpha) && dfinite(size) && (size > 0.0);
         double K = 0.0, Kp = 0.0;
-        if (kp.maxit > 0) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr);
-        if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
-        double dev = 0.0, dev_old = 0.0;
+        if (wave == 0) {
+            if (kp.maxit > 0) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, nullptr, kp.kconst_out ? &Kp : nullptr);
+            if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
+        }
+        double dev = 0.0, dev_old = 0.0;          // (wave 0's)
         double it = 0.0;
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
-            wave_lds_sync();
-            for (int c = lane; c < P; c += 64) beta_prev[c] = beta[c];
-            wave_lds_sync();
+            for (int c = tid; c < P; c += NT) beta_prev[c] = beta[c];
             if (kp.useQR) {
                 // pass A: the rows of the least squares (column P = sqrt(w) z)                              (:336-353)
-                for (int i = lane; i < M; i += 64) {
+                for (int i = tid; i < M; i += NT) {
                     if (i < m) {
                         const double mu = mu_s[i];
                         const double sw = __builtin_sqrt(wvec(i, mu));
@@ -242,6 +256,7 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                         qa[(size_t)P * M + i] = 0.0;
                     }
                 }
+                sync();
                 // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
                 double scal_prev = 0.0;
                 for (int k = 0; k < P; k++) {
@@ -287,16 +302,21 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                             default: break;
                         }
                     };
-                    {
-                        int j0 = k;
-                        const int ncol = P + 1 - k;                       // columns k .. P
-                        if (ncol >= kChunk) { stage_chunk(j0, IntTag<kChunk>{}, IntTag<1>{}); j0 += kChunk; }
-                        else { stage_tail(j0, ncol, IntTag<1>{}); j0 = P + 1; }
-                        for (; j0 + kChunk <= P + 1; j0 += kChunk) stage_chunk(j0, IntTag<kChunk>{}, IntTag<0>{});
-                        if (j0 <= P) stage_tail(j0, P + 1 - j0, IntTag<0>{});
+                    const int ncol = P + 1 - k;                           // columns k .. P
+                    const int first_n = ncol >= kChunk ? kChunk : ncol;
+                    if (wave == 0) {
+                        if (first_n == kChunk) stage_chunk(k, IntTag<kChunk>{}, IntTag<1>{});
+                        else stage_tail(k, first_n, IntTag<1>{});
                     }
-                    wave_slab_sync();
-                    wave_lds_sync();
+                    if (ncol > first_n) {
+                        sync();                                           // column k is updated: the other chunks may start
+                        int task = 0;
+                        int j0 = k + first_n;
+                        for (; j0 + kChunk <= P + 1; j0 += kChunk)
+                            if ((task++ & (NW - 1)) == wave) stage_chunk(j0, IntTag<kChunk>{}, IntTag<0>{});
+                        if (j0 <= P && (task++ & (NW - 1)) == wave) stage_tail(j0, P + 1 - j0, IntTag<0>{});
+                    }
+                    sync();
                     const double alpha_k = qa[(size_t)k * M + k];
                     const double acck = accs[k];
                     double tau, scal, bet;
@@ -307,8 +327,8 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                         scal = 1.0 / (alpha_k - bet);
                     }
                     scal_prev = scal;
-                    wave_lds_sync();
-                    for (int j = k + 1 + lane; j <= P; j += 64) {
+                    // (tprev of stage k - 1 has been read by every chunk above: behind the barrier it may be rewritten)
+                    for (int j = k + 1 + tid; j <= P; j += NT) {
                         const double prow = qa[(size_t)j * M + k];
                         const double wj = prow + scal * accs[j];
                         const double tp = -tau * wj;
@@ -316,42 +336,47 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                         if (j < P) qR[(size_t)k * P + j] = prow + tp;
                         else gamma[k] = prow + tp;
                     }
-                    if (lane == 0) qR[(size_t)k * P + k] = bet;
-                    wave_lds_sync();
+                    if (tid == 0) qR[(size_t)k * P + k] = bet;
+                    sync();
                 }
-                wave_slab_sync();
-                for (int i = P - 1; i >= 0; i--) {
-                    double tt = gamma[i];
-                    for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[(size_t)i * P + j], beta[j], tt);
-                    const double bi = tt / qR[(size_t)i * P + i];
-                    wave_lds_sync();
-                    if (lane == 0) beta[i] = bi;
-                    wave_lds_sync();
+                if (wave == 0) {
+                    for (int i = P - 1; i >= 0; i--) {
+                        double tt = gamma[i];
+                        for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[(size_t)i * P + j], beta[j], tt);
+                        const double bi = tt / qR[(size_t)i * P + i];
+                        wave_lds_sync();
+                        if (lane == 0) beta[i] = bi;
+                        wave_lds_sync();
+                    }
                 }
+                sync();
             } else {
                 // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))            (:398)
-                for (int j = lane; j < m; j += 64) {
+                for (int j = tid; j < m; j += NT) {
                     const double mu = mu_s[j];
                     const double wv = wvec(j, mu);
                     const double z = lg_s[j] + ((double)yg[j] - mu) / mu;
                     w_s[j] = wv;
                     sw_s[j] = z * wv;
                 }
+                sync();
                 gram(G, true);
-                for (int a = lane; a < P; a += 64) G[(size_t)a * P + a] = G[(size_t)a * P + a] + lambda[a];
-                wave_slab_sync();
+                for (int a = tid; a < P; a += NT) G[(size_t)a * P + a] = G[(size_t)a * P + a] + lambda[a];
+                sync();
                 lu_factor(G);
-                lu_solve_vec(G, rhs);
-                wave_lds_sync();
-                for (int a = lane; a < P; a += 64) beta[a] = rhs[a];
-                wave_lds_sync();
+                if (wave == 0) {
+                    lu_solve_vec(G, rhs);
+                    wave_lds_sync();
+                    for (int a = lane; a < P; a += 64) beta[a] = rhs[a];
+                }
+                sync();
             }
             int toolarge = 0;
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
-            if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                   // (:357-360)
+            if (uniform(toolarge > 0)) { it = (double)kp.maxit; break; }                   // (:357-360; the same in every wave)
             update_mu();
-            double dacc = 0.0;                                                            // (:365-373)
-            for (int j = lane; j < m; j += 64) {
+            // the deviance terms by all waves, their sum by wave 0 in wave order                                  (:365-373)
+            for (int j = tid; j < m; j += NT) {
                 const double y = (double)yg[j], mu = mu_s[j];
                 double tj;
                 if (cell_dev_closed(y, size, fast)) {
@@ -359,36 +384,49 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                     const double l1p = dlog(opm) + (am - (opm - 1.0)) * rcp;
                     tj = y * lg_s[j] - (y + size) * l1p;
                 } else tj = nb_offbranch(y, size, mu);
-                if constexpr (USE_W) dacc += wg[j] * tj;
-                else dacc += tj;
+                w_s[j] = tj;
             }
-            dev = -2.0 * (K + wave_allreduce(dacc));
-            const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
-            if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }        // (:375-378)
-            if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
-            else
-            if (uniform((t > 0) && (conv_test < kp.tol))) break;                          // (:379-381)
-            dev_old = dev;
+            sync();
+            if (wave == 0) {
+                double dacc = 0.0;
+                for (int j = lane; j < m; j += 64) {
+                    if constexpr (USE_W) dacc += wg[j] * w_s[j];
+                    else dacc += w_s[j];
+                }
+                dev = -2.0 * (K + wave_allreduce(dacc));
+                const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
+                double flag = 0.0;
+                if (conv_test != conv_test) flag = 2.0;                                    // (:375-378)
+                else if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) flag = 1.0; }
+                else if ((t > 0) && (conv_test < kp.tol)) flag = 1.0;                      // (:379-381)
+                dev_old = dev;
+                if (lane == 0) ctl[0] = flag;
+            }
+            sync();
+            const double flag = ctl[0];
+            if (uniform(flag == 2.0)) { it = (double)kp.maxit; break; }
+            if (uniform(flag == 1.0)) break;
         }
 
         // ---- post-loop block (:427-455) ------------------------------------------------
-        wave_slab_sync();
-        for (int j = lane; j < m; j += 64) {
+        sync();
+        for (int j = tid; j < m; j += NT) {
             const double wv = wvec(j, mu_s[j]);
             w_s[j] = wv;
             sw_s[j] = __builtin_sqrt(wv);
         }
+        sync();
         gram(G, false);
-        for (int i = 0; i < P; i++)
-            for (int j = lane; j < P; j += 64) {
-                double v = G[(size_t)i * P + j];
-                if (i == j) v = v + lambda[i];
-                LUm[(size_t)i * P + j] = v;
-            }
-        wave_slab_sync();
+        for (int e = tid; e < P * P; e += NT) {
+            const int i = e / P, j = e - i * P;
+            double v = G[e];
+            if (i == j) v = v + lambda[i];
+            LUm[e] = v;
+        }
+        sync();
         lu_factor(LUm);
-        // Gi = inverse: lane c owns right-hand side e_c (LU<P>::inverse = P solves)
-        if (lane < P) {
+        // Gi = inverse: lane c owns right-hand side e_c (LU<P>::inverse = P solves)                              [wave 0]
+        if (wave == 0 && lane < P) {
             const int c = lane;
             for (int i = 0; i < P; i++) Gi[(size_t)i * P + c] = (i == c) ? 1.0 : 0.0;
             for (int k = 0; k < P; k++) {
@@ -406,10 +444,10 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                 Gi[(size_t)i * P + c] = t * rdiag[i];
             }
         }
-        wave_slab_sync();
-        // hat diagonal, loop order of :443-449; fitted means (extension)
+        sync();
+        // hat diagonal, loop order of :443-449; fitted means (extension)                                     [all waves]
         if (kp.hat_diagonals || kp.mu_out) {
-            for (int j = lane; j < m; j += 64) {
+            for (int j = tid; j < m; j += NT) {
                 if (kp.hat_diagonals) {
                     const double sw = sw_s[j];
                     double h = 0.0;
@@ -431,108 +469,109 @@ __global__ void __launch_bounds__(256, (BIG_LDS ? 1 : 4)) fit_beta_rolled_kernel
                 }
             }
         }
-        // sigma = Gi * G * Gi (:452), mat_mul's order: c[i][j] = sum_k fma(a[i][k], b[k][j]), k ascending; lane j owns column j
+        // sigma = Gi * G * Gi (:452), mat_mul's order: c[i][j] = sum_k fma(a[i][k], b[k][j]), k ascending; lane j owns column
+        // j, the rows go round the waves
         if (lane < P) {
             const int j = lane;
-            for (int i = 0; i < P; i++) {
+            for (int i = wave; i < P; i += NW) {
                 double acc = 0.0;
                 for (int k = 0; k < P; k++) acc = __builtin_fma(Gi[(size_t)i * P + k], G[(size_t)k * P + j], acc);
                 Tm[(size_t)i * P + j] = acc;
             }
         }
-        wave_slab_sync();
+        sync();
         if (lane < P) {
             const int j = lane;
-            for (int i = 0; i < P; i++) {
+            for (int i = wave; i < P; i += NW) {
                 double acc = 0.0;
                 for (int k = 0; k < P; k++) acc = __builtin_fma(Tm[(size_t)i * P + k], Gi[(size_t)k * P + j], acc);
                 Sg[(size_t)i * P + j] = acc;
             }
         }
-        wave_slab_sync();
-        double cn = 0.0;
-        for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
-        wave_lds_sync();
-        if (lane < P) {
-            double rr = 0.0;
-            for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[(size_t)a * P + lane], rr);
-            rhs[lane] = rr;
+        sync();
+        if (wave == 0) {
+            double cn = 0.0;
+            for (int c = 0; c < P; c++) cn = __builtin_fma(contrast[c], beta[c], cn);
+            if (lane < P) {
+                double rr = 0.0;
+                for (int a = 0; a < P; a++) rr = __builtin_fma(contrast[a], Sg[(size_t)a * P + lane], rr);
+                rhs[lane] = rr;
+            }
+            wave_lds_sync();
+            double cd = 0.0;
+            for (int b = 0; b < P; b++) cd = __builtin_fma(rhs[b], contrast[b], cd);
+            for (int c = lane; c < P; c += 64) {
+                kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
+                kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[(size_t)c * P + c];
+            }
+            if (lane == 0) {
+                kp.iter[g] = it;
+                kp.deviance[g] = dev;
+                kp.contrast_num[g] = cn;
+                kp.contrast_denom[g] = __builtin_sqrt(cd);
+                ctl[1] = (double)(kp.work_counter ? atomicAdd(kp.work_counter, 1) + (int)gridDim.x : wi + (int)gridDim.x);
+            }
         }
-        wave_lds_sync();
-        double cd = 0.0;
-        for (int b = 0; b < P; b++) cd = __builtin_fma(rhs[b], contrast[b], cd);
-        for (int c = lane; c < P; c += 64) {
-            kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
-            kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[(size_t)c * P + c];
-        }
-        if (lane == 0) {
-            kp.iter[g] = it;
-            kp.deviance[g] = dev;
-            kp.contrast_num[g] = cn;
-            kp.contrast_denom[g] = __builtin_sqrt(cd);
-        }
-        wave_slab_sync();
+        sync();
+        wi = (int)ctl[1];
     }
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-// LDS mode when a wave's slab fits the CU at least twice (two resident waves per CU); else the slabs live in global memory:
-// persistent grid, four waves per workgroup, as many workgroups as the registers admit -- but no more resident waves than
-// keep the slabs of all of them inside DSQ_WIDE_SLAB_MB (default 192) of memory: the stages stream a wave's rows once per
-// column chunk, and slabs that fit the 256 MB infinity cache together are served from there instead of from HBM
-struct WideGeom { int grid, waves; size_t lds; bool big_lds; };
+// One workgroup of four waves per gene, persistent grid.  LDS mode whenever a gene's slab fits the CU's 160 KB next to the
+// vectors (as many genes per CU as fit); else the slabs live in global memory: two workgroups per CU by the registers -- but
+// no more resident genes than keep their slabs inside DSQ_WIDE_SLAB_MB (default 192): slabs that fit the 256 MB infinity
+// cache together are served from there instead of from HBM.
+struct WideGeom { int grid, nw; size_t lds; bool big_lds; };
+template <bool USE_W, bool BIG_LDS>
+static const void *wide_fn(int nw) {
+    return nw == 1 ? (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 1> : nw == 2 ? (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 2>
+                                                                                      : (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 4>;
+}
+static const void *wide_fn(bool useW, bool big, int nw) {
+    return useW ? (big ? wide_fn<true, true>(nw) : wide_fn<true, false>(nw)) : (big ? wide_fn<false, true>(nw) : wide_fn<false, false>(nw));
+}
 static WideGeom wide_geometry(int n, int m, int p, bool useW) {
     WideGeom g;
     const size_t cu_lds = 160 * 1024;
     const size_t vec_b = wide_lds_doubles(p) * sizeof(double), slab_b = wide_slab_doubles(m, p) * sizeof(double);
-    static const int force = getenv("DSQ_WIDE_LDS") ? atoi(getenv("DSQ_WIDE_LDS")) : -1;       // 0: never, 1: whenever it fits once
-    const int fit = (int)(cu_lds / (vec_b + slab_b));              // waves per CU with their slabs in LDS
-    g.big_lds = force == 0 ? false : (force == 1 ? fit >= 1 : fit >= 2);
+    static const int force = getenv("DSQ_WIDE_LDS") ? atoi(getenv("DSQ_WIDE_LDS")) : -1;       // 0: never; k > 0: only with k genes per CU
+    static const int force_nw = getenv("DSQ_WIDE_NW") ? atoi(getenv("DSQ_WIDE_NW")) : 0;       // waves per gene (1, 2, 4)
+    const int fit = (int)(cu_lds / (vec_b + slab_b));              // genes per CU with their slabs in LDS
+    g.big_lds = force == 0 ? false : fit >= (force > 0 ? force : 1);
     const int cus = device_cu_count();
     if (g.big_lds) {
-        g.waves = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;                 // per workgroup
-        g.lds = (size_t)g.waves * (vec_b + slab_b);
-        const int bpc = (int)(cu_lds / g.lds);
-        const void *fn = useW ? (const void *)fit_beta_rolled_kernel<true, true> : (const void *)fit_beta_rolled_kernel<false, true>;
-        static thread_local size_t attr_set[2];
-        if (g.lds > 64 * 1024 && attr_set[useW] < g.lds) {
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cu_lds);
-            attr_set[useW] = cu_lds;
-        }
-        long need = ((long)n + g.waves - 1) / g.waves, cap = (long)cus * (bpc < 1 ? 1 : bpc);
-        g.grid = (int)(need < cap ? need : cap);
+        g.lds = vec_b + slab_b;
+        g.nw = fit >= 8 ? 1 : fit >= 4 ? 2 : 4;                    // about eight resident waves per CU
+        if (force_nw == 1 || force_nw == 2 || force_nw == 4) g.nw = force_nw;
+        int bpc = fit;
+        if (bpc * g.nw > 8) bpc = 8 / g.nw;                        // (two waves per SIMD by the registers)
+        if (bpc < 1) bpc = 1;
+        const void *fn = wide_fn(useW, true, g.nw);
+        if (g.lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cu_lds);
+        const long cap = (long)cus * bpc;
+        g.grid = (int)((long)n < cap ? (long)n : cap);
         if (g.grid < 1) g.grid = 1;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in LDS, %d waves/block, lds=%zu, %d blocks/CU\n", p, m, g.waves, g.lds, bpc);
+        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in LDS, lds=%zu, %d waves per gene, %d genes/CU\n", p, m, g.lds, g.nw, bpc);
         return g;
     }
-    g.waves = 4;
-    g.lds = (size_t)g.waves * vec_b;
-    static thread_local int bpc_cache[2];
-    static thread_local size_t lds_cache[2];
-    DSQ_CACHE_PER_DEVICE(bpc_cache, lds_cache);
-    if (lds_cache[useW] != g.lds) { bpc_cache[useW] = 0; lds_cache[useW] = g.lds; }
-    int bpc = bpc_cache[useW];
-    if (bpc == 0) {
-        const void *fn = useW ? (const void *)fit_beta_rolled_kernel<true, false> : (const void *)fit_beta_rolled_kernel<false, false>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, 64 * g.waves, g.lds) != hipSuccess || bpc < 1) bpc = 1;
-        bpc_cache[useW] = bpc;
-        if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in global memory, lds=%zu occupancy-api blocks/CU=%d\n", p, m, g.lds, bpc);
-    }
+    g.lds = vec_b;
+    g.nw = (force_nw == 1 || force_nw == 2 || force_nw == 4) ? force_nw : 4;
+    int bpc = 8 / g.nw;
     static const int slab_mb = getenv("DSQ_WIDE_SLAB_MB") ? atoi(getenv("DSQ_WIDE_SLAB_MB")) : 192;
     long cap = (long)cus * bpc;
-    const size_t per_block = (size_t)g.waves * slab_b;
-    const long fitb = (long)(((size_t)slab_mb << 20) / per_block);
+    const long fitb = (long)(((size_t)slab_mb << 20) / slab_b);
     if (cap > fitb) cap = fitb < cus ? cus : fitb;              // (never below one workgroup per CU)
-    const long need = ((long)n + g.waves - 1) / g.waves;
-    long gr = need < cap ? need : cap;
+    long gr = (long)n < cap ? (long)n : cap;
     if (gr < 1) gr = 1;
     g.grid = (int)gr;
+    if (getenv("DSQ_VERBOSE")) fprintf(stderr, "[dsq] fit_beta_rolled p=%d m=%d: slab in global memory, %d waves per gene, grid %d\n", p, m, g.nw, g.grid);
     return g;
 }
 
 void fit_beta_rolled_scratch_doubles(int n, int m, int p, int useW, size_t *slab, size_t *cscr) {
     const WideGeom g = wide_geometry(n, m, p, useW != 0);
-    *slab = g.big_lds ? 0 : (size_t)g.grid * g.waves * wide_slab_doubles(m, p);
+    *slab = g.big_lds ? 0 : (size_t)g.grid * wide_slab_doubles(m, p);
     *cscr = 0;
 }
 
@@ -543,14 +582,8 @@ hipError_t launch_fit_beta_rolled(const BetaKernelParams &kp0, hipStream_t st) {
     int grid = g.grid;
     // (a row list: its length lives on the device; the scratch was sized for the full grid, a smaller one uses its head)
     if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();
-    if (g.big_lds) {
-        if (kp.useWeights) hipLaunchKernelGGL((fit_beta_rolled_kernel<true, true>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
-        else hipLaunchKernelGGL((fit_beta_rolled_kernel<false, true>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
-    } else {
-        if (kp.useWeights) hipLaunchKernelGGL((fit_beta_rolled_kernel<true, false>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
-        else hipLaunchKernelGGL((fit_beta_rolled_kernel<false, false>), dim3(grid), dim3(64 * g.waves), g.lds, st, kp);
-    }
-    return hipGetLastError();
+    void *args[] = {&kp};
+    return hipLaunchKernel(wide_fn(kp.useWeights != 0, g.big_lds, g.nw), dim3(grid), dim3(64 * g.nw), args, g.lds, st);
 }
 
 }  // namespace dsq
