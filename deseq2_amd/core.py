@@ -378,6 +378,8 @@ def estimateDispersionsGeneEst(dds, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6, max
         raise ValueError("the model matrix is not full rank")                       # checkFullRank :2624
     if x.shape[0] == x.shape[1]:
         raise ValueError("the number of samples and the number of model coefficients are equal")
+    if modelMatrix is not None:
+        dds.attrs["geneEstModelMatrix"] = x           # attr(object, "dispModelMatrix"): estimateDispersionsMAP's default (R/core.R:850, 1003)
     if not (int(niter) == niter and niter > 0):
         raise ValueError("length(niter) == 1 & niter > 0 is not TRUE")              # :730
     getBaseMeansAndVariances(dds)
@@ -616,19 +618,23 @@ def estimateDispersionsPriorVar(dds, minDisp=1e-8):
 
 
 def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, kappa_0=1.0, dispTol=1e-6,
-                           maxit=100, useCR=True, weightThreshold=1e-2):
-    """R/core.R:943-1131"""
+                           maxit=100, useCR=True, weightThreshold=1e-2, modelMatrix=None):
+    """R/core.R:943-1131.  modelMatrix: the caller's design (R/core.R:945, 1003-1005: the Cox-Reid term of the MAP search runs
+    on it); default: the one the gene-wise estimate ran on, else the object's"""
     E = dds.engine
+    if modelMatrix is None:
+        modelMatrix = dds.attrs.get("geneEstModelMatrix")
+    xh = dds.xh if modelMatrix is None else E.design(np.asarray(modelMatrix, np.float64))
     if dispPriorVar is None:
         dispPriorVar = estimateDispersionsPriorVar(dds, minDisp)                     # :986
     dds.dispersionFunction["dispPriorVar"] = dispPriorVar
-    weights, useWeights = getAndCheckWeights(dds, weightThreshold)                   # :999 (no 1e-6 floor here)
+    weights, useWeights = getAndCheckWeights(dds, weightThreshold, modelMatrix=modelMatrix)      # :999 (no 1e-6 floor here)
     dge, dfit = dds.mcols["dispGeneEst"], dds.mcols["dispFit"]
     mu = dds.assays["mu"]
     dispInit = np.where(dge > 0.1 * dfit, dge, dfit)                                 # :1019-1021
     dispInit = np.where(np.isnan(dispInit), dfit, dispInit)
     log_dfit = E.vlog(dfit)
-    res = E.fit_disp(dds.y, dds.xh, mu, E.vlog(dispInit), log_dfit, dispPriorVar, np.log(minDisp / 10),
+    res = E.fit_disp(dds.y, xh, mu, E.vlog(dispInit), log_dfit, dispPriorVar, np.log(minDisp / 10),
                      kappa_0, dispTol, maxit, True, weights, useWeights, weightThreshold, useCR)   # :1027-1039
     dispMAP = E.vexp(res["log_alpha"])
     dispIter = res["iter"]
@@ -636,7 +642,7 @@ def estimateDispersionsMAP(dds, outlierSD=2, dispPriorVar=None, minDisp=1e-8, ka
     refitDisp = ~dispConv
     if refitDisp.sum() > 0:
         idx = np.where(refitDisp)[0]
-        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), dds.xh, E.take_rows(mu, idx),
+        dispGrid = fitDispGridWrapper(E, E.take_rows(dds.y, idx), xh, E.take_rows(mu, idx),
                                       log_dfit[idx], dispPriorVar, True, E.take_rows(weights, idx),
                                       useWeights, weightThreshold, True, dds.m)      # :1051-1061
         dispMAP[refitDisp] = dispGrid
@@ -657,7 +663,7 @@ def estimateDispersions(dds, fitType="parametric", maxit=100, dispPriorVar=None,
     residual df <= 3 gets its prior variance (R's estimate there needs R's RNG, :1155-1190)."""
     estimateDispersionsGeneEst(dds, maxit=maxit, **kw)
     estimateDispersionsFit(dds, fitType=fitType)
-    estimateDispersionsMAP(dds, maxit=maxit, dispPriorVar=dispPriorVar)
+    estimateDispersionsMAP(dds, maxit=maxit, dispPriorVar=dispPriorVar, modelMatrix=kw.get("modelMatrix"))   # (R/methods.R:546)
     return dds
 
 
@@ -965,7 +971,8 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
     # the refit runs estimateDispersionsGeneEst / MAP and nbinomWaldTest / nbinomLRT on their DEFAULTS: DESeq()'s betaTol,
     # maxit, useQR, minmu, useT, df are not handed on (:2509-2531) -- refitted rows carry normal-distribution p-values
     # even in a useT analysis
-    # ... but the caller's model matrix IS (modelMatrix = modelMatrix in all three calls of the refit, :2509-2527)
+    # ... but the caller's model matrix IS (modelMatrix = modelMatrix in the gene-wise estimate, the MAP estimate and the test of
+    # the refit, :2509-2527)
     kw = {k: v for k, v in kw.items() if k == "modelMatrix" and v is not None}
     replaceOutliers(dds, minReplicates=minReplicatesForReplace)
     if "replace" not in dds.mcols:
@@ -992,7 +999,7 @@ def refitWithoutOutliers(dds, test="Wald", reduced=None, minReplicatesForReplace
         sub = whole if keep.all() else dds.subset(refitReplace, dds.assays["replaceCounts"])
         estimateDispersionsGeneEst(sub, maxit=disp_maxit, **kw)                       # :2509
         sub.mcols["dispFit"] = _dispersion_function(dds, sub.mcols["baseMean"])       # :2512
-        estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"], maxit=disp_maxit)   # :2518-2519
+        estimateDispersionsMAP(sub, dispPriorVar=dds.dispersionFunction["dispPriorVar"], maxit=disp_maxit, **kw)   # :2518-2519
         if test == "Wald":
             nbinomWaldTest(sub, betaPrior=dds.attrs.get("betaPrior", False), betaPriorVar=(
                 dds.attrs["betaPriorVar"] if dds.attrs.get("betaPrior", False) else None),

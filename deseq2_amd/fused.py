@@ -430,7 +430,7 @@ def _global_refit_count(run, comm_device, t):
 def finish(dds):
     """the second half of DESeq(dds, wait=False): waits for the result block and fills in mcols / assays / attrs"""
     f = dds.__dict__.pop("_fused_pending", None)
-    return f() if f is not None else dds
+    return f(dds) if f is not None else dds
 
 
 def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesForReplace=7, comm_device=None,
@@ -439,8 +439,9 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
     chain.  With torch.distributed initialised, `dds` is this rank's gene shard and the dispersion trend is fitted
     over the gathered (baseMean, dispGeneEst) of all ranks.
 
-    wait = False (single process): returns as soon as the chain and the copy of its result block are ENQUEUED; the
-    object is complete after fused.finish(dds).  A loop over analyses then keeps the device busy while the host
+    wait = False (single process): returns as soon as the chain is ENQUEUED; the object is complete after
+    fused.finish(dds), which enqueues the copy of the result block (side stream), waits for it and builds the columns --
+    input errors the device detects (negative weights, all-zero counts, a trend that does not fit) surface THERE.  A loop over analyses then keeps the device busy while the host
     prepares the next one and post-processes the previous one, and the result copy (a side stream) runs beside the
     next chain's kernels -- bench.py's pipelined steps."""
     if not supported(dds, test=test, reduced=reduced, fitType=fitType, minReplicatesForReplace=minReplicatesForReplace, **kw):
@@ -547,12 +548,13 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST)
         early_host, early_done = run.early_loglike()
         run.launch(L.DSQ_PH_OUTLIERS)
+        p_full = dds.p                        # (the closure below must not hold `dds`: see _finish)
 
         def early():                          # (first thing of _finish below)
             early_done.synchronize()
             eh = early_host.numpy()
             e = 2 * (eh[:n] - eh[n:])
-            return e, core.pchisq_upper(e, dds.p - run.p_red)            # (the device is in the outlier phase meanwhile)
+            return e, core.pchisq_upper(e, p_full - run.p_red)            # (the device is in the outlier phase meanwhile)
     elif world == 1:
         run.launch(L.DSQ_PH_GENE_EST | L.DSQ_PH_TREND | L.DSQ_PH_MAP_TEST | L.DSQ_PH_OUTLIERS)
     else:
@@ -566,7 +568,10 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         run.n_refit_all = _global_refit_count(run, comm_device, t)
         run.args.n_refit_global = _ptr(run.n_refit_all)
         run.launch(L.DSQ_PH_FINISH)
-    def _finish():
+    def _finish(dds):
+        # (`dds` is a PARAMETER: the closure holds the run and the call's settings, not the data set -- an analysis enqueued
+        #  with wait = False hangs this function on dds._fused_pending, and a dds -> closure -> dds cycle would keep its
+        #  n x m device buffers until the cyclic collector runs)
         early_v = early() if early is not None else None
         st, sc, hv, hm, hi, hmle = run.read_all()
         st2 = st
@@ -671,7 +676,7 @@ def DESeq(dds, test="Wald", fitType="parametric", reduced=None, minReplicatesFor
         return dds
 
     if wait or world > 1:
-        return _finish()
+        return _finish(dds)
     run.mark_ready()
     dds._fused_pending = _finish
     return dds

@@ -3,6 +3,10 @@
 --stats` on ROCm 7.2) into the per-kernel table kept under profiles/.
 usage: python profiles/summarize_rocpd.py gpurun_out/prof/x_results.db > profiles/rNN_kernel_stats.md"""
 import sqlite3
+
+NOTE = ("(* `arch vgpr`: the vgpr_count rocprofv3 records for the dispatch (architectural registers). The code object's own "
+        ".vgpr_count -- the unified allocation that bounds the occupancy on gfx950, accumulation registers included -- is "
+        "listed in profiles/rNN_isa_mix.md (fit_disp<4>: 84 here, 166 there).)")
 import sys
 
 
@@ -14,7 +18,8 @@ def main(path, top=18):
         "max(grid_x), max(workgroup_x) from kernels group by name, grid_x order by 3 desc").fetchall()
     # one row per (kernel, grid): DESeq()'s outlier refit re-launches the fit kernels on a handful of rows
     tot = sum(r[2] for r in rows)
-    print("| kernel | calls | total ms | avg ms | min ms | max ms | % GPU time | vgpr | agpr | sgpr | LDS B | scratch B | grid | wg |")
+    print(NOTE + "\n")
+    print("| kernel | calls | total ms | avg ms | min ms | max ms | % GPU time | arch vgpr* | agpr | sgpr | LDS B | scratch B | grid | wg |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows[:top]:
         print("| `%s` | %d | %.3f | %.3f | %.3f | %.3f | %.1f | %s | %s | %s | %s | %s | %s | %s |" %
