@@ -1660,6 +1660,13 @@ static void beta_geometry(int n, int m, bool useW, int *waves, bool *stage, int 
 #error "compile with -DDSQ_P=<number of design columns>"
 #endif
 
+// narrowest width whose designs WITHOUT cells take the rolled kernel of fit_beta_wide.hip instead of this file's general
+// kernel (DSQ_ROLLED_MINP; the wide builds always do)
+static inline int rolled_minp() {
+    static const int v = getenv("DSQ_ROLLED_MINP") ? atoi(getenv("DSQ_ROLLED_MINP")) : DSQ_BETA_ROLLED_MIN;
+    return v;
+}
+
 template <>
 void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_t *cscr) {
 #if DSQ_P >= DSQ_BETA_ROLLED_MIN
@@ -1671,6 +1678,11 @@ void fit_beta_scratch_doubles<DSQ_P>(int n, int m, int useW, size_t *slab, size_
     beta_geometry<DSQ_P>(n, m, useW != 0, &waves, &stage, &xlds, &grid, &lds);
     *slab = stage ? 0 : (size_t)grid * waves * (size_t)m * kSlabVecs;
     *cscr = 0;      // (the hoisted NB-density constants are gone: the deviance needs no per-sample scratch row)
+    if (DSQ_P >= rolled_minp()) {        // (the general designs of this width on the rolled kernel: the larger of the two)
+        size_t s2 = 0, c2 = 0;
+        fit_beta_rolled_scratch_doubles(n, m, DSQ_P, useW, &s2, &c2);
+        if (s2 > *slab) *slab = s2;
+    }
 #endif
 }
 
@@ -1681,6 +1693,7 @@ hipError_t launch_fit_beta_p<DSQ_P>(const BetaKernelParams &kp0, hipStream_t st)
 #if DSQ_P >= DSQ_BETA_ROLLED_MIN
     return launch_fit_beta_rolled(kp0, st);
 #else
+    if (DSQ_P >= rolled_minp()) return launch_fit_beta_rolled(kp0, st);
     int waves, grid, xlds;
     bool stage;
     size_t lds;
