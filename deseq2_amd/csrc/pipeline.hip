@@ -789,13 +789,25 @@ __global__ void __launch_bounds__(256) masked_max_kernel(Rows rw, int m, long ld
 // listed by DESCENDING iteration count of the first fit: the slow genes start first, the quick ones fill the gaps
 // (longest-processing-time-first).  A counting sort by one workgroup; the order inside a bin is whatever the atomics give --
 // every gene's results are written at its own position and no kernel couples two genes, so the order changes no bit.
-__global__ void __launch_bounds__(1024) lpt_order_kernel(Rows rw, const int32_t *key_i, const double *key_d, int32_t *out) {
+// What an order can and cannot do at 6 250 genes on 3 072 slots (a simulation on the iteration counts of that workload,
+// cost = iterations): fit_beta in list order ends at 2.5x the ideal, longest-first at 1.8x = the slowest single gene (19
+// iterations) -- the floor of any order; the dispersion searches end at 1.4x either way: 6 250 = 2.03 x 3 072, the last
+// hundred genes are a third round whatever the order.
+// small_first: the key is a MEAN COUNT and the slow genes are the ones with few counts (the gene-wise IRLS, which has no
+// earlier fit to go by: its iteration count falls with log(baseMean), correlation -0.84 at C3) -- the bins are sixths of
+// an octave of 1 + mean, taken in ascending order.
+__global__ void __launch_bounds__(1024) lpt_order_kernel(Rows rw, const int32_t *key_i, const double *key_d, int small_first,
+                                                         int32_t *out) {
     __shared__ int hist[128], cursor[128];
     const int cnt = rows_count(rw);
     if (threadIdx.x < 128) hist[threadIdx.x] = 0;
     __syncthreads();
     auto key_of = [&](int g) {
         double kd = key_i ? (double)key_i[g] : key_d[g];
+        if (small_first) {
+            kd = 127.0 - 8.656170245333781 * dlog(1.0 + kd);      // 6 / ln 2: a mean of 2^21 reaches bin 0
+            if (kd < 0.0) kd = 0.0;
+        }
         if (!(kd >= 0.0)) kd = 127.0;             // (NaN: an aborted fit -- treat as long)
         return kd > 127.0 ? 127 : (int)kd;
     };
@@ -1098,6 +1110,17 @@ static int launch_optim(Pipe &P, int cnt_optim, const int32_t *y, const double *
     return DSQ_OK;
 }
 
+// the rows of a full-size launch in longest-expected-first order (see lpt_order_kernel); DSQ_LPT=0 switches it off
+static Rows lpt_rows(Pipe &P, const Rows &rw, const int32_t *key_i, const double *key_d, int small_first = 0) {
+    // only where it pays: below ~ 5 genes per resident wave slot (measured, C3 shapes: 6 250 genes fit_beta 0.305 -> 0.256 ms;
+    // 50 000 genes: the launch gains 0.03 ms and the one-workgroup sort in front of it costs 0.1)
+    static const bool on = !(getenv("DSQ_LPT") && atoi(getenv("DSQ_LPT")) == 0);
+    static const int maxn = getenv("DSQ_LPT_MAXN") ? atoi(getenv("DSQ_LPT_MAXN")) : 16384;
+    if (!on || rw.rows != P.rows_nz || P.n > maxn) return rw;
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, P.st, rw, key_i, key_d, small_first, P.rows_lpt);
+    return Rows{P.rows_lpt, rw.n_dev, rw.n};
+}
+
 // estimateDispersionsGeneEst on the rows `rw` of the count matrix y (R/core.R:657-860, niter = 1); mu-hat -> mu_hat
 static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, int cnt_grid, int cnt_optim,
                     int32_t *optim_flag) {
@@ -1121,7 +1144,9 @@ static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, i
         // to the optim fallback are flagged for the caller
         // (the arguments of THIS fitNbinomGLMs call are its defaults -- betaTol 1e-8, maxit 100, QR, the IRLS's own minmu
         // 0.5, R/core.R:755-757; the caller's minmu is the FLOOR of the fitted means it hands to the search, :763)
-        rc = launch_fit_beta(P, rw, y, P.alpha_init, a->weights_norm, mu_hat, P.ge_floor, nullptr, 1e-8, 100, 1, 0.5, "fit_beta");
+        // (small launches: the rows with the fewest counts first -- they take the most iterations; see lpt_order_kernel)
+        rc = launch_fit_beta(P, lpt_rows(P, rw, nullptr, P.o->baseMean, 1), y, P.alpha_init, a->weights_norm, mu_hat, P.ge_floor, nullptr,
+                             1e-8, 100, 1, 0.5, "fit_beta");
         if (rc) return rc;
         RuleParams b = rule_params(P, rw);
         b.betaMaxit = 100;
@@ -1141,16 +1166,6 @@ static int gene_est(Pipe &P, const Rows &rw, const int32_t *y, double *mu_hat, i
     hipLaunchKernelGGL(gene_est_final_kernel, ew_grid(P.n), dim3(256), 0, P.st, q);
     PIPE_HIP(hipGetLastError());
     return DSQ_OK;
-}
-
-// the rows of a full-size launch in longest-expected-first order (see lpt_order_kernel); DSQ_LPT=0 switches it off
-static Rows lpt_rows(Pipe &P, const Rows &rw, const int32_t *key_i, const double *key_d) {
-    // only where it pays: below ~ 5 genes per resident wave slot (measured, C3 shapes: 6 250 genes fit_beta 0.305 -> 0.256 ms;
-    // 50 000 genes: the launch gains 0.03 ms and the one-workgroup sort in front of it costs 0.1)
-    static const bool on = !(getenv("DSQ_LPT") && atoi(getenv("DSQ_LPT")) == 0);
-    if (!on || rw.rows != P.rows_nz || P.n > 16384) return rw;
-    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, P.st, rw, key_i, key_d, P.rows_lpt);
-    return Rows{P.rows_lpt, rw.n_dev, rw.n};
 }
 
 // estimateDispersionsMAP (R/core.R:943-1131) on the rows `rw`
@@ -1287,7 +1302,9 @@ static int test_fit(Pipe &P, const Rows &rw, const int32_t *y, double *mu_out, d
     const DsqDeseqOut *o = P.o;
     if (a->betaPrior) return mle_fit(P, rw, y, mu_out, hat);         // (the prior fit follows once lambda is known)
     // (P.beta_iter: the iteration counts of the gene-wise estimate's IRLS on the same rows, when that fit ran)
-    int rc = launch_fit_beta(P, a->linearMu ? rw : lpt_rows(P, rw, nullptr, P.beta_iter), y, o->dispersion, a->weights_norm, mu_out, 0.0, hat,
+    static const bool by_mean = getenv("DSQ_LPT_KEY2") && atoi(getenv("DSQ_LPT_KEY2")) == 1;
+    int rc = launch_fit_beta(P, by_mean ? lpt_rows(P, rw, nullptr, o->baseMean, 1) : (a->linearMu ? rw : lpt_rows(P, rw, nullptr, P.beta_iter)),
+                             y, o->dispersion, a->weights_norm, mu_out, 0.0, hat,
                              P.t_tol, P.t_maxit, P.t_useQR, P.t_minmu, "fit_beta");
     if (rc) return rc;
     LogLikeKernelParams lk;
