@@ -110,9 +110,31 @@ DSQ_DEV double double_of(uint64_t k) {
     return bits2d(u);
 }
 
+// the rank-th smallest (0-based) of the <= kSelDirect keys in `keys` (LDS), by counting: thread t takes key t and counts the
+// keys that sort before it (smaller, or equal with a smaller index); exactly one thread finds `rank` and publishes its key
+static constexpr int kSelDirect = 1024;       // = hist[2048] reinterpreted as 64-bit keys
+DSQ_DEV uint64_t rank_direct(const uint64_t *keys, int cnt, long rank, unsigned long long *bc) {
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        const uint64_t mine = keys[t];
+        int before = 0;
+        for (int j = 0; j < cnt; j++) {
+            const uint64_t o = keys[j];
+            before += (o < mine || (o == mine && j < t)) ? 1 : 0;
+        }
+        if (before == (int)rank) bc[0] = mine;
+    }
+    __syncthreads();
+    const uint64_t r = bc[0];
+    __syncthreads();
+    return r;
+}
+
 template <class F>
 DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc) {
     // the rank-th smallest (0-based) of value(i), i < n; every thread returns it.  Digits of 11, 11, 11, 11, 11, 9 bits.
+    // (r6) Once the candidates left (the keys that share the digits chosen so far) fit the histogram's LDS -- after two
+    // passes, usually: the first 22 bits of a double leave a handful of 50 000 residuals -- they are gathered there and the
+    // order statistic is taken by direct counting: three passes over the values instead of six, the same (exact) result.
     uint64_t prefix = 0, mask = 0;
     int shift = 64;
     while (shift > 0) {
@@ -133,6 +155,7 @@ DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigne
         if (threadIdx.x < 64) {
             long r = rank;
             int found = -1;
+            unsigned inbin = 0;
             for (unsigned b0 = 0; b0 < nb && found < 0; b0 += 64) {
                 const unsigned h = hist[b0 + threadIdx.x];
                 unsigned incl = h;                              // inclusive prefix over the 64 lanes
@@ -146,18 +169,31 @@ DSQ_DEV double block_select(int n, long rank, F &&value, unsigned *hist, unsigne
                     const int l = __ffsll((long long)m) - 1;
                     const unsigned before = __shfl(incl, l, 64) - __shfl(h, l, 64);
                     found = (int)b0 + l;
+                    inbin = __shfl(h, l, 64);
                     r -= (long)before;
                 } else {
                     r -= (long)tot;
                 }
             }
-            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; }
+            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; bc[2] = found < 0 ? 0ull : inbin; }
         }
         __syncthreads();
         prefix |= (uint64_t)bc[0] << shift;
         mask |= (uint64_t)(nb - 1u) << shift;
         rank = (long)bc[1];
+        const unsigned left = (unsigned)bc[2];
         __syncthreads();
+        if (shift > 0 && left > 0 && left <= (unsigned)kSelDirect) {
+            uint64_t *keys = reinterpret_cast<uint64_t *>(hist);
+            if (threadIdx.x == 0) bc[2] = 0ull;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint64_t k = key_of(value(i));
+                if ((k & mask) == prefix) keys[atomicAdd(&bc[2], 1ull)] = k;
+            }
+            __syncthreads();
+            return double_of(rank_direct(keys, (int)left, rank, bc));
+        }
     }
     return double_of(prefix);
 }
@@ -189,8 +225,8 @@ __global__ void __launch_bounds__(1024) prior_var_kernel(const double *mean, con
                                                          double expVarLogDisp, int m_gt_p, double *resbuf,
                                                          double *scalars, int32_t *status, const double *fit_in,
                                                          double pv_in) {
-    __shared__ unsigned hist[2048];
-    __shared__ unsigned long long bc[2];
+    __shared__ __attribute__((aligned(16))) unsigned hist[2048];
+    __shared__ unsigned long long bc[3];
     __shared__ int kshared;
     const double inf = __builtin_inf();
     const double c0 = scalars[DSQ_SC_COEF0], c1 = scalars[DSQ_SC_COEF1];
@@ -248,6 +284,10 @@ struct SelWs {
     unsigned long long cnt[8];
     unsigned long long inv_min[8];       // ~key of the smallest value above a median candidate (atomicMax; zero = none)
     unsigned int ghist[16][2048];
+    // (r6) the early exit of a selection: the candidates left after a pass, gathered by all workgroups (one list and one fill
+    // counter per selection: a launch makes two)
+    unsigned long long gfill[2];
+    unsigned long long glist[2][1024];
 };
 size_t prior_var_workspace_bytes() { return sizeof(SelWs); }
 
@@ -270,7 +310,7 @@ DSQ_DEV void sel_barrier(SelWs *ws) {
 }
 
 template <class F>
-DSQ_DEV double grid_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc, SelWs *ws, int &phase) {
+DSQ_DEV double grid_select(int n, long rank, F &&value, unsigned *hist, unsigned long long *bc, SelWs *ws, int &phase, int slot) {
     uint64_t prefix = 0, mask = 0;
     int shift = 64;
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
@@ -293,6 +333,7 @@ DSQ_DEV double grid_select(int n, long rank, F &&value, unsigned *hist, unsigned
         if (threadIdx.x < 64) {
             long r = rank;
             int found = -1;
+            unsigned inbin = 0;
             for (unsigned b0 = 0; b0 < nb && found < 0; b0 += 64) {
                 const unsigned h = hist[b0 + threadIdx.x];
                 unsigned incl = h;
@@ -306,26 +347,43 @@ DSQ_DEV double grid_select(int n, long rank, F &&value, unsigned *hist, unsigned
                     const int l = __ffsll((long long)m) - 1;
                     const unsigned before = __shfl(incl, l, 64) - __shfl(h, l, 64);
                     found = (int)b0 + l;
+                    inbin = __shfl(h, l, 64);
                     r -= (long)before;
                 } else {
                     r -= (long)tot;
                 }
             }
-            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; }
+            if (threadIdx.x == 0) { bc[0] = (unsigned long long)(found < 0 ? (int)nb - 1 : found); bc[1] = (unsigned long long)r; bc[2] = found < 0 ? 0ull : inbin; }
         }
         __syncthreads();
         prefix |= (uint64_t)bc[0] << shift;
         mask |= (uint64_t)(nb - 1u) << shift;
         rank = (long)bc[1];
+        const unsigned left = (unsigned)bc[2];
         __syncthreads();
         phase++;
+        // (r6) the candidates left fit one LDS list: every workgroup appends its own to the launch's global list, a grid
+        // barrier, then each workgroup ranks the whole list itself (see block_select) -- the same decision in every
+        // workgroup: `left` comes from the shared histogram
+        if (shift > 0 && left > 0 && left <= (unsigned)kSelDirect) {
+            for (long i = first; i < n; i += stride) {
+                const uint64_t k = key_of(value((int)i));
+                if ((k & mask) == prefix) ws->glist[slot][atomicAdd(&ws->gfill[slot], 1ull)] = k;
+            }
+            sel_barrier(ws);
+            uint64_t *keys = reinterpret_cast<uint64_t *>(hist);
+            for (unsigned t = threadIdx.x; t < left; t += blockDim.x)
+                keys[t] = __hip_atomic_load(&ws->glist[slot][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            return double_of(rank_direct(keys, (int)left, rank, bc));
+        }
     }
     return double_of(prefix);
 }
 
 template <class F>
 DSQ_DEV double grid_median(int n, long k, F &&value, unsigned *hist, unsigned long long *bc, SelWs *ws, int &phase, int slot) {
-    const double a = grid_select(n, (k - 1) / 2, value, hist, bc, ws, phase);
+    const double a = grid_select(n, (k - 1) / 2, value, hist, bc, ws, phase, slot);
     if (k & 1) return a;
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
     unsigned long long le = 0, inv = 0;
@@ -346,8 +404,8 @@ DSQ_DEV double grid_median(int n, long k, F &&value, unsigned *hist, unsigned lo
 __global__ void __launch_bounds__(1024) prior_var_grid_kernel(const double *mean, const double *disp, int n, double minDisp,
                                                               double expVarLogDisp, int m_gt_p, double *resbuf, double *scalars,
                                                               int32_t *status, const double *fit_in, double pv_in, SelWs *ws) {
-    __shared__ unsigned hist[2048];
-    __shared__ unsigned long long bc[2];
+    __shared__ __attribute__((aligned(16))) unsigned hist[2048];
+    __shared__ unsigned long long bc[3];
     const double inf = __builtin_inf();
     const double c0 = scalars[DSQ_SC_COEF0], c1 = scalars[DSQ_SC_COEF1];
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)blockDim.x * kSelBlocks;
@@ -458,8 +516,8 @@ DSQ_DEV double u192_mean(const U192 &S, uint64_t cnt) {   // RN-even(S / cnt) 2^
 // the constant: COEF0 = the mean, COEF1 = 0 (dispFit = COEF0 + COEF1 / baseMean is that constant, exactly).
 __global__ void __launch_bounds__(1024) trend_mean_kernel(const double *disp, int n, double minDisp, int mode, double *scalars,
                                                           int32_t *status) {
-    __shared__ unsigned hist[2048];
-    __shared__ unsigned long long bc[2];
+    __shared__ __attribute__((aligned(16))) unsigned hist[2048];
+    __shared__ unsigned long long bc[3];
     __shared__ unsigned long long cnts[5];
     __shared__ U192 part[1024];
     if (mode == DSQ_FIT_PARAMETRIC_OR_MEAN && status[DSQ_ST_TREND_STATUS] == 0) return;
