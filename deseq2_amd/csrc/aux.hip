@@ -797,6 +797,14 @@ hipError_t launch_trend_fit_dev(const double *means, const double *disps, const 
     return hipGetLastError();
 }
 
+// ... with the workspace already zeroed by the caller (the chain's one init launch, pipeline.hip)
+hipError_t launch_trend_fit_dev_zeroed(const double *means, const double *disps, const int32_t *n_dev, double *coefs,
+                                       int32_t *status, void *workspace, hipStream_t st) {
+    hipLaunchKernelGGL(trend_fit_kernel, dim3(kTrendBlocks), dim3(1024), 0, st, means, disps, 0L, n_dev, coefs, status,
+                       (TrendWs *)workspace);
+    return hipGetLastError();
+}
+
 static inline int aux_grid(int n) {
     int blocks = (n + 3) / 4;
     int cap = device_cu_count() * 8;

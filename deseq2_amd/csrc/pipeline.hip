@@ -25,6 +25,9 @@ namespace dsq {
 
 hipError_t launch_trend_fit_dev(const double *means, const double *disps, const int32_t *n_dev, double *coefs,
                                 int32_t *status, void *workspace, hipStream_t st);
+hipError_t launch_trend_fit_dev_zeroed(const double *means, const double *disps, const int32_t *n_dev, double *coefs,
+                                       int32_t *status, void *workspace, hipStream_t st);
+size_t trend_fit_workspace_bytes();
 
 // numpy.minimum / numpy.maximum: NaN if either operand is NaN
 DSQ_DEV double np_min(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? a : b); }
@@ -787,7 +790,11 @@ __global__ void na_rows_kernel(NaRowsParams q) {
 // the n x m assays of the rows that were never fitted (all-zero counts, or weights that leave a degenerate design): NA, as
 // buildMatrixWithNARows leaves them in R -- the kernels skip those rows, so without this they keep whatever the buffer
 // held (found by the 8-range host-entry test of round 5: two calls returned different garbage there)
-__global__ void __launch_bounds__(256) na_assay_rows_kernel(int n, int m, long ld, const int32_t *allZero, double *a0, double *a1) {
+__global__ void __launch_bounds__(256) na_assay_rows_kernel(int n, int m, long ld, const int32_t *allZero, double *a0, double *a1,
+                                                            int32_t *zero_p = nullptr, int zero_n = 0) {
+    // (zero_p: the row-list counters of the outlier phase that follows in the same call -- a memset of 8 int32 at an odd
+    //  offset is three fill commands of the runtime)
+    if (blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero_p[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;            // one gene per lane for the flag ...
     unsigned long long todo = __ballot(g < n && allZero[g] != 0);
@@ -1695,6 +1702,22 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         }
     }
     if (a->phases & DSQ_PH_TREND) fill_words(o->scalars + DSQ_SC_FIT_USED, sizeof(double), 0u);     // 0.0 = DSQ_FIT_PARAMETRIC
+    void *tws_zeroed = nullptr;          // the trend fit's barrier / partial-sum block, zeroed by the same launch
+    if ((a->phases & DSQ_PH_TREND) && !a->dispFit_in && a->fitType != DSQ_FIT_MEAN) {
+        rc = capi_ws_get(DSQ_WS_PIPE_META, trend_fit_workspace_bytes() + 64, &tws_zeroed);
+        if (rc) return rc;
+        fill_words(tws_zeroed, (trend_fit_workspace_bytes() + 3) / 4 * 4, 0u);
+    }
+    void *sws_zeroed = nullptr;          // ... and the selection workspace of the sixteen-workgroup prior variance
+    if (a->phases & DSQ_PH_TREND) {
+        static const int one_block = getenv("DSQ_PRIOR_VAR_ONE_BLOCK") ? atoi(getenv("DSQ_PRIOR_VAR_ONE_BLOCK")) : 0;
+        const int nt_ = a->trend_mean ? a->n_trend : n;
+        if (!(one_block || nt_ < 16384)) {     // (6 250 genes: 0.116 ms on one workgroup, 0.146 on sixteen; 50 000: 0.243 / 0.124)
+            rc = capi_ws_get(DSQ_WS_PIPE_SEL, prior_var_workspace_bytes() + 64, &sws_zeroed);
+            if (rc) return rc;
+            fill_words(sws_zeroed, (prior_var_workspace_bytes() + 3) / 4 * 4, 0u);
+        }
+    }
     {
         size_t words = 0;
         for (int sgi = 0; sgi < ip.nseg; sgi++) words += ip.seg[sgi].words;
@@ -1789,8 +1812,8 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
             hipLaunchKernelGGL(trend_given_kernel, dim3(1), dim3(1), 0, st, o->scalars, o->status);
         } else {
             if (a->fitType != DSQ_FIT_MEAN)
-                PIPE_HIP(launch_trend_fit_dev(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
-                                              o->status + DSQ_ST_TREND_STATUS, tws, st));
+                PIPE_HIP(launch_trend_fit_dev_zeroed(P.trend_mean_c, P.trend_disp_c, P.counters + CNT_TREND, o->scalars + DSQ_SC_COEF0,
+                                                     o->status + DSQ_ST_TREND_STATUS, tws_zeroed, st));
             if (a->fitType != DSQ_FIT_PARAMETRIC)            // R/core.R:894-899 over the same vector, uncompacted
                 hipLaunchKernelGGL(trend_mean_kernel, dim3(1), dim3(1024), 0, st, td, nt, a->minDisp, (int)a->fitType, o->scalars, o->status);
         }
@@ -1798,23 +1821,18 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         capi_prof_begin("prior_var", nt, st);
         {
             const double *fin = a->dispFit_in ? (a->trend_mean ? a->trend_fit_in : a->dispFit_in) : (const double *)nullptr;
-            static const int one_block = getenv("DSQ_PRIOR_VAR_ONE_BLOCK") ? atoi(getenv("DSQ_PRIOR_VAR_ONE_BLOCK")) : 0;
-            if (one_block || nt < 16384)          // (6 250 genes: 0.116 ms on one workgroup, 0.146 on sixteen; 50 000: 0.243 / 0.124)
+            if (!sws_zeroed)
                 hipLaunchKernelGGL(prior_var_kernel, dim3(1), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
                                    (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status, fin, a->dispPriorVar_in);
-            else {
-                void *sws;
-                rc = capi_ws_get(DSQ_WS_PIPE_SEL, prior_var_workspace_bytes() + 64, &sws);
-                if (rc) return rc;
-                PIPE_HIP(hipMemsetAsync(sws, 0, prior_var_workspace_bytes(), st));
+            else
                 hipLaunchKernelGGL(prior_var_grid_kernel, dim3(kSelBlocks), dim3(1024), 0, st, tm, td, nt, a->minDisp, a->expVarLogDisp,
-                                   (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status, fin, a->dispPriorVar_in, (SelWs *)sws);
-            }
+                                   (m > p) ? 1 : 0, P.resbuf, o->scalars, o->status, fin, a->dispPriorVar_in, (SelWs *)sws_zeroed);
         }
         capi_prof_end(st);
         PIPE_HIP(hipGetLastError());
     }
     // ================================================================ MAP dispersions + test
+    bool counters_zeroed = false;
     if (a->phases & DSQ_PH_MAP_TEST) {
         if (!with_gene_est) {            // (else still zero from the status fill: nothing in between counts into them)
             PIPE_HIP(hipMemsetAsync(P.counters + CNT_GRID2, 0, sizeof(int32_t), st));
@@ -1825,7 +1843,11 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         if (rc) return rc;
         rc = test_fit(P, nz, a->y, o->mu, o->H, CNT_OPT2);
         if (rc) return rc;
-        hipLaunchKernelGGL(na_assay_rows_kernel, ew_grid(n), dim3(256), 0, st, n, m, P.ld, (const int32_t *)o->allZero, o->mu, o->H);
+        // (the counters of the outlier phase -- REP .. OPT3R -- are zeroed here when that phase follows in this call and no
+        //  beta-prior pass, which counts into OPT3, comes in between)
+        counters_zeroed = (a->phases & (DSQ_PH_OUTLIERS | DSQ_PH_OUTLIERS_DETECT)) && !((a->phases & DSQ_PH_PRIOR) && a->betaPrior);
+        hipLaunchKernelGGL(na_assay_rows_kernel, ew_grid(n), dim3(256), 0, st, n, m, P.ld, (const int32_t *)o->allZero, o->mu, o->H,
+                           counters_zeroed ? P.counters + CNT_REP : (int32_t *)nullptr, counters_zeroed ? (int)(CNT_N - CNT_REP) : 0);
     }
     // ================================================================ betaPrior: the pass with lambda = 1 / betaPriorVar
     if ((a->phases & DSQ_PH_PRIOR) && a->betaPrior) {
@@ -1845,7 +1867,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         int32_t *dperm = M.dperm, *din3 = M.din3, *drepl = M.drepl, *dstart = M.dstart;
         const int any3 = M.any3, maxcell = M.maxcell;
       if (ph_detect) {
-        PIPE_HIP(hipMemsetAsync(P.counters + CNT_REP, 0, (CNT_N - CNT_REP) * sizeof(int32_t), st));      // REP .. OPT3R
+        if (!counters_zeroed) PIPE_HIP(hipMemsetAsync(P.counters + CNT_REP, 0, (CNT_N - CNT_REP) * sizeof(int32_t), st));      // REP .. OPT3R
 
         CooksKernelParams ck;
         memset(&ck, 0, sizeof ck);

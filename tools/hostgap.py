@@ -5,7 +5,7 @@ import bench
 from deseq2_amd import core, fused, simulate
 from deseq2_amd.engine import DeviceEngine
 cfg = dict(bench.CONFIGS["C3"]); m = cfg["samples"]; x = bench.make_design(cfg["design"], m)
-d = simulate.make_counts(cfg["genes"], x, seed=1); counts = d["counts"]; n = counts.shape[0]
+d = simulate.make_counts(int(sys.argv[1]) if len(sys.argv) > 1 else cfg["genes"], x, seed=1); counts = d["counts"]; n = counts.shape[0]
 dev = torch.device("cuda", 0); E = DeviceEngine(dev)
 counts_r = torch.as_tensor(np.ascontiguousarray(counts.T), device=dev)
 nf_r = torch.ones((m, n), dtype=torch.float64, device=dev)
@@ -16,6 +16,9 @@ def w(name, f):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); mark(name, t0); return r
     return g
+fused._design_facts = w("design_facts", fused._design_facts)
+E._design_qr_dev = w("design_qr_dev", E._design_qr_dev); E.design = w("design", E.design)
+fused._Run.start_read = w("start_read", fused._Run.start_read)
 fused._Run.__init__ = w("run_init", orig_init); fused._Run.launch = w("launch", orig_launch); fused._Run.read_all = w("read_all(sync)", orig_read); fused.supported = w("supported", orig_sup)
 core.DESeqDataSet.from_device = classmethod(w("from_device", core.DESeqDataSet.from_device.__func__))
 def step():
