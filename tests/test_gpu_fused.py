@@ -477,12 +477,15 @@ def test_pipelined_analyses_equal_the_waiting_ones(E):
 
 
 def test_pipelined_analyses_of_different_designs(E):
-    """three analyses with DIFFERENT designs (p = 4 / 6 / 2, other cells, other sample counts) enqueued back to back before
+    """six analyses with DIFFERENT designs (p = 4 / 4 / 6 / 2 / 5 / 4, other cells, other sample counts) enqueued back to back before
     any is finished: each chain's small host-side tables (ridge, design cells, outlier metadata) must have left the host
     by the time the call returns -- the next call overwrites them -- and the library's device scratch is shared
     stream-ordered; results equal the one-call-at-a-time ones"""
-    designs = [simulate.design_batch_condition(48), simulate.design_factor(42, 6), simulate.design_two_group(16),
-               np.column_stack([simulate.design_batch_condition(36), np.random.default_rng(1).normal(size=36)])]
+    # (round 6: the tables go up through a pinned ring and only when a slot's bytes change -- designs 0, 1 and 5 have the same
+    #  shape (48 samples, 4 columns) and different cells, 0 and 5 are the same design: A, B, ..., A in flight together)
+    designs = [simulate.design_batch_condition(48), simulate.design_factor(48, 4), simulate.design_factor(42, 6), simulate.design_two_group(16),
+               np.column_stack([simulate.design_batch_condition(36), np.random.default_rng(1).normal(size=36)]),
+               simulate.design_batch_condition(48)]
     jobs = []
     for i, x in enumerate(designs):
         d = simulate.make_counts(400 + 150 * i, x, seed=90 + i, size_factors=np.exp(np.random.default_rng(i).normal(0, .2, x.shape[0])))
