@@ -535,8 +535,8 @@ static WideGeom wide_geometry(int n, int m, int p, bool useW) {
     WideGeom g;
     const size_t cu_lds = 160 * 1024;
     const size_t vec_b = wide_lds_doubles(p) * sizeof(double), slab_b = wide_slab_doubles(m, p) * sizeof(double);
-    static const int force = getenv("DSQ_WIDE_LDS") ? atoi(getenv("DSQ_WIDE_LDS")) : -1;       // 0: never; k > 0: only with k genes per CU
-    static const int force_nw = getenv("DSQ_WIDE_NW") ? atoi(getenv("DSQ_WIDE_NW")) : 0;       // waves per gene (1, 2, 4)
+    const int force = getenv("DSQ_WIDE_LDS") ? atoi(getenv("DSQ_WIDE_LDS")) : -1;       // 0: never; k > 0: only with k genes per CU
+    const int force_nw = getenv("DSQ_WIDE_NW") ? atoi(getenv("DSQ_WIDE_NW")) : 0;       // waves per gene (1, 2, 4)
     const int fit = (int)(cu_lds / (vec_b + slab_b));              // genes per CU with their slabs in LDS
     g.big_lds = force == 0 ? false : fit >= (force > 0 ? force : 1);
     const int cus = device_cu_count();
@@ -558,7 +558,7 @@ static WideGeom wide_geometry(int n, int m, int p, bool useW) {
     g.lds = vec_b;
     g.nw = (force_nw == 1 || force_nw == 2 || force_nw == 4) ? force_nw : 4;
     int bpc = 8 / g.nw;
-    static const int slab_mb = getenv("DSQ_WIDE_SLAB_MB") ? atoi(getenv("DSQ_WIDE_SLAB_MB")) : 192;
+    const int slab_mb = getenv("DSQ_WIDE_SLAB_MB") ? atoi(getenv("DSQ_WIDE_SLAB_MB")) : 192;
     long cap = (long)cus * bpc;
     const long fitb = (long)(((size_t)slab_mb << 20) / slab_b);
     if (cap > fitb) cap = fitb < cus ? cus : fitb;              // (never below one workgroup per CU)

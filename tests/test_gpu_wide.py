@@ -373,3 +373,50 @@ def test_too_wide_is_refused():
     with pytest.raises(_lib.DsqError):
         native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
                        np.full(p, 1e-6), d["weights"], False, 1e-8, 100, True, 0.5)
+
+
+@pytest.mark.parametrize("geometry", [{}, {"DSQ_WIDE_LDS": "0"}, {"DSQ_WIDE_NW": "1"}, {"DSQ_WIDE_NW": "2"}, {"DSQ_WIDE_NW": "4"},
+                                      {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "1"}, {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "2"}])
+def test_rolled_fit_beta_in_every_geometry(oracle, monkeypatch, geometry):
+    """round 6: the rolled fitBeta kernel of the wide designs without cells (csrc/fit_beta_wide.hip) in each of its launch
+    geometries -- the gene's slab in LDS or in global memory, 1 / 2 / 4 waves per gene -- on a paired design (p = 19, 36
+    cells), with and without weights, QR and normal equations, the contrast-only mode (maxit = 0, R/results.R:797), a row
+    with every second sample at 3000 and the others at zero (fitted means on the minmu floor) and an all-but-one-zero row: every
+    output identical to the oracle's in every geometry (which wave takes a sum does not enter the result)."""
+    for k, v in geometry.items():
+        monkeypatch.setenv(k, v)
+    x = _paired_design(18)
+    m, p = x.shape
+    rng = np.random.default_rng(19)
+    sf = np.exp(rng.normal(0, 0.2, m))
+    d = simulate.make_counts(90, x, seed=19, beta_sd=np.array([0.4] * 17 + [1.0]), size_factors=sf)
+    y = d["counts"].copy()
+    y[3] = 0
+    y[3, 5] = 7                                            # a single count
+    y[4] = 0
+    y[4, ::2] = 3000                                       # every patient's first sample 3000, the second 0
+    nf = np.broadcast_to(sf, y.shape).copy()
+    w = rng.uniform(0.2, 1.0, y.shape)
+    w[7, :4] = 0.0
+    from tests.helpers import beta_init_qr, rough_alpha
+    with np.errstate(all="ignore"):
+        b0 = beta_init_qr(y.astype(float), nf, x)
+        a0 = rough_alpha(y.astype(float), nf, x)
+    lam = np.full(p, 1e-6) / np.log(2) ** 2
+    lam[2] = 0.5
+    con = np.zeros(p); con[-1] = 1.0
+    for useW in (False, True):
+        for useQR in (True, False):
+            args = (y, x, nf, a0, con, b0, lam, w if useW else np.ones(y.shape), useW, 1e-8, 100, useQR, 0.5)
+            g, o = native.fitBeta(*args), oracle.fitBeta(*args)
+            for k in BETA_KEYS:
+                assert_same(g[k], o[k], "rolled fitBeta$%s (weights %s, QR %s, %r)" % (k, useW, useQR, geometry))
+            if not useW and useQR:
+                fitted = (g, o)
+    # the contrast-only call on the fitted coefficients
+    c2 = np.zeros(p); c2[1] = 1.0; c2[2] = -1.0
+    args0 = (y, x, nf, a0, c2, fitted[1]["beta_mat"], lam, np.ones(y.shape), False, 1e-8, 0, True, 0.5)
+    g0, o0 = native.fitBeta(*args0), oracle.fitBeta(*args0)
+    for k in BETA_KEYS:
+        assert_same(g0[k], o0[k], "rolled fitBeta (maxit = 0)$%s (%r)" % (k, geometry))
+    assert (o0["iter"] == 0).all()
