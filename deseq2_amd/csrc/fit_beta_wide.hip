@@ -264,24 +264,28 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : 8 / NW)) fit_beta_roll
                     // FIRST: the chunk starts at column k itself (its updated values are the multiplier of every sum of the
                     // stage; the later chunks read them back).  R and FIRST are compile-time: straight-line passes.
                     const int i0 = lane + 64 * (k / 64);                 // (trips whose rows are all finished rows of R: skipped)
-                    auto stage_chunk = [&](int j0, auto rtag, auto ftag) __attribute__((always_inline)) {
+                    auto stage_chunk_t = [&](int j0, auto rtag, auto ftag, auto ptag) __attribute__((always_inline)) {
                         constexpr int R = decltype(rtag)::value;
                         constexpr bool FIRST = decltype(ftag)::value != 0;
-                        double acc[R];
+                        constexpr bool HASPREV = decltype(ptag)::value != 0;     // k > 0: reflection k - 1 is applied on the way
+                        double acc[R], tp[R];
                         _Pragma("unroll")
-                        for (int u = 0; u < R; u++) acc[u] = 0.0;
+                        for (int u = 0; u < R; u++) { acc[u] = 0.0; tp[u] = HASPREV ? tprev[j0 + u] : 0.0; }
                         double *colp = qa + (size_t)j0 * M;
                         const double *prevp = qa + (size_t)(k > 0 ? k - 1 : 0) * M, *kp_ = qa + (size_t)k * M;
                         for (int i = i0; i < M; i += 64) {
-                            if (i < k) continue;                          // finished rows of R (first live trip only)
-                            const double v = k > 0 ? prevp[i] * scal_prev : 0.0;
-                            double ak = FIRST ? 0.0 : kp_[i];
-                            _Pragma("unroll")
-                            for (int u = 0; u < R; u++) {
-                                double a = colp[(size_t)u * M + i];
-                                if (k > 0) { a = __builtin_fma(v, tprev[j0 + u], a); colp[(size_t)u * M + i] = a; }
-                                if (FIRST && u == 0) ak = a;
-                                if (i > k) acc[u] += ak * a;
+                            if (i >= k) {                                 // (rows above k: finished rows of R, first live trip only)
+                                const double v = HASPREV ? prevp[i] * scal_prev : 0.0;
+                                double ak = FIRST ? 0.0 : kp_[i];
+                                const bool below = i > k;                 // (row k itself is the pivot row: no term)
+                                _Pragma("unroll")
+                                for (int u = 0; u < R; u++) {
+                                    double a = colp[(size_t)u * M + i];
+                                    if constexpr (HASPREV) { a = __builtin_fma(v, tp[u], a); colp[(size_t)u * M + i] = a; }
+                                    if (FIRST && u == 0) ak = a;
+                                    // (a running sum that starts at +0.0 is never -0.0: adding +0.0 for the pivot row changes no bit)
+                                    acc[u] += below ? ak * a : 0.0;
+                                }
                             }
                         }
                         wave_allreduce_many(acc, lane);
@@ -289,6 +293,10 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : 8 / NW)) fit_beta_roll
                             _Pragma("unroll")
                             for (int u = 0; u < R; u++) accs[j0 + u] = acc[u];
                         }
+                    };
+                    auto stage_chunk = [&](int j0, auto rtag, auto ftag) __attribute__((always_inline)) {
+                        if (k > 0) stage_chunk_t(j0, rtag, ftag, IntTag<1>{});
+                        else stage_chunk_t(j0, rtag, ftag, IntTag<0>{});
                     };
                     auto stage_tail = [&](int j0, int r, auto ftag) __attribute__((always_inline)) {
                         switch (r) {
