@@ -39,22 +39,22 @@ __host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_
 constexpr int kChunk = 8;     // column sums reduced together (wave_allreduce_many: the bits of one butterfly each)
 template <int V> struct IntTag { static constexpr int value = V; };
 
-// ONE WORKGROUP (four waves) PER GENE.  A gene of a wide design is 10^5 .. 10^6 wave instructions, most of them in the
+// ONE WORKGROUP OF NW WAVES PER GENE.  A gene of a wide design is 10^5 .. 10^6 wave instructions, most of them in the
 // Householder stages, and its slab leaves room for only a few genes per CU: with a wave per gene the CU ran one wave per
-// SIMD (or fewer), every instruction exposed to its own latency.  The four waves share the gene's slab and split what is
+// SIMD (or fewer), every instruction exposed to its own latency.  The NW waves share the gene's slab and split what is
 // independent -- the column chunks of a Householder stage (after the first, which updates the multiplier column), the
 // (row, column-chunk) sums of the Gram matrices, the rows of an elimination step, the samples of the elementwise passes,
 // the rows of the p x p products -- and meet at workgroup barriers.  EVERY SUM OVER THE SAMPLES IS STILL TAKEN BY ONE
 // WAVE in wave order (64 per-lane partials over the trips in order, then the butterfly): which wave takes it does not
 // enter the result.  Serial recurrences (back substitution, the triangular solves of the inverse, the convergence
 // control) stay with wave 0; their results reach the other waves through LDS.
-// BIG_LDS: the gene's slab (rows, matrices, per-sample vectors) in LDS instead of global memory -- taken when at least
-// two genes fit a CU (wide_geometry): a Householder stage is a chain of dependent round trips through the slab
+// BIG_LDS: the gene's slab (rows, matrices, per-sample vectors) in LDS instead of global memory -- taken whenever one
+// fits a CU (wide_geometry): a Householder stage is a chain of dependent round trips through the slab
 // (rows -> column sums -> pivot row -> reflector), ~ 100 ns each in LDS against 1-3 us through L2 / the infinity cache.
-// NW = 1, 2 or 4 waves per gene: as many as bring a CU to about eight resident waves (two per SIMD: what the registers of
+// NW = 1, 2, 4 or 8 waves per gene: as many as bring a CU to about eight resident waves (two per SIMD: what the registers of
 // this kernel admit) given how many genes' slabs fit its LDS -- small problems run a wave per gene, without barriers.
 template <bool USE_W, bool BIG_LDS, int NW>
-__global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : 8 / NW)) fit_beta_rolled_kernel(BetaKernelParams kp) {
+__global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW))) fit_beta_rolled_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -311,7 +311,9 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : 8 / NW)) fit_beta_roll
                         }
                     };
                     const int ncol = P + 1 - k;                           // columns k .. P
-                    const int first_n = ncol >= kChunk ? kChunk : ncol;
+                    // with several waves the serial first chunk is column k ALONE (the other waves wait for it), and columns
+                    // k + 1 .. P go round the waves in chunks of eight; one wave takes k .. k + 7 together
+                    const int first_n = NW > 1 ? 1 : (ncol >= kChunk ? kChunk : ncol);
                     if (wave == 0) {
                         if (first_n == kChunk) stage_chunk(k, IntTag<kChunk>{}, IntTag<1>{});
                         else stage_tail(k, first_n, IntTag<1>{});
@@ -534,7 +536,7 @@ struct WideGeom { int grid, nw; size_t lds; bool big_lds; };
 template <bool USE_W, bool BIG_LDS>
 static const void *wide_fn(int nw) {
     return nw == 1 ? (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 1> : nw == 2 ? (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 2>
-                                                                                      : (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 4>;
+           : nw == 4 ? (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 4> : (const void *)fit_beta_rolled_kernel<USE_W, BIG_LDS, 8>;
 }
 static const void *wide_fn(bool useW, bool big, int nw) {
     return useW ? (big ? wide_fn<true, true>(nw) : wide_fn<true, false>(nw)) : (big ? wide_fn<false, true>(nw) : wide_fn<false, false>(nw));
@@ -550,8 +552,8 @@ static WideGeom wide_geometry(int n, int m, int p, bool useW) {
     const int cus = device_cu_count();
     if (g.big_lds) {
         g.lds = vec_b + slab_b;
-        g.nw = fit >= 8 ? 1 : fit >= 4 ? 2 : 4;                    // about eight resident waves per CU
-        if (force_nw == 1 || force_nw == 2 || force_nw == 4) g.nw = force_nw;
+        g.nw = fit >= 8 ? 1 : fit >= 4 ? 2 : fit >= 2 ? 4 : 8;     // about eight resident waves per CU
+        if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) g.nw = force_nw;
         int bpc = fit;
         if (bpc * g.nw > 8) bpc = 8 / g.nw;                        // (two waves per SIMD by the registers)
         if (bpc < 1) bpc = 1;
@@ -564,7 +566,7 @@ static WideGeom wide_geometry(int n, int m, int p, bool useW) {
         return g;
     }
     g.lds = vec_b;
-    g.nw = (force_nw == 1 || force_nw == 2 || force_nw == 4) ? force_nw : 4;
+    g.nw = (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) ? force_nw : 4;
     int bpc = 8 / g.nw;
     const int slab_mb = getenv("DSQ_WIDE_SLAB_MB") ? atoi(getenv("DSQ_WIDE_SLAB_MB")) : 192;
     long cap = (long)cus * bpc;
