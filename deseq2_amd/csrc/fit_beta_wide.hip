@@ -22,8 +22,13 @@
 #include "dsq_math.hpp"
 #include "dsq_wave.hpp"
 #include "fit_beta_common.hpp"
+#include "dsq_prof.hpp"
 
 namespace dsq {
+
+#ifdef DSQ_WIDE_PROF
+__device__ unsigned long long betaw_prof[DSQ_PROF_SLOTS];
+#endif
 
 // per-wave slab in global memory (doubles): the four per-sample vectors, then the larger of
 //   IRLS      the (m + p) x (p + 1) rows (column c of row i at qa[c M + i]) and R (p x p)
@@ -53,8 +58,9 @@ template <int V> struct IntTag { static constexpr int value = V; };
 // (rows -> column sums -> pivot row -> reflector), ~ 100 ns each in LDS against 1-3 us through L2 / the infinity cache.
 // NW = 1, 2, 4 or 8 waves per gene: as many as bring a CU to about eight resident waves (two per SIMD: what the registers of
 // this kernel admit) given how many genes' slabs fit its LDS -- small problems run a wave per gene, without barriers.
+// (HIP's second launch bound is WAVES PER SIMD, not blocks per CU)
 template <bool USE_W, bool BIG_LDS, int NW>
-__global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW))) fit_beta_rolled_kernel(BetaKernelParams kp) {
+__global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
     for (int c = tid; c < P; c += NT) { lambda[c] = kp.lambda[c]; contrast[c] = kp.contrast[c]; }
     const double large = 30.0;
 
+    DSQ_PROF_DECL;
     int wi = blockIdx.x;
     while (wi < nwork) {
         const int g = DSQ_GENE(kp, wi);
@@ -171,12 +178,22 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
         auto lu_factor = [&](double *A) {
             for (int k = 0; k < P; k++) {
                 if (wave == 0) {
-                    int pr = k;
-                    double best = __builtin_fabs(A[(size_t)k * P + k]);
-                    for (int i = k + 1; i < P; i++) {
-                        const double v = __builtin_fabs(A[(size_t)i * P + k]);
-                        if (v > best) { best = v; pr = i; }
+                    // the scan "best = |a_kk|; a later row wins when its |a_ik| > best" with a row per lane: a NaN never wins
+                    // from a later row (key -1) and is never beaten in row k (key +inf); the first of equal maxima is the
+                    // lowest set bit of the ballot
+                    double key = -2.0;
+                    if (lane >= k && lane < P) {
+                        const double v = __builtin_fabs(A[(size_t)lane * P + k]);
+                        key = (v != v) ? (lane == k ? __builtin_inf() : -1.0) : v;
                     }
+                    double mx = key, xa, xb;
+                    mx = __builtin_fmax(mx, lane_xor1(mx));
+                    mx = __builtin_fmax(mx, lane_xor2(mx));
+                    mx = __builtin_fmax(mx, lane_xor4(mx));
+                    mx = __builtin_fmax(mx, lane_xor8(mx));
+                    lane_pair16(mx, xa, xb); mx = __builtin_fmax(xa, xb);
+                    lane_pair32(mx, xa, xb); mx = __builtin_fmax(xa, xb);
+                    const int pr = (int)__builtin_ctzll(__ballot(key == mx));
                     if (lane == 0) piv[k] = pr;
                     if (pr != k) {
                         for (int j = lane; j < P; j += 64) {
@@ -190,42 +207,60 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                 const double rinv = 1.0 / A[(size_t)k * P + k];
                 if (tid == 0) rdiag[k] = rinv;
                 const double akj = lane < P ? A[(size_t)k * P + lane] : 0.0;
-                for (int i = k + 1 + wave; i < P; i += NW) {
-                    // (every lane loads A[i][k] in the instruction BEFORE lane k's store to it: a wave's memory operations
-                    //  issue in program order)
-                    const double l = A[(size_t)i * P + k] * rinv;
-                    if (lane == k) A[(size_t)i * P + k] = l;
-                    else if (lane > k && lane < P) A[(size_t)i * P + lane] = __builtin_fma(-l, akj, A[(size_t)i * P + lane]);
+                const int lc = lane < P ? lane : P - 1;
+                for (int i0 = k + 1 + wave; i0 < P; i0 += 4 * NW) {      // four of the wave's rows in flight
+                    // (every lane loads A[i][k] BEFORE lane k's store to it: a wave's memory operations issue in program order)
+                    double lv4[4], av4[4];
+                    _Pragma("unroll")
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * NW;
+                        if (i < P) { lv4[u] = A[(size_t)i * P + k]; av4[u] = A[(size_t)i * P + lc]; }
+                    }
+                    _Pragma("unroll")
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * NW;
+                        if (i < P) {
+                            const double l = lv4[u] * rinv;
+                            if (lane == k) A[(size_t)i * P + k] = l;
+                            else if (lane > k && lane < P) A[(size_t)i * P + lane] = __builtin_fma(-l, akj, av4[u]);
+                        }
+                    }
                 }
                 sync();
             }
         };
         // LU<P>::solve on ONE right-hand side in LDS                                                        [wave 0 only]
         auto lu_solve_vec = [&](const double *A, double *b) {
+            // the right-hand side lives across the lanes (lane j holds b[j]), rows of the factors are read once, an entry per
+            // lane: the chains fma(-a[i][j], b[j], t) take their operands from v_readlane, not from LDS round trips
+            const int lc = lane < P ? lane : P - 1;
+            double bv = b[lc];
+            const int pv = piv[lc];
+            const double rd = rdiag[lc];
             for (int k = 0; k < P; k++) {
-                const int pr = piv[k];
+                const int pr = __builtin_amdgcn_readlane(pv, k);
                 if (pr != k) {
-                    wave_lds_sync();
-                    const double t = b[k], u = b[pr];
-                    wave_lds_sync();
-                    if (lane == 0) { b[k] = u; b[pr] = t; }
-                    wave_lds_sync();
+                    const double t = lane_read(bv, k), u = lane_read(bv, pr);
+                    if (lane == k) bv = u;
+                    if (lane == pr) bv = t;
                 }
             }
             for (int i = 0; i < P; i++) {
-                double t = b[i];
-                for (int j = 0; j < i; j++) t = __builtin_fma(-A[(size_t)i * P + j], b[j], t);
-                wave_lds_sync();
-                if (lane == 0) b[i] = t;
-                wave_lds_sync();
+                const double arow = A[(size_t)i * P + lc];
+                double t = lane_read(bv, i);
+                for (int j = 0; j < i; j++) t = __builtin_fma(-lane_read(arow, j), lane_read(bv, j), t);
+                if (lane == i) bv = t;
             }
             for (int i = P - 1; i >= 0; i--) {
-                double t = b[i];
-                for (int j = i + 1; j < P; j++) t = __builtin_fma(-A[(size_t)i * P + j], b[j], t);
-                wave_lds_sync();
-                if (lane == 0) b[i] = t * rdiag[i];
-                wave_lds_sync();
+                const double arow = A[(size_t)i * P + lc];
+                double t = lane_read(bv, i);
+                for (int j = i + 1; j < P; j++) t = __builtin_fma(-lane_read(arow, j), lane_read(bv, j), t);
+                t = t * lane_read(rd, i);
+                if (lane == i) bv = t;
             }
+            wave_lds_sync();
+            if (lane < P) b[lane] = bv;
+            wave_lds_sync();
         };
 
         update_mu();
@@ -238,6 +273,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
         }
         double dev = 0.0, dev_old = 0.0;          // (wave 0's)
         double it = 0.0;
+        DSQ_PROF(0);
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
             for (int c = tid; c < P; c += NT) beta_prev[c] = beta[c];
@@ -257,6 +293,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                     }
                 }
                 sync();
+                DSQ_PROF(1);
                 // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
                 double scal_prev = 0.0;
                 for (int k = 0; k < P; k++) {
@@ -349,17 +386,24 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                     if (tid == 0) qR[(size_t)k * P + k] = bet;
                     sync();
                 }
+                DSQ_PROF(2);
                 if (wave == 0) {
+                    // R beta = gamma from the last row up: the solution lives across the lanes (lane j holds beta[j]), a row of
+                    // R is read once, an entry per lane -- the chain's operands come from v_readlane
+                    const int lc = lane < P ? lane : P - 1;
+                    const double gv = gamma[lc];
+                    double bv = 0.0;
                     for (int i = P - 1; i >= 0; i--) {
-                        double tt = gamma[i];
-                        for (int j = i + 1; j < P; j++) tt = __builtin_fma(-qR[(size_t)i * P + j], beta[j], tt);
-                        const double bi = tt / qR[(size_t)i * P + i];
-                        wave_lds_sync();
-                        if (lane == 0) beta[i] = bi;
-                        wave_lds_sync();
+                        const double rrow = qR[(size_t)i * P + lc];
+                        double tt = lane_read(gv, i);
+                        for (int j = i + 1; j < P; j++) tt = __builtin_fma(-lane_read(rrow, j), lane_read(bv, j), tt);
+                        const double bi = tt / lane_read(rrow, i);
+                        if (lane == i) bv = bi;
                     }
+                    if (lane < P) beta[lane] = bv;
                 }
                 sync();
+                DSQ_PROF(3);
             } else {
                 // solve(beta_hat, x.t() * (x.each_col() % w_vec) + ridge, x.t() * (z % w_vec))            (:398)
                 for (int j = tid; j < m; j += NT) {
@@ -373,13 +417,16 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                 gram(G, true);
                 for (int a = tid; a < P; a += NT) G[(size_t)a * P + a] = G[(size_t)a * P + a] + lambda[a];
                 sync();
+                DSQ_PROF(1);
                 lu_factor(G);
+                DSQ_PROF(2);
                 if (wave == 0) {
                     lu_solve_vec(G, rhs);
                     wave_lds_sync();
                     for (int a = lane; a < P; a += 64) beta[a] = rhs[a];
                 }
                 sync();
+                DSQ_PROF(3);
             }
             int toolarge = 0;
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
@@ -413,6 +460,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                 if (lane == 0) ctl[0] = flag;
             }
             sync();
+            DSQ_PROF(4);
             const double flag = ctl[0];
             if (uniform(flag == 2.0)) { it = (double)kp.maxit; break; }
             if (uniform(flag == 1.0)) break;
@@ -427,6 +475,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
         }
         sync();
         gram(G, false);
+        DSQ_PROF(5);
         for (int e = tid; e < P * P; e += NT) {
             const int i = e / P, j = e - i * P;
             double v = G[e];
@@ -435,26 +484,49 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
         }
         sync();
         lu_factor(LUm);
+        DSQ_PROF(6);
         // Gi = inverse: lane c owns right-hand side e_c (LU<P>::inverse = P solves)                              [wave 0]
-        if (wave == 0 && lane < P) {
-            const int c = lane;
-            for (int i = 0; i < P; i++) Gi[(size_t)i * P + c] = (i == c) ? 1.0 : 0.0;
+        // (row i of the factors is read ONCE, an entry per lane, its multipliers come from v_readlane; the solution's entries
+        //  are loaded eight ahead of the chain)
+        if (wave == 0) {
+            const int c = lane < P ? lane : P - 1;       // (the spare lanes shadow the last column and store nothing)
+            const bool own = lane < P;
+            int pos = c;                                 // e_c under the row swaps: where its 1 ends
             for (int k = 0; k < P; k++) {
                 const int pr = piv[k];
-                if (pr != k) { const double t = Gi[(size_t)k * P + c]; Gi[(size_t)k * P + c] = Gi[(size_t)pr * P + c]; Gi[(size_t)pr * P + c] = t; }
+                pos = (pos == k) ? pr : ((pos == pr) ? k : pos);
             }
             for (int i = 0; i < P; i++) {
-                double t = Gi[(size_t)i * P + c];
-                for (int j = 0; j < i; j++) t = __builtin_fma(-LUm[(size_t)i * P + j], Gi[(size_t)j * P + c], t);
-                Gi[(size_t)i * P + c] = t;
+                const double arow = LUm[(size_t)i * P + c];
+                double t = (i == pos) ? 1.0 : 0.0;
+                int j = 0;
+                for (; j + 8 <= i; j += 8) {
+                    double xv[8];
+                    _Pragma("unroll")
+                    for (int u = 0; u < 8; u++) xv[u] = Gi[(size_t)(j + u) * P + c];
+                    _Pragma("unroll")
+                    for (int u = 0; u < 8; u++) t = __builtin_fma(-lane_read(arow, j + u), xv[u], t);
+                }
+                for (; j < i; j++) t = __builtin_fma(-lane_read(arow, j), Gi[(size_t)j * P + c], t);
+                if (own) Gi[(size_t)i * P + c] = t;
             }
             for (int i = P - 1; i >= 0; i--) {
+                const double arow = LUm[(size_t)i * P + c];
                 double t = Gi[(size_t)i * P + c];
-                for (int j = i + 1; j < P; j++) t = __builtin_fma(-LUm[(size_t)i * P + j], Gi[(size_t)j * P + c], t);
-                Gi[(size_t)i * P + c] = t * rdiag[i];
+                int j = i + 1;
+                for (; j + 8 <= P; j += 8) {
+                    double xv[8];
+                    _Pragma("unroll")
+                    for (int u = 0; u < 8; u++) xv[u] = Gi[(size_t)(j + u) * P + c];
+                    _Pragma("unroll")
+                    for (int u = 0; u < 8; u++) t = __builtin_fma(-lane_read(arow, j + u), xv[u], t);
+                }
+                for (; j < P; j++) t = __builtin_fma(-lane_read(arow, j), Gi[(size_t)j * P + c], t);
+                if (own) Gi[(size_t)i * P + c] = t * rdiag[i];
             }
         }
         sync();
+        DSQ_PROF(7);
         // hat diagonal, loop order of :443-449; fitted means (extension)                                     [all waves]
         if (kp.hat_diagonals || kp.mu_out) {
             for (int j = tid; j < m; j += NT) {
@@ -463,7 +535,15 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                     double h = 0.0;
                     for (int i1 = 0; i1 < P; i1++) {
                         const double xw1 = xs[(size_t)i1 * m + j] * sw;
-                        for (int i2 = 0; i2 < P; i2++) {
+                        int i2 = 0;
+                        for (; i2 + 8 <= P; i2 += 8) {                    // (eight terms' loads ahead of the additions)
+                            double x2[8], gv[8];
+                            _Pragma("unroll")
+                            for (int u = 0; u < 8; u++) { x2[u] = xs[(size_t)(i2 + u) * m + j]; gv[u] = Gi[(size_t)(i2 + u) * P + i1]; }
+                            _Pragma("unroll")
+                            for (int u = 0; u < 8; u++) h += xw1 * ((x2[u] * sw) * gv[u]);
+                        }
+                        for (; i2 < P; i2++) {
                             const double xw2 = xs[(size_t)i2 * m + j] * sw;
                             h += xw1 * (xw2 * Gi[(size_t)i2 * P + i1]);
                         }
@@ -479,6 +559,7 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
                 }
             }
         }
+        DSQ_PROF(8);
         // sigma = Gi * G * Gi (:452), mat_mul's order: c[i][j] = sum_k fma(a[i][k], b[k][j]), k ascending; lane j owns column
         // j, the rows go round the waves
         if (lane < P) {
@@ -523,8 +604,10 @@ __global__ void __launch_bounds__(64 * NW, (BIG_LDS ? 1 : (NW >= 8 ? 1 : 8 / NW)
             }
         }
         sync();
+        DSQ_PROF(9);
         wi = (int)ctl[1];
     }
+    DSQ_PROF_FLUSH(betaw_prof);
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
@@ -593,6 +676,22 @@ hipError_t launch_fit_beta_rolled(const BetaKernelParams &kp0, hipStream_t st) {
     // (a row list: its length lives on the device; the scratch was sized for the full grid, a smaller one uses its head)
     if (kp.rows_few && grid > device_cu_count()) grid = device_cu_count();
     void *args[] = {&kp};
+#ifdef DSQ_WIDE_PROF
+    {
+        unsigned long long z[DSQ_PROF_SLOTS] = {}, h[DSQ_PROF_SLOTS];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(betaw_prof), z, sizeof(z));
+        const hipError_t e = hipLaunchKernel(wide_fn(kp.useWeights != 0, g.big_lds, g.nw), dim3(grid), dim3(64 * g.nw), args, g.lds, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(betaw_prof), sizeof(h));
+        double tot = 0;
+        for (int q = 0; q < DSQ_PROF_SLOTS; q++) tot += (double)h[q];
+        static const char *nm[10] = {"start", "rows / gram", "QR stages / LU", "back-subst / solve", "mu + deviance", "post gram", "post LU", "post inverse", "hat", "sigma + out"};
+        fprintf(stderr, "[betaw_prof] p=%d m=%d nw=%d lds=%d qr=%d:", kp.p, kp.m, g.nw, (int)g.big_lds, kp.useQR);
+        for (int q = 0; q < 10; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)h[q] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "  (%.0f Mcycles of thread 0 over %d workgroups)\n", tot / 1e6, grid);
+        return e;
+    }
+#endif
     return hipLaunchKernel(wide_fn(kp.useWeights != 0, g.big_lds, g.nw), dim3(grid), dim3(64 * g.nw), args, g.lds, st);
 }
 

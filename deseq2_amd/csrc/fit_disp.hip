@@ -1299,8 +1299,15 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
 #error "compile with -DDSQ_P=<number of design columns>"
 #endif
 
+// wide designs without cells on short rows: the rolled kernel of fit_disp_wide.hip (one build for every width)
+bool fit_disp_rolled_applies(const DispKernelParams &kp, int *p_true);
+hipError_t launch_fit_disp_rolled(const DispKernelParams &kp, hipStream_t st, bool grid);
+
 template <>
 hipError_t launch_fit_disp_p<DSQ_P>(const DispKernelParams &kp, hipStream_t st, bool grid) {
+#if DSQ_P >= 16
+    if (fit_disp_rolled_applies(kp, nullptr)) return launch_fit_disp_rolled(kp, st, grid);
+#endif
     if (grid)
         return kp.useWeights ? launch_disp_p<DSQ_P, true, 1>(kp, st) : launch_disp_p<DSQ_P, false, 1>(kp, st);
     hipError_t e = kp.useWeights ? launch_disp_p<DSQ_P, true, 0>(kp, st) : launch_disp_p<DSQ_P, false, 0>(kp, st);
