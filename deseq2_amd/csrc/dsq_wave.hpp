@@ -80,6 +80,14 @@ DSQ_DEV void lane_pair32(double v, double &a, double &b) {
     b = __hiloint2double((int)ph[1], (int)pl[1]);
 }
 
+// lane l <- lane l - 1 across the whole wave (DPP wave_shr:1, a gfx9 control); lane 0 keeps its own value
+DSQ_DEV double wave_shr1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // all-reduce: every lane ends with the same bits (a+b is commutative in IEEE).
 DSQ_DEV double wave_allreduce(double v) {
     v = v + lane_xor1(v);

@@ -39,7 +39,7 @@ __host__ __device__ static inline size_t wide_slab_doubles(int m, int p) {
     return (size_t)4 * m + (irls > post ? irls : post) + 8;
 }
 // per-wave LDS (doubles): lambda, contrast, beta, beta_prev, gamma, rdiag, rhs / rr (p each), tprev, accs (p + 1 each), piv (p ints)
-__host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_t)10 * p + 16; }     // (+ the control words)
+__host__ __device__ static inline size_t wide_lds_doubles(int p) { return (size_t)11 * p + 24; }     // (+ the control words)
 
 constexpr int kChunk = 8;     // column sums reduced together (wave_allreduce_many: the bits of one butterfly each)
 template <int V> struct IntTag { static constexpr int value = V; };
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
            *rhs = lv + 6 * P, *tprev = lv + 7 * P, *accs = lv + 8 * P + 1;
     int *piv = reinterpret_cast<int *>(lv + 9 * P + 2);
     double *ctl = lv + 10 * P + 8;             // [0] loop control of the IRLS, [1] next gene, [2] dev, [3] iterations
+    double *tprev2 = lv + 10 * P + 16;         // (the stages of the QR write tprev and tprev2 in turn)
     double *slab;
     if constexpr (BIG_LDS) slab = smem + wide_lds_doubles(P);
     else slab = kp.scratch + (size_t)blockIdx.x * wide_slab_doubles(m, P);
@@ -245,17 +246,19 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                     if (lane == pr) bv = t;
                 }
             }
-            for (int i = 0; i < P; i++) {
+            // (the chains walk the lanes: lane j takes the running value of lane j - 1 by one DPP shift and applies its term)
+            for (int i = 1; i < P; i++) {
                 const double arow = A[(size_t)i * P + lc];
-                double t = lane_read(bv, i);
-                for (int j = 0; j < i; j++) t = __builtin_fma(-lane_read(arow, j), lane_read(bv, j), t);
+                double tv = __builtin_fma(-arow, bv, lane_read(bv, i));      // (lane 0: the first term on b[i])
+                for (int j = 1; j < i; j++) tv = __builtin_fma(-arow, bv, wave_shr1(tv));
+                const double t = lane_read(tv, i - 1);
                 if (lane == i) bv = t;
             }
             for (int i = P - 1; i >= 0; i--) {
                 const double arow = A[(size_t)i * P + lc];
-                double t = lane_read(bv, i);
-                for (int j = i + 1; j < P; j++) t = __builtin_fma(-lane_read(arow, j), lane_read(bv, j), t);
-                t = t * lane_read(rd, i);
+                double tv = bv;                                           // (lane i: b[i])
+                for (int j = i + 1; j < P; j++) tv = __builtin_fma(-arow, bv, wave_shr1(tv));
+                const double t = lane_read(tv, P - 1) * lane_read(rd, i);
                 if (lane == i) bv = t;
             }
             wave_lds_sync();
@@ -294,76 +297,28 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                 }
                 sync();
                 DSQ_PROF(1);
-                // pass B: Householder QR, LAPACK dgeqr2 order; stage k first applies reflection k - 1 to the rows below it
+                // pass B: Householder QR, LAPACK dgeqr2 order, ONE barrier per stage.  Entering stage k, column k already carries
+                // reflection k - 1 and accs[k] holds the sum of squares below its diagonal (the look-ahead of stage k - 1; for
+                // k = 0 the pass in front of the loop).  Every wave derives reflection k from them; the columns k + 1 .. P then go
+                // round the waves in chunks -- a chunk applies reflection k - 1 to its columns on the way, takes their sums with
+                // column k, and turns them into the stage's tprev / row k of R itself (its sums never leave the registers).
+                // Column k + 1 is a task of its own: its wave goes on to apply reflection k to it and to take ITS sum of squares
+                // -- what stage k + 1 starts from -- while the other waves are still in their chunks.  The operations on every
+                // element, and the order of every sum, are those of the stage-by-stage statement (one wave's wave-order sums).
+                {
+                    double a0[1] = {0.0};
+                    if (wave == 0) {
+                        const double *c0 = qa;
+                        for (int i = lane; i < M; i += 64) { const double a = c0[i]; a0[0] += (i > 0) ? a * a : 0.0; }
+                        wave_allreduce_many(a0, lane);
+                        if (lane == 0) accs[0] = a0[0];
+                    }
+                }
+                sync();
                 double scal_prev = 0.0;
                 for (int k = 0; k < P; k++) {
-                    // columns j0 .. j0 + R - 1 of the rows from k down: apply reflection k - 1, take the sums with column k.
-                    // FIRST: the chunk starts at column k itself (its updated values are the multiplier of every sum of the
-                    // stage; the later chunks read them back).  R and FIRST are compile-time: straight-line passes.
-                    const int i0 = lane + 64 * (k / 64);                 // (trips whose rows are all finished rows of R: skipped)
-                    auto stage_chunk_t = [&](int j0, auto rtag, auto ftag, auto ptag) __attribute__((always_inline)) {
-                        constexpr int R = decltype(rtag)::value;
-                        constexpr bool FIRST = decltype(ftag)::value != 0;
-                        constexpr bool HASPREV = decltype(ptag)::value != 0;     // k > 0: reflection k - 1 is applied on the way
-                        double acc[R], tp[R];
-                        _Pragma("unroll")
-                        for (int u = 0; u < R; u++) { acc[u] = 0.0; tp[u] = HASPREV ? tprev[j0 + u] : 0.0; }
-                        double *colp = qa + (size_t)j0 * M;
-                        const double *prevp = qa + (size_t)(k > 0 ? k - 1 : 0) * M, *kp_ = qa + (size_t)k * M;
-                        for (int i = i0; i < M; i += 64) {
-                            if (i >= k) {                                 // (rows above k: finished rows of R, first live trip only)
-                                const double v = HASPREV ? prevp[i] * scal_prev : 0.0;
-                                double ak = FIRST ? 0.0 : kp_[i];
-                                const bool below = i > k;                 // (row k itself is the pivot row: no term)
-                                _Pragma("unroll")
-                                for (int u = 0; u < R; u++) {
-                                    double a = colp[(size_t)u * M + i];
-                                    if constexpr (HASPREV) { a = __builtin_fma(v, tp[u], a); colp[(size_t)u * M + i] = a; }
-                                    if (FIRST && u == 0) ak = a;
-                                    // (a running sum that starts at +0.0 is never -0.0: adding +0.0 for the pivot row changes no bit)
-                                    acc[u] += below ? ak * a : 0.0;
-                                }
-                            }
-                        }
-                        wave_allreduce_many(acc, lane);
-                        if (lane == 0) {
-                            _Pragma("unroll")
-                            for (int u = 0; u < R; u++) accs[j0 + u] = acc[u];
-                        }
-                    };
-                    auto stage_chunk = [&](int j0, auto rtag, auto ftag) __attribute__((always_inline)) {
-                        if (k > 0) stage_chunk_t(j0, rtag, ftag, IntTag<1>{});
-                        else stage_chunk_t(j0, rtag, ftag, IntTag<0>{});
-                    };
-                    auto stage_tail = [&](int j0, int r, auto ftag) __attribute__((always_inline)) {
-                        switch (r) {
-                            case 1: stage_chunk(j0, IntTag<1>{}, ftag); break;
-                            case 2: stage_chunk(j0, IntTag<2>{}, ftag); break;
-                            case 3: stage_chunk(j0, IntTag<3>{}, ftag); break;
-                            case 4: stage_chunk(j0, IntTag<4>{}, ftag); break;
-                            case 5: stage_chunk(j0, IntTag<5>{}, ftag); break;
-                            case 6: stage_chunk(j0, IntTag<6>{}, ftag); break;
-                            case 7: stage_chunk(j0, IntTag<7>{}, ftag); break;
-                            default: break;
-                        }
-                    };
-                    const int ncol = P + 1 - k;                           // columns k .. P
-                    // with several waves the serial first chunk is column k ALONE (the other waves wait for it), and columns
-                    // k + 1 .. P go round the waves in chunks of eight; one wave takes k .. k + 7 together
-                    const int first_n = NW > 1 ? 1 : (ncol >= kChunk ? kChunk : ncol);
-                    if (wave == 0) {
-                        if (first_n == kChunk) stage_chunk(k, IntTag<kChunk>{}, IntTag<1>{});
-                        else stage_tail(k, first_n, IntTag<1>{});
-                    }
-                    if (ncol > first_n) {
-                        sync();                                           // column k is updated: the other chunks may start
-                        int task = 0;
-                        int j0 = k + first_n;
-                        for (; j0 + kChunk <= P + 1; j0 += kChunk)
-                            if ((task++ & (NW - 1)) == wave) stage_chunk(j0, IntTag<kChunk>{}, IntTag<0>{});
-                        if (j0 <= P && (task++ & (NW - 1)) == wave) stage_tail(j0, P + 1 - j0, IntTag<0>{});
-                    }
-                    sync();
+                    const double *tp_cur = (k & 1) ? tprev2 : tprev;       // written by stage k - 1
+                    double *tp_next = (k & 1) ? tprev : tprev2;
                     const double alpha_k = qa[(size_t)k * M + k];
                     const double acck = accs[k];
                     double tau, scal, bet;
@@ -373,17 +328,95 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                         tau = (bet - alpha_k) / bet;
                         scal = 1.0 / (alpha_k - bet);
                     }
-                    scal_prev = scal;
-                    // (tprev of stage k - 1 has been read by every chunk above: behind the barrier it may be rewritten)
-                    for (int j = k + 1 + tid; j <= P; j += NT) {
-                        const double prow = qa[(size_t)j * M + k];
-                        const double wj = prow + scal * accs[j];
-                        const double tp = -tau * wj;
-                        tprev[j] = tp;
-                        if (j < P) qR[(size_t)k * P + j] = prow + tp;
-                        else gamma[k] = prow + tp;
-                    }
                     if (tid == 0) qR[(size_t)k * P + k] = bet;
+                    const int i0 = lane + 64 * (k / 64);                 // (trips whose rows are all finished rows of R: skipped)
+                    const double *prevp = qa + (size_t)(k > 0 ? k - 1 : 0) * M, *kcol = qa + (size_t)k * M;
+                    // columns j0 .. j0 + R - 1 (j0 > k) of the rows from k down
+                    auto chunk_t = [&](int j0, auto rtag, auto ptag, double (&tpn)[decltype(rtag)::value]) __attribute__((always_inline)) {
+                        constexpr int R = decltype(rtag)::value;
+                        constexpr bool HASPREV = decltype(ptag)::value != 0;     // k > 0: reflection k - 1 is applied on the way
+                        double acc[R], tp[R], rowk[R];
+                        _Pragma("unroll")
+                        for (int u = 0; u < R; u++) { acc[u] = 0.0; rowk[u] = 0.0; tp[u] = HASPREV ? tp_cur[j0 + u] : 0.0; }
+                        double *colp = qa + (size_t)j0 * M;
+                        auto row = [&](int i, auto ctag) __attribute__((always_inline)) {
+                            if (i >= k && i < M) {                        // (rows above k: finished rows of R, first live trip only)
+                                const double v = HASPREV ? prevp[i] * scal_prev : 0.0;
+                                const double ak = kcol[i];
+                                const bool below = i > k;                 // (row k itself is the pivot row: no term)
+                                _Pragma("unroll")
+                                for (int u = 0; u < R; u++) {
+                                    double a = colp[(size_t)u * M + i];
+                                    if constexpr (HASPREV) { a = __builtin_fma(v, tp[u], a); colp[(size_t)u * M + i] = a; }
+                                    if constexpr (decltype(ctag)::value != 0) rowk[u] = a;      // (first trip: lane k % 64 holds row k)
+                                    // (a running sum that starts at +0.0 is never -0.0: adding +0.0 for the pivot row changes no bit)
+                                    acc[u] += below ? ak * a : 0.0;
+                                }
+                            }
+                        };
+                        row(i0, IntTag<1>{});
+                        for (int i = i0 + 64; i < M; i += 64) row(i, IntTag<0>{});
+                        wave_allreduce_many(acc, lane);
+                        _Pragma("unroll")
+                        for (int u = 0; u < R; u++) {
+                            const double prow = lane_read(rowk[u], k & 63);
+                            const double wj = prow + scal * acc[u];
+                            const double tpv = -tau * wj;
+                            tpn[u] = tpv;
+                            if (lane == 0) {
+                                const int j = j0 + u;
+                                tp_next[j] = tpv;
+                                if (j < P) qR[(size_t)k * P + j] = prow + tpv;
+                                else gamma[k] = prow + tpv;
+                            }
+                        }
+                    };
+                    auto chunk = [&](int j0, auto rtag) __attribute__((always_inline)) {
+                        double tpn[decltype(rtag)::value];
+                        if (k > 0) chunk_t(j0, rtag, IntTag<1>{}, tpn);
+                        else chunk_t(j0, rtag, IntTag<0>{}, tpn);
+                        return tpn[0];
+                    };
+                    auto chunk_tail = [&](int j0, int r) __attribute__((always_inline)) {
+                        switch (r) {
+                            case 1: chunk(j0, IntTag<1>{}); break;
+                            case 2: chunk(j0, IntTag<2>{}); break;
+                            case 3: chunk(j0, IntTag<3>{}); break;
+                            case 4: chunk(j0, IntTag<4>{}); break;
+                            case 5: chunk(j0, IntTag<5>{}); break;
+                            case 6: chunk(j0, IntTag<6>{}); break;
+                            case 7: chunk(j0, IntTag<7>{}); break;
+                            default: break;
+                        }
+                    };
+                    // task 0 (wave 0): column k + 1 alone, then the look-ahead; the chunks of eight from k + 2 go round from wave 1
+                    if (wave == 0) {
+                        const double tpn = chunk(k + 1, IntTag<1>{});
+                        if (k + 1 < P) {
+                            const int kk = k + 1;
+                            double *col = qa + (size_t)kk * M;
+                            double a2[1] = {0.0};
+                            for (int i = lane + 64 * (kk / 64); i < M; i += 64) {
+                                if (i >= kk) {
+                                    const double v = kcol[i] * scal;
+                                    double a = col[i];
+                                    a = __builtin_fma(v, tpn, a);
+                                    col[i] = a;
+                                    a2[0] += (i > kk) ? a * a : 0.0;
+                                }
+                            }
+                            wave_allreduce_many(a2, lane);
+                            if (lane == 0) accs[kk] = a2[0];
+                        }
+                    }
+                    {
+                        int task = 1;
+                        int j0 = k + 2;
+                        for (; j0 + kChunk <= P + 1; j0 += kChunk)
+                            if ((task++ & (NW - 1)) == wave) chunk(j0, IntTag<kChunk>{});
+                        if (j0 <= P && (task++ & (NW - 1)) == wave) chunk_tail(j0, P + 1 - j0);
+                    }
+                    scal_prev = scal;
                     sync();
                 }
                 DSQ_PROF(2);
@@ -393,11 +426,14 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                     const int lc = lane < P ? lane : P - 1;
                     const double gv = gamma[lc];
                     double bv = 0.0;
+                    // the chain tt <- fma(-r[i][j], beta[j], tt), j ascending, walks the lanes: lane j takes the value of lane
+                    // j - 1 (one DPP shift) and applies ITS term -- no operand leaves its lane; what the other lanes compute on
+                    // the way is never read
                     for (int i = P - 1; i >= 0; i--) {
                         const double rrow = qR[(size_t)i * P + lc];
-                        double tt = lane_read(gv, i);
-                        for (int j = i + 1; j < P; j++) tt = __builtin_fma(-lane_read(rrow, j), lane_read(bv, j), tt);
-                        const double bi = tt / lane_read(rrow, i);
+                        double tv = gv;                                   // (lane i: gamma[i])
+                        for (int j = i + 1; j < P; j++) tv = __builtin_fma(-rrow, bv, wave_shr1(tv));
+                        const double bi = lane_read(tv, P - 1) / lane_read(rrow, i);
                         if (lane == i) bv = bi;
                     }
                     if (lane < P) beta[lane] = bv;
