@@ -16,7 +16,7 @@ DSQ_LAYOUT_R = 0
 DSQ_LAYOUT_GENE_MAJOR = 1
 DSQ_Y_INT32 = 0
 DSQ_Y_FLOAT64 = 1
-DSQ_MAX_P = 48
+DSQ_MAX_P = 64
 
 DSQ_ERR_FIT = 6
 ERR_NAMES = {1: "DSQ_ERR_ARG", 2: "DSQ_ERR_UNSUPPORTED", 3: "DSQ_ERR_DEVICE", 4: "DSQ_ERR_NOMEM",

@@ -337,6 +337,9 @@ void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *
     DispatchP<DSQ_P_REG>::beta_scratch(p, n, m, useW, slab, cscr);
 }
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok) {
+    // (beyond DSQ_DISP_PERWIDTH_MAX columns the rolled kernel of fit_disp_wide.hip is the only one: what it does not take --
+    //  rows of more than 1024 samples, a working set beyond the LDS -- is refused)
+    if (p > DSQ_DISP_PERWIDTH_MAX && !fit_disp_rolled_applies(kp, nullptr)) { *ok = false; return hipSuccess; }
 #define DSQ_X(W) if (p == W) { *ok = true; return launch_fit_disp_p<W>(kp, st, grid); }
     DSQ_WIDE_LIST(DSQ_X)
 #undef DSQ_X
@@ -374,7 +377,7 @@ static int wide_pad_x(int m, int p, const double *x, hipStream_t st, const doubl
     int rc = wide_pad_matrix(WS_PAD_X, x, (size_t)m, p, st, &b);
     if (rc) return rc;
     *xout = b;
-    *padmask = ((1ull << wide_width(p)) - 1ull) & ~((1ull << p) - 1ull);
+    *padmask = dsq_low_bits(wide_width(p)) & ~dsq_low_bits(p);
     return DSQ_OK;
 }
 
@@ -619,7 +622,7 @@ static int fit_disp_dev_locked(const DsqFitDispArgs *a, const DsqFitDispOut *o, 
     prof_begin(st);
     DSQ_HIP(dispatch_fit_disp(kp.p, kp, st, false, &ok));       // (kp.p: the padded width for a wide design)
     prof_end(st);
-    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d", a->p);
+    if (!ok) return fail(DSQ_ERR_UNSUPPORTED, "no kernel for p=%d, m=%d (49..%d columns: rows of at most 1024 samples whose working set fits the LDS)", a->p, a->m, DSQ_P_WIDE);
     return finish_ycheck(ycheck, st);
 }
 

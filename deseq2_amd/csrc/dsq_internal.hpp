@@ -216,16 +216,20 @@ hipError_t launch_xim_rows(const double *nf, const int32_t *rows, const int32_t 
 // 11 <= p <= DSQ_P_WIDE run on the translation units of DSQ_WIDE_LIST (-DDSQ_P=16, 24, ...: loops not unrolled, p x p state in
 // scratch memory) over designs zero-padded to the next listed width: a padded column gets ridge 1 and a unit diagonal in
 // the Cox-Reid matrix, which leaves every quantity of the real coefficients unchanged (capi.hip, "wide designs").
-// (round 5: 32 and 48 added -- `~ patient + treatment` with up to 47 patients, factors of up to 48 levels; a 64-column
-//  build compiles for half an hour and is left out: p > 48 is refused)
+// (round 5: 32 and 48 added -- `~ patient + treatment` with up to 47 patients, factors of up to 48 levels.  Round 6: 64 --
+//  its fits are the ROLLED kernels alone (fit_beta_wide.hip, fit_disp_wide.hip: one build for every width); the per-width
+//  fitDisp kernel, whose 64-column build compiles for half an hour, stops at DSQ_DISP_PERWIDTH_MAX)
 #define DSQ_P_WIDE0 16
-#define DSQ_WIDE_LIST(X) X(16) X(24) X(32) X(48)
-#define DSQ_P_WIDE 48
-static inline int dsq_wide_width(int p) { return p <= 16 ? 16 : p <= 24 ? 24 : p <= 32 ? 32 : 48; }   // padded width of a wide p
+#define DSQ_WIDE_LIST(X) X(16) X(24) X(32) X(48) X(64)
+#define DSQ_P_WIDE 64
+#define DSQ_DISP_PERWIDTH_MAX 48
+static inline unsigned long long dsq_low_bits(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }   // bits 0 .. k - 1
+static inline int dsq_wide_width(int p) { return p <= 16 ? 16 : p <= 24 ? 24 : p <= 32 ? 32 : p <= 48 ? 48 : 64; }   // padded width of a wide p
 // every design width 1 .. DSQ_P_WIDE (the small per-width kernels of aux.hip: pre-fit moments, linear mu)
 #define DSQ_P_EACH(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) \
     X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) \
-    X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48)
+    X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) \
+    X(61) X(62) X(63) X(64)
 #define DSQ_CMAX 32       // most design cells the cell-collapsed paths take
 #define DSQ_DISP_CELL_MINP 4   // fitDisp assembles the Cox-Reid matrices from cell sums from this design width up
 template <int P> hipError_t launch_fit_disp_p(const DispKernelParams &kp, hipStream_t st, bool grid);
@@ -281,6 +285,7 @@ void fit_beta_rolled_scratch_doubles(int n, int m, int p, int useW, size_t *slab
 hipError_t dispatch_fit_beta(int p, const BetaKernelParams &kp, hipStream_t st, bool *ok);
 void dispatch_beta_scratch(int p, int n, int m, int useW, size_t *slab, size_t *cscr);
 hipError_t dispatch_fit_disp(int p, const DispKernelParams &kp, hipStream_t st, bool grid, bool *ok);
+bool fit_disp_rolled_applies(const DispKernelParams &kp, int *p_true);       // fit_disp_wide.hip
 hipError_t dispatch_optim_rows(int p, const OptimKernelParams &kp, hipStream_t st, bool *ok);
 void capi_prof_begin(const char *name, int n, hipStream_t st);   // no-ops unless dsq_profile_enable(1)
 void capi_prof_end(hipStream_t st);

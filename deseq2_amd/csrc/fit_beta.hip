@@ -1456,8 +1456,8 @@ DSQ_UNROLL_P
         DSQ_BRESET(iter_mark);
         DSQ_BWORK(DsqMatP, G);
         DSQ_BWORK(DsqMatP, Gi);
-        DSQ_BWORK(DsqMatP, T);
         DSQ_BWORK(DsqMatP, Sg);
+        DSQ_BMARK(lu_mark);                      // (the LU below and T after it share this space: 64 columns fit a CU's LDS)
         // pmax(mu, minmu) enters the covariance and the log likelihood; the reported mean keeps the caller's floor
         auto final_w = [&](int j, double muc) {
             if constexpr (USE_W) return wg[j] / (1.0 / muc + alpha);
@@ -1518,6 +1518,8 @@ DSQ_UNROLL_P
             lu.factor();
             lu.inverse(Gi);
         }
+        DSQ_BRESET(lu_mark);
+        DSQ_BWORK(DsqMatP, T);
         mat_mul<P>(Gi, G, T);
         mat_mul<P>(T, Gi, Sg);
         if (lane == 0) {
@@ -1532,9 +1534,9 @@ DSQ_UNROLL_P
     }
 }
 
-// LDS of one single-wave block of the wide build: lam, gam, trial | LU, rhs | G, Gi, T, Sg (+ the final LU)
+// LDS of one single-wave block of the wide build: lam, gam, trial | LU, rhs | G, Gi, Sg, the final LU (then T in its place)
 __host__ __device__ static inline size_t optim_arena_doubles(int p) {
-    return p >= DSQ_BETA_ARENA_MIN ? (size_t)6 * p * p + 12 * p + 32 : 0;
+    return p >= DSQ_BETA_ARENA_MIN ? (size_t)4 * p * p + 12 * p + 32 : 0;
 }
 
 template <>

@@ -1308,11 +1308,17 @@ hipError_t launch_fit_disp_p<DSQ_P>(const DispKernelParams &kp, hipStream_t st, 
 #if DSQ_P >= 16
     if (fit_disp_rolled_applies(kp, nullptr)) return launch_fit_disp_rolled(kp, st, grid);
 #endif
+#if DSQ_P > DSQ_DISP_PERWIDTH_MAX
+    // (beyond DSQ_DISP_PERWIDTH_MAX columns there is no per-width kernel: rows of more than DSQ_SPEC_SERIAL_GRAM_MAXM samples, or
+    //  whose slab does not fit the LDS, are refused -- capi.hip says so before the launch)
+    return hipErrorNotSupported;
+#else
     if (grid)
         return kp.useWeights ? launch_disp_p<DSQ_P, true, 1>(kp, st) : launch_disp_p<DSQ_P, false, 1>(kp, st);
     hipError_t e = kp.useWeights ? launch_disp_p<DSQ_P, true, 0>(kp, st) : launch_disp_p<DSQ_P, false, 0>(kp, st);
     if (e != hipSuccess || !kp.last_d2lp) return e;
     return kp.useWeights ? launch_disp_p<DSQ_P, true, 2>(kp, st) : launch_disp_p<DSQ_P, false, 2>(kp, st);
+#endif
 }
 
 }  // namespace dsq

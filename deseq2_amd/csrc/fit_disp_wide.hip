@@ -34,7 +34,7 @@ __device__ unsigned long long dispw_prof[DSQ_PROF_SLOTS];
 __host__ __device__ static inline size_t dispw_vec_doubles(int p) { return (size_t)4 * p + 24; }
 __host__ __device__ static inline size_t dispw_lds_doubles(int m, int p, bool useW, int mode) {
     const size_t half = ((size_t)m + 1) / 2;
-    const int nmat = mode == 2 ? 5 : (mode == 1 ? 1 : 3);
+    const int nmat = mode == 2 ? 4 : (mode == 1 ? 1 : 3);       // (mode 2: B0 (-> LU), B1, B2 (-> M = Bi B1, once its trace is taken), Bi)
     return dispw_vec_doubles(p) + (size_t)m * (useW ? 2 : 1) + half + (useW ? 0 : (size_t)m) + (size_t)2 * m + (size_t)3 * m +
            (size_t)nmat * p * p + 8;
 }
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fit_disp_rolled_kernel(DispKernelP
     double *wdbuf = p0; p0 += 3 * (size_t)m;
     double *Bm = p0;                             // B[k] at Bm + k P P (k < K); MODE 0 / 2: then Bi (and M)
     constexpr int KMAX = MODE == 2 ? 3 : (MODE == 1 ? 1 : 2);
-    double *Bi = Bm + (size_t)KMAX * P * P, *Mm = Bi + (size_t)P * P;
+    double *Bi = Bm + (size_t)KMAX * P * P, *Mm = Bm + 2 * (size_t)P * P;     // (M takes the place of B2)
     (void)Mm;
 
     auto sync = [] {
@@ -539,8 +539,15 @@ __global__ void __launch_bounds__(64 * NW, 2) fit_disp_rolled_kernel(DispKernelP
                 lu_factor(Bm, sign);
                 lu_inverse(Bm, Bi);
                 sync();
-                // M = Bi B1 (lane_mat_mul: c[i] = sum_k fma(Bi[i][k], B1[k][j]), k ascending), the rows round the waves
                 const double *B1 = Bm + (size_t)P * P, *B2 = Bm + 2 * (size_t)P * P;
+                double detb = 0.0, tr1 = 0.0, tr3 = 0.0;
+                if (wave == 0) {                                  // (the traces with B2 first: M is about to take its place)
+                    detb = lu_det(Bm, sign);
+                    tr1 = trace_sym(Bi, B1);
+                    tr3 = trace_sym(Bi, B2);
+                }
+                sync();
+                // M = Bi B1 (lane_mat_mul: c[i] = sum_k fma(Bi[i][k], B1[k][j]), k ascending), the rows round the waves
                 if (lane < P)
                     for (int i = wave; i < P; i += NW) {
                         double acc = 0.0;
@@ -549,13 +556,10 @@ __global__ void __launch_bounds__(64 * NW, 2) fit_disp_rolled_kernel(DispKernelP
                     }
                 sync();
                 if (wave == 0) {
-                    const double detb = lu_det(Bm, sign);
-                    const double tr1 = trace_sym(Bi, B1);
                     // lane_trace_prod(M, M): the fma chain over (i, k) of M[i][k] M[k][i]
                     double tr2 = 0.0;
                     for (int i = 0; i < P; i++)
                         for (int k = 0; k < P; k++) tr2 = __builtin_fma(Mm[(size_t)i * P + k], Mm[(size_t)k * P + i], tr2);
-                    const double tr3 = trace_sym(Bi, B2);
                     const double ddetb = detb * tr1;
                     const double d2detb = detb * (tr1 * tr1 - tr2 + tr3);
                     const double rr = ddetb / detb;
@@ -712,7 +716,7 @@ bool fit_disp_rolled_applies(const DispKernelParams &kp, int *p_true) {
     if (p_true) *p_true = pt;
     if (getenv("DSQ_DISP_ROLLED") && atoi(getenv("DSQ_DISP_ROLLED")) == 0) return false;
     if (kp.ncell > 0 || pt < 11 || pt > 64) return false;
-    if (kp.padmask != 0 && kp.padmask != ((kp.p >= 64 ? ~0ull : ((1ull << kp.p) - 1ull)) & ~((1ull << pt) - 1ull))) return false;   // (padding at the end)
+    if (kp.padmask != 0 && kp.padmask != (dsq_low_bits(kp.p) & ~dsq_low_bits(pt))) return false;   // (padding at the end)
     if (!(kp.m <= DSQ_SPEC_SERIAL_GRAM_MAXM)) return false;
     const size_t need = dispw_lds_doubles(kp.m, pt, kp.useWeights != 0, kp.last_d2lp ? 2 : 0) * sizeof(double);
     return need + 1024 <= 160 * 1024;

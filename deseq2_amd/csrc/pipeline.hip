@@ -1737,7 +1737,7 @@ static int run_chain(const DsqDeseqArgs *a, const DsqDeseqOut *o, hipStream_t st
         PIPE_HIP(hipMemsetAsync(b, 0, (size_t)m * pk * sizeof(double), st));
         PIPE_HIP(hipMemcpyAsync(b, a->x, (size_t)m * p * sizeof(double), hipMemcpyDeviceToDevice, st));
         P.x_k = (const double *)b;
-        P.padmask = ((1ull << pk) - 1ull) & ~((1ull << p) - 1ull);
+        P.padmask = dsq_low_bits(pk) & ~dsq_low_bits(p);
         PIPE_HIP(hipMemsetAsync(P.beta_init + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
         PIPE_HIP(hipMemsetAsync(P.opt_start + (size_t)n * p, 0, (size_t)n * (pk - p) * sizeof(double), st));
     }

@@ -7,7 +7,7 @@ without a host decision -- including the rows that go to the reference's host-si
 R/fitNbinomGLMs.R:340-407), which the library re-fits by a row-listed launch of its optim kernel.  The host looks at
 the device ONCE per analysis, at the end: counters and the dispersion-trend scalars.  Results are bit-identical to core.DESeq() (tests/test_gpu_fused.py).
 
-Supported: DeviceEngine, p <= 48, fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
+Supported: DeviceEngine, p <= 64, fitType = "parametric" / "mean", test = "Wald" (also with betaPrior = TRUE on the standard or
 the expanded model matrix, and with useT) or "LRT" (any full-rank reduced model matrix), niter = 1, more than 3
 residual degrees of freedom.  Anything else falls back to core.DESeq() / parallel.DESeqParallel().
 """
@@ -27,7 +27,7 @@ def supported(dds, test="Wald", reduced=None, fitType="parametric", **kw):
         return False
     if dds.p > L.DSQ_MAX_P or dds.m <= dds.p:
         return False
-    # (wide designs, 10 < p <= 48 on the zero-padded kernel builds, take everything the narrow ones do since round 5:
+    # (wide designs, 10 < p <= 64 on the zero-padded kernel builds, take everything the narrow ones do since round 5:
     #  observation weights -- csrc/aux.hip weights_prep_wide_kernel --, reduced models and beta-prior passes of more than 10
     #  columns, each design at its own padded width in csrc/pipeline.hip)
     # the preconditions core.estimateDispersionsGeneEst raises on (rank, R/core.R:2624) and the residual-df <= 3

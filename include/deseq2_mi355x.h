@@ -58,9 +58,10 @@ enum {
 enum { DSQ_LAYOUT_R = 0, DSQ_LAYOUT_GENE_MAJOR = 1 };
 enum { DSQ_Y_INT32 = 0, DSQ_Y_FLOAT64 = 1 }; /* R INTSXP or REALSXP count matrix */
 
-#define DSQ_MAX_P 48 /* largest number of design columns served: 1..10 by register-resident kernels (one per
-                       width), 11..48 by generic kernels over the design zero-padded to 16, 24, 32 or 48 (slower; the
-                       reference itself has no limit, src/DESeq2.cpp:283-465 -- a 64-column build compiles for half an hour) */
+#define DSQ_MAX_P 64 /* largest number of design columns served: 1..10 by register-resident kernels (one per
+                       width), 11..64 by kernels over the design zero-padded to 16, 24, 32, 48 or 64 columns (the reference
+                       itself has no limit, src/DESeq2.cpp:283-465).  49..64 columns: fitDisp / fitDispGrid take rows of
+                       at most 1024 samples whose working set fits a CU's LDS (else DSQ_ERR_UNSUPPORTED) */
 
 /* ---- fitBeta ------------------------------------------------------------------
  * reference: List fitBeta(ySEXP, xSEXP, nfSEXP, alpha_hatSEXP, contrastSEXP,
@@ -560,7 +561,7 @@ int64_t dsq_deseq_workspace_bytes(int32_t n, int32_t m, int32_t p, int32_t n_tre
  * classic routines it cuts the genes into the contiguous ranges of R/parallel.R:10, one per visible device
  * (DSQ_HOST_DEVICES / DSQ_HOST_SHARDS as there); the ranges exchange the two n-vectors of the dispersion trend
  * through host memory, as DESeqParallel does (R/parallel.R:27-40).
- * Covers what the fused chain covers: parametric trend, fitType "mean" or the caller's own trend (geneEstOnly / dispFit), Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= 48
+ * Covers what the fused chain covers: parametric trend, fitType "mean" or the caller's own trend (geneEstOnly / dispFit), Wald (also with betaPrior = TRUE) or LRT (any nested reduced model), p <= DSQ_MAX_P
  * (wide designs, 10 < p, included: observation weights, reduced models of any width < p and the beta-prior pass since round 5),
  * m - p > 3, size factors or a normalization-factor matrix, observation weights; anything else returns
  * DSQ_ERR_UNSUPPORTED and the caller keeps to the three classic routines.  The design-only quantities R has functions

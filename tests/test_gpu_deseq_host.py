@@ -365,8 +365,8 @@ def test_host_entry_argument_errors():
     with pytest.raises(L.DsqError, match="residual degrees of freedom"):
         native.DESeq(counts[:, :4], simulate.design_two_group(4), sf[:4])
     with pytest.raises(L.DsqError, match="design columns"):
-        native.DESeq(np.ones((5, 60), dtype=np.int32), np.column_stack([np.ones(60)] + [np.cos(np.arange(60.0) * k) for k in range(1, 49)]),
-                     np.ones(60))                                   # 49 columns: beyond the widest (48-column) build
+        native.DESeq(np.ones((5, 80), dtype=np.int32), np.column_stack([np.ones(80)] + [np.cos(np.arange(80.0) * k) for k in range(1, 65)]),
+                     np.ones(80))                                   # 65 columns: beyond the widest (64-column) build
     with pytest.raises(L.DsqError, match="zero counts"):
         native.DESeq(np.zeros((20, 12), dtype=np.int32), x, sf)
     bad = counts.astype(np.float64)

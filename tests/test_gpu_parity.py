@@ -174,10 +174,10 @@ def test_double_counts_and_bad_counts():
         native.fitBeta(bad, d["x"], d["nf"], d["alpha_init"], [1, 0], d["beta_init"], lam, d["weights"], False,
                        1e-8, 100, True, 0.5)
     with pytest.raises(_lib.DsqError):   # p beyond compiled kernels must fail loudly, never fall back
-        d60 = make_case(20, 60, "two_group", seed=7)
-        x9 = np.column_stack([d60["x"]] + [np.random.default_rng(i).normal(size=60) for i in range(47)])   # p = 49
-        native.fitBeta(d60["counts"], x9, d60["nf"], d60["alpha_init"], np.r_[1, np.zeros(48)],
-                       np.zeros((d60["counts"].shape[0], 49)), np.full(49, 1e-6), d60["weights"], False, 1e-8, 100,
+        d60 = make_case(20, 80, "two_group", seed=7)
+        x9 = np.column_stack([d60["x"]] + [np.random.default_rng(i).normal(size=80) for i in range(63)])   # p = 65 > DSQ_MAX_P
+        native.fitBeta(d60["counts"], x9, d60["nf"], d60["alpha_init"], np.r_[1, np.zeros(64)],
+                       np.zeros((d60["counts"].shape[0], 65)), np.full(65, 1e-6), d60["weights"], False, 1e-8, 100,
                        True, 0.5)
 
 

@@ -233,7 +233,7 @@ def test_wide_chain_paired_design_matches_oracle(oracle):
         assert_same(np.asarray(res[k], float), np.asarray(b.mcols[kr], float), "paired-design dsq_deseq$" + k)
 
 
-@pytest.mark.parametrize("p,m", [(12, 60), (16, 130), (24, 120), (31, 93), (46, 200)])
+@pytest.mark.parametrize("p,m", [(12, 60), (16, 130), (24, 120), (31, 93), (46, 200), (56, 150), (64, 200)])
 def test_wide_weights_prep_matches_host(p, m):
     """getAndCheckWeights (R/core.R:2697-2751) on designs of more than 10 columns (round 5: weights_prep_wide_kernel, the
     Gram matrices entry-per-lane, the rank test one column per lane): normalised weights, their floor and the
@@ -366,10 +366,57 @@ def test_wide_chain_with_beta_prior(oracle, levels, mode):
         assert_same(np.asarray(res[k], float), np.asarray(c.mcols[kr], float), "wide betaPrior dsq_deseq$" + k)
 
 
+@pytest.mark.parametrize("kind,levels,useW", [("paired", 55, False), ("paired", 63, True), ("factor", 56, False), ("factor", 64, False)])
+def test_designs_of_49_to_64_columns(oracle, kind, levels, useW):
+    """round 6: DSQ_MAX_P = 64.  49 .. 64 columns run on the 64-column build, whose fits are the rolled
+    kernels alone (fit_beta_wide.hip, fit_disp_wide.hip): `~ patient + treatment` with 55 / 63 patients (p = 56 / 64),
+    factors of 56 / 64 levels with four samples each -- fitBeta, fitDisp (with and without prior, d2 included), fitDispGrid
+    identical to the oracle at the true p."""
+    if kind == "paired":
+        x = _paired_design(levels)
+        rng = np.random.default_rng(levels)
+        sf = np.exp(rng.normal(0, 0.2, x.shape[0]))
+        d = simulate.make_counts(48, x, seed=levels, beta_sd=np.array([0.4] * (levels - 1) + [1.0]), size_factors=sf)
+        _native_triplet_vs_oracle(oracle, d["counts"], x, sf, "paired %d" % levels, useW=useW, seed=levels)
+    else:
+        d = make_case(48, 4 * levels, ("factor", levels), seed=levels, sf_random=True)
+        _native_triplet_vs_oracle(oracle, d["counts"], d["x"], d["size_factors"], "factor %d" % levels, useW=useW)
+
+
+def test_wide_chain_on_a_56_column_design(oracle):
+    """the whole DESeq() chain (fused device chain and the one-call host entry) on a paired design with 55 patients"""
+    from deseq2_amd import fused
+    x = _paired_design(55)
+    d = simulate.make_counts(96, x, seed=56, beta_sd=np.array([0.4] * 54 + [1.0]))
+    E = DeviceEngine("cuda:0")
+    a = core.DESeqDataSet(d["counts"], x, engine=E)
+    assert fused.supported(a)
+    fused.DESeq(a)
+    assert a.attrs.get("fused")
+    b = core.DESeq(core.DESeqDataSet(d["counts"], x, engine=HostEngine(oracle)))
+    for k in ("dispGeneEst", "dispGeneIter", "dispersion", "dispIter", "beta", "betaSE", "WaldStatistic", "betaIter", "deviance"):
+        assert_same(a.mcols[k], b.mcols[k], "56-column chain$" + k)
+    res = native.DESeq(d["counts"], x, np.ones(x.shape[0]), assays=())
+    for k, kr in (("dispGeneEst", "dispGeneEst"), ("dispersion", "dispersion"), ("beta", "beta"), ("betaSE", "betaSE"),
+                  ("stat", "WaldStatistic")):
+        assert_same(np.asarray(res[k], float), np.asarray(b.mcols[kr], float), "56-column dsq_deseq$" + k)
+
+
+def test_long_rows_beyond_48_columns_are_refused():
+    """49 .. 64 columns: fitDisp takes rows of at most 1024 samples (the serial Gram sums of the arithmetic spec) -- longer
+    ones are refused, not fitted otherwise"""
+    from deseq2_amd import _lib
+    d = make_case(4, 1100, ("factor", 50), seed=3)
+    mu = np.full(d["counts"].shape, 10.0)
+    la = np.zeros(4)
+    with pytest.raises(_lib.DsqError):
+        native.fitDisp(d["counts"], d["x"], mu, la, la, 1.0, np.log(1e-9), 1.0, 1e-6, 100, False, d["weights"], False, 1e-2, True)
+
+
 def test_too_wide_is_refused():
     from deseq2_amd import _lib
-    d = make_case(10, 147, ("factor", 49), seed=1)
-    p = 49
+    d = make_case(10, 195, ("factor", 65), seed=1)
+    p = 65
     with pytest.raises(_lib.DsqError):
         native.fitBeta(d["counts"], d["x"], d["nf"], d["alpha_init"], np.r_[1.0, np.zeros(p - 1)], d["beta_init"],
                        np.full(p, 1e-6), d["weights"], False, 1e-8, 100, True, 0.5)

@@ -8,3 +8,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; cd $R
 timeout 900 python tools/widebench.py > $O/wide.txt 2>&1; grep "^p=" $O/wide.txt
 timeout 600 python tools/contbench.py > $O/general_path.txt 2>&1; tail -5 $O/general_path.txt
 sha256sum deseq2_amd/libdeseq2_mi355x.so > $O/library.sha256
+# the phase shares of the rolled wide kernels (make prof), when the profiling build travelled
+if [ -f deseq2_amd/libdeseq2_prof.so ]; then
+  DSQ_LIB=$R/deseq2_amd/libdeseq2_prof.so timeout 600 python tools/widebench.py 48 31 2>&1 | grep -E "_prof\]" | sort | uniq > $O/wide_phases.txt; cat $O/wide_phases.txt
+fi
+# the default bench line with the PMC files of THIS library next to it (bench.py binds them by the library's sha256)
+cp $O/pmc_C3.json profiles/r06_pmc_C3.json; cp $O/pmc_C4.json profiles/r06_pmc_C4.json
+timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.log; python - <<PY
+import json
+d = json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+print("default bench:", d["value"], d["unit"], d["ms_per_step"], "ms/step; roofline", d.get("roofline"), "; pmc_matches_library", d.get("pmc_matches_library", d.get("roofline", {}).get("pmc_matches_library")))
+PY

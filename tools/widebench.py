@@ -21,7 +21,8 @@ def main(cases):
 
 CASES = [(10, 20000, 200, None), (12, 20000, 200, None), (16, 20000, 200, None), (20, 20000, 200, None), (24, 20000, 240, None),
          (32, 20000, 256, None), (40, 20000, 240, None), (48, 20000, 288, None),          # round 5: the 32- and 48-column builds
-         (31, 20000, 60, paired(30)), (46, 20000, 90, paired(45))]
+         (31, 20000, 60, paired(30)), (46, 20000, 90, paired(45)),
+         (56, 20000, 110, paired(55)), (64, 20000, 256, None)]                              # round 6: the 64-column build
 def run(levels, n, m, xx):
     x = simulate.design_factor(m, levels) if xx is None else xx
     d = simulate.make_counts(n, x, seed=3)
