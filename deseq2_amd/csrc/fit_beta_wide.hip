@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
     int *piv = reinterpret_cast<int *>(lv + 9 * P + 2);
     double *ctl = lv + 10 * P + 8;             // [0] loop control of the IRLS, [1] next gene, [2] dev, [3] iterations
     double *tprev2 = lv + 10 * P + 16;         // (the stages of the QR write tprev and tprev2 in turn)
+    double *refl = lv + 11 * P + 17;           // reflector constants (bet, tau, scal) of the next stage, two sets in turn
     double *slab;
     if constexpr (BIG_LDS) slab = smem + wide_lds_doubles(P);
     else slab = kp.scratch + (size_t)blockIdx.x * wide_slab_doubles(m, P);
@@ -319,15 +320,18 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                 for (int k = 0; k < P; k++) {
                     const double *tp_cur = (k & 1) ? tprev2 : tprev;       // written by stage k - 1
                     double *tp_next = (k & 1) ? tprev : tprev2;
-                    const double alpha_k = qa[(size_t)k * M + k];
-                    const double acck = accs[k];
+                    // reflection k's constants: stage 0 derives them here; later stages read what the look-ahead wave left
+                    auto reflector = [&](double alpha_k, double acck, double &bet, double &tau, double &scal) __attribute__((always_inline)) {
+                        if (acck == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
+                        else {
+                            bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acck), alpha_k);
+                            tau = (bet - alpha_k) / bet;
+                            scal = 1.0 / (alpha_k - bet);
+                        }
+                    };
                     double tau, scal, bet;
-                    if (acck == 0.0) { tau = 0.0; scal = 0.0; bet = alpha_k; }
-                    else {
-                        bet = -__builtin_copysign(__builtin_sqrt(alpha_k * alpha_k + acck), alpha_k);
-                        tau = (bet - alpha_k) / bet;
-                        scal = 1.0 / (alpha_k - bet);
-                    }
+                    if (k == 0) reflector(qa[0], accs[0], bet, tau, scal);
+                    else { const double *rc = refl + 3 * (k & 1); bet = rc[0]; tau = rc[1]; scal = rc[2]; }
                     if (tid == 0) qR[(size_t)k * P + k] = bet;
                     const int i0 = lane + 64 * (k / 64);                 // (trips whose rows are all finished rows of R: skipped)
                     const double *prevp = qa + (size_t)(k > 0 ? k - 1 : 0) * M, *kcol = qa + (size_t)k * M;
@@ -395,18 +399,22 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                         if (k + 1 < P) {
                             const int kk = k + 1;
                             double *col = qa + (size_t)kk * M;
-                            double a2[1] = {0.0};
+                            double a2[1] = {0.0}, akk = 0.0;
                             for (int i = lane + 64 * (kk / 64); i < M; i += 64) {
                                 if (i >= kk) {
                                     const double v = kcol[i] * scal;
                                     double a = col[i];
                                     a = __builtin_fma(v, tpn, a);
                                     col[i] = a;
+                                    if (i == kk) akk = a;
                                     a2[0] += (i > kk) ? a * a : 0.0;
                                 }
                             }
                             wave_allreduce_many(a2, lane);
-                            if (lane == 0) accs[kk] = a2[0];
+                            // ... and reflection k + 1's constants, for every wave to read behind the barrier
+                            double nb, nt, ns;
+                            reflector(lane_read(akk, kk & 63), a2[0], nb, nt, ns);
+                            if (lane == 0) { double *rc = refl + 3 * (kk & 1); rc[0] = nb; rc[1] = nt; rc[2] = ns; }
                         }
                     }
                     {

@@ -42,11 +42,51 @@ def design(rng, m):
     return x
 
 
+WIDE_BASE = 1000000      # seeds from here on draw WIDE designs (round 6: 11 .. 64 columns; the seeds below keep their meaning)
+
+
+def design_wide(rng):
+    """11 .. 64 columns without (useful) cells: paired designs, factors of many levels, continuous covariates, mixtures"""
+    kind = rng.integers(4)
+    if kind == 0:                                  # ~ patient + treatment
+        patients = int(rng.integers(10, 64))
+        reps = int(rng.integers(1, 3))
+        m = 2 * patients * reps
+        pat = np.repeat(np.arange(patients), 2 * reps)
+        trt = np.tile(np.repeat([0.0, 1.0], reps), patients)
+        x = np.column_stack([np.ones(m)] + [(pat == k).astype(float) for k in range(1, patients)] + [trt])
+    elif kind == 1:                                # a factor of many levels
+        levels = int(rng.integers(11, 65))
+        m = levels * int(rng.integers(2, 5))
+        f = np.arange(m) % levels
+        rng.shuffle(f)
+        x = np.column_stack([np.ones(m)] + [(f == l).astype(float) for l in range(1, levels)])
+    else:                                          # continuous covariates (kind 3: next to a small factor)
+        p = int(rng.integers(11, 65))
+        m = int(rng.integers(p + 4, max(p + 5, 260)))
+        cols = [np.ones(m)]
+        if kind == 3:
+            f = np.arange(m) % 4
+            rng.shuffle(f)
+            cols += [(f == l).astype(float) for l in range(1, 4)]
+        while len(cols) < p:
+            cols.append(rng.normal(size=m))
+        x = np.column_stack(cols)
+    if np.linalg.matrix_rank(x) < x.shape[1]:
+        x[:, 1:] += rng.normal(0, 0.1, (x.shape[0], x.shape[1] - 1))
+    return x
+
+
 def one(seed):
     rng = np.random.default_rng(50000 + seed)
-    m = int(rng.integers(4, 300))
-    n = int(rng.integers(1, 60))
-    x = design(rng, m)
+    if seed >= WIDE_BASE:
+        x = design_wide(rng)
+        m = x.shape[0]
+        n = int(rng.integers(1, 24))
+    else:
+        m = int(rng.integers(4, 300))
+        n = int(rng.integers(1, 60))
+        x = design(rng, m)
     p = x.shape[1]
     mu = np.exp(rng.normal(3, 1.5, (n, 1))) * np.exp(rng.normal(0, 0.3, (n, m)))
     size = 1.0 / rng.uniform(0.02, 2.0, (n, 1))
