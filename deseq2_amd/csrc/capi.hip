@@ -498,6 +498,7 @@ static int fit_beta_dev_locked(const DsqFitBetaArgs *a, const DsqFitBetaOut *o, 
         DSQ_HIP(hipMemsetAsync(bb, 0, npw * sizeof(double), st));
         DSQ_HIP(hipMemcpyAsync(bb, a->beta_mat, (size_t)a->n * a->p * sizeof(double), hipMemcpyDeviceToDevice, st));
         kp.beta_init = bb; kp.beta_mat = bb + npw; kp.beta_var_mat = bb + 2 * npw;
+        kp.p_true = a->p;
         wide_out = bb + npw;
         kp.p = pk;
     }

@@ -77,6 +77,9 @@ struct BetaKernelParams {
     int ncell;
     double *kconst_out;     // n values or NULL: K' of the row -- the mu-independent part of sum [wts] log NB(y; 1/alpha, mu) on
                             // the closed split (dsq_math.hpp) -- for the nbinomLogLike launch that follows this fit
+    int p_true;             // WIDE designs: the design's own number of columns (the zero padding follows them); 0 = p.  The
+                            // rolled kernel runs at this width -- the padded coefficients' ridge rows and zero columns only
+                            // ever add exact zeros to the real ones' sums -- and writes the padding's outputs (0) itself
 };
 
 struct PrefitKernelParams {

@@ -66,7 +66,9 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
     const int lane = tid & 63;
     const int wave = tid >> 6;
     constexpr int NT = 64 * NW;                // threads per gene (= per workgroup)
-    const int m = kp.m, P = kp.p;
+    // (P: the width the fit runs at -- the design's own, kp.p_true, when the launch found its slab to fit the LDS; kp.p is
+    //  the padded width of the n x p arrays, whose padding columns get their outputs, 0, at the end)
+    const int m = kp.m, P = kp.p_true > 0 ? kp.p_true : kp.p;
     const int M = m + P;
     const int nwork = DSQ_NWORK(kp);
     if ((int)blockIdx.x >= nwork) return;
@@ -635,9 +637,9 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
             wave_lds_sync();
             double cd = 0.0;
             for (int b = 0; b < P; b++) cd = __builtin_fma(rhs[b], contrast[b], cd);
-            for (int c = lane; c < P; c += 64) {
-                kp.beta_mat[(size_t)g + (size_t)kp.n * c] = beta[c];
-                kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = Sg[(size_t)c * P + c];
+            for (int c = lane; c < kp.p; c += 64) {
+                kp.beta_mat[(size_t)g + (size_t)kp.n * c] = c < P ? beta[c] : 0.0;
+                kp.beta_var_mat[(size_t)g + (size_t)kp.n * c] = c < P ? Sg[(size_t)c * P + c] : 0.0;
             }
             if (lane == 0) {
                 kp.iter[g] = it;
@@ -713,8 +715,15 @@ void fit_beta_rolled_scratch_doubles(int n, int m, int p, int useW, size_t *slab
 }
 
 hipError_t launch_fit_beta_rolled(const BetaKernelParams &kp0, hipStream_t st) {
-    const WideGeom g = wide_geometry(kp0.n, kp0.m, kp0.p, kp0.useWeights != 0);
+    // at the design's own width when its slab then fits the LDS (no scratch involved); else at the padded width the scratch
+    // was sized for
+    WideGeom g = wide_geometry(kp0.n, kp0.m, kp0.p, kp0.useWeights != 0);
     BetaKernelParams kp = kp0;
+    kp.p_true = kp0.p;
+    if (kp0.p_true >= 11 && kp0.p_true < kp0.p && !(getenv("DSQ_WIDE_PADDED") && atoi(getenv("DSQ_WIDE_PADDED")))) {
+        const WideGeom gt = wide_geometry(kp0.n, kp0.m, kp0.p_true, kp0.useWeights != 0);
+        if (gt.big_lds) { g = gt; kp.p_true = kp0.p_true; }
+    }
     kp.xlds = 0;
     int grid = g.grid;
     // (a row list: its length lives on the device; the scratch was sized for the full grid, a smaller one uses its head)

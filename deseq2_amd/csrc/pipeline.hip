@@ -1063,6 +1063,7 @@ static int launch_fit_beta(Pipe &P, const Rows &rw, const int32_t *y, const doub
     kp.work_counter = next_work_counter(P);
     kp.rows = rw.rows; kp.n_dev = rw.n_dev; kp.rows_few = (rw.rows && rw.rows != P.rows_nz && rw.rows != P.rows_lpt) ? 1 : 0;
     kp.cell_perm = ds.cperm; kp.cell_start = ds.cstart; kp.ncell = ds.ncell;
+    kp.p_true = ds.p_true;
     bool ok = false;
     char nm[32];
     snprintf(nm, sizeof nm, "%s%s", name, P.tag);
