@@ -38,7 +38,8 @@
 #include "dsq_math.hpp"
 #include "dsq_wave.hpp"
 #include "../../include/dsq_arith_spec.h"
-#include "fit_beta_common.hpp"     // nb_offbranch, irls_constants: shared with the rolled wide kernel (fit_beta_wide.hip)
+#include "fit_beta_common.hpp"
+#include "dsq_prof.hpp"     // nb_offbranch, irls_constants: shared with the rolled wide kernel (fit_beta_wide.hip)
 
 namespace dsq {
 
@@ -804,6 +805,14 @@ __host__ __device__ static inline size_t beta_cell_wave_doubles(int m, bool use_
 }
 static_assert((4 + 16) * DSQ_CMAX >= kIrlsTab / 2 + 2 * kIrlsTab, "the constants pass borrows the wave's cell slab + park area");
 
+// -DDSQ_WIDE_PROF (make prof): the phases of a gene's fit in shader-clock cycles, per wave, flushed once at the end of the
+// kernel and printed by the launch (dsq_prof.hpp)
+#ifdef DSQ_WIDE_PROF
+__device__ unsigned long long betac_prof[DSQ_PROF_SLOTS];
+#define DSQ_CPROF(slot) do { const unsigned long long t1_ = clock64(); pacc_k[slot] += t1_ - pt0_k; pt0_k = t1_; } while (0)
+#else
+#define DSQ_CPROF(slot)
+#endif
 template <int P, bool USE_W>
 __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(BetaKernelParams kp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -850,7 +859,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
     asm volatile("" : "+v"(minmu_));
     const double minmu = minmu_;
 
+#ifdef DSQ_WIDE_PROF
+    unsigned long long pacc_k[DSQ_PROF_SLOTS] = {}, pt0_k = clock64();
+#endif
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
+        DSQ_CPROF(7);                                      // (drawing the gene)
         const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *nfg = kp.nf_is_vector ? kp.nf : kp.nf + (size_t)g * kp.ld;
@@ -882,6 +895,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         //  pass its presence flags and its table)
         if (with_dev_ever) K = irls_constants<USE_W>(yg, nfg, wg, m, lane, alpha, size, fast, lnf_s, kp.kconst_out ? &Kp : nullptr, slab);
         if (kp.kconst_out && lane == 0) kp.kconst_out[g] = Kp;
+        DSQ_CPROF(0);
         // one sweep over the samples at the current beta: positions k = lane, lane + 64, ... of the cell-sorted
         // sequence (full trips); the sums of a cell are closed when the sweep leaves it.  Deviance term of a sample:
         // y lg - (y + size) log1p(alpha mu), lg = log(mu / nf) -- one logarithm (of the rounded 1 + alpha mu, plus
@@ -1006,7 +1020,9 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
         };
 
         cell_eta();
+        DSQ_CPROF(3);
         sweep(false);
+        DSQ_CPROF(1);
         double dev_old = 0.0, it = 0.0;
         for (int t = 0; t < kp.maxit; t++) {
             it += 1.0;
@@ -1126,8 +1142,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
 #pragma unroll
             for (int c = 0; c < P; c++) toolarge += (__builtin_fabs(beta[c]) > large) ? 1 : 0;
             if (uniform(toolarge > 0)) { it = (double)kp.maxit; expl = exp_prev; break; }          // (:357-360)
+            DSQ_CPROF(2);
             cell_eta();
+            DSQ_CPROF(3);
             sweep(true);
+            DSQ_CPROF(1);
             const double conv_test = __builtin_fabs(dev - dev_old) / (__builtin_fabs(dev) + 0.1);
             if (uniform(conv_test != conv_test)) { it = (double)kp.maxit; break; }                  // (:375-378)
             if (kp.force_iters > 0) { if (t + 1 >= kp.force_iters) break; }
@@ -1135,6 +1154,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             dev_old = dev;
         }
 
+        DSQ_CPROF(4);
         // ---- post-loop block (:427-455) from the cell sums of the final mu ----------------------------------------
         if constexpr (P >= DSQ_BETA_LANE_MIN) {
             // one matrix column per lane: X'WX, its ridge inverse and sigma = Gi G Gi cost 2 P registers each
@@ -1303,7 +1323,11 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             kp.contrast_denom[g] = __builtin_sqrt(cd);
         }
         }
+        DSQ_CPROF(5);
     }
+#ifdef DSQ_WIDE_PROF
+    if (lane == 0) for (int q_ = 0; q_ < DSQ_PROF_SLOTS; q_++) atomicAdd(&betac_prof[q_], pacc_k[q_]);
+#endif
 }
 
 template <int P>
@@ -1328,8 +1352,25 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
     int grid = blocks_needed < cus * bpc_cache[wi] ? blocks_needed : cus * bpc_cache[wi];
     if (kp.rows_few && grid > cus) grid = cus;
     if (grid < 1) grid = 1;
+#ifdef DSQ_WIDE_PROF
+    unsigned long long pz[DSQ_PROF_SLOTS] = {}, ph[DSQ_PROF_SLOTS];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(betac_prof), pz, sizeof(pz));
+#endif
     if (kp.useWeights) hipLaunchKernelGGL((fit_beta_cell_kernel<P, true>), dim3(grid), dim3(64 * waves), lds, st, kp);
     else hipLaunchKernelGGL((fit_beta_cell_kernel<P, false>), dim3(grid), dim3(64 * waves), lds, st, kp);
+#ifdef DSQ_WIDE_PROF
+    if (kp.n >= 1000) {
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(betac_prof), sizeof(ph));
+        double tot = 0;
+        for (int q = 0; q < DSQ_PROF_SLOTS; q++) tot += (double)ph[q];
+        static const char *nm[8] = {"start + IRLS constants", "sample sweeps (+ closes, deviance)", "collapsed least squares", "cell eta / exp", "convergence control",
+                                    "post-loop block + outputs", "-", "next gene"};
+        fprintf(stderr, "[betac_prof] p=%d m=%d n=%d cells=%d maxit=%d:", P, kp.m, kp.n, kp.ncell, kp.maxit);
+        for (int q = 0; q < 8; q++) if (q != 6) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "  (%.0f Mcycles over all waves)\n", tot / 1e6);
+    }
+#endif
     return hipGetLastError();
 }
 

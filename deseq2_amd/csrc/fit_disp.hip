@@ -46,6 +46,16 @@ typedef double DsqMat2[2][DSQ_P][DSQ_P];
 typedef double DsqMat3[3][DSQ_P][DSQ_P];
 typedef double DsqMat[DSQ_P][DSQ_P];
 
+// -DDSQ_WIDE_PROF (make prof): the phases of a gene's fit in shader-clock cycles, per wave, summed over the launch and
+// printed by it (dsq_prof.hpp) -- the dynamic attribution PC sampling would give, were it available on this pool
+#include "dsq_prof.hpp"
+#ifdef DSQ_WIDE_PROF
+__device__ unsigned long long disp_prof[DSQ_PROF_SLOTS];
+#define DSQ_GPROF(slot) do { const unsigned long long t1_ = clock64(); pacc[slot] += t1_ - pt0; pt0 = t1_; } while (0)
+#else
+#define DSQ_GPROF(slot)
+#endif
+
 template <int P>
 struct SymN { static constexpr int value = P * (P + 1) / 2; };
 
@@ -62,6 +72,9 @@ struct DispGene {
     unsigned long long dropmask;  // bit c: design column c is all-zero over the kept rows (:41-43)
     unsigned long long padmask;   // bit c: column c is zero padding of a wide design (WIDE translation unit only)
     int ablate;         // profiling only (DSQ_ABLATE), 0 in production
+#ifdef DSQ_WIDE_PROF
+    mutable unsigned long long pt0, pacc[DSQ_PROF_SLOTS];
+#endif
     // every fitted mean of the gene lies in [0, 1e140): with alpha in [e^-30, e^10] (the search's clamp, :215-224) and
     // on the dispersion grid, 1 + mu alpha is then a normal number far from the ends of the exponent range and its
     // reciprocal takes the scaling-free division (drcp_n: same quotient, 4 instructions less per sample)
@@ -238,6 +251,7 @@ DSQ_UNROLL_P
                 for (int b = 0; b < NB; b++)
                     if (k0 + 64 * b < m) trip(k0 + 64 * b, vb[b], jb[b], cb[b], yb[b], mb[b]);
             }
+            DSQ_GPROF(4);
             if (!useCR) return;
             close_cell();
             wave_lds_sync();
@@ -255,6 +269,7 @@ DSQ_UNROLL_P
                 }
             }
             wave_lds_sync();                                  // (the next evaluation parks into the same slots)
+            DSQ_GPROF(5);
             if constexpr (LANE) {
                 // lane b builds column b: entry (i, b) = sum_c (x_c[i] x_c[b]) S_c, cells in order
                 const int bl = lane < P ? lane : 0;
@@ -659,12 +674,14 @@ DSQ_UNROLL_P
     // digamma of the same argument -- the shift, log(xs) and 1/xs.  Each shared value is produced
     // by the very expression the separate functions use, so lp and dlp keep their bits.
     DSQ_DEV double lp_dlp(double la, bool withPrior, double &dlp_out) const {
+        DSQ_GPROF(10);                                     // (the search's own statements since the last evaluation)
         const double alpha = dexp(la);
         const double an1 = 1.0 / alpha;
         const double an2 = 1.0 / (alpha * alpha);
         double lg_an1 = 0.0, dg_an1 = 0.0;
         if constexpr (USE_W) dlgamma_digamma(an1, lg_an1, dg_an1);
         double acc = 0.0, acc2 = 0.0;
+        DSQ_GPROF(3);
         double cr_lp = 0.0, cr_dlp = 0.0;
         {
             Bmat<2> B;
@@ -703,6 +720,7 @@ DSQ_UNROLL_P
                     }
                 },
                 B);
+            DSQ_GPROF(6);
             if (useCR) {
                 double detb, tr1;
                 cr_algebra(B, detb, tr1);
@@ -710,6 +728,7 @@ DSQ_UNROLL_P
                 double ddetb = detb * tr1;
                 cr_dlp = -0.5 * ddetb / detb;
             }
+            DSQ_GPROF(7);
         }
         double ll_part, ll_dpart;
         if constexpr (USE_W) {
@@ -734,6 +753,7 @@ DSQ_UNROLL_P
                     accv2 += c * (dg_an1 - dg);
                 }
             }
+            DSQ_GPROF(8);
 #ifdef DSQ_DISP_SINGLE_REDUCTIONS
             double sv = wave_allreduce(accv), sv2 = wave_allreduce(accv2);
             ll_part = sv + wave_allreduce(acc);
@@ -752,6 +772,7 @@ DSQ_UNROLL_P
         }
         if (withPrior) prior_dpart = -1.0 * (la - prior_mean) / prior_sigmasq;
         dlp_out = (ll_dpart + cr_dlp) * alpha + prior_dpart;
+        DSQ_GPROF(9);
         return ll_part + prior_part + cr_lp;
     }
 
@@ -1060,14 +1081,24 @@ __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? D
     }
     if (C > 0 || (STAGE && kp.xlds)) __syncthreads();
 
+#ifdef DSQ_WIDE_PROF
+    unsigned long long pacc_k[DSQ_PROF_SLOTS] = {}, pt_gene = clock64();
+#endif
     for (int wi = blockIdx.x * waves + wave; wi < nwork; wi = next_gene(kp.work_counter, wi, gridDim.x * waves, lane)) {
         const int g = DSQ_GENE(kp, wi);
         const int32_t *yg = kp.y + (size_t)g * kp.ld;
         const double *mug = kp.mu_hat + (size_t)g * kp.ld;
         const double *wg = USE_W ? kp.weights + (size_t)g * kp.ld : nullptr;
+#ifdef DSQ_WIDE_PROF
+        pacc_k[11] += clock64() - pt_gene;              // (drawing the next gene)
+#endif
 
         using Rows = typename std::conditional<STAGE, RowsLds, RowsGlobal>::type;
         DispGene<P, USE_W, Rows> G;
+#ifdef DSQ_WIDE_PROF
+        for (int q_ = 0; q_ < DSQ_PROF_SLOTS; q_++) G.pacc[q_] = pacc_k[q_];       // (the wave's running totals: flushed once, at the end)
+        G.pt0 = clock64();
+#endif
         int32_t *dist;
         if constexpr (STAGE) {
             double *ms = slab, *ws = slab + (size_t)m;
@@ -1119,8 +1150,17 @@ __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? D
         //  large count would pay both -- measured at m = 100: fit_disp 0.387 -> 0.406 ms with it)
         G.hist_lds = (disp_global_dv<USE_W, STAGE, MODE>() && disp_hist_doubles(P, m) > 0) ? reinterpret_cast<int32_t *>(slab) : nullptr;
         G.hist_ok = (!disp_global_dv<USE_W, STAGE, MODE>() || G.hist_lds != nullptr) && m >= 256;
+#ifdef DSQ_WIDE_PROF
+        { const unsigned long long t1_ = clock64(); G.pacc[0] += t1_ - G.pt0; G.pt0 = t1_; }
+#endif
         G.build_distinct(dist);
+#ifdef DSQ_WIDE_PROF
+        { const unsigned long long t1_ = clock64(); G.pacc[1] += t1_ - G.pt0; G.pt0 = t1_; }
+#endif
         G.setup_cr();
+#ifdef DSQ_WIDE_PROF
+        { const unsigned long long t1_ = clock64(); G.pacc[2] += t1_ - G.pt0; G.pt0 = t1_; }
+#endif
 
         if constexpr (MODE == 2) {
             double d2 = G.d2lp(kp.log_alpha[g]);
@@ -1220,7 +1260,15 @@ __global__ void __launch_bounds__(256, (disp_global_dv<USE_W, STAGE, MODE>() ? D
                 kp.last_dlp[g] = dlp;
             }
         }
+#ifdef DSQ_WIDE_PROF
+        { const unsigned long long t1_ = clock64(); G.pacc[10] += t1_ - G.pt0; G.pt0 = t1_; }
+        for (int q_ = 0; q_ < DSQ_PROF_SLOTS; q_++) pacc_k[q_] = G.pacc[q_];
+        pt_gene = clock64();
+#endif
     }
+#ifdef DSQ_WIDE_PROF
+    if (lane == 0) for (int q_ = 0; q_ < DSQ_PROF_SLOTS; q_++) atomicAdd(&disp_prof[q_], pacc_k[q_]);
+#endif
 }
 
 // ---- launch ---------------------------------------------------------------------
@@ -1286,10 +1334,27 @@ static hipError_t launch_disp_p(const DispKernelParams &kp, hipStream_t st) {
         if (capi_ws_get(DSQ_WS_DISP_DIST, (size_t)grid * waves * 2 * (size_t)kp.m * sizeof(int32_t), &v) != 0) return hipErrorOutOfMemory;
         kq.dist_global = (int32_t *)v;
     }
+#ifdef DSQ_WIDE_PROF
+    unsigned long long pz[DSQ_PROF_SLOTS] = {}, ph[DSQ_PROF_SLOTS];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(disp_prof), pz, sizeof(pz));
+#endif
     if (stage)
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, true, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
     else
         hipLaunchKernelGGL((fit_disp_kernel<P, USE_W, false, MODE>), dim3(grid), dim3(64 * waves), lds, st, kq);
+#ifdef DSQ_WIDE_PROF
+    if (MODE == 0 && kp.n >= 1000) {
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(disp_prof), sizeof(ph));
+        double tot = 0;
+        for (int q = 0; q < DSQ_PROF_SLOTS; q++) tot += (double)ph[q];
+        static const char *nm[12] = {"stage row", "distinct counts", "setup", "eval head (exp, 1/alpha)", "sample sweep (+ closes in it)", "parked closes", "cell sums -> matrices",
+                                     "LU / inverse / trace", "lgamma over distinct counts", "reductions + tail", "search statements + results", "next gene"};
+        fprintf(stderr, "[disp_prof] p=%d m=%d n=%d cells=%d waves/block=%d:", P, kp.m, kp.n, kp.ncell, waves);
+        for (int q = 0; q < 12; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "  (%.0f Mcycles over all waves)\n", tot / 1e6);
+    }
+#endif
     return hipGetLastError();
 }
 
