@@ -468,3 +468,48 @@ def test_rolled_fit_beta_in_every_geometry(oracle, monkeypatch, geometry):
     for k in BETA_KEYS:
         assert_same(g0[k], o0[k], "rolled fitBeta (maxit = 0)$%s (%r)" % (k, geometry))
     assert (o0["iter"] == 0).all()
+
+
+@pytest.mark.parametrize("geometry", [{}, {"DSQ_WIDE_NW": "1"}, {"DSQ_WIDE_NW": "2"}, {"DSQ_WIDE_NW": "4"}, {"DSQ_WIDE_NW": "8"},
+                                      {"DSQ_DISP_ROLLED": "0"}])
+def test_rolled_fit_disp_in_every_geometry(oracle, monkeypatch, geometry):
+    """round 6: the rolled fitDisp / fitDispGrid / d2log_posterior kernel of the wide designs without cells
+    (csrc/fit_disp_wide.hip) with 1 / 2 / 4 / 8 waves per gene, and the per-width kernel it replaces (DSQ_DISP_ROLLED=0), on
+    a paired design (p = 27 on the 32-column build, 52 cells): with and without weights (a row with a sample group below the
+    weight threshold: a dropped column), with and without prior and Cox-Reid term, an all-zero row and a row on the minmu
+    floor -- every output identical to the oracle's in every geometry (which thread takes a matrix entry, which wave a row of
+    an elimination step, does not enter the result)."""
+    for k, v in geometry.items():
+        monkeypatch.setenv(k, v)
+    x = _paired_design(26)
+    m, p = x.shape
+    rng = np.random.default_rng(27)
+    sf = np.exp(rng.normal(0, 0.2, m))
+    d = simulate.make_counts(60, x, seed=27, beta_sd=np.array([0.4] * 25 + [1.0]), size_factors=sf)
+    y = d["counts"].copy()
+    y[2] = 0
+    y[5] = 0
+    y[5, ::2] = 2000
+    nf = np.broadcast_to(sf, y.shape).copy()
+    from tests.helpers import beta_init_qr, rough_alpha
+    with np.errstate(all="ignore"):
+        alpha = np.nan_to_num(rough_alpha(y.astype(float), nf, x), nan=0.1)
+    alpha = np.clip(alpha, 1e-8, 10.0)
+    la = np.log(alpha)
+    mu = np.maximum(nf * np.exp(rng.normal(3, 1, (y.shape[0], 1))), 0.5)
+    mu[5] = 0.5
+    for useW in (False, True):
+        w = np.ones(y.shape)
+        if useW:
+            w = rng.uniform(0.05, 1.0, y.shape)
+            w[7, x[:, 3] == 1] = 1e-4                      # patient 3's samples below the threshold: column 3 is dropped
+            w = np.maximum(w / w.max(axis=1, keepdims=True), 1e-6)
+        for prior, useCR in ((False, True), (True, True), (True, False)):
+            dargs = (y, x, mu, la, la - 0.2, 0.7, np.log(1e-9), 1.0, 1e-6, 100, prior, w, useW, 1e-2, useCR)
+            gd, od = native.fitDisp(*dargs), oracle.fitDisp(*dargs)
+            for k in DISP_KEYS:
+                assert_same(gd[k], od[k], "rolled fitDisp$%s (useW=%d prior=%d CR=%d, %r)" % (k, useW, prior, useCR, geometry))
+        grid = np.linspace(np.log(1e-8), np.log(10.0), 10)
+        gargs = (y, x, mu, grid, la, 1.0, True, w, useW, 1e-2, True)
+        assert_same(native.fitDispGrid(*gargs)["log_alpha"], oracle.fitDispGrid(*gargs)["log_alpha"],
+                    "rolled fitDispGrid (useW=%d, %r)" % (useW, geometry))
