@@ -40,7 +40,7 @@ __host__ __device__ static inline size_t dispw_lds_doubles(int m, int p, bool us
 }
 
 template <bool USE_W, int MODE, int NW>
-__global__ void __launch_bounds__(64 * NW, 2) fit_disp_rolled_kernel(DispKernelParams kp, int P, const double *xt) {
+__global__ void __launch_bounds__(64 * NW, NW <= 2 ? 3 : 2) fit_disp_rolled_kernel(DispKernelParams kp, int P, const double *xt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = 64 * NW;
@@ -738,7 +738,8 @@ static hipError_t launch_dispw(const DispKernelParams &kp, int pt, const double 
     const int force_nw = getenv("DSQ_WIDE_NW") ? atoi(getenv("DSQ_WIDE_NW")) : 0;
     if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) nw = force_nw;
     int bpc = fit;
-    if (bpc * nw > 8) bpc = 8 / nw;
+    const int wmax = nw <= 2 ? 12 : 8;           // (the one- and two-wave builds are compiled for three waves per SIMD)
+    if (bpc * nw > wmax) bpc = wmax / nw;
     if (bpc < 1) bpc = 1;
     const int cus = device_cu_count();
     long cap = (long)cus * bpc;
