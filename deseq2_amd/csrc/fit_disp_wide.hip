@@ -7,13 +7,15 @@
 // lane in REGISTERS -- 2 P .. 5 P doubles per lane, the p x p steps fully unrolled: four-minute builds per padded width, one
 // wave per SIMD at 48 columns, 130 - 390 ms per 20 000 genes.  Here the matrices live in the gene's LDS slab (row-major,
 // lane j owns column j), the samples' terms are produced by all waves, and what is independent is split between them: the
-// entries of the Gram matrices, the rows of an elimination step.  THE ARITHMETIC IS THAT OF DispGene (fit_disp.hip) in
+// entries of the Gram matrices (2 x 2 blocks per thread, read from a SAMPLE-major copy of the design: a wave's loads of one
+// sample touch its three or four cache lines, not 64), the rows of an elimination step.  THE ARITHMETIC IS THAT OF DispGene (fit_disp.hip) in
 // general mode with the entry-per-lane Gram: every matrix entry is the SERIAL sum of its m terms in sample order (the
 // arithmetic spec's order for these shapes, include/dsq_arith_spec.h -- which thread takes an entry does not enter it), the
 // likelihood sums are wave-order sums taken by ONE wave over terms the others have left in LDS, LU / inverse / traces are
 // LaneLU's operations on the same values, the line search is the per-width kernel's statement by statement: the results keep
 // the oracle's bits (tests/test_gpu_wide.py).  The design arrives zero-padded (kp.p columns, kp.padmask): the kernel runs on
-// its first p columns, the true width.
+// its first p columns, the true width.  Measured (profiles/r06_wide.txt): paired p = 46 132 -> 75 ms, factor p = 48 390 -> 108 ms
+// per 20 000 genes; phase shares in profiles/r06_wide_phases.txt (make prof).
 #include "dsq_internal.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +32,7 @@ template <int V> struct DTag { static constexpr int value = V; };
 __device__ unsigned long long dispw_prof[DSQ_PROF_SLOTS];
 #endif
 
-// LDS per gene (doubles): vectors | mu m | w m | y m int32 | distinct counts 2 m int32 | terms 2 m | wd 3 m | matrices 5 p p
+// LDS per gene (doubles): vectors | mu m | w m | y m int32 | distinct counts 2 m int32 | terms 2 m | wd 3 m | 1, 3 or 4 matrices p p
 __host__ __device__ static inline size_t dispw_vec_doubles(int p) { return (size_t)4 * p + 24; }
 __host__ __device__ static inline size_t dispw_lds_doubles(int m, int p, bool useW, int mode) {
     const size_t half = ((size_t)m + 1) / 2;
@@ -40,6 +42,8 @@ __host__ __device__ static inline size_t dispw_lds_doubles(int m, int p, bool us
 }
 
 template <bool USE_W, int MODE, int NW>
+// (HIP's second launch bound is WAVES PER SIMD: the one- and two-wave builds at three -- 168 registers, the spills sit in the
+//  once-per-gene parts -- so that five or six genes fit a CU where the LDS admits them; the others at two)
 __global__ void __launch_bounds__(64 * NW, NW <= 2 ? 3 : 2) fit_disp_rolled_kernel(DispKernelParams kp, int P, const double *xt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
