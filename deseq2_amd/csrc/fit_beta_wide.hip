@@ -392,6 +392,7 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                             case 5: chunk(j0, IntTag<5>{}); break;
                             case 6: chunk(j0, IntTag<6>{}); break;
                             case 7: chunk(j0, IntTag<7>{}); break;
+                            case 8: chunk(j0, IntTag<8>{}); break;
                             default: break;
                         }
                     };
@@ -420,10 +421,25 @@ __global__ void __launch_bounds__(64 * NW, BIG_LDS ? 1 : 2) fit_beta_rolled_kern
                         }
                     }
                     {
+                        // chunk length of the stage: eight columns, or -- several waves -- as few as give each of the other
+                        // NW - 1 waves ONE chunk (late stages have few columns left: a wave with two columns finishes its pass,
+                        // its reduction and its tprev sooner than one with eight while the rest idle; which columns share a
+                        // chunk does not enter any sum)
+                        int rch = kChunk;
+                        if constexpr (NW > 1) {
+                            const int rest = P - k - 1;                       // columns k + 2 .. P
+                            rch = (rest + NW - 2) / (NW - 1);
+                            rch = rch < 1 ? 1 : (rch > kChunk ? kChunk : rch);
+                        }
                         int task = 1;
                         int j0 = k + 2;
-                        for (; j0 + kChunk <= P + 1; j0 += kChunk)
-                            if ((task++ & (NW - 1)) == wave) chunk(j0, IntTag<kChunk>{});
+                        if (rch == kChunk) {
+                            for (; j0 + kChunk <= P + 1; j0 += kChunk)
+                                if ((task++ & (NW - 1)) == wave) chunk(j0, IntTag<kChunk>{});
+                        } else {
+                            for (; j0 + rch <= P + 1; j0 += rch)
+                                if ((task++ & (NW - 1)) == wave) chunk_tail(j0, rch);
+                        }
                         if (j0 <= P && (task++ & (NW - 1)) == wave) chunk_tail(j0, P + 1 - j0);
                     }
                     scal_prev = scal;
