@@ -149,7 +149,53 @@ __global__ void __launch_bounds__(64 * NW, NW <= 2 ? 3 : 2) fit_disp_rolled_kern
             // additions of an entry stay in sample order
             constexpr int SB = 4;
             const int PB = (P + 1) >> 1, NB = PB * (PB + 1) / 2;
-            for (int e = tid; e < NB; e += NT) {
+            // the blocks of the last, PARTIAL round (NB mod NT of them) are split into their single entries over all threads
+            // when that fills the round better: at 48 columns and 256 threads 300 blocks are one full round and 44 left over
+            // -- 176 single entries, a third of a block's work each, instead of a second round for 44 threads
+            const int nfull = NB - NB % NT;
+            const int nsplit = ((NB - nfull) * 4 <= 2 * NT) ? NB - nfull : 0;       // blocks whose entries are spread
+            const int nblk = NB - nsplit;
+            for (int q = tid; q < 4 * nsplit; q += NT) {
+                const int e = nblk + (q >> 2), ia = (q >> 1) & 1, ib = q & 1;
+                int ab = 0, rem = e;
+                while (rem >= PB - ab) { rem -= PB - ab; ab++; }
+                const int ea = 2 * ab + ia, eb = 2 * (ab + rem) + ib;
+                if (ea < P && eb < P && ea <= eb) {
+                    const double *xa_p = xt + ea, *xb_p = xt + eb;
+                    double acc1[K];
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) acc1[k] = 0.0;
+                    int j = 0;
+                    for (; j + 8 <= m; j += 8) {
+                        double xa[8], xb[8], wv[K][8];
+                        _Pragma("unroll")
+                        for (int u = 0; u < 8; u++) {
+                            const size_t o = (size_t)(j + u) * P;
+                            xa[u] = xa_p[o]; xb[u] = xb_p[o];
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) wv[k][u] = wdbuf[(size_t)k * m + j + u];
+                        }
+                        _Pragma("unroll")
+                        for (int u = 0; u < 8; u++)
+                            _Pragma("unroll")
+                            for (int k = 0; k < K; k++) acc1[k] += xa[u] * (xb[u] * wv[k][u]);
+                    }
+                    for (; j < m; j++) {
+                        const size_t o = (size_t)j * P;
+                        const double xa = xa_p[o], xb = xb_p[o];
+                        _Pragma("unroll")
+                        for (int k = 0; k < K; k++) acc1[k] += xa * (xb * wdbuf[(size_t)k * m + j]);
+                    }
+                    const bool live = !(((dropmask >> ea) | (dropmask >> eb)) & 1ull);
+                    _Pragma("unroll")
+                    for (int k = 0; k < K; k++) {
+                        const double v = live ? acc1[k] : 0.0;
+                        Bm[((size_t)k * P + ea) * P + eb] = v;
+                        Bm[((size_t)k * P + eb) * P + ea] = v;
+                    }
+                }
+            }
+            for (int e = tid; e < nblk; e += NT) {
                 int ab = 0, rem = e;
                 while (rem >= PB - ab) { rem -= PB - ab; ab++; }
                 const int a0 = 2 * ab, b0 = 2 * (ab + rem);
