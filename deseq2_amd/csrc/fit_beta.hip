@@ -1175,6 +1175,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 lu.factor(lane);
                 lu.inverse(Gic, lane);
             }
+            DSQ_CPROF(5);
             if (kp.hat_diagonals || kp.mu_out) {
                 wave_lds_sync();
                 {
@@ -1215,6 +1216,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                     }
                 }
             }
+            DSQ_CPROF(6);
             double Tc[P], Sgc[P];
             lane_mat_mul<P>(Gic, Gc, Tc);
             lane_mat_mul<P>(Tc, Gic, Sgc);
@@ -1261,6 +1263,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             lu.factor();
             lu.inverse(Gi);
         }
+        DSQ_CPROF(5);
         if (kp.hat_diagonals || kp.mu_out) {
             // fitted means from the FINAL coefficients (also when they diverged), as the general kernel reports them
             wave_lds_sync();
@@ -1297,6 +1300,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
                 }
             }
         }
+        DSQ_CPROF(6);
         double T[P][P], Sg[P][P];
         mat_mul<P>(Gi, G, T);
         mat_mul<P>(T, Gi, Sg);
@@ -1323,7 +1327,7 @@ __global__ void __launch_bounds__(256, DSQ_BETA_CELL_MINW) fit_beta_cell_kernel(
             kp.contrast_denom[g] = __builtin_sqrt(cd);
         }
         }
-        DSQ_CPROF(5);
+        DSQ_CPROF(8);
     }
 #ifdef DSQ_WIDE_PROF
     if (lane == 0) for (int q_ = 0; q_ < DSQ_PROF_SLOTS; q_++) atomicAdd(&betac_prof[q_], pacc_k[q_]);
@@ -1364,10 +1368,10 @@ static hipError_t launch_beta_cells(const BetaKernelParams &kp, hipStream_t st) 
         (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(betac_prof), sizeof(ph));
         double tot = 0;
         for (int q = 0; q < DSQ_PROF_SLOTS; q++) tot += (double)ph[q];
-        static const char *nm[8] = {"start + IRLS constants", "sample sweeps (+ closes, deviance)", "collapsed least squares", "cell eta / exp", "convergence control",
-                                    "post-loop block + outputs", "-", "next gene"};
+        static const char *nm[9] = {"start + IRLS constants", "sample sweeps (+ closes, deviance)", "collapsed least squares", "cell eta / exp", "convergence control",
+                                    "post-loop: X'WX and its inverse", "post-loop: hat / mu output loop", "next gene", "post-loop: sigma, contrast, results"};
         fprintf(stderr, "[betac_prof] p=%d m=%d n=%d cells=%d maxit=%d:", P, kp.m, kp.n, kp.ncell, kp.maxit);
-        for (int q = 0; q < 8; q++) if (q != 6) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / (tot > 0 ? tot : 1));
+        for (int q = 0; q < 9; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / (tot > 0 ? tot : 1));
         fprintf(stderr, "  (%.0f Mcycles over all waves)\n", tot / 1e6);
     }
 #endif
