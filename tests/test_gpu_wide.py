@@ -424,13 +424,14 @@ def test_too_wide_is_refused():
 
 @pytest.mark.parametrize("geometry", [{}, {"DSQ_WIDE_LDS": "0"}, {"DSQ_WIDE_NW": "1"}, {"DSQ_WIDE_NW": "2"}, {"DSQ_WIDE_NW": "4"},
                                       {"DSQ_WIDE_NW": "8"}, {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "1"}, {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "2"},
-                                      {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "8"}])
+                                      {"DSQ_WIDE_LDS": "0", "DSQ_WIDE_NW": "8"}, {"DSQ_WIDE_PADDED": "1"}])
 def test_rolled_fit_beta_in_every_geometry(oracle, monkeypatch, geometry):
     """round 6: the rolled fitBeta kernel of the wide designs without cells (csrc/fit_beta_wide.hip) in each of its launch
     geometries -- the gene's slab in LDS or in global memory, 1 / 2 / 4 / 8 waves per gene -- on a paired design (p = 19, 36
     cells), with and without weights, QR and normal equations, the contrast-only mode (maxit = 0, R/results.R:797), a row
     with every second sample at 3000 and the others at zero (fitted means on the minmu floor) and an all-but-one-zero row: every
-    output identical to the oracle's in every geometry (which wave takes a sum does not enter the result)."""
+    output identical to the oracle's in every geometry (which wave takes a sum does not enter the result).  The default runs
+    at the design's own width (19 columns of the 24-column build), DSQ_WIDE_PADDED=1 at the padded one."""
     for k, v in geometry.items():
         monkeypatch.setenv(k, v)
     x = _paired_design(18)
